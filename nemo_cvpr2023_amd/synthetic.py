@@ -1,0 +1,169 @@
+"""Seeded synthetic stand-ins for the licensed assets and the dataset.
+
+The real SMPL / VPoser / GMM / J_regressor_extra files are not redistributable
+(reference loads them from ``software/`` -- hmr/hmr_config.py:70-76,
+nemo/neural_motion_model.py:217-238), so every test and benchmark in this
+repository runs on SMPL-*shaped* random assets produced here.  The same
+generator feeds (a) the golden-vector script that drives the real reference,
+(b) the oracle and (c) the HIP product path, so all three see identical
+numbers.  Shapes and distributions follow SURVEY.md section 8(d).
+
+All draws come from explicit CPU ``torch.Generator`` objects, so the values are
+identical on the build container and on the GPU box.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+# SMPL kinematic tree (24 joints); parents[i] < i for i >= 1.
+SMPL_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16,
+                17, 18, 19, 20, 21]
+
+# 49-entry joint map = [JOINT_MAP[n] for n in JOINT_NAMES] of
+# hmr/hmr_constants.py:37-150 (model data, verified against the reference by
+# tools/gen_golden.py).  Indices refer to the 54-joint superset
+# [24 FK joints | 21 selector vertices | 9 J_regressor_extra rows].
+JOINT_MAP_49 = [24, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 25, 26,
+                27, 28, 29, 30, 31, 32, 33, 34,
+                8, 5, 45, 46, 4, 7, 21, 19, 17, 16, 18, 20, 47, 48, 49, 50, 51,
+                52, 53, 24, 26, 25, 28, 27]
+
+NUM_SELECTOR_VERTS = 21       # smplx VertexJointSelector for SMPL (joints 24..44)
+NUM_EXTRA_ROWS = 9            # hmr/smpl.py:22-26 (J_regressor_extra)
+FOCAL_LENGTH = 5000.0         # hmr/hmr_constants.py:1
+
+
+def _row_normalised(gen, rows, cols, power):
+    w = torch.rand(rows, cols, generator=gen, dtype=torch.float64) ** power
+    return (w / w.sum(1, keepdim=True)).float()
+
+
+def make_smpl_assets(num_verts: int = 6890, seed: int = 1) -> dict:
+    """SMPL-shaped random model.  Keys mirror the buffers smplx.SMPL registers."""
+    g = torch.Generator().manual_seed(seed)
+    nv = num_verts
+    a = {}
+    a['v_template'] = 0.3 * torch.randn(nv, 3, generator=g)
+    a['shapedirs'] = 0.01 * torch.randn(nv, 3, 10, generator=g)
+    a['posedirs'] = 1e-3 * torch.randn(207, nv * 3, generator=g)
+    a['J_regressor'] = _row_normalised(g, 24, nv, 8)
+    a['J_regressor_extra'] = _row_normalised(g, NUM_EXTRA_ROWS, nv, 8)
+    a['lbs_weights'] = _row_normalised(g, nv, 24, 6)
+    a['parents'] = torch.tensor(SMPL_PARENTS, dtype=torch.long)
+    a['extra_vids'] = torch.randint(0, nv, (NUM_SELECTOR_VERTS,), generator=g)
+    a['joint_map'] = torch.tensor(JOINT_MAP_49, dtype=torch.long)
+    return a
+
+
+def make_vposer_state(seed: int = 3, num_neurons: int = 512, latent: int = 32) -> dict:
+    """Random VPoser-v2 weights with the checkpoint key names of
+    human_body_prior/models/vposer_model.py:69-88 (encoder_net.{1,2,4,6,7,8},
+    decoder_net.{0,3,5}).  BatchNorm running statistics are non-trivial so the
+    eval-mode affine is exercised."""
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(prefix, fin, fout, sd):
+        bound = 1.0 / np.sqrt(fin)
+        sd[prefix + '.weight'] = (torch.rand(fout, fin, generator=g) * 2 - 1) * bound
+        sd[prefix + '.bias'] = (torch.rand(fout, generator=g) * 2 - 1) * bound
+
+    def bn(prefix, f, sd):
+        sd[prefix + '.weight'] = 1.0 + 0.1 * torch.randn(f, generator=g)
+        sd[prefix + '.bias'] = 0.1 * torch.randn(f, generator=g)
+        sd[prefix + '.running_mean'] = 0.1 * torch.randn(f, generator=g)
+        sd[prefix + '.running_var'] = 0.5 + torch.rand(f, generator=g)
+        sd[prefix + '.num_batches_tracked'] = torch.tensor(100, dtype=torch.long)
+
+    sd = {}
+    nf = 63
+    bn('encoder_net.1', nf, sd)
+    lin('encoder_net.2', nf, num_neurons, sd)
+    bn('encoder_net.4', num_neurons, sd)
+    lin('encoder_net.6', num_neurons, num_neurons, sd)
+    lin('encoder_net.7', num_neurons, num_neurons, sd)
+    lin('encoder_net.8.mu', num_neurons, latent, sd)
+    lin('encoder_net.8.logvar', num_neurons, latent, sd)
+    lin('decoder_net.0', latent, num_neurons, sd)
+    lin('decoder_net.3', num_neurons, num_neurons, sd)
+    lin('decoder_net.5', num_neurons, 126, sd)
+    return sd
+
+
+def make_gmm(seed: int = 4, num_gaussians: int = 8, dim: int = 69) -> dict:
+    """Synthetic content of ``gmm_08.pkl`` (hmr/smplify/prior.py:124-131)."""
+    g = torch.Generator().manual_seed(seed)
+    means = 0.2 * torch.randn(num_gaussians, dim, generator=g, dtype=torch.float64)
+    A = 0.1 * torch.randn(num_gaussians, dim, dim, generator=g, dtype=torch.float64)
+    covars = A @ A.transpose(1, 2) + 0.5 * torch.eye(dim, dtype=torch.float64)
+    w = 0.5 + torch.rand(num_gaussians, generator=g, dtype=torch.float64)
+    w = w / w.sum()
+    return {'means': means.numpy(), 'covars': covars.numpy(), 'weights': w.numpy()}
+
+
+class SyntheticSequences:
+    """Array-backed stand-in for ``nemo.multi_view_sequence.MultiViewSequence``.
+
+    Provides exactly the fields the model reads:
+    ``num_views, num_frames, IMG_D0, IMG_D1, sequences[v]['pose_2d_op'|'pose_2d_gt'|'pose']``.
+    """
+
+    def __init__(self, num_views: int, num_frames: int, seed: int = 1234,
+                 img_d0: int = 1080, img_d1: int = 1920, empty_frac: float = 0.02):
+        rng = np.random.default_rng(seed)
+        self.num_views = num_views
+        self.num_frames = num_frames
+        self.IMG_D0 = img_d0   # height
+        self.IMG_D1 = img_d1   # width
+        self.sequences = []
+        for _ in range(num_views):
+            seq = {}
+            for key in ('pose_2d_op', 'pose_2d_gt'):
+                kp = np.empty((num_frames, 25, 3), dtype=np.float32)
+                kp[..., 0] = rng.uniform(0, img_d1, (num_frames, 25))
+                kp[..., 1] = rng.uniform(0, img_d0, (num_frames, 25))
+                kp[..., 2] = rng.uniform(0, 1, (num_frames, 25))
+                empty = rng.uniform(size=num_frames) < empty_frac
+                kp[empty] = 0.0   # undetected person (multi_view_sequence.py:422-423)
+                seq[key] = [kp[t] for t in range(num_frames)]
+            pose = np.zeros((num_frames, 73), dtype=np.float32)
+            pose[:, 3:72] = 0.2 * rng.standard_normal((num_frames, 69))
+            pose[:, 72] = (rng.uniform(size=num_frames) > 0.1).astype(np.float32)
+            seq['pose'] = [pose[t] for t in range(num_frames)]
+            self.sequences.append(seq)
+
+    def get_image(self, v, t):  # rendering only; never used by the fit
+        raise NotImplementedError('synthetic sequences carry no images')
+
+
+def published_args(**overrides) -> SimpleNamespace:
+    """Hyper-parameters of the published Baseball-Pitch run
+    (run_scripts_examples/nemomocap-example.sh:3-17,23-46 over config/default-v1.yml)."""
+    a = dict(load_ckpt_path='', out_dir='out', model_version=2, h_dim=1000,
+             instance_code_size=5, phase_rbf_dim=100, rbf_kernel='quadratic',
+             monotonic_network_n_nodes=200, phase_init='linear', lr_camera=0.1,
+             lr_instance=1e-3, lr_human=1e-4, lr_phase=1e-4, opt_human='adam',
+             wd_human=0.001, lr_factor=1, loss='mse_robust', label_type='op',
+             batch_size=512, weight_vp_loss=10, weight_vp_z_loss=1,
+             weight_gmm_loss=1, weight_instance_loss=0, weight_3d_loss=0,
+             code_noise=0, label_intersection_threshold=50,
+             n_steps=2000, warmup_step=300, opt_cam_step=1000)
+    a.update(overrides)
+    return SimpleNamespace(**a)
+
+
+def default_v1_args(**overrides) -> SimpleNamespace:
+    """config/default-v1.yml:1-25 (NemoV1, h=500, C=10, batch 128, plateau schedulers)."""
+    a = dict(load_ckpt_path='', out_dir='out', model_version=1, h_dim=500,
+             instance_code_size=10, phase_rbf_dim=0, rbf_kernel='quadratic',
+             monotonic_network_n_nodes=200, phase_init='linear', lr_camera=0.1,
+             lr_instance=1e-3, lr_human=0.01, lr_phase=1e-5, opt_human='adam',
+             wd_human=0.001, lr_factor=0.5, loss='mse_robust', label_type='op',
+             batch_size=128, weight_vp_loss=0, weight_vp_z_loss=0,
+             weight_gmm_loss=0.5, weight_instance_loss=0, weight_3d_loss=0,
+             code_noise=0, label_intersection_threshold=50,
+             n_steps=5000, warmup_step=0, opt_cam_step=1000)
+    a.update(overrides)
+    return SimpleNamespace(**a)

@@ -1,0 +1,468 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the *real* reference (build container only).
+
+Run:  python -B tools/gen_golden.py            (needs /root/reference; CPU only)
+
+Writes small ``.npz`` fixtures to ``tests/golden/``.  Nothing from the reference
+travels: only seeded inputs and the numbers the reference computed from them.
+The reference's missing, non-arithmetic dependencies (cv2, ipdb, smplx, pyrender,
+...) are replaced by ``MagicMock`` modules *before* import; ``smplx.SMPL`` is
+replaced by a thin wrapper that calls the reference's own vendored
+``human_body_prior/body_model/lbs.py`` on synthetic SMPL-shaped assets and then
+applies exactly the joint plumbing of ``hmr/smpl.py:29-43``.
+"""
+import argparse
+import os
+import pickle
+import sys
+import tempfile
+import unittest.mock
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.path.insert(0, REPO)
+from nemo_cvpr2023_amd import synthetic as syn  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+
+# ----------------------------------------------------------------------------
+# reference import with stubs
+# ----------------------------------------------------------------------------
+def import_reference(scratch):
+    sys.dont_write_bytecode = True
+    for name in ['cv2', 'ipdb', 'smplx', 'smplx.body_models', 'smplx.lbs', 'smplx.utils',
+                 'torchvision', 'torchvision.utils', 'torchvision.transforms',
+                 'torchvision.models', 'torchvision.models.resnet', 'pyrender',
+                 'pyrender.constants', 'trimesh', 'dotmap', 'yacs', 'yacs.config', 'skimage',
+                 'skimage.util', 'skimage.util.shape']:
+        sys.modules[name] = unittest.mock.MagicMock(name=name)
+    sys.path.insert(0, REF)
+    os.makedirs(os.path.join(scratch, 'software', 'spin_data'), exist_ok=True)
+    with open(os.path.join(scratch, 'software', 'spin_data', 'gmm_08.pkl'), 'wb') as f:
+        pickle.dump(syn.make_gmm(), f)
+    os.chdir(scratch)
+    import warnings
+    warnings.filterwarnings('ignore')
+    import nemo.neural_motion_model as nmm
+    return nmm
+
+
+def install_synthetic_models(nmm, assets):
+    from human_body_prior.body_model.lbs import lbs, vertices2joints
+    from human_body_prior.models.vposer_model import VPoser
+
+    class SynthSMPL(torch.nn.Module):
+        """smplx.SMPL.forward semantics (concat orient+body pose, expand betas,
+        VertexJointSelector) + hmr/smpl.py:29-43, on the vendored lbs."""
+
+        def __init__(self, *a, **k):
+            super().__init__()
+            for key in ('v_template', 'shapedirs', 'posedirs', 'J_regressor',
+                        'J_regressor_extra', 'lbs_weights'):
+                self.register_buffer(key, assets[key].clone())
+            self.parents = assets['parents'].clone()
+            self.extra_vids = assets['extra_vids'].clone()
+            self.joint_map = assets['joint_map'].clone()
+            self.faces = np.zeros((10, 3), dtype=np.int64)
+
+        def forward(self, betas=None, body_pose=None, global_orient=None, pose2rot=True, **kw):
+            if pose2rot:
+                n = body_pose.shape[0]
+                if global_orient is None:
+                    global_orient = torch.zeros(n, 3)
+                if betas is None:
+                    betas = torch.zeros(1, 10)
+                full = torch.cat([global_orient.reshape(n, -1), body_pose.reshape(n, -1)], 1)
+            else:
+                full = torch.cat([global_orient, body_pose], 1)
+            if betas.shape[0] != full.shape[0]:
+                betas = betas.expand(full.shape[0], -1)
+            v, j = lbs(betas, full, self.v_template, self.shapedirs, self.posedirs,
+                       self.J_regressor, self.parents, self.lbs_weights, pose2rot=pose2rot)
+            j = torch.cat([j, v[:, self.extra_vids]], 1)
+            j = torch.cat([j, vertices2joints(self.J_regressor_extra, v)], 1)
+            return SimpleNamespace(vertices=v, joints=j[:, self.joint_map], joints54=j)
+
+    class VP(VPoser):
+        def to(self, *a, **k):
+            return self
+
+    def fake_load_model(*a, **k):
+        vp = VP(SimpleNamespace(model_params=SimpleNamespace(num_neurons=512, latentD=32)))
+        vp.load_state_dict(syn.make_vposer_state(), strict=True)
+        for p in vp.parameters():
+            p.requires_grad = False
+        vp.eval()
+        return vp, None
+
+    nmm.SMPL = SynthSMPL
+    nmm.load_model = fake_load_model
+    # renderers are CPU offscreen-GL helpers, never touched by the fit
+    for rname in ('Renderer', 'MultiPersonRenderer', 'VIBERenderer'):
+        setattr(nmm, rname, unittest.mock.MagicMock(name=rname))
+    return SynthSMPL, fake_load_model
+
+
+def npify(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.detach().cpu().numpy()
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **npify(arrays))
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
+
+
+def rand_rotmats(g, n):
+    """Random proper rotations via QR (float64 -> float32)."""
+    a = torch.randn(n, 3, 3, generator=g, dtype=torch.float64)
+    q, r = torch.linalg.qr(a)
+    q = q * torch.sign(torch.diagonal(r, dim1=1, dim2=2)).unsqueeze(1)
+    det = torch.linalg.det(q)
+    q[:, :, 2] *= det.unsqueeze(1)
+    return q.float()
+
+
+def axis_angle_rot(axis, angle):
+    axis = axis / axis.norm(dim=1, keepdim=True)
+    K = torch.zeros(axis.shape[0], 3, 3, dtype=torch.float64)
+    K[:, 0, 1], K[:, 0, 2] = -axis[:, 2], axis[:, 1]
+    K[:, 1, 0], K[:, 1, 2] = axis[:, 2], -axis[:, 0]
+    K[:, 2, 0], K[:, 2, 1] = -axis[:, 1], axis[:, 0]
+    s = torch.sin(angle)[:, None, None]
+    c = torch.cos(angle)[:, None, None]
+    return (torch.eye(3, dtype=torch.float64) + s * K + (1 - c) * (K @ K)).float()
+
+
+# ----------------------------------------------------------------------------
+# per-function goldens
+# ----------------------------------------------------------------------------
+def gen_function_goldens(nmm, assets_small):
+    import hmr.geometry as geo
+    from human_body_prior.body_model import lbs as lbsmod
+    from human_body_prior.models.vposer_model import VPoser  # noqa: F401
+    from human_body_prior.tools.rotation_tools import matrot2aa
+    from hmr.smplify.prior import MaxMixturePrior
+    from monotonic_network import MonotonicNetwork
+    from nemo.rbf import RBF
+    from nemo.utils import GMoF
+
+    g = torch.Generator().manual_seed(100)
+
+    # rot6d_to_rotmat (hmr/geometry.py:47-61)
+    x = torch.randn(64, 6, generator=g)
+    x[:8] = torch.tensor([1., 0, 0, 1, 0, 0]) + 1e-5 * torch.randn(8, 6, generator=g)
+    x.requires_grad_(True)
+    ct = torch.randn(64, 3, 3, generator=g)
+    R = geo.rot6d_to_rotmat(x)
+    (R * ct).sum().backward()
+    save('fn_rot6d_to_rotmat', x=x, ct=ct, out=R, grad_x=x.grad)
+
+    # rotation_matrix_to_angle_axis (hmr/geometry.py:181-346): all four branches,
+    # near-identity, near-pi, exact identity (forward only there: grad is NaN)
+    Rr = rand_rotmats(g, 96)
+    ax = torch.randn(32, 3, generator=g, dtype=torch.float64)
+    ang_small = torch.cat([torch.full((8,), 1e-5), torch.full((8,), 1e-3),
+                           torch.full((8,), 3.1), torch.full((8,), 3.14159)]).double()
+    Rs = axis_angle_rot(ax, ang_small)
+    Rall = torch.cat([Rr, Rs], 0).clone().requires_grad_(True)
+    ct = torch.randn(Rall.shape[0], 3, generator=g)
+    aa = geo.rotation_matrix_to_angle_axis(Rall)
+    (aa * ct).sum().backward()
+    save('fn_rotmat_to_aa', R=Rall, ct=ct, out=aa, grad_R=Rall.grad,
+         out_identity=geo.rotation_matrix_to_angle_axis(torch.eye(3).unsqueeze(0)))
+
+    # VPoser-side matrot2aa (tgm_conversion.py:219-373): same math, no NaN zeroing
+    save('fn_matrot2aa', R=Rall, out=matrot2aa(Rall.detach()))
+
+    # batch_rodrigues, quaternion form (hmr/geometry.py:9-45)
+    th = torch.randn(64, 3, generator=g)
+    th[:8] *= 1e-4
+    th[8:12] = 0.0
+    th.requires_grad_(True)
+    ct = torch.randn(64, 3, 3, generator=g)
+    Rq = geo.batch_rodrigues(th)
+    (Rq * ct).sum().backward()
+    save('fn_batch_rodrigues', theta=th, ct=ct, out=Rq, grad_theta=th.grad)
+
+    # lbs-side Rodrigues (human_body_prior/body_model/lbs.py:303-334) -- eval path
+    th2 = torch.randn(32, 3, generator=g)
+    save('fn_lbs_rodrigues', theta=th2, out=lbsmod.batch_rodrigues(th2))
+
+    # perspective_projection (hmr/geometry.py:78-106)
+    P = torch.randn(6, 25, 3, generator=g, requires_grad=True)
+    Rc = rand_rotmats(g, 6).requires_grad_(True)
+    t = (torch.randn(6, 3, generator=g) + torch.tensor([0, 0, 9.0])).requires_grad_(True)
+    f = torch.full((6,), 5000.0)
+    c = torch.tensor([[540.0, 960.0]]).expand(6, -1)
+    ct = torch.randn(6, 25, 2, generator=g)
+    p2 = geo.perspective_projection(P, Rc, t, f, c)
+    (p2 * ct).sum().backward()
+    save('fn_perspective_projection', points=P, rotation=Rc, translation=t, focal=f, center=c,
+         ct=ct, out=p2, grad_points=P.grad, grad_rotation=Rc.grad, grad_translation=t.grad)
+
+    # SMPL on synthetic 128-vertex assets: vendored lbs + hmr/smpl.py joint plumbing
+    smpl = nmm.SMPL()
+    n = 5
+    rot = rand_rotmats(g, n * 24).view(n, 24, 3, 3)
+    # mix in small rotations (the regime the fit lives in)
+    small = axis_angle_rot(torch.randn(n * 24, 3, generator=g, dtype=torch.float64),
+                           0.3 * torch.rand(n * 24, generator=g, dtype=torch.float64)).view(n, 24, 3, 3)
+    rot[2:] = small[2:]
+    rot.requires_grad_(True)
+    betas = torch.zeros(1, 10)
+    out = smpl(betas=betas, body_pose=rot[:, 1:], global_orient=rot[:, :1], pose2rot=False)
+    ctv = torch.randn(n, 128, 3, generator=g)
+    ctj = torch.randn(n, 49, 3, generator=g)
+    ((out.vertices * ctv).sum() + (out.joints * ctj).sum()).backward()
+    save('fn_smpl_rotmat', rotmats=rot, betas=betas, ct_vertices=ctv, ct_joints=ctj,
+         vertices=out.vertices, joints49=out.joints, joints54=out.joints54, grad_rotmats=rot.grad)
+    betas2 = 0.5 * torch.randn(1, 10, generator=g)
+    out2 = smpl(betas=betas2, body_pose=rot[:, 1:].detach(), global_orient=rot[:, :1].detach(),
+                pose2rot=False)
+    save('fn_smpl_betas', rotmats=rot, betas=betas2, vertices=out2.vertices, joints49=out2.joints)
+    aa_pose = 0.4 * torch.randn(n, 69, generator=g)
+    out3 = smpl(betas=None, body_pose=aa_pose, global_orient=None, pose2rot=True)
+    save('fn_smpl_aa_eval', body_pose=aa_pose, vertices=out3.vertices, joints49=out3.joints)
+
+    # GMoF (nemo/utils/misc_utils.py:91-105)
+    r = 300 * torch.randn(7, 25, 2, generator=g)
+    rob = GMoF()
+    save('fn_gmof', residual=r, out_sq=rob(r, sqrt=False), out_sqrt=rob(r, sqrt=True))
+
+    # MonotonicNetwork (monotonic_network.py:7-39)
+    for init in ('linear', 'rand'):
+        torch.manual_seed(7)
+        net = MonotonicNetwork(20, init)
+        with torch.no_grad():
+            net.shifts.add_(0.05 * torch.randn(20, generator=g))
+            net.scales.add_(2.0 * torch.randn(20, generator=g))
+            net.shifts[3] = -0.1   # exercise the relu clamps
+            net.scales[5] = -1.0
+        xx = torch.rand(16, 1, generator=g).requires_grad_(True)
+        ct = torch.randn(16, 1, generator=g)
+        y = net(xx)
+        (y * ct).sum().backward()
+        save('fn_monotonic_' + init, shifts=net.shifts, scales=net.scales, x=xx, ct=ct, out=y,
+             grad_shifts=net.shifts.grad, grad_scales=net.scales.grad, grad_x=xx.grad)
+
+    # RBF (nemo/rbf.py:11-56) -- every kernel the reference can be configured with
+    for kern in ('quadratic', 'linear', 'gaussian', 'inverse_quadratic', 'multiquadric',
+                 'inverse_multiquadric', 'spline', 'poisson_one', 'poisson_two', 'matern32',
+                 'matern52'):
+        rbf = RBF(16, kern)
+        with torch.no_grad():
+            rbf.log_sigmas.add_(0.3 * torch.randn(16, generator=g))
+        xx = torch.rand(9, 1, generator=g).requires_grad_(True)
+        ct = torch.randn(9, 16, generator=g)
+        y = rbf(xx)
+        (y * ct).sum().backward()
+        save('fn_rbf_' + kern, log_sigmas=rbf.log_sigmas, centres=rbf.centres, x=xx, ct=ct,
+             out=y, grad_log_sigmas=rbf.log_sigmas.grad, grad_x=xx.grad)
+
+    # VPoser encode / decode (vposer_model.py:68-106), eval mode
+    vp, _ = nmm.load_model()
+    pb = (0.3 * torch.randn(6, 63, generator=g)).requires_grad_(True)
+    q = vp.encode(pb)
+    dec = vp.decode(q.mean)
+    kl = torch.distributions.kl.kl_divergence(
+        q, torch.distributions.normal.Normal(torch.zeros(6, 32), torch.ones(6, 32))).sum(1).mean()
+    kl.backward()
+    save('fn_vposer', pose_body=pb, mean=q.mean, scale=q.scale, dec_aa=dec['pose_body'],
+         dec_matrot=dec['pose_body_matrot'], kl=kl, grad_pose_body=pb.grad)
+
+    # MaxMixturePrior (hmr/smplify/prior.py:100-196)
+    prior = MaxMixturePrior(prior_folder='software/spin_data', num_gaussians=8, dtype=torch.float32)
+    pose = (0.3 * torch.randn(10, 69, generator=g)).requires_grad_(True)
+    ll = prior(pose, None)
+    ll.mean().backward()
+    save('fn_gmm_prior', pose=pose, out=ll, grad_pose=pose.grad, precisions=prior.precisions,
+         means=prior.means, nll_weights=prior.nll_weights)
+
+    # MotionNet (nemo/neural_motion_model.py:106-148)
+    torch.manual_seed(11)
+    mn = nmm.MotionNet(21, 32, 24, 3, init_last_layer_zero=True)
+    with torch.no_grad():
+        mn.rot_out.weight.mul_(3e4)   # leave the near-identity regime for a stronger test
+    xin = torch.randn(5, 21, generator=g)
+    pd, od, tr = mn(xin)
+    sd = {k.replace('.', '__'): v for k, v in mn.state_dict().items()}
+    save('fn_motionnet', x=xin, rot6d=torch.cat([od['rot6d'], pd['rot6d']], 1),
+         rotmat=torch.cat([od['rotmat'], pd['rotmat']], 1),
+         pose=torch.cat([od['pose'], pd['pose']], 1), trans=tr, **sd)
+
+
+# ----------------------------------------------------------------------------
+# whole-model goldens
+# ----------------------------------------------------------------------------
+def model_state(model):
+    skip = ('vp.', 'pose_prior.', 'renderer', 'smpl.')
+    return {k: v.clone() for k, v in model.state_dict().items() if not k.startswith(skip)}
+
+
+def opt_state(model):
+    out = {}
+    for oi, opt in enumerate(model.optimizers):
+        sd = opt.state_dict()
+        out[f'opt{oi}__lr'] = torch.tensor(sd['param_groups'][0]['lr'])
+        for pi, st in sd['state'].items():
+            for k, v in st.items():
+                out[f'opt{oi}__{pi}__{k}'] = v.clone() if isinstance(v, torch.Tensor) else torch.tensor(v)
+    return out
+
+
+def install_pure_kp_capture(model, store):
+    """Reference quirk: on the CPU backend loss_dict['kp_loss'] aliases the
+    tensor later modified in place.  Capture the un-contaminated value (= CUDA semantics)
+    from the caller's frame at the moment vposer_loss is entered."""
+    orig = model.vposer_loss
+
+    def wrapped(poses, orient):
+        fr = sys._getframe(1)
+        if 'loss' in fr.f_locals and isinstance(fr.f_locals['loss'], torch.Tensor):
+            store.append(fr.f_locals['loss'].detach().clone())
+        return orig(poses, orient)
+    model.vposer_loss = wrapped
+
+
+def run_model_case(nmm, name, version, args_over, V, T, B, n_steps, n_warm, n_cam, seed=0,
+                   forced_first_batch=None, full_batch_steps=0):
+    base = syn.published_args if version >= 2 else syn.default_v1_args
+    over = dict(h_dim=48, monotonic_network_n_nodes=20, batch_size=B, out_dir='out_' + name)
+    if version >= 2:
+        over['phase_rbf_dim'] = 16
+    over.update(args_over)
+    args = base(**over)
+    args.model_version = version
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    torch.manual_seed(seed)
+    model = getattr(nmm, f'NemoV{version}')(args, seqs, 'cpu')
+    pure = []
+    install_pure_kp_capture(model, pure)
+    rec = {}
+    for k, v in model_state(model).items():
+        rec['init__' + k.replace('.', '__')] = v
+    rec['gt_bbox_size'] = model.gt_bbox_size
+    rec['points2d_gt_all'] = model.points2d_gt_all
+
+    torch.manual_seed(2)   # batch-index stream (scripts/learned_multi_view_recon_nn.py:213-218)
+
+    def draw():
+        vi = torch.randint(0, V, size=(B,))
+        fi = torch.randint(0, T, size=(B,))
+        return vi, fi
+
+    def record_step(tag, ld, info):
+        for k, v in ld.items():
+            rec[f'{tag}__{k}'] = np.asarray(v, dtype=np.float32).copy()
+        rec[f'{tag}__kp_loss_pure'] = pure[-1]
+        rec[f'{tag}__loss_all'] = info['loss_all']
+
+    # eval at init (full batch), as the script does (:220)
+    vi, fi = draw()
+    ld, info = model.step(vi, fi, update=False, full_batch=True)
+    record_step('evalinit', ld, info)
+
+    # predictions for a fixed batch (forward parity of get_preds_batch)
+    vi, fi = draw()
+    if forced_first_batch is not None:
+        vi, fi = forced_first_batch
+    with torch.no_grad():
+        pd = model.get_preds_batch(vi, fi)
+        p2d = model.learned_camera_projection(pd['j'], vi)
+    rec['preds__view_idx'], rec['preds__frame_idx'] = vi, fi
+    for k in ('v', 'j', 'poses', 'orient', 'orient_aa', 'trans'):
+        rec['preds__' + k] = pd[k]
+    rec['preds__points2d'] = p2d
+
+    if n_warm:
+        rec['warmup_losses'] = np.asarray(model.warmup(n_warm), dtype=np.float32)
+        for k, v in model_state(model).items():
+            rec['afterwarm__' + k.replace('.', '__')] = v
+    if n_cam:
+        cl = model.opt_cam(n_cam)
+        rec['cam_losses'] = np.asarray([float(x) for x in cl], dtype=np.float32)
+        rec['aftercam__learned_cameras'] = model.learned_cameras.detach().clone()
+
+    batches_v, batches_f = [], []
+    for s in range(n_steps):
+        vi, fi = draw()
+        if s == 0 and forced_first_batch is not None:
+            vi, fi = forced_first_batch
+        batches_v.append(vi)
+        batches_f.append(fi)
+        fb = s >= n_steps - full_batch_steps
+        ld, info = model.step(vi, fi, full_batch=fb)
+        record_step(f'step{s}', ld, info)
+        if s == 0:
+            for k, p in model.named_parameters():
+                if p.grad is not None and not k.startswith(('vp.', 'smpl.')):
+                    rec['step0grad__' + k.replace('.', '__')] = p.grad.clone()
+    rec['batches_view'] = torch.stack(batches_v)
+    rec['batches_frame'] = torch.stack(batches_f)
+    for k, v in model_state(model).items():
+        rec['final__' + k.replace('.', '__')] = v
+    for k, v in opt_state(model).items():
+        rec['final__' + k] = v
+    rec['meta__V'], rec['meta__T'], rec['meta__B'] = V, T, B
+    save('model_' + name, **rec)
+    return model
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--skip-6890', action='store_true')
+    opts = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    scratch = tempfile.mkdtemp(prefix='nemo_golden_')
+    nmm = import_reference(scratch)
+
+    # the restated joint map must equal the reference's
+    import hmr.hmr_constants as constants
+    ref_map = [constants.JOINT_MAP[n] for n in constants.JOINT_NAMES]
+    assert ref_map == syn.JOINT_MAP_49, 'JOINT_MAP_49 drifted from hmr/hmr_constants.py'
+    assert constants.FOCAL_LENGTH == syn.FOCAL_LENGTH
+
+    assets_small = syn.make_smpl_assets(128, seed=1)
+    install_synthetic_models(nmm, assets_small)
+    gen_function_goldens(nmm, assets_small)
+
+    # NemoV2, published-run structure (all loss terms on), tiny sizes
+    fb = (torch.tensor([0, 2, 2, 0, 2, 0, 0, 2]), torch.tensor([1, 3, 0, 6, 6, 2, 5, 4]))  # view 1 absent
+    run_model_case(nmm, 'v2_small', 2, {}, V=3, T=7, B=8, n_steps=6, n_warm=3, n_cam=3,
+                   forced_first_batch=fb, full_batch_steps=1)
+    # NemoV1, default-v1 structure (plateau schedulers on, no RBF, gmm only)
+    run_model_case(nmm, 'v1_small', 1, {'lr_human': 0.01}, V=1, T=6, B=4, n_steps=30, n_warm=0, n_cam=2)
+    # NemoV1 true full-batch mode (batch_size == -1) -- step ignores the indices
+    run_model_case(nmm, 'v1_fullbatch', 1, {'batch_size': -1, 'lr_factor': 1}, V=2, T=5, B=4,
+                   n_steps=3, n_warm=0, n_cam=2)
+    # NemoV3: instance-code regulariser + 3-D loss + AdamW
+    run_model_case(nmm, 'v3_small', 3, {'weight_instance_loss': 0.1, 'weight_3d_loss': 0.5,
+                                        'opt_human': 'adamw'}, V=2, T=5, B=6, n_steps=4, n_warm=2, n_cam=2)
+    # NemoV4: joints 0..24, stochastic opt_cam with detached pose
+    run_model_case(nmm, 'v4_small', 4, {'weight_3d_loss': 0.5}, V=2, T=5, B=6, n_steps=4, n_warm=2, n_cam=3)
+    # other 2-D loss types through the whole step
+    for lt in ('mse', 'rmse', 'rmse_robust', 'mse_robust_resized'):
+        run_model_case(nmm, 'v2_loss_' + lt, 2, {'loss': lt, 'weight_vp_loss': 0,
+                                                 'weight_vp_z_loss': 0}, V=2, T=4, B=5,
+                       n_steps=2, n_warm=0, n_cam=0)
+
+    if not opts.skip_6890:
+        assets_full = syn.make_smpl_assets(6890, seed=1)
+        install_synthetic_models(nmm, assets_full)
+        run_model_case(nmm, 'v2_6890', 2, {}, V=2, T=4, B=6, n_steps=2, n_warm=0, n_cam=0)
+
+
+if __name__ == '__main__':
+    main()
