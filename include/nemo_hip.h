@@ -1,0 +1,241 @@
+/* libnemo_hip.so -- C ABI of the MI355X (gfx950) NeMo fitting kernels.
+ *
+ * Drop-in boundary for the per-iteration hot path of wangkua1/nemo-cvpr2023
+ * (scripts/learned_multi_view_recon_nn.py -> nemo/neural_motion_model.py NemoV*.step).
+ * The reference has no native/FFI layer on this path (everything is PyTorch aten ops), so
+ * every entry point below cites the reference *operator* it replaces (file:line under the
+ * reference tree).  The Python host in nemo_cvpr2023_amd/ binds these with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - every function returns int32: 0 ok, <0 invalid argument, >0 a hipError_t;
+ *  - all pointers are DEVICE pointers to contiguous row-major fp32 unless stated
+ *    (index arrays are int64); the caller (PyTorch allocator) owns all memory; no
+ *    allocation, no hidden global state, re-entrant; "ld*" arguments are row strides
+ *    in elements;
+ *  - the last argument is the hipStream_t to launch on (as void*);
+ *  - immutable model constants live in an opaque nemo_ctx created per device.
+ *  - "_bwd" entry points *accumulate* (+=) into parameter-gradient outputs (the caller
+ *    zeroes one flat gradient buffer per step) and *overwrite* activation gradients,
+ *    unless stated.
+ */
+#ifndef NEMO_HIP_H
+#define NEMO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEMO_ABI_VERSION 1
+int32_t nemo_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense fp32 contraction on the matrix cores (v_mfma_f32_32x32x2_f32), fused epilogue:
+ *   C (op)= maskfn( act( alpha * opA(A) @ opB(B) + bias[n] ) )
+ * transA=0: A[m*lda+k], 1: A[k*lda+m].  transB=0: B[k*ldb+n], 1: B[n*ldb+k].
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.01).  mask_mode: 0 none, 1 v*=(mask>0),
+ * 2 v*=(mask>0 ? 1 : 0.01)  (activation backward from the saved *output*).
+ * out_mode: 0 store, 1 C+=, 2 atomicAdd (required when split_k>1; then act/mask must be 0).
+ * Replaces nn.Linear fwd/bwd (nemo/neural_motion_model.py:58-71,130-148;
+ * human_body_prior/models/vposer_model.py:69-88) and the pose-blend matmul
+ * (human_body_prior/body_model/lbs.py:229-233).
+ */
+int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
+                      const float* A, int64_t lda, const float* B, int64_t ldb,
+                      float* C, int64_t ldc, const float* bias, int32_t act,
+                      const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
+                      int32_t out_mode, int32_t split_k, void* stream);
+/* out[n] += sum_m X[m*ldx+n]   (bias gradients). */
+int32_t nemo_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Phase warp + RBF embedding + instance code -> MLP input rows.
+ * K1/K2 of SURVEY.md: monotonic_network.py:23-39, nemo/rbf.py:47-74,
+ * nemo/neural_motion_model.py:3647-3657,3740-3744,3755-3764.
+ * X is (N+1, ldx): row s<N = [ phi_d(phase_s) (D cols, or the phase itself if D==0) | code[view_s] (C cols) ],
+ * row N = the "phase 0, zero code" row used for trans_0.  Only the owning view's network is
+ * evaluated per sample.  raw_phase (N) optional: overrides linspace(0,1,T)[frame_idx].
+ * kernel_id: 0 quadratic 1 linear 2 gaussian 3 inverse_quadratic 4 multiquadric
+ *            5 inverse_multiquadric 6 spline 7 poisson_one 8 poisson_two 9 matern32 10 matern52.
+ * phase_out (N) receives the warped phase (saved for backward).  shifts/scales row v starts at
+ * shifts + v*ldp / scales + v*ldp (ldp = 2K when the V networks are stored [sh_0|sc_0|sh_1|...]).
+ * code_noise (N,C) optional: additive instance-code noise of NemoV3/V4 (:3921-3923).
+ */
+int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
+                             const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
+                             const float* shifts, const float* scales, int64_t ldp,
+                             const float* log_sigmas, const float* codes, const float* code_noise,
+                             int32_t kernel_id, float* X, int64_t ldx, float* phase_out, void* stream);
+/* dX (N+1, ldx) -> d_shifts,d_scales (V,K), d_log_sigmas (D), d_codes (V,C); all accumulated. */
+int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
+                             const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
+                             const float* shifts, const float* scales, int64_t ldp,
+                             const float* log_sigmas, int32_t kernel_id, const float* phase,
+                             const float* dX, int64_t ldx,
+                             float* d_shifts, float* d_scales, float* d_log_sigmas, float* d_codes,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * rot6d -> rotation matrix -> axis-angle, per (row, joint).
+ * hmr/geometry.py:47-61 (rot6d_to_rotmat), :181-346 (rotation_matrix_to_angle_axis; 4-branch
+ * quaternion, eps 1e-6; NaN->0 when zero_nan!=0), == human_body_prior/tools/rotation_tools.py:73-81
+ * with zero_nan=0 (VPoser decoder, vposer_model.py:32-45,98-106).
+ * rot6d (rows, ld6) holds J*6 numbers per row; R (rows,J,9) and aa (rows,J*3) may be NULL.
+ */
+int32_t nemo_rot6d_fwd(int64_t rows, int64_t J, const float* rot6d, int64_t ld6, int32_t zero_nan,
+                       float* R, float* aa, void* stream);
+/* d_rot6d (rows, ld6) = J^T [dR ; daa]  (either may be NULL); overwrites the J*6 columns. */
+int32_t nemo_rot6d_bwd(int64_t rows, int64_t J, const float* rot6d, int64_t ld6, int32_t zero_nan,
+                       const float* dR, const float* daa, float* d_rot6d, int64_t ldd, void* stream);
+/* Stand-alone conversions (API parity with hmr/geometry.py). */
+int32_t nemo_rotmat_to_aa(int64_t M, const float* R, int32_t zero_nan, float* aa, void* stream);
+/* hmr/geometry.py:9-45: quaternion-form Rodrigues, angle = ||theta + 1e-8||; form=1 selects the
+ * matrix form of human_body_prior/body_model/lbs.py:303-334 (eval path, forward only). */
+int32_t nemo_rodrigues_fwd(int64_t M, const float* theta, int32_t form, float* R, void* stream);
+int32_t nemo_rodrigues_bwd(int64_t M, const float* theta, const float* dR, float* dtheta, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SMPL model context (immutable constants on the device).
+ * smplx.SMPL buffers + hmr/smpl.py:17-43 (J_regressor_extra, joint_map).  All inputs are HOST
+ * pointers.  posedirs is (207, 3*NV) as smplx stores it; lbs_weights (NV,24); J_regressor (24,NV);
+ * J_regressor_extra (n_extra,NV); sel_vertex_ids (n_sel) are the VertexJointSelector picks
+ * (joints 24..24+n_sel-1 of the 45+n_extra superset); out_joints (n_out) index that superset and
+ * select what nemo_kp_* produce (V0-3: joint_map[[38]+[1..24]], V4: joint_map[0..24]).
+ * The context pre-contracts every non-kinematic output joint (a linear functional of the posed
+ * mesh) with the skinning weights and pose blend-shapes so the 2-D objective never touches
+ * the 6890-vertex mesh.
+ */
+typedef struct nemo_ctx nemo_ctx;
+int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_template, const float* shapedirs,
+                        const float* posedirs, const float* J_regressor, const float* lbs_weights,
+                        const int64_t* parents, int64_t n_extra, const float* J_regressor_extra,
+                        int64_t n_sel, const int64_t* sel_vertex_ids,
+                        int64_t n_out, const int64_t* out_joints);
+/* betas: HOST (10); recomputes v_shaped, rest joints and the shape-dependent constants
+ * (lbs.py:209-216).  Called once by nemo_ctx_create with zeros. */
+int32_t nemo_ctx_set_betas(nemo_ctx* ctx, const float* betas);
+int32_t nemo_ctx_destroy(nemo_ctx* ctx);
+int64_t nemo_ctx_num_verts(const nemo_ctx* ctx);
+int64_t nemo_ctx_nq(const nemo_ctx* ctx);            /* # non-kinematic output joints            */
+const float* nemo_ctx_C1(const nemo_ctx* ctx);       /* device (207, nq*72) pre-contracted basis   */
+const float* nemo_ctx_c0(const nemo_ctx* ctx);       /* device (nq*72) shape-dependent offset      */
+const float* nemo_ctx_posedirs(const nemo_ctx* ctx); /* device (207, 3*NV)                         */
+const float* nemo_ctx_v_shaped(const nemo_ctx* ctx); /* device (3*NV)                              */
+
+/* Forward kinematics (human_body_prior/body_model/lbs.py:350-404 batch_rigid_transform +
+ * :229 pose_feature).  R (rows,24,9) -> A (rows,24,12) [3x4 relative transforms, row-major],
+ * Jp (rows,24,3) posed joints, PF (rows,207) = (R[1:]-I) flattened. */
+int32_t nemo_fk_fwd(const nemo_ctx* ctx, int64_t rows, const float* R, float* A, float* Jp, float* PF,
+                    void* stream);
+/* dA (rows,24,12) is consumed as scratch (overwritten); dJp, dPF may be NULL. -> dR (rows,24,9). */
+int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R, const float* A, float* dA,
+                    const float* dJp, const float* dPF, float* dR, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Keypoint objective: output joints -> +translation -> per-view camera -> 2-D loss.
+ * nemo/neural_motion_model.py:3073-3124 (learned_camera_projection), hmr/geometry.py:78-106,
+ * :2806-2843 (keypoint_loss), nemo/utils/misc_utils.py:91-105 (GMoF), :3551-3558 (per-view mean).
+ * Mq (N, ldq>=nq*72) = PF @ C1 + c0 (one nemo_gemm_f32).  TR (N+1, ldt): predicted translation,
+ * row N = trans_0 (pass add_trans=0 to skip).  cams (V,9) = [t(3) | rot6d(6)].  targets
+ * (V,T,25,3) = (x, y, conf); gt_size (V,T).  loss_type: 0 mse_robust 1 mse 2 rmse 3 rmse_robust
+ * 4 mse_robust_resized 5 rmse_resized.  Outputs (each may be NULL): j3d (N,n_out,3), p2d (N,n_out,2),
+ * loss_all (N,n_out,W) with W=2 (mse*) or 1 (rmse*); view_acc (V,2) += [sum(loss*conf), #samples].
+ */
+int32_t nemo_kp_fwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A, const float* Jp,
+                    const float* Mq, int64_t ldq, const float* TR, int64_t ldt, int32_t add_trans,
+                    const int64_t* view_idx, const int64_t* frame_idx, const float* cams,
+                    const float* targets, const float* gt_size, float focal, float cx, float cy,
+                    int32_t loss_type, int32_t mean_mode, float* j3d, float* p2d, float* loss_all,
+                    float* view_acc, void* stream);
+/* mean_mode 0 (step, :3551-3558): *scalar_out += (1/n_U) sum_{v present} view_acc[v,0] /
+ * (view_acc[v,1]*n_out*W), norm[0] = n_U.  mean_mode 1 (camera_fitting_loss, :2845-2867): plain mean
+ * over all N*n_out*W elements of loss_all (no confidence weight), norm[0] = N.  norm is a device
+ * scalar consumed by nemo_kp_bwd.  The same mean_mode must be given to nemo_kp_fwd / _bwd. */
+int32_t nemo_kp_finalize(int64_t V, int64_t n_out, int32_t W, int32_t mean_mode, const float* view_acc,
+                         float* scalar_out, float* norm, void* stream);
+/* upstream = d total / d kp_loss.  Outputs: dA (N,24,12) and dMq (N,ldq) overwritten; dJp (N,24,3)
+ * accumulated (caller zeroes it); dTR (N, lddt) rows overwritten (row N, the trans_0 gradient, is
+ * -sum of the rows: nemo_scale_neg_rowsum); d_cams (V,9) accumulated.  dA==NULL skips the body
+ * gradients (camera-only fitting, :2869-2906). */
+int32_t nemo_kp_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A, const float* Jp,
+                    const float* Mq, int64_t ldq, const float* TR, int64_t ldt, int32_t add_trans,
+                    const int64_t* view_idx, const int64_t* frame_idx, const float* cams,
+                    const float* targets, const float* gt_size, float focal, float cx, float cy,
+                    int32_t loss_type, int32_t mean_mode, const float* view_acc, const float* norm,
+                    float upstream, float* dA, float* dJp, float* dMq, float* dTR, int64_t lddt,
+                    float* d_cams, void* stream);
+/* Projection only (API parity: learned_camera_projection on arbitrary points (N,Jn,3)). */
+int32_t nemo_project(int64_t N, int64_t Jn, int64_t V, const float* pts, const int64_t* view_idx,
+                     const float* cams, float focal, float cx, float cy, float* p2d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Full-mesh skinning (lbs.py:238-252) on a pose-blended mesh VP = PF @ posedirs + v_shaped.
+ * nemo_skin_vertices: verts (rows,NV,3) (+ trans (rows,3), may be NULL) -- get_preds()['v'].
+ * nemo_joints_from_verts: the 45+n_extra joint superset from explicit vertices (eval / API parity).
+ */
+int32_t nemo_skin_vertices(const nemo_ctx* ctx, int64_t rows, const float* VP, int64_t ldvp,
+                           const float* A, const float* trans, int64_t ldt, float* verts, void* stream);
+
+/* VPoser v2v term (nemo/neural_motion_model.py:2787-2793): rows [0,N) of VP/A are the
+ * "orig" bodies, rows [N,2N) the detached VPoser reconstructions.
+ *   loss_sum += sum |v_rec - v_orig|            (caller divides by N*NV*3)
+ *   dVP (N, lddvp) = d(sum)/d VP_orig,  dA (N,24,12) = d(sum)/d A_orig      (overwritten)
+ * i.e. the gradient of the un-normalised L1 sum is produced in the same pass. */
+int32_t nemo_v2v_skin_l1(const nemo_ctx* ctx, int64_t N, const float* VP, int64_t ldvp, const float* A,
+                         float* loss_sum, float* dVP, int64_t lddvp, float* dA, void* stream);
+/* Builds the (2N,24,9) rotation set of the two bodies from the MLP pose:
+ * rows<N: [R[:,0], Rodrigues(aa[:,3:72])], rows>=N: [R[:,0], Rodrigues(cat(aa_dec, aa[:,66:72]))]
+ * (:2783-2791, hmr/geometry.py:9-45). */
+int32_t nemo_v2v_prep_fwd(int64_t N, const float* R, const float* aa, const float* aa_dec, float* R2,
+                          void* stream);
+/* dR2 (N,24,9) -> d_aa (N,72) += scale * J^T dR2[:,1:],  dR (N,24,9)[:,0] += scale * dR2[:,0]. */
+int32_t nemo_v2v_prep_bwd(int64_t N, const float* aa, const float* dR2, float scale, float* d_aa,
+                          float* dR, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Priors.
+ * KL( N(mu, softplus(lv)) || N(0,1) ) summed over L, averaged over N
+ * (vposer_model.py:48-56, nemo/neural_motion_model.py:2795-2802).  mulv (N, 2L) = [mu | lv].
+ * scalar_out += kl;  d_mulv (N,2L) = upstream-free gradient (d kl / d [mu|lv]), overwritten. */
+int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int64_t ld, float* scalar_out,
+                        float* d_mulv, int64_t ldd, void* stream);
+/* MaxMixturePrior (hmr/smplify/prior.py:181-196): per-sample min over M Gaussians, mean over N.
+ * x (N, ldx) uses `dim` columns.  means (M,dim), precisions (M,dim,dim), log_nllw (M) = log(nll_weights).
+ * scalar_out += mean;  per_sample (N) optional;  d_x (N, lddx) += scale * d mean / d x. */
+int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const float* x, int64_t ldx,
+                         const float* means, const float* precisions, const float* log_nllw,
+                         float* scalar_out, float* per_sample, float scale, float* d_x, int64_t lddx,
+                         void* stream);
+/* Robust 3-D pose loss used by warmup / NemoV3+ (:3489-3491, :3870-3882): mean over (N*dim) of
+ * (mask>0.5) * GMoF(x - target).  scalar_out += mean; d_x += scale * grad. */
+int32_t nemo_pose3d_fwd_bwd(int64_t N, int64_t dim, const float* x, int64_t ldx, const float* target,
+                            const float* mask, const int64_t* view_idx, const int64_t* frame_idx,
+                            int64_t T, float* scalar_out, float scale, float* d_x, int64_t lddx,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-segment Adam / AdamW over one flat parameter buffer (torch.optim.Adam semantics,
+ * betas (0.9,0.999), eps 1e-8; :3405-3431, :3588-3592).  Up to NEMO_ADAM_MAX_SEG segments per
+ * launch; segment s covers [offset, offset+numel) of the flat buffers.
+ */
+#define NEMO_ADAM_MAX_SEG 16
+typedef struct {
+    int64_t offset, numel;
+    float lr, weight_decay;
+    float step_size;        /* lr / (1 - beta1^t), computed in double on the host */
+    float bias_corr2_sqrt;  /* sqrt(1 - beta2^t) */
+    int32_t adamw;                                        /* 0: coupled L2 (Adam), 1: decoupled */
+    int32_t pad;
+} nemo_adam_seg;
+int32_t nemo_adam_step(int32_t n_seg, const nemo_adam_seg* segs /* HOST */, float* params,
+                       const float* grads, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
+                       float eps, void* stream);
+
+/* Small utilities. */
+int32_t nemo_scale_neg_rowsum(int64_t N, int64_t cols, const float* X, int64_t ldx, float* out_row,
+                              void* stream);  /* out_row[c] -= sum_s X[s][c]   (d trans_0) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEMO_HIP_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of ``libnemo_hip.so`` (the C ABI declared in ``include/nemo_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/Makefile``.  There is NO
+fallback: if the shared object is missing or a kernel call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnemo_hip.so')
+
+ADAM_MAX_SEG = 16
+
+
+class AdamSeg(Structure):
+    _fields_ = [('offset', c_int64), ('numel', c_int64), ('lr', c_float), ('weight_decay', c_float),
+                ('step_size', c_float), ('bias_corr2_sqrt', c_float), ('adamw', c_int32), ('pad', c_int32)]
+
+
+i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
+
+# name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
+SIGNATURES = {
+    'nemo_abi_version': (i32, []),
+    'nemo_gemm_f32': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32,
+                            f32, i32, i32, ptr]),
+    'nemo_colsum_f32': (i32, [ptr, i64, i64, i64, ptr, ptr]),
+    'nemo_phase_embed_fwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
+                                   i32, ptr, i64, ptr, ptr]),
+    'nemo_phase_embed_bwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i32, ptr,
+                                   ptr, i64, ptr, ptr, ptr, ptr, ptr]),
+    'nemo_rot6d_fwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr]),
+    'nemo_rot6d_bwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr]),
+    'nemo_rotmat_to_aa': (i32, [i64, ptr, i32, ptr, ptr]),
+    'nemo_rodrigues_fwd': (i32, [i64, ptr, i32, ptr, ptr]),
+    'nemo_rodrigues_bwd': (i32, [i64, ptr, ptr, ptr, ptr]),
+    'nemo_ctx_create': (i32, [POINTER(c_void_p), i64, ptr, ptr, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i64,
+                              ptr]),
+    'nemo_ctx_set_betas': (i32, [ptr, ptr]),
+    'nemo_ctx_destroy': (i32, [ptr]),
+    'nemo_ctx_num_verts': (i64, [ptr]),
+    'nemo_ctx_nq': (i64, [ptr]),
+    'nemo_ctx_C1': (ptr, [ptr]),
+    'nemo_ctx_c0': (ptr, [ptr]),
+    'nemo_ctx_posedirs': (ptr, [ptr]),
+    'nemo_ctx_v_shaped': (ptr, [ptr]),
+    'nemo_fk_fwd': (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr]),
+    'nemo_fk_bwd': (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr]),
+    'nemo_kp_fwd': (i32, [ptr, i64, i64, i64, ptr, ptr, ptr, i64, ptr, i64, i32, ptr, ptr, ptr, ptr, ptr,
+                          f32, f32, f32, i32, i32, ptr, ptr, ptr, ptr, ptr]),
+    'nemo_kp_finalize': (i32, [i64, i64, i32, i32, ptr, ptr, ptr, ptr]),
+    'nemo_kp_bwd': (i32, [ptr, i64, i64, i64, ptr, ptr, ptr, i64, ptr, i64, i32, ptr, ptr, ptr, ptr, ptr,
+                          f32, f32, f32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i64, ptr, ptr]),
+    'nemo_project': (i32, [i64, i64, i64, ptr, ptr, ptr, f32, f32, f32, ptr, ptr]),
+    'nemo_skin_vertices': (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, ptr]),
+    'nemo_v2v_skin_l1': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr]),
+    'nemo_v2v_prep_fwd': (i32, [i64, ptr, ptr, ptr, ptr, ptr]),
+    'nemo_v2v_prep_bwd': (i32, [i64, ptr, ptr, f32, ptr, ptr, ptr]),
+    'nemo_kl_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, i64, ptr]),
+    'nemo_gmm_fwd_bwd': (i32, [i64, i64, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, f32, ptr, i64, ptr]),
+    'nemo_pose3d_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, f32, ptr, i64, ptr]),
+    'nemo_adam_step': (i32, [i32, POINTER(AdamSeg), ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),
+    'nemo_scale_neg_rowsum': (i32, [i64, i64, ptr, i64, ptr, ptr]),
+}
+
+_lib = None
+
+
+class NemoHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and attach prototypes.  Raises if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NemoHipError(
+            f'{LIB_PATH} not found: the HIP extension is not built. Run `python -c "import '
+            f'__graft_entry__ as g; g.build()"` (or `make -C nemo_cvpr2023_amd/csrc`). '
+            'There is no CPU fallback by design.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.nemo_abi_version()
+    if ver != 1:
+        raise NemoHipError(f'libnemo_hip.so ABI version {ver} != 1 (stale build?)')
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = 'invalid argument' if rc < 0 else f'hipError_t {rc}'
+        raise NemoHipError(f'{what} failed: {kind}')
+
+
+def dptr(t):
+    """Device pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    return t.data_ptr()

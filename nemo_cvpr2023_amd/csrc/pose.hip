@@ -1,0 +1,429 @@
+// Per-sample pose kernels: phase warp + RBF embedding, rot6d -> R -> axis-angle, Rodrigues.
+// All of these are tiny (O(100) flops per sample-joint); they are written one thread per
+// (sample, joint) / per (sample), with coalesced reads along the (instance x frame) batch axis,
+// and exist to replace ~100 aten launches per step of the reference by 1 each.
+#include "common.h"
+#include "rot_math.h"
+#include "../../include/nemo_hip.h"
+
+extern "C" int32_t nemo_abi_version(void) { return NEMO_ABI_VERSION; }
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// RBF kernels, nemo/rbf.py:62-120.  a = (x-c)^2 / exp(log_sigma).
+__device__ __forceinline__ float rbf_phi(int id, float a) {
+    switch (id) {
+        case 0: return a * a;                                   // quadratic
+        case 1: return a;                                       // linear
+        case 2: return expf(-(a * a));                          // gaussian
+        case 3: return 1.f / (1.f + a * a);                     // inverse_quadratic
+        case 4: return sqrtf(1.f + a * a);                      // multiquadric
+        case 5: return 1.f / sqrtf(1.f + a * a);                // inverse_multiquadric
+        case 6: return a * a * logf(a + 1.f);                   // spline
+        case 7: return (a - 1.f) * expf(-a);                    // poisson_one
+        case 8: return ((a - 2.f) / 2.f) * a * expf(-a);        // poisson_two
+        case 9: return (1.f + 1.7320508075688772f * a) * expf(-1.7320508075688772f * a);   // matern32
+        default: return (1.f + 2.23606797749979f * a + (5.f / 3.f) * a * a) * expf(-2.23606797749979f * a);
+    }
+}
+__device__ __forceinline__ float rbf_dphi(int id, float a) {
+    switch (id) {
+        case 0: return 2.f * a;
+        case 1: return 1.f;
+        case 2: return -2.f * a * expf(-(a * a));
+        case 3: { const float u = 1.f + a * a; return -2.f * a / (u * u); }
+        case 4: return a / sqrtf(1.f + a * a);
+        case 5: { const float u = 1.f + a * a; return -a / (u * sqrtf(u)); }
+        case 6: return 2.f * a * logf(a + 1.f) + a * a / (a + 1.f);
+        case 7: return expf(-a) * (2.f - a);
+        case 8: return expf(-a) * (-0.5f * a * a + 2.f * a - 1.f);
+        case 9: return -3.f * a * expf(-1.7320508075688772f * a);
+        default: { const float r5 = 2.23606797749979f;
+                   return expf(-r5 * a) * (-(5.f / 3.f) * a - (5.f * r5 / 3.f) * a * a); }
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+
+// mean_k sigmoid(relu(sc_k) * (x - relu(sh_k)))      monotonic_network.py:23-31
+__device__ __forceinline__ float mono_pass(const float* __restrict__ sh, const float* __restrict__ sc,
+                                           int K, float x) {
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += sigmoidf_(fmaxf(sc[k], 0.f) * (x - fmaxf(sh[k], 0.f)));
+    return s / (float)K;
+}
+
+__global__ __launch_bounds__(256) void phase_embed_fwd_kernel(
+    long N, long V, long T, int K, int D, int C, const int64_t* __restrict__ view_idx,
+    const int64_t* __restrict__ frame_idx, const float* __restrict__ raw_phase,
+    const float* __restrict__ shifts, const float* __restrict__ scales, long ldp,
+    const float* __restrict__ log_sigmas, const float* __restrict__ codes,
+    const float* __restrict__ code_noise, int kid, float* __restrict__ X, long ldx,
+    float* __restrict__ phase_out) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > N) return;
+    float ph = 0.f;
+    long v = 0;
+    if (s < N) {
+        v = view_idx[s];
+        // torch.linspace(0, 1, T)[f]: start + f*step below the midpoint, end - (T-1-f)*step above
+        float x;
+        if (raw_phase) x = raw_phase[s];
+        else {
+            const long f = frame_idx[s];
+            const float step = T > 1 ? 1.0f / (float)(T - 1) : 0.f;
+            x = (f < T / 2) ? (float)f * step : 1.0f - (float)(T - 1 - f) * step;
+        }
+        const float* sh = shifts + v * ldp;
+        const float* sc = scales + v * ldp;
+        const float y = mono_pass(sh, sc, K, x), z = mono_pass(sh, sc, K, 0.f), o = mono_pass(sh, sc, K, 1.f);
+        ph = (y - z) / (o - z + 1e-6f);                 // monotonic_network.py:33-39
+        if (phase_out) phase_out[s] = ph;
+    }
+    float* xr = X + s * ldx;
+    if (D > 0) {
+        for (int d = 0; d < D; ++d) {
+            const float c = D > 1 ? (d < D / 2 ? (float)d * (1.0f / (float)(D - 1))
+                                               : 1.0f - (float)(D - 1 - d) * (1.0f / (float)(D - 1)))
+                                  : 0.f;           // centres = linspace(0,1,D)  rbf.py:38-39
+            const float diff = ph - c;
+            xr[d] = rbf_phi(kid, (diff * diff) / expf(log_sigmas[d]));
+        }
+    } else {
+        xr[0] = ph;
+    }
+    const int off = D > 0 ? D : 1;
+    for (int c = 0; c < C; ++c) {
+        float cv = 0.f;
+        if (s < N) {
+            cv = codes[v * C + c];
+            if (code_noise) cv += code_noise[s * C + c];
+        }
+        xr[off + c] = cv;
+    }
+}
+
+// One thread per sample; parameter gradients reduced with atomics (the per-step volume is
+// N*(2K + D + C) adds into L2-resident accumulators).
+__global__ __launch_bounds__(256) void phase_embed_bwd_kernel(
+    long N, long V, long T, int K, int D, int C, const int64_t* __restrict__ view_idx,
+    const int64_t* __restrict__ frame_idx, const float* __restrict__ raw_phase,
+    const float* __restrict__ shifts, const float* __restrict__ scales, long ldp,
+    const float* __restrict__ log_sigmas, int kid, const float* __restrict__ phase,
+    const float* __restrict__ dX, long ldx, float* __restrict__ d_shifts, float* __restrict__ d_scales,
+    float* __restrict__ d_log_sigmas, float* __restrict__ d_codes) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > N) return;
+    const float ph = s < N ? phase[s] : 0.f;
+    const float* g = dX + s * ldx;
+    float dph = 0.f;
+    if (D > 0) {
+        for (int d = 0; d < D; ++d) {
+            const float c = D > 1 ? (d < D / 2 ? (float)d * (1.0f / (float)(D - 1))
+                                               : 1.0f - (float)(D - 1 - d) * (1.0f / (float)(D - 1)))
+                                  : 0.f;
+            const float diff = ph - c;
+            const float es = expf(log_sigmas[d]);
+            const float a = (diff * diff) / es;
+            const float da = g[d] * rbf_dphi(kid, a);
+            dph += da * 2.f * diff / es;
+            if (d_log_sigmas && da != 0.f) atomicAdd(d_log_sigmas + d, -da * a);   // d a / d log_sigma = -a
+        }
+    } else {
+        dph = g[0];
+    }
+    if (s == N) return;   // the phase-0 row has no phase network and a constant zero code
+    const long v = view_idx[s];
+    const int off = D > 0 ? D : 1;
+    if (d_codes)
+        for (int c = 0; c < C; ++c) atomicAdd(d_codes + v * C + c, g[off + c]);
+    if (!d_shifts) return;
+    float x;
+    if (raw_phase) x = raw_phase[s];
+    else {
+        const long f = frame_idx[s];
+        const float step = T > 1 ? 1.0f / (float)(T - 1) : 0.f;
+        x = (f < T / 2) ? (float)f * step : 1.0f - (float)(T - 1 - f) * step;
+    }
+    const float* sh = shifts + v * ldp;
+    const float* sc = scales + v * ldp;
+    const float y = mono_pass(sh, sc, K, x), z = mono_pass(sh, sc, K, 0.f), o = mono_pass(sh, sc, K, 1.f);
+    const float den = o - z + 1e-6f;
+    const float num = y - z;
+    // ph = num / den
+    const float dy = dph / den;
+    const float dden = -dph * num / (den * den);
+    const float dz = -dy - dden;
+    const float dob = dden;
+    const float invK = 1.f / (float)K;
+    for (int k = 0; k < K; ++k) {
+        const float shr = sh[k], scr = sc[k];
+        const float shp = fmaxf(shr, 0.f), scp = fmaxf(scr, 0.f);
+        float gsh = 0.f, gsc = 0.f;
+        {   const float sg = sigmoidf_(scp * (x - shp)); const float w = dy * invK * sg * (1.f - sg);
+            gsc += w * (x - shp); gsh -= w * scp; }
+        {   const float sg = sigmoidf_(scp * (0.f - shp)); const float w = dz * invK * sg * (1.f - sg);
+            gsc += w * (0.f - shp); gsh -= w * scp; }
+        {   const float sg = sigmoidf_(scp * (1.f - shp)); const float w = dob * invK * sg * (1.f - sg);
+            gsc += w * (1.f - shp); gsh -= w * scp; }
+        if (shr > 0.f && gsh != 0.f) atomicAdd(d_shifts + v * ldp + k, gsh);   // relu'(0) = 0 as in torch
+        if (scr > 0.f && gsc != 0.f) atomicAdd(d_scales + v * ldp + k, gsc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rot6d_fwd_kernel(long total, int J, const float* __restrict__ rot6d,
+                                                        long ld6, int zero_nan, float* __restrict__ R,
+                                                        float* __restrict__ aa) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long row = i / J;
+    const int j = (int)(i % J);
+    float x[6], Rm[9];
+    const float* src = rot6d + row * ld6 + j * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = src[k];
+    rot6d_fwd(x, Rm);
+    if (R) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[i * 9 + k] = Rm[k];
+    }
+    if (aa) {
+        float a[3];
+        rotmat_to_aa_fwd(Rm, zero_nan, a);
+        aa[i * 3 + 0] = a[0]; aa[i * 3 + 1] = a[1]; aa[i * 3 + 2] = a[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void rot6d_bwd_kernel(long total, int J, const float* __restrict__ rot6d,
+                                                        long ld6, int zero_nan, const float* __restrict__ dR,
+                                                        const float* __restrict__ daa,
+                                                        float* __restrict__ d_rot6d, long ldd) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long row = i / J;
+    const int j = (int)(i % J);
+    float x[6], Rm[9], g[9];
+    const float* src = rot6d + row * ld6 + j * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = src[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = dR ? dR[i * 9 + k] : 0.f;
+    if (daa) {
+        rot6d_fwd(x, Rm);
+        const float ga[3] = {daa[i * 3], daa[i * 3 + 1], daa[i * 3 + 2]};
+        if (ga[0] != 0.f || ga[1] != 0.f || ga[2] != 0.f) rotmat_to_aa_bwd(Rm, zero_nan, ga, g);
+    }
+    float dx[6];
+    rot6d_bwd(x, g, dx);
+    float* dst = d_rot6d + row * ldd + j * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dst[k] = dx[k];
+}
+
+__global__ __launch_bounds__(256) void rotmat_to_aa_kernel(long M, const float* __restrict__ R, int zero_nan,
+                                                           float* __restrict__ aa) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    float Rm[9], a[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rm[k] = R[i * 9 + k];
+    rotmat_to_aa_fwd(Rm, zero_nan, a);
+    aa[i * 3] = a[0]; aa[i * 3 + 1] = a[1]; aa[i * 3 + 2] = a[2];
+}
+
+__global__ __launch_bounds__(256) void rodrigues_fwd_kernel(long M, const float* __restrict__ th, int form,
+                                                            float* __restrict__ R) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float t[3] = {th[i * 3], th[i * 3 + 1], th[i * 3 + 2]};
+    float Rm[9];
+    if (form == 0) rodrigues_fwd(t, Rm); else rodrigues_lbs_fwd(t, Rm);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[i * 9 + k] = Rm[k];
+}
+
+__global__ __launch_bounds__(256) void rodrigues_bwd_kernel(long M, const float* __restrict__ th,
+                                                            const float* __restrict__ dR,
+                                                            float* __restrict__ dth) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float t[3] = {th[i * 3], th[i * 3 + 1], th[i * 3 + 2]};
+    float G[9], d[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) G[k] = dR[i * 9 + k];
+    rodrigues_bwd(t, G, d);
+    dth[i * 3] = d[0]; dth[i * 3 + 1] = d[1]; dth[i * 3 + 2] = d[2];
+}
+
+// rows<N : joint 0 = R[s][0];  joints 1..23 = Rodrigues(aa[s][3j .. 3j+2])
+// rows>=N: joint 0 = R[s][0];  joints 1..21 = Rodrigues(aa_dec[s][3(j-1)..]); 22,23 from aa
+__global__ __launch_bounds__(256) void v2v_prep_fwd_kernel(long N, const float* __restrict__ R,
+                                                           const float* __restrict__ aa,
+                                                           const float* __restrict__ aa_dec,
+                                                           float* __restrict__ R2) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * N * 24) return;
+    const long row = i / 24;
+    const int j = (int)(i % 24);
+    const long s = row < N ? row : row - N;
+    float Rm[9];
+    if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rm[k] = R[s * 216 + k];
+    } else {
+        const float* src = (row >= N && j <= 21) ? aa_dec + s * 63 + (j - 1) * 3 : aa + s * 72 + j * 3;
+        const float t[3] = {src[0], src[1], src[2]};
+        rodrigues_fwd(t, Rm);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R2[i * 9 + k] = Rm[k];
+}
+
+__global__ __launch_bounds__(256) void v2v_prep_bwd_kernel(long N, const float* __restrict__ aa,
+                                                           const float* __restrict__ dR2, float scale,
+                                                           float* __restrict__ d_aa, float* __restrict__ dR) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 24) return;
+    const long s = i / 24;
+    const int j = (int)(i % 24);
+    float G[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) G[k] = dR2[i * 9 + k];
+    if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dR[s * 216 + k] += scale * G[k];
+    } else {
+        const float t[3] = {aa[s * 72 + j * 3], aa[s * 72 + j * 3 + 1], aa[s * 72 + j * 3 + 2]};
+        float d[3];
+        rodrigues_bwd(t, G, d);
+        d_aa[s * 72 + j * 3 + 0] += scale * d[0];
+        d_aa[s * 72 + j * 3 + 1] += scale * d[1];
+        d_aa[s * 72 + j * 3 + 2] += scale * d[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void neg_rowsum_kernel(long N, int cols, const float* __restrict__ X,
+                                                         long ldx, float* __restrict__ out) {
+    __shared__ float red[16];
+    for (int c = 0; c < cols; ++c) {
+        float s = 0.f;
+        for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (long)gridDim.x * blockDim.x)
+            s += X[r * ldx + c];
+        const float t = block_sum(s, red);
+        if (threadIdx.x == 0 && t != 0.f) atomicAdd(out + c, -t);
+    }
+}
+
+}  // namespace
+
+#define GRID1D(n) dim3(nemo_cdiv((n), 256)), dim3(256), 0, (hipStream_t)stream
+
+extern "C" int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
+                                        const int64_t* view_idx, const int64_t* frame_idx,
+                                        const float* raw_phase, const float* shifts, const float* scales,
+                                        int64_t ldp, const float* log_sigmas, const float* codes,
+                                        const float* code_noise, int32_t kernel_id, float* X, int64_t ldx,
+                                        float* phase_out, void* stream) {
+    if (N < 0 || V <= 0 || K <= 0 || D < 0 || C < 0 || !X || !shifts || !scales) return NEMO_EINVAL;
+    if (N > 0 && (!view_idx || (!frame_idx && !raw_phase))) return NEMO_EINVAL;
+    if ((D > 0 && !log_sigmas) || (C > 0 && !codes) || kernel_id < 0 || kernel_id > 10) return NEMO_EINVAL;
+    if (ldx < (D > 0 ? D : 1) + C || ldp < K) return NEMO_EINVAL;
+    hipLaunchKernelGGL(phase_embed_fwd_kernel, GRID1D(N + 1), (long)N, (long)V, (long)T, (int)K, (int)D,
+                       (int)C, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp, log_sigmas, codes, code_noise,
+                       (int)kernel_id, X, (long)ldx, phase_out);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
+                                        const int64_t* view_idx, const int64_t* frame_idx,
+                                        const float* raw_phase, const float* shifts, const float* scales,
+                                        int64_t ldp, const float* log_sigmas, int32_t kernel_id, const float* phase,
+                                        const float* dX, int64_t ldx, float* d_shifts, float* d_scales,
+                                        float* d_log_sigmas, float* d_codes, void* stream) {
+    if (N < 0 || V <= 0 || K <= 0 || D < 0 || C < 0 || !dX || !shifts || !scales || !phase) return NEMO_EINVAL;
+    if ((d_shifts == nullptr) != (d_scales == nullptr)) return NEMO_EINVAL;
+    hipLaunchKernelGGL(phase_embed_bwd_kernel, GRID1D(N + 1), (long)N, (long)V, (long)T, (int)K, (int)D,
+                       (int)C, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp, log_sigmas, (int)kernel_id,
+                       phase, dX, (long)ldx, d_shifts, d_scales, d_log_sigmas, d_codes);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_rot6d_fwd(int64_t rows, int64_t J, const float* rot6d, int64_t ld6, int32_t zero_nan,
+                                  float* R, float* aa, void* stream) {
+    if (rows < 0 || J <= 0 || !rot6d || ld6 < J * 6) return NEMO_EINVAL;
+    if (rows == 0) return NEMO_OK;
+    hipLaunchKernelGGL(rot6d_fwd_kernel, GRID1D(rows * J), (long)(rows * J), (int)J, rot6d, (long)ld6,
+                       (int)zero_nan, R, aa);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_rot6d_bwd(int64_t rows, int64_t J, const float* rot6d, int64_t ld6, int32_t zero_nan,
+                                  const float* dR, const float* daa, float* d_rot6d, int64_t ldd,
+                                  void* stream) {
+    if (rows < 0 || J <= 0 || !rot6d || !d_rot6d || ld6 < J * 6 || ldd < J * 6) return NEMO_EINVAL;
+    if (rows == 0) return NEMO_OK;
+    hipLaunchKernelGGL(rot6d_bwd_kernel, GRID1D(rows * J), (long)(rows * J), (int)J, rot6d, (long)ld6,
+                       (int)zero_nan, dR, daa, d_rot6d, (long)ldd);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_rotmat_to_aa(int64_t M, const float* R, int32_t zero_nan, float* aa, void* stream) {
+    if (M < 0 || !R || !aa) return NEMO_EINVAL;
+    if (M == 0) return NEMO_OK;
+    hipLaunchKernelGGL(rotmat_to_aa_kernel, GRID1D(M), (long)M, R, (int)zero_nan, aa);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_rodrigues_fwd(int64_t M, const float* theta, int32_t form, float* R, void* stream) {
+    if (M < 0 || !theta || !R || form < 0 || form > 1) return NEMO_EINVAL;
+    if (M == 0) return NEMO_OK;
+    hipLaunchKernelGGL(rodrigues_fwd_kernel, GRID1D(M), (long)M, theta, (int)form, R);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_rodrigues_bwd(int64_t M, const float* theta, const float* dR, float* dtheta,
+                                      void* stream) {
+    if (M < 0 || !theta || !dR || !dtheta) return NEMO_EINVAL;
+    if (M == 0) return NEMO_OK;
+    hipLaunchKernelGGL(rodrigues_bwd_kernel, GRID1D(M), (long)M, theta, dR, dtheta);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_v2v_prep_fwd(int64_t N, const float* R, const float* aa, const float* aa_dec,
+                                     float* R2, void* stream) {
+    if (N < 0 || !R || !aa || !aa_dec || !R2) return NEMO_EINVAL;
+    if (N == 0) return NEMO_OK;
+    hipLaunchKernelGGL(v2v_prep_fwd_kernel, GRID1D(2 * N * 24), (long)N, R, aa, aa_dec, R2);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_v2v_prep_bwd(int64_t N, const float* aa, const float* dR2, float scale, float* d_aa,
+                                     float* dR, void* stream) {
+    if (N < 0 || !aa || !dR2 || !d_aa || !dR) return NEMO_EINVAL;
+    if (N == 0) return NEMO_OK;
+    hipLaunchKernelGGL(v2v_prep_bwd_kernel, GRID1D(N * 24), (long)N, aa, dR2, scale, d_aa, dR);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_scale_neg_rowsum(int64_t N, int64_t cols, const float* X, int64_t ldx, float* out_row,
+                                         void* stream) {
+    if (N < 0 || cols <= 0 || !X || !out_row) return NEMO_EINVAL;
+    if (N == 0) return NEMO_OK;
+    int blocks = nemo_cdiv(N, 256);
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(neg_rowsum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)N, (int)cols,
+                       X, (long)ldx, out_row);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}

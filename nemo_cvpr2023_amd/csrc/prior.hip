@@ -1,0 +1,221 @@
+// Pose priors and the fused optimiser: VPoser KL term, GMM max-mixture prior, robust 3-D pose loss,
+// multi-segment Adam.  Each loss kernel produces its (upstream-free) gradient in the same pass.
+#include "common.h"
+#include "../../include/nemo_hip.h"
+
+namespace {
+
+// KL(N(mu, s) || N(0,1)) = 0.5 (s^2 + mu^2 - 1 - log s^2),  s = softplus(lv)
+// (torch.distributions.kl._kl_normal_normal; vposer_model.py:55; nemo/neural_motion_model.py:2795-2802)
+__global__ __launch_bounds__(256) void kl_kernel(long N, int L, const float* __restrict__ mulv, long ld,
+                                                 float* __restrict__ out, float* __restrict__ d, long ldd) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    const long total = N * L;
+    const float invN = 1.f / (float)N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long s = i / L;
+        const int k = (int)(i % L);
+        const float mu = mulv[s * ld + k], lv = mulv[s * ld + L + k];
+        // F.softplus (beta=1, threshold=20)
+        const float sp = lv > 20.f ? lv : log1pf(expf(lv));
+        const float var = sp * sp;
+        acc += 0.5f * (var + mu * mu - 1.f - logf(var));
+        if (d) {
+            const float dsp = sp - 1.f / sp;                         // d/ds 0.5(s^2 - log s^2)
+            const float sig = lv > 20.f ? 1.f : 1.f / (1.f + expf(-lv));
+            d[s * ldd + k] = mu * invN;
+            d[s * ldd + L + k] = dsp * sig * invN;
+        }
+    }
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, t * invN);
+}
+
+// MaxMixturePrior.  One thread per sample; the precision matrices are wave-uniform operands
+// (scalar loads), the sample's pose lives in LDS transposed ([dim][64]) so that x_i for a runtime i
+// is a conflict-free LDS read instead of a dynamically indexed register.
+template <int DIM>
+__global__ __launch_bounds__(64) void gmm_kernel(long N, int M, const float* __restrict__ x, long ldx,
+                                                 const float* __restrict__ means,
+                                                 const float* __restrict__ prec,
+                                                 const float* __restrict__ log_nllw, float* __restrict__ out,
+                                                 float* __restrict__ per_sample, float scale,
+                                                 float* __restrict__ dx, long lddx) {
+    __shared__ float xs[DIM][64];
+    __shared__ float ys[DIM][64];
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    const long s = (long)blockIdx.x * 64 + tid;
+    const bool live = s < N;
+    for (int i = 0; i < DIM; ++i) xs[i][tid] = live ? x[s * ldx + i] : 0.f;
+    float best = 0.f;
+    int best_m = 0;
+    for (int m = 0; m < M; ++m) {
+        const float* mu = means + m * DIM;
+        const float* P = prec + (long)m * DIM * DIM;
+        float d[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) d[j] = xs[j][tid] - mu[j];
+        float qf = 0.f;
+        for (int i = 0; i < DIM; ++i) {
+            float y = 0.f;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) y += P[i * DIM + j] * d[j];     // einsum('mij,bmj->bmi')
+            qf += y * (xs[i][tid] - mu[i]);
+        }
+        const float ll = 0.5f * qf - log_nllw[m];
+        if (m == 0 || ll < best) { best = ll; best_m = m; }
+    }
+    if (per_sample && live) per_sample[s] = best;
+    const float tot = block_sum(live ? best : 0.f, red);
+    if (tid == 0) atomicAdd(out, tot / (float)N);
+    if (!dx) return;
+    // gradient of the selected component: 0.5 (P + P^T) d / N
+    const float coef = 0.5f * scale / (float)N;
+    for (int m = 0; m < M; ++m) {
+        // wave-uniform skip when no lane selected this component
+        if (__ballot(live && best_m == m) == 0ull) continue;
+        const float* mu = means + m * DIM;
+        const float* P = prec + (long)m * DIM * DIM;
+        float d[DIM], yt[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) { d[j] = xs[j][tid] - mu[j]; yt[j] = 0.f; }
+        for (int i = 0; i < DIM; ++i) {
+            float y = 0.f;
+            const float di = xs[i][tid] - mu[i];
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) {
+                const float p = P[i * DIM + j];
+                y += p * d[j];
+                yt[j] += p * di;
+            }
+            ys[i][tid] = y;
+        }
+        if (live && best_m == m) {
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) dx[s * lddx + j] += coef * (ys[j][tid] + yt[j]);
+        }
+    }
+}
+
+// mean over N*dim of (mask>0.5) * rho^2 r^2/(r^2+rho^2), r = x - target[view, frame]
+__global__ __launch_bounds__(256) void pose3d_kernel(long N, int dim, const float* __restrict__ x, long ldx,
+                                                     const float* __restrict__ target,
+                                                     const float* __restrict__ mask,
+                                                     const int64_t* __restrict__ view_idx,
+                                                     const int64_t* __restrict__ frame_idx, long T,
+                                                     float* __restrict__ out, float scale,
+                                                     float* __restrict__ dx, long lddx) {
+    __shared__ float red[16];
+    const long total = N * dim;
+    const float inv = 1.f / (float)total;
+    const float rho2 = 10000.f;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long s = i / dim;
+        const int k = (int)(i % dim);
+        const long vt = view_idx[s] * T + frame_idx[s];
+        const float m = mask[vt] > 0.5f ? 1.f : 0.f;
+        const float r = x[s * ldx + k] - target[vt * dim + k];
+        const float r2 = r * r;
+        acc += m * (rho2 * (r2 / (r2 + rho2)));
+        if (dx) {
+            const float den = r2 + rho2;
+            dx[s * lddx + k] += scale * inv * m * 2.f * r * rho2 * rho2 / (den * den);
+        }
+    }
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out, t * inv);
+}
+
+struct AdamSegs {
+    nemo_adam_seg s[NEMO_ADAM_MAX_SEG];
+    int n;
+};
+
+// torch.optim.Adam / AdamW single-tensor update rule (torch/optim/adam.py _single_tensor_adam):
+//   grad += wd * p (Adam)  |  p *= 1 - lr*wd (AdamW)
+//   m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g^2
+//   p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(AdamSegs segs, float* __restrict__ p,
+                                                   const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, float b1, float b2, float eps) {
+    const nemo_adam_seg sg = segs.s[blockIdx.y];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < sg.numel; i += (long)gridDim.x * blockDim.x) {
+        const long k = sg.offset + i;
+        float grad = g[k], par = p[k];
+        if (sg.weight_decay != 0.f) {
+            if (sg.adamw) par *= 1.f - sg.lr * sg.weight_decay;
+            else grad += sg.weight_decay * par;
+        }
+        const float mm = m[k] + (grad - m[k]) * (1.f - b1);
+        const float vv = b2 * v[k] + (1.f - b2) * (grad * grad);
+        m[k] = mm; v[k] = vv;
+        const float denom = sqrtf(vv) / sg.bias_corr2_sqrt + eps;
+        p[k] = par - sg.step_size * (mm / denom);
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int64_t ld, float* scalar_out,
+                                   float* d_mulv, int64_t ldd, void* stream) {
+    if (N <= 0 || L <= 0 || !mulv || !scalar_out || ld < 2 * L || (d_mulv && ldd < 2 * L)) return NEMO_EINVAL;
+    int blocks = nemo_cdiv(N * L, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(kl_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)N, (int)L, mulv,
+                       (long)ld, scalar_out, d_mulv, (long)ldd);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const float* x, int64_t ldx,
+                                    const float* means, const float* precisions, const float* log_nllw,
+                                    float* scalar_out, float* per_sample, float scale, float* d_x,
+                                    int64_t lddx, void* stream) {
+    if (N <= 0 || M <= 0 || !x || !means || !precisions || !log_nllw || !scalar_out || ldx < dim) return NEMO_EINVAL;
+    if (dim != 69) return NEMO_EINVAL;   // SMPL body pose (23 joints x 3), prior.py:150
+    if (d_x && lddx < dim) return NEMO_EINVAL;
+    hipLaunchKernelGGL(gmm_kernel<69>, dim3(nemo_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, (long)N,
+                       (int)M, x, (long)ldx, means, precisions, log_nllw, scalar_out, per_sample, scale, d_x,
+                       (long)lddx);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_pose3d_fwd_bwd(int64_t N, int64_t dim, const float* x, int64_t ldx,
+                                       const float* target, const float* mask, const int64_t* view_idx,
+                                       const int64_t* frame_idx, int64_t T, float* scalar_out, float scale,
+                                       float* d_x, int64_t lddx, void* stream) {
+    if (N <= 0 || dim <= 0 || !x || !target || !mask || !view_idx || !frame_idx || !scalar_out) return NEMO_EINVAL;
+    int blocks = nemo_cdiv(N * dim, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pose3d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)N, (int)dim, x,
+                       (long)ldx, target, mask, view_idx, frame_idx, (long)T, scalar_out, scale, d_x,
+                       (long)lddx);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_adam_step(int32_t n_seg, const nemo_adam_seg* segs, float* params, const float* grads,
+                                  float* exp_avg, float* exp_avg_sq, float beta1, float beta2, float eps,
+                                  void* stream) {
+    if (n_seg < 0 || n_seg > NEMO_ADAM_MAX_SEG || !segs || !params || !grads || !exp_avg || !exp_avg_sq)
+        return NEMO_EINVAL;
+    if (n_seg == 0) return NEMO_OK;
+    AdamSegs a;
+    a.n = n_seg;
+    long maxn = 0;
+    for (int i = 0; i < n_seg; ++i) {
+        a.s[i] = segs[i];
+        if (segs[i].numel > maxn) maxn = segs[i].numel;
+    }
+    int bx = nemo_cdiv(maxn, 256 * 4);
+    if (bx < 1) bx = 1;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3(bx, n_seg), dim3(256), 0, (hipStream_t)stream, a, params, grads,
+                       exp_avg, exp_avg_sq, beta1, beta2, eps);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}

@@ -1,0 +1,854 @@
+// SMPL kinematics, keypoint objective and full-mesh skinning kernels + the model context.
+//
+// Design (MI355X-first):
+//  * the 2-D keypoint objective never touches the 6890-vertex mesh: every non-kinematic output
+//    joint is a linear functional of the posed mesh, so nemo_ctx_create pre-contracts it with the
+//    skinning weights and the pose blend-shapes into a (207 x nq*72) basis C1; per step one MFMA
+//    GEMM (PF @ C1) + a 24-term sum per joint reproduces smplx's vertex pick / J_regressor_extra
+//    exactly (up to fp32 re-association);
+//  * the full mesh (VPoser v2v term, get_preds()['v']) is pose-blended by the MFMA GEMM and
+//    skinned here with the 3x4 transforms fed from SGPRs (block-uniform) and the per-vertex
+//    weights in VGPRs; the L1 loss and its gradient are produced in the same pass, the
+//    vertex->joint gradient reduction runs on the matrix cores (16x16x4 f32 MFMA).
+#include <vector>
+#include <utility>
+#include <cstring>
+#include "common.h"
+#include "rot_math.h"
+#include "../../include/nemo_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NEMO_MAX_OUT 64
+
+struct KpConst {
+    int parents[24];
+    int out_kind[NEMO_MAX_OUT];   // >=0: kinematic joint index; <0: -(q+1) mesh functional q
+    int n_out, nq;
+};
+
+struct nemo_ctx {
+    long NV;
+    int n_out, nq;
+    KpConst kc;
+    // device constants
+    float *d_posedirs, *d_v_shaped, *d_W, *d_Wt, *d_Jrest, *d_C1, *d_c0, *d_w0;
+    // host copies needed to re-derive the shape-dependent constants
+    std::vector<float> h_v_template, h_shapedirs, h_Jreg, h_W;
+    std::vector<std::vector<std::pair<long, float>>> q_rows;   // sparse rows of the nq functionals
+};
+
+// ------------------------------------------------------------------------------------------ ctx
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return (int32_t)e_; } while (0)
+
+extern "C" int32_t nemo_ctx_set_betas(nemo_ctx* ctx, const float* betas) {
+    if (!ctx) return NEMO_EINVAL;
+    const long NV = ctx->NV;
+    float b[10] = {0};
+    if (betas) memcpy(b, betas, sizeof(b));
+    std::vector<float> vs(NV * 3);
+    for (long v = 0; v < NV; ++v)
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0.0;   // lbs.py:299  einsum('bl,mkl->bmk')
+            for (int l = 0; l < 10; ++l) acc += (double)b[l] * ctx->h_shapedirs[(v * 3 + c) * 10 + l];
+            vs[v * 3 + c] = ctx->h_v_template[v * 3 + c] + (float)acc;
+        }
+    std::vector<float> J(72);
+    for (int j = 0; j < 24; ++j)
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0.0;   // lbs.py:274  einsum('bik,ji->bjk')
+            for (long v = 0; v < NV; ++v) acc += (double)ctx->h_Jreg[j * NV + v] * vs[v * 3 + c];
+            J[j * 3 + c] = (float)acc;
+        }
+    std::vector<float> c0((size_t)ctx->nq * 72 + 1, 0.f);
+    for (int q = 0; q < ctx->nq; ++q)
+        for (int j = 0; j < 24; ++j) {
+            double acc[3] = {0, 0, 0};
+            for (auto& e : ctx->q_rows[q]) {
+                const double w = (double)e.second * ctx->h_W[e.first * 24 + j];
+                for (int c = 0; c < 3; ++c) acc[c] += w * vs[e.first * 3 + c];
+            }
+            for (int c = 0; c < 3; ++c) c0[q * 72 + j * 3 + c] = (float)acc[c];
+        }
+    HIPCHK(hipMemcpy(ctx->d_v_shaped, vs.data(), sizeof(float) * NV * 3, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_Jrest, J.data(), sizeof(float) * 72, hipMemcpyHostToDevice));
+    if (ctx->nq)
+        HIPCHK(hipMemcpy(ctx->d_c0, c0.data(), sizeof(float) * ctx->nq * 72, hipMemcpyHostToDevice));
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_template,
+                                   const float* shapedirs, const float* posedirs, const float* J_regressor,
+                                   const float* lbs_weights, const int64_t* parents, int64_t n_extra,
+                                   const float* J_regressor_extra, int64_t n_sel,
+                                   const int64_t* sel_vertex_ids, int64_t n_out, const int64_t* out_joints) {
+    if (!out || NV <= 0 || !v_template || !shapedirs || !posedirs || !J_regressor || !lbs_weights ||
+        !parents || n_out < 0 || n_out > NEMO_MAX_OUT || (n_out && !out_joints))
+        return NEMO_EINVAL;
+    if (parents[0] >= 0) return NEMO_EINVAL;
+    for (int i = 1; i < 24; ++i)
+        if (parents[i] < 0 || parents[i] >= i) return NEMO_EINVAL;   // topological order required
+    nemo_ctx* c = new nemo_ctx();
+    c->NV = NV;
+    c->n_out = (int)n_out;
+    for (int i = 0; i < 24; ++i) c->kc.parents[i] = (int)parents[i];
+    c->h_v_template.assign(v_template, v_template + NV * 3);
+    c->h_shapedirs.assign(shapedirs, shapedirs + NV * 30);
+    c->h_Jreg.assign(J_regressor, J_regressor + 24 * NV);
+    c->h_W.assign(lbs_weights, lbs_weights + NV * 24);
+    // classify the output joints
+    int nq = 0;
+    for (int o = 0; o < n_out; ++o) {
+        const long idx = out_joints[o];
+        if (idx < 0 || idx >= 24 + n_sel + n_extra) { delete c; return NEMO_EINVAL; }
+        if (idx < 24) { c->kc.out_kind[o] = (int)idx; continue; }
+        std::vector<std::pair<long, float>> row;
+        if (idx < 24 + n_sel) {
+            const long v = sel_vertex_ids[idx - 24];
+            if (v < 0 || v >= NV) { delete c; return NEMO_EINVAL; }
+            row.push_back({v, 1.0f});                               // smplx VertexJointSelector pick
+        } else {
+            const float* r = J_regressor_extra + (idx - 24 - n_sel) * NV;   // hmr/smpl.py:33-34
+            for (long v = 0; v < NV; ++v)
+                if (r[v] != 0.f) row.push_back({v, r[v]});
+        }
+        c->q_rows.push_back(std::move(row));
+        c->kc.out_kind[o] = -(nq + 1);
+        ++nq;
+    }
+    c->nq = nq;
+    c->kc.n_out = (int)n_out;
+    c->kc.nq = nq;
+
+    // pre-contraction: w0[q][j] = sum_v r_q[v] W[v][j];  C1[p][q][j][c] = sum_v r_q[v] W[v][j] P[p][3v+c]
+    std::vector<float> w0((size_t)nq * 24 + 1, 0.f), C1((size_t)207 * nq * 72 + 1, 0.f);
+    for (int q = 0; q < nq; ++q) {
+        const auto& row = c->q_rows[q];
+        for (int j = 0; j < 24; ++j) {
+            double acc = 0.0;
+            for (auto& e : row) acc += (double)e.second * lbs_weights[e.first * 24 + j];
+            w0[q * 24 + j] = (float)acc;
+        }
+        std::vector<double> acc(72);
+        for (int p = 0; p < 207; ++p) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            const float* Pp = posedirs + (size_t)p * NV * 3;
+            for (auto& e : row) {
+                const float* pv = Pp + e.first * 3;
+                const float* wv = lbs_weights + e.first * 24;
+                for (int j = 0; j < 24; ++j) {
+                    const double w = (double)e.second * wv[j];
+                    acc[j * 3 + 0] += w * pv[0];
+                    acc[j * 3 + 1] += w * pv[1];
+                    acc[j * 3 + 2] += w * pv[2];
+                }
+            }
+            for (int k = 0; k < 72; ++k) C1[((size_t)p * nq + q) * 72 + k] = (float)acc[k];
+        }
+    }
+    std::vector<float> Wt((size_t)24 * NV);
+    for (long v = 0; v < NV; ++v)
+        for (int j = 0; j < 24; ++j) Wt[j * NV + v] = lbs_weights[v * 24 + j];
+
+    c->d_posedirs = c->d_v_shaped = c->d_W = c->d_Wt = c->d_Jrest = c->d_C1 = c->d_c0 = c->d_w0 = nullptr;
+#define ALLOC(p, n) HIPCHK(hipMalloc((void**)&(p), sizeof(float) * (size_t)((n) > 0 ? (n) : 1)))
+    ALLOC(c->d_posedirs, 207 * NV * 3); ALLOC(c->d_v_shaped, NV * 3); ALLOC(c->d_W, NV * 24);
+    ALLOC(c->d_Wt, NV * 24); ALLOC(c->d_Jrest, 72); ALLOC(c->d_C1, 207 * nq * 72);
+    ALLOC(c->d_c0, nq * 72); ALLOC(c->d_w0, nq * 24);
+#undef ALLOC
+    HIPCHK(hipMemcpy(c->d_posedirs, posedirs, sizeof(float) * 207 * NV * 3, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_W, lbs_weights, sizeof(float) * NV * 24, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_Wt, Wt.data(), sizeof(float) * NV * 24, hipMemcpyHostToDevice));
+    if (nq) {
+        HIPCHK(hipMemcpy(c->d_C1, C1.data(), sizeof(float) * 207 * nq * 72, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c->d_w0, w0.data(), sizeof(float) * nq * 24, hipMemcpyHostToDevice));
+    }
+    const int32_t rc = nemo_ctx_set_betas(c, nullptr);
+    if (rc) return rc;
+    *out = c;
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_ctx_destroy(nemo_ctx* c) {
+    if (!c) return NEMO_OK;
+    float* ptrs[] = {c->d_posedirs, c->d_v_shaped, c->d_W, c->d_Wt, c->d_Jrest, c->d_C1, c->d_c0, c->d_w0};
+    for (float* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete c;
+    return NEMO_OK;
+}
+extern "C" int64_t nemo_ctx_num_verts(const nemo_ctx* c) { return c ? c->NV : -1; }
+extern "C" int64_t nemo_ctx_nq(const nemo_ctx* c) { return c ? c->nq : -1; }
+extern "C" const float* nemo_ctx_C1(const nemo_ctx* c) { return c ? c->d_C1 : nullptr; }
+extern "C" const float* nemo_ctx_c0(const nemo_ctx* c) { return c ? c->d_c0 : nullptr; }
+extern "C" const float* nemo_ctx_posedirs(const nemo_ctx* c) { return c ? c->d_posedirs : nullptr; }
+extern "C" const float* nemo_ctx_v_shaped(const nemo_ctx* c) { return c ? c->d_v_shaped : nullptr; }
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ FK
+// One thread per body.  The chain state lives in the output buffers themselves (A holds G_R in
+// its 3x3 block, Jp holds G_t): each thread re-reads only what it wrote, so no LDS is needed.
+__global__ __launch_bounds__(128) void fk_fwd_kernel(long rows, const float* __restrict__ R,
+                                                     const float* __restrict__ Jrest, KpConst kc,
+                                                     float* A, float* Jp, float* __restrict__ PF) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float* Rr = R + row * 216;
+    float* Ar = A + row * 288;
+    float* Jr = Jp + row * 72;
+    {
+        float G[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) G[k] = Rr[k];
+        const float j0[3] = {Jrest[0], Jrest[1], Jrest[2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            Ar[r * 4 + 0] = G[r * 3]; Ar[r * 4 + 1] = G[r * 3 + 1]; Ar[r * 4 + 2] = G[r * 3 + 2];
+            Ar[r * 4 + 3] = j0[r] - (G[r * 3] * j0[0] + G[r * 3 + 1] * j0[1] + G[r * 3 + 2] * j0[2]);
+            Jr[r] = j0[r];
+        }
+    }
+    for (int i = 1; i < 24; ++i) {
+        const int p = kc.parents[i];
+        float Gp[9], Ri[9], G[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Gp[r * 3 + c] = Ar[p * 12 + r * 4 + c];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
+        const float ji[3] = {Jrest[i * 3], Jrest[i * 3 + 1], Jrest[i * 3 + 2]};
+        const float rel[3] = {ji[0] - Jrest[p * 3], ji[1] - Jrest[p * 3 + 1], ji[2] - Jrest[p * 3 + 2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                G[r * 3 + c] = Gp[r * 3] * Ri[c] + Gp[r * 3 + 1] * Ri[3 + c] + Gp[r * 3 + 2] * Ri[6 + c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float gt = Gp[r * 3] * rel[0] + Gp[r * 3 + 1] * rel[1] + Gp[r * 3 + 2] * rel[2] + Jr[p * 3 + r];
+            Jr[i * 3 + r] = gt;
+            Ar[i * 12 + r * 4 + 0] = G[r * 3]; Ar[i * 12 + r * 4 + 1] = G[r * 3 + 1];
+            Ar[i * 12 + r * 4 + 2] = G[r * 3 + 2];
+            Ar[i * 12 + r * 4 + 3] = gt - (G[r * 3] * ji[0] + G[r * 3 + 1] * ji[1] + G[r * 3 + 2] * ji[2]);
+        }
+        if (PF) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) PF[row * 207 + (i - 1) * 9 + k] = Ri[k] - ((k % 4 == 0) ? 1.f : 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void fk_bwd_kernel(long rows, const float* __restrict__ R,
+                                                     const float* __restrict__ A,
+                                                     const float* __restrict__ Jrest, KpConst kc, float* dA,
+                                                     const float* __restrict__ dJp,
+                                                     const float* __restrict__ dPF, float* __restrict__ dR) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float* Rr = R + row * 216;
+    const float* Ar = A + row * 288;
+    float* D = dA + row * 288;     // becomes dG in place: [dG_R (3x3 in the 3x4 block) | dG_t (col 3)]
+    // dA -> dG:  A_t = G_t - G_R J  =>  dG_R -= dA_t (x) J ;  dG_t = dA_t (+ dJp)
+    for (int i = 0; i < 24; ++i) {
+        const float ji[3] = {Jrest[i * 3], Jrest[i * 3 + 1], Jrest[i * 3 + 2]};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float dat = D[i * 12 + r * 4 + 3];
+            D[i * 12 + r * 4 + 0] -= dat * ji[0];
+            D[i * 12 + r * 4 + 1] -= dat * ji[1];
+            D[i * 12 + r * 4 + 2] -= dat * ji[2];
+            if (dJp) D[i * 12 + r * 4 + 3] = dat + dJp[row * 72 + i * 3 + r];
+        }
+    }
+    for (int i = 23; i >= 1; --i) {
+        const int p = kc.parents[i];
+        float Gp[9], Ri[9], dG[9], dgt[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Gp[r * 3 + c] = Ar[p * 12 + r * 4 + c];
+                dG[r * 3 + c] = D[i * 12 + r * 4 + c];
+            }
+            dgt[r] = D[i * 12 + r * 4 + 3];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
+        const float rel[3] = {Jrest[i * 3] - Jrest[p * 3], Jrest[i * 3 + 1] - Jrest[p * 3 + 1],
+                              Jrest[i * 3 + 2] - Jrest[p * 3 + 2]};
+        // dR_i = Gp^T dG_i  (+ pose-feature gradient)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = Gp[r] * dG[c] + Gp[3 + r] * dG[3 + c] + Gp[6 + r] * dG[6 + c];
+                if (dPF) v += dPF[row * 207 + (i - 1) * 9 + r * 3 + c];
+                dR[row * 216 + i * 9 + r * 3 + c] = v;
+            }
+        // dG_R[p] += dG_i Ri^T + dgt (x) rel ;  dG_t[p] += dgt
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                D[p * 12 + r * 4 + c] += dG[r * 3] * Ri[c * 3] + dG[r * 3 + 1] * Ri[c * 3 + 1] +
+                                         dG[r * 3 + 2] * Ri[c * 3 + 2] + dgt[r] * rel[c];
+            D[p * 12 + r * 4 + 3] += dgt[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dR[row * 216 + r * 3 + c] = D[r * 4 + c];
+}
+
+// ------------------------------------------------------------------------------------------ KP
+struct KpArgs {
+    long N, V, T;
+    const float *A, *Jp, *Mq, *TR, *w0;
+    long ldq, ldt;
+    const int64_t *view_idx, *frame_idx;
+    const float *cams, *targets, *gt_size;
+    float focal, cx, cy;
+    int add_trans, loss_type, mean_mode;
+};
+
+__device__ __forceinline__ int loss_width(int loss_type) { return (loss_type == 2 || loss_type == 3 || loss_type == 5) ? 1 : 2; }
+
+// 3-D position of output joint o of sample s (before the global translation).
+__device__ __forceinline__ void kp_joint(const KpArgs& a, const KpConst& kc, long s, int o, float* pos) {
+    const int kind = kc.out_kind[o];
+    if (kind >= 0) {
+        pos[0] = a.Jp[s * 72 + kind * 3]; pos[1] = a.Jp[s * 72 + kind * 3 + 1]; pos[2] = a.Jp[s * 72 + kind * 3 + 2];
+        return;
+    }
+    const int q = -kind - 1;
+    const float* Ar = a.A + s * 288;
+    const float* M = a.Mq + s * a.ldq + q * 72;
+    const float* w = a.w0 + q * 24;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    for (int j = 0; j < 24; ++j) {
+        const float m0 = M[j * 3], m1 = M[j * 3 + 1], m2 = M[j * 3 + 2], wj = w[j];
+        const float* Aj = Ar + j * 12;
+        p0 += Aj[0] * m0 + Aj[1] * m1 + Aj[2] * m2 + Aj[3] * wj;
+        p1 += Aj[4] * m0 + Aj[5] * m1 + Aj[6] * m2 + Aj[7] * wj;
+        p2 += Aj[8] * m0 + Aj[9] * m1 + Aj[10] * m2 + Aj[11] * wj;
+    }
+    pos[0] = p0; pos[1] = p1; pos[2] = p2;
+}
+
+// loss value(s) and d loss / d (u, v) for one joint.  l[2]: per-coordinate losses (W=2) or l[0] (W=1).
+__device__ __forceinline__ void kp_loss_eval(int loss_type, float u, float v, float gx, float gy, float conf,
+                                             float size, float* l, float* dl_du, float* dl_dv) {
+    const float m = conf > 0.5f ? 1.f : 0.f;
+    const float rho2 = 10000.f;
+    float ru = u - gx, rv = v - gy, k = 1.f;
+    if (loss_type == 4) { ru = u / size * 1000.f - gx / size * 1000.f; rv = v / size * 1000.f - gy / size * 1000.f; k = 1000.f / size; }
+    if (loss_type == 5) { ru = u / size - gx / size; rv = v / size - gy / size; k = 1.f / size; }
+    switch (loss_type) {
+        case 0: case 4: {   // mse_robust(_resized): rho^2 r^2 / (r^2 + rho^2) per coordinate
+            const float su = ru * ru, sv = rv * rv;
+            l[0] = m * (rho2 * (su / (su + rho2))); l[1] = m * (rho2 * (sv / (sv + rho2)));
+            const float du_ = su + rho2, dv_ = sv + rho2;
+            *dl_du = m * k * 2.f * ru * rho2 * rho2 / (du_ * du_);
+            *dl_dv = m * k * 2.f * rv * rho2 * rho2 / (dv_ * dv_);
+        } break;
+        case 1: {           // mse
+            l[0] = m * ru * ru; l[1] = m * rv * rv;
+            *dl_du = m * 2.f * ru; *dl_dv = m * 2.f * rv;
+        } break;
+        case 2: case 5: {   // rmse(_resized): sqrt(1e-6 + |r|^2)
+            const float d = sqrtf(1e-6f + (ru * ru + rv * rv));
+            l[0] = m * d; l[1] = 0.f;
+            *dl_du = m * k * ru / d; *dl_dv = m * k * rv / d;
+        } break;
+        default: {          // rmse_robust: rho^2 d / (d + rho^2), d = |r|
+            const float d = sqrtf(ru * ru + rv * rv);
+            l[0] = m * (rho2 * (d / (d + rho2))); l[1] = 0.f;
+            const float dd = rho2 * rho2 / ((d + rho2) * (d + rho2));   // d l / d d
+            *dl_du = m * dd * ru / d; *dl_dv = m * dd * rv / d;        // NaN at d == 0, as autograd
+        }
+    }
+}
+
+// 32 lanes per sample (n_out <= 32 active), two samples per wave.
+__device__ __forceinline__ float group32_sum(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int LANES>
+__global__ __launch_bounds__(256) void kp_fwd_kernel(KpArgs a, KpConst kc, float* __restrict__ j3d,
+                                                     float* __restrict__ p2d, float* __restrict__ loss_all,
+                                                     float* __restrict__ view_acc) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long s = t / LANES;
+    const int o = (int)(t % LANES);
+    const bool active = s < a.N && o < kc.n_out;
+    float wsum = 0.f;
+    long v = 0;
+    if (s < a.N) v = a.view_idx[s];
+    if (active) {
+        float pos[3];
+        kp_joint(a, kc, s, o, pos);
+        if (a.add_trans) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pos[c] += a.TR[s * a.ldt + c] - a.TR[a.N * a.ldt + c];
+        }
+        if (j3d) { j3d[(s * kc.n_out + o) * 3] = pos[0]; j3d[(s * kc.n_out + o) * 3 + 1] = pos[1]; j3d[(s * kc.n_out + o) * 3 + 2] = pos[2]; }
+        const float* cam = a.cams + v * 9;
+        float Rc[9];
+        rot6d_fwd(cam + 3, Rc);
+        const float px = Rc[0] * pos[0] + Rc[1] * pos[1] + Rc[2] * pos[2] + cam[0];
+        const float py = Rc[3] * pos[0] + Rc[4] * pos[1] + Rc[5] * pos[2] + cam[1];
+        const float pz = Rc[6] * pos[0] + Rc[7] * pos[1] + Rc[8] * pos[2] + cam[2];
+        const float nx = px / pz, ny = py / pz, nz = pz / pz;
+        const float u = a.focal * nx + a.cx * nz, w = a.focal * ny + a.cy * nz;
+        if (p2d) { p2d[(s * kc.n_out + o) * 2] = u; p2d[(s * kc.n_out + o) * 2 + 1] = w; }
+        if (a.targets) {
+            const long f = a.frame_idx[s];
+            const float* g = a.targets + ((v * a.T + f) * kc.n_out + o) * 3;
+            const float size = a.gt_size ? a.gt_size[v * a.T + f] : 1.f;
+            float l[2], du, dv;
+            kp_loss_eval(a.loss_type, u, w, g[0], g[1], g[2], size, l, &du, &dv);
+            const int W = loss_width(a.loss_type);
+            if (loss_all) {
+                loss_all[(s * kc.n_out + o) * W] = l[0];
+                if (W == 2) loss_all[(s * kc.n_out + o) * W + 1] = l[1];
+            }
+            wsum = (l[0] + (W == 2 ? l[1] : 0.f)) * (a.mean_mode == 0 ? g[2] : 1.f);
+        }
+    }
+    if (view_acc) {
+        if (LANES == 32) wsum = group32_sum(wsum);
+        if (s < a.N && o == 0) {
+            atomicAdd(view_acc + v * 2, wsum);
+            atomicAdd(view_acc + v * 2 + 1, 1.f);
+        }
+    }
+}
+
+__global__ void kp_finalize_kernel(long V, int n_out, int W, int mean_mode, const float* __restrict__ view_acc,
+                                   float* __restrict__ scalar_out, float* __restrict__ norm) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = 0.f, nu = 0.f, cnt = 0.f, sum = 0.f;
+    for (long v = 0; v < V; ++v) {
+        const float c = view_acc[v * 2 + 1];
+        if (c > 0.f) { total += view_acc[v * 2] / (c * (float)(n_out * W)); nu += 1.f; }
+        cnt += c; sum += view_acc[v * 2];
+    }
+    if (mean_mode == 0) { *scalar_out += nu > 0.f ? total / nu : 0.f; norm[0] = nu; }
+    else { *scalar_out += cnt > 0.f ? sum / (cnt * (float)(n_out * W)) : 0.f; norm[0] = cnt; }
+}
+
+template <int LANES>
+__global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const float* __restrict__ view_acc,
+                                                     const float* __restrict__ norm, float upstream,
+                                                     float* __restrict__ dA, float* __restrict__ dJp,
+                                                     float* __restrict__ dMq, float* __restrict__ dTR,
+                                                     long lddt, float* __restrict__ d_cams) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long s = t / LANES;
+    const int o = (int)(t % LANES);
+    const bool live = s < a.N;
+    const bool active = live && o < kc.n_out;
+    long v = 0;
+    if (live) v = a.view_idx[s];
+    float dpos[3] = {0.f, 0.f, 0.f};
+    float dcam[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int kind = 0;
+    if (active) {
+        kind = kc.out_kind[o];
+        float pos[3];
+        kp_joint(a, kc, s, o, pos);
+        if (a.add_trans) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pos[c] += a.TR[s * a.ldt + c] - a.TR[a.N * a.ldt + c];
+        }
+        const float* cam = a.cams + v * 9;
+        float Rc[9];
+        rot6d_fwd(cam + 3, Rc);
+        const float px = Rc[0] * pos[0] + Rc[1] * pos[1] + Rc[2] * pos[2] + cam[0];
+        const float py = Rc[3] * pos[0] + Rc[4] * pos[1] + Rc[5] * pos[2] + cam[1];
+        const float pz = Rc[6] * pos[0] + Rc[7] * pos[1] + Rc[8] * pos[2] + cam[2];
+        const float nx = px / pz, ny = py / pz, nz = pz / pz;
+        const float u = a.focal * nx + a.cx * nz, w = a.focal * ny + a.cy * nz;
+        const long f = a.frame_idx[s];
+        const float* g = a.targets + ((v * a.T + f) * kc.n_out + o) * 3;
+        const float size = a.gt_size ? a.gt_size[v * a.T + f] : 1.f;
+        float l[2], du, dv;
+        kp_loss_eval(a.loss_type, u, w, g[0], g[1], g[2], size, l, &du, &dv);
+        const int W = loss_width(a.loss_type);
+        // d total / d loss_all element
+        float coef;
+        if (a.mean_mode == 0) coef = upstream * g[2] / (norm[0] * view_acc[v * 2 + 1] * (float)(kc.n_out * W));
+        else coef = upstream / (norm[0] * (float)(kc.n_out * W));
+        du *= coef; dv *= coef;
+        // u = f*px/pz + cx*(pz/pz)
+        const float dpx = du * a.focal / pz, dpy = dv * a.focal / pz;
+        const float dpz = -(du * a.focal * px + dv * a.focal * py) / (pz * pz);
+        dpos[0] = Rc[0] * dpx + Rc[3] * dpy + Rc[6] * dpz;
+        dpos[1] = Rc[1] * dpx + Rc[4] * dpy + Rc[7] * dpz;
+        dpos[2] = Rc[2] * dpx + Rc[5] * dpy + Rc[8] * dpz;
+        const float dRc[9] = {dpx * pos[0], dpx * pos[1], dpx * pos[2], dpy * pos[0], dpy * pos[1],
+                              dpy * pos[2], dpz * pos[0], dpz * pos[1], dpz * pos[2]};
+        dcam[0] = dpx; dcam[1] = dpy; dcam[2] = dpz;
+        rot6d_bwd(cam + 3, dRc, dcam + 3);
+    }
+    // camera gradient: reduce over the sample's joints, one atomic set per sample
+    if (d_cams) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            float r = dcam[k];
+            if (LANES == 32) r = group32_sum(r);
+            if (live && o == 0 && r != 0.f) atomicAdd(d_cams + v * 9 + k, r);
+        }
+    }
+    // translation gradient
+    if (dTR && a.add_trans) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float r = dpos[c];
+            if (LANES == 32) r = group32_sum(r);
+            if (live && o == 0) dTR[s * lddt + c] = r;
+        }
+    }
+    if (!dA) return;
+    // kinematic joints: scatter into dJp (zero-initialised by the caller)
+    if (active && kind >= 0) {
+        atomicAdd(dJp + s * 72 + kind * 3, dpos[0]);
+        atomicAdd(dJp + s * 72 + kind * 3 + 1, dpos[1]);
+        atomicAdd(dJp + s * 72 + kind * 3 + 2, dpos[2]);
+    }
+    // mesh functionals: pos = sum_j A_R[j] Mq[q][j] + A_t[j] w0[q][j]
+    const bool mesh = active && kind < 0;
+    const int q = mesh ? -kind - 1 : 0;
+    for (int j = 0; j < 24; ++j) {
+        float m[3] = {0.f, 0.f, 0.f}, wj = 0.f;
+        if (mesh) {
+            const float* M = a.Mq + s * a.ldq + q * 72 + j * 3;
+            m[0] = M[0]; m[1] = M[1]; m[2] = M[2];
+            wj = a.w0[q * 24 + j];
+            const float* Aj = a.A + s * 288 + j * 12;
+            float* dM = dMq + s * a.ldq + q * 72 + j * 3;
+            dM[0] = Aj[0] * dpos[0] + Aj[4] * dpos[1] + Aj[8] * dpos[2];
+            dM[1] = Aj[1] * dpos[0] + Aj[5] * dpos[1] + Aj[9] * dpos[2];
+            dM[2] = Aj[2] * dpos[0] + Aj[6] * dpos[1] + Aj[10] * dpos[2];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float e0 = dpos[r] * m[0], e1 = dpos[r] * m[1], e2 = dpos[r] * m[2], e3 = dpos[r] * wj;
+            if (LANES == 32) { e0 = group32_sum(e0); e1 = group32_sum(e1); e2 = group32_sum(e2); e3 = group32_sum(e3); }
+            if (live && o == 0) {
+                float* d = dA + s * 288 + j * 12 + r * 4;
+                d[0] = e0; d[1] = e1; d[2] = e2; d[3] = e3;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void project_kernel(long N, int Jn, const float* __restrict__ pts,
+                                                      const int64_t* __restrict__ view_idx,
+                                                      const float* __restrict__ cams, float focal, float cx,
+                                                      float cy, float* __restrict__ p2d) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Jn) return;
+    const long s = i / Jn;
+    const float* cam = cams + view_idx[s] * 9;
+    float Rc[9];
+    rot6d_fwd(cam + 3, Rc);
+    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    const float px = Rc[0] * x + Rc[1] * y + Rc[2] * z + cam[0];
+    const float py = Rc[3] * x + Rc[4] * y + Rc[5] * z + cam[1];
+    const float pz = Rc[6] * x + Rc[7] * y + Rc[8] * z + cam[2];
+    const float nz = pz / pz;
+    p2d[i * 2] = focal * (px / pz) + cx * nz;
+    p2d[i * 2 + 1] = focal * (py / pz) + cy * nz;
+}
+
+// ------------------------------------------------------------------------------------------ mesh
+// verts[row][v] = T[row][v] * [VP[row][v]; 1] (+ trans[row]),  T = sum_j W[v][j] A[row][j]
+__global__ __launch_bounds__(256) void skin_vertices_kernel(long rows, long NV, const float* __restrict__ VP,
+                                                            long ldvp, const float* __restrict__ A,
+                                                            const float* __restrict__ Wt,
+                                                            const float* __restrict__ trans, long ldt,
+                                                            float* __restrict__ verts) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = v < NV;
+    float w[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) w[j] = valid ? Wt[j * NV + v] : 0.f;
+    for (long row = blockIdx.y; row < rows; row += gridDim.y) {
+        const float* Ar = A + row * 288;     // block-uniform -> scalar loads
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 24; ++j)
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] += w[j] * Ar[j * 12 + e];
+        if (valid) {
+            const float* vp = VP + row * ldvp + v * 3;
+            const float x = vp[0], y = vp[1], z = vp[2];
+            float* out = verts + (row * NV + v) * 3;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float o = T[r * 4] * x + T[r * 4 + 1] * y + T[r * 4 + 2] * z + T[r * 4 + 3];
+                if (trans) o += trans[row * ldt + r];
+                out[r] = o;
+            }
+        }
+    }
+}
+
+// VPoser v2v term.  Block = S bodies (orig row s, reconstruction row N+s) x all vertices in chunks of
+// 256.  Forward skinning on the VALU with the transforms in SGPRs; d(sum|.|)/dA reduced over the
+// vertices on the matrix cores: dA[j][e] = sum_v W[v][j] dT[v][e]  (16x16x4 f32 MFMA, K = vertices).
+template <int S>
+__global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const float* __restrict__ VP,
+                                                          long ldvp, const float* __restrict__ A,
+                                                          const float* __restrict__ Wt,
+                                                          float* __restrict__ loss_sum,
+                                                          float* __restrict__ dVP, long lddvp,
+                                                          float* __restrict__ dA) {
+    __shared__ float Wl[256][25];        // chunk weights, stride 25 -> conflict-free row reads
+    __shared__ float dTl[4][64][13];     // per-wave dT tile
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const long s0 = (long)blockIdx.x * S;
+
+    f32x4 acc[S][2];
+#pragma unroll
+    for (int si = 0; si < S; ++si)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[si][t][r] = 0.f;
+    float lsum = 0.f;
+
+    for (long c0 = 0; c0 < NV; c0 += 256) {
+        const long v = c0 + tid;
+        const bool valid = v < NV;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 24; ++j) Wl[tid][j] = valid ? Wt[j * NV + v] : 0.f;
+        __syncthreads();
+        float w[24];
+#pragma unroll
+        for (int j = 0; j < 24; ++j) w[j] = Wl[tid][j];
+        // A-operand fragments: Aop[i = joint][k = vertex] = W[vertex][joint]
+        float af[16][2];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int vr = wid * 64 + 4 * kk + lq;
+            af[kk][0] = Wl[vr][l15];
+            af[kk][1] = (l15 < 8) ? Wl[vr][16 + l15] : 0.f;
+        }
+#pragma unroll
+        for (int si = 0; si < S; ++si) {
+            const long s = s0 + si;
+            if (s >= N) break;                 // block-uniform
+            const float* Ao = A + s * 288;
+            const float* Ar = A + (N + s) * 288;
+            float To[12], Tr[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) { To[e] = 0.f; Tr[e] = 0.f; }
+#pragma unroll
+            for (int j = 0; j < 24; ++j)
+#pragma unroll
+                for (int e = 0; e < 12; ++e) {
+                    To[e] += w[j] * Ao[j * 12 + e];
+                    Tr[e] += w[j] * Ar[j * 12 + e];
+                }
+            float po[3] = {0.f, 0.f, 0.f}, pr[3] = {0.f, 0.f, 0.f};
+            if (valid) {
+                const float* a = VP + s * ldvp + v * 3;
+                const float* b = VP + (N + s) * ldvp + v * 3;
+                po[0] = a[0]; po[1] = a[1]; po[2] = a[2];
+                pr[0] = b[0]; pr[1] = b[1]; pr[2] = b[2];
+            }
+            float g[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float vo = To[r * 4] * po[0] + To[r * 4 + 1] * po[1] + To[r * 4 + 2] * po[2] + To[r * 4 + 3];
+                const float vr = Tr[r * 4] * pr[0] + Tr[r * 4 + 1] * pr[1] + Tr[r * 4 + 2] * pr[2] + Tr[r * 4 + 3];
+                const float d = vr - vo;
+                lsum += valid ? fabsf(d) : 0.f;
+                // d |v_rec - v_orig| / d v_orig = -sign(d)
+                g[r] = (!valid || d == 0.f) ? 0.f : (d > 0.f ? -1.f : 1.f);
+            }
+            if (valid) {
+                float* o = dVP + s * lddvp + v * 3;
+                o[0] = To[0] * g[0] + To[4] * g[1] + To[8] * g[2];
+                o[1] = To[1] * g[0] + To[5] * g[1] + To[9] * g[2];
+                o[2] = To[2] * g[0] + To[6] * g[1] + To[10] * g[2];
+            }
+            __syncthreads();                   // previous body's tile fully consumed
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                dTl[wid][lane][r * 4 + 0] = g[r] * po[0];
+                dTl[wid][lane][r * 4 + 1] = g[r] * po[1];
+                dTl[wid][lane][r * 4 + 2] = g[r] * po[2];
+                dTl[wid][lane][r * 4 + 3] = g[r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const float b = (l15 < 12) ? dTl[wid][4 * kk + lq][l15] : 0.f;
+                acc[si][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk][0], b, acc[si][0], 0, 0, 0);
+                acc[si][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk][1], b, acc[si][1], 0, 0, 0);
+            }
+        }
+    }
+    // cross-wave reduction of dA through LDS (reuse Wl as scratch: 4 waves x 32 joints x 16 cols)
+    __syncthreads();
+    float* scratch = &Wl[0][0];                // 6400 floats available, need 4*512
+#pragma unroll
+    for (int si = 0; si < S; ++si) {
+        const long s = s0 + si;
+        if (s >= N) break;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) scratch[wid * 512 + (t * 16 + lq * 4 + r) * 16 + l15] = acc[si][t][r];
+        __syncthreads();
+        for (int idx = tid; idx < 288; idx += 256) {
+            const int j = idx / 12, e = idx % 12;
+            const int off = j * 16 + e;
+            dA[s * 288 + idx] = scratch[off] + scratch[512 + off] + scratch[1024 + off] + scratch[1536 + off];
+        }
+        __syncthreads();
+    }
+    const float tot = block_sum(lsum, red);
+    if (tid == 0) atomicAdd(loss_sum, tot);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" int32_t nemo_fk_fwd(const nemo_ctx* ctx, int64_t rows, const float* R, float* A, float* Jp,
+                               float* PF, void* stream) {
+    if (!ctx || rows < 0 || !R || !A || !Jp) return NEMO_EINVAL;
+    if (rows == 0) return NEMO_OK;
+    hipLaunchKernelGGL(fk_fwd_kernel, dim3(nemo_cdiv(rows, 128)), dim3(128), 0, (hipStream_t)stream,
+                       (long)rows, R, ctx->d_Jrest, ctx->kc, A, Jp, PF);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R, const float* A, float* dA,
+                               const float* dJp, const float* dPF, float* dR, void* stream) {
+    if (!ctx || rows < 0 || !R || !A || !dA || !dR) return NEMO_EINVAL;
+    if (rows == 0) return NEMO_OK;
+    hipLaunchKernelGGL(fk_bwd_kernel, dim3(nemo_cdiv(rows, 128)), dim3(128), 0, (hipStream_t)stream,
+                       (long)rows, R, A, ctx->d_Jrest, ctx->kc, dA, dJp, dPF, dR);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+static int kp_args(const nemo_ctx* ctx, KpArgs& a, int64_t N, int64_t V, int64_t T, const float* A,
+                   const float* Jp, const float* Mq, int64_t ldq, const float* TR, int64_t ldt,
+                   int32_t add_trans, const int64_t* view_idx, const int64_t* frame_idx, const float* cams,
+                   const float* targets, const float* gt_size, float focal, float cx, float cy,
+                   int32_t loss_type, int32_t mean_mode) {
+    if (!ctx || N < 0 || V <= 0 || !A || !Jp || !view_idx || !cams) return NEMO_EINVAL;
+    if (ctx->nq > 0 && (!Mq || ldq < ctx->nq * 72)) return NEMO_EINVAL;
+    if (add_trans && (!TR || ldt < 3)) return NEMO_EINVAL;
+    if (targets && !frame_idx) return NEMO_EINVAL;
+    if (loss_type < 0 || loss_type > 5 || mean_mode < 0 || mean_mode > 1) return NEMO_EINVAL;
+    if ((loss_type == 4 || loss_type == 5) && targets && !gt_size) return NEMO_EINVAL;
+    a.N = N; a.V = V; a.T = T; a.A = A; a.Jp = Jp; a.Mq = Mq; a.TR = TR; a.w0 = ctx->d_w0;
+    a.ldq = ldq; a.ldt = ldt; a.view_idx = view_idx; a.frame_idx = frame_idx; a.cams = cams;
+    a.targets = targets; a.gt_size = gt_size; a.focal = focal; a.cx = cx; a.cy = cy;
+    a.add_trans = add_trans; a.loss_type = loss_type; a.mean_mode = mean_mode;
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_kp_fwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A,
+                               const float* Jp, const float* Mq, int64_t ldq, const float* TR, int64_t ldt,
+                               int32_t add_trans, const int64_t* view_idx, const int64_t* frame_idx,
+                               const float* cams, const float* targets, const float* gt_size, float focal,
+                               float cx, float cy, int32_t loss_type, int32_t mean_mode, float* j3d,
+                               float* p2d, float* loss_all, float* view_acc, void* stream) {
+    KpArgs a;
+    const int rc = kp_args(ctx, a, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams,
+                           targets, gt_size, focal, cx, cy, loss_type, mean_mode);
+    if (rc) return rc;
+    if (N == 0) return NEMO_OK;
+    if (ctx->n_out > 32) return NEMO_EINVAL;
+    hipLaunchKernelGGL(kp_fwd_kernel<32>, dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       ctx->kc, j3d, p2d, loss_all, view_acc);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_kp_finalize(int64_t V, int64_t n_out, int32_t W, int32_t mean_mode,
+                                    const float* view_acc, float* scalar_out, float* norm, void* stream) {
+    if (V <= 0 || n_out <= 0 || (W != 1 && W != 2) || !view_acc || !scalar_out || !norm) return NEMO_EINVAL;
+    hipLaunchKernelGGL(kp_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long)V, (int)n_out,
+                       (int)W, (int)mean_mode, view_acc, scalar_out, norm);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_kp_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A,
+                               const float* Jp, const float* Mq, int64_t ldq, const float* TR, int64_t ldt,
+                               int32_t add_trans, const int64_t* view_idx, const int64_t* frame_idx,
+                               const float* cams, const float* targets, const float* gt_size, float focal,
+                               float cx, float cy, int32_t loss_type, int32_t mean_mode,
+                               const float* view_acc, const float* norm, float upstream, float* dA,
+                               float* dJp, float* dMq, float* dTR, int64_t lddt, float* d_cams,
+                               void* stream) {
+    KpArgs a;
+    const int rc = kp_args(ctx, a, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams,
+                           targets, gt_size, focal, cx, cy, loss_type, mean_mode);
+    if (rc) return rc;
+    if (!targets || !view_acc || !norm) return NEMO_EINVAL;
+    if (dA && (!dJp || (ctx->nq > 0 && !dMq))) return NEMO_EINVAL;
+    if (N == 0) return NEMO_OK;
+    if (ctx->n_out > 32) return NEMO_EINVAL;
+    hipLaunchKernelGGL(kp_bwd_kernel<32>, dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       ctx->kc, view_acc, norm, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_project(int64_t N, int64_t Jn, int64_t V, const float* pts, const int64_t* view_idx,
+                                const float* cams, float focal, float cx, float cy, float* p2d,
+                                void* stream) {
+    if (N < 0 || Jn <= 0 || V <= 0 || !pts || !view_idx || !cams || !p2d) return NEMO_EINVAL;
+    if (N == 0) return NEMO_OK;
+    hipLaunchKernelGGL(project_kernel, dim3(nemo_cdiv(N * Jn, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (long)N, (int)Jn, pts, view_idx, cams, focal, cx, cy, p2d);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_skin_vertices(const nemo_ctx* ctx, int64_t rows, const float* VP, int64_t ldvp,
+                                      const float* A, const float* trans, int64_t ldt, float* verts,
+                                      void* stream) {
+    if (!ctx || rows < 0 || !VP || !A || !verts || ldvp < ctx->NV * 3) return NEMO_EINVAL;
+    if (rows == 0) return NEMO_OK;
+    long gy = rows < 4096 ? rows : 4096;
+    hipLaunchKernelGGL(skin_vertices_kernel, dim3(nemo_cdiv(ctx->NV, 256), (unsigned)gy), dim3(256), 0,
+                       (hipStream_t)stream, (long)rows, ctx->NV, VP, (long)ldvp, A, ctx->d_Wt, trans,
+                       (long)ldt, verts);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_v2v_skin_l1(const nemo_ctx* ctx, int64_t N, const float* VP, int64_t ldvp,
+                                    const float* A, float* loss_sum, float* dVP, int64_t lddvp, float* dA,
+                                    void* stream) {
+    if (!ctx || N < 0 || !VP || !A || !loss_sum || !dVP || !dA || ldvp < ctx->NV * 3 || lddvp < ctx->NV * 3)
+        return NEMO_EINVAL;
+    if (N == 0) return NEMO_OK;
+    constexpr int S = 4;
+    hipLaunchKernelGGL(v2v_skin_l1_kernel<S>, dim3(nemo_cdiv(N, S)), dim3(256), 0, (hipStream_t)stream,
+                       (long)N, ctx->NV, VP, (long)ldvp, A, ctx->d_Wt, loss_sum, dVP, (long)lddvp, dA);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}

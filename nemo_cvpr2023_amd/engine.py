@@ -1,0 +1,460 @@
+"""Fit engine: the per-iteration NeMo optimisation step as an explicit sequence of HIP kernels.
+
+Host-side orchestration of ``libnemo_hip.so`` for the hot path of the reference
+(``nemo/neural_motion_model.py`` ``NemoV*.step`` :3511-3598 / :3796-3909, ``warmup`` :3455-3509,
+``opt_cam`` :2869-2906 / :4060-4151).  There is no autograd here: forward, hand-derived backward
+and the fused Adam update are ~60 kernel launches on one HIP stream writing into pre-allocated
+workspaces, so the same sequence can be replayed / captured.  PyTorch only provides device
+memory, the stream and (for multi-GPU) ``torch.distributed``.
+
+Parameters live in ONE flat fp32 buffer laid out in optimiser order
+``[cameras | motion MLP (+RBF log_sigmas) | phase networks | instance codes]``; gradients and the
+Adam moments are flat buffers with the same layout.  The ``nn.Parameter`` objects the drop-in
+classes expose are views into it (so ``state_dict`` keeps the reference's key names).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import AdamSeg, check, dptr
+
+FOCAL_LENGTH = 5000.0          # hmr/hmr_constants.py:1
+LOSS_TYPES = {'mse_robust': 0, 'mse': 1, 'rmse': 2, 'rmse_robust': 3, 'mse_robust_resized': 4,
+              'rmse_resized': 5}
+RBF_KERNELS = {'quadratic': 0, 'linear': 1, 'gaussian': 2, 'inverse_quadratic': 3, 'multiquadric': 4,
+               'inverse_multiquadric': 5, 'spline': 6, 'poisson_one': 7, 'poisson_two': 8, 'matern32': 9,
+               'matern52': 10}
+# slots of the per-step device scalar buffer
+S_KP, S_V2V, S_KL, S_GMM, S_3D = 0, 1, 2, 3, 4
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class SmplContext:
+    """Owns a ``nemo_ctx`` (device constants of one SMPL model + output-joint selection)."""
+
+    def __init__(self, assets: dict, out_joints, device):
+        self.lib = _lib.load()
+        torch.cuda.set_device(device)
+        f = lambda k: np.ascontiguousarray(assets[k].detach().cpu().numpy().astype(np.float32))
+        vt, sd, pd, jr, w = f('v_template'), f('shapedirs'), f('posedirs'), f('J_regressor'), f('lbs_weights')
+        jx = f('J_regressor_extra')
+        par = np.ascontiguousarray(np.asarray(assets['parents'], dtype=np.int64))
+        sel = np.ascontiguousarray(np.asarray(assets['extra_vids'], dtype=np.int64))
+        oj = np.ascontiguousarray(np.asarray(out_joints, dtype=np.int64))
+        self.NV = vt.shape[0]
+        assert pd.shape == (207, self.NV * 3) and w.shape == (self.NV, 24) and jr.shape == (24, self.NV)
+        h = ctypes.c_void_p()
+        P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        check(self.lib.nemo_ctx_create(ctypes.byref(h), self.NV, P(vt), P(sd), P(pd), P(jr), P(w), P(par),
+                                       jx.shape[0], P(jx), len(sel), P(sel), len(oj), P(oj)),
+              'nemo_ctx_create')
+        self.handle = h
+        self.n_out = len(oj)
+        self.nq = int(self.lib.nemo_ctx_nq(h))
+        self.C1 = self.lib.nemo_ctx_C1(h)
+        self.c0 = self.lib.nemo_ctx_c0(h)
+        self.posedirs = self.lib.nemo_ctx_posedirs(h)
+        self.v_shaped = self.lib.nemo_ctx_v_shaped(h)
+        self._betas = np.zeros(10, dtype=np.float32)
+
+    def set_betas(self, betas):
+        b = np.ascontiguousarray(np.asarray(betas, dtype=np.float32).reshape(-1)[:10])
+        if not np.array_equal(b, self._betas):
+            torch.cuda.synchronize()
+            check(self.lib.nemo_ctx_set_betas(self.handle, b.ctypes.data_as(ctypes.c_void_p)),
+                  'nemo_ctx_set_betas')
+            self._betas = b.copy()
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.nemo_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def fold_vposer(sd: dict, device):
+    """Frozen VPoser-v2 weights (vposer_model.py:69-88) with the two eval-mode BatchNorm layers
+    folded into the Linear that follows them (float64 on the host), mu|logvar heads stacked."""
+    g = lambda k: sd[k].detach().cpu().double()
+
+    def bn(p):
+        s = g(p + '.weight') / torch.sqrt(g(p + '.running_var') + 1e-5)
+        return s, g(p + '.bias') - g(p + '.running_mean') * s
+    s1, t1 = bn('encoder_net.1')
+    s2, t2 = bn('encoder_net.4')
+    W2, b2 = g('encoder_net.2.weight'), g('encoder_net.2.bias')
+    W6, b6 = g('encoder_net.6.weight'), g('encoder_net.6.bias')
+    out = {
+        'e2w': W2 * s1.unsqueeze(0), 'e2b': W2 @ t1 + b2,
+        'e6w': W6 * s2.unsqueeze(0), 'e6b': W6 @ t2 + b6,
+        'e7w': g('encoder_net.7.weight'), 'e7b': g('encoder_net.7.bias'),
+        'emw': torch.cat([g('encoder_net.8.mu.weight'), g('encoder_net.8.logvar.weight')], 0),
+        'emb': torch.cat([g('encoder_net.8.mu.bias'), g('encoder_net.8.logvar.bias')], 0),
+        'd0w': g('decoder_net.0.weight'), 'd0b': g('decoder_net.0.bias'),
+        'd3w': g('decoder_net.3.weight'), 'd3b': g('decoder_net.3.bias'),
+        'd5w': g('decoder_net.5.weight'), 'd5b': g('decoder_net.5.bias'),
+    }
+    return {k: v.float().contiguous().to(device) for k, v in out.items()}
+
+
+def gmm_constants(gmm: dict, device):
+    """hmr/smplify/prior.py:124-160: precisions = inv(cov) in fp32, merged nll weights."""
+    means = gmm['means'].astype(np.float32)
+    covs = gmm['covars'].astype(np.float32)
+    prec = np.stack([np.linalg.inv(c) for c in covs]).astype(np.float32)
+    sqrdets = np.array([np.sqrt(np.linalg.det(c)) for c in gmm['covars']])
+    const = (2 * np.pi) ** (69 / 2.0)
+    nllw = np.asarray(gmm['weights'] / (const * (sqrdets / sqrdets.min()))).astype(np.float32)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)
+    return {'means': t(means), 'prec': t(prec), 'log_nllw': torch.log(t(nllw)), 'M': means.shape[0]}
+
+
+class ParamLayout:
+    """Flat parameter buffer in optimiser order; ``entries`` maps state_dict name -> (offset, shape)."""
+
+    def __init__(self, V, K, D, C, h, din):
+        self.entries = OrderedDict()
+        self.groups = OrderedDict()    # optimiser name -> [names]
+        off = 0
+
+        def add(group, name, shape):
+            nonlocal off
+            n = int(np.prod(shape))
+            self.entries[name] = (off, tuple(shape))
+            self.groups.setdefault(group, []).append(name)
+            off += n
+        add('cameras', 'learned_cameras', (V, 9))
+        for lname, (fo, fi) in (('net.net.0', (h, din)), ('net.net.2', (h, h)), ('net.net.4', (h, h)),
+                                ('rot_out', (144, h)), ('linear_out', (3, h))):
+            add('motion', f'learned_motion.{lname}.weight', (fo, fi))
+            add('motion', f'learned_motion.{lname}.bias', (fo,))
+        if D > 0:
+            add('motion', 'phase_rbf.log_sigmas', (D,))
+        for i in range(V):
+            add('phase', f'phase_networks.{i}.shifts', (K,))
+            add('phase', f'phase_networks.{i}.scales', (K,))
+        if C > 0:
+            add('instance', 'learned_instance_code', (V, C))
+        self.total = off
+
+    def span(self, names):
+        a = min(self.entries[n][0] for n in names)
+        b = max(self.entries[n][0] + int(np.prod(self.entries[n][1])) for n in names)
+        return a, b
+
+
+class FitEngine:
+    def __init__(self, version, args, V, T, img_d0, img_d1, assets, vposer_sd, gmm, device,
+                 targets, gt_size, hmr_theta, hmr_mask):
+        if not torch.cuda.is_available():
+            raise _lib.NemoHipError('FitEngine needs an MI355X (no CPU fallback by design)')
+        self.lib = _lib.load()
+        self.version, self.args = version, args
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.V, self.T = V, T
+        self.K = args.monotonic_network_n_nodes
+        self.C = args.instance_code_size
+        self.D = args.phase_rbf_dim if version >= 2 else 0
+        self.h = args.h_dim
+        self.din = (self.D if self.D > 0 else 1) + self.C
+        self.cx, self.cy = float(img_d0 // 2), float(img_d1 // 2)       # :3104-3106 (sic)
+        self.kernel_id = RBF_KERNELS[args.rbf_kernel] if self.D > 0 else 0
+        # 25 output joints out of the 49-joint map (:3662 / :3997)
+        jm = [int(x) for x in assets['joint_map']]
+        idx = list(range(0, 25)) if version == 4 else [38] + list(range(1, 25))
+        self.ctx = SmplContext(assets, [jm[i] for i in idx], self.device)
+        self.ctx49 = None      # lazily: all 49 joints (get_preds API)
+        self._assets = assets
+        self._jm = jm
+        self.NV = self.ctx.NV
+        self.vp = fold_vposer(vposer_sd, self.device)
+        self.gmm = gmm_constants(gmm, self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.targets = targets.to(**f32).contiguous()
+        self.gt_size = gt_size.to(**f32).contiguous()
+        self.hmr_theta = hmr_theta.to(**f32).contiguous()
+        self.hmr_mask = hmr_mask.to(**f32).contiguous()
+        # flat parameter / gradient / Adam-moment buffers
+        self.layout = ParamLayout(V, self.K, self.D, self.C, self.h, self.din)
+        n = self.layout.total
+        self.params = torch.zeros(n, **f32)
+        self.grads = torch.zeros(n, **f32)
+        self.exp_avg = torch.zeros(n, **f32)
+        self.exp_avg_sq = torch.zeros(n, **f32)
+        self.betas = torch.zeros(1, 10, **f32)
+        self.scal = torch.zeros(8, **f32)
+        self._scal_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+        self.ws = {}
+        self.detach_articulation = False
+        self.start_global_traj_anywhere = False
+
+    # ------------------------------------------------------------------ parameter views
+    def view(self, name, buf=None):
+        off, shape = self.layout.entries[name]
+        buf = self.params if buf is None else buf
+        return buf[off:off + int(np.prod(shape))].view(shape)
+
+    def p(self, name):
+        return self.view(name).data_ptr()
+
+    def g(self, name):
+        return self.view(name, self.grads).data_ptr()
+
+    # ------------------------------------------------------------------ workspaces
+    def _ws(self, N):
+        w = self.ws.get(N)
+        if w is not None:
+            return w
+        f32 = dict(dtype=torch.float32, device=self.device)
+        Z = lambda *s: torch.zeros(*s, **f32)
+        h, nq = self.h, self.ctx.nq
+        Nc = min(N, 8192)
+        w = dict(
+            X=Z(N + 1, self.din), H1=Z(N + 1, h), H2=Z(N + 1, h), H3=Z(N + 1, h), ROT=Z(N + 1, 144),
+            TR=Z(N + 1, 3), phase=Z(N), R=Z(N, 24, 9), AA=Z(N, 72), A=Z(N, 24, 12), Jp=Z(N, 24, 3),
+            PF=Z(N, 207), Mq=Z(N, max(nq * 72, 1)), j3d=Z(N, self.ctx.n_out, 3), p2d=Z(N, self.ctx.n_out, 2),
+            loss_all=Z(N, self.ctx.n_out, 2), view_acc=Z(self.V, 2), norm=Z(1),
+            E1=Z(N, 512), E2=Z(N, 512), E3=Z(N, 512), MULV=Z(N, 64), D1=Z(N, 512), D2=Z(N, 512),
+            D3=Z(N, 126), AAdec=Z(N, 63),
+            R2=Z(2 * Nc, 24, 9), A2=Z(2 * Nc, 24, 12), Jp2=Z(2 * Nc, 24, 3), PF2=Z(2 * Nc, 207),
+            VP2=Z(2 * Nc, 3 * self.NV), dVP=Z(Nc, 3 * self.NV), dA2=Z(Nc, 24, 12), dPF2=Z(Nc, 207),
+            dR2=Z(N, 24, 9),
+            dAA=Z(N, 72), dR=Z(N, 24, 9), dA=Z(N, 24, 12), dJp=Z(N, 24, 3), dMq=Z(N, max(nq * 72, 1)),
+            dPF=Z(N, 207), dROT=Z(N + 1, 144), dTR=Z(N + 1, 3), dH=Z(N + 1, h), dH_b=Z(N + 1, h),
+            dX=Z(N + 1, self.din), dMULV=Z(N, 64), dE_a=Z(N, 512), dE_b=Z(N, 512), Nc=Nc)
+        self.ws[N] = w
+        return w
+
+    # ------------------------------------------------------------------ kernel helpers
+    def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias=None, act=0, mask=None, ldmask=0,
+             mask_mode=0, alpha=1.0, out_mode=0, split_k=1):
+        check(self.lib.nemo_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias, act, mask, ldmask,
+                                     mask_mode, alpha, out_mode, split_k, _stream()), 'nemo_gemm_f32')
+
+    def _linear(self, rows, x, ldx, fin, w, b, fout, y, ldy, act=0):
+        """y = act(x @ w^T + b), w stored (fout, fin) like nn.Linear."""
+        self.gemm(0, 1, rows, fout, fin, x, ldx, w, fin, y, ldy, bias=b, act=act)
+
+    def _linear_bwd_params(self, rows, x, ldx, fin, dy, lddy, fout, gw, gb):
+        """gw (fout,fin) += dy^T @ x ;  gb += colsum(dy).  K = rows is split for occupancy."""
+        tiles = ((fout + 63) // 64) * ((fin + 63) // 64)
+        split = max(1, min(64, (512 + tiles - 1) // tiles, (rows + 255) // 256))
+        self.gemm(1, 0, fout, fin, rows, dy, lddy, x, ldx, gw, fin, out_mode=2, split_k=split)
+        check(self.lib.nemo_colsum_f32(dy, rows, fout, lddy, gb, _stream()), 'nemo_colsum_f32')
+
+    # ------------------------------------------------------------------ forward pieces
+    def forward_pose(self, w, N, view_idx, frame_idx, raw_phase=None, code_noise=None):
+        """K1-K5: phase warp, RBF, MLP, rot6d->R->aa.  Fills X,H1..H3,ROT,TR,R,AA."""
+        L, st = self.lib, _stream()
+        sh0 = self.p('phase_networks.0.shifts')
+        sc0 = self.p('phase_networks.0.scales')
+        check(L.nemo_phase_embed_fwd(
+            N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
+            sh0, sc0, 2 * self.K, self.p('phase_rbf.log_sigmas') if self.D > 0 else None,
+            self.p('learned_instance_code') if self.C > 0 else None, dptr(code_noise), self.kernel_id,
+            dptr(w['X']), self.din, dptr(w['phase']), st), 'nemo_phase_embed_fwd')
+        h, r = self.h, N + 1
+        lm = 'learned_motion.'
+        self._linear(r, dptr(w['X']), self.din, self.din, self.p(lm + 'net.net.0.weight'),
+                     self.p(lm + 'net.net.0.bias'), h, dptr(w['H1']), h, act=1)
+        self._linear(r, dptr(w['H1']), h, h, self.p(lm + 'net.net.2.weight'), self.p(lm + 'net.net.2.bias'),
+                     h, dptr(w['H2']), h, act=1)
+        self._linear(r, dptr(w['H2']), h, h, self.p(lm + 'net.net.4.weight'), self.p(lm + 'net.net.4.bias'),
+                     h, dptr(w['H3']), h, act=1)
+        self._linear(r, dptr(w['H3']), h, h, self.p(lm + 'rot_out.weight'), self.p(lm + 'rot_out.bias'),
+                     144, dptr(w['ROT']), 144)
+        self._linear(r, dptr(w['H3']), h, h, self.p(lm + 'linear_out.weight'), self.p(lm + 'linear_out.bias'),
+                     3, dptr(w['TR']), 3)
+        check(L.nemo_rot6d_fwd(N, 24, dptr(w['ROT']), 144, 1, dptr(w['R']), dptr(w['AA']), st),
+              'nemo_rot6d_fwd')
+
+    def forward_joints(self, w, N, view_idx, frame_idx, with_loss, mean_mode=0, add_trans=True, ctx=None,
+                       j3d=None, p2d=None):
+        """K6-K8: FK, mesh-functional joints, projection, 2-D loss accumulators."""
+        L, st = self.lib, _stream()
+        ctx = ctx or self.ctx
+        ctx.set_betas(self.betas.detach().cpu().numpy())
+        check(L.nemo_fk_fwd(ctx.handle, N, dptr(w['R']), dptr(w['A']), dptr(w['Jp']), dptr(w['PF']), st),
+              'nemo_fk_fwd')
+        nq72 = ctx.nq * 72
+        Mq = w['Mq'] if ctx is self.ctx else torch.zeros(N, max(nq72, 1), device=self.device)
+        if ctx.nq:
+            self.gemm(0, 0, N, nq72, 207, dptr(w['PF']), 207, ctx.C1, nq72, dptr(Mq), max(nq72, 1),
+                      bias=ctx.c0)
+        lt = LOSS_TYPES[self.args.loss]
+        check(L.nemo_kp_fwd(
+            ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), max(nq72, 1),
+            dptr(w['TR']), 3, 1 if (add_trans and not self.start_global_traj_anywhere) else 0,
+            dptr(view_idx), dptr(frame_idx), self.p('learned_cameras'),
+            dptr(self.targets) if with_loss else None, dptr(self.gt_size) if with_loss else None,
+            FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode,
+            dptr(j3d if j3d is not None else w['j3d']), dptr(p2d if p2d is not None else w['p2d']),
+            dptr(w['loss_all']) if with_loss else None, dptr(w['view_acc']) if with_loss else None, st),
+            'nemo_kp_fwd')
+        if with_loss:
+            Wd = 1 if lt in (2, 3, 5) else 2
+            check(L.nemo_kp_finalize(self.V, ctx.n_out, Wd, mean_mode, dptr(w['view_acc']),
+                                     self.scal.data_ptr() + 4 * S_KP, dptr(w['norm']), st), 'nemo_kp_finalize')
+        return Mq
+
+    def forward_vposer(self, w, N):
+        """K9 + K12: encode(mean) -> decode -> axis-angle; KL and its gradient."""
+        L, st, vp = self.lib, _stream(), self.vp
+        aa63 = w['AA'].data_ptr() + 4 * 3
+        self._linear(N, aa63, 72, 63, dptr(vp['e2w']), dptr(vp['e2b']), 512, dptr(w['E1']), 512, act=2)
+        self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['e6w']), dptr(vp['e6b']), 512, dptr(w['E2']), 512)
+        self._linear(N, dptr(w['E2']), 512, 512, dptr(vp['e7w']), dptr(vp['e7b']), 512, dptr(w['E3']), 512)
+        self._linear(N, dptr(w['E3']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
+        self._linear(N, dptr(w['MULV']), 64, 32, dptr(vp['d0w']), dptr(vp['d0b']), 512, dptr(w['D1']), 512,
+                     act=2)
+        self._linear(N, dptr(w['D1']), 512, 512, dptr(vp['d3w']), dptr(vp['d3b']), 512, dptr(w['D2']), 512,
+                     act=2)
+        self._linear(N, dptr(w['D2']), 512, 512, dptr(vp['d5w']), dptr(vp['d5b']), 126, dptr(w['D3']), 126)
+        check(L.nemo_rot6d_fwd(N, 21, dptr(w['D3']), 126, 0, None, dptr(w['AAdec']), st), 'nemo_rot6d_fwd')
+        check(L.nemo_kl_fwd_bwd(N, 32, dptr(w['MULV']), 64, self.scal.data_ptr() + 4 * S_KL,
+                                dptr(w['dMULV']), 64, st), 'nemo_kl_fwd_bwd')
+
+    def forward_v2v(self, w, N, need_grad):
+        """K10 + K11: the two full-mesh bodies, L1 sum and (same pass) its gradient wrt the pose."""
+        L, st, ctx = self.lib, _stream(), self.ctx
+        Nc, NV3 = w['Nc'], 3 * self.NV
+        for c0 in range(0, N, Nc):
+            n = min(Nc, N - c0)
+            R = w['R'].data_ptr() + 4 * c0 * 216
+            AA = w['AA'].data_ptr() + 4 * c0 * 72
+            AAd = w['AAdec'].data_ptr() + 4 * c0 * 63
+            check(L.nemo_v2v_prep_fwd(n, R, AA, AAd, dptr(w['R2']), st), 'nemo_v2v_prep_fwd')
+            check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']),
+                                dptr(w['PF2']), st), 'nemo_fk_fwd')
+            self.gemm(0, 0, 2 * n, NV3, 207, dptr(w['PF2']), 207, ctx.posedirs, NV3, dptr(w['VP2']), NV3,
+                      bias=ctx.v_shaped)
+            check(L.nemo_v2v_skin_l1(ctx.handle, n, dptr(w['VP2']), NV3, dptr(w['A2']),
+                                     self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVP']), NV3, dptr(w['dA2']),
+                                     st), 'nemo_v2v_skin_l1')
+            if need_grad:
+                w['dPF2'].zero_()
+                self.gemm(0, 1, n, 207, NV3, dptr(w['dVP']), NV3, ctx.posedirs, NV3, dptr(w['dPF2']), 207,
+                          out_mode=2, split_k=8)
+                check(L.nemo_fk_bwd(ctx.handle, n, dptr(w['R2']), dptr(w['A2']), dptr(w['dA2']), None,
+                                    dptr(w['dPF2']), w['dR2'].data_ptr() + 4 * c0 * 216, st), 'nemo_fk_bwd')
+
+    # ------------------------------------------------------------------ backward pieces
+    def backward_kp(self, w, N, view_idx, frame_idx, Mq, mean_mode, upstream, cams_only=False,
+                    detach_pose=False):
+        L, st, ctx = self.lib, _stream(), self.ctx
+        nq72 = max(ctx.nq * 72, 1)
+        lt = LOSS_TYPES[self.args.loss]
+        add_trans = 0 if self.start_global_traj_anywhere else 1
+        if not cams_only:
+            w['dJp'].zero_()
+        check(L.nemo_kp_bwd(
+            ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), nq72, dptr(w['TR']), 3,
+            add_trans, dptr(view_idx), dptr(frame_idx), self.p('learned_cameras'), dptr(self.targets),
+            dptr(self.gt_size), FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode, dptr(w['view_acc']),
+            dptr(w['norm']), upstream, None if cams_only else dptr(w['dA']),
+            None if cams_only else dptr(w['dJp']), None if cams_only else dptr(w['dMq']),
+            None if cams_only else dptr(w['dTR']), 3, self.g('learned_cameras'), st), 'nemo_kp_bwd')
+        if cams_only:
+            return
+        if self.detach_articulation:
+            w['dR'].zero_()
+            return
+        dPF = None
+        if ctx.nq and not detach_pose:
+            self.gemm(0, 1, N, 207, ctx.nq * 72, dptr(w['dMq']), nq72, ctx.C1, ctx.nq * 72, dptr(w['dPF']),
+                      207)
+            dPF = dptr(w['dPF'])
+        check(L.nemo_fk_bwd(ctx.handle, N, dptr(w['R']), dptr(w['A']), dptr(w['dA']), dptr(w['dJp']), dPF,
+                            dptr(w['dR']), st), 'nemo_fk_bwd')
+        if detach_pose:
+            w['dR'][:, 1:].zero_()       # body rotmats detached, global orient keeps its gradient (:4031)
+
+    def backward_vposer_kl(self, w, N, weight):
+        """d(weight*KL)/d poses[:, :63] through the frozen encoder, accumulated into dAA[:, 3:66]."""
+        vp = self.vp
+        self.gemm(0, 0, N, 512, 64, dptr(w['dMULV']), 64, dptr(vp['emw']), 512, dptr(w['dE_a']), 512,
+                  alpha=weight)
+        self.gemm(0, 0, N, 512, 512, dptr(w['dE_a']), 512, dptr(vp['e7w']), 512, dptr(w['dE_b']), 512)
+        self.gemm(0, 0, N, 512, 512, dptr(w['dE_b']), 512, dptr(vp['e6w']), 512, dptr(w['dE_a']), 512,
+                  mask=dptr(w['E1']), ldmask=512, mask_mode=2)
+        self.gemm(0, 0, N, 63, 512, dptr(w['dE_a']), 512, dptr(vp['e2w']), 63,
+                  w['dAA'].data_ptr() + 4 * 3, 72, out_mode=1)
+
+    def backward_mlp(self, w, N, view_idx, frame_idx, raw_phase, has_trans_grad=True):
+        """dROT (N+1,144), dTR (N+1,3) -> all MLP / RBF / phase / code gradients."""
+        L, st, h, r = self.lib, _stream(), self.h, N + 1
+        lm = 'learned_motion.'
+        self._linear_bwd_params(r, dptr(w['H3']), h, h, dptr(w['dROT']), 144, 144,
+                                self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'))
+        self.gemm(0, 0, r, h, 144, dptr(w['dROT']), 144, self.p(lm + 'rot_out.weight'), h, dptr(w['dH']), h,
+                  mask=dptr(w['H3']), ldmask=h, mask_mode=1)
+        if has_trans_grad:
+            self._linear_bwd_params(r, dptr(w['H3']), h, h, dptr(w['dTR']), 3, 3,
+                                    self.g(lm + 'linear_out.weight'), self.g(lm + 'linear_out.bias'))
+            self.gemm(0, 0, r, h, 3, dptr(w['dTR']), 3, self.p(lm + 'linear_out.weight'), h, dptr(w['dH']), h,
+                      mask=dptr(w['H3']), ldmask=h, mask_mode=1, out_mode=1)
+        self._linear_bwd_params(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'),
+                                self.g(lm + 'net.net.4.bias'))
+        self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
+                  mask=dptr(w['H2']), ldmask=h, mask_mode=1)
+        self._linear_bwd_params(r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h,
+                                self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+        self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH']), h,
+                  mask=dptr(w['H1']), ldmask=h, mask_mode=1)
+        self._linear_bwd_params(r, dptr(w['X']), self.din, self.din, dptr(w['dH']), h, h,
+                                self.g(lm + 'net.net.0.weight'), self.g(lm + 'net.net.0.bias'))
+        self.gemm(0, 0, r, self.din, h, dptr(w['dH']), h, self.p(lm + 'net.net.0.weight'), self.din,
+                  dptr(w['dX']), self.din)
+        check(L.nemo_phase_embed_bwd(
+            N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
+            self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), 2 * self.K,
+            self.p('phase_rbf.log_sigmas') if self.D > 0 else None, self.kernel_id, dptr(w['phase']),
+            dptr(w['dX']), self.din, self.g('phase_networks.0.shifts'), self.g('phase_networks.0.scales'),
+            self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
+            self.g('learned_instance_code') if self.C > 0 else None, st), 'nemo_phase_embed_bwd')
+
+    def finish_trans_grad(self, w, N):
+        """d trans_0 = - sum_s d trans_s  (row N of dTR), :3764-3766."""
+        w['dTR'][N].zero_()
+        if not self.start_global_traj_anywhere:
+            check(self.lib.nemo_scale_neg_rowsum(N, 3, dptr(w['dTR']), 3, w['dTR'].data_ptr() + 4 * 3 * N,
+                                                 _stream()), 'nemo_scale_neg_rowsum')
+
+    # ------------------------------------------------------------------ optimiser
+    def adam(self, segments, exp_avg=None, exp_avg_sq=None):
+        """segments: list of dicts(offset, numel, lr, wd, adamw, step) -- step is the NEW step count."""
+        if not segments:
+            return
+        arr = (AdamSeg * len(segments))()
+        for i, s in enumerate(segments):
+            t = s['step']
+            arr[i].offset, arr[i].numel = s['offset'], s['numel']
+            arr[i].lr, arr[i].weight_decay = s['lr'], s['wd']
+            arr[i].step_size = s['lr'] / (1.0 - 0.9 ** t)
+            arr[i].bias_corr2_sqrt = math.sqrt(1.0 - 0.999 ** t)
+            arr[i].adamw = 1 if s['adamw'] else 0
+        m = self.exp_avg if exp_avg is None else exp_avg
+        v = self.exp_avg_sq if exp_avg_sq is None else exp_avg_sq
+        for i in range(0, len(segments), _lib.ADAM_MAX_SEG):
+            n = min(_lib.ADAM_MAX_SEG, len(segments) - i)
+            check(self.lib.nemo_adam_step(n, ctypes.cast(ctypes.byref(arr, i * ctypes.sizeof(AdamSeg)),
+                                                         ctypes.POINTER(AdamSeg)),
+                                          self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(),
+                                          v.data_ptr(), 0.9, 0.999, 1e-8, _stream()), 'nemo_adam_step')
+
+    def read_scalars(self):
+        self._scal_host.copy_(self.scal, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self._scal_host.numpy().copy()

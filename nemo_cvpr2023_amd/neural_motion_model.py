@@ -1,0 +1,625 @@
+"""Drop-in ``NemoV1..V4`` classes on the MI355X fit engine.
+
+Mirrors the public surface of ``nemo/neural_motion_model.py`` that
+``scripts/learned_multi_view_recon_nn.py:192-335`` and ``nemo/utils/render_utils.py:90-158`` use:
+constructor ``NemoVk(args, multi_view_seqs, device)``, ``step / warmup / opt_cam / get_preds /
+get_preds_batch / learned_camera_projection / keypoint_loss / save / load``, attributes
+``optimizers, phase_networks, learned_cameras, num_views, num_frames, args, device`` and the
+``state_dict`` key names (SURVEY.md section 5 "Checkpoint / resume").
+
+All arithmetic of the fit runs in ``libnemo_hip.so`` through :class:`engine.FitEngine`; the tensors
+returned by ``get_preds*`` are plain (non-differentiable) device tensors.
+
+Deliberate deviations from the reference (documented in DESIGN.md):
+  * ``loss_dict['kp_loss']`` is the pure 2-D term (CUDA semantics; the CPU backend aliases it);
+  * a batch of exactly three samples is NOT special (reference: ``torch.cross`` without ``dim``
+    crosses over the batch axis for a (3,3) input, hmr/geometry.py:60);
+  * NaN gradients raise ``FloatingPointError`` instead of dropping into ``ipdb`` (:3497-3500);
+  * NemoV3/V4 with ``weight_3d_loss == 0`` report ``loss_3d = 0`` (reference: UnboundLocalError).
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict, defaultdict
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, dptr
+from .engine import (FOCAL_LENGTH, LOSS_TYPES, S_3D, S_GMM, S_KL, S_KP, S_V2V, FitEngine, _stream)
+
+
+# ----------------------------------------------------------------------------- parameter holders
+class _Linear(nn.Module):
+    def __init__(self, weight, bias):
+        super().__init__()
+        self.weight, self.bias = weight, bias
+
+
+class _Holder(nn.Module):
+    pass
+
+
+class MonotonicNetwork(nn.Module):
+    """monotonic_network.py:7-39.  Parameters are views into the engine's flat buffer; calling the
+    module evaluates the warp with the HIP kernel (used by the script to plot, :317-328)."""
+
+    def __init__(self, engine, index, shifts, scales):
+        super().__init__()
+        self._engine = [engine]
+        self.index = index
+        self.n_nodes = shifts.numel()
+        self.shifts, self.scales = shifts, scales
+
+    def forward(self, x):
+        e = self._engine[0]
+        x = x.to(e.device, torch.float32).reshape(-1).contiguous()
+        n = x.numel()
+        out = torch.empty(n + 1, 1, device=e.device)
+        ph = torch.empty(n, device=e.device)
+        vi = torch.zeros(n, dtype=torch.long, device=e.device)
+        check(e.lib.nemo_phase_embed_fwd(n, 1, e.T, e.K, 0, 0, dptr(vi), None, dptr(x),
+                                         self.shifts.data_ptr(), self.scales.data_ptr(), 2 * e.K, None, None,
+                                         None, 0, dptr(out), 1, dptr(ph), _stream()), 'nemo_phase_embed_fwd')
+        return ph.unsqueeze(1)
+
+
+class RBF(nn.Module):
+    """nemo/rbf.py:11-56 parameter holder (centres buffer + log_sigmas)."""
+
+    def __init__(self, out_features, basis_func, log_sigmas):
+        super().__init__()
+        self.in_features, self.out_features = 1, out_features
+        self.basis_func_name = basis_func
+        self.register_buffer('centres', torch.linspace(0, 1, out_features).unsqueeze(1))
+        self.log_sigmas = log_sigmas
+
+
+# ----------------------------------------------------------------------------- optimiser
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam/AdamW-compatible facade over ``nemo_adam_step``.
+
+    ``param_groups[0]['lr']`` is live (ReduceLROnPlateau and the script's LR logging work),
+    ``state_dict()/load_state_dict()`` use torch's Adam format.  Step counts are tracked per tensor
+    because torch skips tensors whose ``.grad`` is None (e.g. ``linear_out`` during warm-up)."""
+
+    def __init__(self, engine, names, params, lr, weight_decay=0.0, adamw=False, exp_avg=None,
+                 exp_avg_sq=None):
+        defaults = dict(lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay, amsgrad=False,
+                        maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+        self._engine = engine
+        self.names = list(names)
+        self.adamw = adamw
+        self.steps = {n: 0 for n in names}
+        self._m = engine.exp_avg if exp_avg is None else exp_avg
+        self._v = engine.exp_avg_sq if exp_avg_sq is None else exp_avg_sq
+
+    def segments(self, active=None):
+        """Advance the step counters of the active tensors and return merged launch segments."""
+        g = self.param_groups[0]
+        segs = []
+        for n in self.names:
+            if active is not None and n not in active:
+                continue
+            self.steps[n] += 1
+            off, shape = self._engine.layout.entries[n]
+            numel = int(np.prod(shape))
+            s = dict(offset=off, numel=numel, lr=float(g['lr']), wd=float(g['weight_decay']),
+                     adamw=self.adamw, step=self.steps[n])
+            if segs and segs[-1]['offset'] + segs[-1]['numel'] == off and segs[-1]['step'] == s['step']:
+                segs[-1]['numel'] += numel
+            else:
+                segs.append(s)
+        return segs
+
+    @torch.no_grad()
+    def step(self, closure=None, active=None):
+        self._engine.adam(self.segments(active), self._m, self._v)
+
+    def zero_grad(self, set_to_none=False):
+        a, b = self._engine.layout.span(self.names)
+        self._engine.grads[a:b].zero_()
+
+    def _sync_state(self):
+        self.state.clear()
+        for n, p in zip(self.names, self.param_groups[0]['params']):
+            if self.steps[n] > 0:
+                self.state[p] = {'step': torch.tensor(float(self.steps[n])),
+                                 'exp_avg': self._engine.view(n, self._m),
+                                 'exp_avg_sq': self._engine.view(n, self._v)}
+
+    def state_dict(self):
+        self._sync_state()
+        return super().state_dict()
+
+    def load_state_dict(self, sd):
+        sd = deepcopy(sd)
+        super().load_state_dict(sd)
+        for n, p in zip(self.names, self.param_groups[0]['params']):
+            st = self.state.get(p)
+            if st:
+                self.steps[n] = int(float(st['step']))
+                self._engine.view(n, self._m).copy_(st['exp_avg'].to(self._m.device))
+                self._engine.view(n, self._v).copy_(st['exp_avg_sq'].to(self._v.device))
+            else:
+                self.steps[n] = 0
+        self._sync_state()
+
+
+# ----------------------------------------------------------------------------- model
+class MultiViewModel(nn.Module):
+    """Common part of nemo/neural_motion_model.py:151-280, :2758-3124."""
+
+    VERSION = 1
+
+    def __init__(self, args, multi_view_seqs, device, smpl_assets=None, vposer_state=None, gmm=None):
+        super().__init__()
+        self.args = args
+        if not hasattr(self.args, 'include_vs'):
+            self.args.include_vs = False
+            self.args.include_pare = False
+        self.FOCAL_LENGTH = FOCAL_LENGTH
+        self.IMG_D0, self.IMG_D1 = multi_view_seqs.IMG_D0, multi_view_seqs.IMG_D1
+        self.n_joints = 23
+        self.device = torch.device(device)
+        self.multi_view_seqs = multi_view_seqs
+        self.num_views, self.num_frames = multi_view_seqs.num_views, multi_view_seqs.num_frames
+        out_dir = getattr(args, 'out_dir', None)
+        if out_dir and getattr(args, 'write_config', True):                 # :199-202
+            try:
+                import joblib
+                os.makedirs(out_dir, exist_ok=True)
+                joblib.dump({'args': self.args}, os.path.join(out_dir, 'model_config.p'))
+            except Exception:
+                pass
+        if smpl_assets is None or vposer_state is None or gmm is None:
+            from .assets import load_real_assets
+            smpl_assets, vposer_state, gmm = load_real_assets(smpl_assets, vposer_state, gmm)
+        points, size = collate_gt_2d(multi_view_seqs, args.label_type,
+                                     getattr(args, 'label_intersection_threshold', 30.0))
+        pose = torch.tensor(np.array([np.array(multi_view_seqs.sequences[v]['pose'])
+                                      for v in range(self.num_views)])).float()
+        self._engine = [FitEngine(self.VERSION, args, self.num_views, self.num_frames, self.IMG_D0,
+                                  self.IMG_D1, smpl_assets, vposer_state, gmm, self.device, points, size,
+                                  pose[..., 3:-1].contiguous(), pose[..., -1:].contiguous())]
+        e = self.engine
+        self.points2d_gt_all, self.gt_bbox_size = e.targets, e.gt_size
+        self.hmr_theta, self.hmr_mask = e.hmr_theta, e.hmr_mask
+        self.training = False
+        self._build_parameters()
+        self._init_parameters()
+        self._build_optimizers()
+
+    @property
+    def engine(self) -> FitEngine:
+        return self._engine[0]
+
+    # ------------------------------------------------------------------ parameters
+    def _param(self, name):
+        p = nn.Parameter(self.engine.view(name))
+        p.grad = self.engine.view(name, self.engine.grads)
+        return p
+
+    def _build_parameters(self):
+        e = self.engine
+        self.learned_cameras = self._param('learned_cameras')
+        if e.C > 0:
+            self.learned_instance_code = self._param('learned_instance_code')
+        lm = _Holder()
+        lm.net = _Holder()
+        lm.net.net = _Holder()
+        for k in ('0', '2', '4'):
+            lm.net.net.add_module(k, _Linear(self._param(f'learned_motion.net.net.{k}.weight'),
+                                             self._param(f'learned_motion.net.net.{k}.bias')))
+        lm.rot_out = _Linear(self._param('learned_motion.rot_out.weight'),
+                             self._param('learned_motion.rot_out.bias'))
+        lm.linear_out = _Linear(self._param('learned_motion.linear_out.weight'),
+                                self._param('learned_motion.linear_out.bias'))
+        self.learned_motion = lm
+        self.learned_betas = nn.Parameter(e.betas)
+        self.phase_networks = nn.ModuleList([
+            MonotonicNetwork(e, i, self._param(f'phase_networks.{i}.shifts'),
+                             self._param(f'phase_networks.{i}.scales')) for i in range(e.V)])
+        if e.D > 0:
+            self.phase_rbf = RBF(e.D, self.args.rbf_kernel, self._param('phase_rbf.log_sigmas'))
+
+    @torch.no_grad()
+    def _init_parameters(self):
+        """Same distributions as :3375-3402, :106-126, monotonic_network.py:11-21 (drawn on the CPU
+        global RNG in the reference's order; bit-identical initial states are obtained by loading a
+        reference ``state_dict``)."""
+        e, a = self.engine, self.args
+        cams = 1e-4 * torch.randn(e.V, 9)
+        cams[:, 3] += 1
+        cams[:, 6] += 1
+        cams[:, 2] += 2 * FOCAL_LENGTH / (self.IMG_D0 * 1 + 1e-9)
+        self.learned_cameras.copy_(cams)
+        if e.C > 0:
+            self.learned_instance_code.copy_(1e-4 * torch.randn(e.V, e.C))
+        for name, (fo, fi) in (('net.net.0', (e.h, e.din)), ('net.net.2', (e.h, e.h)),
+                               ('net.net.4', (e.h, e.h)), ('rot_out', (144, e.h)), ('linear_out', (3, e.h))):
+            lin = nn.Linear(fi, fo)
+            if name == 'rot_out':
+                nn.init.xavier_uniform_(lin.weight, gain=0.00001)
+                lin.bias.data = torch.tensor([1., 0, 0, 1, 0, 0]).repeat(24)
+            e.view(f'learned_motion.{name}.weight').copy_(lin.weight.data)
+            e.view(f'learned_motion.{name}.bias').copy_(lin.bias.data)
+        for i in range(e.V):
+            sh = torch.linspace(0, 1, e.K) if a.phase_init == 'linear' else torch.rand(e.K)
+            e.view(f'phase_networks.{i}.shifts').copy_(sh.clamp_(0, 1))
+            e.view(f'phase_networks.{i}.scales').fill_(15.0)
+        if e.D > 0:
+            e.view('phase_rbf.log_sigmas').zero_()
+
+    def _build_optimizers(self):
+        e, a, G = self.engine, self.args, self.engine.layout.groups
+        named = dict(self.named_parameters())
+        mk = lambda grp, lr, wd=0.0, adamw=False: FusedAdam(e, G[grp], [named[n] for n in G[grp]], lr, wd,
+                                                            adamw)
+        self.opt_cameras = mk('cameras', a.lr_camera)
+        self.opt_motion = mk('motion', a.lr_human, a.wd_human, a.opt_human == 'adamw')
+        self.opt_phase = mk('phase', a.lr_phase)
+        self.optimizers = [self.opt_cameras, self.opt_motion, self.opt_phase]
+        if e.C > 0:
+            self.opt_instance = mk('instance', a.lr_instance)
+            self.optimizers.append(self.opt_instance)
+        self.schedulers = []
+        if a.lr_factor < 1:
+            self.schedulers = [torch.optim.lr_scheduler.ReduceLROnPlateau(o, factor=a.lr_factor, min_lr=1e-6)
+                               for o in self.optimizers]
+
+    def _adam_all(self, optimizers, active=None):
+        segs = []
+        for o in optimizers:
+            segs += o.segments(active)
+        self.engine.adam(segs)
+
+    # ------------------------------------------------------------------ checkpointing (:257-280)
+    def save(self, path):
+        torch.save({'model_sd': self.state_dict(), 'opt_sd': [o.state_dict() for o in self.optimizers]}, path)
+
+    def load(self, path):
+        saved = torch.load(path, map_location=self.device, weights_only=False)
+        sd = {k: v for k, v in saved['model_sd'].items()
+              if not k.startswith(('vp', 'pose_prior', 'renderer', 'smpl'))}
+        self.load_state_dict(sd, strict=False)
+        for i, opt in enumerate(self.optimizers):
+            opt.load_state_dict(saved['opt_sd'][i])
+
+    # ------------------------------------------------------------------ helpers
+    def _idx(self, t):
+        return torch.as_tensor(t).to(self.device, torch.long).contiguous()
+
+    def full_indices(self):
+        v = torch.arange(self.num_views, device=self.device).repeat_interleave(self.num_frames)
+        f = torch.arange(self.num_frames, device=self.device).repeat(self.num_views)
+        return v, f
+
+    def frame_idx_to_raw_phase(self, frame_idx):
+        return torch.linspace(0, 1, self.num_frames).to(frame_idx.device)[frame_idx]      # :2978-2984
+
+    def keypoint_loss(self, pred, gt, weight, gt_size=None, loss_type=None):
+        """:2806-2843, elementwise API-parity helper (the fit uses the fused kernel)."""
+        loss_type = loss_type or self.args.loss
+        m = (weight > 0.5).float()
+        rho2 = 100.0 ** 2
+        gm = lambda r2: rho2 * (r2 / (r2 + rho2))
+        if loss_type in ('rmse_resized', 'mse_robust_resized'):
+            s = gt_size.unsqueeze(-1).unsqueeze(-1)
+            k = 1000.0 if loss_type == 'mse_robust_resized' else 1.0
+            pred, gt = pred / s * k, gt / s * k
+        if loss_type in ('rmse', 'rmse_resized'):
+            return m * torch.sqrt(1e-6 + ((pred - gt) ** 2).sum(-1, keepdim=True))
+        if loss_type == 'mse':
+            return m * (pred - gt) ** 2
+        if loss_type == 'rmse_robust':
+            return m * gm(torch.sqrt(((pred - gt) ** 2).sum(-1)).unsqueeze(-1))
+        if loss_type in ('mse_robust', 'mse_robust_resized'):
+            return m * gm((pred - gt) ** 2)
+        raise ValueError(loss_type)
+
+    def learned_camera_projection(self, input_points3d, view_idx):
+        """:3073-3124 for arbitrary (N, J, 3) points."""
+        e = self.engine
+        pts = input_points3d.detach().to(self.device, torch.float32).contiguous()
+        vi = self._idx(view_idx)
+        out = torch.empty(pts.shape[0], pts.shape[1], 2, device=self.device)
+        check(e.lib.nemo_project(pts.shape[0], pts.shape[1], e.V, dptr(pts), dptr(vi), e.p('learned_cameras'),
+                                 FOCAL_LENGTH, e.cx, e.cy, dptr(out), _stream()), 'nemo_project')
+        return out
+
+    # ------------------------------------------------------------------ predictions
+    def _noise(self, N):
+        a, e = self.args, self.engine
+        if self.VERSION >= 3 and self.training and getattr(a, 'code_noise', 0) > 0 and e.C > 0:
+            return a.code_noise * torch.randn(N, e.C, device=self.device)
+        return None
+
+    @torch.no_grad()
+    def get_preds_batch(self, view_idx, frame_idx, add_trans=True, phases=None, detach_pose=False,
+                        with_vertices=True):
+        """:3637-3672 / :3968-4008.  Returns fresh tensors: v (N,NV,3), j (N,25,3), poses (N,69),
+        orient (N,6), orient_aa (N,3), trans (N,3)."""
+        e = self.engine
+        vi = self._idx(view_idx)
+        fi = self._idx(frame_idx) if frame_idx is not None else None
+        N = vi.numel()
+        w = e._ws(N)
+        raw = None if phases is None else phases.to(self.device, torch.float32).reshape(-1).contiguous()
+        e.forward_pose(w, N, vi, fi, raw_phase=raw, code_noise=self._noise(N))
+        j3d = torch.empty(N, e.ctx.n_out, 3, device=self.device)
+        e.forward_joints(w, N, vi, fi, with_loss=False, add_trans=add_trans, j3d=j3d)
+        trans = w['TR'][:N] - w['TR'][N:N + 1] if not e.start_global_traj_anywhere else w['TR'][:N].clone()
+        out = {'view_idx': view_idx, 'frame_idx': frame_idx, 'j': j3d, 'poses': w['AA'][:, 3:].clone(),
+               'orient': w['ROT'][:N, :6].clone(), 'orient_aa': w['AA'][:, :3].clone(), 'trans': trans}
+        if with_vertices:
+            out['v'] = self._vertices(w, N, trans if add_trans else None)
+        return out
+
+    def _vertices(self, w, N, trans):
+        e = self.engine
+        NV3 = 3 * e.NV
+        verts = torch.empty(N, e.NV, 3, device=self.device)
+        chunk = 4096
+        VP = torch.empty(min(N, chunk), NV3, device=self.device)
+        for c0 in range(0, N, chunk):
+            n = min(chunk, N - c0)
+            e.gemm(0, 0, n, NV3, 207, w['PF'].data_ptr() + 4 * c0 * 207, 207, e.ctx.posedirs, NV3, dptr(VP),
+                   NV3, bias=e.ctx.v_shaped)
+            t = None if trans is None else trans[c0:c0 + n].contiguous()
+            check(e.lib.nemo_skin_vertices(e.ctx.handle, n, dptr(VP), NV3, w['A'].data_ptr() + 4 * c0 * 288,
+                                           dptr(t), 3, verts.data_ptr() + 4 * c0 * NV3, _stream()),
+                  'nemo_skin_vertices')
+        return verts
+
+    def get_preds(self, add_trans=True):
+        """:2986-3003: all (view, frame) pairs, tensors shaped (V, T, ...)."""
+        vi, fi = self.full_indices()
+        p = self.get_preds_batch(vi, fi, add_trans=add_trans)
+        V, T = self.num_views, self.num_frames
+        return {k: v.reshape(V, T, *v.shape[1:]) for k, v in p.items()}
+
+    # ------------------------------------------------------------------ the hot path
+    def _forward_losses(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False):
+        """Forward of :3511-3584 (+V3 extras).  Accumulates the weighted pose gradients into dAA."""
+        e, a = self.engine, self.args
+        e.scal.zero_()
+        w['view_acc'].zero_()
+        if update:
+            e.grads.zero_()
+            w['dAA'].zero_()
+        e.forward_pose(w, N, vi, fi, code_noise=self._noise(N))
+        Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0)
+        st = _stream()
+        aa69, daa69 = w['AA'].data_ptr() + 12, w['dAA'].data_ptr() + 12
+        if use_vposer:
+            e.forward_vposer(w, N)                                            # always evaluated, :3569
+            e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss))
+            g = e.gmm
+            check(e.lib.nemo_gmm_fwd_bwd(N, g['M'], 69, aa69, 72, dptr(g['means']), dptr(g['prec']),
+                                         dptr(g['log_nllw']), e.scal.data_ptr() + 4 * S_GMM, None,
+                                         float(a.weight_gmm_loss),
+                                         daa69 if (update and a.weight_gmm_loss) else None, 72, st),
+                  'nemo_gmm_fwd_bwd')
+        if self.VERSION >= 3 and getattr(a, 'weight_3d_loss', 0):
+            check(e.lib.nemo_pose3d_fwd_bwd(N, 69, aa69, 72, dptr(e.hmr_theta), dptr(e.hmr_mask), dptr(vi),
+                                            dptr(fi), e.T, e.scal.data_ptr() + 4 * S_3D,
+                                            float(a.weight_3d_loss), daa69 if update else None, 72, st),
+                  'nemo_pose3d_fwd_bwd')
+        return Mq
+
+    def _backward(self, w, N, vi, fi, Mq, use_vposer=True, detach_pose=False):
+        e, a = self.engine, self.args
+        st = _stream()
+        e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=1.0, detach_pose=detach_pose)
+        if use_vposer and a.weight_vp_loss:
+            check(e.lib.nemo_v2v_prep_bwd(N, dptr(w['AA']), dptr(w['dR2']),
+                                          float(a.weight_vp_loss) / float(N * e.NV * 3), dptr(w['dAA']),
+                                          dptr(w['dR']), st), 'nemo_v2v_prep_bwd')
+        if use_vposer and a.weight_vp_z_loss:
+            e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss))
+        check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), 144, 1, dptr(w['dR']), dptr(w['dAA']),
+                                   dptr(w['dROT']), 144, st), 'nemo_rot6d_bwd')
+        e.finish_trans_grad(w, N)
+        e.backward_mlp(w, N, vi, fi, None)
+
+    def step(self, view_idx, frame_idx, update=True, full_batch=False):
+        """:3511-3598 (V1/V2), :3796-3909 (V3/V4)."""
+        e, a = self.engine, self.args
+        if self.VERSION >= 3 and update:
+            self.training = True
+        if a.batch_size > -1 and not full_batch:
+            vi, fi = self._idx(view_idx), self._idx(frame_idx)
+        else:
+            vi, fi = self.full_indices()
+        N = vi.numel()
+        w = e._ws(N)
+        Mq = self._forward_losses(w, N, vi, fi, update)
+        inst_t = None
+        if self.VERSION >= 3 and getattr(a, 'weight_instance_loss', 0) and e.C > 0:
+            inst_t = (self.learned_instance_code.detach() ** 2).mean()                    # :3864-3867
+        if update:
+            self._backward(w, N, vi, fi, Mq)
+            if inst_t is not None:
+                code = self.learned_instance_code.detach()
+                e.view('learned_instance_code', e.grads).add_(
+                    code, alpha=2.0 * float(a.weight_instance_loss) / code.numel())
+            self._adam_all(self.optimizers)
+        s = e.read_scalars()
+        f32 = np.float32
+        kp = f32(s[S_KP])
+        v2v = f32(s[S_V2V]) / f32(N * e.NV * 3)
+        kl, gmm, l3d = f32(s[S_KL]), f32(s[S_GMM]), f32(s[S_3D])
+        loss = kp
+        if a.weight_vp_loss:
+            loss = f32(loss + f32(a.weight_vp_loss) * v2v)
+        if a.weight_vp_z_loss:
+            loss = f32(loss + f32(a.weight_vp_z_loss) * kl)
+        loss_dict = {'kp_loss': np.asarray(kp)}
+        if self.VERSION >= 3:
+            inst = f32(float(inst_t)) if inst_t is not None else 0
+            if inst_t is not None:
+                loss = f32(loss + f32(a.weight_instance_loss) * inst)
+            if getattr(a, 'weight_3d_loss', 0):
+                loss = f32(loss + f32(a.weight_3d_loss) * l3d)
+            loss_dict['instance_loss'] = np.asarray(inst)
+            loss_dict['loss_3d'] = np.asarray(l3d)
+        if a.weight_gmm_loss:
+            loss = f32(loss + f32(a.weight_gmm_loss) * gmm)
+        loss_dict.update(gmm_loss=np.asarray(gmm), vp_recon_loss=np.asarray(v2v), vp_kl_loss=np.asarray(kl),
+                         total_loss=np.asarray(loss))
+        info_dict = {'view_idx': vi, 'frame_idx': fi, 'loss_all': self._loss_all(w, N),
+                     'points2d_gt': e.targets[vi, fi], 'points2d': w['p2d'].clone(), 'j': w['j3d'].clone()}
+        if update and self.schedulers:
+            for sch in self.schedulers:
+                sch.step(float(loss))
+        self.training = False
+        return loss_dict, info_dict
+
+    def _loss_all(self, w, N):
+        Wd = 1 if LOSS_TYPES[self.args.loss] in (2, 3, 5) else 2
+        return w['loss_all'].reshape(-1)[:N * self.engine.ctx.n_out * Wd].reshape(N, -1, Wd).clone()
+
+    def draw_batch(self):
+        """scripts/learned_multi_view_recon_nn.py:291-296: CPU global RNG, views first then frames."""
+        B = self.args.batch_size
+        return (torch.randint(0, self.num_views, size=(B,)), torch.randint(0, self.num_frames, size=(B,)))
+
+    def warmup(self, warmup_steps=1000):
+        """:3455-3509: fit the MLP pose output to the HMR/VIBE 3-D pose (motion + phase optimisers)."""
+        if warmup_steps == 0:
+            return []
+        e, a = self.engine, self.args
+        if a.batch_size <= -1:
+            raise NotImplementedError()
+        lm = 'learned_motion.'
+        active = set(e.layout.groups['motion'] + e.layout.groups['phase']) - {
+            lm + 'linear_out.weight', lm + 'linear_out.bias'}            # their .grad is None in the reference
+        losses = []
+        st = _stream()
+        for _ in range(warmup_steps):
+            vi, fi = self.draw_batch()
+            vi, fi = self._idx(vi), self._idx(fi)
+            N = vi.numel()
+            w = e._ws(N)
+            e.scal.zero_()
+            e.grads.zero_()
+            w['dAA'].zero_()
+            e.forward_pose(w, N, vi, fi)
+            check(e.lib.nemo_pose3d_fwd_bwd(N, 69, w['AA'].data_ptr() + 12, 72, dptr(e.hmr_theta),
+                                            dptr(e.hmr_mask), dptr(vi), dptr(fi), e.T,
+                                            e.scal.data_ptr() + 4 * S_3D, 1.0, w['dAA'].data_ptr() + 12, 72,
+                                            st), 'nemo_pose3d_fwd_bwd')
+            check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), 144, 1, None, dptr(w['dAA']), dptr(w['dROT']),
+                                       144, st), 'nemo_rot6d_bwd')
+            e.backward_mlp(w, N, vi, fi, None, has_trans_grad=False)
+            if bool(torch.isnan(e.grads).any()):
+                raise FloatingPointError('nan gradient found during warmup')        # :3497-3500
+            self._adam_all([self.opt_motion, self.opt_phase], active)
+            losses.append(float(e.read_scalars()[S_3D]))
+        return losses
+
+    def opt_cam(self, cam_opt_steps=2000):
+        """:2869-2906: a fresh Adam on the cameras only, first frame of every view."""
+        e, a = self.engine, self.args
+        m, v = torch.zeros_like(e.exp_avg), torch.zeros_like(e.exp_avg_sq)
+        cam_opt = FusedAdam(e, ['learned_cameras'], [self.learned_cameras], a.lr_camera, exp_avg=m,
+                            exp_avg_sq=v)
+        vi = torch.arange(self.num_views, device=self.device)
+        fi = torch.zeros(self.num_views, dtype=torch.long, device=self.device)
+        N = self.num_views
+        w = e._ws(N)
+        log = []
+        for _ in range(cam_opt_steps):
+            cam_opt.zero_grad()
+            e.scal.zero_()
+            w['view_acc'].zero_()
+            e.forward_pose(w, N, vi, fi)
+            Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=1)
+            e.backward_kp(w, N, vi, fi, Mq, mean_mode=1, upstream=1.0, cams_only=True)
+            cam_opt.step()
+            log.append(np.asarray(e.read_scalars()[S_KP]))
+        return log
+
+
+class NemoV1(MultiViewModel):
+    """:3364-3672: one MLP for pose + orient + trans, raw phase input."""
+    VERSION = 1
+
+
+class NemoV2(NemoV1):
+    """:3675-3781: V1 + RBF phase embedding."""
+    VERSION = 2
+
+    @property
+    def detach_articulation(self):
+        return self.engine.detach_articulation
+
+    @detach_articulation.setter
+    def detach_articulation(self, v):
+        self.engine.detach_articulation = bool(v)
+
+    @property
+    def start_global_traj_anywhere(self):
+        return self.engine.start_global_traj_anywhere
+
+    @start_global_traj_anywhere.setter
+    def start_global_traj_anywhere(self, v):
+        self.engine.start_global_traj_anywhere = bool(v)
+
+
+class NemoV3(NemoV2):
+    """:3786-3956: V2 + instance-code regulariser + 3-D pose loss + code noise."""
+    VERSION = 3
+
+
+class NemoV4(NemoV3):
+    """:3959-4151: V3 with joints 0..24 and a stochastic camera phase."""
+    VERSION = 4
+
+    def opt_cam(self, cam_opt_steps=2000):
+        """:4060-4151: random batches, body pose detached, every optimiser steps."""
+        e, a = self.engine, self.args
+        if a.batch_size <= -1 and cam_opt_steps:
+            raise NotImplementedError()
+        for _ in range(cam_opt_steps):
+            vi, fi = self.draw_batch()
+            vi, fi = self._idx(vi), self._idx(fi)
+            N = vi.numel()
+            w = e._ws(N)
+            Mq = self._forward_losses(w, N, vi, fi, update=True, use_vposer=False)
+            self._backward(w, N, vi, fi, Mq, use_vposer=False, detach_pose=True)
+            self._adam_all(self.optimizers)
+        return []
+
+
+def collate_gt_2d(seqs, label_type='op', thr=30.0):
+    """:2908-2961 -> targets (V,T,25,3), bbox diagonal (V,T) + 1e-4."""
+    gt = []
+    for v in range(seqs.num_views):
+        s = seqs.sequences[v]
+        if label_type == 'op':
+            gt.append(np.array(s['pose_2d_op']))
+        elif label_type == 'gt':
+            gt.append(np.array(s['pose_2d_gt']))
+        elif label_type in ('vibe', 'pare', 'vs'):
+            gt.append(np.array(s[label_type + '_joints2d']))
+        elif label_type == 'intersection':
+            g1, g2 = np.array(s['pose_2d_op']), np.array(s['pose_2d_gt'])
+            mean = (g1 + g2)[..., :2] / 2
+            dist = np.sqrt(np.power(g1[..., :2] - g2[..., :2], 2).sum(-1, keepdims=True))
+            conf = (dist < thr).astype('float32') * g1[..., -1:]
+            gt.append(np.concatenate([mean, conf], -1))
+        else:
+            raise ValueError(label_type)
+    pts = torch.tensor(np.array(gt)).float()
+    d0 = pts[..., 0].max(-1)[0] - pts[..., 0].min(-1)[0]
+    d1 = pts[..., 1].max(-1)[0] - pts[..., 1].min(-1)[0]
+    return pts, torch.sqrt(d0 ** 2 + d1 ** 2) + 1e-4
+
+
+NEMO_VERSIONS = {1: NemoV1, 2: NemoV2, 3: NemoV3, 4: NemoV4}

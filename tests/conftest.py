@@ -19,9 +19,18 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + '.npz')))
 
 
+def _np(x):
+    if hasattr(x, 'detach'):
+        x = x.detach().cpu().numpy()
+    elif isinstance(x, (list, tuple)) and len(x) and hasattr(x[0], 'detach'):
+        x = [float(t) for t in x]
+    return np.asarray(x, dtype=np.float64)
+
+
 def rel_err(a, b):
     """max |a-b| / max(|b|) -- relative to the tensor's scale (fp32 parity metric)."""
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    a = _np(a)
+    b = _np(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
     denom = max(np.abs(b).max(), 1e-30)
     return float(np.abs(a - b).max() / denom)

@@ -1,0 +1,99 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol (no compute calls),
+the flat parameter layout mirrors the reference optimiser order, the product never imports the oracle."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'nemo_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(nemo_[A-Za-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nemo_cvpr2023_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/nemo_hip.h but not exported'
+    assert sorted(_lib.SIGNATURES) == declared, set(_lib.SIGNATURES) ^ set(declared)
+    assert lib.nemo_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """Entry points validate before touching the device: bad arguments return <0 on any box."""
+    from nemo_cvpr2023_amd import _lib
+    lib = _lib.load()
+    assert lib.nemo_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, None, 0, 0, 1.0, 0, 1, None) < 0
+    assert lib.nemo_rot6d_fwd(4, 0, None, 0, 1, None, None, None) < 0
+    assert lib.nemo_adam_step(99, None, None, None, None, None, 0.9, 0.999, 1e-8, None) < 0
+    assert lib.nemo_ctx_num_verts(None) == -1
+
+
+def test_param_layout_matches_reference_optimizer_order():
+    from nemo_cvpr2023_amd.engine import ParamLayout
+    lay = ParamLayout(V=3, K=20, D=16, C=5, h=48, din=21)
+    assert list(lay.groups) == ['cameras', 'motion', 'phase', 'instance']
+    assert lay.groups['motion'] == [
+        'learned_motion.net.net.0.weight', 'learned_motion.net.net.0.bias',
+        'learned_motion.net.net.2.weight', 'learned_motion.net.net.2.bias',
+        'learned_motion.net.net.4.weight', 'learned_motion.net.net.4.bias',
+        'learned_motion.rot_out.weight', 'learned_motion.rot_out.bias',
+        'learned_motion.linear_out.weight', 'learned_motion.linear_out.bias', 'phase_rbf.log_sigmas']
+    assert lay.groups['phase'][:4] == ['phase_networks.0.shifts', 'phase_networks.0.scales',
+                                       'phase_networks.1.shifts', 'phase_networks.1.scales']
+    # contiguous, non-overlapping
+    end = 0
+    for name, (off, shape) in lay.entries.items():
+        assert off == end, name
+        end = off + int(np.prod(shape))
+    assert end == lay.total
+    a, b = lay.span(lay.groups['motion'])
+    assert b - a == 48 * 21 + 48 + 2 * (48 * 48 + 48) + 144 * 48 + 144 + 3 * 48 + 3 + 16
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'nemo_cvpr2023_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), fn
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from nemo_cvpr2023_amd import synthetic as syn
+    from nemo_cvpr2023_amd._lib import NemoHipError
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    args = syn.published_args(h_dim=16, out_dir='')
+    with pytest.raises(NemoHipError):
+        NemoV2(args, syn.SyntheticSequences(2, 4), 'cuda:0', smpl_assets=syn.make_smpl_assets(64),
+               vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
+
+
+def test_vposer_folding_matches_unfolded():
+    """BatchNorm folding done on the host for the HIP path equals the oracle's eval-mode encoder."""
+    import torch
+    from nemo_cvpr2023_amd import synthetic as syn
+    from nemo_cvpr2023_amd.engine import fold_vposer
+    from oracle import ops
+    sd = syn.make_vposer_state()
+    f = fold_vposer(sd, 'cpu')
+    x = 0.3 * torch.randn(7, 63, generator=torch.Generator().manual_seed(0))
+    lin = torch.nn.functional.linear
+    h = torch.nn.functional.leaky_relu(lin(x, f['e2w'], f['e2b']))
+    h = lin(lin(h, f['e6w'], f['e6b']), f['e7w'], f['e7b'])
+    ml = lin(h, f['emw'], f['emb'])
+    mean, scale = ops.VPoserOracle(sd).encode(x)
+    assert float((ml[:, :32] - mean).abs().max()) < 1e-5
+    assert float((torch.nn.functional.softplus(ml[:, 32:]) - scale).abs().max()) < 1e-5

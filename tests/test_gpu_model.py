@@ -1,0 +1,167 @@
+"""GPU parity of the drop-in NemoV* classes: the trajectories recorded from the real reference
+(tests/golden/model_*.npz) replayed through the HIP engine, plus full-size checks against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from nemo_cvpr2023_amd import synthetic as syn
+from test_oracle_golden import CASES, replay
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def build_hip_case(name, num_verts=128, tmp_path=None):
+    from nemo_cvpr2023_amd.neural_motion_model import NEMO_VERSIONS
+    version, over, _ = CASES.get(name, (2, {}, 0))
+    g = load_golden('model_' + name)
+    V, Tn, B = int(g['meta__V']), int(g['meta__T']), int(g['meta__B'])
+    base = syn.published_args if version >= 2 else syn.default_v1_args
+    o = dict(h_dim=48, monotonic_network_n_nodes=20, batch_size=B, out_dir=str(tmp_path) if tmp_path else '')
+    if version >= 2:
+        o['phase_rbf_dim'] = 16
+    o.update(over)
+    args = base(**o)
+    seqs = syn.SyntheticSequences(V, Tn, seed=1234)
+    torch.manual_seed(0)
+    m = NEMO_VERSIONS[version](args, seqs, DEV, smpl_assets=syn.make_smpl_assets(num_verts, seed=1),
+                               vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
+    state = {k[len('init__'):].replace('__', '.'): torch.tensor(v) for k, v in g.items()
+             if k.startswith('init__')}
+    missing, unexpected = m.load_state_dict(state, strict=False)
+    assert not unexpected, unexpected
+    assert not missing, missing
+    return m, g
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_reference_trajectory(name, tmp_path):
+    m, g = build_hip_case(name, tmp_path=tmp_path)
+    replay(m, g, name, n_cam_default=3, tol=1e-4, state_tol=5e-3)
+
+
+def test_reference_trajectory_full_mesh(tmp_path):
+    m, g = build_hip_case('v2_6890', num_verts=6890, tmp_path=tmp_path)
+    replay(m, g, 'v2_6890', tol=1e-4, state_tol=2e-2)
+
+
+def test_step0_gradients_vs_reference(tmp_path):
+    m, g = build_hip_case('v2_small', tmp_path=tmp_path)
+    torch.manual_seed(2)
+    V, Tn, B = 4, 7, 8
+    for _ in range(2):
+        torch.randint(0, V, size=(B,)), torch.randint(0, Tn, size=(B,))
+    m.warmup(3)
+    m.opt_cam(3)
+    m.step(torch.as_tensor(g['batches_view'][0]), torch.as_tensor(g['batches_frame'][0]))
+    named = dict(m.named_parameters())
+    checked = 0
+    for k, v in g.items():
+        if k.startswith('step0grad__'):
+            name = k[len('step0grad__'):].replace('__', '.')
+            if name == 'learned_betas':
+                continue           # in no optimiser; its gradient is deliberately not computed
+            if np.abs(v).max() < 1e-12:
+                assert float(named[name].grad.abs().max()) < 1e-9, name
+            else:
+                assert rel_err(named[name].grad, v) < 1e-3, name
+            checked += 1
+    assert checked >= 20
+
+
+def test_published_config_step_vs_oracle(tmp_path):
+    """One real-size step (NemoV2, h=1000, RBF 100, 6890 vertices, minibatch 512 drawn from 8x300)
+    against the CPU oracle on the same initial state: losses, 3-D joints, 2-D points."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    from oracle.model import OracleNemo
+    V, T, B = 8, 300, 512
+    args = syn.published_args(batch_size=B, out_dir=str(tmp_path))
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    torch.manual_seed(0)
+    m = NemoV2(args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+    # leave the near-identity regime so that every term is exercised
+    with torch.no_grad():
+        m.learned_motion.rot_out.weight.mul_(2e3)
+    state = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    o = OracleNemo(2, args, seqs, assets, vps, gmm, state=state)
+    torch.manual_seed(2)
+    vi, fi = torch.randint(0, V, (B,)), torch.randint(0, T, (B,))
+    ld_o, info_o = o.step(vi, fi, update=True)
+    ld_h, info_h = m.step(vi, fi, update=True)
+    for k in ('kp_loss', 'gmm_loss', 'vp_recon_loss', 'vp_kl_loss', 'total_loss'):
+        assert rel_err(ld_h[k], ld_o[k]) < 1e-4, (k, ld_h[k], ld_o[k])
+    assert rel_err(info_h['j'], info_o['j']) < 1e-4
+    assert rel_err(info_h['points2d'], info_o['points2d']) < 1e-4
+    assert rel_err(info_h['loss_all'], info_o['loss_all']) < 1e-4
+    # gradients of the big shared tensors (before Adam they are in .grad on both sides)
+    named = dict(m.named_parameters())
+    for k in ('learned_motion.net.net.2.weight', 'learned_motion.rot_out.weight', 'learned_cameras',
+              'phase_rbf.log_sigmas', 'learned_instance_code', 'phase_networks.3.shifts'):
+        assert rel_err(named[k].grad, o.P[k].grad) < 2e-3, k
+    # second step: the post-update state must produce matching losses too
+    vi, fi = torch.randint(0, V, (B,)), torch.randint(0, T, (B,))
+    ld_o, _ = o.step(vi, fi, update=False)
+    ld_h, _ = m.step(vi, fi, update=False)
+    for k in ('kp_loss', 'total_loss'):
+        assert rel_err(ld_h[k], ld_o[k]) < 1e-4, k
+
+
+def test_full_batch_properties_at_benchmark_size(tmp_path):
+    """Size-independent properties at the BASELINE configuration (8 x 300 full batch, N = 2400):
+    (i) the full-batch step equals the same indices passed explicitly, (ii) the per-view
+    decomposition of the keypoint loss, (iii) losses are finite and decrease over a few steps,
+    (iv) get_preds shapes."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    V, T = 8, 300
+    args = syn.published_args(batch_size=512, out_dir=str(tmp_path))
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    torch.manual_seed(0)
+    m = NemoV2(args, seqs, DEV, smpl_assets=syn.make_smpl_assets(6890, seed=1),
+               vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
+    ld_full, info = m.step(None, None, update=False, full_batch=True)
+    vi, fi = m.full_indices()
+    ld_idx, _ = m.step(vi.cpu(), fi.cpu(), update=False)
+    for k in ld_full:
+        assert ld_full[k] == ld_idx[k], k
+    la, gt = info['loss_all'], info['points2d_gt']
+    per_view = torch.stack([(la[vi == v] * gt[vi == v][..., -1:]).mean() for v in range(V)]).mean()
+    assert rel_err(ld_full['kp_loss'], per_view) < 1e-5
+    first = float(ld_full['total_loss'])
+    for _ in range(5):
+        ld, _ = m.step(None, None, update=True, full_batch=True)
+        assert np.isfinite(ld['total_loss'])
+    assert float(ld['total_loss']) < first
+    p = m.get_preds()
+    assert p['v'].shape == (V, T, 6890, 3) and p['j'].shape == (V, T, 25, 3) and p['poses'].shape == (V, T, 69)
+    p2 = m.learned_camera_projection(p['j'].reshape(V * T, 25, 3), vi)
+    assert rel_err(p2, info['points2d']) > 0      # parameters moved
+    assert torch.isfinite(p2).all()
+
+
+def test_checkpoint_roundtrip_and_api(tmp_path):
+    m, g = build_hip_case('v2_small', tmp_path=tmp_path)
+    torch.manual_seed(2)
+    vi, fi = m.draw_batch()
+    m.step(vi, fi)
+    m.step(vi, fi)
+    path = str(tmp_path / 'sd.pt')
+    m.save(path)
+    ld_a, _ = m.step(vi, fi)
+    m2, _ = build_hip_case('v2_small', tmp_path=tmp_path)
+    m2.load(path)
+    ld_b, _ = m2.step(vi, fi)
+    for k in ld_a:
+        assert ld_a[k] == ld_b[k], k           # resumed run is bit-identical (moments + step counts)
+    sd = torch.load(path, weights_only=False)
+    assert set(sd) == {'model_sd', 'opt_sd'} and len(sd['opt_sd']) == 4
+    assert 'learned_motion.net.net.0.weight' in sd['model_sd'] and 'phase_rbf.centres' in sd['model_sd']
+    st = sd['opt_sd'][1]['state']
+    assert float(st[0]['step']) == 2.0 and st[0]['exp_avg'].shape == (48, 21)
+    # phase network modules are callable (script plots them, :317-328)
+    y = m.phase_networks[0](torch.linspace(0, 1, 50).unsqueeze(1))
+    assert y.shape == (50, 1) and float(y[0]) == 0.0 and abs(float(y[-1]) - 1.0) < 1e-4
+    assert (y[1:] >= y[:-1] - 1e-6).all()
+    lrs = [o.param_groups[0]['lr'] for o in m.optimizers]
+    assert lrs == [0.1, 1e-4, 1e-4, 1e-3]

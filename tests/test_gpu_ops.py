@@ -1,0 +1,488 @@
+"""GPU parity tests: every HIP kernel (through the C ABI) against the CPU oracle on seeded inputs.
+Tolerances are relative to the tensor's max magnitude (fp32; north-star gate is 1e-4)."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from nemo_cvpr2023_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope='module')
+def L():
+    from nemo_cvpr2023_amd import _lib
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return _lib.load()
+
+
+def _ops():
+    import hipops
+    return hipops
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(70, 33, 45), (257, 130, 207), (300, 1000, 1000), (1, 3, 7), (129, 64, 16)])
+def test_gemm_layouts(L, ta, tb, M, N, K):
+    H = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = (A.T if ta else A).double() @ (B.T if tb else B).double()
+    C = H.gemm(H.dev(A), H.dev(B), ta, tb)
+    assert rel_err(C, ref) < TOL
+
+
+def test_gemm_big_tile_path(L):
+    H = _ops()
+    g = torch.Generator().manual_seed(5)
+    A, B = torch.randn(2600, 207, generator=g), torch.randn(207, 3000, generator=g)
+    bias = torch.randn(3000, generator=g)
+    C = H.gemm(H.dev(A), H.dev(B), bias=H.dev(bias))       # >= 512 tiles of 128x128
+    assert rel_err(C, A.double() @ B.double() + bias.double()) < TOL
+
+
+def test_gemm_epilogues(L):
+    H = _ops()
+    g = torch.Generator().manual_seed(9)
+    A, B = torch.randn(150, 90, generator=g), torch.randn(70, 90, generator=g)
+    bias, mask = torch.randn(70, generator=g), torch.randn(150, 70, generator=g)
+    pre = A.double() @ B.double().T + bias.double()
+    dA, dB, db, dm = H.dev(A), H.dev(B), H.dev(bias), H.dev(mask)
+    assert rel_err(H.gemm(dA, dB, 0, 1, bias=db, act=1), torch.relu(pre)) < TOL
+    assert rel_err(H.gemm(dA, dB, 0, 1, bias=db, act=2), torch.nn.functional.leaky_relu(pre, 0.01)) < TOL
+    assert rel_err(H.gemm(dA, dB, 0, 1, mask=dm, mask_mode=1), (A.double() @ B.double().T) * (mask > 0)) < TOL
+    lm = torch.where(mask > 0, torch.ones_like(mask), torch.full_like(mask, 0.01)).double()
+    assert rel_err(H.gemm(dA, dB, 0, 1, mask=dm, mask_mode=2), (A.double() @ B.double().T) * lm) < TOL
+    C0 = torch.randn(150, 70, generator=g)
+    C = H.dev(C0).clone()
+    H.gemm(dA, dB, 0, 1, alpha=0.5, out_mode=1, C=C)
+    assert rel_err(C, C0.double() + 0.5 * (A.double() @ B.double().T)) < TOL
+    C = H.dev(C0).clone()
+    H.gemm(dA, dB, 0, 1, out_mode=2, split_k=4, bias=db, C=C)
+    assert rel_err(C, C0.double() + pre) < TOL
+    # strided views (ld > cols), as the engine uses for AA[:, 3:66]
+    big = H.dev(torch.randn(150, 200, generator=g))
+    sub = big[:, 5:95]
+    assert rel_err(H.gemm(sub, dB, 0, 1), sub.cpu().double() @ B.double().T) < TOL
+
+
+def test_gemm_rejects_bad_args(L):
+    x = torch.zeros(4, 4, device='cuda')
+    rc = L.nemo_gemm_f32(0, 0, 4, 4, 4, x.data_ptr(), 4, x.data_ptr(), 4, x.data_ptr(), 4, None, 1, None, 0, 0,
+                         1.0, 0, 2, None)
+    assert rc < 0      # split-K with a non-linear epilogue
+    assert L.nemo_gemm_f32(0, 0, 0, 4, 4, None, 4, None, 4, x.data_ptr(), 4, None, 0, None, 0, 0, 1.0, 0, 1,
+                           None) == 0   # empty problem is a no-op
+
+
+def test_colsum(L):
+    H = _ops()
+    X = torch.randn(1000, 77, generator=torch.Generator().manual_seed(1))
+    out = torch.zeros(77, device='cuda')
+    assert L.nemo_colsum_f32(H.dev(X).data_ptr(), 1000, 77, 77, out.data_ptr(), H.st()) == 0
+    assert rel_err(out, X.double().sum(0)) < TOL
+
+
+# ------------------------------------------------------------------------------------------ rotations
+def test_rot6d_fwd_bwd_vs_oracle_and_golden(L):
+    from oracle import ops
+    H = _ops()
+    g = load_golden('fn_rot6d_to_rotmat')
+    x = torch.tensor(g['x'])              # (64, 6) incl. near-identity rows
+    rows, J = 8, 8
+    x144 = H.dev(x.reshape(rows, J * 6))
+    R = torch.zeros(rows, J, 9, device='cuda')
+    aa = torch.zeros(rows, J * 3, device='cuda')
+    assert L.nemo_rot6d_fwd(rows, J, x144.data_ptr(), J * 6, 1, R.data_ptr(), aa.data_ptr(), H.st()) == 0
+    assert rel_err(R.reshape(-1, 3, 3), g['out']) < TOL
+    xo = x.clone().requires_grad_(True)
+    Ro = ops.rot6d_to_rotmat(xo)
+    aao = ops.rotmat_to_aa(Ro)
+    assert rel_err(aa.reshape(-1, 3), aao.detach()) < 1e-4
+    gen = torch.Generator().manual_seed(3)
+    ctR, cta = torch.randn(64, 3, 3, generator=gen), torch.randn(64, 3, generator=gen)
+    ((Ro * ctR).sum() + (aao * cta).sum()).backward()
+    dx = torch.zeros(rows, J * 6, device='cuda')
+    assert L.nemo_rot6d_bwd(rows, J, x144.data_ptr(), J * 6, 1, H.dev(ctR).data_ptr(), H.dev(cta).data_ptr(),
+                            dx.data_ptr(), J * 6, H.st()) == 0
+    assert rel_err(dx.reshape(-1, 6), xo.grad) < 1e-4
+    # dR only (golden gradient from the real reference)
+    assert L.nemo_rot6d_bwd(rows, J, x144.data_ptr(), J * 6, 1, H.dev(g['ct']).data_ptr(), None,
+                            dx.data_ptr(), J * 6, H.st()) == 0
+    assert rel_err(dx.reshape(-1, 6), g['grad_x']) < 1e-4
+
+
+def test_rotmat_to_aa_all_branches(L):
+    H = _ops()
+    g = load_golden('fn_rotmat_to_aa')
+    R = H.dev(g['R'])
+    M = R.shape[0]
+    aa = torch.zeros(M, 3, device='cuda')
+    assert L.nemo_rotmat_to_aa(M, R.data_ptr(), 1, aa.data_ptr(), H.st()) == 0
+    assert rel_err(aa, g['out']) < 1e-4
+    eye = torch.eye(3, device='cuda').reshape(1, 9).contiguous()
+    out = torch.ones(1, 3, device='cuda')
+    assert L.nemo_rotmat_to_aa(1, eye.data_ptr(), 1, out.data_ptr(), H.st()) == 0
+    assert np.array_equal(out.cpu().numpy(), g['out_identity'])
+    g2 = load_golden('fn_matrot2aa')
+    assert L.nemo_rotmat_to_aa(M, R.data_ptr(), 0, aa.data_ptr(), H.st()) == 0
+    assert rel_err(aa, g2['out']) < 1e-4
+
+
+def test_rotmat_to_aa_backward_all_branches(L):
+    """Adjoint of the 4-branch quaternion path: feed R through an (invertible) rot6d so that the
+    C entry point (rot6d_bwd with daa only) exercises it; compare with the reference gradient chain."""
+    from oracle import ops
+    H = _ops()
+    g = load_golden('fn_rotmat_to_aa')
+    R = torch.tensor(g['R'])
+    x = torch.stack([R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 0], R[:, 2, 1]], 1)
+    M = x.shape[0]
+    xo = x.clone().requires_grad_(True)
+    aao = ops.rotmat_to_aa(ops.rot6d_to_rotmat(xo))
+    ct = torch.tensor(g['ct'])
+    (aao * ct).sum().backward()
+    dx = torch.zeros(M, 6, device='cuda')
+    assert L.nemo_rot6d_bwd(M, 1, H.dev(x).data_ptr(), 6, 1, None, H.dev(ct).data_ptr(), dx.data_ptr(), 6,
+                            H.st()) == 0
+    ref = xo.grad
+    ok = torch.isfinite(ref).all(1)
+    assert ok.sum() > 100
+    assert rel_err(dx.cpu()[ok], ref[ok]) < 2e-4
+
+
+def test_rodrigues(L):
+    H = _ops()
+    g = load_golden('fn_batch_rodrigues')
+    th = H.dev(g['theta'])
+    M = th.shape[0]
+    R = torch.zeros(M, 9, device='cuda')
+    assert L.nemo_rodrigues_fwd(M, th.data_ptr(), 0, R.data_ptr(), H.st()) == 0
+    assert rel_err(R.reshape(-1, 3, 3), g['out']) < TOL
+    d = torch.zeros(M, 3, device='cuda')
+    assert L.nemo_rodrigues_bwd(M, th.data_ptr(), H.dev(g['ct']).data_ptr(), d.data_ptr(), H.st()) == 0
+    assert rel_err(d, g['grad_theta']) < 1e-4
+    g = load_golden('fn_lbs_rodrigues')
+    th = H.dev(g['theta'])
+    R = torch.zeros(th.shape[0], 9, device='cuda')
+    assert L.nemo_rodrigues_fwd(th.shape[0], th.data_ptr(), 1, R.data_ptr(), H.st()) == 0
+    assert rel_err(R.reshape(-1, 3, 3), g['out']) < TOL
+
+
+# ------------------------------------------------------------------------------------------ phase / RBF
+@pytest.mark.parametrize('kern', ['quadratic', 'linear', 'gaussian', 'inverse_quadratic', 'multiquadric',
+                                  'inverse_multiquadric', 'spline', 'poisson_one', 'poisson_two', 'matern32',
+                                  'matern52'])
+def test_phase_embed_vs_oracle(L, kern):
+    from oracle import ops
+    from nemo_cvpr2023_amd.engine import RBF_KERNELS
+    H = _ops()
+    gen = torch.Generator().manual_seed(11)
+    N, V, T, K, D, C = 37, 3, 9, 20, 16, 5
+    vi = torch.randint(0, V, (N,), generator=gen)
+    vi[vi == 1] = 0                                  # view 1 absent -> zero gradient rows
+    fi = torch.randint(0, T, (N,), generator=gen)
+    sh = (torch.linspace(0, 1, K).repeat(V, 1) + 0.05 * torch.randn(V, K, generator=gen))
+    sc = 15 + 2 * torch.randn(V, K, generator=gen)
+    sh[0, 3], sc[2, 5] = -0.1, -1.0                  # exercise the relu clamps
+    ls = 0.3 * torch.randn(D, generator=gen)
+    codes = torch.randn(V, C, generator=gen)
+    ct = torch.randn(N + 1, D + C, generator=gen)
+    # oracle
+    sho, sco, lso, co = (t.clone().requires_grad_(True) for t in (sh, sc, ls, codes))
+    raw = torch.linspace(0, 1, T)[fi].unsqueeze(1)
+    ph = ops.monotonic_forward(sho[vi], sco[vi], raw)
+    cen = torch.linspace(0, 1, D).unsqueeze(1)
+    X = torch.cat([ops.rbf_forward(lso, cen, ph, kern), co[vi]], 1)
+    X0 = torch.cat([ops.rbf_forward(lso, cen, torch.zeros(1, 1), kern), torch.zeros(1, C)], 1)
+    Xo = torch.cat([X, X0], 0)
+    (Xo * ct).sum().backward()
+    # HIP: the V networks are stored interleaved [sh_0 | sc_0 | sh_1 | ...]
+    pn = H.dev(torch.stack([sh, sc], 1).reshape(-1))
+    Xd = torch.zeros(N + 1, D + C, device='cuda')
+    phd = torch.zeros(N, device='cuda')
+    dvi, dfi, dls, dco = H.dev(vi, torch.long), H.dev(fi, torch.long), H.dev(ls), H.dev(codes)
+    kid = RBF_KERNELS[kern]
+    assert L.nemo_phase_embed_fwd(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
+                                  pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), dco.data_ptr(), None, kid,
+                                  Xd.data_ptr(), D + C, phd.data_ptr(), H.st()) == 0
+    assert rel_err(phd, ph.detach().squeeze(1)) < 1e-5
+    assert rel_err(Xd, Xo.detach()) < 1e-5
+    gpn = torch.zeros_like(pn)
+    gls, gco = torch.zeros(D, device='cuda'), torch.zeros(V, C, device='cuda')
+    assert L.nemo_phase_embed_bwd(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
+                                  pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), kid, phd.data_ptr(),
+                                  H.dev(ct).data_ptr(), D + C, gpn.data_ptr(), gpn.data_ptr() + 4 * K,
+                                  gls.data_ptr(), gco.data_ptr(), H.st()) == 0
+    gpn = gpn.reshape(V, 2, K)
+    assert rel_err(gls, lso.grad) < 1e-4
+    assert rel_err(gco, co.grad) < 1e-5
+    assert rel_err(gpn[:, 0], sho.grad) < 1e-4
+    assert rel_err(gpn[:, 1], sco.grad) < 1e-4
+    assert float(gpn[1].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------ SMPL pieces
+def _ctx(num_verts, version=2):
+    from nemo_cvpr2023_amd.engine import SmplContext
+    assets = syn.make_smpl_assets(num_verts, seed=1)
+    jm = [int(x) for x in assets['joint_map']]
+    idx = list(range(25)) if version == 4 else [38] + list(range(1, 25))
+    return assets, SmplContext(assets, [jm[i] for i in idx], 'cuda:0'), idx
+
+
+def _rand_rot(gen, n, small=False):
+    from oracle import ops
+    th = torch.randn(n, 3, generator=gen) * (0.3 if small else 1.5)
+    return ops.batch_rodrigues(th)
+
+
+@pytest.mark.parametrize('num_verts,version', [(128, 2), (128, 4), (6890, 2)])
+def test_keypoint_path_forward_backward(L, num_verts, version):
+    """FK -> pre-contracted mesh joints -> projection -> robust loss, and the whole adjoint chain,
+    against the oracle's unfused lbs + autograd."""
+    from oracle import ops
+    H = _ops()
+    assets, ctx, idx = _ctx(num_verts, version)
+    gen = torch.Generator().manual_seed(21)
+    N, V, T = 13, 3, 6
+    R = _rand_rot(gen, N * 24, small=True).reshape(N, 24, 3, 3)
+    TR = 0.2 * torch.randn(N + 1, 3, generator=gen)
+    cams = 1e-2 * torch.randn(V, 9, generator=gen)
+    cams[:, 3] += 1; cams[:, 6] += 1; cams[:, 2] += 9.26
+    vi = torch.randint(0, V, (N,), generator=gen); vi[vi == 1] = 2
+    fi = torch.randint(0, T, (N,), generator=gen)
+    seqs = syn.SyntheticSequences(V, T, seed=5)
+    tgt = torch.tensor(np.array([np.array(s['pose_2d_op']) for s in seqs.sequences]))
+    # oracle
+    Ro, TRo, co = (t.clone().requires_grad_(True) for t in (R, TR, cams))
+    smpl = ops.SMPLOracle(assets)
+    _, j49, _ = smpl.forward(torch.zeros(1, 10), Ro)
+    j = j49[:, idx] + (TRo[:N] - TRo[N:]).unsqueeze(1)
+    Rc = ops.rot6d_to_rotmat(co[vi][:, 3:])
+    cen = torch.tensor([[540.0, 960.0]]).expand(N, -1)
+    p2 = ops.perspective_projection(j, Rc, co[vi][:, :3], 5000.0, cen)
+    gt = tgt[vi, fi]
+    la = ops.keypoint_loss(p2, gt[..., :2], gt[..., 2:], None, 'mse_robust')
+    kp = ops.per_view_mean_loss(la, gt[..., -1:], vi)
+    kp.backward()
+    # HIP
+    dR, dTR, dc = H.dev(R.reshape(N, 24, 9)), H.dev(TR), H.dev(cams)
+    dvi, dfi, dt = H.dev(vi, torch.long), H.dev(fi, torch.long), H.dev(tgt)
+    Z = lambda *s: torch.zeros(*s, device='cuda')
+    A, Jp, PF = Z(N, 24, 12), Z(N, 24, 3), Z(N, 207)
+    assert L.nemo_fk_fwd(ctx.handle, N, dR.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), H.st()) == 0
+    nq72 = ctx.nq * 72
+    Mq = Z(N, nq72)
+    assert L.nemo_gemm_f32(0, 0, N, nq72, 207, PF.data_ptr(), 207, ctx.C1, nq72, Mq.data_ptr(), nq72, ctx.c0, 0,
+                           None, 0, 0, 1.0, 0, 1, H.st()) == 0
+    j3d, p2d, lall, vacc, norm, scal = Z(N, 25, 3), Z(N, 25, 2), Z(N, 25, 2), Z(V, 2), Z(1), Z(8)
+    args = (ctx.handle, N, V, T, A.data_ptr(), Jp.data_ptr(), Mq.data_ptr(), nq72, dTR.data_ptr(), 3, 1,
+            dvi.data_ptr(), dfi.data_ptr(), dc.data_ptr(), dt.data_ptr(), None, 5000.0, 540.0, 960.0, 0, 0)
+    assert L.nemo_kp_fwd(*args, j3d.data_ptr(), p2d.data_ptr(), lall.data_ptr(), vacc.data_ptr(), H.st()) == 0
+    assert L.nemo_kp_finalize(V, 25, 2, 0, vacc.data_ptr(), scal.data_ptr(), norm.data_ptr(), H.st()) == 0
+    assert rel_err(j3d, j.detach()) < 1e-5
+    assert rel_err(p2d, p2.detach()) < 1e-5
+    assert rel_err(lall, la.detach()) < 1e-4
+    assert rel_err(scal[0], kp.detach()) < 1e-5
+    assert float(norm[0]) == 2.0
+    dA, dJp, dMq, dTRg, dcg, dPF, dRg = (Z(N, 24, 12), Z(N, 24, 3), Z(N, nq72), Z(N + 1, 3), Z(V, 9), Z(N, 207),
+                                         Z(N, 24, 9))
+    assert L.nemo_kp_bwd(*args, vacc.data_ptr(), norm.data_ptr(), 1.0, dA.data_ptr(), dJp.data_ptr(),
+                         dMq.data_ptr(), dTRg.data_ptr(), 3, dcg.data_ptr(), H.st()) == 0
+    assert L.nemo_gemm_f32(0, 1, N, 207, nq72, dMq.data_ptr(), nq72, ctx.C1, nq72, dPF.data_ptr(), 207, None, 0,
+                           None, 0, 0, 1.0, 0, 1, H.st()) == 0
+    assert L.nemo_fk_bwd(ctx.handle, N, dR.data_ptr(), A.data_ptr(), dA.data_ptr(), dJp.data_ptr(),
+                         dPF.data_ptr(), dRg.data_ptr(), H.st()) == 0
+    assert L.nemo_scale_neg_rowsum(N, 3, dTRg.data_ptr(), 3, dTRg.data_ptr() + 4 * 3 * N, H.st()) == 0
+    assert rel_err(dRg.reshape(N, 24, 3, 3), Ro.grad) < 1e-4
+    assert rel_err(dTRg, TRo.grad) < 1e-4
+    assert rel_err(dcg, co.grad) < 1e-4
+    assert float(dcg[1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('loss_type,lid', [('mse', 1), ('rmse', 2), ('rmse_robust', 3),
+                                           ('mse_robust_resized', 4), ('rmse_resized', 5)])
+def test_keypoint_loss_types_and_camera_mode(L, loss_type, lid):
+    from oracle import ops
+    H = _ops()
+    assets, ctx, idx = _ctx(128, 2)
+    gen = torch.Generator().manual_seed(31 + lid)
+    N, V, T = 9, 2, 5
+    R = _rand_rot(gen, N * 24, small=True).reshape(N, 24, 3, 3)
+    cams = 1e-2 * torch.randn(V, 9, generator=gen)
+    cams[:, 3] += 1; cams[:, 6] += 1; cams[:, 2] += 9.26
+    vi, fi = torch.randint(0, V, (N,), generator=gen), torch.randint(0, T, (N,), generator=gen)
+    seqs = syn.SyntheticSequences(V, T, seed=6)
+    tgt = torch.tensor(np.array([np.array(s['pose_2d_op']) for s in seqs.sequences]))
+    size = 200 + 500 * torch.rand(V, T, generator=gen)
+    co = cams.clone().requires_grad_(True)
+    smpl = ops.SMPLOracle(assets)
+    _, j49, _ = smpl.forward(torch.zeros(1, 10), R)
+    p2 = ops.perspective_projection(j49[:, idx], ops.rot6d_to_rotmat(co[vi][:, 3:]), co[vi][:, :3], 5000.0,
+                                    torch.tensor([[540.0, 960.0]]).expand(N, -1))
+    gt = tgt[vi, fi]
+    la = ops.keypoint_loss(p2, gt[..., :2], gt[..., 2:], size[vi, fi], loss_type)
+    mean = la.mean()                      # camera_fitting_loss (mean_mode 1)
+    mean.backward()
+    Z = lambda *s: torch.zeros(*s, device='cuda')
+    dR, dc = H.dev(R.reshape(N, 24, 9)), H.dev(cams)
+    dvi, dfi, dt, dsz = H.dev(vi, torch.long), H.dev(fi, torch.long), H.dev(tgt), H.dev(size)
+    A, Jp, PF = Z(N, 24, 12), Z(N, 24, 3), Z(N, 207)
+    L.nemo_fk_fwd(ctx.handle, N, dR.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), H.st())
+    nq72 = ctx.nq * 72
+    Mq = Z(N, nq72)
+    L.nemo_gemm_f32(0, 0, N, nq72, 207, PF.data_ptr(), 207, ctx.C1, nq72, Mq.data_ptr(), nq72, ctx.c0, 0, None,
+                    0, 0, 1.0, 0, 1, H.st())
+    W = la.shape[-1]
+    lall, vacc, norm, scal, dcg = Z(N, 25, W), Z(V, 2), Z(1), Z(8), Z(V, 9)
+    args = (ctx.handle, N, V, T, A.data_ptr(), Jp.data_ptr(), Mq.data_ptr(), nq72, None, 3, 0, dvi.data_ptr(),
+            dfi.data_ptr(), dc.data_ptr(), dt.data_ptr(), dsz.data_ptr(), 5000.0, 540.0, 960.0, lid, 1)
+    assert L.nemo_kp_fwd(*args, None, None, lall.data_ptr(), vacc.data_ptr(), H.st()) == 0
+    assert L.nemo_kp_finalize(V, 25, W, 1, vacc.data_ptr(), scal.data_ptr(), norm.data_ptr(), H.st()) == 0
+    assert rel_err(lall, la.detach()) < 1e-4
+    assert rel_err(scal[0], mean.detach()) < 1e-5
+    assert L.nemo_kp_bwd(*args, vacc.data_ptr(), norm.data_ptr(), 1.0, None, None, None, None, 3,
+                         dcg.data_ptr(), H.st()) == 0
+    assert rel_err(dcg, co.grad) < 1e-4
+
+
+@pytest.mark.parametrize('num_verts', [128, 6890])
+def test_vertices_and_v2v(L, num_verts):
+    """Full-mesh path: pose-blend GEMM + skinning; the fused L1 + gradient kernel against autograd."""
+    from oracle import ops
+    H = _ops()
+    assets, ctx, idx = _ctx(num_verts, 2)
+    gen = torch.Generator().manual_seed(41)
+    N = 6
+    NV3 = 3 * num_verts
+    R2 = _rand_rot(gen, 2 * N * 24, small=True).reshape(2 * N, 24, 3, 3)
+    R2[N:, 0] = R2[:N, 0]
+    Ro = R2[:N].clone().requires_grad_(True)
+    smpl = ops.SMPLOracle(assets)
+    vo, _, _ = smpl.forward(torch.zeros(1, 10), Ro)
+    vr, _, _ = smpl.forward(torch.zeros(1, 10), R2[N:])
+    l1 = (vr.detach() - vo).abs().sum()
+    l1.backward()
+    Z = lambda *s: torch.zeros(*s, device='cuda')
+    dR2 = H.dev(R2.reshape(2 * N, 24, 9))
+    A, Jp, PF, VP = Z(2 * N, 24, 12), Z(2 * N, 24, 3), Z(2 * N, 207), Z(2 * N, NV3)
+    assert L.nemo_fk_fwd(ctx.handle, 2 * N, dR2.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), H.st()) == 0
+    assert L.nemo_gemm_f32(0, 0, 2 * N, NV3, 207, PF.data_ptr(), 207, ctx.posedirs, NV3, VP.data_ptr(), NV3,
+                           ctx.v_shaped, 0, None, 0, 0, 1.0, 0, 1, H.st()) == 0
+    verts = Z(2 * N, num_verts, 3)
+    tr = H.dev(0.1 * torch.randn(2 * N, 3, generator=gen))
+    assert L.nemo_skin_vertices(ctx.handle, 2 * N, VP.data_ptr(), NV3, A.data_ptr(), tr.data_ptr(), 3,
+                                verts.data_ptr(), H.st()) == 0
+    ref = torch.cat([vo.detach(), vr], 0) + tr.cpu().unsqueeze(1)
+    assert rel_err(verts, ref) < 1e-5
+    loss, dVP, dA, dPF, dRg = Z(1), Z(N, NV3), Z(N, 24, 12), Z(N, 207), Z(N, 24, 9)
+    assert L.nemo_v2v_skin_l1(ctx.handle, N, VP.data_ptr(), NV3, A.data_ptr(), loss.data_ptr(), dVP.data_ptr(),
+                              NV3, dA.data_ptr(), H.st()) == 0
+    assert rel_err(loss[0], l1.detach()) < 1e-5
+    assert L.nemo_gemm_f32(0, 1, N, 207, NV3, dVP.data_ptr(), NV3, ctx.posedirs, NV3, dPF.data_ptr(), 207, None,
+                           0, None, 0, 0, 1.0, 2, 8, H.st()) == 0
+    assert L.nemo_fk_bwd(ctx.handle, N, dR2.data_ptr(), A.data_ptr(), dA.data_ptr(), None, dPF.data_ptr(),
+                         dRg.data_ptr(), H.st()) == 0
+    # |.| is non-smooth: a vertex coordinate within rounding of a tie flips a sign; compare in aggregate
+    assert rel_err(dRg.reshape(N, 24, 3, 3), Ro.grad) < 2e-3
+
+
+def test_v2v_prep(L):
+    from oracle import ops
+    H = _ops()
+    gen = torch.Generator().manual_seed(43)
+    N = 5
+    R = _rand_rot(gen, N * 24).reshape(N, 24, 9)
+    aa, aad = 0.5 * torch.randn(N, 72, generator=gen), 0.5 * torch.randn(N, 63, generator=gen)
+    R2 = torch.zeros(2 * N, 24, 9, device='cuda')
+    assert L.nemo_v2v_prep_fwd(N, H.dev(R).data_ptr(), H.dev(aa).data_ptr(), H.dev(aad).data_ptr(),
+                               R2.data_ptr(), H.st()) == 0
+    aao = aa.clone().requires_grad_(True)
+    Ro = ops.batch_rodrigues(aao[:, 3:].reshape(-1, 3)).reshape(N, 23, 9)
+    Rr = ops.batch_rodrigues(torch.cat([aad, aa[:, 66:]], 1).reshape(-1, 3)).reshape(N, 23, 9)
+    assert rel_err(R2[:N, 1:], Ro.detach()) < TOL and rel_err(R2[N:, 1:], Rr) < TOL
+    assert rel_err(R2[:N, 0], R[:, 0]) == 0 and rel_err(R2[N:, 0], R[:, 0]) == 0
+    ct = torch.randn(N, 24, 9, generator=gen)
+    (Ro * ct[:, 1:]).sum().backward()
+    daa, dRm = torch.zeros(N, 72, device='cuda'), torch.zeros(N, 24, 9, device='cuda')
+    assert L.nemo_v2v_prep_bwd(N, H.dev(aa).data_ptr(), H.dev(ct).data_ptr(), 0.5, daa.data_ptr(),
+                               dRm.data_ptr(), H.st()) == 0
+    assert rel_err(daa, 0.5 * aao.grad) < 1e-4
+    assert rel_err(dRm[:, 0], 0.5 * ct[:, 0]) < TOL and float(dRm[:, 1:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------ priors
+def test_kl_gmm_pose3d(L):
+    from oracle import ops
+    from nemo_cvpr2023_amd.engine import gmm_constants
+    H = _ops()
+    gen = torch.Generator().manual_seed(51)
+    N = 70
+    mulv = torch.randn(N, 64, generator=gen)
+    mulv[0, 40] = 25.0                                 # softplus threshold branch
+    mo = mulv.clone().requires_grad_(True)
+    kl = ops.kl_to_std_normal(mo[:, :32], torch.nn.functional.softplus(mo[:, 32:]))
+    kl.backward()
+    out, d = torch.zeros(8, device='cuda'), torch.zeros(N, 64, device='cuda')
+    assert L.nemo_kl_fwd_bwd(N, 32, H.dev(mulv).data_ptr(), 64, out.data_ptr(), d.data_ptr(), 64, H.st()) == 0
+    assert rel_err(out[0], kl.detach()) < 1e-5 and rel_err(d, mo.grad) < 1e-4
+
+    g = syn.make_gmm()
+    prior = ops.GMMPriorOracle(g)
+    c = gmm_constants(g, 'cuda:0')
+    x = 0.3 * torch.randn(N, 72, generator=gen)
+    xo = x.clone().requires_grad_(True)
+    ll = prior(xo[:, 3:])
+    ll.mean().backward()
+    per, dx = torch.zeros(N, device='cuda'), torch.zeros(N, 72, device='cuda')
+    dxp = H.dev(x)
+    assert L.nemo_gmm_fwd_bwd(N, 8, 69, dxp.data_ptr() + 12, 72, c['means'].data_ptr(), c['prec'].data_ptr(),
+                              c['log_nllw'].data_ptr(), out.data_ptr() + 4, per.data_ptr(), 2.0,
+                              dx.data_ptr() + 12, 72, H.st()) == 0
+    assert rel_err(per, ll.detach()) < 1e-5 and rel_err(out[1], ll.mean().detach()) < 1e-5
+    assert rel_err(dx, 2.0 * xo.grad) < 1e-4
+
+    V, T = 3, 4
+    theta, mask = 0.2 * torch.randn(V, T, 69, generator=gen), (torch.rand(V, T, 1, generator=gen) > 0.3).float()
+    vi, fi = torch.randint(0, V, (N,), generator=gen), torch.randint(0, T, (N,), generator=gen)
+    xo = x.clone().requires_grad_(True)
+    l3 = ops.keypoint_loss(xo[:, 3:], theta[vi, fi], mask[vi, fi], None, 'mse_robust').mean()
+    l3.backward()
+    dx.zero_()
+    assert L.nemo_pose3d_fwd_bwd(N, 69, dxp.data_ptr() + 12, 72, H.dev(theta).data_ptr(), H.dev(mask).data_ptr(),
+                                 H.dev(vi, torch.long).data_ptr(), H.dev(fi, torch.long).data_ptr(), T,
+                                 out.data_ptr() + 8, 1.0, dx.data_ptr() + 12, 72, H.st()) == 0
+    assert rel_err(out[2], l3.detach()) < 1e-5 and rel_err(dx, xo.grad) < 1e-4
+
+
+@pytest.mark.parametrize('adamw,wd', [(False, 0.0), (False, 0.001), (True, 0.01)])
+def test_fused_adam_matches_torch(L, adamw, wd):
+    from nemo_cvpr2023_amd._lib import AdamSeg
+    H = _ops()
+    gen = torch.Generator().manual_seed(61)
+    n = 5000
+    p0 = torch.randn(n, generator=gen)
+    pt = p0.clone().requires_grad_(True)
+    opt = (torch.optim.AdamW if adamw else torch.optim.Adam)([pt], lr=1e-2, weight_decay=wd)
+    p, m, v = H.dev(p0), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    for t in range(1, 6):
+        gr = torch.randn(n, generator=gen) * (10.0 ** -t)
+        pt.grad = gr.clone()
+        opt.step()
+        seg = (AdamSeg * 2)()
+        for i, (a, b) in enumerate(((0, 2000), (2000, 3000))):
+            seg[i].offset, seg[i].numel, seg[i].lr, seg[i].weight_decay = a, b, 1e-2, wd
+            seg[i].step_size, seg[i].bias_corr2_sqrt = 1e-2 / (1 - 0.9 ** t), math.sqrt(1 - 0.999 ** t)
+            seg[i].adamw = int(adamw)
+        assert L.nemo_adam_step(2, seg, p.data_ptr(), H.dev(gr).data_ptr(), m.data_ptr(), v.data_ptr(), 0.9,
+                                0.999, 1e-8, H.st()) == 0
+    assert rel_err(p, pt.detach()) < 1e-6
