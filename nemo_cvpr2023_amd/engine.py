@@ -248,11 +248,13 @@ class FitEngine:
         self.gemm(0, 1, rows, fout, fin, x, ldx, w, fin, y, ldy, bias=b, act=act)
 
     def _linear_bwd_params(self, rows, x, ldx, fin, dy, lddy, fout, gw, gb):
-        """gw (fout,fin) += dy^T @ x ;  gb += colsum(dy).  K = rows is split for occupancy."""
+        """gw (fout,fin) += dy^T @ x ;  gb += colsum(dy) (skipped when gb is None).  K = rows is
+        split for occupancy."""
         tiles = ((fout + 63) // 64) * ((fin + 63) // 64)
         split = max(1, min(64, (512 + tiles - 1) // tiles, (rows + 255) // 256))
         self.gemm(1, 0, fout, fin, rows, dy, lddy, x, ldx, gw, fin, out_mode=2, split_k=split)
-        check(self.lib.nemo_colsum_f32(dy, rows, fout, lddy, gb, _stream()), 'nemo_colsum_f32')
+        if gb is not None:
+            check(self.lib.nemo_colsum_f32(dy, rows, fout, lddy, gb, _stream()), 'nemo_colsum_f32')
 
     # ------------------------------------------------------------------ forward pieces
     def forward_pose(self, w, N, view_idx, frame_idx, raw_phase=None, code_noise=None):
@@ -401,8 +403,12 @@ class FitEngine:
         self.gemm(0, 0, r, h, 144, dptr(w['dROT']), 144, self.p(lm + 'rot_out.weight'), h, dptr(w['dH']), h,
                   mask=dptr(w['H3']), ldmask=h, mask_mode=1)
         if has_trans_grad:
+            # trans - trans_0 cancels the bias exactly: d/d(linear_out.bias) == 0 (the reference's
+            # autograd also produces an exact 0 there), so the column sum is skipped unless the
+            # global trajectory is left un-anchored.
+            gb = self.g(lm + 'linear_out.bias') if self.start_global_traj_anywhere else None
             self._linear_bwd_params(r, dptr(w['H3']), h, h, dptr(w['dTR']), 3, 3,
-                                    self.g(lm + 'linear_out.weight'), self.g(lm + 'linear_out.bias'))
+                                    self.g(lm + 'linear_out.weight'), gb)
             self.gemm(0, 0, r, h, 3, dptr(w['dTR']), 3, self.p(lm + 'linear_out.weight'), h, dptr(w['dH']), h,
                       mask=dptr(w['H3']), ldmask=h, mask_mode=1, out_mode=1)
         self._linear_bwd_params(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'),
