@@ -141,6 +141,8 @@ class ParamLayout:
             add('motion', f'learned_motion.{lname}.bias', (fo,))
         if D > 0:
             add('motion', 'phase_rbf.log_sigmas', (D,))
+        # 8 floats that travel with the shared-gradient all-reduce (loss scalars); no optimiser owns them
+        add('comm', '_comm_scalars', (8,))
         for i in range(V):
             add('phase', f'phase_networks.{i}.shifts', (K,))
             add('phase', f'phase_networks.{i}.scales', (K,))
@@ -197,6 +199,7 @@ class FitEngine:
         self.scal = torch.zeros(8, **f32)
         self._scal_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.ws = {}
+        self.timers = None
         self.detach_articulation = False
         self.start_global_traj_anywhere = False
 
@@ -239,13 +242,30 @@ class FitEngine:
 
     # ------------------------------------------------------------------ kernel helpers
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias=None, act=0, mask=None, ldmask=0,
-             mask_mode=0, alpha=1.0, out_mode=0, split_k=1):
+             mask_mode=0, alpha=1.0, out_mode=0, split_k=1, tag=None):
+        ev = self._event_begin(tag, 2.0 * M * N * K)
         check(self.lib.nemo_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias, act, mask, ldmask,
                                      mask_mode, alpha, out_mode, split_k, _stream()), 'nemo_gemm_f32')
+        self._event_end(ev)
 
-    def _linear(self, rows, x, ldx, fin, w, b, fout, y, ldy, act=0):
+    # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
+    # recorded on the stream the kernels are launched on (torch's current stream).
+    def _event_begin(self, tag, flops):
+        if self.timers is None or tag is None:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        self.timers.setdefault(tag, []).append((a, b, flops))
+        return b
+
+    @staticmethod
+    def _event_end(ev):
+        if ev is not None:
+            ev.record()
+
+    def _linear(self, rows, x, ldx, fin, w, b, fout, y, ldy, act=0, tag=None):
         """y = act(x @ w^T + b), w stored (fout, fin) like nn.Linear."""
-        self.gemm(0, 1, rows, fout, fin, x, ldx, w, fin, y, ldy, bias=b, act=act)
+        self.gemm(0, 1, rows, fout, fin, x, ldx, w, fin, y, ldy, bias=b, act=act, tag=tag)
 
     def _linear_bwd_params(self, rows, x, ldx, fin, dy, lddy, fout, gw, gb):
         """gw (fout,fin) += dy^T @ x ;  gb += colsum(dy) (skipped when gb is None).  K = rows is
@@ -272,7 +292,7 @@ class FitEngine:
         self._linear(r, dptr(w['X']), self.din, self.din, self.p(lm + 'net.net.0.weight'),
                      self.p(lm + 'net.net.0.bias'), h, dptr(w['H1']), h, act=1)
         self._linear(r, dptr(w['H1']), h, h, self.p(lm + 'net.net.2.weight'), self.p(lm + 'net.net.2.bias'),
-                     h, dptr(w['H2']), h, act=1)
+                     h, dptr(w['H2']), h, act=1, tag='gemm_mlp_hidden_fwd')
         self._linear(r, dptr(w['H2']), h, h, self.p(lm + 'net.net.4.weight'), self.p(lm + 'net.net.4.bias'),
                      h, dptr(w['H3']), h, act=1)
         self._linear(r, dptr(w['H3']), h, h, self.p(lm + 'rot_out.weight'), self.p(lm + 'rot_out.bias'),
@@ -341,14 +361,16 @@ class FitEngine:
             check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']),
                                 dptr(w['PF2']), st), 'nemo_fk_fwd')
             self.gemm(0, 0, 2 * n, NV3, 207, dptr(w['PF2']), 207, ctx.posedirs, NV3, dptr(w['VP2']), NV3,
-                      bias=ctx.v_shaped)
+                      bias=ctx.v_shaped, tag='gemm_pose_blend')
+            ev = self._event_begin('v2v_skin_l1', 2.0 * n * self.NV * (2 * 288 + 288 + 30))
             check(L.nemo_v2v_skin_l1(ctx.handle, n, dptr(w['VP2']), NV3, dptr(w['A2']),
                                      self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVP']), NV3, dptr(w['dA2']),
                                      st), 'nemo_v2v_skin_l1')
+            self._event_end(ev)
             if need_grad:
                 w['dPF2'].zero_()
                 self.gemm(0, 1, n, 207, NV3, dptr(w['dVP']), NV3, ctx.posedirs, NV3, dptr(w['dPF2']), 207,
-                          out_mode=2, split_k=8)
+                          out_mode=2, split_k=8, tag='gemm_pose_blend_bwd')
                 check(L.nemo_fk_bwd(ctx.handle, n, dptr(w['R2']), dptr(w['A2']), dptr(w['dA2']), None,
                                     dptr(w['dPF2']), w['dR2'].data_ptr() + 4 * c0 * 216, st), 'nemo_fk_bwd')
 
@@ -414,7 +436,7 @@ class FitEngine:
         self._linear_bwd_params(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'),
                                 self.g(lm + 'net.net.4.bias'))
         self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
-                  mask=dptr(w['H2']), ldmask=h, mask_mode=1)
+                  mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx')
         self._linear_bwd_params(r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h,
                                 self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
         self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH']), h,

@@ -31,6 +31,20 @@ from . import _lib
 from ._lib import check, dptr
 from .engine import (FOCAL_LENGTH, LOSS_TYPES, S_3D, S_GMM, S_KL, S_KP, S_V2V, FitEngine, _stream)
 
+S_INST = 5
+
+
+class ShardInfo:
+    """Normalisers of one rank's share of a step when the (instance x frame) batch is sharded by
+    instance (nemo_cvpr2023_amd/dist.py).  kr = n_U_local / n_U_global scales the per-view keypoint
+    mean (:3551-3558); mr = N_local / N_global the per-sample means (GMM, KL, v2v, 3-D); vr =
+    V_local / V_global the instance-code regulariser.  ``comm(engine)`` all-reduces the shared
+    gradients together with the loss scalars.  The single-process default is the identity."""
+
+    def __init__(self, kr=1.0, mr=1.0, vr=1.0, n_global=None, comm=None):
+        self.kr, self.mr, self.vr, self.n_global, self.comm = kr, mr, vr, n_global, comm
+
+
 
 # ----------------------------------------------------------------------------- parameter holders
 class _Linear(nn.Module):
@@ -229,31 +243,10 @@ class MultiViewModel(nn.Module):
 
     @torch.no_grad()
     def _init_parameters(self):
-        """Same distributions as :3375-3402, :106-126, monotonic_network.py:11-21 (drawn on the CPU
-        global RNG in the reference's order; bit-identical initial states are obtained by loading a
-        reference ``state_dict``)."""
-        e, a = self.engine, self.args
-        cams = 1e-4 * torch.randn(e.V, 9)
-        cams[:, 3] += 1
-        cams[:, 6] += 1
-        cams[:, 2] += 2 * FOCAL_LENGTH / (self.IMG_D0 * 1 + 1e-9)
-        self.learned_cameras.copy_(cams)
-        if e.C > 0:
-            self.learned_instance_code.copy_(1e-4 * torch.randn(e.V, e.C))
-        for name, (fo, fi) in (('net.net.0', (e.h, e.din)), ('net.net.2', (e.h, e.h)),
-                               ('net.net.4', (e.h, e.h)), ('rot_out', (144, e.h)), ('linear_out', (3, e.h))):
-            lin = nn.Linear(fi, fo)
-            if name == 'rot_out':
-                nn.init.xavier_uniform_(lin.weight, gain=0.00001)
-                lin.bias.data = torch.tensor([1., 0, 0, 1, 0, 0]).repeat(24)
-            e.view(f'learned_motion.{name}.weight').copy_(lin.weight.data)
-            e.view(f'learned_motion.{name}.bias').copy_(lin.bias.data)
-        for i in range(e.V):
-            sh = torch.linspace(0, 1, e.K) if a.phase_init == 'linear' else torch.rand(e.K)
-            e.view(f'phase_networks.{i}.shifts').copy_(sh.clamp_(0, 1))
-            e.view(f'phase_networks.{i}.scales').fill_(15.0)
-        if e.D > 0:
-            e.view('phase_rbf.log_sigmas').zero_()
+        e = self.engine
+        st = make_init_state(self.args, self.VERSION, e.V, self.IMG_D0)
+        for k, v in st.items():
+            e.view(k).copy_(v)
 
     def _build_optimizers(self):
         e, a, G = self.engine, self.args, self.engine.layout.groups
@@ -384,9 +377,10 @@ class MultiViewModel(nn.Module):
         return {k: v.reshape(V, T, *v.shape[1:]) for k, v in p.items()}
 
     # ------------------------------------------------------------------ the hot path
-    def _forward_losses(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False):
+    def _forward_losses(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False, sh=None):
         """Forward of :3511-3584 (+V3 extras).  Accumulates the weighted pose gradients into dAA."""
         e, a = self.engine, self.args
+        sh = sh or ShardInfo()
         e.scal.zero_()
         w['view_acc'].zero_()
         if update:
@@ -402,34 +396,37 @@ class MultiViewModel(nn.Module):
             g = e.gmm
             check(e.lib.nemo_gmm_fwd_bwd(N, g['M'], 69, aa69, 72, dptr(g['means']), dptr(g['prec']),
                                          dptr(g['log_nllw']), e.scal.data_ptr() + 4 * S_GMM, None,
-                                         float(a.weight_gmm_loss),
+                                         float(a.weight_gmm_loss) * sh.mr,
                                          daa69 if (update and a.weight_gmm_loss) else None, 72, st),
                   'nemo_gmm_fwd_bwd')
         if self.VERSION >= 3 and getattr(a, 'weight_3d_loss', 0):
             check(e.lib.nemo_pose3d_fwd_bwd(N, 69, aa69, 72, dptr(e.hmr_theta), dptr(e.hmr_mask), dptr(vi),
                                             dptr(fi), e.T, e.scal.data_ptr() + 4 * S_3D,
-                                            float(a.weight_3d_loss), daa69 if update else None, 72, st),
+                                            float(a.weight_3d_loss) * sh.mr, daa69 if update else None, 72,
+                                            st),
                   'nemo_pose3d_fwd_bwd')
         return Mq
 
-    def _backward(self, w, N, vi, fi, Mq, use_vposer=True, detach_pose=False):
+    def _backward(self, w, N, vi, fi, Mq, use_vposer=True, detach_pose=False, sh=None):
         e, a = self.engine, self.args
+        sh = sh or ShardInfo()
         st = _stream()
-        e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=1.0, detach_pose=detach_pose)
+        e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose)
         if use_vposer and a.weight_vp_loss:
             check(e.lib.nemo_v2v_prep_bwd(N, dptr(w['AA']), dptr(w['dR2']),
-                                          float(a.weight_vp_loss) / float(N * e.NV * 3), dptr(w['dAA']),
-                                          dptr(w['dR']), st), 'nemo_v2v_prep_bwd')
+                                          float(a.weight_vp_loss) * sh.mr / float(N * e.NV * 3),
+                                          dptr(w['dAA']), dptr(w['dR']), st), 'nemo_v2v_prep_bwd')
         if use_vposer and a.weight_vp_z_loss:
-            e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss))
+            e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
         check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), 144, 1, dptr(w['dR']), dptr(w['dAA']),
                                    dptr(w['dROT']), 144, st), 'nemo_rot6d_bwd')
         e.finish_trans_grad(w, N)
         e.backward_mlp(w, N, vi, fi, None)
 
-    def step(self, view_idx, frame_idx, update=True, full_batch=False):
+    def step(self, view_idx, frame_idx, update=True, full_batch=False, _shard=None):
         """:3511-3598 (V1/V2), :3796-3909 (V3/V4)."""
         e, a = self.engine, self.args
+        sh = _shard or ShardInfo()
         if self.VERSION >= 3 and update:
             self.training = True
         if a.batch_size > -1 and not full_batch:
@@ -437,22 +434,29 @@ class MultiViewModel(nn.Module):
         else:
             vi, fi = self.full_indices()
         N = vi.numel()
-        w = e._ws(N)
-        Mq = self._forward_losses(w, N, vi, fi, update)
-        inst_t = None
-        if self.VERSION >= 3 and getattr(a, 'weight_instance_loss', 0) and e.C > 0:
-            inst_t = (self.learned_instance_code.detach() ** 2).mean()                    # :3864-3867
+        w = e._ws(max(N, 1))
+        has_inst = self.VERSION >= 3 and getattr(a, 'weight_instance_loss', 0) and e.C > 0
+        if N > 0:
+            Mq = self._forward_losses(w, N, vi, fi, update, sh=sh)
+        else:                       # a shard may own none of a minibatch's samples
+            e.scal.zero_()
+            if update:
+                e.grads.zero_()
+        if has_inst:
+            e.scal[S_INST] = (self.learned_instance_code.detach() ** 2).mean()            # :3864-3867
         if update:
-            self._backward(w, N, vi, fi, Mq)
-            if inst_t is not None:
+            if N > 0:
+                self._backward(w, N, vi, fi, Mq, sh=sh)
+            if has_inst:
                 code = self.learned_instance_code.detach()
                 e.view('learned_instance_code', e.grads).add_(
-                    code, alpha=2.0 * float(a.weight_instance_loss) / code.numel())
+                    code, alpha=2.0 * float(a.weight_instance_loss) * sh.vr / code.numel())
+        s = self._reduce_and_read(sh, update)
+        if update:
             self._adam_all(self.optimizers)
-        s = e.read_scalars()
         f32 = np.float32
         kp = f32(s[S_KP])
-        v2v = f32(s[S_V2V]) / f32(N * e.NV * 3)
+        v2v = f32(s[S_V2V]) / f32((sh.n_global or N) * e.NV * 3)
         kl, gmm, l3d = f32(s[S_KL]), f32(s[S_GMM]), f32(s[S_3D])
         loss = kp
         if a.weight_vp_loss:
@@ -461,8 +465,8 @@ class MultiViewModel(nn.Module):
             loss = f32(loss + f32(a.weight_vp_z_loss) * kl)
         loss_dict = {'kp_loss': np.asarray(kp)}
         if self.VERSION >= 3:
-            inst = f32(float(inst_t)) if inst_t is not None else 0
-            if inst_t is not None:
+            inst = f32(s[S_INST]) if has_inst else 0
+            if has_inst:
                 loss = f32(loss + f32(a.weight_instance_loss) * inst)
             if getattr(a, 'weight_3d_loss', 0):
                 loss = f32(loss + f32(a.weight_3d_loss) * l3d)
@@ -472,13 +476,28 @@ class MultiViewModel(nn.Module):
             loss = f32(loss + f32(a.weight_gmm_loss) * gmm)
         loss_dict.update(gmm_loss=np.asarray(gmm), vp_recon_loss=np.asarray(v2v), vp_kl_loss=np.asarray(kl),
                          total_loss=np.asarray(loss))
-        info_dict = {'view_idx': vi, 'frame_idx': fi, 'loss_all': self._loss_all(w, N),
-                     'points2d_gt': e.targets[vi, fi], 'points2d': w['p2d'].clone(), 'j': w['j3d'].clone()}
+        info_dict = {'view_idx': vi, 'frame_idx': fi}
+        if N > 0:
+            info_dict.update(loss_all=self._loss_all(w, N), points2d_gt=e.targets[vi, fi],
+                             points2d=w['p2d'].clone(), j=w['j3d'].clone())
         if update and self.schedulers:
             for sch in self.schedulers:
                 sch.step(float(loss))
         self.training = False
         return loss_dict, info_dict
+
+    def _reduce_and_read(self, sh, update):
+        """Loss scalars to the host (one 32-byte copy per step).  Sharded: the scalars are weighted
+        into global terms, ride along the shared-gradient all-reduce, and are read back reduced."""
+        e = self.engine
+        if sh.comm is None:
+            return e.read_scalars()
+        wv = torch.tensor([sh.kr, 1.0, sh.mr, sh.mr, sh.mr, sh.vr, 0.0, 0.0], device=self.device)
+        slot = e.view('_comm_scalars', e.grads)
+        torch.mul(e.scal, wv, out=slot)
+        sh.comm(e, update)
+        e.scal.copy_(slot)
+        return e.read_scalars()
 
     def _loss_all(self, w, N):
         Wd = 1 if LOSS_TYPES[self.args.loss] in (2, 3, 5) else 2
@@ -489,7 +508,7 @@ class MultiViewModel(nn.Module):
         B = self.args.batch_size
         return (torch.randint(0, self.num_views, size=(B,)), torch.randint(0, self.num_frames, size=(B,)))
 
-    def warmup(self, warmup_steps=1000):
+    def warmup(self, warmup_steps=1000, _sharder=None):
         """:3455-3509: fit the MLP pose output to the HMR/VIBE 3-D pose (motion + phase optimisers)."""
         if warmup_steps == 0:
             return []
@@ -502,30 +521,36 @@ class MultiViewModel(nn.Module):
         losses = []
         st = _stream()
         for _ in range(warmup_steps):
-            vi, fi = self.draw_batch()
+            if _sharder is not None:          # sharded: GLOBAL draw, routed to this rank's samples
+                vi, fi, sh = _sharder()
+            else:
+                (vi, fi), sh = self.draw_batch(), ShardInfo()
             vi, fi = self._idx(vi), self._idx(fi)
             N = vi.numel()
-            w = e._ws(N)
+            w = e._ws(max(N, 1))
             e.scal.zero_()
             e.grads.zero_()
-            w['dAA'].zero_()
-            e.forward_pose(w, N, vi, fi)
-            check(e.lib.nemo_pose3d_fwd_bwd(N, 69, w['AA'].data_ptr() + 12, 72, dptr(e.hmr_theta),
-                                            dptr(e.hmr_mask), dptr(vi), dptr(fi), e.T,
-                                            e.scal.data_ptr() + 4 * S_3D, 1.0, w['dAA'].data_ptr() + 12, 72,
-                                            st), 'nemo_pose3d_fwd_bwd')
-            check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), 144, 1, None, dptr(w['dAA']), dptr(w['dROT']),
-                                       144, st), 'nemo_rot6d_bwd')
-            e.backward_mlp(w, N, vi, fi, None, has_trans_grad=False)
+            if N > 0:
+                w['dAA'].zero_()
+                e.forward_pose(w, N, vi, fi)
+                check(e.lib.nemo_pose3d_fwd_bwd(N, 69, w['AA'].data_ptr() + 12, 72, dptr(e.hmr_theta),
+                                                dptr(e.hmr_mask), dptr(vi), dptr(fi), e.T,
+                                                e.scal.data_ptr() + 4 * S_3D, float(sh.mr),
+                                                w['dAA'].data_ptr() + 12, 72, st), 'nemo_pose3d_fwd_bwd')
+                check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), 144, 1, None, dptr(w['dAA']),
+                                           dptr(w['dROT']), 144, st), 'nemo_rot6d_bwd')
+                e.backward_mlp(w, N, vi, fi, None, has_trans_grad=False)
+            s = self._reduce_and_read(sh, True)
             if bool(torch.isnan(e.grads).any()):
                 raise FloatingPointError('nan gradient found during warmup')        # :3497-3500
             self._adam_all([self.opt_motion, self.opt_phase], active)
-            losses.append(float(e.read_scalars()[S_3D]))
+            losses.append(float(s[S_3D]))
         return losses
 
-    def opt_cam(self, cam_opt_steps=2000):
+    def opt_cam(self, cam_opt_steps=2000, _shard=None):
         """:2869-2906: a fresh Adam on the cameras only, first frame of every view."""
         e, a = self.engine, self.args
+        sh = _shard or ShardInfo()
         m, v = torch.zeros_like(e.exp_avg), torch.zeros_like(e.exp_avg_sq)
         cam_opt = FusedAdam(e, ['learned_cameras'], [self.learned_cameras], a.lr_camera, exp_avg=m,
                             exp_avg_sq=v)
@@ -540,9 +565,9 @@ class MultiViewModel(nn.Module):
             w['view_acc'].zero_()
             e.forward_pose(w, N, vi, fi)
             Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=1)
-            e.backward_kp(w, N, vi, fi, Mq, mean_mode=1, upstream=1.0, cams_only=True)
+            e.backward_kp(w, N, vi, fi, Mq, mean_mode=1, upstream=float(sh.mr), cams_only=True)
             cam_opt.step()
-            log.append(np.asarray(e.read_scalars()[S_KP]))
+            log.append(np.asarray(self._reduce_and_read(ShardInfo(kr=sh.mr, comm=sh.comm), False)[S_KP]))
         return log
 
 
@@ -581,20 +606,63 @@ class NemoV4(NemoV3):
     """:3959-4151: V3 with joints 0..24 and a stochastic camera phase."""
     VERSION = 4
 
-    def opt_cam(self, cam_opt_steps=2000):
+    def opt_cam(self, cam_opt_steps=2000, _sharder=None):
         """:4060-4151: random batches, body pose detached, every optimiser steps."""
         e, a = self.engine, self.args
         if a.batch_size <= -1 and cam_opt_steps:
             raise NotImplementedError()
         for _ in range(cam_opt_steps):
-            vi, fi = self.draw_batch()
+            if _sharder is not None:
+                vi, fi, sh = _sharder()
+            else:
+                (vi, fi), sh = self.draw_batch(), ShardInfo()
             vi, fi = self._idx(vi), self._idx(fi)
             N = vi.numel()
-            w = e._ws(N)
-            Mq = self._forward_losses(w, N, vi, fi, update=True, use_vposer=False)
-            self._backward(w, N, vi, fi, Mq, use_vposer=False, detach_pose=True)
+            w = e._ws(max(N, 1))
+            if N > 0:
+                Mq = self._forward_losses(w, N, vi, fi, update=True, use_vposer=False, sh=sh)
+                self._backward(w, N, vi, fi, Mq, use_vposer=False, detach_pose=True, sh=sh)
+            else:
+                e.scal.zero_()
+                e.grads.zero_()
+            if sh.comm is not None:
+                self._reduce_and_read(sh, True)
             self._adam_all(self.optimizers)
         return []
+
+
+def make_init_state(args, version, V, img_d0):
+    """Initial parameters with the distributions of :3375-3402, :106-126, monotonic_network.py:11-21,
+    drawn from the CPU global RNG (bit-identical initial states are obtained by loading a reference
+    ``state_dict``).  Returned on the CPU under the reference's state_dict names, so a
+    sharded run can build the global state on every rank and keep its slice."""
+    C = args.instance_code_size
+    D = args.phase_rbf_dim if version >= 2 else 0
+    h, K = args.h_dim, args.monotonic_network_n_nodes
+    din = (D if D > 0 else 1) + C
+    st = OrderedDict()
+    cams = 1e-4 * torch.randn(V, 9)
+    cams[:, 3] += 1
+    cams[:, 6] += 1
+    cams[:, 2] += 2 * FOCAL_LENGTH / (img_d0 * 1 + 1e-9)
+    st['learned_cameras'] = cams
+    if C > 0:
+        st['learned_instance_code'] = 1e-4 * torch.randn(V, C)
+    for name, (fo, fi) in (('net.net.0', (h, din)), ('net.net.2', (h, h)), ('net.net.4', (h, h)),
+                           ('rot_out', (144, h)), ('linear_out', (3, h))):
+        lin = nn.Linear(fi, fo)
+        if name == 'rot_out':
+            nn.init.xavier_uniform_(lin.weight, gain=0.00001)
+            lin.bias.data = torch.tensor([1., 0, 0, 1, 0, 0]).repeat(24)
+        st[f'learned_motion.{name}.weight'] = lin.weight.data.clone()
+        st[f'learned_motion.{name}.bias'] = lin.bias.data.clone()
+    for i in range(V):
+        sh = torch.linspace(0, 1, K) if args.phase_init == 'linear' else torch.rand(K)
+        st[f'phase_networks.{i}.shifts'] = sh.clamp_(0, 1)
+        st[f'phase_networks.{i}.scales'] = torch.full((K,), 15.0)
+    if D > 0:
+        st['phase_rbf.log_sigmas'] = torch.zeros(D)
+    return st
 
 
 def collate_gt_2d(seqs, label_type='op', thr=30.0):

@@ -224,52 +224,82 @@ class OracleNemo:
         return loss_all, gt
 
     # ------------------------------------------------------------------ optimisation API
-    def step(self, view_idx, frame_idx, update=True, full_batch=False):
+    def step(self, view_idx, frame_idx, update=True, full_batch=False, shard=None):
         """:3511-3598 (V1/V2) and :3796-3909 (V3/V4).  ``kp_loss`` is the pure (GPU-semantics)
-        value, SURVEY.md section 7 quirk (v)."""
+        value, SURVEY.md section 7 quirk (v).
+
+        ``shard`` (tests of the instance-sharding maths only): dict(kr, mr, vr, comm) -- this
+        process holds a block of the views; its local terms are scaled to global ones and
+        ``comm(shared_grads, scalars)`` sums the shared gradients / loss scalars over the ranks."""
         a = self.args
+        kr, mr, vr, comm = 1.0, 1.0, 1.0, None
+        if shard is not None:
+            kr, mr, vr, comm = shard['kr'], shard['mr'], shard['vr'], shard['comm']
         if self.version >= 3 and update:
             self.training = True
         if not (a.batch_size > -1 and not full_batch):
             view_idx, frame_idx = self.full_indices()
         N = len(view_idx)
-        pd = self.get_preds_batch(view_idx, frame_idx)
-        p2d = self.learned_camera_projection(pd['j'], view_idx)
-        loss_all, gt = self.kp_loss(p2d, view_idx, frame_idx)
-        loss = ops.per_view_mean_loss(loss_all, gt[..., -1:], view_idx)
-        out = {'kp_loss': loss.detach().clone()}
-        vp_recon, vp_kl = self.vposer_loss(pd['poses'], pd['orient'])
+        zero = torch.zeros(())
+        terms = dict(kp=zero, v2v=zero, kl=zero, gmm=zero, l3=zero, inst=zero)
+        info = {'view_idx': view_idx, 'frame_idx': frame_idx}
+        if N > 0:
+            pd = self.get_preds_batch(view_idx, frame_idx)
+            p2d = self.learned_camera_projection(pd['j'], view_idx)
+            loss_all, gt = self.kp_loss(p2d, view_idx, frame_idx)
+            terms['kp'] = kr * ops.per_view_mean_loss(loss_all, gt[..., -1:], view_idx)
+            v2v, kl = self.vposer_loss(pd['poses'], pd['orient'])
+            terms['v2v'], terms['kl'] = mr * v2v, mr * kl
+            if self.version >= 3 and a.weight_3d_loss:
+                terms['l3'] = mr * ops.keypoint_loss(pd['poses'], self.hmr_theta[view_idx, frame_idx],
+                                                     self.hmr_mask[view_idx, frame_idx], None,
+                                                     'mse_robust').mean()
+            terms['gmm'] = mr * self.prior(pd['poses']).mean()                          # :2758-2773
+            info.update(loss_all=loss_all.detach(), points2d_gt=gt, points2d=p2d.detach(),
+                        j=pd['j'].detach())
+        if self.version >= 3 and a.weight_instance_loss:
+            terms['inst'] = vr * (self.P['learned_instance_code'] ** 2).mean()
+        loss = terms['kp']
         if a.weight_vp_loss:
-            loss = loss + a.weight_vp_loss * vp_recon
+            loss = loss + a.weight_vp_loss * terms['v2v']
         if a.weight_vp_z_loss:
-            loss = loss + a.weight_vp_z_loss * vp_kl
+            loss = loss + a.weight_vp_z_loss * terms['kl']
         if self.version >= 3:
-            inst = 0
             if a.weight_instance_loss:
-                inst = (self.P['learned_instance_code'] ** 2).mean()
-                loss = loss + a.weight_instance_loss * inst
-            out['instance_loss'] = inst
+                loss = loss + a.weight_instance_loss * terms['inst']
             if a.weight_3d_loss:
-                l3 = ops.keypoint_loss(pd['poses'], self.hmr_theta[view_idx, frame_idx],
-                                       self.hmr_mask[view_idx, frame_idx], None, 'mse_robust').mean()
-                loss = loss + a.weight_3d_loss * l3
-                out['loss_3d'] = l3
-        gmm = self.prior(pd['poses']).mean()                                         # :2758-2773
+                loss = loss + a.weight_3d_loss * terms['l3']
         if a.weight_gmm_loss:
-            loss = loss + a.weight_gmm_loss * gmm
-        out.update(gmm_loss=gmm, vp_recon_loss=vp_recon, vp_kl_loss=vp_kl, total_loss=loss)
-        loss_dict = {k: np.asarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v,
-                                   dtype=np.float32) for k, v in out.items()}
-        info = {'view_idx': view_idx, 'frame_idx': frame_idx, 'loss_all': loss_all.detach(),
-                'points2d_gt': gt, 'points2d': p2d.detach(), 'j': pd['j'].detach()}
+            loss = loss + a.weight_gmm_loss * terms['gmm']
         if update:
             for o in self.optimizers:
                 o.zero_grad()
-            loss.backward()
+            if loss.requires_grad:
+                loss.backward()
+        scal = torch.stack([terms[k].detach().float() for k in ('kp', 'v2v', 'kl', 'gmm', 'l3', 'inst')]
+                           + [loss.detach().float()])
+        if comm is not None:
+            shared = [p for p in self.opt_motion.param_groups[0]['params']]
+            for p in shared:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            comm([p.grad for p in shared] if update else [], scal)
+        if update:
             for o in self.optimizers:
+                for p in o.param_groups[0]['params']:
+                    if p.grad is None and shard is not None:
+                        p.grad = torch.zeros_like(p)        # absent views still take an Adam step
                 o.step()
-            for s in self.schedulers:
-                s.step(float(loss.detach()))
+            for s_ in self.schedulers:
+                s_.step(float(scal[6]))
+        out = {'kp_loss': scal[0], 'gmm_loss': scal[3], 'vp_recon_loss': scal[1], 'vp_kl_loss': scal[2],
+               'total_loss': scal[6]}
+        if self.version >= 3:
+            out['instance_loss'] = scal[5] if a.weight_instance_loss else 0
+            if a.weight_3d_loss:
+                out['loss_3d'] = scal[4]
+        loss_dict = {k: np.asarray(v.numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
+                     for k, v in out.items()}
         self.training = False
         return loss_dict, info
 

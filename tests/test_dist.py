@@ -1,0 +1,202 @@
+"""Instance sharding (nemo_cvpr2023_amd/dist.py).
+
+CPU (gloo, world_size 2): the routing / normaliser maths of ShardPlan and the single all-reduce of
+the shared gradients, exercised with the oracle as the local compute, must reproduce the
+single-process run.  GPU: the same through ShardedNemo on the HIP engine (2 ranks on one GPU, gloo)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+from nemo_cvpr2023_amd import synthetic as syn                                   # noqa: E402
+from nemo_cvpr2023_amd.dist import SequenceSubset, ShardPlan, partition_views, slice_state   # noqa: E402
+
+V, T, B, NV = 5, 6, 12, 64
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _args(version):
+    over = dict(h_dim=16, monotonic_network_n_nodes=10, batch_size=B, out_dir='', phase_rbf_dim=8,
+                weight_instance_loss=0.1, weight_3d_loss=0.5)
+    return syn.published_args(**over)
+
+
+def _draws(n):
+    g = torch.Generator().manual_seed(7)
+    return [(torch.randint(0, V, (B,), generator=g), torch.randint(0, T, (B,), generator=g)) for _ in range(n)]
+
+
+def test_partition_and_routing():
+    assert partition_views(8, 8) == [(i, i + 1) for i in range(8)]
+    assert partition_views(5, 2) == [(0, 3), (3, 5)]
+    assert partition_views(8, 3) == [(0, 3), (3, 6), (6, 8)]
+    vi = torch.tensor([0, 4, 4, 1, 3, 0, 2, 4])
+    fi = torch.arange(8)
+    tot_k = tot_m = 0.0
+    seen = []
+    for r in range(2):
+        p = ShardPlan(5, 10, r, 2)
+        lv, lf, d = p.route(vi, fi)
+        assert (lv >= 0).all() and (lv < p.v_local).all()
+        seen += (lf.tolist())
+        tot_k += d['kr']
+        tot_m += d['mr']
+        assert d['n_global'] == 8
+    assert sorted(seen) == list(range(8))          # every sample routed exactly once
+    assert abs(tot_k - 1.0) < 1e-12 and abs(tot_m - 1.0) < 1e-12
+    # a rank that owns none of the batch's samples
+    lv, lf, d = ShardPlan(5, 10, 1, 2).route(torch.tensor([0, 1, 2]), torch.tensor([0, 0, 0]))
+    assert lv.numel() == 0 and d['kr'] == 0.0 and d['mr'] == 0.0
+    fb = [ShardPlan(8, 300, r, 4).full_batch() for r in range(4)]
+    assert abs(sum(x['kr'] for x in fb) - 1) < 1e-12 and fb[0]['n_global'] == 2400
+
+
+def _oracle_worker(rank, world, port, version, q):
+    from nemo_cvpr2023_amd.neural_motion_model import make_init_state
+    from oracle.model import OracleNemo
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    args = _args(version)
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    torch.manual_seed(0)
+    state = make_init_state(args, version, V, seqs.IMG_D0)
+    plan = ShardPlan(V, T, rank, world)
+    o = OracleNemo(version, args, SequenceSubset(seqs, plan.lo, plan.hi), syn.make_smpl_assets(NV, seed=1),
+                   syn.make_vposer_state(), syn.make_gmm(), state=slice_state(state, plan.lo, plan.hi))
+
+    def comm(grads, scal):          # ONE collective: shared gradients + loss scalars
+        flat = torch.cat([g.reshape(-1) for g in grads] + [scal])
+        dist.all_reduce(flat)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        scal.copy_(flat[off:])
+
+    losses = []
+    for vi, fi in _draws(3):
+        lv, lf, d = plan.route(vi, fi)
+        ld, _ = o.step(lv, lf, shard=dict(d, comm=comm))
+        losses.append({k: float(v) for k, v in ld.items()})
+    ld, _ = o.step(None, None, full_batch=True, shard=dict(plan.full_batch(), comm=comm))
+    losses.append({k: float(v) for k, v in ld.items()})
+    sd = {k: v.numpy() for k, v in o.state_dict().items()}
+    q.put((rank, plan.lo, plan.hi, losses, sd))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('version', [2, 3])
+def test_sharded_oracle_equals_single_process(version):
+    from nemo_cvpr2023_amd.neural_motion_model import make_init_state
+    from oracle.model import OracleNemo
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_oracle_worker, args=(r, world, port, version, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference run
+    args = _args(version)
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    torch.manual_seed(0)
+    state = make_init_state(args, version, V, seqs.IMG_D0)
+    o = OracleNemo(version, args, seqs, syn.make_smpl_assets(NV, seed=1), syn.make_vposer_state(),
+                   syn.make_gmm(), state=state)
+    ref = []
+    for vi, fi in _draws(3):
+        ref.append({k: float(v) for k, v in o.step(vi, fi)[0].items()})
+    ref.append({k: float(v) for k, v in o.step(None, None, full_batch=True)[0].items()})
+    for r in res:
+        for got, want in zip(r[3], ref):
+            for k in want:
+                assert abs(got[k] - want[k]) <= 2e-5 * max(abs(want[k]), 1e-6), (r[0], k, got[k], want[k])
+    sd = o.state_dict()
+    shared = [k for k in sd if k.startswith('learned_motion.') or k == 'phase_rbf.log_sigmas']
+    for k in shared:        # replicas identical to each other and equal to the single-process result
+        assert np.array_equal(res[0][4][k], res[1][4][k]), k
+        assert np.abs(res[0][4][k] - sd[k].numpy()).max() <= 2e-3 * max(np.abs(sd[k].numpy()).max(), 1e-12), k
+    for rank, lo, hi, _, lsd in res:
+        assert np.abs(lsd['learned_cameras'] - sd['learned_cameras'][lo:hi].numpy()).max() < 1e-3
+        for i in range(lo, hi):
+            a = lsd[f'phase_networks.{i - lo}.shifts']
+            assert np.abs(a - sd[f'phase_networks.{i}.shifts'].numpy()).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _hip_worker(rank, world, port, q):
+    from nemo_cvpr2023_amd.dist import ShardedNemo
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    args = _args(3)
+    args.model_version = 3
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    m = ShardedNemo(3, args, seqs, 'cuda:0', rank=rank, world=world, seed=0,
+                    smpl_assets=syn.make_smpl_assets(NV, seed=1), vposer_state=syn.make_vposer_state(),
+                    gmm=syn.make_gmm())
+    losses = []
+    wl = m.warmup(2)
+    cl = m.opt_cam(2)
+    for vi, fi in _draws(3):
+        losses.append({k: float(v) for k, v in m.step(vi, fi)[0].items()})
+    losses.append({k: float(v) for k, v in m.step(None, None, full_batch=True)[0].items()})
+    sd = {k: v.numpy() for k, v in m.gather_state_dict().items()}
+    q.put((rank, losses, sd, wl, [float(x) for x in cl]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_hip_equals_single_process_hip(tmp_path):
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV3, make_init_state
+    from conftest import rel_err
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hip_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    args = _args(3)
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    torch.manual_seed(0)
+    state = make_init_state(args, 3, V, seqs.IMG_D0)
+    m = NemoV3(args, seqs, 'cuda:0', smpl_assets=syn.make_smpl_assets(NV, seed=1),
+               vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
+    m.load_state_dict(state, strict=False)
+    torch.manual_seed(1)             # ShardedNemo re-seeds with seed + 1 after construction
+    wl = m.warmup(2)
+    cl = m.opt_cam(2)
+    ref = [{k: float(v) for k, v in m.step(vi, fi)[0].items()} for vi, fi in _draws(3)]
+    ref.append({k: float(v) for k, v in m.step(None, None, full_batch=True)[0].items()})
+    for r in res:
+        assert rel_err(r[3], wl) < 1e-4 and rel_err(r[4], [float(x) for x in cl]) < 1e-4
+        for got, want in zip(r[1], ref):
+            for k in want:
+                assert abs(got[k] - want[k]) <= 1e-4 * max(abs(want[k]), 1e-6), (r[0], k, got[k], want[k])
+    for k, v in res[0][2].items():
+        assert np.array_equal(v, res[1][2][k]), k         # both ranks assemble the same global state
