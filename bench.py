@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""NeMo fit benchmark: iterations/second of the per-iteration optimisation step (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): the Baseball-Pitch fit of BASELINE.json configs[1] -- 8 instances x 300
+frames, full batch N = 2400 (instance x frame) samples per step, NemoV2 with the published-run
+hyper-parameters (h_dim 1000, RBF 100, instance code 5, mse_robust, w_vp 10, w_vp_z 1, w_gmm 1; every
+loss term evaluated as the reference does), 6890-vertex SMPL, fp32, synthetic SMPL-shaped assets and
+random OpenPose targets (no dataset / licensed model files on the box).  One "step" = one
+``model.step(update=True)``: forward, backward, Adam on all four optimisers, loss read-back.
+
+N > 1: strong scaling -- the same 8 x 300 problem sharded by instance over the ranks
+(nemo_cvpr2023_amd/dist.py), one RCCL all-reduce of the shared MLP gradient per step.
+
+Output (rank 0, ONE JSON line): metric/value/... per the driver contract plus
+  roofline     -- the dominant kernel, timed live with HIP events on the launch stream inside the timed
+                  region; achieved = algorithmic FLOPs per launch / mean launch time vs the fp32 MFMA peak
+  cpu_baseline -- the CPU oracle ("port" of the reference PyTorch path) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+V, T = 8, 300
+FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    opts = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from nemo_cvpr2023_amd import synthetic as syn
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != opts.gpus and world > 1:
+        raise SystemExit(f'--gpus {opts.gpus} but WORLD_SIZE={world}')
+    device = f'cuda:{local_rank}'
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl')          # RCCL on ROCm
+
+    args = syn.published_args(batch_size=512, out_dir='')
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets = dict(smpl_assets=syn.make_smpl_assets(6890, seed=1), vposer_state=syn.make_vposer_state(),
+                  gmm=syn.make_gmm())
+    torch.manual_seed(0)
+    if world > 1:
+        from nemo_cvpr2023_amd.dist import ShardedNemo
+        model = ShardedNemo(2, args, seqs, device, rank=rank, world=world, seed=0, **assets)
+        engine = model.model.engine
+    else:
+        from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+        model = NemoV2(args, seqs, device, **assets)
+        engine = model.engine
+
+    def step():
+        return model.step(None, None, update=True, full_batch=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(opts.warmup):
+        step()
+    barrier()
+    engine.timers = {}                 # HIP events around the tagged kernels, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(opts.steps):
+        ld, _ = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timers, engine.timers = engine.timers, None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    ms_per_step = 1e3 * elapsed / opts.steps
+    iters_per_s = opts.steps / elapsed
+
+    # dominant tagged kernel (largest total time in the timed region)
+    roof = None
+    best = None
+    for tag, evs in timers.items():
+        ms = [a.elapsed_time(b) for a, b, _ in evs]
+        tot = sum(ms)
+        if best is None or tot > best[0]:
+            best = (tot, tag, sum(ms) / len(ms), evs[0][2], len(ms))
+    if best is not None:
+        _, tag, mean_ms, flops, n = best
+        achieved = flops / (mean_ms * 1e-3) / 1e12
+        roof = {'kernel': tag, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                'launches': n, 'mean_launch_ms': round(mean_ms, 4), 'flops_per_launch': flops,
+                'per_kernel_ms_per_step': {t: round(sum(a.elapsed_time(b) for a, b, _ in e) / opts.steps, 4)
+                                           for t, e in timers.items()}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not opts.no_cpu_baseline:
+        from oracle.model import OracleNemo
+        # PyTorch's CPU backend degrades badly when oversubscribed on small tensors (measured: 196 s/step
+        # with 256 threads); 16 threads is near the optimum for this op mix.
+        ncores = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(ncores)
+        o = OracleNemo(2, args, seqs, assets['smpl_assets'], assets['vposer_state'], assets['gmm'])
+        o.step(None, None, update=True, full_batch=True)            # warm-up
+        c0 = time.perf_counter()
+        for _ in range(opts.cpu_steps):
+            o.step(None, None, update=True, full_batch=True)
+        cdt = time.perf_counter() - c0
+        cpu = {'value': round(opts.cpu_steps / cdt, 4), 'unit': 'iters/s', 'cores': ncores, 'kind': 'port',
+               'sample': f'{opts.cpu_steps} full-batch steps (8x300, N=2400) of the CPU oracle '
+                         f'(plain PyTorch fp32 restatement of the reference step) after 1 warm-up, '
+                         f'{ncores} threads'}
+
+    if rank == 0:
+        out = {
+            'metric': 'NeMo fit iters/sec (instances x frames/step), Baseball-Pitch',
+            'value': round(iters_per_s, 3), 'unit': 'iters/s', 'n_gpus': world, 'steps': opts.steps,
+            'warmup': opts.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'samples_per_s': round(iters_per_s * V * T, 1),
+            'config': {'workload': 'Baseball-Pitch-shaped fit, 8 instances x 300 frames full batch (N=2400), '
+                                   'NemoV2 published hyper-parameters, all loss terms, 6890-vertex SMPL',
+                       'instances': V, 'frames': T, 'samples_per_step': V * T, 'h_dim': args.h_dim,
+                       'parallelism': f'instance-shard x{world}' if world > 1 else 'single GPU'},
+            'final_total_loss': float(ld['total_loss']),
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -66,12 +66,14 @@ int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t
                              const float* shifts, const float* scales, int64_t ldp,
                              const float* log_sigmas, const float* codes, const float* code_noise,
                              int32_t kernel_id, float* X, int64_t ldx, float* phase_out, void* stream);
-/* dX (N+1, ldx) -> d_shifts,d_scales (V,K), d_log_sigmas (D), d_codes (V,C); all accumulated. */
+/* dX (N+1, ldx) -> d_shifts,d_scales (V rows of stride ldp), d_log_sigmas (D), d_codes (V,C); all
+ * accumulated.  ws: scratch of 4*N floats.  Reductions over the samples are per (view, node) /
+ * per column blocks -- no same-address atomic contention. */
 int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
                              const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
                              const float* shifts, const float* scales, int64_t ldp,
                              const float* log_sigmas, int32_t kernel_id, const float* phase,
-                             const float* dX, int64_t ldx,
+                             const float* dX, int64_t ldx, float* ws,
                              float* d_shifts, float* d_scales, float* d_log_sigmas, float* d_codes,
                              void* stream);
 
@@ -127,8 +129,8 @@ const float* nemo_ctx_v_shaped(const nemo_ctx* ctx); /* device (3*NV)           
  * Jp (rows,24,3) posed joints, PF (rows,207) = (R[1:]-I) flattened. */
 int32_t nemo_fk_fwd(const nemo_ctx* ctx, int64_t rows, const float* R, float* A, float* Jp, float* PF,
                     void* stream);
-/* dA (rows,24,12) is consumed as scratch (overwritten); dJp, dPF may be NULL. -> dR (rows,24,9). */
-int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R, const float* A, float* dA,
+/* dA (rows,24,12), optional dJp (rows,24,3), dPF (rows,207) -> dR (rows,24,9). */
+int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R, const float* A, const float* dA,
                     const float* dJp, const float* dPF, float* dR, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -201,11 +203,12 @@ int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int64_t ld, flo
                         float* d_mulv, int64_t ldd, void* stream);
 /* MaxMixturePrior (hmr/smplify/prior.py:181-196): per-sample min over M Gaussians, mean over N.
  * x (N, ldx) uses `dim` columns.  means (M,dim), precisions (M,dim,dim), log_nllw (M) = log(nll_weights).
+ * ws: scratch of N*M floats (per-component log-likelihoods).
  * scalar_out += mean;  per_sample (N) optional;  d_x (N, lddx) += scale * d mean / d x. */
 int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const float* x, int64_t ldx,
                          const float* means, const float* precisions, const float* log_nllw,
-                         float* scalar_out, float* per_sample, float scale, float* d_x, int64_t lddx,
-                         void* stream);
+                         float* ws, float* scalar_out, float* per_sample, float scale, float* d_x,
+                         int64_t lddx, void* stream);
 /* Robust 3-D pose loss used by warmup / NemoV3+ (:3489-3491, :3870-3882): mean over (N*dim) of
  * (mask>0.5) * GMoF(x - target).  scalar_out += mean; d_x += scale * grad. */
 int32_t nemo_pose3d_fwd_bwd(int64_t N, int64_t dim, const float* x, int64_t ldx, const float* target,

@@ -31,7 +31,7 @@ SIGNATURES = {
     'nemo_phase_embed_fwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
                                    i32, ptr, i64, ptr, ptr]),
     'nemo_phase_embed_bwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i32, ptr,
-                                   ptr, i64, ptr, ptr, ptr, ptr, ptr]),
+                                   ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr]),
     'nemo_rot6d_fwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr]),
     'nemo_rot6d_bwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr]),
     'nemo_rotmat_to_aa': (i32, [i64, ptr, i32, ptr, ptr]),
@@ -60,7 +60,7 @@ SIGNATURES = {
     'nemo_v2v_prep_fwd': (i32, [i64, ptr, ptr, ptr, ptr, ptr]),
     'nemo_v2v_prep_bwd': (i32, [i64, ptr, ptr, f32, ptr, ptr, ptr]),
     'nemo_kl_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, i64, ptr]),
-    'nemo_gmm_fwd_bwd': (i32, [i64, i64, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, f32, ptr, i64, ptr]),
+    'nemo_gmm_fwd_bwd': (i32, [i64, i64, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, f32, ptr, i64, ptr]),
     'nemo_pose3d_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, f32, ptr, i64, ptr]),
     'nemo_adam_step': (i32, [i32, POINTER(AdamSeg), ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),
     'nemo_scale_neg_rowsum': (i32, [i64, i64, ptr, i64, ptr, ptr]),

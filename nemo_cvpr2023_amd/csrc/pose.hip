@@ -46,14 +46,16 @@ __device__ __forceinline__ float rbf_dphi(int id, float a) {
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
 
-// mean_k sigmoid(relu(sc_k) * (x - relu(sh_k)))      monotonic_network.py:23-31
-__device__ __forceinline__ float mono_pass(const float* __restrict__ sh, const float* __restrict__ sc,
-                                           int K, float x) {
-    float s = 0.f;
-    for (int k = 0; k < K; ++k) s += sigmoidf_(fmaxf(sc[k], 0.f) * (x - fmaxf(sh[k], 0.f)));
-    return s / (float)K;
+__device__ __forceinline__ float lin01(long i, long n) {
+    // torch.linspace(0, 1, n)[i]: start + i*step below the midpoint, end - (n-1-i)*step above
+    if (n <= 1) return 0.f;
+    const float step = 1.0f / (float)(n - 1);
+    return (i < n / 2) ? (float)i * step : 1.0f - (float)(n - 1 - i) * step;
 }
 
+// One wave per sample.  Lanes stride over the K nodes of the owning phase network (the three passes
+// x, 0, 1 of monotonic_network.py:23-39 share one sweep), wave-reduce, then stride over the D RBF
+// centres / C code entries of the MLP input row.
 __global__ __launch_bounds__(256) void phase_embed_fwd_kernel(
     long N, long V, long T, int K, int D, int C, const int64_t* __restrict__ view_idx,
     const int64_t* __restrict__ frame_idx, const float* __restrict__ raw_phase,
@@ -61,40 +63,38 @@ __global__ __launch_bounds__(256) void phase_embed_fwd_kernel(
     const float* __restrict__ log_sigmas, const float* __restrict__ codes,
     const float* __restrict__ code_noise, int kid, float* __restrict__ X, long ldx,
     float* __restrict__ phase_out) {
-    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > N) return;
+    const long s = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (s > N) return;                      // wave-uniform
     float ph = 0.f;
     long v = 0;
     if (s < N) {
         v = view_idx[s];
-        // torch.linspace(0, 1, T)[f]: start + f*step below the midpoint, end - (T-1-f)*step above
-        float x;
-        if (raw_phase) x = raw_phase[s];
-        else {
-            const long f = frame_idx[s];
-            const float step = T > 1 ? 1.0f / (float)(T - 1) : 0.f;
-            x = (f < T / 2) ? (float)f * step : 1.0f - (float)(T - 1 - f) * step;
-        }
+        const float x = raw_phase ? raw_phase[s] : lin01(frame_idx[s], T);
         const float* sh = shifts + v * ldp;
         const float* sc = scales + v * ldp;
-        const float y = mono_pass(sh, sc, K, x), z = mono_pass(sh, sc, K, 0.f), o = mono_pass(sh, sc, K, 1.f);
+        float y = 0.f, z = 0.f, o = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float shp = fmaxf(sh[k], 0.f), scp = fmaxf(sc[k], 0.f);
+            y += sigmoidf_(scp * (x - shp));
+            z += sigmoidf_(scp * (0.f - shp));
+            o += sigmoidf_(scp * (1.f - shp));
+        }
+        y = wave_sum(y) / (float)K; z = wave_sum(z) / (float)K; o = wave_sum(o) / (float)K;
         ph = (y - z) / (o - z + 1e-6f);                 // monotonic_network.py:33-39
-        if (phase_out) phase_out[s] = ph;
+        if (phase_out && lane == 0) phase_out[s] = ph;
     }
     float* xr = X + s * ldx;
     if (D > 0) {
-        for (int d = 0; d < D; ++d) {
-            const float c = D > 1 ? (d < D / 2 ? (float)d * (1.0f / (float)(D - 1))
-                                               : 1.0f - (float)(D - 1 - d) * (1.0f / (float)(D - 1)))
-                                  : 0.f;           // centres = linspace(0,1,D)  rbf.py:38-39
-            const float diff = ph - c;
+        for (int d = lane; d < D; d += 64) {
+            const float diff = ph - lin01(d, D);        // centres = linspace(0,1,D)  rbf.py:38-39
             xr[d] = rbf_phi(kid, (diff * diff) / expf(log_sigmas[d]));
         }
-    } else {
+    } else if (lane == 0) {
         xr[0] = ph;
     }
     const int off = D > 0 ? D : 1;
-    for (int c = 0; c < C; ++c) {
+    for (int c = lane; c < C; c += 64) {
         float cv = 0.f;
         if (s < N) {
             cv = codes[v * C + c];
@@ -104,71 +104,110 @@ __global__ __launch_bounds__(256) void phase_embed_fwd_kernel(
     }
 }
 
-// One thread per sample; parameter gradients reduced with atomics (the per-step volume is
-// N*(2K + D + C) adds into L2-resident accumulators).
-__global__ __launch_bounds__(256) void phase_embed_bwd_kernel(
-    long N, long V, long T, int K, int D, int C, const int64_t* __restrict__ view_idx,
+// Backward, stage A (one wave per sample): d phase = sum_d dX[s][d] d rbf_d / d phase, then the three
+// coefficients that multiply the per-node sigmoid derivatives of the y / z / o passes.
+// ws[s] = { x, dy/K, dz/K, do/K }.
+__global__ __launch_bounds__(256) void phase_bwd_sample_kernel(
+    long N, long T, int K, int D, const int64_t* __restrict__ view_idx,
     const int64_t* __restrict__ frame_idx, const float* __restrict__ raw_phase,
     const float* __restrict__ shifts, const float* __restrict__ scales, long ldp,
     const float* __restrict__ log_sigmas, int kid, const float* __restrict__ phase,
-    const float* __restrict__ dX, long ldx, float* __restrict__ d_shifts, float* __restrict__ d_scales,
-    float* __restrict__ d_log_sigmas, float* __restrict__ d_codes) {
-    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > N) return;
-    const float ph = s < N ? phase[s] : 0.f;
+    const float* __restrict__ dX, long ldx, float* __restrict__ ws) {
+    const long s = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (s >= N) return;
+    const float ph = phase[s];
     const float* g = dX + s * ldx;
     float dph = 0.f;
     if (D > 0) {
-        for (int d = 0; d < D; ++d) {
-            const float c = D > 1 ? (d < D / 2 ? (float)d * (1.0f / (float)(D - 1))
-                                               : 1.0f - (float)(D - 1 - d) * (1.0f / (float)(D - 1)))
-                                  : 0.f;
-            const float diff = ph - c;
+        for (int d = lane; d < D; d += 64) {
+            const float diff = ph - lin01(d, D);
             const float es = expf(log_sigmas[d]);
-            const float a = (diff * diff) / es;
-            const float da = g[d] * rbf_dphi(kid, a);
-            dph += da * 2.f * diff / es;
-            if (d_log_sigmas && da != 0.f) atomicAdd(d_log_sigmas + d, -da * a);   // d a / d log_sigma = -a
+            dph += g[d] * rbf_dphi(kid, (diff * diff) / es) * 2.f * diff / es;
         }
+        dph = wave_sum(dph);
     } else {
         dph = g[0];
     }
-    if (s == N) return;   // the phase-0 row has no phase network and a constant zero code
     const long v = view_idx[s];
-    const int off = D > 0 ? D : 1;
-    if (d_codes)
-        for (int c = 0; c < C; ++c) atomicAdd(d_codes + v * C + c, g[off + c]);
-    if (!d_shifts) return;
-    float x;
-    if (raw_phase) x = raw_phase[s];
-    else {
-        const long f = frame_idx[s];
-        const float step = T > 1 ? 1.0f / (float)(T - 1) : 0.f;
-        x = (f < T / 2) ? (float)f * step : 1.0f - (float)(T - 1 - f) * step;
-    }
+    const float x = raw_phase ? raw_phase[s] : lin01(frame_idx[s], T);
     const float* sh = shifts + v * ldp;
     const float* sc = scales + v * ldp;
-    const float y = mono_pass(sh, sc, K, x), z = mono_pass(sh, sc, K, 0.f), o = mono_pass(sh, sc, K, 1.f);
-    const float den = o - z + 1e-6f;
-    const float num = y - z;
-    // ph = num / den
-    const float dy = dph / den;
+    float y = 0.f, z = 0.f, o = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float shp = fmaxf(sh[k], 0.f), scp = fmaxf(sc[k], 0.f);
+        y += sigmoidf_(scp * (x - shp));
+        z += sigmoidf_(scp * (0.f - shp));
+        o += sigmoidf_(scp * (1.f - shp));
+    }
+    y = wave_sum(y) / (float)K; z = wave_sum(z) / (float)K; o = wave_sum(o) / (float)K;
+    const float den = o - z + 1e-6f, num = y - z;
+    const float dy = dph / den;                          // ph = num / den
     const float dden = -dph * num / (den * den);
-    const float dz = -dy - dden;
-    const float dob = dden;
-    const float invK = 1.f / (float)K;
-    for (int k = 0; k < K; ++k) {
-        const float shr = sh[k], scr = sc[k];
+    if (lane == 0) {
+        const float invK = 1.f / (float)K;
+        ws[s * 4 + 0] = x;
+        ws[s * 4 + 1] = dy * invK;
+        ws[s * 4 + 2] = (-dy - dden) * invK;
+        ws[s * 4 + 3] = dden * invK;
+    }
+}
+
+// Stage B: block (view v, sample chunk) -- threads own the nodes k; samples of other views are skipped
+// block-uniformly.  One atomic per (v, k, chunk): no same-address contention.
+__global__ __launch_bounds__(256) void phase_bwd_nodes_kernel(
+    long N, int K, long chunk, const int64_t* __restrict__ view_idx, const float* __restrict__ shifts,
+    const float* __restrict__ scales, long ldp, const float* __restrict__ ws,
+    float* __restrict__ d_shifts, float* __restrict__ d_scales) {
+    const long v = blockIdx.x;
+    const long s0 = (long)blockIdx.y * chunk, s1 = min(N, s0 + chunk);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float shr = shifts[v * ldp + k], scr = scales[v * ldp + k];
         const float shp = fmaxf(shr, 0.f), scp = fmaxf(scr, 0.f);
+        const float s0v = sigmoidf_(scp * (0.f - shp)), s1v = sigmoidf_(scp * (1.f - shp));
+        const float d0 = s0v * (1.f - s0v), d1 = s1v * (1.f - s1v);
         float gsh = 0.f, gsc = 0.f;
-        {   const float sg = sigmoidf_(scp * (x - shp)); const float w = dy * invK * sg * (1.f - sg);
-            gsc += w * (x - shp); gsh -= w * scp; }
-        {   const float sg = sigmoidf_(scp * (0.f - shp)); const float w = dz * invK * sg * (1.f - sg);
-            gsc += w * (0.f - shp); gsh -= w * scp; }
-        {   const float sg = sigmoidf_(scp * (1.f - shp)); const float w = dob * invK * sg * (1.f - sg);
-            gsc += w * (1.f - shp); gsh -= w * scp; }
+        for (long s = s0; s < s1; ++s) {
+            if (view_idx[s] != v) continue;
+            const float x = ws[s * 4], cy = ws[s * 4 + 1], cz = ws[s * 4 + 2], co = ws[s * 4 + 3];
+            const float sx = sigmoidf_(scp * (x - shp));
+            const float wy = cy * sx * (1.f - sx), wz = cz * d0, wo = co * d1;
+            gsc += wy * (x - shp) + wz * (0.f - shp) + wo * (1.f - shp);
+            gsh -= (wy + wz + wo) * scp;
+        }
         if (shr > 0.f && gsh != 0.f) atomicAdd(d_shifts + v * ldp + k, gsh);   // relu'(0) = 0 as in torch
         if (scr > 0.f && gsc != 0.f) atomicAdd(d_scales + v * ldp + k, gsc);
+    }
+}
+
+// Stage C: one block per reduced column.  blockIdx.x < D: d log_sigma_d over all N+1 rows;
+// otherwise (c, v): d code[v][c] over the samples of view v.
+__global__ __launch_bounds__(256) void phase_bwd_cols_kernel(
+    long N, long V, int D, int C, const int64_t* __restrict__ view_idx, const float* __restrict__ log_sigmas,
+    int kid, const float* __restrict__ phase, const float* __restrict__ dX, long ldx,
+    float* __restrict__ d_log_sigmas, float* __restrict__ d_codes) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    float acc = 0.f;
+    if (b < D) {
+        const int d = b;
+        const float es = expf(log_sigmas[d]), c = lin01(d, D);
+        for (long s = threadIdx.x; s <= N; s += blockDim.x) {
+            const float diff = (s < N ? phase[s] : 0.f) - c;
+            const float a = (diff * diff) / es;
+            acc -= dX[s * ldx + d] * rbf_dphi(kid, a) * a;      // d a / d log_sigma = -a
+        }
+        const float t = block_sum(acc, red);
+        if (threadIdx.x == 0 && d_log_sigmas) d_log_sigmas[d] += t;
+    } else {
+        const int idx = b - D;
+        const int c = idx % C;
+        const long v = idx / C;
+        const int off = D > 0 ? D : 1;
+        for (long s = threadIdx.x; s < N; s += blockDim.x)
+            if (view_idx[s] == v) acc += dX[s * ldx + off + c];
+        const float t = block_sum(acc, red);
+        if (threadIdx.x == 0) d_codes[v * C + c] += t;
     }
 }
 
@@ -330,9 +369,10 @@ extern "C" int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t
     if (N > 0 && (!view_idx || (!frame_idx && !raw_phase))) return NEMO_EINVAL;
     if ((D > 0 && !log_sigmas) || (C > 0 && !codes) || kernel_id < 0 || kernel_id > 10) return NEMO_EINVAL;
     if (ldx < (D > 0 ? D : 1) + C || ldp < K) return NEMO_EINVAL;
-    hipLaunchKernelGGL(phase_embed_fwd_kernel, GRID1D(N + 1), (long)N, (long)V, (long)T, (int)K, (int)D,
-                       (int)C, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp, log_sigmas, codes, code_noise,
-                       (int)kernel_id, X, (long)ldx, phase_out);
+    hipLaunchKernelGGL(phase_embed_fwd_kernel, dim3(nemo_cdiv(N + 1, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (long)N, (long)V, (long)T, (int)K, (int)D, (int)C, view_idx, frame_idx, raw_phase,
+                       shifts, scales, (long)ldp, log_sigmas, codes, code_noise, (int)kernel_id, X, (long)ldx,
+                       phase_out);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -340,15 +380,33 @@ extern "C" int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t
 extern "C" int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
                                         const int64_t* view_idx, const int64_t* frame_idx,
                                         const float* raw_phase, const float* shifts, const float* scales,
-                                        int64_t ldp, const float* log_sigmas, int32_t kernel_id, const float* phase,
-                                        const float* dX, int64_t ldx, float* d_shifts, float* d_scales,
-                                        float* d_log_sigmas, float* d_codes, void* stream) {
+                                        int64_t ldp, const float* log_sigmas, int32_t kernel_id,
+                                        const float* phase, const float* dX, int64_t ldx, float* ws,
+                                        float* d_shifts, float* d_scales, float* d_log_sigmas,
+                                        float* d_codes, void* stream) {
     if (N < 0 || V <= 0 || K <= 0 || D < 0 || C < 0 || !dX || !shifts || !scales || !phase) return NEMO_EINVAL;
     if ((d_shifts == nullptr) != (d_scales == nullptr)) return NEMO_EINVAL;
-    hipLaunchKernelGGL(phase_embed_bwd_kernel, GRID1D(N + 1), (long)N, (long)V, (long)T, (int)K, (int)D,
-                       (int)C, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp, log_sigmas, (int)kernel_id,
-                       phase, dX, (long)ldx, d_shifts, d_scales, d_log_sigmas, d_codes);
-    NEMO_LAUNCH_CHECK();
+    if (d_shifts && N > 0 && !ws) return NEMO_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (d_shifts && N > 0) {
+        hipLaunchKernelGGL(phase_bwd_sample_kernel, dim3(nemo_cdiv(N, 4)), dim3(256), 0, st, (long)N, (long)T,
+                           (int)K, (int)D, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp,
+                           log_sigmas, (int)kernel_id, phase, dX, (long)ldx, ws);
+        NEMO_LAUNCH_CHECK();
+        const long chunk = 512;
+        hipLaunchKernelGGL(phase_bwd_nodes_kernel, dim3((unsigned)V, nemo_cdiv(N, chunk)), dim3(256), 0, st,
+                           (long)N, (int)K, chunk, view_idx, shifts, scales, (long)ldp, ws, d_shifts, d_scales);
+        NEMO_LAUNCH_CHECK();
+    }
+    const long nblk = (d_log_sigmas ? D : 0) + (d_codes ? V * C : 0);
+    if (nblk > 0) {
+        // blocks [0, D) reduce log_sigma columns; if d_log_sigmas is NULL they are still launched as
+        // no-ops so that the block -> column map stays fixed
+        hipLaunchKernelGGL(phase_bwd_cols_kernel, dim3((unsigned)(D + (d_codes ? V * C : 0))), dim3(256), 0, st,
+                           (long)N, (long)V, (int)D, (int)C, view_idx, log_sigmas, (int)kernel_id, phase, dX,
+                           (long)ldx, d_log_sigmas, d_codes);
+        NEMO_LAUNCH_CHECK();
+    }
     return NEMO_OK;
 }
 

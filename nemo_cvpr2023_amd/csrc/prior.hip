@@ -32,70 +32,95 @@ __global__ __launch_bounds__(256) void kl_kernel(long N, int L, const float* __r
     if (threadIdx.x == 0) atomicAdd(out, t * invN);
 }
 
-// MaxMixturePrior.  One thread per sample; the precision matrices are wave-uniform operands
-// (scalar loads), the sample's pose lives in LDS transposed ([dim][64]) so that x_i for a runtime i
-// is a conflict-free LDS read instead of a dynamically indexed register.
-template <int DIM>
-__global__ __launch_bounds__(64) void gmm_kernel(long N, int M, const float* __restrict__ x, long ldx,
-                                                 const float* __restrict__ means,
-                                                 const float* __restrict__ prec,
-                                                 const float* __restrict__ log_nllw, float* __restrict__ out,
-                                                 float* __restrict__ per_sample, float scale,
-                                                 float* __restrict__ dx, long lddx) {
-    __shared__ float xs[DIM][64];
-    __shared__ float ys[DIM][64];
-    __shared__ float red[16];
-    const int tid = threadIdx.x;
-    const long s = (long)blockIdx.x * 64 + tid;
-    const bool live = s < N;
-    for (int i = 0; i < DIM; ++i) xs[i][tid] = live ? x[s * ldx + i] : 0.f;
-    float best = 0.f;
-    int best_m = 0;
-    for (int m = 0; m < M; ++m) {
-        const float* mu = means + m * DIM;
-        const float* P = prec + (long)m * DIM * DIM;
-        float d[DIM];
-#pragma unroll
-        for (int j = 0; j < DIM; ++j) d[j] = xs[j][tid] - mu[j];
-        float qf = 0.f;
-        for (int i = 0; i < DIM; ++i) {
-            float y = 0.f;
-#pragma unroll
-            for (int j = 0; j < DIM; ++j) y += P[i * DIM + j] * d[j];     // einsum('mij,bmj->bmi')
-            qf += y * (xs[i][tid] - mu[i]);
-        }
-        const float ll = 0.5f * qf - log_nllw[m];
-        if (m == 0 || ll < best) { best = ll; best_m = m; }
+// MaxMixturePrior.  Grid = (sample blocks of 128, mixture components): a block owns ONE component,
+// stages its 69x69 precision matrix in LDS (rows padded to 72 floats so the broadcast reads are
+// ds_read_b128) and the poses of its 128 samples transposed ([dim][128], conflict-free).  Every lane
+// then runs the 69x69 quadratic form with LDS-broadcast operands.  Pass 1 writes the per-component
+// log-likelihoods, pass 2 picks the arg-min and back-propagates only through the selected component.
+#define GMM_TS 128
+template <int DIM, bool SYM>
+__device__ __forceinline__ void gmm_stage(const float* __restrict__ P, float (*Ps)[72]) {
+    for (int idx = threadIdx.x; idx < DIM * DIM; idx += GMM_TS) {
+        const int i = idx / DIM, j = idx % DIM;
+        Ps[i][j] = SYM ? 0.5f * (P[i * DIM + j] + P[j * DIM + i]) : P[i * DIM + j];
     }
-    if (per_sample && live) per_sample[s] = best;
-    const float tot = block_sum(live ? best : 0.f, red);
-    if (tid == 0) atomicAdd(out, tot / (float)N);
-    if (!dx) return;
-    // gradient of the selected component: 0.5 (P + P^T) d / N
-    const float coef = 0.5f * scale / (float)N;
-    for (int m = 0; m < M; ++m) {
-        // wave-uniform skip when no lane selected this component
-        if (__ballot(live && best_m == m) == 0ull) continue;
-        const float* mu = means + m * DIM;
-        const float* P = prec + (long)m * DIM * DIM;
-        float d[DIM], yt[DIM];
+}
+
+template <int DIM>
+__global__ __launch_bounds__(GMM_TS) void gmm_ll_kernel(long N, int M, const float* __restrict__ x, long ldx,
+                                                        const float* __restrict__ means,
+                                                        const float* __restrict__ prec,
+                                                        const float* __restrict__ log_nllw,
+                                                        float* __restrict__ ll) {
+    __shared__ __attribute__((aligned(16))) float Ps[DIM][72];
+    __shared__ float xs[DIM][GMM_TS];
+    const int tid = threadIdx.x, m = blockIdx.y;
+    const long s = (long)blockIdx.x * GMM_TS + tid;
+    const bool live = s < N;
+    gmm_stage<DIM, false>(prec + (long)m * DIM * DIM, Ps);
+    const float* mu = means + m * DIM;
+    for (int i = 0; i < DIM; ++i) xs[i][tid] = (live ? x[s * ldx + i] : 0.f) - mu[i];
+    __syncthreads();
+    float d[DIM];
 #pragma unroll
-        for (int j = 0; j < DIM; ++j) { d[j] = xs[j][tid] - mu[j]; yt[j] = 0.f; }
-        for (int i = 0; i < DIM; ++i) {
-            float y = 0.f;
-            const float di = xs[i][tid] - mu[i];
+    for (int j = 0; j < DIM; ++j) d[j] = xs[j][tid];
+    float qf = 0.f;
+    for (int i = 0; i < DIM; ++i) {
+        float y = 0.f;
 #pragma unroll
-            for (int j = 0; j < DIM; ++j) {
-                const float p = P[i * DIM + j];
-                y += p * d[j];
-                yt[j] += p * di;
-            }
-            ys[i][tid] = y;
+        for (int j = 0; j < DIM; ++j) y += Ps[i][j] * d[j];       // einsum('mij,bmj->bmi'), prior.py:184
+        qf += y * xs[i][tid];
+    }
+    if (live) ll[s * M + m] = 0.5f * qf - log_nllw[m];
+}
+
+template <int DIM>
+__global__ __launch_bounds__(GMM_TS) void gmm_grad_kernel(long N, int M, const float* __restrict__ x, long ldx,
+                                                          const float* __restrict__ means,
+                                                          const float* __restrict__ prec,
+                                                          const float* __restrict__ ll,
+                                                          float* __restrict__ out,
+                                                          float* __restrict__ per_sample, float coef,
+                                                          float* __restrict__ dx, long lddx) {
+    __shared__ __attribute__((aligned(16))) float Ps[DIM][72];
+    __shared__ float xs[DIM][GMM_TS];
+    __shared__ float red[16];
+    __shared__ int any_sel;
+    const int tid = threadIdx.x, m = blockIdx.y;
+    const long s = (long)blockIdx.x * GMM_TS + tid;
+    const bool live = s < N;
+    float best = 0.f;
+    int best_m = -1;
+    if (live) {
+        best = ll[s * M]; best_m = 0;
+        for (int k = 1; k < M; ++k) {                         // torch.min: first minimum wins
+            const float v = ll[s * M + k];
+            if (v < best) { best = v; best_m = k; }
         }
-        if (live && best_m == m) {
+    }
+    if (tid == 0) any_sel = 0;
+    __syncthreads();
+    if (m == 0) {                                             // loss value: one block row does it
+        if (per_sample && live) per_sample[s] = best;
+        const float tot = block_sum(live ? best : 0.f, red);
+        if (tid == 0) atomicAdd(out, tot / (float)N);
+    }
+    const bool mine = live && best_m == m;
+    if (mine) any_sel = 1;
+    __syncthreads();
+    if (!dx || !any_sel) return;                              // block-uniform
+    gmm_stage<DIM, true>(prec + (long)m * DIM * DIM, Ps);     // 0.5 (P + P^T): adjoint of d^T P d / 2
+    const float* mu = means + m * DIM;
+    for (int i = 0; i < DIM; ++i) xs[i][tid] = (live ? x[s * ldx + i] : 0.f) - mu[i];
+    __syncthreads();
+    float d[DIM];
 #pragma unroll
-            for (int j = 0; j < DIM; ++j) dx[s * lddx + j] += coef * (ys[j][tid] + yt[j]);
-        }
+    for (int j = 0; j < DIM; ++j) d[j] = xs[j][tid];
+    for (int i = 0; i < DIM; ++i) {
+        float y = 0.f;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) y += Ps[i][j] * d[j];
+        if (mine) dx[s * lddx + i] += coef * y;
     }
 }
 
@@ -172,13 +197,18 @@ extern "C" int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int6
 
 extern "C" int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const float* x, int64_t ldx,
                                     const float* means, const float* precisions, const float* log_nllw,
-                                    float* scalar_out, float* per_sample, float scale, float* d_x,
+                                    float* ws, float* scalar_out, float* per_sample, float scale, float* d_x,
                                     int64_t lddx, void* stream) {
-    if (N <= 0 || M <= 0 || !x || !means || !precisions || !log_nllw || !scalar_out || ldx < dim) return NEMO_EINVAL;
+    if (N <= 0 || M <= 0 || !x || !means || !precisions || !log_nllw || !scalar_out || !ws || ldx < dim)
+        return NEMO_EINVAL;
     if (dim != 69) return NEMO_EINVAL;   // SMPL body pose (23 joints x 3), prior.py:150
     if (d_x && lddx < dim) return NEMO_EINVAL;
-    hipLaunchKernelGGL(gmm_kernel<69>, dim3(nemo_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, (long)N,
-                       (int)M, x, (long)ldx, means, precisions, log_nllw, scalar_out, per_sample, scale, d_x,
+    dim3 grid(nemo_cdiv(N, GMM_TS), (unsigned)M);
+    hipLaunchKernelGGL(gmm_ll_kernel<69>, grid, dim3(GMM_TS), 0, (hipStream_t)stream, (long)N, (int)M, x,
+                       (long)ldx, means, precisions, log_nllw, ws);
+    NEMO_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gmm_grad_kernel<69>, grid, dim3(GMM_TS), 0, (hipStream_t)stream, (long)N, (int)M, x,
+                       (long)ldx, means, precisions, ws, scalar_out, per_sample, scale / (float)N, d_x,
                        (long)lddx);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;

@@ -187,79 +187,90 @@ extern "C" const float* nemo_ctx_v_shaped(const nemo_ctx* c) { return c ? c->d_v
 namespace {
 
 // ------------------------------------------------------------------------------------------ FK
-// One thread per body.  The chain state lives in the output buffers themselves (A holds G_R in
-// its 3x3 block, Jp holds G_t): each thread re-reads only what it wrote, so no LDS is needed.
-__global__ __launch_bounds__(128) void fk_fwd_kernel(long rows, const float* __restrict__ R,
-                                                     const float* __restrict__ Jrest, KpConst kc,
-                                                     float* A, float* Jp, float* __restrict__ PF) {
-    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// One thread per body, 64 bodies per block.  The kinematic chain is inherently sequential (depth <= 9
+// in SMPL, 23 dependent 3x3 products); its state lives in LDS as [joint*12 + e][lane] (conflict-free,
+// 72 KB per block, opted in as dynamic LDS) so that parent transforms are re-read at LDS latency
+// instead of a global store -> load round trip per joint.
+#define FK_TB 64
+#define FK_LDS_BYTES (24 * 12 * FK_TB * (int)sizeof(float))
+
+__global__ __launch_bounds__(FK_TB) void fk_fwd_kernel(long rows, const float* __restrict__ R,
+                                                       const float* __restrict__ Jrest, KpConst kc,
+                                                       float* __restrict__ A, float* __restrict__ Jp,
+                                                       float* __restrict__ PF) {
+    extern __shared__ float G[];          // G[(j*12 + e) * FK_TB + lane]: e<9 rotation, e>=9 translation
+    const int lane = threadIdx.x;
+    const long row = (long)blockIdx.x * FK_TB + lane;
     if (row >= rows) return;
     const float* Rr = R + row * 216;
     float* Ar = A + row * 288;
     float* Jr = Jp + row * 72;
-    {
-        float G[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) G[k] = Rr[k];
-        const float j0[3] = {Jrest[0], Jrest[1], Jrest[2]};
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            Ar[r * 4 + 0] = G[r * 3]; Ar[r * 4 + 1] = G[r * 3 + 1]; Ar[r * 4 + 2] = G[r * 3 + 2];
-            Ar[r * 4 + 3] = j0[r] - (G[r * 3] * j0[0] + G[r * 3 + 1] * j0[1] + G[r * 3 + 2] * j0[2]);
-            Jr[r] = j0[r];
-        }
-    }
-    for (int i = 1; i < 24; ++i) {
-        const int p = kc.parents[i];
-        float Gp[9], Ri[9], G[9];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) Gp[r * 3 + c] = Ar[p * 12 + r * 4 + c];
+#define GL(j, e) G[((j) * 12 + (e)) * FK_TB + lane]
+    for (int i = 0; i < 24; ++i) {
+        float Ri[9], Gi[9], gt[3];
 #pragma unroll
         for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
         const float ji[3] = {Jrest[i * 3], Jrest[i * 3 + 1], Jrest[i * 3 + 2]};
-        const float rel[3] = {ji[0] - Jrest[p * 3], ji[1] - Jrest[p * 3 + 1], ji[2] - Jrest[p * 3 + 2]};
+        if (i == 0) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int k = 0; k < 9; ++k) Gi[k] = Ri[k];
+            gt[0] = ji[0]; gt[1] = ji[1]; gt[2] = ji[2];
+        } else {
+            const int p = kc.parents[i];
+            float Gp[9];
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                G[r * 3 + c] = Gp[r * 3] * Ri[c] + Gp[r * 3 + 1] * Ri[3 + c] + Gp[r * 3 + 2] * Ri[6 + c];
+            for (int k = 0; k < 9; ++k) Gp[k] = GL(p, k);
+            const float rel[3] = {ji[0] - Jrest[p * 3], ji[1] - Jrest[p * 3 + 1], ji[2] - Jrest[p * 3 + 2]};
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    Gi[r * 3 + c] = Gp[r * 3] * Ri[c] + Gp[r * 3 + 1] * Ri[3 + c] + Gp[r * 3 + 2] * Ri[6 + c];
+                gt[r] = Gp[r * 3] * rel[0] + Gp[r * 3 + 1] * rel[1] + Gp[r * 3 + 2] * rel[2] + GL(p, 9 + r);
+            }
+            if (PF) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) PF[row * 207 + (i - 1) * 9 + k] = Ri[k] - ((k % 4 == 0) ? 1.f : 0.f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) GL(i, k) = Gi[k];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float gt = Gp[r * 3] * rel[0] + Gp[r * 3 + 1] * rel[1] + Gp[r * 3 + 2] * rel[2] + Jr[p * 3 + r];
-            Jr[i * 3 + r] = gt;
-            Ar[i * 12 + r * 4 + 0] = G[r * 3]; Ar[i * 12 + r * 4 + 1] = G[r * 3 + 1];
-            Ar[i * 12 + r * 4 + 2] = G[r * 3 + 2];
-            Ar[i * 12 + r * 4 + 3] = gt - (G[r * 3] * ji[0] + G[r * 3 + 1] * ji[1] + G[r * 3 + 2] * ji[2]);
-        }
-        if (PF) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) PF[row * 207 + (i - 1) * 9 + k] = Ri[k] - ((k % 4 == 0) ? 1.f : 0.f);
+            GL(i, 9 + r) = gt[r];
+            Jr[i * 3 + r] = gt[r];
+            Ar[i * 12 + r * 4 + 0] = Gi[r * 3]; Ar[i * 12 + r * 4 + 1] = Gi[r * 3 + 1];
+            Ar[i * 12 + r * 4 + 2] = Gi[r * 3 + 2];
+            Ar[i * 12 + r * 4 + 3] = gt[r] - (Gi[r * 3] * ji[0] + Gi[r * 3 + 1] * ji[1] + Gi[r * 3 + 2] * ji[2]);
         }
     }
+#undef GL
 }
 
-__global__ __launch_bounds__(128) void fk_bwd_kernel(long rows, const float* __restrict__ R,
-                                                     const float* __restrict__ A,
-                                                     const float* __restrict__ Jrest, KpConst kc, float* dA,
-                                                     const float* __restrict__ dJp,
-                                                     const float* __restrict__ dPF, float* __restrict__ dR) {
-    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(FK_TB) void fk_bwd_kernel(long rows, const float* __restrict__ R,
+                                                       const float* __restrict__ A,
+                                                       const float* __restrict__ Jrest, KpConst kc,
+                                                       const float* __restrict__ dA,
+                                                       const float* __restrict__ dJp,
+                                                       const float* __restrict__ dPF, float* __restrict__ dR) {
+    extern __shared__ float D[];          // dG accumulators: [(j*12 + r*4 + c) * FK_TB + lane]
+    const int lane = threadIdx.x;
+    const long row = (long)blockIdx.x * FK_TB + lane;
     if (row >= rows) return;
     const float* Rr = R + row * 216;
     const float* Ar = A + row * 288;
-    float* D = dA + row * 288;     // becomes dG in place: [dG_R (3x3 in the 3x4 block) | dG_t (col 3)]
-    // dA -> dG:  A_t = G_t - G_R J  =>  dG_R -= dA_t (x) J ;  dG_t = dA_t (+ dJp)
+#define DL(j, e) D[((j) * 12 + (e)) * FK_TB + lane]
+    // dA -> dG:  A_t = G_t - G_R J  =>  dG_R = dA_R - dA_t (x) J ;  dG_t = dA_t (+ dJp)
     for (int i = 0; i < 24; ++i) {
         const float ji[3] = {Jrest[i * 3], Jrest[i * 3 + 1], Jrest[i * 3 + 2]};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const float dat = D[i * 12 + r * 4 + 3];
-            D[i * 12 + r * 4 + 0] -= dat * ji[0];
-            D[i * 12 + r * 4 + 1] -= dat * ji[1];
-            D[i * 12 + r * 4 + 2] -= dat * ji[2];
-            if (dJp) D[i * 12 + r * 4 + 3] = dat + dJp[row * 72 + i * 3 + r];
+            const float* src = dA + row * 288 + i * 12 + r * 4;
+            const float dat = src[3];
+            DL(i, r * 4 + 0) = src[0] - dat * ji[0];
+            DL(i, r * 4 + 1) = src[1] - dat * ji[1];
+            DL(i, r * 4 + 2) = src[2] - dat * ji[2];
+            DL(i, r * 4 + 3) = dat + (dJp ? dJp[row * 72 + i * 3 + r] : 0.f);
         }
     }
     for (int i = 23; i >= 1; --i) {
@@ -270,9 +281,9 @@ __global__ __launch_bounds__(128) void fk_bwd_kernel(long rows, const float* __r
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 Gp[r * 3 + c] = Ar[p * 12 + r * 4 + c];
-                dG[r * 3 + c] = D[i * 12 + r * 4 + c];
+                dG[r * 3 + c] = DL(i, r * 4 + c);
             }
-            dgt[r] = D[i * 12 + r * 4 + 3];
+            dgt[r] = DL(i, r * 4 + 3);
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
@@ -292,15 +303,16 @@ __global__ __launch_bounds__(128) void fk_bwd_kernel(long rows, const float* __r
         for (int r = 0; r < 3; ++r) {
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                D[p * 12 + r * 4 + c] += dG[r * 3] * Ri[c * 3] + dG[r * 3 + 1] * Ri[c * 3 + 1] +
-                                         dG[r * 3 + 2] * Ri[c * 3 + 2] + dgt[r] * rel[c];
-            D[p * 12 + r * 4 + 3] += dgt[r];
+                DL(p, r * 4 + c) += dG[r * 3] * Ri[c * 3] + dG[r * 3 + 1] * Ri[c * 3 + 1] +
+                                    dG[r * 3 + 2] * Ri[c * 3 + 2] + dgt[r] * rel[c];
+            DL(p, r * 4 + 3) += dgt[r];
         }
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) dR[row * 216 + r * 3 + c] = D[r * 4 + c];
+        for (int c = 0; c < 3; ++c) dR[row * 216 + r * 3 + c] = DL(0, r * 4 + c);
+#undef DL
 }
 
 // ------------------------------------------------------------------------------------------ KP
@@ -522,30 +534,43 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
         atomicAdd(dJp + s * 72 + kind * 3 + 1, dpos[1]);
         atomicAdd(dJp + s * 72 + kind * 3 + 2, dpos[2]);
     }
-    // mesh functionals: pos = sum_j A_R[j] Mq[q][j] + A_t[j] w0[q][j]
+    // mesh functionals: pos = sum_j A_R[j] Mq[q][j] + A_t[j] w0[q][j].
+    // d Mq[q][j] = A_R[j]^T dpos_q is private to the (sample, joint) lane; dA[j] sums over the mesh
+    // joints of the sample: stage dpos in LDS and let every thread own output entries of dA.
+    __shared__ float dps[256 / LANES][NEMO_MAX_OUT][3];
+    __shared__ int qof[256 / LANES][NEMO_MAX_OUT];
+    const int sl = threadIdx.x / LANES;
     const bool mesh = active && kind < 0;
-    const int q = mesh ? -kind - 1 : 0;
-    for (int j = 0; j < 24; ++j) {
-        float m[3] = {0.f, 0.f, 0.f}, wj = 0.f;
-        if (mesh) {
-            const float* M = a.Mq + s * a.ldq + q * 72 + j * 3;
-            m[0] = M[0]; m[1] = M[1]; m[2] = M[2];
-            wj = a.w0[q * 24 + j];
+    if (o < NEMO_MAX_OUT) {
+        dps[sl][o][0] = mesh ? dpos[0] : 0.f; dps[sl][o][1] = mesh ? dpos[1] : 0.f; dps[sl][o][2] = mesh ? dpos[2] : 0.f;
+        qof[sl][o] = mesh ? (-kind - 1) : -1;
+    }
+    if (mesh) {
+        const int q = -kind - 1;
+        for (int j = 0; j < 24; ++j) {
             const float* Aj = a.A + s * 288 + j * 12;
             float* dM = dMq + s * a.ldq + q * 72 + j * 3;
             dM[0] = Aj[0] * dpos[0] + Aj[4] * dpos[1] + Aj[8] * dpos[2];
             dM[1] = Aj[1] * dpos[0] + Aj[5] * dpos[1] + Aj[9] * dpos[2];
             dM[2] = Aj[2] * dpos[0] + Aj[6] * dpos[1] + Aj[10] * dpos[2];
         }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            float e0 = dpos[r] * m[0], e1 = dpos[r] * m[1], e2 = dpos[r] * m[2], e3 = dpos[r] * wj;
-            if (LANES == 32) { e0 = group32_sum(e0); e1 = group32_sum(e1); e2 = group32_sum(e2); e3 = group32_sum(e3); }
-            if (live && o == 0) {
-                float* d = dA + s * 288 + j * 12 + r * 4;
-                d[0] = e0; d[1] = e1; d[2] = e2; d[3] = e3;
-            }
+    }
+    __syncthreads();
+    constexpr int SPB = 256 / LANES;                  // samples per block
+    const long sbase = (long)blockIdx.x * SPB;
+    for (int idx = threadIdx.x; idx < SPB * 288; idx += 256) {
+        const int ls = idx / 288, e = idx % 288;
+        const long ss = sbase + ls;
+        if (ss >= a.N) continue;
+        const int j = e / 12, r = (e % 12) / 4, c = e % 4;
+        float acc = 0.f;
+        for (int oo = 0; oo < kc.n_out; ++oo) {
+            const int q = qof[ls][oo];
+            if (q < 0) continue;
+            const float m = c < 3 ? a.Mq[ss * a.ldq + q * 72 + j * 3 + c] : a.w0[q * 24 + j];
+            acc += dps[ls][oo][r] * m;
         }
+        dA[ss * 288 + e] = acc;
     }
 }
 
@@ -604,8 +629,11 @@ __global__ __launch_bounds__(256) void skin_vertices_kernel(long rows, long NV, 
 }
 
 // VPoser v2v term.  Block = S bodies (orig row s, reconstruction row N+s) x all vertices in chunks of
-// 256.  Forward skinning on the VALU with the transforms in SGPRs; d(sum|.|)/dA reduced over the
-// vertices on the matrix cores: dA[j][e] = sum_v W[v][j] dT[v][e]  (16x16x4 f32 MFMA, K = vertices).
+// 256.  Forward skinning on the VALU: the per-vertex weights sit in LDS (stride 25, conflict-free),
+// the block-uniform 3x4 transforms are streamed joint by joint through SGPRs (a runtime j loop keeps
+// the scalar live ranges short -- fully unrolling it made the compiler spill ~1700 SGPRs into VGPR
+// lanes).  d(sum|.|)/dA is reduced over the vertices on the matrix cores:
+// dA[j][e] = sum_v W[v][j] dT[v][e]  (16x16x4 f32 MFMA, K = vertices).
 template <int S>
 __global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const float* __restrict__ VP,
                                                           long ldvp, const float* __restrict__ A,
@@ -636,9 +664,6 @@ __global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const
 #pragma unroll
         for (int j = 0; j < 24; ++j) Wl[tid][j] = valid ? Wt[j * NV + v] : 0.f;
         __syncthreads();
-        float w[24];
-#pragma unroll
-        for (int j = 0; j < 24; ++j) w[j] = Wl[tid][j];
         // A-operand fragments: Aop[i = joint][k = vertex] = W[vertex][joint]
         float af[16][2];
 #pragma unroll
@@ -656,13 +681,15 @@ __global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const
             float To[12], Tr[12];
 #pragma unroll
             for (int e = 0; e < 12; ++e) { To[e] = 0.f; Tr[e] = 0.f; }
-#pragma unroll
-            for (int j = 0; j < 24; ++j)
+#pragma unroll 2
+            for (int j = 0; j < 24; ++j) {
+                const float wj = Wl[tid][j];
 #pragma unroll
                 for (int e = 0; e < 12; ++e) {
-                    To[e] += w[j] * Ao[j * 12 + e];
-                    Tr[e] += w[j] * Ar[j * 12 + e];
+                    To[e] += wj * Ao[j * 12 + e];
+                    Tr[e] += wj * Ar[j * 12 + e];
                 }
+            }
             float po[3] = {0.f, 0.f, 0.f}, pr[3] = {0.f, 0.f, 0.f};
             if (valid) {
                 const float* a = VP + s * ldvp + v * 3;
@@ -733,18 +760,30 @@ extern "C" int32_t nemo_fk_fwd(const nemo_ctx* ctx, int64_t rows, const float* R
                                float* PF, void* stream) {
     if (!ctx || rows < 0 || !R || !A || !Jp) return NEMO_EINVAL;
     if (rows == 0) return NEMO_OK;
-    hipLaunchKernelGGL(fk_fwd_kernel, dim3(nemo_cdiv(rows, 128)), dim3(128), 0, (hipStream_t)stream,
-                       (long)rows, R, ctx->d_Jrest, ctx->kc, A, Jp, PF);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)fk_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   FK_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fk_fwd_kernel, dim3(nemo_cdiv(rows, FK_TB)), dim3(FK_TB), FK_LDS_BYTES,
+                       (hipStream_t)stream, (long)rows, R, ctx->d_Jrest, ctx->kc, A, Jp, PF);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
 
-extern "C" int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R, const float* A, float* dA,
-                               const float* dJp, const float* dPF, float* dR, void* stream) {
+extern "C" int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R, const float* A,
+                               const float* dA, const float* dJp, const float* dPF, float* dR, void* stream) {
     if (!ctx || rows < 0 || !R || !A || !dA || !dR) return NEMO_EINVAL;
     if (rows == 0) return NEMO_OK;
-    hipLaunchKernelGGL(fk_bwd_kernel, dim3(nemo_cdiv(rows, 128)), dim3(128), 0, (hipStream_t)stream,
-                       (long)rows, R, A, ctx->d_Jrest, ctx->kc, dA, dJp, dPF, dR);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)fk_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   FK_LDS_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fk_bwd_kernel, dim3(nemo_cdiv(rows, FK_TB)), dim3(FK_TB), FK_LDS_BYTES,
+                       (hipStream_t)stream, (long)rows, R, A, ctx->d_Jrest, ctx->kc, dA, dJp, dPF, dR);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

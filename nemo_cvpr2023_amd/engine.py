@@ -226,7 +226,7 @@ class FitEngine:
         Nc = min(N, 8192)
         w = dict(
             X=Z(N + 1, self.din), H1=Z(N + 1, h), H2=Z(N + 1, h), H3=Z(N + 1, h), ROT=Z(N + 1, 144),
-            TR=Z(N + 1, 3), phase=Z(N), R=Z(N, 24, 9), AA=Z(N, 72), A=Z(N, 24, 12), Jp=Z(N, 24, 3),
+            TR=Z(N + 1, 3), phase=Z(N), phase_ws=Z(N, 4), gmm_ws=Z(N, self.gmm['M']), R=Z(N, 24, 9), AA=Z(N, 72), A=Z(N, 24, 12), Jp=Z(N, 24, 3),
             PF=Z(N, 207), Mq=Z(N, max(nq * 72, 1)), j3d=Z(N, self.ctx.n_out, 3), p2d=Z(N, self.ctx.n_out, 2),
             loss_all=Z(N, self.ctx.n_out, 2), view_acc=Z(self.V, 2), norm=Z(1),
             E1=Z(N, 512), E2=Z(N, 512), E3=Z(N, 512), MULV=Z(N, 64), D1=Z(N, 512), D2=Z(N, 512),
@@ -449,7 +449,8 @@ class FitEngine:
             N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
             self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), 2 * self.K,
             self.p('phase_rbf.log_sigmas') if self.D > 0 else None, self.kernel_id, dptr(w['phase']),
-            dptr(w['dX']), self.din, self.g('phase_networks.0.shifts'), self.g('phase_networks.0.scales'),
+            dptr(w['dX']), self.din, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
+            self.g('phase_networks.0.scales'),
             self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
             self.g('learned_instance_code') if self.C > 0 else None, st), 'nemo_phase_embed_bwd')
 

@@ -395,7 +395,8 @@ class MultiViewModel(nn.Module):
             e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss))
             g = e.gmm
             check(e.lib.nemo_gmm_fwd_bwd(N, g['M'], 69, aa69, 72, dptr(g['means']), dptr(g['prec']),
-                                         dptr(g['log_nllw']), e.scal.data_ptr() + 4 * S_GMM, None,
+                                         dptr(g['log_nllw']), dptr(w['gmm_ws']),
+                                         e.scal.data_ptr() + 4 * S_GMM, None,
                                          float(a.weight_gmm_loss) * sh.mr,
                                          daa69 if (update and a.weight_gmm_loss) else None, 72, st),
                   'nemo_gmm_fwd_bwd')

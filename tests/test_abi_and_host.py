@@ -41,7 +41,8 @@ def test_argument_validation_without_gpu():
 def test_param_layout_matches_reference_optimizer_order():
     from nemo_cvpr2023_amd.engine import ParamLayout
     lay = ParamLayout(V=3, K=20, D=16, C=5, h=48, din=21)
-    assert list(lay.groups) == ['cameras', 'motion', 'phase', 'instance']
+    # 'comm' = 8 floats that ride the shared-gradient all-reduce; no optimiser owns them
+    assert list(lay.groups) == ['cameras', 'motion', 'comm', 'phase', 'instance']
     assert lay.groups['motion'] == [
         'learned_motion.net.net.0.weight', 'learned_motion.net.net.0.bias',
         'learned_motion.net.net.2.weight', 'learned_motion.net.net.2.bias',
@@ -58,6 +59,8 @@ def test_param_layout_matches_reference_optimizer_order():
     assert end == lay.total
     a, b = lay.span(lay.groups['motion'])
     assert b - a == 48 * 21 + 48 + 2 * (48 * 48 + 48) + 144 * 48 + 144 + 3 * 48 + 3 + 16
+    a2, b2 = lay.span(lay.groups['motion'] + lay.groups['comm'])
+    assert (a2, b2) == (a, b + 8)          # one contiguous all-reduce slice
 
 
 def test_product_never_imports_oracle():

@@ -220,7 +220,8 @@ def test_phase_embed_vs_oracle(L, kern):
     gls, gco = torch.zeros(D, device='cuda'), torch.zeros(V, C, device='cuda')
     assert L.nemo_phase_embed_bwd(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
                                   pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), kid, phd.data_ptr(),
-                                  H.dev(ct).data_ptr(), D + C, gpn.data_ptr(), gpn.data_ptr() + 4 * K,
+                                  H.dev(ct).data_ptr(), D + C, torch.zeros(N, 4, device='cuda').data_ptr(),
+                                  gpn.data_ptr(), gpn.data_ptr() + 4 * K,
                                   gls.data_ptr(), gco.data_ptr(), H.st()) == 0
     gpn = gpn.reshape(V, 2, K)
     assert rel_err(gls, lso.grad) < 1e-4
@@ -446,7 +447,8 @@ def test_kl_gmm_pose3d(L):
     per, dx = torch.zeros(N, device='cuda'), torch.zeros(N, 72, device='cuda')
     dxp = H.dev(x)
     assert L.nemo_gmm_fwd_bwd(N, 8, 69, dxp.data_ptr() + 12, 72, c['means'].data_ptr(), c['prec'].data_ptr(),
-                              c['log_nllw'].data_ptr(), out.data_ptr() + 4, per.data_ptr(), 2.0,
+                              c['log_nllw'].data_ptr(), torch.zeros(N, 8, device='cuda').data_ptr(),
+                              out.data_ptr() + 4, per.data_ptr(), 2.0,
                               dx.data_ptr() + 12, 72, H.st()) == 0
     assert rel_err(per, ll.detach()) < 1e-5 and rel_err(out[1], ll.mean().detach()) < 1e-5
     assert rel_err(dx, 2.0 * xo.grad) < 1e-4
