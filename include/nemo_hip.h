@@ -121,17 +121,18 @@ int64_t nemo_ctx_num_verts(const nemo_ctx* ctx);
 int64_t nemo_ctx_nq(const nemo_ctx* ctx);            /* # non-kinematic output joints            */
 const float* nemo_ctx_C1(const nemo_ctx* ctx);       /* device (207, nq*72) pre-contracted basis   */
 const float* nemo_ctx_c0(const nemo_ctx* ctx);       /* device (nq*72) shape-dependent offset      */
-const float* nemo_ctx_posedirs(const nemo_ctx* ctx); /* device (207, 3*NV)                         */
+const float* nemo_ctx_posedirs(const nemo_ctx* ctx); /* device (207, ld) zero-padded rows              */
+int64_t nemo_ctx_posedirs_ld(const nemo_ctx* ctx);   /* ld = 3*NV rounded up to a multiple of 4    */
 const float* nemo_ctx_v_shaped(const nemo_ctx* ctx); /* device (3*NV)                              */
 
 /* Forward kinematics (human_body_prior/body_model/lbs.py:350-404 batch_rigid_transform +
  * :229 pose_feature).  R (rows,24,9) -> A (rows,24,12) [3x4 relative transforms, row-major],
- * Jp (rows,24,3) posed joints, PF (rows,207) = (R[1:]-I) flattened. */
+ * Jp (rows,24,3) posed joints, PF (rows, ldpf>=207) = (R[1:]-I) flattened (optional). */
 int32_t nemo_fk_fwd(const nemo_ctx* ctx, int64_t rows, const float* R, float* A, float* Jp, float* PF,
-                    void* stream);
-/* dA (rows,24,12), optional dJp (rows,24,3), dPF (rows,207) -> dR (rows,24,9). */
+                    int64_t ldpf, void* stream);
+/* dA (rows,24,12), optional dJp (rows,24,3), dPF (rows, lddpf) -> dR (rows,24,9). */
 int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R, const float* A, const float* dA,
-                    const float* dJp, const float* dPF, float* dR, void* stream);
+                    const float* dJp, const float* dPF, int64_t lddpf, float* dR, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Keypoint objective: output joints -> +translation -> per-view camera -> 2-D loss.

@@ -46,9 +46,10 @@ SIGNATURES = {
     'nemo_ctx_C1': (ptr, [ptr]),
     'nemo_ctx_c0': (ptr, [ptr]),
     'nemo_ctx_posedirs': (ptr, [ptr]),
+    'nemo_ctx_posedirs_ld': (i64, [ptr]),
     'nemo_ctx_v_shaped': (ptr, [ptr]),
-    'nemo_fk_fwd': (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr]),
-    'nemo_fk_bwd': (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, ptr]),
+    'nemo_fk_fwd': (i32, [ptr, i64, ptr, ptr, ptr, ptr, i64, ptr]),
+    'nemo_fk_bwd': (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr]),
     'nemo_kp_fwd': (i32, [ptr, i64, i64, i64, ptr, ptr, ptr, i64, ptr, i64, i32, ptr, ptr, ptr, ptr, ptr,
                           f32, f32, f32, i32, i32, ptr, ptr, ptr, ptr, ptr]),
     'nemo_kp_finalize': (i32, [i64, i64, i32, i32, ptr, ptr, ptr, ptr]),

@@ -7,6 +7,13 @@
 // (nemo/neural_motion_model.py:58-71,130-148), VPoser's Linear layers
 // (human_body_prior/models/vposer_model.py:69-88), the pose-blend contraction
 // (human_body_prior/body_model/lbs.py:229-233) and their autograd backward GEMMs.
+//
+// Structure: 256 threads = 4 waves in a 2x2 grid, each wave owns (BM/2)x(BN/2) of the block tile as
+// 32x32 MFMA accumulators.  K is walked in tiles of 16 through a double-buffered LDS image stored
+// k-major ([k][m], [k][n]) so that the per-lane MFMA operand reads are conflict-free ds_read_b32;
+// one barrier per K-tile; the next tile's global loads are issued before the MFMAs of the current
+// one.  Operands whose rows are 16-byte aligned are staged with dwordx4 loads (VEC path), anything
+// else (e.g. nn.Linear weights with in_features = 105 / 63) with dword loads.
 #include "common.h"
 #include "../../include/nemo_hip.h"
 
@@ -27,44 +34,95 @@ struct GemmArgs {
 constexpr int BK = 16;
 constexpr int PAD = 4;
 
-// Load a (ROWS x BK) operand tile into registers.  Element (r, kk) of the tile is
+// Per-thread staging of one (ROWS x BK) operand tile.  Element (r, kk) of the tile is
 //   KCONTIG : src[(row0 + r) * ld + k0 + kk]      (k is the contiguous axis)
 //   !KCONTIG: src[(k0 + kk) * ld + row0 + r]      (r is the contiguous axis)
-// Out-of-range elements are zero.  Thread->element mapping keeps global reads coalesced
-// along the contiguous axis.
-template <int ROWS, bool KCONTIG>
-__device__ __forceinline__ void load_tile(const float* __restrict__ src, long ld, long row0, long k0,
-                                          long row_lim, long k_lim, float (&reg)[ROWS / 16]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < ROWS / 16; ++i) {
-        int r, kk;
-        if (KCONTIG) { kk = t & 15; r = (t >> 4) + 16 * i; }
-        else         { r = t % ROWS; kk = t / ROWS + (256 / ROWS) * i; }
-        const long gr = row0 + r, gk = k0 + kk;
-        float v = 0.f;
-        if (gr < row_lim && gk < k_lim) v = KCONTIG ? src[gr * ld + gk] : src[gk * ld + gr];
-        reg[i] = v;
-    }
-}
+// Out-of-range elements are zero.
+template <int ROWS, bool KCONTIG, bool VEC>
+struct Stager {
+    static constexpr int NV = VEC ? ROWS / 64 : ROWS / 16;       // float4 / float per thread
+    const float* p[NV];           // per-slot base pointers (advanced every K tile)
+    bool row_ok[NV];              // VEC: all rows of the slot in range (KCONTIG: its single row)
+    int r_[NV], k_[NV];           // slot position inside the tile
+    float4 v4[VEC ? NV : 1];
+    float v1[VEC ? 1 : NV];
+    long step;                    // pointer advance per K tile
+    long row_lim_rem[NV];         // !KCONTIG VEC: rows remaining from the slot's first row
 
-template <int ROWS, bool KCONTIG>
-__device__ __forceinline__ void store_tile(float (*lds)[ROWS + PAD], const float (&reg)[ROWS / 16]) {
-    const int t = threadIdx.x;
+    __device__ __forceinline__ void init(const float* src, long ld, long row0, long k0, long row_lim) {
+        const int t = threadIdx.x;
+        step = KCONTIG ? BK : BK * ld;
 #pragma unroll
-    for (int i = 0; i < ROWS / 16; ++i) {
-        int r, kk;
-        if (KCONTIG) { kk = t & 15; r = (t >> 4) + 16 * i; }
-        else         { r = t % ROWS; kk = t / ROWS + (256 / ROWS) * i; }
-        lds[kk][r] = reg[i];
+        for (int i = 0; i < NV; ++i) {
+            int r, kk;
+            if (VEC) {
+                if (KCONTIG) { kk = 4 * (t & 3); r = (t >> 2) + 64 * i; }
+                else { r = 4 * (t % (ROWS / 4)); kk = t / (ROWS / 4) + (1024 / ROWS) * i; }
+            } else {
+                if (KCONTIG) { kk = t & 15; r = (t >> 4) + 16 * i; }
+                else { r = t % ROWS; kk = t / ROWS + (256 / ROWS) * i; }
+            }
+            r_[i] = r; k_[i] = kk;
+            const long gr = row0 + r;
+            row_lim_rem[i] = row_lim - gr;
+            row_ok[i] = (VEC && !KCONTIG) ? (gr + 3 < row_lim) : (gr < row_lim);
+            p[i] = KCONTIG ? src + gr * ld + k0 + kk : src + (k0 + kk) * ld + gr;
+        }
     }
-}
 
-template <int BM, int BN, bool TA, bool TB>
+    // k_rem = k_lim - k0 of the tile being loaded
+    __device__ __forceinline__ void load(long k_rem) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (VEC) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (KCONTIG) {
+                    if (row_ok[i]) {
+                        if (k_[i] + 3 < k_rem) v = *reinterpret_cast<const float4*>(p[i]);
+                        else {
+                            if (k_[i] + 0 < k_rem) v.x = p[i][0];
+                            if (k_[i] + 1 < k_rem) v.y = p[i][1];
+                            if (k_[i] + 2 < k_rem) v.z = p[i][2];
+                        }
+                    }
+                } else if (k_[i] < k_rem) {
+                    if (row_ok[i]) v = *reinterpret_cast<const float4*>(p[i]);
+                    else {
+                        if (row_lim_rem[i] > 0) v.x = p[i][0];
+                        if (row_lim_rem[i] > 1) v.y = p[i][1];
+                        if (row_lim_rem[i] > 2) v.z = p[i][2];
+                    }
+                }
+                v4[i] = v;
+            } else {
+                v1[i] = (row_ok[i] && k_[i] < k_rem) ? *p[i] : 0.f;
+            }
+            p[i] += step;
+        }
+    }
+
+    __device__ __forceinline__ void store(float (*lds)[ROWS + PAD]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (VEC) {
+                if (KCONTIG) {
+                    lds[k_[i] + 0][r_[i]] = v4[i].x; lds[k_[i] + 1][r_[i]] = v4[i].y;
+                    lds[k_[i] + 2][r_[i]] = v4[i].z; lds[k_[i] + 3][r_[i]] = v4[i].w;
+                } else {
+                    *reinterpret_cast<float4*>(&lds[k_[i]][r_[i]]) = v4[i];
+                }
+            } else {
+                lds[k_[i]][r_[i]] = v1[i];
+            }
+        }
+    }
+};
+
+template <int BM, int BN, bool TA, bool TB, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    __shared__ float As[BK][BM + PAD];
-    __shared__ float Bs[BK][BN + PAD];
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + PAD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + PAD];
 
     const int bid = blockIdx.x;
     const int tm = bid % g.tiles_m, tn = bid / g.tiles_m;
@@ -84,34 +142,37 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float ra[BM / 16], rb[BN / 16];
-    // A tile: "rows" = m.  transA == 0 -> A[m][k], k contiguous.
-    load_tile<BM, !TA>(g.A, g.lda, m0, kbeg, g.M, kend, ra);
-    // B tile: "rows" = n.  transB == 1 -> B[n][k], k contiguous.
-    load_tile<BN, TB>(g.B, g.ldb, n0, kbeg, g.N, kend, rb);
+    // A tile: "rows" = m; transA == 0 -> A[m][k], k contiguous.  B tile: "rows" = n; transB == 1 -> B[n][k].
+    Stager<BM, !TA, VEC> sa;
+    Stager<BN, TB, VEC> sb;
+    sa.init(g.A, g.lda, m0, kbeg, g.M);
+    sb.init(g.B, g.ldb, n0, kbeg, g.N);
 
+    if (kbeg < kend) {
+        sa.load(kend - kbeg); sb.load(kend - kbeg);
+        sa.store(As[0]); sb.store(Bs[0]);
+    }
+    __syncthreads();
+    int cur = 0;
     for (long k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();   // previous iteration's LDS reads are done
-        store_tile<BM, !TA>(As, ra);
-        store_tile<BN, TB>(Bs, rb);
-        __syncthreads();
-        if (k0 + BK < kend) {   // prefetch the next tile while the MFMAs run
-            load_tile<BM, !TA>(g.A, g.lda, m0, k0 + BK, g.M, kend, ra);
-            load_tile<BN, TB>(g.B, g.ldb, n0, k0 + BK, g.N, kend, rb);
-        }
+        const bool more = k0 + BK < kend;
+        if (more) { sa.load(kend - k0 - BK); sb.load(kend - k0 - BK); }   // in flight during the MFMAs
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 2) {
             float a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[ks + lhi][wm * WM + i * 32 + l31];
+            for (int i = 0; i < TM; ++i) a[i] = As[cur][ks + lhi][wm * WM + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[ks + lhi][wn * WN + j * 32 + l31];
+            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][ks + lhi][wn * WN + j * 32 + l31];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) { sa.store(As[cur ^ 1]); sb.store(Bs[cur ^ 1]); }
+        __syncthreads();
+        cur ^= 1;
     }
 
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -143,13 +204,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool VEC>
 void launch(int ta, int tb, const GemmArgs& g, dim3 grid, hipStream_t s) {
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, dim3(256), 0, s, g);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false, VEC>), grid, dim3(256), 0, s, g);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true, VEC>), grid, dim3(256), 0, s, g);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false, VEC>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true, VEC>), grid, dim3(256), 0, s, g);
 }
+
+inline bool aligned16(const void* p, long ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
 
 }  // namespace
 
@@ -179,15 +242,21 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     int nz = (int)((K + kc - 1) / kc);
     if (nz < 1) nz = 1;
 
+    // K-chunk starts are multiples of 16, so operand alignment only depends on the base and the ld
+    const bool vec = aligned16(A, lda) && aligned16(B, ldb);
     // 128x128 tiles once they alone fill the 256 CUs a couple of times over; 64x64 otherwise
     const long big_tiles = ((M + 127) / 128) * ((N + 127) / 128) * nz;
     hipStream_t s = (hipStream_t)stream;
     if (big_tiles >= 512) {
         g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (int)((N + 127) / 128);
-        launch<128, 128>(transA, transB, g, dim3(g.tiles_m * g.tiles_n, 1, nz), s);
+        dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
+        if (vec) launch<128, 128, true>(transA, transB, g, grid, s);
+        else launch<128, 128, false>(transA, transB, g, grid, s);
     } else {
         g.tiles_m = (int)((M + 63) / 64); g.tiles_n = (int)((N + 63) / 64);
-        launch<64, 64>(transA, transB, g, dim3(g.tiles_m * g.tiles_n, 1, nz), s);
+        dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
+        if (vec) launch<64, 64, true>(transA, transB, g, grid, s);
+        else launch<64, 64, false>(transA, transB, g, grid, s);
     }
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;

@@ -29,6 +29,7 @@ struct KpConst {
 
 struct nemo_ctx {
     long NV;
+    long ldP;                 // row stride of d_posedirs: 3*NV rounded up to a multiple of 4 (dwordx4 staging)
     int n_out, nq;
     KpConst kc;
     // device constants
@@ -90,6 +91,7 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
         if (parents[i] < 0 || parents[i] >= i) return NEMO_EINVAL;   // topological order required
     nemo_ctx* c = new nemo_ctx();
     c->NV = NV;
+    c->ldP = ((NV * 3 + 3) / 4) * 4;
     c->n_out = (int)n_out;
     for (int i = 0; i < 24; ++i) c->kc.parents[i] = (int)parents[i];
     c->h_v_template.assign(v_template, v_template + NV * 3);
@@ -152,11 +154,13 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
 
     c->d_posedirs = c->d_v_shaped = c->d_W = c->d_Wt = c->d_Jrest = c->d_C1 = c->d_c0 = c->d_w0 = nullptr;
 #define ALLOC(p, n) HIPCHK(hipMalloc((void**)&(p), sizeof(float) * (size_t)((n) > 0 ? (n) : 1)))
-    ALLOC(c->d_posedirs, 207 * NV * 3); ALLOC(c->d_v_shaped, NV * 3); ALLOC(c->d_W, NV * 24);
+    ALLOC(c->d_posedirs, 207 * c->ldP); ALLOC(c->d_v_shaped, NV * 3); ALLOC(c->d_W, NV * 24);
     ALLOC(c->d_Wt, NV * 24); ALLOC(c->d_Jrest, 72); ALLOC(c->d_C1, 207 * nq * 72);
     ALLOC(c->d_c0, nq * 72); ALLOC(c->d_w0, nq * 24);
 #undef ALLOC
-    HIPCHK(hipMemcpy(c->d_posedirs, posedirs, sizeof(float) * 207 * NV * 3, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(c->d_posedirs, 0, sizeof(float) * 207 * c->ldP));
+    HIPCHK(hipMemcpy2D(c->d_posedirs, sizeof(float) * c->ldP, posedirs, sizeof(float) * NV * 3,
+                       sizeof(float) * NV * 3, 207, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_W, lbs_weights, sizeof(float) * NV * 24, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_Wt, Wt.data(), sizeof(float) * NV * 24, hipMemcpyHostToDevice));
     if (nq) {
@@ -182,6 +186,7 @@ extern "C" int64_t nemo_ctx_nq(const nemo_ctx* c) { return c ? c->nq : -1; }
 extern "C" const float* nemo_ctx_C1(const nemo_ctx* c) { return c ? c->d_C1 : nullptr; }
 extern "C" const float* nemo_ctx_c0(const nemo_ctx* c) { return c ? c->d_c0 : nullptr; }
 extern "C" const float* nemo_ctx_posedirs(const nemo_ctx* c) { return c ? c->d_posedirs : nullptr; }
+extern "C" int64_t nemo_ctx_posedirs_ld(const nemo_ctx* c) { return c ? c->ldP : -1; }
 extern "C" const float* nemo_ctx_v_shaped(const nemo_ctx* c) { return c ? c->d_v_shaped : nullptr; }
 
 namespace {
@@ -197,7 +202,7 @@ namespace {
 __global__ __launch_bounds__(FK_TB) void fk_fwd_kernel(long rows, const float* __restrict__ R,
                                                        const float* __restrict__ Jrest, KpConst kc,
                                                        float* __restrict__ A, float* __restrict__ Jp,
-                                                       float* __restrict__ PF) {
+                                                       float* __restrict__ PF, long ldpf) {
     extern __shared__ float G[];          // G[(j*12 + e) * FK_TB + lane]: e<9 rotation, e>=9 translation
     const int lane = threadIdx.x;
     const long row = (long)blockIdx.x * FK_TB + lane;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(FK_TB) void fk_fwd_kernel(long rows, const float* _
             }
             if (PF) {
 #pragma unroll
-                for (int k = 0; k < 9; ++k) PF[row * 207 + (i - 1) * 9 + k] = Ri[k] - ((k % 4 == 0) ? 1.f : 0.f);
+                for (int k = 0; k < 9; ++k) PF[row * ldpf + (i - 1) * 9 + k] = Ri[k] - ((k % 4 == 0) ? 1.f : 0.f);
             }
         }
 #pragma unroll
@@ -252,7 +257,8 @@ __global__ __launch_bounds__(FK_TB) void fk_bwd_kernel(long rows, const float* _
                                                        const float* __restrict__ Jrest, KpConst kc,
                                                        const float* __restrict__ dA,
                                                        const float* __restrict__ dJp,
-                                                       const float* __restrict__ dPF, float* __restrict__ dR) {
+                                                       const float* __restrict__ dPF, long lddpf,
+                                                       float* __restrict__ dR) {
     extern __shared__ float D[];          // dG accumulators: [(j*12 + r*4 + c) * FK_TB + lane]
     const int lane = threadIdx.x;
     const long row = (long)blockIdx.x * FK_TB + lane;
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(FK_TB) void fk_bwd_kernel(long rows, const float* _
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float v = Gp[r] * dG[c] + Gp[3 + r] * dG[3 + c] + Gp[6 + r] * dG[6 + c];
-                if (dPF) v += dPF[row * 207 + (i - 1) * 9 + r * 3 + c];
+                if (dPF) v += dPF[row * lddpf + (i - 1) * 9 + r * 3 + c];
                 dR[row * 216 + i * 9 + r * 3 + c] = v;
             }
         // dG_R[p] += dG_i Ri^T + dgt (x) rel ;  dG_t[p] += dgt
@@ -757,8 +763,8 @@ __global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" int32_t nemo_fk_fwd(const nemo_ctx* ctx, int64_t rows, const float* R, float* A, float* Jp,
-                               float* PF, void* stream) {
-    if (!ctx || rows < 0 || !R || !A || !Jp) return NEMO_EINVAL;
+                               float* PF, int64_t ldpf, void* stream) {
+    if (!ctx || rows < 0 || !R || !A || !Jp || (PF && ldpf < 207)) return NEMO_EINVAL;
     if (rows == 0) return NEMO_OK;
     static bool attr_set = false;
     if (!attr_set) {
@@ -767,14 +773,15 @@ extern "C" int32_t nemo_fk_fwd(const nemo_ctx* ctx, int64_t rows, const float* R
         attr_set = true;
     }
     hipLaunchKernelGGL(fk_fwd_kernel, dim3(nemo_cdiv(rows, FK_TB)), dim3(FK_TB), FK_LDS_BYTES,
-                       (hipStream_t)stream, (long)rows, R, ctx->d_Jrest, ctx->kc, A, Jp, PF);
+                       (hipStream_t)stream, (long)rows, R, ctx->d_Jrest, ctx->kc, A, Jp, PF, (long)ldpf);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
 
 extern "C" int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R, const float* A,
-                               const float* dA, const float* dJp, const float* dPF, float* dR, void* stream) {
-    if (!ctx || rows < 0 || !R || !A || !dA || !dR) return NEMO_EINVAL;
+                               const float* dA, const float* dJp, const float* dPF, int64_t lddpf, float* dR,
+                               void* stream) {
+    if (!ctx || rows < 0 || !R || !A || !dA || !dR || (dPF && lddpf < 207)) return NEMO_EINVAL;
     if (rows == 0) return NEMO_OK;
     static bool attr_set = false;
     if (!attr_set) {
@@ -783,7 +790,7 @@ extern "C" int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R
         attr_set = true;
     }
     hipLaunchKernelGGL(fk_bwd_kernel, dim3(nemo_cdiv(rows, FK_TB)), dim3(FK_TB), FK_LDS_BYTES,
-                       (hipStream_t)stream, (long)rows, R, A, ctx->d_Jrest, ctx->kc, dA, dJp, dPF, dR);
+                       (hipStream_t)stream, (long)rows, R, A, ctx->d_Jrest, ctx->kc, dA, dJp, dPF, (long)lddpf, dR);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

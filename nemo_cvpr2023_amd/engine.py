@@ -63,6 +63,7 @@ class SmplContext:
         self.C1 = self.lib.nemo_ctx_C1(h)
         self.c0 = self.lib.nemo_ctx_c0(h)
         self.posedirs = self.lib.nemo_ctx_posedirs(h)
+        self.ldP = int(self.lib.nemo_ctx_posedirs_ld(h))
         self.v_shaped = self.lib.nemo_ctx_v_shaped(h)
         self._betas = np.zeros(10, dtype=np.float32)
 
@@ -227,15 +228,15 @@ class FitEngine:
         w = dict(
             X=Z(N + 1, self.din), H1=Z(N + 1, h), H2=Z(N + 1, h), H3=Z(N + 1, h), ROT=Z(N + 1, 144),
             TR=Z(N + 1, 3), phase=Z(N), phase_ws=Z(N, 4), gmm_ws=Z(N, self.gmm['M']), R=Z(N, 24, 9), AA=Z(N, 72), A=Z(N, 24, 12), Jp=Z(N, 24, 3),
-            PF=Z(N, 207), Mq=Z(N, max(nq * 72, 1)), j3d=Z(N, self.ctx.n_out, 3), p2d=Z(N, self.ctx.n_out, 2),
+            PF=Z(N, 208), Mq=Z(N, max(nq * 72, 1)), j3d=Z(N, self.ctx.n_out, 3), p2d=Z(N, self.ctx.n_out, 2),
             loss_all=Z(N, self.ctx.n_out, 2), view_acc=Z(self.V, 2), norm=Z(1),
             E1=Z(N, 512), E2=Z(N, 512), E3=Z(N, 512), MULV=Z(N, 64), D1=Z(N, 512), D2=Z(N, 512),
             D3=Z(N, 126), AAdec=Z(N, 63),
-            R2=Z(2 * Nc, 24, 9), A2=Z(2 * Nc, 24, 12), Jp2=Z(2 * Nc, 24, 3), PF2=Z(2 * Nc, 207),
-            VP2=Z(2 * Nc, 3 * self.NV), dVP=Z(Nc, 3 * self.NV), dA2=Z(Nc, 24, 12), dPF2=Z(Nc, 207),
+            R2=Z(2 * Nc, 24, 9), A2=Z(2 * Nc, 24, 12), Jp2=Z(2 * Nc, 24, 3), PF2=Z(2 * Nc, 208),
+            VP2=Z(2 * Nc, self.ctx.ldP), dVP=Z(Nc, self.ctx.ldP), dA2=Z(Nc, 24, 12), dPF2=Z(Nc, 208),
             dR2=Z(N, 24, 9),
             dAA=Z(N, 72), dR=Z(N, 24, 9), dA=Z(N, 24, 12), dJp=Z(N, 24, 3), dMq=Z(N, max(nq * 72, 1)),
-            dPF=Z(N, 207), dROT=Z(N + 1, 144), dTR=Z(N + 1, 3), dH=Z(N + 1, h), dH_b=Z(N + 1, h),
+            dPF=Z(N, 208), dROT=Z(N + 1, 144), dTR=Z(N + 1, 3), dH=Z(N + 1, h), dH_b=Z(N + 1, h),
             dX=Z(N + 1, self.din), dMULV=Z(N, 64), dE_a=Z(N, 512), dE_b=Z(N, 512), Nc=Nc)
         self.ws[N] = w
         return w
@@ -308,12 +309,12 @@ class FitEngine:
         L, st = self.lib, _stream()
         ctx = ctx or self.ctx
         ctx.set_betas(self.betas.detach().cpu().numpy())
-        check(L.nemo_fk_fwd(ctx.handle, N, dptr(w['R']), dptr(w['A']), dptr(w['Jp']), dptr(w['PF']), st),
+        check(L.nemo_fk_fwd(ctx.handle, N, dptr(w['R']), dptr(w['A']), dptr(w['Jp']), dptr(w['PF']), 208, st),
               'nemo_fk_fwd')
         nq72 = ctx.nq * 72
         Mq = w['Mq'] if ctx is self.ctx else torch.zeros(N, max(nq72, 1), device=self.device)
         if ctx.nq:
-            self.gemm(0, 0, N, nq72, 207, dptr(w['PF']), 207, ctx.C1, nq72, dptr(Mq), max(nq72, 1),
+            self.gemm(0, 0, N, nq72, 207, dptr(w['PF']), 208, ctx.C1, nq72, dptr(Mq), max(nq72, 1),
                       bias=ctx.c0)
         lt = LOSS_TYPES[self.args.loss]
         check(L.nemo_kp_fwd(
@@ -351,7 +352,7 @@ class FitEngine:
     def forward_v2v(self, w, N, need_grad):
         """K10 + K11: the two full-mesh bodies, L1 sum and (same pass) its gradient wrt the pose."""
         L, st, ctx = self.lib, _stream(), self.ctx
-        Nc, NV3 = w['Nc'], 3 * self.NV
+        Nc, NV3, ldP = w['Nc'], 3 * self.NV, self.ctx.ldP
         for c0 in range(0, N, Nc):
             n = min(Nc, N - c0)
             R = w['R'].data_ptr() + 4 * c0 * 216
@@ -359,20 +360,20 @@ class FitEngine:
             AAd = w['AAdec'].data_ptr() + 4 * c0 * 63
             check(L.nemo_v2v_prep_fwd(n, R, AA, AAd, dptr(w['R2']), st), 'nemo_v2v_prep_fwd')
             check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']),
-                                dptr(w['PF2']), st), 'nemo_fk_fwd')
-            self.gemm(0, 0, 2 * n, NV3, 207, dptr(w['PF2']), 207, ctx.posedirs, NV3, dptr(w['VP2']), NV3,
+                                dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
+            self.gemm(0, 0, 2 * n, NV3, 207, dptr(w['PF2']), 208, ctx.posedirs, ldP, dptr(w['VP2']), ldP,
                       bias=ctx.v_shaped, tag='gemm_pose_blend')
             ev = self._event_begin('v2v_skin_l1', 2.0 * n * self.NV * (2 * 288 + 288 + 30))
-            check(L.nemo_v2v_skin_l1(ctx.handle, n, dptr(w['VP2']), NV3, dptr(w['A2']),
-                                     self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVP']), NV3, dptr(w['dA2']),
+            check(L.nemo_v2v_skin_l1(ctx.handle, n, dptr(w['VP2']), ldP, dptr(w['A2']),
+                                     self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVP']), ldP, dptr(w['dA2']),
                                      st), 'nemo_v2v_skin_l1')
             self._event_end(ev)
             if need_grad:
                 w['dPF2'].zero_()
-                self.gemm(0, 1, n, 207, NV3, dptr(w['dVP']), NV3, ctx.posedirs, NV3, dptr(w['dPF2']), 207,
+                self.gemm(0, 1, n, 207, NV3, dptr(w['dVP']), ldP, ctx.posedirs, ldP, dptr(w['dPF2']), 208,
                           out_mode=2, split_k=8, tag='gemm_pose_blend_bwd')
                 check(L.nemo_fk_bwd(ctx.handle, n, dptr(w['R2']), dptr(w['A2']), dptr(w['dA2']), None,
-                                    dptr(w['dPF2']), w['dR2'].data_ptr() + 4 * c0 * 216, st), 'nemo_fk_bwd')
+                                    dptr(w['dPF2']), 208, w['dR2'].data_ptr() + 4 * c0 * 216, st), 'nemo_fk_bwd')
 
     # ------------------------------------------------------------------ backward pieces
     def backward_kp(self, w, N, view_idx, frame_idx, Mq, mean_mode, upstream, cams_only=False,
@@ -398,10 +399,10 @@ class FitEngine:
         dPF = None
         if ctx.nq and not detach_pose:
             self.gemm(0, 1, N, 207, ctx.nq * 72, dptr(w['dMq']), nq72, ctx.C1, ctx.nq * 72, dptr(w['dPF']),
-                      207)
+                      208)
             dPF = dptr(w['dPF'])
         check(L.nemo_fk_bwd(ctx.handle, N, dptr(w['R']), dptr(w['A']), dptr(w['dA']), dptr(w['dJp']), dPF,
-                            dptr(w['dR']), st), 'nemo_fk_bwd')
+                            208, dptr(w['dR']), st), 'nemo_fk_bwd')
         if detach_pose:
             w['dR'][:, 1:].zero_()       # body rotmats detached, global orient keeps its gradient (:4031)
 

@@ -355,16 +355,16 @@ class MultiViewModel(nn.Module):
 
     def _vertices(self, w, N, trans):
         e = self.engine
-        NV3 = 3 * e.NV
+        NV3, ldP = 3 * e.NV, e.ctx.ldP
         verts = torch.empty(N, e.NV, 3, device=self.device)
         chunk = 4096
-        VP = torch.empty(min(N, chunk), NV3, device=self.device)
+        VP = torch.empty(min(N, chunk), ldP, device=self.device)
         for c0 in range(0, N, chunk):
             n = min(chunk, N - c0)
-            e.gemm(0, 0, n, NV3, 207, w['PF'].data_ptr() + 4 * c0 * 207, 207, e.ctx.posedirs, NV3, dptr(VP),
-                   NV3, bias=e.ctx.v_shaped)
+            e.gemm(0, 0, n, NV3, 207, w['PF'].data_ptr() + 4 * c0 * 208, 208, e.ctx.posedirs, ldP, dptr(VP),
+                   ldP, bias=e.ctx.v_shaped)
             t = None if trans is None else trans[c0:c0 + n].contiguous()
-            check(e.lib.nemo_skin_vertices(e.ctx.handle, n, dptr(VP), NV3, w['A'].data_ptr() + 4 * c0 * 288,
+            check(e.lib.nemo_skin_vertices(e.ctx.handle, n, dptr(VP), ldP, w['A'].data_ptr() + 4 * c0 * 288,
                                            dptr(t), 3, verts.data_ptr() + 4 * c0 * NV3, _stream()),
                   'nemo_skin_vertices')
         return verts

@@ -74,6 +74,24 @@ def test_gemm_epilogues(L):
     assert rel_err(H.gemm(sub, dB, 0, 1), sub.cpu().double() @ B.double().T) < TOL
 
 
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(2401, 1000, 1000), (130, 72, 100), (64, 20, 207), (4100, 3000, 208)])
+def test_gemm_vector_path(L, ta, tb, M, N, K):
+    """16-byte aligned operands take the dwordx4 staging path; ragged M/N/K tails included."""
+    H = _ops()
+    g = torch.Generator().manual_seed(M + N + K + 2 * ta + tb)
+    lda = ((M if ta else K) + 3) // 4 * 4
+    ldb = ((K if tb else N) + 3) // 4 * 4
+    Af = torch.randn((K if ta else M), lda, generator=g)
+    Bf = torch.randn((N if tb else K), ldb, generator=g)
+    A, B = Af[:, :(M if ta else K)], Bf[:, :(K if tb else N)]
+    ref = (A.T if ta else A).double() @ (B.T if tb else B).double()
+    dA, dB = H.dev(Af)[:, :A.shape[1]], H.dev(Bf)[:, :B.shape[1]]
+    assert dA.data_ptr() % 16 == 0 and dA.stride(0) % 4 == 0
+    C = H.gemm(dA, dB, ta, tb)
+    assert rel_err(C, ref) < TOL
+
+
 def test_gemm_rejects_bad_args(L):
     x = torch.zeros(4, 4, device='cuda')
     rc = L.nemo_gemm_f32(0, 0, 4, 4, 4, x.data_ptr(), 4, x.data_ptr(), 4, x.data_ptr(), 4, None, 1, None, 0, 0,
@@ -280,7 +298,7 @@ def test_keypoint_path_forward_backward(L, num_verts, version):
     dvi, dfi, dt = H.dev(vi, torch.long), H.dev(fi, torch.long), H.dev(tgt)
     Z = lambda *s: torch.zeros(*s, device='cuda')
     A, Jp, PF = Z(N, 24, 12), Z(N, 24, 3), Z(N, 207)
-    assert L.nemo_fk_fwd(ctx.handle, N, dR.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), H.st()) == 0
+    assert L.nemo_fk_fwd(ctx.handle, N, dR.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), 207, H.st()) == 0
     nq72 = ctx.nq * 72
     Mq = Z(N, nq72)
     assert L.nemo_gemm_f32(0, 0, N, nq72, 207, PF.data_ptr(), 207, ctx.C1, nq72, Mq.data_ptr(), nq72, ctx.c0, 0,
@@ -302,7 +320,7 @@ def test_keypoint_path_forward_backward(L, num_verts, version):
     assert L.nemo_gemm_f32(0, 1, N, 207, nq72, dMq.data_ptr(), nq72, ctx.C1, nq72, dPF.data_ptr(), 207, None, 0,
                            None, 0, 0, 1.0, 0, 1, H.st()) == 0
     assert L.nemo_fk_bwd(ctx.handle, N, dR.data_ptr(), A.data_ptr(), dA.data_ptr(), dJp.data_ptr(),
-                         dPF.data_ptr(), dRg.data_ptr(), H.st()) == 0
+                         dPF.data_ptr(), 207, dRg.data_ptr(), H.st()) == 0
     assert L.nemo_scale_neg_rowsum(N, 3, dTRg.data_ptr(), 3, dTRg.data_ptr() + 4 * 3 * N, H.st()) == 0
     assert rel_err(dRg.reshape(N, 24, 3, 3), Ro.grad) < 1e-4
     assert rel_err(dTRg, TRo.grad) < 1e-4
@@ -338,7 +356,7 @@ def test_keypoint_loss_types_and_camera_mode(L, loss_type, lid):
     dR, dc = H.dev(R.reshape(N, 24, 9)), H.dev(cams)
     dvi, dfi, dt, dsz = H.dev(vi, torch.long), H.dev(fi, torch.long), H.dev(tgt), H.dev(size)
     A, Jp, PF = Z(N, 24, 12), Z(N, 24, 3), Z(N, 207)
-    L.nemo_fk_fwd(ctx.handle, N, dR.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), H.st())
+    L.nemo_fk_fwd(ctx.handle, N, dR.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), 207, H.st())
     nq72 = ctx.nq * 72
     Mq = Z(N, nq72)
     L.nemo_gemm_f32(0, 0, N, nq72, 207, PF.data_ptr(), 207, ctx.C1, nq72, Mq.data_ptr(), nq72, ctx.c0, 0, None,
@@ -375,9 +393,12 @@ def test_vertices_and_v2v(L, num_verts):
     l1.backward()
     Z = lambda *s: torch.zeros(*s, device='cuda')
     dR2 = H.dev(R2.reshape(2 * N, 24, 9))
+    ldP = ctx.ldP
+    assert ldP % 4 == 0 and 0 <= ldP - NV3 < 4
     A, Jp, PF, VP = Z(2 * N, 24, 12), Z(2 * N, 24, 3), Z(2 * N, 207), Z(2 * N, NV3)
-    assert L.nemo_fk_fwd(ctx.handle, 2 * N, dR2.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), H.st()) == 0
-    assert L.nemo_gemm_f32(0, 0, 2 * N, NV3, 207, PF.data_ptr(), 207, ctx.posedirs, NV3, VP.data_ptr(), NV3,
+    assert L.nemo_fk_fwd(ctx.handle, 2 * N, dR2.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), 207,
+                         H.st()) == 0
+    assert L.nemo_gemm_f32(0, 0, 2 * N, NV3, 207, PF.data_ptr(), 207, ctx.posedirs, ldP, VP.data_ptr(), NV3,
                            ctx.v_shaped, 0, None, 0, 0, 1.0, 0, 1, H.st()) == 0
     verts = Z(2 * N, num_verts, 3)
     tr = H.dev(0.1 * torch.randn(2 * N, 3, generator=gen))
@@ -389,9 +410,9 @@ def test_vertices_and_v2v(L, num_verts):
     assert L.nemo_v2v_skin_l1(ctx.handle, N, VP.data_ptr(), NV3, A.data_ptr(), loss.data_ptr(), dVP.data_ptr(),
                               NV3, dA.data_ptr(), H.st()) == 0
     assert rel_err(loss[0], l1.detach()) < 1e-5
-    assert L.nemo_gemm_f32(0, 1, N, 207, NV3, dVP.data_ptr(), NV3, ctx.posedirs, NV3, dPF.data_ptr(), 207, None,
+    assert L.nemo_gemm_f32(0, 1, N, 207, NV3, dVP.data_ptr(), NV3, ctx.posedirs, ldP, dPF.data_ptr(), 207, None,
                            0, None, 0, 0, 1.0, 2, 8, H.st()) == 0
-    assert L.nemo_fk_bwd(ctx.handle, N, dR2.data_ptr(), A.data_ptr(), dA.data_ptr(), None, dPF.data_ptr(),
+    assert L.nemo_fk_bwd(ctx.handle, N, dR2.data_ptr(), A.data_ptr(), dA.data_ptr(), None, dPF.data_ptr(), 207,
                          dRg.data_ptr(), H.st()) == 0
     # |.| is non-smooth: a vertex coordinate within rounding of a tie flips a sign; compare in aggregate
     assert rel_err(dRg.reshape(N, 24, 3, 3), Ro.grad) < 2e-3
