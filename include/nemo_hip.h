@@ -122,7 +122,7 @@ int64_t nemo_ctx_nq(const nemo_ctx* ctx);            /* # non-kinematic output j
 const float* nemo_ctx_C1(const nemo_ctx* ctx);       /* device (207, nq*72) pre-contracted basis   */
 const float* nemo_ctx_c0(const nemo_ctx* ctx);       /* device (nq*72) shape-dependent offset      */
 const float* nemo_ctx_posedirs(const nemo_ctx* ctx); /* device (207, ld) zero-padded rows              */
-int64_t nemo_ctx_posedirs_ld(const nemo_ctx* ctx);   /* ld = 3*NV rounded up to a multiple of 4    */
+int64_t nemo_ctx_posedirs_ld(const nemo_ctx* ctx);   /* ld = 3*NVp, NVp = NV rounded up to 16       */
 const float* nemo_ctx_v_shaped(const nemo_ctx* ctx); /* device (3*NV)                              */
 
 /* Forward kinematics (human_body_prior/body_model/lbs.py:350-404 batch_rigid_transform +
@@ -186,6 +186,14 @@ int32_t nemo_skin_vertices(const nemo_ctx* ctx, int64_t rows, const float* VP, i
  * i.e. the gradient of the un-normalised L1 sum is produced in the same pass. */
 int32_t nemo_v2v_skin_l1(const nemo_ctx* ctx, int64_t N, const float* VP, int64_t ldvp, const float* A,
                          float* loss_sum, float* dVP, int64_t lddvp, float* dA, void* stream);
+/* Same term, fused: pose blend + skinning of both bodies + L1 + gradient in one MFMA kernel; the
+ * blended mesh never reaches HBM.  PF2 (2N, ldpf) pose features [orig rows | reconstruction rows] with
+ * column 207 (if ldpf > 207) ZERO, A2 (2N,24,12).  loss_sum += sum|v_rec - v_orig|;
+ * dVPt (3*NVp rows, NVp = NV rounded up to 16; ldn >= N rounded up to 16) = TRANSPOSED
+ * d(sum)/dVP_orig (operand of the blend-shape adjoint GEMM with transA=1; pad rows/columns are
+ * written with zeros); dA (N,24,12) += d(sum)/dA_orig (atomic accumulate: caller zeroes it). */
+int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
+                       float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* stream);
 /* Builds the (2N,24,9) rotation set of the two bodies from the MLP pose:
  * rows<N: [R[:,0], Rodrigues(aa[:,3:72])], rows>=N: [R[:,0], Rodrigues(cat(aa_dec, aa[:,66:72]))]
  * (:2783-2791, hmr/geometry.py:9-45). */

@@ -58,6 +58,7 @@ SIGNATURES = {
     'nemo_project': (i32, [i64, i64, i64, ptr, ptr, ptr, f32, f32, f32, ptr, ptr]),
     'nemo_skin_vertices': (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, ptr]),
     'nemo_v2v_skin_l1': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr]),
+    'nemo_v2v_fused': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr]),
     'nemo_v2v_prep_fwd': (i32, [i64, ptr, ptr, ptr, ptr, ptr]),
     'nemo_v2v_prep_bwd': (i32, [i64, ptr, ptr, f32, ptr, ptr, ptr]),
     'nemo_kl_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, i64, ptr]),

@@ -13,6 +13,7 @@
 #include <vector>
 #include <utility>
 #include <cstring>
+#include <cstdlib>
 #include "common.h"
 #include "rot_math.h"
 #include "../../include/nemo_hip.h"
@@ -29,7 +30,9 @@ struct KpConst {
 
 struct nemo_ctx {
     long NV;
-    long ldP;                 // row stride of d_posedirs: 3*NV rounded up to a multiple of 4 (dwordx4 staging)
+    long NVp;                 // NV rounded up to a multiple of 16
+    long ldP;                 // row stride of d_posedirs = 3*NVp; the array has 224 zero-padded rows so that
+                              // the fused mesh kernel never needs a bounds predicate
     int n_out, nq;
     KpConst kc;
     // device constants
@@ -91,7 +94,8 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
         if (parents[i] < 0 || parents[i] >= i) return NEMO_EINVAL;   // topological order required
     nemo_ctx* c = new nemo_ctx();
     c->NV = NV;
-    c->ldP = ((NV * 3 + 3) / 4) * 4;
+    c->NVp = ((NV + 15) / 16) * 16;          // vertices padded to whole 16-vertex MFMA tiles
+    c->ldP = c->NVp * 3;                     // multiple of 48: 16-byte aligned rows
     c->n_out = (int)n_out;
     for (int i = 0; i < 24; ++i) c->kc.parents[i] = (int)parents[i];
     c->h_v_template.assign(v_template, v_template + NV * 3);
@@ -154,11 +158,13 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
 
     c->d_posedirs = c->d_v_shaped = c->d_W = c->d_Wt = c->d_Jrest = c->d_C1 = c->d_c0 = c->d_w0 = nullptr;
 #define ALLOC(p, n) HIPCHK(hipMalloc((void**)&(p), sizeof(float) * (size_t)((n) > 0 ? (n) : 1)))
-    ALLOC(c->d_posedirs, 207 * c->ldP); ALLOC(c->d_v_shaped, NV * 3); ALLOC(c->d_W, NV * 24);
+    ALLOC(c->d_posedirs, 224 * c->ldP); ALLOC(c->d_v_shaped, c->NVp * 3); ALLOC(c->d_W, c->NVp * 24);
     ALLOC(c->d_Wt, NV * 24); ALLOC(c->d_Jrest, 72); ALLOC(c->d_C1, 207 * nq * 72);
     ALLOC(c->d_c0, nq * 72); ALLOC(c->d_w0, nq * 24);
 #undef ALLOC
-    HIPCHK(hipMemset(c->d_posedirs, 0, sizeof(float) * 207 * c->ldP));
+    HIPCHK(hipMemset(c->d_posedirs, 0, sizeof(float) * 224 * c->ldP));
+    HIPCHK(hipMemset(c->d_v_shaped, 0, sizeof(float) * c->NVp * 3));
+    HIPCHK(hipMemset(c->d_W, 0, sizeof(float) * c->NVp * 24));
     HIPCHK(hipMemcpy2D(c->d_posedirs, sizeof(float) * c->ldP, posedirs, sizeof(float) * NV * 3,
                        sizeof(float) * NV * 3, 207, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_W, lbs_weights, sizeof(float) * NV * 24, hipMemcpyHostToDevice));
@@ -759,6 +765,238 @@ __global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const
     if (tid == 0) atomicAdd(loss_sum, tot);
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused full-mesh v2v term: pose blend + skinning of BOTH bodies + L1 + its gradient, entirely in the
+// 16x16 MFMA accumulator layout (v_mfma_f32_16x16x4_f32; rows i = 16 vertices, columns n = 16
+// samples).  For one (vertex tile, sample group) a lane owns 4 vertices x 1 sample of
+//   vp_c[v][s]  = v_shaped + sum_p P[p][3v+c] pf[s][p]        (K = 207, A-operand streamed from L2)
+//   T_e[v][s]   = sum_j W[v][j] A[s][j][e]                     (K = 24, 12 entries e of the 3x4 map)
+// so vert = T.[vp;1], the |v_rec - v_orig| term, g = -sign, dvp = T^T g and dT = g (x) [vp;1] are all
+// lane-local VALU work, and dT is *already* the B-operand (k = vertex) of the vertex->joint reduction
+// dA[j][e][s] += sum_v W[v][j] dT_e[v][s].  Nothing of the 2N x 20670 blended mesh ever touches HBM;
+// only dVP^T (3NV x N, the operand of the blend-shape adjoint GEMM) is written.
+// Block = one group of 16 samples (their pose features and transforms for both bodies staged once in
+// LDS, strides == 2 mod 32 -> conflict-free B-operand reads) x one vertex range; the 4 waves take
+// alternating vertex tiles.
+#define MF_PFS 226      // pose-feature row stride in LDS (>= 208, == 2 mod 32)
+#define MF_AS 290       // transform row stride in LDS   (>= 288, == 2 mod 32)
+
+__global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
+    long N, long NV, const float* __restrict__ PF2, long ldpf, const float* __restrict__ A2,
+    const float* __restrict__ P, long ldP, const float* __restrict__ vs, const float* __restrict__ W,
+    int tiles_per_range, float* __restrict__ loss_sum, float* __restrict__ dVPt, long ldn,
+    float* __restrict__ dA) {
+    // All constants are zero-padded by nemo_ctx_create (P: 224 rows x 3*NVp columns, W / v_shaped: NVp
+    // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
+    // predicate: padded vertices / samples produce v_rec == v_orig == 0, i.e. zero loss and gradient.
+    extern __shared__ float lds[];
+    float* pfL = lds;                                   // [2][16][MF_PFS]
+    float* AL = lds + 2 * 16 * MF_PFS;                  // [2][16][MF_AS], entry (e*24 + j)
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const long s0 = (long)blockIdx.x * 16;
+    const long ntiles = (NV + 15) / 16;
+    const long t_beg = (long)blockIdx.y * tiles_per_range;
+    const long t_end = min(ntiles, t_beg + tiles_per_range);
+
+    // ---- stage the sample group: pf rows (224 incl. the zero pad) and transforms re-ordered to [e][j]
+    for (int idx = tid; idx < 2 * 16 * 224; idx += 256) {
+        const int set = idx / (16 * 224), n = (idx / 224) % 16, p = idx % 224;
+        const long s = s0 + n;
+        pfL[(set * 16 + n) * MF_PFS + p] = (s < N && p < 207) ? PF2[(set * N + s) * ldpf + p] : 0.f;
+    }
+    for (int idx = tid; idx < 2 * 16 * 288; idx += 256) {
+        const int set = idx / (16 * 288), n = (idx / 288) % 16, je = idx % 288;
+        const int j = je / 12, e = je % 12;
+        const long s = s0 + n;
+        AL[(set * 16 + n) * MF_AS + e * 24 + j] = (s < N) ? A2[(set * N + s) * 288 + je] : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 accdA[12][2];
+#pragma unroll
+    for (int e = 0; e < 12; ++e)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accdA[e][t][r] = 0.f;
+    float lsum = 0.f;
+    const float* pf0 = pfL + (0 * 16 + l15) * MF_PFS + g;      // orig body, this lane's sample column
+    const float* pf1 = pfL + (1 * 16 + l15) * MF_PFS + g;      // reconstruction
+    const float* A0 = AL + (0 * 16 + l15) * MF_AS + g;
+    const float* A1 = AL + (1 * 16 + l15) * MF_AS + g;
+    const long rowstep = 16 * ldP;                              // 4 k-steps of 4 blend-shape rows
+
+    for (long t = t_beg + wid; t < t_end; t += 4) {
+        const long v0 = t * 16;
+        // weights as A-operands: forward (rows = vertices, k = joints) and adjoint (rows = joints, k = vertices)
+        float wf[6], wa[4][2];
+        const float* Wf = W + (v0 + l15) * 24 + g;
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) wf[kk] = Wf[4 * kk];
+        const float* Wa = W + (v0 + 4 * g) * 24 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            wa[r][0] = Wa[r * 24];
+            wa[r][1] = l15 < 8 ? Wa[r * 24 + 16] : 0.f;
+        }
+        // ---- pose blend of both bodies: 52 k-steps x 3 components, A-operand P[p][3v+c] from L2
+        f32x4 vp[2][3];
+        const float* vsl = vs + (v0 + 4 * g) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float b = vsl[r * 3 + c];
+                vp[0][c][r] = b; vp[1][c][r] = b;
+            }
+        // eight running row pointers (rows g + 4u, u = 0..7; advanced by 32 rows per outer iteration):
+        // the A-operands of k-step kk are loaded 8 k-steps (~1500 MFMA cycles) ahead of their use
+        const float* pr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pr[u] = P + (long)(g + 4 * u) * ldP + (v0 + l15) * 3;
+        float pa[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pa[u][c] = pr[u][c];
+        for (int kk0 = 0; kk0 < 56; kk0 += 8) {                  // 52 real k-steps + 4 of zero padding
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float a0 = pa[u][0], a1 = pa[u][1], a2 = pa[u][2];
+                pr[u] += 2 * rowstep;                                        // rows of k-step kk + 8
+                if (kk0 + 8 < 56) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) pa[u][c] = pr[u][c];
+                }
+                const float b0 = pf0[4 * (kk0 + u)], b1 = pf1[4 * (kk0 + u)];
+                vp[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, vp[0][0], 0, 0, 0);
+                vp[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, vp[1][0], 0, 0, 0);
+                vp[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, vp[0][1], 0, 0, 0);
+                vp[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, vp[1][1], 0, 0, 0);
+                vp[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b0, vp[0][2], 0, 0, 0);
+                vp[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1, vp[1][2], 0, 0, 0);
+            }
+        }
+        // ---- reconstruction body, one output row c (4 transform entries) at a time
+        float vrec[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 T4[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T4[d][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk)
+#pragma unroll
+                for (int d = 0; d < 4; ++d)       // 4 independent accumulators back to back
+                    T4[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk], A1[(4 * c + d) * 24 + 4 * kk], T4[d], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                vrec[c][r] = T4[0][r] * vp[1][0][r] + T4[1][r] * vp[1][1][r] + T4[2][r] * vp[1][2][r] + T4[3][r];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- original body: row c of the transform -> vertex coordinate c -> sign -> its share of dvp and
+        // the four dT entries (c, 0..3), which go straight into the vertex->joint MFMA as B-operands
+        float dvp[3][4];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dvp[d][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 T4[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T4[d][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk)
+#pragma unroll
+                for (int d = 0; d < 4; ++d)       // 4 independent accumulators back to back
+                    T4[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk], A0[(4 * c + d) * 24 + 4 * kk], T4[d], 0, 0, 0);
+            float gs[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float vo = T4[0][r] * vp[0][0][r] + T4[1][r] * vp[0][1][r] + T4[2][r] * vp[0][2][r] + T4[3][r];
+                const float d = vrec[c][r] - vo;
+                lsum += fabsf(d);
+                gs[r] = d == 0.f ? 0.f : (d > 0.f ? -1.f : 1.f);          // d|v_rec - v_orig| / d v_orig
+#pragma unroll
+                for (int d2 = 0; d2 < 3; ++d2) dvp[d2][r] += T4[d2][r] * gs[r];
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int e = 4 * c + d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dT = d < 3 ? gs[r] * vp[0][d][r] : gs[r];
+                    accdA[e][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[r][0], dT, accdA[e][0], 0, 0, 0);
+                    accdA[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[r][1], dT, accdA[e][1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // d vp (transposed store: row 3v+d, 16 consecutive samples per 64-byte segment)
+        float* dst = dVPt + ((v0 + 4 * g) * 3) * ldn + s0 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) dst[(r * 3 + d) * ldn] = dvp[d][r];
+    }
+
+    // ---- cross-wave reduction of dA through LDS (the staged sample data is dead now), then one
+    // atomic add per entry (vertex ranges of other blocks add into the same rows)
+    __syncthreads();
+    float* scr = lds;                                   // 2 x [16 samples][288] floats
+    auto put = [&](int slot) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * t + 4 * g + r;
+                    if (j < 24) scr[(slot * 16 + l15) * 288 + j * 12 + e] = accdA[e][t][r];
+                }
+    };
+    auto take = [&](int slot) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * t + 4 * g + r;
+                    if (j < 24) accdA[e][t][r] += scr[(slot * 16 + l15) * 288 + j * 12 + e];
+                }
+    };
+    if (wid >= 2) put(wid - 2);
+    __syncthreads();
+    if (wid < 2) take(wid);
+    __syncthreads();
+    if (wid == 1) put(0);
+    __syncthreads();
+    if (wid == 0) {
+        take(0);
+        if (s0 + l15 < N) {
+#pragma unroll
+            for (int e = 0; e < 12; ++e)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * t + 4 * g + r;
+                        if (j < 24) atomicAdd(dA + (s0 + l15) * 288 + j * 12 + e, accdA[e][t][r]);
+                    }
+        }
+    }
+    const float tot = block_sum(lsum, red);
+    if (tid == 0) atomicAdd(loss_sum, tot);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ C ABI
@@ -892,9 +1130,40 @@ extern "C" int32_t nemo_v2v_skin_l1(const nemo_ctx* ctx, int64_t N, const float*
     if (!ctx || N < 0 || !VP || !A || !loss_sum || !dVP || !dA || ldvp < ctx->NV * 3 || lddvp < ctx->NV * 3)
         return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
-    constexpr int S = 4;
-    hipLaunchKernelGGL(v2v_skin_l1_kernel<S>, dim3(nemo_cdiv(N, S)), dim3(256), 0, (hipStream_t)stream,
-                       (long)N, ctx->NV, VP, (long)ldvp, A, ctx->d_Wt, loss_sum, dVP, (long)lddvp, dA);
+    static int S = -1;
+    if (S < 0) { const char* e = getenv("NEMO_V2V_S"); S = e ? atoi(e) : 4; }
+#define V2V_LAUNCH(SS) hipLaunchKernelGGL(v2v_skin_l1_kernel<SS>, dim3(nemo_cdiv(N, SS)), dim3(256), 0, \
+        (hipStream_t)stream, (long)N, ctx->NV, VP, (long)ldvp, A, ctx->d_Wt, loss_sum, dVP, (long)lddvp, dA)
+    if (S == 1) V2V_LAUNCH(1); else if (S == 2) V2V_LAUNCH(2); else V2V_LAUNCH(4);
+#undef V2V_LAUNCH
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
+                                  const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
+                                  void* stream) {
+    if (!ctx || N < 0 || !PF2 || !A2 || !loss_sum || !dVPt || !dA || ldpf < 207 || ldn < ((N + 15) / 16) * 16)
+        return NEMO_EINVAL;
+    if (N == 0) return NEMO_OK;
+    const int lds_bytes = (2 * 16 * MF_PFS + 2 * 16 * MF_AS) * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void*)mesh_v2v_fused_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
+    // at most 256 CUs x 2 resident blocks: the whole grid must be co-resident (a second, partially
+    // filled wave of blocks costs up to 2x), and as close to that as the vertex ranges allow
+    long nr = 500 / groups;
+    if (nr < 1) nr = 1;
+    if (nr > (ntiles + 3) / 4) nr = (ntiles + 3) / 4;
+    const int tpr = (int)((ntiles + nr - 1) / nr);
+    nr = (ntiles + tpr - 1) / tpr;
+    hipLaunchKernelGGL(mesh_v2v_fused_kernel, dim3((unsigned)groups, (unsigned)nr), dim3(256), lds_bytes,
+                       (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, ctx->d_posedirs, ctx->ldP,
+                       ctx->d_v_shaped, ctx->d_W, tpr, loss_sum, dVPt, (long)ldn, dA);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

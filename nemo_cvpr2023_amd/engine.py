@@ -64,6 +64,7 @@ class SmplContext:
         self.c0 = self.lib.nemo_ctx_c0(h)
         self.posedirs = self.lib.nemo_ctx_posedirs(h)
         self.ldP = int(self.lib.nemo_ctx_posedirs_ld(h))
+        self.NVp = self.ldP // 3
         self.v_shaped = self.lib.nemo_ctx_v_shaped(h)
         self._betas = np.zeros(10, dtype=np.float32)
 
@@ -233,7 +234,7 @@ class FitEngine:
             E1=Z(N, 512), E2=Z(N, 512), E3=Z(N, 512), MULV=Z(N, 64), D1=Z(N, 512), D2=Z(N, 512),
             D3=Z(N, 126), AAdec=Z(N, 63),
             R2=Z(2 * Nc, 24, 9), A2=Z(2 * Nc, 24, 12), Jp2=Z(2 * Nc, 24, 3), PF2=Z(2 * Nc, 208),
-            VP2=Z(2 * Nc, self.ctx.ldP), dVP=Z(Nc, self.ctx.ldP), dA2=Z(Nc, 24, 12), dPF2=Z(Nc, 208),
+            dVPt=Z(3 * self.ctx.NVp, (Nc + 15) // 16 * 16), dA2=Z(Nc, 24, 12), dPF2=Z(Nc, 208),
             dR2=Z(N, 24, 9),
             dAA=Z(N, 72), dR=Z(N, 24, 9), dA=Z(N, 24, 12), dJp=Z(N, 24, 3), dMq=Z(N, max(nq * 72, 1)),
             dPF=Z(N, 208), dROT=Z(N + 1, 144), dTR=Z(N + 1, 3), dH=Z(N + 1, h), dH_b=Z(N + 1, h),
@@ -350,9 +351,12 @@ class FitEngine:
                                 dptr(w['dMULV']), 64, st), 'nemo_kl_fwd_bwd')
 
     def forward_v2v(self, w, N, need_grad):
-        """K10 + K11: the two full-mesh bodies, L1 sum and (same pass) its gradient wrt the pose."""
+        """K10 + K11: the two full-mesh bodies, L1 sum and (same pass) its gradient wrt the pose.
+        One fused MFMA kernel per chunk (pose blend + skinning + L1 + gradient, nothing of the
+        blended mesh goes to HBM); the blend-shape adjoint is one GEMM on the transposed dVP."""
         L, st, ctx = self.lib, _stream(), self.ctx
         Nc, NV3, ldP = w['Nc'], 3 * self.NV, self.ctx.ldP
+        ldn = w['dVPt'].shape[1]
         for c0 in range(0, N, Nc):
             n = min(Nc, N - c0)
             R = w['R'].data_ptr() + 4 * c0 * 216
@@ -361,16 +365,15 @@ class FitEngine:
             check(L.nemo_v2v_prep_fwd(n, R, AA, AAd, dptr(w['R2']), st), 'nemo_v2v_prep_fwd')
             check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']),
                                 dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
-            self.gemm(0, 0, 2 * n, NV3, 207, dptr(w['PF2']), 208, ctx.posedirs, ldP, dptr(w['VP2']), ldP,
-                      bias=ctx.v_shaped, tag='gemm_pose_blend')
-            ev = self._event_begin('v2v_skin_l1', 2.0 * n * self.NV * (2 * 288 + 288 + 30))
-            check(L.nemo_v2v_skin_l1(ctx.handle, n, dptr(w['VP2']), ldP, dptr(w['A2']),
-                                     self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVP']), ldP, dptr(w['dA2']),
-                                     st), 'nemo_v2v_skin_l1')
+            w['dA2'].zero_()
+            ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * (2 * 3 * 207 + 2 * 288 + 288))
+            check(L.nemo_v2v_fused(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
+                                   self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPt']), ldn, dptr(w['dA2']),
+                                   st), 'nemo_v2v_fused')
             self._event_end(ev)
             if need_grad:
                 w['dPF2'].zero_()
-                self.gemm(0, 1, n, 207, NV3, dptr(w['dVP']), ldP, ctx.posedirs, ldP, dptr(w['dPF2']), 208,
+                self.gemm(1, 1, n, 207, NV3, dptr(w['dVPt']), ldn, ctx.posedirs, ldP, dptr(w['dPF2']), 208,
                           out_mode=2, split_k=8, tag='gemm_pose_blend_bwd')
                 check(L.nemo_fk_bwd(ctx.handle, n, dptr(w['R2']), dptr(w['A2']), dptr(w['dA2']), None,
                                     dptr(w['dPF2']), 208, w['dR2'].data_ptr() + 4 * c0 * 216, st), 'nemo_fk_bwd')

@@ -394,7 +394,7 @@ def test_vertices_and_v2v(L, num_verts):
     Z = lambda *s: torch.zeros(*s, device='cuda')
     dR2 = H.dev(R2.reshape(2 * N, 24, 9))
     ldP = ctx.ldP
-    assert ldP % 4 == 0 and 0 <= ldP - NV3 < 4
+    assert ldP % 4 == 0 and ldP == 3 * ctx.NVp and 0 <= ctx.NVp - num_verts < 16
     A, Jp, PF, VP = Z(2 * N, 24, 12), Z(2 * N, 24, 3), Z(2 * N, 207), Z(2 * N, NV3)
     assert L.nemo_fk_fwd(ctx.handle, 2 * N, dR2.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), 207,
                          H.st()) == 0
@@ -415,6 +415,42 @@ def test_vertices_and_v2v(L, num_verts):
     assert L.nemo_fk_bwd(ctx.handle, N, dR2.data_ptr(), A.data_ptr(), dA.data_ptr(), None, dPF.data_ptr(), 207,
                          dRg.data_ptr(), H.st()) == 0
     # |.| is non-smooth: a vertex coordinate within rounding of a tie flips a sign; compare in aggregate
+    assert rel_err(dRg.reshape(N, 24, 3, 3), Ro.grad) < 2e-3
+
+
+@pytest.mark.parametrize('num_verts,N', [(128, 6), (100, 37), (6890, 20)])
+def test_v2v_fused_mesh_kernel(L, num_verts, N):
+    """Fused pose blend + skinning + L1 + gradient (MFMA accumulator layout end to end) against the
+    oracle's unfused lbs + autograd; ragged vertex tiles (100, 6890 = 430*16+10) and sample groups."""
+    from oracle import ops
+    H = _ops()
+    assets, ctx, idx = _ctx(num_verts, 2)
+    gen = torch.Generator().manual_seed(47 + N)
+    NV3 = 3 * num_verts
+    R2 = _rand_rot(gen, 2 * N * 24, small=True).reshape(2 * N, 24, 3, 3)
+    R2[N:, 0] = R2[:N, 0]
+    Ro = R2[:N].clone().requires_grad_(True)
+    smpl = ops.SMPLOracle(assets)
+    vo, _, _ = smpl.forward(torch.zeros(1, 10), Ro)
+    vr, _, _ = smpl.forward(torch.zeros(1, 10), R2[N:])
+    l1 = (vr.detach() - vo).abs().sum()
+    l1.backward()
+    Z = lambda *s: torch.zeros(*s, device='cuda')
+    dR2 = H.dev(R2.reshape(2 * N, 24, 9))
+    A, Jp, PF = Z(2 * N, 24, 12), Z(2 * N, 24, 3), Z(2 * N, 208)
+    assert L.nemo_fk_fwd(ctx.handle, 2 * N, dR2.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), 208,
+                         H.st()) == 0
+    ldn = (N + 15) // 16 * 16
+    loss, dVPt, dA, dPF, dRg = Z(1), Z(3 * ctx.NVp, ldn), Z(N, 24, 12), Z(N, 208), Z(N, 24, 9)
+    assert L.nemo_v2v_fused(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss.data_ptr(), dVPt.data_ptr(),
+                            ldn, dA.data_ptr(), H.st()) == 0
+    assert rel_err(loss[0], l1.detach()) < 1e-5
+    assert float(dVPt[NV3:].abs().sum()) == 0.0 and float(dVPt[:, N:].abs().sum()) == 0.0   # pads stay zero
+    assert L.nemo_gemm_f32(1, 1, N, 207, NV3, dVPt.data_ptr(), ldn, ctx.posedirs, ctx.ldP, dPF.data_ptr(), 208,
+                           None, 0, None, 0, 0, 1.0, 2, 8, H.st()) == 0
+    assert L.nemo_fk_bwd(ctx.handle, N, dR2.data_ptr(), A.data_ptr(), dA.data_ptr(), None, dPF.data_ptr(), 208,
+                         dRg.data_ptr(), H.st()) == 0
+    # |.| is non-smooth: a coordinate within rounding of a tie flips a sign; compare in aggregate
     assert rel_err(dRg.reshape(N, 24, 3, 3), Ro.grad) < 2e-3
 
 
