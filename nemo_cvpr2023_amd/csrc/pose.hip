@@ -393,7 +393,10 @@ extern "C" int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t
                            (int)K, (int)D, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp,
                            log_sigmas, (int)kernel_id, phase, dX, (long)ldx, ws);
         NEMO_LAUNCH_CHECK();
-        const long chunk = 512;
+        // ~2 blocks per CU: V * ceil(N / chunk) blocks, each atomic address touched once per chunk
+        long chunk = (N * V + 511) / 512;
+        if (chunk < 32) chunk = 32;
+        if (chunk > 512) chunk = 512;
         hipLaunchKernelGGL(phase_bwd_nodes_kernel, dim3((unsigned)V, nemo_cdiv(N, chunk)), dim3(256), 0, st,
                            (long)N, (int)K, chunk, view_idx, shifts, scales, (long)ldp, ws, d_shifts, d_scales);
         NEMO_LAUNCH_CHECK();

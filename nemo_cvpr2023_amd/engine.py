@@ -32,6 +32,7 @@ RBF_KERNELS = {'quadratic': 0, 'linear': 1, 'gaussian': 2, 'inverse_quadratic': 
                'matern52': 10}
 # slots of the per-step device scalar buffer
 S_KP, S_V2V, S_KL, S_GMM, S_3D = 0, 1, 2, 3, 4
+HEAD_LD = 148      # row stride of the merged MLP head output [rot6d 144 | trans 3 | pad]
 
 
 def _stream():
@@ -97,12 +98,15 @@ def fold_vposer(sd: dict, device):
     s2, t2 = bn('encoder_net.4')
     W2, b2 = g('encoder_net.2.weight'), g('encoder_net.2.bias')
     W6, b6 = g('encoder_net.6.weight'), g('encoder_net.6.bias')
+    # encoder tail: BN(512) -> Linear6 -> Linear7 -> [mu | logvar] has no activation in between
+    # (vposer_model.py:74-78), so it is ONE affine map 512 -> 64 (3 GEMMs + their 3 adjoints -> 1 + 1)
+    W6f, b6f = W6 * s2.unsqueeze(0), W6 @ t2 + b6
+    W7, b7 = g('encoder_net.7.weight'), g('encoder_net.7.bias')
+    Wm = torch.cat([g('encoder_net.8.mu.weight'), g('encoder_net.8.logvar.weight')], 0)
+    bm = torch.cat([g('encoder_net.8.mu.bias'), g('encoder_net.8.logvar.bias')], 0)
     out = {
         'e2w': W2 * s1.unsqueeze(0), 'e2b': W2 @ t1 + b2,
-        'e6w': W6 * s2.unsqueeze(0), 'e6b': W6 @ t2 + b6,
-        'e7w': g('encoder_net.7.weight'), 'e7b': g('encoder_net.7.bias'),
-        'emw': torch.cat([g('encoder_net.8.mu.weight'), g('encoder_net.8.logvar.weight')], 0),
-        'emb': torch.cat([g('encoder_net.8.mu.bias'), g('encoder_net.8.logvar.bias')], 0),
+        'emw': Wm @ W7 @ W6f, 'emb': Wm @ (W7 @ b6f + b7) + bm,
         'd0w': g('decoder_net.0.weight'), 'd0b': g('decoder_net.0.bias'),
         'd3w': g('decoder_net.3.weight'), 'd3b': g('decoder_net.3.bias'),
         'd5w': g('decoder_net.5.weight'), 'd5b': g('decoder_net.5.bias'),
@@ -123,33 +127,45 @@ def gmm_constants(gmm: dict, device):
 
 
 class ParamLayout:
-    """Flat parameter buffer in optimiser order; ``entries`` maps state_dict name -> (offset, shape)."""
+    """Flat parameter buffer.  ``groups`` lists the tensors of each optimiser in the reference's
+    parameter order (what ``state_dict`` / torch-format optimiser states follow); ``entries`` maps
+    state_dict name -> (offset, shape).  Memory order differs from the optimiser order in one place:
+    the rot_out / linear_out weights are adjacent and so are their biases, so the two MLP heads run as
+    ONE (h -> 147) GEMM forward and backward."""
 
     def __init__(self, V, K, D, C, h, din):
         self.entries = OrderedDict()
-        self.groups = OrderedDict()    # optimiser name -> [names]
-        off = 0
+        self.groups = OrderedDict()    # optimiser name -> [names] in optimiser order
+        lm = 'learned_motion.'
+        shapes = OrderedDict()
+        order = []                     # memory order
 
-        def add(group, name, shape):
-            nonlocal off
-            n = int(np.prod(shape))
-            self.entries[name] = (off, tuple(shape))
+        def reg(group, name, shape, place=True):
+            shapes[name] = tuple(shape)
             self.groups.setdefault(group, []).append(name)
-            off += n
-        add('cameras', 'learned_cameras', (V, 9))
-        for lname, (fo, fi) in (('net.net.0', (h, din)), ('net.net.2', (h, h)), ('net.net.4', (h, h)),
-                                ('rot_out', (144, h)), ('linear_out', (3, h))):
-            add('motion', f'learned_motion.{lname}.weight', (fo, fi))
-            add('motion', f'learned_motion.{lname}.bias', (fo,))
+            if place:
+                order.append(name)
+        reg('cameras', 'learned_cameras', (V, 9))
+        for lname, (fo, fi) in (('net.net.0', (h, din)), ('net.net.2', (h, h)), ('net.net.4', (h, h))):
+            reg('motion', f'{lm}{lname}.weight', (fo, fi))
+            reg('motion', f'{lm}{lname}.bias', (fo,))
+        for lname, fo in (('rot_out', 144), ('linear_out', 3)):
+            reg('motion', f'{lm}{lname}.weight', (fo, h), place=False)
+            reg('motion', f'{lm}{lname}.bias', (fo,), place=False)
+        order += [lm + 'rot_out.weight', lm + 'linear_out.weight', lm + 'rot_out.bias', lm + 'linear_out.bias']
         if D > 0:
-            add('motion', 'phase_rbf.log_sigmas', (D,))
+            reg('motion', 'phase_rbf.log_sigmas', (D,))
         # 8 floats that travel with the shared-gradient all-reduce (loss scalars); no optimiser owns them
-        add('comm', '_comm_scalars', (8,))
+        reg('comm', '_comm_scalars', (8,))
         for i in range(V):
-            add('phase', f'phase_networks.{i}.shifts', (K,))
-            add('phase', f'phase_networks.{i}.scales', (K,))
+            reg('phase', f'phase_networks.{i}.shifts', (K,))
+            reg('phase', f'phase_networks.{i}.scales', (K,))
         if C > 0:
-            add('instance', 'learned_instance_code', (V, C))
+            reg('instance', 'learned_instance_code', (V, C))
+        off = 0
+        for name in order:
+            self.entries[name] = (off, shapes[name])
+            off += int(np.prod(shapes[name]))
         self.total = off
 
     def span(self, names):
@@ -227,18 +243,21 @@ class FitEngine:
         h, nq = self.h, self.ctx.nq
         Nc = min(N, 8192)
         w = dict(
-            X=Z(N + 1, self.din), H1=Z(N + 1, h), H2=Z(N + 1, h), H3=Z(N + 1, h), ROT=Z(N + 1, 144),
-            TR=Z(N + 1, 3), phase=Z(N), phase_ws=Z(N, 4), gmm_ws=Z(N, self.gmm['M']), R=Z(N, 24, 9), AA=Z(N, 72), A=Z(N, 24, 12), Jp=Z(N, 24, 3),
+            X=Z(N + 1, self.din), H1=Z(N + 1, h), H2=Z(N + 1, h), H3=Z(N + 1, h), HEAD=Z(N + 1, HEAD_LD),
+            phase=Z(N), phase_ws=Z(N, 4), gmm_ws=Z(N, self.gmm['M']), R=Z(N, 24, 9), AA=Z(N, 72), A=Z(N, 24, 12), Jp=Z(N, 24, 3),
             PF=Z(N, 208), Mq=Z(N, max(nq * 72, 1)), j3d=Z(N, self.ctx.n_out, 3), p2d=Z(N, self.ctx.n_out, 2),
             loss_all=Z(N, self.ctx.n_out, 2), view_acc=Z(self.V, 2), norm=Z(1),
-            E1=Z(N, 512), E2=Z(N, 512), E3=Z(N, 512), MULV=Z(N, 64), D1=Z(N, 512), D2=Z(N, 512),
+            E1=Z(N, 512), MULV=Z(N, 64), D1=Z(N, 512), D2=Z(N, 512),
             D3=Z(N, 126), AAdec=Z(N, 63),
             R2=Z(2 * Nc, 24, 9), A2=Z(2 * Nc, 24, 12), Jp2=Z(2 * Nc, 24, 3), PF2=Z(2 * Nc, 208),
             dVPt=Z(3 * self.ctx.NVp, (Nc + 15) // 16 * 16), dA2=Z(Nc, 24, 12), dPF2=Z(Nc, 208),
             dR2=Z(N, 24, 9),
             dAA=Z(N, 72), dR=Z(N, 24, 9), dA=Z(N, 24, 12), dJp=Z(N, 24, 3), dMq=Z(N, max(nq * 72, 1)),
-            dPF=Z(N, 208), dROT=Z(N + 1, 144), dTR=Z(N + 1, 3), dH=Z(N + 1, h), dH_b=Z(N + 1, h),
-            dX=Z(N + 1, self.din), dMULV=Z(N, 64), dE_a=Z(N, 512), dE_b=Z(N, 512), Nc=Nc)
+            dPF=Z(N, 208), dHEAD=Z(N + 1, HEAD_LD), dH=Z(N + 1, h), dH_b=Z(N + 1, h),
+            dX=Z(N + 1, self.din), dMULV=Z(N, 64), dE_a=Z(N, 512), Nc=Nc)
+        # strided views into the merged MLP-head buffers
+        w['ROT'], w['TR'] = w['HEAD'][:, :144], w['HEAD'][:, 144:147]
+        w['dROT'], w['dTR'] = w['dHEAD'][:, :144], w['dHEAD'][:, 144:147]
         self.ws[N] = w
         return w
 
@@ -269,14 +288,15 @@ class FitEngine:
         """y = act(x @ w^T + b), w stored (fout, fin) like nn.Linear."""
         self.gemm(0, 1, rows, fout, fin, x, ldx, w, fin, y, ldy, bias=b, act=act, tag=tag)
 
-    def _linear_bwd_params(self, rows, x, ldx, fin, dy, lddy, fout, gw, gb):
-        """gw (fout,fin) += dy^T @ x ;  gb += colsum(dy) (skipped when gb is None).  K = rows is
-        split for occupancy."""
+    def _linear_bwd_params(self, rows, x, ldx, fin, dy, lddy, fout, gw, gb, nbias=None):
+        """gw (fout,fin) += dy^T @ x ;  gb[:nbias] += colsum(dy) (skipped when gb is None).  K = rows
+        is split for occupancy."""
         tiles = ((fout + 63) // 64) * ((fin + 63) // 64)
         split = max(1, min(64, (512 + tiles - 1) // tiles, (rows + 255) // 256))
         self.gemm(1, 0, fout, fin, rows, dy, lddy, x, ldx, gw, fin, out_mode=2, split_k=split)
         if gb is not None:
-            check(self.lib.nemo_colsum_f32(dy, rows, fout, lddy, gb, _stream()), 'nemo_colsum_f32')
+            check(self.lib.nemo_colsum_f32(dy, rows, fout if nbias is None else nbias, lddy, gb, _stream()),
+                  'nemo_colsum_f32')
 
     # ------------------------------------------------------------------ forward pieces
     def forward_pose(self, w, N, view_idx, frame_idx, raw_phase=None, code_noise=None):
@@ -297,11 +317,10 @@ class FitEngine:
                      h, dptr(w['H2']), h, act=1, tag='gemm_mlp_hidden_fwd')
         self._linear(r, dptr(w['H2']), h, h, self.p(lm + 'net.net.4.weight'), self.p(lm + 'net.net.4.bias'),
                      h, dptr(w['H3']), h, act=1)
+        # both heads in one GEMM: [rot_out.weight ; linear_out.weight] are adjacent in the flat buffer
         self._linear(r, dptr(w['H3']), h, h, self.p(lm + 'rot_out.weight'), self.p(lm + 'rot_out.bias'),
-                     144, dptr(w['ROT']), 144)
-        self._linear(r, dptr(w['H3']), h, h, self.p(lm + 'linear_out.weight'), self.p(lm + 'linear_out.bias'),
-                     3, dptr(w['TR']), 3)
-        check(L.nemo_rot6d_fwd(N, 24, dptr(w['ROT']), 144, 1, dptr(w['R']), dptr(w['AA']), st),
+                     147, dptr(w['HEAD']), HEAD_LD)
+        check(L.nemo_rot6d_fwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, dptr(w['R']), dptr(w['AA']), st),
               'nemo_rot6d_fwd')
 
     def forward_joints(self, w, N, view_idx, frame_idx, with_loss, mean_mode=0, add_trans=True, ctx=None,
@@ -320,7 +339,7 @@ class FitEngine:
         lt = LOSS_TYPES[self.args.loss]
         check(L.nemo_kp_fwd(
             ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), max(nq72, 1),
-            dptr(w['TR']), 3, 1 if (add_trans and not self.start_global_traj_anywhere) else 0,
+            dptr(w['TR']), HEAD_LD, 1 if (add_trans and not self.start_global_traj_anywhere) else 0,
             dptr(view_idx), dptr(frame_idx), self.p('learned_cameras'),
             dptr(self.targets) if with_loss else None, dptr(self.gt_size) if with_loss else None,
             FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode,
@@ -338,9 +357,7 @@ class FitEngine:
         L, st, vp = self.lib, _stream(), self.vp
         aa63 = w['AA'].data_ptr() + 4 * 3
         self._linear(N, aa63, 72, 63, dptr(vp['e2w']), dptr(vp['e2b']), 512, dptr(w['E1']), 512, act=2)
-        self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['e6w']), dptr(vp['e6b']), 512, dptr(w['E2']), 512)
-        self._linear(N, dptr(w['E2']), 512, 512, dptr(vp['e7w']), dptr(vp['e7b']), 512, dptr(w['E3']), 512)
-        self._linear(N, dptr(w['E3']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
+        self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
         self._linear(N, dptr(w['MULV']), 64, 32, dptr(vp['d0w']), dptr(vp['d0b']), 512, dptr(w['D1']), 512,
                      act=2)
         self._linear(N, dptr(w['D1']), 512, 512, dptr(vp['d3w']), dptr(vp['d3b']), 512, dptr(w['D2']), 512,
@@ -388,12 +405,12 @@ class FitEngine:
         if not cams_only:
             w['dJp'].zero_()
         check(L.nemo_kp_bwd(
-            ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), nq72, dptr(w['TR']), 3,
-            add_trans, dptr(view_idx), dptr(frame_idx), self.p('learned_cameras'), dptr(self.targets),
+            ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), nq72, dptr(w['TR']),
+            HEAD_LD, add_trans, dptr(view_idx), dptr(frame_idx), self.p('learned_cameras'), dptr(self.targets),
             dptr(self.gt_size), FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode, dptr(w['view_acc']),
             dptr(w['norm']), upstream, None if cams_only else dptr(w['dA']),
             None if cams_only else dptr(w['dJp']), None if cams_only else dptr(w['dMq']),
-            None if cams_only else dptr(w['dTR']), 3, self.g('learned_cameras'), st), 'nemo_kp_bwd')
+            None if cams_only else dptr(w['dTR']), HEAD_LD, self.g('learned_cameras'), st), 'nemo_kp_bwd')
         if cams_only:
             return
         if self.detach_articulation:
@@ -413,10 +430,7 @@ class FitEngine:
         """d(weight*KL)/d poses[:, :63] through the frozen encoder, accumulated into dAA[:, 3:66]."""
         vp = self.vp
         self.gemm(0, 0, N, 512, 64, dptr(w['dMULV']), 64, dptr(vp['emw']), 512, dptr(w['dE_a']), 512,
-                  alpha=weight)
-        self.gemm(0, 0, N, 512, 512, dptr(w['dE_a']), 512, dptr(vp['e7w']), 512, dptr(w['dE_b']), 512)
-        self.gemm(0, 0, N, 512, 512, dptr(w['dE_b']), 512, dptr(vp['e6w']), 512, dptr(w['dE_a']), 512,
-                  mask=dptr(w['E1']), ldmask=512, mask_mode=2)
+                  alpha=weight, mask=dptr(w['E1']), ldmask=512, mask_mode=2)
         self.gemm(0, 0, N, 63, 512, dptr(w['dE_a']), 512, dptr(vp['e2w']), 63,
                   w['dAA'].data_ptr() + 4 * 3, 72, out_mode=1)
 
@@ -424,19 +438,15 @@ class FitEngine:
         """dROT (N+1,144), dTR (N+1,3) -> all MLP / RBF / phase / code gradients."""
         L, st, h, r = self.lib, _stream(), self.h, N + 1
         lm = 'learned_motion.'
-        self._linear_bwd_params(r, dptr(w['H3']), h, h, dptr(w['dROT']), 144, 144,
-                                self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'))
-        self.gemm(0, 0, r, h, 144, dptr(w['dROT']), 144, self.p(lm + 'rot_out.weight'), h, dptr(w['dH']), h,
-                  mask=dptr(w['H3']), ldmask=h, mask_mode=1)
-        if has_trans_grad:
-            # trans - trans_0 cancels the bias exactly: d/d(linear_out.bias) == 0 (the reference's
-            # autograd also produces an exact 0 there), so the column sum is skipped unless the
-            # global trajectory is left un-anchored.
-            gb = self.g(lm + 'linear_out.bias') if self.start_global_traj_anywhere else None
-            self._linear_bwd_params(r, dptr(w['H3']), h, h, dptr(w['dTR']), 3, 3,
-                                    self.g(lm + 'linear_out.weight'), gb)
-            self.gemm(0, 0, r, h, 3, dptr(w['dTR']), 3, self.p(lm + 'linear_out.weight'), h, dptr(w['dH']), h,
-                      mask=dptr(w['H3']), ldmask=h, mask_mode=1, out_mode=1)
+        # merged heads: dHEAD (N+1, [rot6d 144 | trans 3]) against [rot_out.weight ; linear_out.weight].
+        # trans - trans_0 cancels the linear_out bias exactly (the reference's autograd also yields an
+        # exact 0 there), so its column sum is skipped unless the global trajectory is un-anchored.
+        nout = 147 if has_trans_grad else 144
+        nbias = 147 if (has_trans_grad and self.start_global_traj_anywhere) else 144
+        self._linear_bwd_params(r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
+                                self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
+        self.gemm(0, 0, r, h, nout, dptr(w['dHEAD']), HEAD_LD, self.p(lm + 'rot_out.weight'), h,
+                  dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1)
         self._linear_bwd_params(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'),
                                 self.g(lm + 'net.net.4.bias'))
         self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
@@ -462,8 +472,9 @@ class FitEngine:
         """d trans_0 = - sum_s d trans_s  (row N of dTR), :3764-3766."""
         w['dTR'][N].zero_()
         if not self.start_global_traj_anywhere:
-            check(self.lib.nemo_scale_neg_rowsum(N, 3, dptr(w['dTR']), 3, w['dTR'].data_ptr() + 4 * 3 * N,
-                                                 _stream()), 'nemo_scale_neg_rowsum')
+            check(self.lib.nemo_scale_neg_rowsum(N, 3, dptr(w['dTR']), HEAD_LD,
+                                                 w['dTR'].data_ptr() + 4 * HEAD_LD * N, _stream()),
+                  'nemo_scale_neg_rowsum')
 
     # ------------------------------------------------------------------ optimiser
     def adam(self, segments, exp_avg=None, exp_avg_sq=None):

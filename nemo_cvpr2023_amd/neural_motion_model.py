@@ -29,7 +29,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import check, dptr
-from .engine import (FOCAL_LENGTH, LOSS_TYPES, S_3D, S_GMM, S_KL, S_KP, S_V2V, FitEngine, _stream)
+from .engine import (FOCAL_LENGTH, HEAD_LD, LOSS_TYPES, S_3D, S_GMM, S_KL, S_KP, S_V2V, FitEngine, _stream)
 
 S_INST = 5
 
@@ -115,17 +115,18 @@ class FusedAdam(torch.optim.Optimizer):
     def segments(self, active=None):
         """Advance the step counters of the active tensors and return merged launch segments."""
         g = self.param_groups[0]
-        segs = []
+        raw = []
         for n in self.names:
             if active is not None and n not in active:
                 continue
             self.steps[n] += 1
             off, shape = self._engine.layout.entries[n]
-            numel = int(np.prod(shape))
-            s = dict(offset=off, numel=numel, lr=float(g['lr']), wd=float(g['weight_decay']),
-                     adamw=self.adamw, step=self.steps[n])
-            if segs and segs[-1]['offset'] + segs[-1]['numel'] == off and segs[-1]['step'] == s['step']:
-                segs[-1]['numel'] += numel
+            raw.append(dict(offset=off, numel=int(np.prod(shape)), lr=float(g['lr']),
+                            wd=float(g['weight_decay']), adamw=self.adamw, step=self.steps[n]))
+        segs = []
+        for s in sorted(raw, key=lambda d: d['offset']):       # memory order: adjacent tensors merge
+            if segs and segs[-1]['offset'] + segs[-1]['numel'] == s['offset'] and segs[-1]['step'] == s['step']:
+                segs[-1]['numel'] += s['numel']
             else:
                 segs.append(s)
         return segs
@@ -419,8 +420,8 @@ class MultiViewModel(nn.Module):
                                           dptr(w['dAA']), dptr(w['dR']), st), 'nemo_v2v_prep_bwd')
         if use_vposer and a.weight_vp_z_loss:
             e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
-        check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), 144, 1, dptr(w['dR']), dptr(w['dAA']),
-                                   dptr(w['dROT']), 144, st), 'nemo_rot6d_bwd')
+        check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, dptr(w['dR']), dptr(w['dAA']),
+                                   dptr(w['dROT']), HEAD_LD, st), 'nemo_rot6d_bwd')
         e.finish_trans_grad(w, N)
         e.backward_mlp(w, N, vi, fi, None)
 
@@ -538,8 +539,8 @@ class MultiViewModel(nn.Module):
                                                 dptr(e.hmr_mask), dptr(vi), dptr(fi), e.T,
                                                 e.scal.data_ptr() + 4 * S_3D, float(sh.mr),
                                                 w['dAA'].data_ptr() + 12, 72, st), 'nemo_pose3d_fwd_bwd')
-                check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), 144, 1, None, dptr(w['dAA']),
-                                           dptr(w['dROT']), 144, st), 'nemo_rot6d_bwd')
+                check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, None, dptr(w['dAA']),
+                                           dptr(w['dROT']), HEAD_LD, st), 'nemo_rot6d_bwd')
                 e.backward_mlp(w, N, vi, fi, None, has_trans_grad=False)
             s = self._reduce_and_read(sh, True)
             if bool(torch.isnan(e.grads).any()):

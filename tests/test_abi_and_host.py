@@ -51,12 +51,16 @@ def test_param_layout_matches_reference_optimizer_order():
         'learned_motion.linear_out.weight', 'learned_motion.linear_out.bias', 'phase_rbf.log_sigmas']
     assert lay.groups['phase'][:4] == ['phase_networks.0.shifts', 'phase_networks.0.scales',
                                        'phase_networks.1.shifts', 'phase_networks.1.scales']
-    # contiguous, non-overlapping
+    # contiguous, non-overlapping in MEMORY order (entries); the two MLP heads sit next to each other
     end = 0
     for name, (off, shape) in lay.entries.items():
         assert off == end, name
         end = off + int(np.prod(shape))
     assert end == lay.total
+    e = lay.entries
+    assert e['learned_motion.linear_out.weight'][0] == e['learned_motion.rot_out.weight'][0] + 144 * 48
+    assert e['learned_motion.linear_out.bias'][0] == e['learned_motion.rot_out.bias'][0] + 144
+    assert e['learned_motion.rot_out.bias'][0] == e['learned_motion.linear_out.weight'][0] + 3 * 48
     a, b = lay.span(lay.groups['motion'])
     assert b - a == 48 * 21 + 48 + 2 * (48 * 48 + 48) + 144 * 48 + 144 + 3 * 48 + 3 + 16
     a2, b2 = lay.span(lay.groups['motion'] + lay.groups['comm'])
@@ -95,8 +99,7 @@ def test_vposer_folding_matches_unfolded():
     x = 0.3 * torch.randn(7, 63, generator=torch.Generator().manual_seed(0))
     lin = torch.nn.functional.linear
     h = torch.nn.functional.leaky_relu(lin(x, f['e2w'], f['e2b']))
-    h = lin(lin(h, f['e6w'], f['e6b']), f['e7w'], f['e7b'])
-    ml = lin(h, f['emw'], f['emb'])
+    ml = lin(h, f['emw'], f['emb'])          # BN + Linear6 + Linear7 + heads folded into one 512 -> 64 map
     mean, scale = ops.VPoserOracle(sd).encode(x)
     assert float((ml[:, :32] - mean).abs().max()) < 1e-5
     assert float((torch.nn.functional.softplus(ml[:, 32:]) - scale).abs().max()) < 1e-5
