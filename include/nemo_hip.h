@@ -47,6 +47,10 @@ int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int6
                       int32_t out_mode, int32_t split_k, void* stream);
 /* out[n] += sum_m X[m*ldx+n]   (bias gradients). */
 int32_t nemo_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* stream);
+/* The same for up to NEMO_COLSUM_MAX matrices in ONE launch (all bias gradients of the MLP backward). */
+#define NEMO_COLSUM_MAX 8
+typedef struct { const float* X; int64_t M, N, ldx; float* out; } nemo_colsum_desc;
+int32_t nemo_colsum_multi(int32_t n, const nemo_colsum_desc* descs /* HOST array */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Phase warp + RBF embedding + instance code -> MLP input rows.
@@ -245,7 +249,7 @@ int32_t nemo_adam_step(int32_t n_seg, const nemo_adam_seg* segs /* HOST */, floa
 
 /* Small utilities. */
 int32_t nemo_scale_neg_rowsum(int64_t N, int64_t cols, const float* X, int64_t ldx, float* out_row,
-                              void* stream);  /* out_row[c] -= sum_s X[s][c]   (d trans_0) */
+                              void* stream);  /* out_row[c] = -sum_s X[s][c]   (d trans_0) */
 
 #ifdef __cplusplus
 }

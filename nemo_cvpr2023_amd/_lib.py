@@ -15,6 +15,10 @@ LIB_PATH = os.path.join(_HERE, 'libnemo_hip.so')
 ADAM_MAX_SEG = 16
 
 
+class ColsumDesc(Structure):
+    _fields_ = [('X', c_void_p), ('M', c_int64), ('N', c_int64), ('ldx', c_int64), ('out', c_void_p)]
+
+
 class AdamSeg(Structure):
     _fields_ = [('offset', c_int64), ('numel', c_int64), ('lr', c_float), ('weight_decay', c_float),
                 ('step_size', c_float), ('bias_corr2_sqrt', c_float), ('adamw', c_int32), ('pad', c_int32)]
@@ -28,6 +32,7 @@ SIGNATURES = {
     'nemo_gemm_f32': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32,
                             f32, i32, i32, ptr]),
     'nemo_colsum_f32': (i32, [ptr, i64, i64, i64, ptr, ptr]),
+    'nemo_colsum_multi': (i32, [i32, POINTER(ColsumDesc), ptr]),
     'nemo_phase_embed_fwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
                                    i32, ptr, i64, ptr, ptr]),
     'nemo_phase_embed_bwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i32, ptr,

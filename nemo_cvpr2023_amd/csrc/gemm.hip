@@ -335,6 +335,46 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
 }
 }  // namespace
 
+namespace {
+struct ColsumBatch { nemo_colsum_desc d[NEMO_COLSUM_MAX]; };
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumBatch b, long rows_per_block) {
+    const nemo_colsum_desc d = b.d[blockIdx.z];
+    const long n = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const long mbeg = (long)blockIdx.y * rows_per_block;
+    if (mbeg >= d.M || (long)blockIdx.x * 64 >= d.N) return;       // block-uniform
+    const long mend = min((long)d.M, mbeg + rows_per_block);
+    float s = 0.f;
+    if (n < d.N)
+        for (long m = mbeg + (threadIdx.x >> 6); m < mend; m += 4) s += d.X[m * d.ldx + n];
+    __shared__ float red[4][64];
+    red[threadIdx.x >> 6][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && n < d.N) {
+        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(d.out + n, t);
+    }
+}
+}  // namespace
+
+extern "C" int32_t nemo_colsum_multi(int32_t n, const nemo_colsum_desc* descs, void* stream) {
+    if (n < 0 || n > NEMO_COLSUM_MAX || (n && !descs)) return NEMO_EINVAL;
+    if (n == 0) return NEMO_OK;
+    ColsumBatch b;
+    long maxM = 0, maxN = 0;
+    for (int i = 0; i < n; ++i) {
+        if (descs[i].M < 0 || descs[i].N < 0 || !descs[i].X || !descs[i].out) return NEMO_EINVAL;
+        b.d[i] = descs[i];
+        if (descs[i].M > maxM) maxM = descs[i].M;
+        if (descs[i].N > maxN) maxN = descs[i].N;
+    }
+    if (maxM == 0 || maxN == 0) return NEMO_OK;
+    const long rows_per_block = 128;
+    dim3 grid(nemo_cdiv(maxN, 64), nemo_cdiv(maxM, rows_per_block), n);
+    hipLaunchKernelGGL(colsum_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, b, rows_per_block);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
 extern "C" int32_t nemo_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out,
                                    void* stream) {
     if (M < 0 || N < 0 || !out) return NEMO_EINVAL;

@@ -343,15 +343,14 @@ __global__ __launch_bounds__(256) void v2v_prep_bwd_kernel(long N, const float* 
     }
 }
 
-__global__ __launch_bounds__(256) void neg_rowsum_kernel(long N, int cols, const float* __restrict__ X,
-                                                         long ldx, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void neg_rowsum_kernel(long N, int cols, const float* __restrict__ X,
+                                                          long ldx, float* __restrict__ out) {
     __shared__ float red[16];
     for (int c = 0; c < cols; ++c) {
         float s = 0.f;
-        for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (long)gridDim.x * blockDim.x)
-            s += X[r * ldx + c];
+        for (long r = threadIdx.x; r < N; r += blockDim.x) s += X[r * ldx + c];
         const float t = block_sum(s, red);
-        if (threadIdx.x == 0 && t != 0.f) atomicAdd(out + c, -t);
+        if (threadIdx.x == 0) out[c] = -t;
     }
 }
 
@@ -481,9 +480,7 @@ extern "C" int32_t nemo_scale_neg_rowsum(int64_t N, int64_t cols, const float* X
                                          void* stream) {
     if (N < 0 || cols <= 0 || !X || !out_row) return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
-    int blocks = nemo_cdiv(N, 256);
-    if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(neg_rowsum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)N, (int)cols,
+    hipLaunchKernelGGL(neg_rowsum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (long)N, (int)cols,
                        X, (long)ldx, out_row);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;

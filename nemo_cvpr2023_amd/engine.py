@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import AdamSeg, check, dptr
+from ._lib import AdamSeg, ColsumDesc, check, dptr
 
 FOCAL_LENGTH = 5000.0          # hmr/hmr_constants.py:1
 LOSS_TYPES = {'mse_robust': 0, 'mse': 1, 'rmse': 2, 'rmse_robust': 3, 'mse_robust_resized': 4,
@@ -217,6 +217,7 @@ class FitEngine:
         self.scal = torch.zeros(8, **f32)
         self._scal_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.ws = {}
+        self._colsums = []
         self.timers = None
         self.detach_articulation = False
         self.start_global_traj_anywhere = False
@@ -242,19 +243,29 @@ class FitEngine:
         Z = lambda *s: torch.zeros(*s, **f32)
         h, nq = self.h, self.ctx.nq
         Nc = min(N, 8192)
+        # everything that must be zero at the start of a step lives in ONE arena (a single memset)
+        sizes = OrderedDict(view_acc=(self.V, 2), dAA=(N, 72), dJp=(N, 24, 3), dA2=(Nc, 24, 12), dPF2=(Nc, 208))
+        arena = Z(sum(int(np.prod(v)) for v in sizes.values()))
+        views, off = {}, 0
+        for k, shp in sizes.items():
+            n_ = int(np.prod(shp))
+            views[k] = arena[off:off + n_].view(shp)
+            off += n_
         w = dict(
             X=Z(N + 1, self.din), H1=Z(N + 1, h), H2=Z(N + 1, h), H3=Z(N + 1, h), HEAD=Z(N + 1, HEAD_LD),
             phase=Z(N), phase_ws=Z(N, 4), gmm_ws=Z(N, self.gmm['M']), R=Z(N, 24, 9), AA=Z(N, 72), A=Z(N, 24, 12), Jp=Z(N, 24, 3),
             PF=Z(N, 208), Mq=Z(N, max(nq * 72, 1)), j3d=Z(N, self.ctx.n_out, 3), p2d=Z(N, self.ctx.n_out, 2),
-            loss_all=Z(N, self.ctx.n_out, 2), view_acc=Z(self.V, 2), norm=Z(1),
+            loss_all=Z(N, self.ctx.n_out, 2), norm=Z(1),
             E1=Z(N, 512), MULV=Z(N, 64), D1=Z(N, 512), D2=Z(N, 512),
             D3=Z(N, 126), AAdec=Z(N, 63),
             R2=Z(2 * Nc, 24, 9), A2=Z(2 * Nc, 24, 12), Jp2=Z(2 * Nc, 24, 3), PF2=Z(2 * Nc, 208),
-            dVPt=Z(3 * self.ctx.NVp, (Nc + 15) // 16 * 16), dA2=Z(Nc, 24, 12), dPF2=Z(Nc, 208),
+            dVPt=Z(3 * self.ctx.NVp, (Nc + 15) // 16 * 16),
             dR2=Z(N, 24, 9),
-            dAA=Z(N, 72), dR=Z(N, 24, 9), dA=Z(N, 24, 12), dJp=Z(N, 24, 3), dMq=Z(N, max(nq * 72, 1)),
-            dPF=Z(N, 208), dHEAD=Z(N + 1, HEAD_LD), dH=Z(N + 1, h), dH_b=Z(N + 1, h),
+            dR=Z(N, 24, 9), dA=Z(N, 24, 12), dMq=Z(N, max(nq * 72, 1)),
+            dPF=Z(N, 208), dHEAD=Z(N + 1, HEAD_LD), dH=Z(N + 1, h), dH_b=Z(N + 1, h), dH_c=Z(N + 1, h),
             dX=Z(N + 1, self.din), dMULV=Z(N, 64), dE_a=Z(N, 512), Nc=Nc)
+        w.update(views)
+        w['zero_arena'] = arena
         # strided views into the merged MLP-head buffers
         w['ROT'], w['TR'] = w['HEAD'][:, :144], w['HEAD'][:, 144:147]
         w['dROT'], w['dTR'] = w['dHEAD'][:, :144], w['dHEAD'][:, 144:147]
@@ -294,9 +305,18 @@ class FitEngine:
         tiles = ((fout + 63) // 64) * ((fin + 63) // 64)
         split = max(1, min(64, (512 + tiles - 1) // tiles, (rows + 255) // 256))
         self.gemm(1, 0, fout, fin, rows, dy, lddy, x, ldx, gw, fin, out_mode=2, split_k=split)
-        if gb is not None:
-            check(self.lib.nemo_colsum_f32(dy, rows, fout if nbias is None else nbias, lddy, gb, _stream()),
-                  'nemo_colsum_f32')
+        if gb is not None:       # bias gradients are batched into one launch (flush_colsums)
+            self._colsums.append((dy, rows, fout if nbias is None else nbias, lddy, gb))
+
+    def flush_colsums(self):
+        if not self._colsums:
+            return
+        n = len(self._colsums)
+        arr = (ColsumDesc * n)()
+        for i, (x, m, nn, ld, out) in enumerate(self._colsums):
+            arr[i].X, arr[i].M, arr[i].N, arr[i].ldx, arr[i].out = x, m, nn, ld, out
+        check(self.lib.nemo_colsum_multi(n, arr, _stream()), 'nemo_colsum_multi')
+        self._colsums = []
 
     # ------------------------------------------------------------------ forward pieces
     def forward_pose(self, w, N, view_idx, frame_idx, raw_phase=None, code_noise=None):
@@ -382,14 +402,16 @@ class FitEngine:
             check(L.nemo_v2v_prep_fwd(n, R, AA, AAd, dptr(w['R2']), st), 'nemo_v2v_prep_fwd')
             check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']),
                                 dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
-            w['dA2'].zero_()
+            if c0 > 0:
+                w['dA2'].zero_()
             ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * (2 * 3 * 207 + 2 * 288 + 288))
             check(L.nemo_v2v_fused(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
                                    self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPt']), ldn, dptr(w['dA2']),
                                    st), 'nemo_v2v_fused')
             self._event_end(ev)
             if need_grad:
-                w['dPF2'].zero_()
+                if c0 > 0:
+                    w['dPF2'].zero_()
                 self.gemm(1, 1, n, 207, NV3, dptr(w['dVPt']), ldn, ctx.posedirs, ldP, dptr(w['dPF2']), 208,
                           out_mode=2, split_k=8, tag='gemm_pose_blend_bwd')
                 check(L.nemo_fk_bwd(ctx.handle, n, dptr(w['R2']), dptr(w['A2']), dptr(w['dA2']), None,
@@ -402,8 +424,6 @@ class FitEngine:
         nq72 = max(ctx.nq * 72, 1)
         lt = LOSS_TYPES[self.args.loss]
         add_trans = 0 if self.start_global_traj_anywhere else 1
-        if not cams_only:
-            w['dJp'].zero_()
         check(L.nemo_kp_bwd(
             ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), nq72, dptr(w['TR']),
             HEAD_LD, add_trans, dptr(view_idx), dptr(frame_idx), self.p('learned_cameras'), dptr(self.targets),
@@ -453,12 +473,14 @@ class FitEngine:
                   mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx')
         self._linear_bwd_params(r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h,
                                 self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
-        self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH']), h,
+        # (each layer's dY keeps its own buffer: the bias column sums are batched into one launch below)
+        self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
                   mask=dptr(w['H1']), ldmask=h, mask_mode=1)
-        self._linear_bwd_params(r, dptr(w['X']), self.din, self.din, dptr(w['dH']), h, h,
+        self._linear_bwd_params(r, dptr(w['X']), self.din, self.din, dptr(w['dH_c']), h, h,
                                 self.g(lm + 'net.net.0.weight'), self.g(lm + 'net.net.0.bias'))
-        self.gemm(0, 0, r, self.din, h, dptr(w['dH']), h, self.p(lm + 'net.net.0.weight'), self.din,
+        self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
                   dptr(w['dX']), self.din)
+        self.flush_colsums()
         check(L.nemo_phase_embed_bwd(
             N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
             self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), 2 * self.K,
@@ -470,8 +492,9 @@ class FitEngine:
 
     def finish_trans_grad(self, w, N):
         """d trans_0 = - sum_s d trans_s  (row N of dTR), :3764-3766."""
-        w['dTR'][N].zero_()
-        if not self.start_global_traj_anywhere:
+        if self.start_global_traj_anywhere:
+            w['dTR'][N].zero_()
+        else:
             check(self.lib.nemo_scale_neg_rowsum(N, 3, dptr(w['dTR']), HEAD_LD,
                                                  w['dTR'].data_ptr() + 4 * HEAD_LD * N, _stream()),
                   'nemo_scale_neg_rowsum')
