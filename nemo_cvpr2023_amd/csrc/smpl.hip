@@ -198,133 +198,168 @@ extern "C" const float* nemo_ctx_v_shaped(const nemo_ctx* c) { return c ? c->d_v
 namespace {
 
 // ------------------------------------------------------------------------------------------ FK
-// One thread per body, 64 bodies per block.  The kinematic chain is inherently sequential (depth <= 9
-// in SMPL, 23 dependent 3x3 products); its state lives in LDS as [joint*12 + e][lane] (conflict-free,
-// 72 KB per block, opted in as dynamic LDS) so that parent transforms are re-read at LDS latency
-// instead of a global store -> load round trip per joint.
+// 64 bodies per block, 256 threads.  The kinematic chain is inherently sequential per body (23
+// dependent 3x3 products), so one thread per body walks it -- but at LDS latency: phase 1 stages the
+// block's rotations (64 x 216 contiguous floats) with coalesced loads into LDS rows of stride 217
+// (conflict-free per-body reads), phase 2 runs the chains with their state in LDS as
+// [joint*12 + e][lane], phase 3 writes transforms / posed joints back with coalesced stores.  A thread-
+// per-body kernel working directly on global memory issues ~50 scattered accesses per joint (64 cache
+// lines each) and was 4x slower.
 #define FK_TB 64
-#define FK_LDS_BYTES (24 * 12 * FK_TB * (int)sizeof(float))
+#define FK_GS 65       // chain-state stride: [entry][lane] with +1 pad -> conflict-free for fixed entry (phase 2)
+                       // AND for consecutive entries of one body (coalesced phases 1/3)
+#define FK_RS 217
+#define FK_LDS_BYTES ((24 * 12 * FK_GS + FK_TB * FK_RS) * (int)sizeof(float))
 
-__global__ __launch_bounds__(FK_TB) void fk_fwd_kernel(long rows, const float* __restrict__ R,
-                                                       const float* __restrict__ Jrest, KpConst kc,
-                                                       float* __restrict__ A, float* __restrict__ Jp,
-                                                       float* __restrict__ PF, long ldpf) {
-    extern __shared__ float G[];          // G[(j*12 + e) * FK_TB + lane]: e<9 rotation, e>=9 translation
-    const int lane = threadIdx.x;
-    const long row = (long)blockIdx.x * FK_TB + lane;
-    if (row >= rows) return;
-    const float* Rr = R + row * 216;
-    float* Ar = A + row * 288;
-    float* Jr = Jp + row * 72;
-#define GL(j, e) G[((j) * 12 + (e)) * FK_TB + lane]
-    for (int i = 0; i < 24; ++i) {
-        float Ri[9], Gi[9], gt[3];
+__global__ __launch_bounds__(256) void fk_fwd_kernel(long rows, const float* __restrict__ R,
+                                                     const float* __restrict__ Jrest, KpConst kc,
+                                                     float* __restrict__ A, float* __restrict__ Jp,
+                                                     float* __restrict__ PF, long ldpf) {
+    extern __shared__ float lds[];
+    float* G = lds;                                  // [(j*12 + e) * FK_TB + lane]: e<9 rotation, e>=9 translation
+    float* Rl = lds + 24 * 12 * FK_GS;               // [body][FK_RS]
+    const int tid = threadIdx.x;
+    const long row0 = (long)blockIdx.x * FK_TB;
+    const int nb = (int)min((long)FK_TB, rows - row0);
+    // ---- phase 1: coalesced load of the rotations; pose feature written on the fly
+    for (int idx = tid; idx < nb * 216; idx += 256) {
+        const int bdy = idx / 216, k = idx % 216;
+        const float v = R[row0 * 216 + idx];
+        Rl[bdy * FK_RS + k] = v;
+        if (PF && k >= 9) PF[(row0 + bdy) * ldpf + k - 9] = v - (((k % 9) % 4 == 0) ? 1.f : 0.f);
+    }
+    __syncthreads();
+    // ---- phase 2: one thread per body walks the chain
+    if (tid < nb) {
+        const int lane = tid;
+        const float* Rr = Rl + lane * FK_RS;
+#define GL(j, e) G[((j) * 12 + (e)) * FK_GS + lane]
+        for (int i = 0; i < 24; ++i) {
+            float Ri[9], Gi[9], gt[3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
-        const float ji[3] = {Jrest[i * 3], Jrest[i * 3 + 1], Jrest[i * 3 + 2]};
-        if (i == 0) {
+            for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
+            const float ji[3] = {Jrest[i * 3], Jrest[i * 3 + 1], Jrest[i * 3 + 2]};
+            if (i == 0) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Gi[k] = Ri[k];
-            gt[0] = ji[0]; gt[1] = ji[1]; gt[2] = ji[2];
-        } else {
+                for (int k = 0; k < 9; ++k) Gi[k] = Ri[k];
+                gt[0] = ji[0]; gt[1] = ji[1]; gt[2] = ji[2];
+            } else {
+                const int p = kc.parents[i];
+                float Gp[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Gp[k] = GL(p, k);
+                const float rel[3] = {ji[0] - Jrest[p * 3], ji[1] - Jrest[p * 3 + 1], ji[2] - Jrest[p * 3 + 2]};
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        Gi[r * 3 + c] = Gp[r * 3] * Ri[c] + Gp[r * 3 + 1] * Ri[3 + c] + Gp[r * 3 + 2] * Ri[6 + c];
+                    gt[r] = Gp[r * 3] * rel[0] + Gp[r * 3 + 1] * rel[1] + Gp[r * 3 + 2] * rel[2] + GL(p, 9 + r);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) GL(i, k) = Gi[k];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) GL(i, 9 + r) = gt[r];
+        }
+#undef GL
+    }
+    __syncthreads();
+    // ---- phase 3: coalesced write-out.  A[j] = [G_R | G_t - G_R J_j] (lbs.py:399-402), Jp[j] = G_t
+    for (int idx = tid; idx < nb * 288; idx += 256) {
+        const int bdy = idx / 288, e = idx % 288;
+        const int j = e / 12, r = (e % 12) / 4, c = e % 4;
+        const float* g = G + (j * 12) * FK_GS + bdy;
+        float v;
+        if (c < 3) v = g[(r * 3 + c) * FK_GS];
+        else v = g[(9 + r) * FK_GS] - (g[(r * 3) * FK_GS] * Jrest[j * 3] + g[(r * 3 + 1) * FK_GS] * Jrest[j * 3 + 1] +
+                                       g[(r * 3 + 2) * FK_GS] * Jrest[j * 3 + 2]);
+        A[row0 * 288 + idx] = v;
+    }
+    for (int idx = tid; idx < nb * 72; idx += 256) {
+        const int bdy = idx / 72, e = idx % 72;
+        Jp[row0 * 72 + idx] = G[((e / 3) * 12 + 9 + e % 3) * FK_GS + bdy];
+    }
+}
+
+__global__ __launch_bounds__(256) void fk_bwd_kernel(long rows, const float* __restrict__ R,
+                                                     const float* __restrict__ A,
+                                                     const float* __restrict__ Jrest, KpConst kc,
+                                                     const float* __restrict__ dA,
+                                                     const float* __restrict__ dJp,
+                                                     const float* __restrict__ dPF, long lddpf,
+                                                     float* __restrict__ dR) {
+    extern __shared__ float lds[];
+    float* D = lds;                                  // dG accumulators [(j*12 + r*4 + c) * FK_TB + lane]
+    float* Rl = lds + 24 * 12 * FK_GS;               // rotations in, rotation gradients out (in place)
+    const int tid = threadIdx.x;
+    const long row0 = (long)blockIdx.x * FK_TB;
+    const int nb = (int)min((long)FK_TB, rows - row0);
+    // ---- phase 1: coalesced loads.  dA -> dG:  A_t = G_t - G_R J  =>  dG_R = dA_R - dA_t (x) J ; dG_t = dA_t (+ dJp)
+    for (int idx = tid; idx < nb * 216; idx += 256) Rl[(idx / 216) * FK_RS + idx % 216] = R[row0 * 216 + idx];
+    for (int idx = tid; idx < nb * 288; idx += 256) {
+        const int bdy = idx / 288, e = idx % 288;
+        const int j = e / 12, r = (e % 12) / 4, c = e % 4;
+        const float* src = dA + (row0 + bdy) * 288 + j * 12 + r * 4;
+        const float dat = src[3];
+        float v;
+        if (c < 3) v = src[c] - dat * Jrest[j * 3 + c];
+        else v = dat + (dJp ? dJp[(row0 + bdy) * 72 + j * 3 + r] : 0.f);
+        D[e * FK_GS + bdy] = v;
+    }
+    __syncthreads();
+    // ---- phase 2: reverse sweep, one thread per body
+    if (tid < nb) {
+        const int lane = tid;
+        float* Rr = Rl + lane * FK_RS;
+        const float* Ar = A + (row0 + lane) * 288;
+#define DL(j, e) D[((j) * 12 + (e)) * FK_GS + lane]
+        for (int i = 23; i >= 1; --i) {
             const int p = kc.parents[i];
-            float Gp[9];
+            float Gp[9], Ri[9], dG[9], dgt[3];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Gp[k] = GL(p, k);
-            const float rel[3] = {ji[0] - Jrest[p * 3], ji[1] - Jrest[p * 3 + 1], ji[2] - Jrest[p * 3 + 2]};
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    Gp[r * 3 + c] = Ar[p * 12 + r * 4 + c];
+                    dG[r * 3 + c] = DL(i, r * 4 + c);
+                }
+                dgt[r] = DL(i, r * 4 + 3);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
+            const float rel[3] = {Jrest[i * 3] - Jrest[p * 3], Jrest[i * 3 + 1] - Jrest[p * 3 + 1],
+                                  Jrest[i * 3 + 2] - Jrest[p * 3 + 2]};
+            // dR_i = Gp^T dG_i   (stored in place of R_i, which is not needed again)
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    Rr[i * 9 + r * 3 + c] = Gp[r] * dG[c] + Gp[3 + r] * dG[3 + c] + Gp[6 + r] * dG[6 + c];
+            // dG_R[p] += dG_i Ri^T + dgt (x) rel ;  dG_t[p] += dgt
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    Gi[r * 3 + c] = Gp[r * 3] * Ri[c] + Gp[r * 3 + 1] * Ri[3 + c] + Gp[r * 3 + 2] * Ri[6 + c];
-                gt[r] = Gp[r * 3] * rel[0] + Gp[r * 3 + 1] * rel[1] + Gp[r * 3 + 2] * rel[2] + GL(p, 9 + r);
-            }
-            if (PF) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) PF[row * ldpf + (i - 1) * 9 + k] = Ri[k] - ((k % 4 == 0) ? 1.f : 0.f);
+                    DL(p, r * 4 + c) += dG[r * 3] * Ri[c * 3] + dG[r * 3 + 1] * Ri[c * 3 + 1] +
+                                        dG[r * 3 + 2] * Ri[c * 3 + 2] + dgt[r] * rel[c];
+                DL(p, r * 4 + 3) += dgt[r];
             }
         }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) GL(i, k) = Gi[k];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            GL(i, 9 + r) = gt[r];
-            Jr[i * 3 + r] = gt[r];
-            Ar[i * 12 + r * 4 + 0] = Gi[r * 3]; Ar[i * 12 + r * 4 + 1] = Gi[r * 3 + 1];
-            Ar[i * 12 + r * 4 + 2] = Gi[r * 3 + 2];
-            Ar[i * 12 + r * 4 + 3] = gt[r] - (Gi[r * 3] * ji[0] + Gi[r * 3 + 1] * ji[1] + Gi[r * 3 + 2] * ji[2]);
-        }
-    }
-#undef GL
-}
-
-__global__ __launch_bounds__(FK_TB) void fk_bwd_kernel(long rows, const float* __restrict__ R,
-                                                       const float* __restrict__ A,
-                                                       const float* __restrict__ Jrest, KpConst kc,
-                                                       const float* __restrict__ dA,
-                                                       const float* __restrict__ dJp,
-                                                       const float* __restrict__ dPF, long lddpf,
-                                                       float* __restrict__ dR) {
-    extern __shared__ float D[];          // dG accumulators: [(j*12 + r*4 + c) * FK_TB + lane]
-    const int lane = threadIdx.x;
-    const long row = (long)blockIdx.x * FK_TB + lane;
-    if (row >= rows) return;
-    const float* Rr = R + row * 216;
-    const float* Ar = A + row * 288;
-#define DL(j, e) D[((j) * 12 + (e)) * FK_TB + lane]
-    // dA -> dG:  A_t = G_t - G_R J  =>  dG_R = dA_R - dA_t (x) J ;  dG_t = dA_t (+ dJp)
-    for (int i = 0; i < 24; ++i) {
-        const float ji[3] = {Jrest[i * 3], Jrest[i * 3 + 1], Jrest[i * 3 + 2]};
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const float* src = dA + row * 288 + i * 12 + r * 4;
-            const float dat = src[3];
-            DL(i, r * 4 + 0) = src[0] - dat * ji[0];
-            DL(i, r * 4 + 1) = src[1] - dat * ji[1];
-            DL(i, r * 4 + 2) = src[2] - dat * ji[2];
-            DL(i, r * 4 + 3) = dat + (dJp ? dJp[row * 72 + i * 3 + r] : 0.f);
-        }
-    }
-    for (int i = 23; i >= 1; --i) {
-        const int p = kc.parents[i];
-        float Gp[9], Ri[9], dG[9], dgt[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                Gp[r * 3 + c] = Ar[p * 12 + r * 4 + c];
-                dG[r * 3 + c] = DL(i, r * 4 + c);
-            }
-            dgt[r] = DL(i, r * 4 + 3);
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
-        const float rel[3] = {Jrest[i * 3] - Jrest[p * 3], Jrest[i * 3 + 1] - Jrest[p * 3 + 1],
-                              Jrest[i * 3 + 2] - Jrest[p * 3 + 2]};
-        // dR_i = Gp^T dG_i  (+ pose-feature gradient)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float v = Gp[r] * dG[c] + Gp[3 + r] * dG[3 + c] + Gp[6 + r] * dG[6 + c];
-                if (dPF) v += dPF[row * lddpf + (i - 1) * 9 + r * 3 + c];
-                dR[row * 216 + i * 9 + r * 3 + c] = v;
-            }
-        // dG_R[p] += dG_i Ri^T + dgt (x) rel ;  dG_t[p] += dgt
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                DL(p, r * 4 + c) += dG[r * 3] * Ri[c * 3] + dG[r * 3 + 1] * Ri[c * 3 + 1] +
-                                    dG[r * 3 + 2] * Ri[c * 3 + 2] + dgt[r] * rel[c];
-            DL(p, r * 4 + 3) += dgt[r];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dR[row * 216 + r * 3 + c] = DL(0, r * 4 + c);
+            for (int c = 0; c < 3; ++c) Rr[r * 3 + c] = DL(0, r * 4 + c);
 #undef DL
+    }
+    __syncthreads();
+    // ---- phase 3: coalesced write-out (+ the pose-feature gradient of joints 1..23)
+    for (int idx = tid; idx < nb * 216; idx += 256) {
+        const int bdy = idx / 216, k = idx % 216;
+        float v = Rl[bdy * FK_RS + k];
+        if (dPF && k >= 9) v += dPF[(row0 + bdy) * lddpf + k - 9];
+        dR[row0 * 216 + idx] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ KP
@@ -340,26 +375,40 @@ struct KpArgs {
 
 __device__ __forceinline__ int loss_width(int loss_type) { return (loss_type == 2 || loss_type == 3 || loss_type == 5) ? 1 : 2; }
 
-// 3-D position of output joint o of sample s (before the global translation).
-__device__ __forceinline__ void kp_joint(const KpArgs& a, const KpConst& kc, long s, int o, float* pos) {
+// 3-D position of output joint o of sample s (before the global translation).  Al = the sample's 24
+// relative transforms staged in LDS (all lanes of a sample read the same addresses: broadcast).
+__device__ __forceinline__ void kp_joint(const KpArgs& a, const KpConst& kc, long s, int o, const float* Al,
+                                         float* pos) {
     const int kind = kc.out_kind[o];
     if (kind >= 0) {
         pos[0] = a.Jp[s * 72 + kind * 3]; pos[1] = a.Jp[s * 72 + kind * 3 + 1]; pos[2] = a.Jp[s * 72 + kind * 3 + 2];
         return;
     }
     const int q = -kind - 1;
-    const float* Ar = a.A + s * 288;
     const float* M = a.Mq + s * a.ldq + q * 72;
     const float* w = a.w0 + q * 24;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll 8
     for (int j = 0; j < 24; ++j) {
         const float m0 = M[j * 3], m1 = M[j * 3 + 1], m2 = M[j * 3 + 2], wj = w[j];
-        const float* Aj = Ar + j * 12;
+        const float* Aj = Al + j * 12;
         p0 += Aj[0] * m0 + Aj[1] * m1 + Aj[2] * m2 + Aj[3] * wj;
         p1 += Aj[4] * m0 + Aj[5] * m1 + Aj[6] * m2 + Aj[7] * wj;
         p2 += Aj[8] * m0 + Aj[9] * m1 + Aj[10] * m2 + Aj[11] * wj;
     }
     pos[0] = p0; pos[1] = p1; pos[2] = p2;
+}
+
+// Stage the relative transforms of the block's samples (256/LANES of them) into LDS, coalesced.
+template <int LANES>
+__device__ __forceinline__ void kp_stage_A(const KpArgs& a, float (*Al)[288]) {
+    constexpr int SPB = 256 / LANES;
+    const long sbase = (long)blockIdx.x * SPB;
+    for (int idx = threadIdx.x; idx < SPB * 288; idx += 256) {
+        const long ss = sbase + idx / 288;
+        Al[idx / 288][idx % 288] = ss < a.N ? a.A[ss * 288 + idx % 288] : 0.f;
+    }
+    __syncthreads();
 }
 
 // loss value(s) and d loss / d (u, v) for one joint.  l[2]: per-coordinate losses (W=2) or l[0] (W=1).
@@ -411,12 +460,14 @@ __global__ __launch_bounds__(256) void kp_fwd_kernel(KpArgs a, KpConst kc, float
     const long s = t / LANES;
     const int o = (int)(t % LANES);
     const bool active = s < a.N && o < kc.n_out;
+    __shared__ float Al[256 / LANES][288];
+    kp_stage_A<LANES>(a, Al);
     float wsum = 0.f;
     long v = 0;
     if (s < a.N) v = a.view_idx[s];
     if (active) {
         float pos[3];
-        kp_joint(a, kc, s, o, pos);
+        kp_joint(a, kc, s, o, Al[threadIdx.x / LANES], pos);
         if (a.add_trans) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) pos[c] += a.TR[s * a.ldt + c] - a.TR[a.N * a.ldt + c];
@@ -446,10 +497,26 @@ __global__ __launch_bounds__(256) void kp_fwd_kernel(KpArgs a, KpConst kc, float
         }
     }
     if (view_acc) {
+        // one atomic per (block, view) instead of one per sample: the V x 2 accumulators are hot
+        // same-address targets (300 serialised L2 atomics each at N = 2400 otherwise)
+        constexpr int SPB = 256 / LANES;
+        __shared__ float bsum[SPB];
+        __shared__ long bview[SPB];
         if (LANES == 32) wsum = group32_sum(wsum);
-        if (s < a.N && o == 0) {
-            atomicAdd(view_acc + v * 2, wsum);
-            atomicAdd(view_acc + v * 2 + 1, 1.f);
+        const int sl = threadIdx.x / LANES;
+        if (o == 0) { bsum[sl] = wsum; bview[sl] = s < a.N ? v : -1; }
+        __syncthreads();
+        if (threadIdx.x < SPB && bview[threadIdx.x] >= 0) {
+            const long mv = bview[threadIdx.x];
+            bool first = true;
+            for (int k = 0; k < (int)threadIdx.x; ++k) first = first && bview[k] != mv;
+            if (first) {
+                float tot = 0.f, cnt = 0.f;
+                for (int k = threadIdx.x; k < SPB; ++k)
+                    if (bview[k] == mv) { tot += bsum[k]; cnt += 1.f; }
+                atomicAdd(view_acc + mv * 2, tot);
+                atomicAdd(view_acc + mv * 2 + 1, cnt);
+            }
         }
     }
 }
@@ -478,6 +545,8 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
     const int o = (int)(t % LANES);
     const bool live = s < a.N;
     const bool active = live && o < kc.n_out;
+    __shared__ float Al[256 / LANES][288];
+    kp_stage_A<LANES>(a, Al);
     long v = 0;
     if (live) v = a.view_idx[s];
     float dpos[3] = {0.f, 0.f, 0.f};
@@ -486,7 +555,7 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
     if (active) {
         kind = kc.out_kind[o];
         float pos[3];
-        kp_joint(a, kc, s, o, pos);
+        kp_joint(a, kc, s, o, Al[threadIdx.x / LANES], pos);
         if (a.add_trans) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) pos[c] += a.TR[s * a.ldt + c] - a.TR[a.N * a.ldt + c];
@@ -521,13 +590,34 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
         dcam[0] = dpx; dcam[1] = dpy; dcam[2] = dpz;
         rot6d_bwd(cam + 3, dRc, dcam + 3);
     }
-    // camera gradient: reduce over the sample's joints, one atomic set per sample
+    // camera gradient: reduce over the sample's joints (shuffles), then over the block's samples of the
+    // same view (LDS), one atomic per (block, view, component)
     if (d_cams) {
+        constexpr int SPBc = 256 / LANES;
+        __shared__ float bcam[SPBc][9];
+        __shared__ long bviewc[SPBc];
+        const int slc = threadIdx.x / LANES;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
             float r = dcam[k];
             if (LANES == 32) r = group32_sum(r);
-            if (live && o == 0 && r != 0.f) atomicAdd(d_cams + v * 9 + k, r);
+            if (o == 0) bcam[slc][k] = r;
+        }
+        if (o == 0) bviewc[slc] = live ? v : -1;
+        __syncthreads();
+        if (threadIdx.x < SPBc * 9) {
+            const int sl2 = threadIdx.x / 9, k = threadIdx.x % 9;
+            const long mv = bviewc[sl2];
+            if (mv >= 0) {
+                bool first = true;
+                for (int q2 = 0; q2 < sl2; ++q2) first = first && bviewc[q2] != mv;
+                if (first) {
+                    float tot = 0.f;
+                    for (int q2 = sl2; q2 < SPBc; ++q2)
+                        if (bviewc[q2] == mv) tot += bcam[q2][k];
+                    if (tot != 0.f) atomicAdd(d_cams + mv * 9 + k, tot);
+                }
+            }
         }
     }
     // translation gradient
@@ -559,8 +649,9 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
     }
     if (mesh) {
         const int q = -kind - 1;
+#pragma unroll 8
         for (int j = 0; j < 24; ++j) {
-            const float* Aj = a.A + s * 288 + j * 12;
+            const float* Aj = Al[sl] + j * 12;
             float* dM = dMq + s * a.ldq + q * 72 + j * 3;
             dM[0] = Aj[0] * dpos[0] + Aj[4] * dpos[1] + Aj[8] * dpos[2];
             dM[1] = Aj[1] * dpos[0] + Aj[5] * dpos[1] + Aj[9] * dpos[2];
@@ -1010,7 +1101,7 @@ extern "C" int32_t nemo_fk_fwd(const nemo_ctx* ctx, int64_t rows, const float* R
                                    FK_LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(fk_fwd_kernel, dim3(nemo_cdiv(rows, FK_TB)), dim3(FK_TB), FK_LDS_BYTES,
+    hipLaunchKernelGGL(fk_fwd_kernel, dim3(nemo_cdiv(rows, FK_TB)), dim3(256), FK_LDS_BYTES,
                        (hipStream_t)stream, (long)rows, R, ctx->d_Jrest, ctx->kc, A, Jp, PF, (long)ldpf);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
@@ -1027,7 +1118,7 @@ extern "C" int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R
                                    FK_LDS_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(fk_bwd_kernel, dim3(nemo_cdiv(rows, FK_TB)), dim3(FK_TB), FK_LDS_BYTES,
+    hipLaunchKernelGGL(fk_bwd_kernel, dim3(nemo_cdiv(rows, FK_TB)), dim3(256), FK_LDS_BYTES,
                        (hipStream_t)stream, (long)rows, R, A, ctx->d_Jrest, ctx->kc, dA, dJp, dPF, (long)lddpf, dR);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
