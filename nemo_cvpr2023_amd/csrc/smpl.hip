@@ -211,24 +211,56 @@ namespace {
 #define FK_RS 217
 #define FK_LDS_BYTES ((24 * 12 * FK_GS + FK_TB * FK_RS) * (int)sizeof(float))
 
+// Copy loops have COMPILE-TIME trip counts and issue all their (unconditional, clamped) loads before
+// the first use: a rolled runtime-bound loop waits one full memory round trip per iteration, which
+// made the copy phases 5x longer than the kinematic chain itself.
+__device__ __forceinline__ void fk_load_R(const float* __restrict__ R, long row0, int nb, float* Rl) {
+    // 64 bodies x 216 floats = 3456 float4, 13.5 per thread
+    const float4* src = reinterpret_cast<const float4*>(R + row0 * 216);
+    const int lim = nb * 54;
+    float4 v[14];
+#pragma unroll
+    for (int it = 0; it < 14; ++it) {
+        const int i4 = it * 256 + threadIdx.x;
+        v[it] = src[i4 < lim ? i4 : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < 14; ++it) {
+        const int i4 = it * 256 + threadIdx.x;
+        if (i4 < lim) {
+            const int bdy = i4 / 54, k = (i4 % 54) * 4;
+            float* d = Rl + bdy * FK_RS + k;
+            d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fk_fwd_kernel(long rows, const float* __restrict__ R,
                                                      const float* __restrict__ Jrest, KpConst kc,
                                                      float* __restrict__ A, float* __restrict__ Jp,
                                                      float* __restrict__ PF, long ldpf) {
     extern __shared__ float lds[];
-    float* G = lds;                                  // [(j*12 + e) * FK_TB + lane]: e<9 rotation, e>=9 translation
+    float* G = lds;                                  // [(j*12 + e) * FK_GS + lane]: e<9 rotation, e>=9 translation
     float* Rl = lds + 24 * 12 * FK_GS;               // [body][FK_RS]
+    __shared__ float Js[72];                         // rest joints and parents: the chain must not wait on
+    __shared__ int Ps[24];                           // global / kernarg loads between dependent steps
     const int tid = threadIdx.x;
     const long row0 = (long)blockIdx.x * FK_TB;
     const int nb = (int)min((long)FK_TB, rows - row0);
-    // ---- phase 1: coalesced load of the rotations; pose feature written on the fly
-    for (int idx = tid; idx < nb * 216; idx += 256) {
-        const int bdy = idx / 216, k = idx % 216;
-        const float v = R[row0 * 216 + idx];
-        Rl[bdy * FK_RS + k] = v;
-        if (PF && k >= 9) PF[(row0 + bdy) * ldpf + k - 9] = v - (((k % 9) % 4 == 0) ? 1.f : 0.f);
-    }
+    if (tid < 72) Js[tid] = Jrest[tid];
+    if (tid < 24) Ps[tid] = kc.parents[tid];
+    // ---- phase 1: coalesced load of the rotations
+    fk_load_R(R, row0, nb, Rl);
     __syncthreads();
+    // pose feature (R[1:] - I), written from LDS with coalesced stores: 64 x 207 floats
+    if (PF) {
+#pragma unroll
+        for (int it = 0; it < 52; ++it) {             // ceil(64*207 / 256)
+            const int idx = it * 256 + tid;
+            const int bdy = idx / 207, k = idx % 207;
+            if (bdy < nb) PF[(row0 + bdy) * ldpf + k] = Rl[bdy * FK_RS + 9 + k] - ((k % 9) % 4 == 0 ? 1.f : 0.f);
+        }
+    }
     // ---- phase 2: one thread per body walks the chain
     if (tid < nb) {
         const int lane = tid;
@@ -238,17 +270,17 @@ __global__ __launch_bounds__(256) void fk_fwd_kernel(long rows, const float* __r
             float Ri[9], Gi[9], gt[3];
 #pragma unroll
             for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
-            const float ji[3] = {Jrest[i * 3], Jrest[i * 3 + 1], Jrest[i * 3 + 2]};
+            const float ji[3] = {Js[i * 3], Js[i * 3 + 1], Js[i * 3 + 2]};
             if (i == 0) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) Gi[k] = Ri[k];
                 gt[0] = ji[0]; gt[1] = ji[1]; gt[2] = ji[2];
             } else {
-                const int p = kc.parents[i];
+                const int p = Ps[i];
                 float Gp[9];
 #pragma unroll
                 for (int k = 0; k < 9; ++k) Gp[k] = GL(p, k);
-                const float rel[3] = {ji[0] - Jrest[p * 3], ji[1] - Jrest[p * 3 + 1], ji[2] - Jrest[p * 3 + 2]};
+                const float rel[3] = {ji[0] - Js[p * 3], ji[1] - Js[p * 3 + 1], ji[2] - Js[p * 3 + 2]};
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
 #pragma unroll
@@ -265,20 +297,28 @@ __global__ __launch_bounds__(256) void fk_fwd_kernel(long rows, const float* __r
 #undef GL
     }
     __syncthreads();
-    // ---- phase 3: coalesced write-out.  A[j] = [G_R | G_t - G_R J_j] (lbs.py:399-402), Jp[j] = G_t
-    for (int idx = tid; idx < nb * 288; idx += 256) {
-        const int bdy = idx / 288, e = idx % 288;
-        const int j = e / 12, r = (e % 12) / 4, c = e % 4;
+    // ---- phase 3: coalesced float4 write-out.  A[j] row r = [G_R[r] | G_t[r] - G_R[r].J_j] (lbs.py:399-402)
+    float4* A4 = reinterpret_cast<float4*>(A + row0 * 288);
+#pragma unroll
+    for (int it = 0; it < 18; ++it) {                 // 64 x 72 float4
+        const int i4 = it * 256 + tid;
+        const int bdy = i4 / 72, jr = i4 % 72, j = jr / 3, r = jr % 3;
         const float* g = G + (j * 12) * FK_GS + bdy;
-        float v;
-        if (c < 3) v = g[(r * 3 + c) * FK_GS];
-        else v = g[(9 + r) * FK_GS] - (g[(r * 3) * FK_GS] * Jrest[j * 3] + g[(r * 3 + 1) * FK_GS] * Jrest[j * 3 + 1] +
-                                       g[(r * 3 + 2) * FK_GS] * Jrest[j * 3 + 2]);
-        A[row0 * 288 + idx] = v;
+        const float g0 = g[(r * 3) * FK_GS], g1 = g[(r * 3 + 1) * FK_GS], g2 = g[(r * 3 + 2) * FK_GS];
+        const float t = g[(9 + r) * FK_GS] - (g0 * Js[j * 3] + g1 * Js[j * 3 + 1] + g2 * Js[j * 3 + 2]);
+        if (bdy < nb) A4[i4] = make_float4(g0, g1, g2, t);
     }
-    for (int idx = tid; idx < nb * 72; idx += 256) {
-        const int bdy = idx / 72, e = idx % 72;
-        Jp[row0 * 72 + idx] = G[((e / 3) * 12 + 9 + e % 3) * FK_GS + bdy];
+    float4* J4 = reinterpret_cast<float4*>(Jp + row0 * 72);
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {                  // 64 x 18 float4 = 1152
+        const int i4 = it * 256 + tid;
+        const int bdy = i4 / 18, e0 = (i4 % 18) * 4;
+        if (i4 < 1152 && bdy < nb) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = G[(((e0 + u) / 3) * 12 + 9 + (e0 + u) % 3) * FK_GS + bdy];
+            J4[i4] = make_float4(v[0], v[1], v[2], v[3]);
+        }
     }
 }
 
@@ -290,22 +330,42 @@ __global__ __launch_bounds__(256) void fk_bwd_kernel(long rows, const float* __r
                                                      const float* __restrict__ dPF, long lddpf,
                                                      float* __restrict__ dR) {
     extern __shared__ float lds[];
-    float* D = lds;                                  // dG accumulators [(j*12 + r*4 + c) * FK_TB + lane]
+    float* D = lds;                                  // dG accumulators [(j*12 + r*4 + c) * FK_GS + lane]
     float* Rl = lds + 24 * 12 * FK_GS;               // rotations in, rotation gradients out (in place)
+    __shared__ float Js[72];
+    __shared__ int Ps[24];
     const int tid = threadIdx.x;
     const long row0 = (long)blockIdx.x * FK_TB;
     const int nb = (int)min((long)FK_TB, rows - row0);
+    if (tid < 72) Js[tid] = Jrest[tid];
+    if (tid < 24) Ps[tid] = kc.parents[tid];
+    __syncthreads();
     // ---- phase 1: coalesced loads.  dA -> dG:  A_t = G_t - G_R J  =>  dG_R = dA_R - dA_t (x) J ; dG_t = dA_t (+ dJp)
-    for (int idx = tid; idx < nb * 216; idx += 256) Rl[(idx / 216) * FK_RS + idx % 216] = R[row0 * 216 + idx];
-    for (int idx = tid; idx < nb * 288; idx += 256) {
-        const int bdy = idx / 288, e = idx % 288;
-        const int j = e / 12, r = (e % 12) / 4, c = e % 4;
-        const float* src = dA + (row0 + bdy) * 288 + j * 12 + r * 4;
-        const float dat = src[3];
-        float v;
-        if (c < 3) v = src[c] - dat * Jrest[j * 3 + c];
-        else v = dat + (dJp ? dJp[(row0 + bdy) * 72 + j * 3 + r] : 0.f);
-        D[e * FK_GS + bdy] = v;
+    fk_load_R(R, row0, nb, Rl);
+    {
+        const float4* dA4 = reinterpret_cast<const float4*>(dA + row0 * 288);
+        const int lim = nb * 72;
+        float4 v[18];
+        float dj[18];
+#pragma unroll
+        for (int it = 0; it < 18; ++it) {             // 64 x 72 float4: one (body, joint, row) each
+            const int i4 = it * 256 + tid;
+            const int ic = i4 < lim ? i4 : 0;
+            v[it] = dA4[ic];
+            dj[it] = dJp ? dJp[row0 * 72 + ic] : 0.f;  // (body, joint, r) is the same linear index
+        }
+#pragma unroll
+        for (int it = 0; it < 18; ++it) {
+            const int i4 = it * 256 + tid;
+            if (i4 < lim) {
+                const int bdy = i4 / 72, jr = i4 % 72, j = jr / 3, r = jr % 3;
+                float* d = D + (j * 12 + r * 4) * FK_GS + bdy;
+                d[0] = v[it].x - v[it].w * Js[j * 3];
+                d[FK_GS] = v[it].y - v[it].w * Js[j * 3 + 1];
+                d[2 * FK_GS] = v[it].z - v[it].w * Js[j * 3 + 2];
+                d[3 * FK_GS] = v[it].w + dj[it];
+            }
+        }
     }
     __syncthreads();
     // ---- phase 2: reverse sweep, one thread per body
@@ -314,22 +374,39 @@ __global__ __launch_bounds__(256) void fk_bwd_kernel(long rows, const float* __r
         float* Rr = Rl + lane * FK_RS;
         const float* Ar = A + (row0 + lane) * 288;
 #define DL(j, e) D[((j) * 12 + (e)) * FK_GS + lane]
+        // parent transforms come from global memory but do not depend on the sweep: keep the loads of
+        // the next two iterations in flight (register ring indexed by i & 1; the loop is fully unrolled)
+        float Gq[2][9];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pi = Ps[23 - u];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Gq[(23 - u) & 1][r * 3 + c] = Ar[pi * 12 + r * 4 + c];
+        }
+#pragma unroll
         for (int i = 23; i >= 1; --i) {
-            const int p = kc.parents[i];
+            const int p = Ps[i];
             float Gp[9], Ri[9], dG[9], dgt[3];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Gp[k] = Gq[i & 1][k];
+            if (i >= 3) {
+                const int pn = Ps[i - 2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) Gq[i & 1][r * 3 + c] = Ar[pn * 12 + r * 4 + c];
+            }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    Gp[r * 3 + c] = Ar[p * 12 + r * 4 + c];
-                    dG[r * 3 + c] = DL(i, r * 4 + c);
-                }
+                for (int c = 0; c < 3; ++c) dG[r * 3 + c] = DL(i, r * 4 + c);
                 dgt[r] = DL(i, r * 4 + 3);
             }
 #pragma unroll
             for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
-            const float rel[3] = {Jrest[i * 3] - Jrest[p * 3], Jrest[i * 3 + 1] - Jrest[p * 3 + 1],
-                                  Jrest[i * 3 + 2] - Jrest[p * 3 + 2]};
+            const float rel[3] = {Js[i * 3] - Js[p * 3], Js[i * 3 + 1] - Js[p * 3 + 1], Js[i * 3 + 2] - Js[p * 3 + 2]};
             // dR_i = Gp^T dG_i   (stored in place of R_i, which is not needed again)
 #pragma unroll
             for (int r = 0; r < 3; ++r)
@@ -354,11 +431,21 @@ __global__ __launch_bounds__(256) void fk_bwd_kernel(long rows, const float* __r
     }
     __syncthreads();
     // ---- phase 3: coalesced write-out (+ the pose-feature gradient of joints 1..23)
-    for (int idx = tid; idx < nb * 216; idx += 256) {
-        const int bdy = idx / 216, k = idx % 216;
-        float v = Rl[bdy * FK_RS + k];
-        if (dPF && k >= 9) v += dPF[(row0 + bdy) * lddpf + k - 9];
-        dR[row0 * 216 + idx] = v;
+    {
+        const int lim = nb * 216;
+        float pfv[54];
+#pragma unroll
+        for (int it = 0; it < 54; ++it) {
+            const int idx = it * 256 + tid;
+            const int ic = idx < lim ? idx : 0;
+            const int bdy = ic / 216, k = ic % 216;
+            pfv[it] = (dPF && k >= 9) ? dPF[(row0 + bdy) * lddpf + k - 9] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < 54; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < lim) dR[row0 * 216 + idx] = Rl[(idx / 216) * FK_RS + idx % 216] + pfv[it];
+        }
     }
 }
 
@@ -404,6 +491,7 @@ template <int LANES>
 __device__ __forceinline__ void kp_stage_A(const KpArgs& a, float (*Al)[288]) {
     constexpr int SPB = 256 / LANES;
     const long sbase = (long)blockIdx.x * SPB;
+#pragma unroll
     for (int idx = threadIdx.x; idx < SPB * 288; idx += 256) {
         const long ss = sbase + idx / 288;
         Al[idx / 288][idx % 288] = ss < a.N ? a.A[ss * 288 + idx % 288] : 0.f;
