@@ -246,6 +246,12 @@ typedef struct {
 int32_t nemo_adam_step(int32_t n_seg, const nemo_adam_seg* segs /* HOST */, float* params,
                        const float* grads, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
                        float eps, void* stream);
+/* Same update with the segment table in DEVICE memory (n_seg entries; max_numel = largest segment):
+ * the launch is then capturable in a HIP graph and replayed with per-step learning rates / bias
+ * corrections refreshed by a small async copy. */
+int32_t nemo_adam_step_dev(int32_t n_seg, const nemo_adam_seg* segs_dev, int64_t max_numel, float* params,
+                           const float* grads, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
+                           float eps, void* stream);
 
 /* Small utilities. */
 int32_t nemo_scale_neg_rowsum(int64_t N, int64_t cols, const float* X, int64_t ldx, float* out_row,

@@ -163,10 +163,14 @@ struct AdamSegs {
 //   grad += wd * p (Adam)  |  p *= 1 - lr*wd (AdamW)
 //   m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g^2
 //   p -= (lr / bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-__global__ __launch_bounds__(256) void adam_kernel(AdamSegs segs, float* __restrict__ p,
-                                                   const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, float b1, float b2, float eps) {
-    const nemo_adam_seg sg = segs.s[blockIdx.y];
+// SEGS_DEV: the segment table (learning rates, bias corrections: they change every step) is read from
+// device memory, so a captured HIP graph of the step can be replayed with fresh values.
+template <bool SEGS_DEV>
+__global__ __launch_bounds__(256) void adam_kernel(AdamSegs segs, const nemo_adam_seg* __restrict__ segs_dev,
+                                                   float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, float b1,
+                                                   float b2, float eps) {
+    const nemo_adam_seg sg = SEGS_DEV ? segs_dev[blockIdx.y] : segs.s[blockIdx.y];
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < sg.numel; i += (long)gridDim.x * blockDim.x) {
         const long k = sg.offset + i;
         float grad = g[k], par = p[k];
@@ -244,8 +248,26 @@ extern "C" int32_t nemo_adam_step(int32_t n_seg, const nemo_adam_seg* segs, floa
     int bx = nemo_cdiv(maxn, 256 * 4);
     if (bx < 1) bx = 1;
     if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3(bx, n_seg), dim3(256), 0, (hipStream_t)stream, a, params, grads,
-                       exp_avg, exp_avg_sq, beta1, beta2, eps);
+    hipLaunchKernelGGL(adam_kernel<false>, dim3(bx, n_seg), dim3(256), 0, (hipStream_t)stream, a, nullptr,
+                       params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_adam_step_dev(int32_t n_seg, const nemo_adam_seg* segs_dev, int64_t max_numel,
+                                      float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                      float beta1, float beta2, float eps, void* stream) {
+    if (n_seg < 0 || n_seg > NEMO_ADAM_MAX_SEG || !segs_dev || !params || !grads || !exp_avg || !exp_avg_sq ||
+        max_numel < 0)
+        return NEMO_EINVAL;
+    if (n_seg == 0 || max_numel == 0) return NEMO_OK;
+    AdamSegs a;
+    a.n = n_seg;
+    int bx = nemo_cdiv(max_numel, 256 * 4);
+    if (bx < 1) bx = 1;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(adam_kernel<true>, dim3(bx, n_seg), dim3(256), 0, (hipStream_t)stream, a, segs_dev,
+                       params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

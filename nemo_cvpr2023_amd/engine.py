@@ -217,7 +217,9 @@ class FitEngine:
         self.scal = torch.zeros(8, **f32)
         self._scal_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.ws = {}
+        self.side_stream = torch.cuda.Stream(device=self.device)   # prior branch of the step (see _forward_backward)
         self._colsums = []
+        self._seg_host = self._seg_dev = None
         self.timers = None
         self.detach_articulation = False
         self.start_global_traj_anywhere = False
@@ -263,7 +265,9 @@ class FitEngine:
             dR2=Z(N, 24, 9),
             dR=Z(N, 24, 9), dA=Z(N, 24, 12), dMq=Z(N, max(nq * 72, 1)),
             dPF=Z(N, 208), dHEAD=Z(N + 1, HEAD_LD), dH=Z(N + 1, h), dH_b=Z(N + 1, h), dH_c=Z(N + 1, h),
-            dX=Z(N + 1, self.din), dMULV=Z(N, 64), dE_a=Z(N, 512), Nc=Nc)
+            dX=Z(N + 1, self.din), dMULV=Z(N, 64), dE_a=Z(N, 512), Nc=Nc,
+            vi_static=torch.zeros(N, dtype=torch.long, device=self.device),
+            fi_static=torch.zeros(N, dtype=torch.long, device=self.device), graphs={})
         w.update(views)
         w['zero_arena'] = arena
         # strided views into the merged MLP-head buffers
@@ -348,7 +352,9 @@ class FitEngine:
         """K6-K8: FK, mesh-functional joints, projection, 2-D loss accumulators."""
         L, st = self.lib, _stream()
         ctx = ctx or self.ctx
-        ctx.set_betas(self.betas.detach().cpu().numpy())
+        if self.betas._version != getattr(ctx, '_betas_version', None):   # no D2H sync in the steady state
+            ctx.set_betas(self.betas.detach().cpu().numpy())
+            ctx._betas_version = self.betas._version
         check(L.nemo_fk_fwd(ctx.handle, N, dptr(w['R']), dptr(w['A']), dptr(w['Jp']), dptr(w['PF']), 208, st),
               'nemo_fk_fwd')
         nq72 = ctx.nq * 72
@@ -500,11 +506,7 @@ class FitEngine:
                   'nemo_scale_neg_rowsum')
 
     # ------------------------------------------------------------------ optimiser
-    def adam(self, segments, exp_avg=None, exp_avg_sq=None):
-        """segments: list of dicts(offset, numel, lr, wd, adamw, step) -- step is the NEW step count."""
-        if not segments:
-            return
-        arr = (AdamSeg * len(segments))()
+    def _fill_segs(self, arr, segments):
         for i, s in enumerate(segments):
             t = s['step']
             arr[i].offset, arr[i].numel = s['offset'], s['numel']
@@ -512,6 +514,13 @@ class FitEngine:
             arr[i].step_size = s['lr'] / (1.0 - 0.9 ** t)
             arr[i].bias_corr2_sqrt = math.sqrt(1.0 - 0.999 ** t)
             arr[i].adamw = 1 if s['adamw'] else 0
+
+    def adam(self, segments, exp_avg=None, exp_avg_sq=None):
+        """segments: list of dicts(offset, numel, lr, wd, adamw, step) -- step is the NEW step count."""
+        if not segments:
+            return
+        arr = (AdamSeg * len(segments))()
+        self._fill_segs(arr, segments)
         m = self.exp_avg if exp_avg is None else exp_avg
         v = self.exp_avg_sq if exp_avg_sq is None else exp_avg_sq
         for i in range(0, len(segments), _lib.ADAM_MAX_SEG):
@@ -520,6 +529,27 @@ class FitEngine:
                                                          ctypes.POINTER(AdamSeg)),
                                           self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(),
                                           v.data_ptr(), 0.9, 0.999, 1e-8, _stream()), 'nemo_adam_step')
+
+    # ---- graph-capturable variant: the segment table lives in device memory
+    def adam_table_upload(self, segments):
+        """Write this step's segment table (async H2D on the current stream).  The table layout
+        (count, offsets, sizes) must not change between a captured graph and its replays."""
+        n = len(segments)
+        assert 0 < n <= _lib.ADAM_MAX_SEG
+        if self._seg_host is None:
+            nbytes = ctypes.sizeof(AdamSeg) * _lib.ADAM_MAX_SEG
+            self._seg_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+            self._seg_dev = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        arr = (AdamSeg * n).from_address(self._seg_host.data_ptr())
+        self._fill_segs(arr, segments)
+        self._seg_dev.copy_(self._seg_host, non_blocking=True)
+        return n, max(s['numel'] for s in segments)
+
+    def adam_from_table(self, n, max_numel):
+        check(self.lib.nemo_adam_step_dev(n, self._seg_dev.data_ptr(), max_numel, self.params.data_ptr(),
+                                          self.grads.data_ptr(), self.exp_avg.data_ptr(),
+                                          self.exp_avg_sq.data_ptr(), 0.9, 0.999, 1e-8, _stream()),
+              'nemo_adam_step_dev')
 
     def read_scalars(self):
         self._scal_host.copy_(self.scal, non_blocking=True)

@@ -225,6 +225,8 @@ class MultiViewModel(nn.Module):
         self.points2d_gt_all, self.gt_bbox_size = e.targets, e.gt_size
         self.hmr_theta, self.hmr_mask = e.hmr_theta, e.hmr_mask
         self.training = False
+        # capture each (batch size, mode) variant of the step as a HIP graph after one eager run
+        self.use_graphs = os.environ.get('NEMO_GRAPHS', '1') != '0'
         self._build_parameters()
         self._init_parameters()
         self._build_optimizers()
@@ -398,8 +400,13 @@ class MultiViewModel(nn.Module):
         return {k: v.reshape(V, T, *v.shape[1:]) for k, v in p.items()}
 
     # ------------------------------------------------------------------ the hot path
-    def _forward_losses(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False, sh=None):
-        """Forward of :3511-3584 (+V3 extras).  Accumulates the weighted pose gradients into dAA."""
+    def _forward_backward(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False, sh=None):
+        """Forward of :3511-3584 (+V3 extras) and, when ``update``, the whole backward down to the
+        parameter gradients.  After the pose MLP the step forks into two independent branches that
+        run CONCURRENTLY on two HIP streams (most of their kernels are too small to fill 256 CUs):
+          main stream: FK -> pre-contracted joints -> projection -> 2-D loss -> its backward (dR, dTR, dcams)
+          side stream: VPoser encode/decode, KL (+ its backward), GMM, 3-D pose loss
+        joins, runs the full-mesh v2v term alone, then the rot6d / MLP backward."""
         e, a = self.engine, self.args
         sh = sh or ShardInfo()
         e.scal.zero_()
@@ -407,38 +414,43 @@ class MultiViewModel(nn.Module):
         if update:
             e.grads.zero_()
         e.forward_pose(w, N, vi, fi, code_noise=self._noise(N))
-        Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0)
-        st = _stream()
+        main = torch.cuda.current_stream()
+        side = e.side_stream
+        side.wait_stream(main)
         aa69, daa69 = w['AA'].data_ptr() + 12, w['dAA'].data_ptr() + 12
+        with torch.cuda.stream(side):
+            st = _stream()
+            if use_vposer:
+                e.forward_vposer(w, N)                                        # always evaluated, :3569
+                g = e.gmm
+                check(e.lib.nemo_gmm_fwd_bwd(N, g['M'], 69, aa69, 72, dptr(g['means']), dptr(g['prec']),
+                                             dptr(g['log_nllw']), dptr(w['gmm_ws']),
+                                             e.scal.data_ptr() + 4 * S_GMM, None,
+                                             float(a.weight_gmm_loss) * sh.mr,
+                                             daa69 if (update and a.weight_gmm_loss) else None, 72, st),
+                      'nemo_gmm_fwd_bwd')
+                if update and a.weight_vp_z_loss:
+                    e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
+            if self.VERSION >= 3 and getattr(a, 'weight_3d_loss', 0):
+                check(e.lib.nemo_pose3d_fwd_bwd(N, 69, aa69, 72, dptr(e.hmr_theta), dptr(e.hmr_mask),
+                                                dptr(vi), dptr(fi), e.T, e.scal.data_ptr() + 4 * S_3D,
+                                                float(a.weight_3d_loss) * sh.mr, daa69 if update else None,
+                                                72, st), 'nemo_pose3d_fwd_bwd')
+        Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0)
+        if update:
+            e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose)
+        main.wait_stream(side)
+        # the fused mesh kernel is sized to fill the machine in exactly one resident wave of blocks:
+        # it runs alone (anything co-scheduled pushes part of its grid into a second wave, +60 %)
         if use_vposer:
-            e.forward_vposer(w, N)                                            # always evaluated, :3569
             e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss))
-            g = e.gmm
-            check(e.lib.nemo_gmm_fwd_bwd(N, g['M'], 69, aa69, 72, dptr(g['means']), dptr(g['prec']),
-                                         dptr(g['log_nllw']), dptr(w['gmm_ws']),
-                                         e.scal.data_ptr() + 4 * S_GMM, None,
-                                         float(a.weight_gmm_loss) * sh.mr,
-                                         daa69 if (update and a.weight_gmm_loss) else None, 72, st),
-                  'nemo_gmm_fwd_bwd')
-        if self.VERSION >= 3 and getattr(a, 'weight_3d_loss', 0):
-            check(e.lib.nemo_pose3d_fwd_bwd(N, 69, aa69, 72, dptr(e.hmr_theta), dptr(e.hmr_mask), dptr(vi),
-                                            dptr(fi), e.T, e.scal.data_ptr() + 4 * S_3D,
-                                            float(a.weight_3d_loss) * sh.mr, daa69 if update else None, 72,
-                                            st),
-                  'nemo_pose3d_fwd_bwd')
-        return Mq
-
-    def _backward(self, w, N, vi, fi, Mq, use_vposer=True, detach_pose=False, sh=None):
-        e, a = self.engine, self.args
-        sh = sh or ShardInfo()
+        if not update:
+            return
         st = _stream()
-        e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose)
         if use_vposer and a.weight_vp_loss:
             check(e.lib.nemo_v2v_prep_bwd(N, dptr(w['AA']), dptr(w['dR2']),
                                           float(a.weight_vp_loss) * sh.mr / float(N * e.NV * 3),
                                           dptr(w['dAA']), dptr(w['dR']), st), 'nemo_v2v_prep_bwd')
-        if use_vposer and a.weight_vp_z_loss:
-            e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
         check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, dptr(w['dR']), dptr(w['dAA']),
                                    dptr(w['dROT']), HEAD_LD, st), 'nemo_rot6d_bwd')
         e.finish_trans_grad(w, N)
@@ -456,25 +468,58 @@ class MultiViewModel(nn.Module):
             vi, fi = self.full_indices()
         N = vi.numel()
         w = e._ws(max(N, 1))
-        has_inst = self.VERSION >= 3 and getattr(a, 'weight_instance_loss', 0) and e.C > 0
-        if N > 0:
-            Mq = self._forward_losses(w, N, vi, fi, update, sh=sh)
-        else:                       # a shard may own none of a minibatch's samples
-            e.scal.zero_()
-            if update:
-                e.grads.zero_()
-        if has_inst:
-            e.scal[S_INST] = (self.learned_instance_code.detach() ** 2).mean()            # :3864-3867
-        if update:
+        has_inst = bool(self.VERSION >= 3 and getattr(a, 'weight_instance_loss', 0) and e.C > 0)
+
+        def body(vi_, fi_, adam_table):
+            """Everything of the step that runs on the device without host interaction."""
             if N > 0:
-                self._backward(w, N, vi, fi, Mq, sh=sh)
+                self._forward_backward(w, N, vi_, fi_, update, sh=sh)
+            else:                       # a shard may own none of a minibatch's samples
+                e.scal.zero_()
+                if update:
+                    e.grads.zero_()
             if has_inst:
                 code = self.learned_instance_code.detach()
-                e.view('learned_instance_code', e.grads).add_(
-                    code, alpha=2.0 * float(a.weight_instance_loss) * sh.vr / code.numel())
-        s = self._reduce_and_read(sh, update)
+                e.scal[S_INST] = (code ** 2).mean()                                       # :3864-3867
+                if update:
+                    e.view('learned_instance_code', e.grads).add_(
+                        code, alpha=2.0 * float(a.weight_instance_loss) * sh.vr / code.numel())
+            if adam_table is not None:
+                e.adam_from_table(*adam_table)
+
+        noise = self.VERSION >= 3 and self.training and getattr(a, 'code_noise', 0) > 0
+        graphable = self.use_graphs and N > 0 and e.timers is None and not noise
+        segs = None
         if update:
-            self._adam_all(self.optimizers)
+            segs = []
+            for o in self.optimizers:
+                segs += o.segments(None)
+        # the fused Adam runs inside the captured graph unless a gradient all-reduce must come first
+        in_graph_adam = update and sh.comm is None
+        if graphable:
+            key = (bool(update), sh.kr, sh.mr, sh.vr, sh.comm is not None,
+                   tuple((s_['offset'], s_['numel']) for s_ in segs) if in_graph_adam else None)
+            w['vi_static'].copy_(vi)
+            w['fi_static'].copy_(fi)
+            table = e.adam_table_upload(segs) if in_graph_adam else None
+            entry = w['graphs'].get(key)
+            if entry is None:                     # first sight: eager (sets kernel attributes, sizes pools)
+                w['graphs'][key] = 'warm'
+                body(w['vi_static'], w['fi_static'], table)
+            else:
+                if entry == 'warm':               # second sight: capture the ~70-launch step as one HIP graph
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        body(w['vi_static'], w['fi_static'], table)
+                    w['graphs'][key] = entry = g
+                entry.replay()
+            vi, fi = w['vi_static'], w['fi_static']
+        else:
+            body(vi, fi, None)
+        s = self._reduce_and_read(sh, update)
+        if update and not (graphable and in_graph_adam):
+            e.adam(segs)
         f32 = np.float32
         kp = f32(s[S_KP])
         v2v = f32(s[S_V2V]) / f32((sh.n_global or N) * e.NV * 3)
@@ -649,8 +694,7 @@ class NemoV4(NemoV3):
             N = vi.numel()
             w = e._ws(max(N, 1))
             if N > 0:
-                Mq = self._forward_losses(w, N, vi, fi, update=True, use_vposer=False, sh=sh)
-                self._backward(w, N, vi, fi, Mq, use_vposer=False, detach_pose=True, sh=sh)
+                self._forward_backward(w, N, vi, fi, True, use_vposer=False, detach_pose=True, sh=sh)
             else:
                 e.scal.zero_()
                 e.grads.zero_()
