@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-V, T = 8, 300
+V0, T0 = 8, 300
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 
 
@@ -41,7 +41,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--instances', type=int, default=V0, help='exploration only; the judged workload is 8')
+    ap.add_argument('--frames', type=int, default=T0, help='exploration only; the judged workload is 300')
     opts = ap.parse_args()
+    V, T = opts.instances, opts.frames
 
     import torch
     import torch.distributed as dist
@@ -136,7 +139,7 @@ def main():
             o.step(None, None, update=True, full_batch=True)
         cdt = time.perf_counter() - c0
         cpu = {'value': round(opts.cpu_steps / cdt, 4), 'unit': 'iters/s', 'cores': ncores, 'kind': 'port',
-               'sample': f'{opts.cpu_steps} full-batch steps (8x300, N=2400) of the CPU oracle '
+               'sample': f'{opts.cpu_steps} full-batch steps ({V}x{T}, N={V * T}) of the CPU oracle '
                          f'(plain PyTorch fp32 restatement of the reference step) after 1 warm-up, '
                          f'{ncores} threads'}
 
@@ -147,7 +150,7 @@ def main():
             'warmup': opts.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'samples_per_s': round(iters_per_s * V * T, 1),
-            'config': {'workload': 'Baseball-Pitch-shaped fit, 8 instances x 300 frames full batch (N=2400), '
+            'config': {'workload': f'Baseball-Pitch-shaped fit, {V} instances x {T} frames full batch (N={V * T}), '
                                    'NemoV2 published hyper-parameters, all loss terms, 6890-vertex SMPL',
                        'instances': V, 'frames': T, 'samples_per_step': V * T, 'h_dim': args.h_dim,
                        'parallelism': f'instance-shard x{world}' if world > 1 else 'single GPU'},

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 1
+#define NEMO_ABI_VERSION 2
 int32_t nemo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -35,7 +35,14 @@ int32_t nemo_abi_version(void);
  * transA=0: A[m*lda+k], 1: A[k*lda+m].  transB=0: B[k*ldb+n], 1: B[n*ldb+k].
  * act: 0 none, 1 ReLU, 2 LeakyReLU(0.01).  mask_mode: 0 none, 1 v*=(mask>0),
  * 2 v*=(mask>0 ? 1 : 0.01)  (activation backward from the saved *output*).
- * out_mode: 0 store, 1 C+=, 2 atomicAdd (required when split_k>1; then act/mask must be 0).
+ * out_mode: 0 store, 1 C+=, 2 atomicAdd (act/mask must be 0).
+ * split_k: 0 = chosen by the library (tile shape and K split from a cost model); n >= 1 = exactly n
+ * K slices.  With out_mode 0/1 the slices of a tile are combined inside the launch by its
+ * last-arriving block, in slice order (deterministic), and the epilogue stays fused; this needs the
+ * caller-owned scratch `ws` (16-byte aligned, ws_bytes >= NEMO_GEMM_WS_MIN, ZERO-FILLED ONCE when
+ * allocated -- its first 16 KB are arrival tickets the kernel returns to zero -- and not shared by
+ * launches that may run concurrently).  ws == NULL: no in-launch combine (split_k > 1 then requires
+ * out_mode 2).
  * Replaces nn.Linear fwd/bwd (nemo/neural_motion_model.py:58-71,130-148;
  * human_body_prior/models/vposer_model.py:69-88) and the pose-blend matmul
  * (human_body_prior/body_model/lbs.py:229-233).
@@ -44,7 +51,8 @@ int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int6
                       const float* A, int64_t lda, const float* B, int64_t ldb,
                       float* C, int64_t ldc, const float* bias, int32_t act,
                       const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
-                      int32_t out_mode, int32_t split_k, void* stream);
+                      int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream);
+#define NEMO_GEMM_WS_MIN (16384 + 65536)
 /* out[n] += sum_m X[m*ldx+n]   (bias gradients). */
 int32_t nemo_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* stream);
 /* The same for up to NEMO_COLSUM_MAX matrices in ONE launch (all bias gradients of the MLP backward). */

@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnemo_hip.so')
+LIB_PATH = os.environ.get('NEMO_HIP_LIB') or os.path.join(_HERE, 'libnemo_hip.so')    # env: kernel-variant A/B runs
 
 ADAM_MAX_SEG = 16
 
@@ -30,7 +30,7 @@ i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 SIGNATURES = {
     'nemo_abi_version': (i32, []),
     'nemo_gemm_f32': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32,
-                            f32, i32, i32, ptr]),
+                            f32, i32, i32, ptr, i64, ptr]),
     'nemo_colsum_f32': (i32, [ptr, i64, i64, i64, ptr, ptr]),
     'nemo_colsum_multi': (i32, [i32, POINTER(ColsumDesc), ptr]),
     'nemo_phase_embed_fwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
@@ -97,8 +97,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.nemo_abi_version()
-    if ver != 1:
-        raise NemoHipError(f'libnemo_hip.so ABI version {ver} != 1 (stale build?)')
+    if ver != 2:
+        raise NemoHipError(f'libnemo_hip.so ABI version {ver} != 2 (stale build?)')
     _lib = lib
     return lib
 

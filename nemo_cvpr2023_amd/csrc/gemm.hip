@@ -1,6 +1,7 @@
 // fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled, with the fused
-// epilogues the NeMo step needs (bias, ReLU / LeakyReLU, activation-gradient masks,
-// accumulate, split-K atomics).  Exact fp32 arithmetic (the MFMA is a k-ordered fmaf chain),
+// epilogues the NeMo step needs (bias, ReLU / LeakyReLU, activation-gradient masks, accumulate)
+// and an in-launch split-K whose partial sums are combined by the last-arriving block in a fixed
+// order (deterministic, epilogue still fused).  Exact fp32 arithmetic (the MFMA is an fmaf chain),
 // which is what the 1e-4 parity gate of the fit requires.
 //
 // Replaces, on the hot path of the reference: nn.Linear in FCNN / MotionNet
@@ -9,132 +10,152 @@
 // (human_body_prior/body_model/lbs.py:229-233) and their autograd backward GEMMs.
 //
 // Structure: 256 threads = 4 waves in a 2x2 grid, each wave owns (BM/2)x(BN/2) of the block tile as
-// 32x32 MFMA accumulators.  K is walked in tiles of 16 through a double-buffered LDS image stored
-// k-major ([k][m], [k][n]) so that the per-lane MFMA operand reads are conflict-free ds_read_b32;
-// one barrier per K-tile; the next tile's global loads are issued before the MFMAs of the current
-// one.  Operands whose rows are 16-byte aligned are staged with dwordx4 loads (VEC path), anything
-// else (e.g. nn.Linear weights with in_features = 105 / 63) with dword loads.
+// 32x32 MFMA accumulators (128x128 tile: 4 per wave, 64x64: 1).  K is walked in tiles of 32 through a
+// double-buffered LDS image; one barrier per K tile; the next tile's global loads are issued before
+// the MFMAs of the current one and land in LDS just before its last MFMA group.
+//
+// k permutation: MFMA step j of k-group q takes k = 8q + j from lanes 0-31 and k = 8q + 4 + j from
+// lanes 32-63 (for both operands, so the dot product is complete -- only the fp32 summation order
+// differs from a sequential k walk).  A lane's four operands of a group are then CONTIGUOUS in k:
+// an operand whose source is k-contiguous is staged row-major ([row][k], dwordx4 global loads ->
+// ds_write_b128) and fetched with ONE conflict-free ds_read_b128 per group (row stride 36 floats: the
+// 16-lane service groups of a b128 read cover all 64 banks); an operand whose source is
+// row-contiguous is staged k-major ([k][row]) and fetched with four ds_read_b32.
+#include <type_traits>
 #include "common.h"
 #include "../../include/nemo_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
     const float* bias; const float* mask;
+    float* slabs; int* counters;
     long M, N, K, lda, ldb, ldc, ldmask;
-    long k_chunk;           // K range per grid.z slice (multiple of the K tile)
-    int tiles_m, tiles_n;
+    long k_chunk;           // K range per slice (multiple of the K tile)
+    int tiles_m, tiles_n, n_tiles, split;
     int act, mask_mode, out_mode;
     float alpha;
 };
 
-constexpr int PAD = 4;
-
-// Per-thread staging of (ROWS x BKT) operand tiles, two tiles in flight (register slots 0/1).
-// Element (r, kk) of a tile is
-//   KCONTIG : src[(row0 + r) * ld + k0 + kk]      (k is the contiguous axis)
-//   !KCONTIG: src[(k0 + kk) * ld + row0 + r]      (r is the contiguous axis)
-// Out-of-range elements are zero.
-template <int ROWS, int BKT, bool KCONTIG, bool VEC>
+// Per-thread staging of one (ROWS x BK) operand tile.  Element (r, kk) of a tile is
+//   KCONTIG : src[(row0 + r) * ld + k0 + kk]      (k is the contiguous axis)  -> LDS [r][BK+4]
+//   !KCONTIG: src[(k0 + kk) * ld + row0 + r]      (r is the contiguous axis)  -> LDS [kk][ROWS+4]
+// Rows beyond the operand are NOT zeroed: they only feed output rows / columns the epilogue never
+// writes, so their loads are simply redirected to a valid row (pointer fixed once, in init).  Only
+// k >= K must contribute zeros; that concerns the last K tile alone, which goes through the MASKED
+// variants.  The full-tile variants are one unconditional load and one unconditional LDS store per
+// element -- nothing that could make hipcc wait for a load before the MFMAs it is meant to hide
+// behind (a predicated load, or a select on the loaded value, puts the s_waitcnt right there).
+template <int ROWS, int BK, bool KCONTIG, bool VEC, int NS>
 struct Stager {
-    static constexpr int NV = VEC ? ROWS * BKT / 1024 : ROWS * BKT / 256;   // float4 / float per thread per tile
+    static constexpr int NV = VEC ? ROWS * BK / 1024 : ROWS * BK / 256;   // float4 / float per thread per tile
+    static constexpr int LD = KCONTIG ? BK + 4 : ROWS + 4;
+    static constexpr int SIZE = KCONTIG ? ROWS * LD : BK * LD;
     const float* p[NV];           // per-element pointers (advanced every K tile)
-    bool row_ok[NV];
-    int r_[NV], k_[NV];           // element position inside the tile
-    float4 v4[2][VEC ? NV : 1];
-    float v1[2][VEC ? 1 : NV];
+    int off_[NV], k_[NV];         // LDS offset / k position inside the tile
+    float4 v4[NS][VEC ? NV : 1];  // NS register slots = NS K tiles in flight
+    float v1[NS][VEC ? 1 : NV];
     long step;                    // pointer advance per K tile
     const float* safe;            // always-valid, 16-byte aligned address (the operand base)
-    int row_rem[NV];              // !KCONTIG VEC: rows remaining from the element's first row (clamped)
 
     __device__ __forceinline__ void init(const float* src, long ld, long row0, long k0, long row_lim) {
         const int t = threadIdx.x;
         safe = src;
-        step = KCONTIG ? BKT : (long)BKT * ld;
+        step = KCONTIG ? BK : (long)BK * ld;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int r, kk;
             if (VEC) {
-                if (KCONTIG) { kk = 4 * (t % (BKT / 4)); r = t / (BKT / 4) + (1024 / BKT) * i; }
+                if (KCONTIG) { kk = 4 * (t % (BK / 4)); r = t / (BK / 4) + (1024 / BK) * i; }
                 else { r = 4 * (t % (ROWS / 4)); kk = t / (ROWS / 4) + (1024 / ROWS) * i; }
             } else {
-                if (KCONTIG) { kk = t % BKT; r = t / BKT + (256 / BKT) * i; }
+                if (KCONTIG) { kk = t % BK; r = t / BK + (256 / BK) * i; }
                 else { r = t % ROWS; kk = t / ROWS + (256 / ROWS) * i; }
             }
-            r_[i] = r; k_[i] = kk;
-            const long gr = row0 + r;
-            const long rem = row_lim - gr;
-            row_rem[i] = rem > 4 ? 4 : (rem < 0 ? 0 : (int)rem);
-            row_ok[i] = (VEC && !KCONTIG) ? (gr + 3 < row_lim) : (gr < row_lim);
+            k_[i] = kk;
+            off_[i] = KCONTIG ? r * LD + kk : kk * LD + r;
+            long gr = row0 + r;
+            // a dwordx4 along rows that straddles row_lim stays inside the row storage (ld % 4 == 0)
+            if (gr >= row_lim) gr = 0;
             p[i] = KCONTIG ? src + gr * ld + k0 + kk : src + (k0 + kk) * ld + gr;
         }
     }
 
-    // k_rem = k_lim - k0 of the tile being loaded (may be <= 0: zero fill).
-    // BRANCH-FREE: every load is unconditional from a clamped, always-valid address and invalid
-    // elements are zeroed with selects.  (A predicated load sits in its own basic block and hipcc
-    // waits for it at the block end -- that serialised every staging load behind a full L2 round
-    // trip.)  A dwordx4 that straddles the logical end of a row stays inside the row's storage because
-    // the VEC path requires ld % 4 == 0 (so ld >= the extent rounded up to 4).
-    template <int SLOT>
+    // leading valid k elements of element i when k_rem = K_end - k0 of the tile
+    __device__ __forceinline__ int nvalid(int i, long k_rem) const {
+        const long kr = k_rem - k_[i];
+        if (VEC && KCONTIG) return kr > 4 ? 4 : (kr < 0 ? 0 : (int)kr);
+        return kr > 0 ? 4 : 0;
+    }
+
+    template <bool MASKED, int SLOT>
     __device__ __forceinline__ void load(long k_rem) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            if (VEC) {
-                int nvalid;                       // leading valid elements of the float4 (0..4)
-                if (KCONTIG) {
-                    const long kr = k_rem - k_[i];
-                    nvalid = row_ok[i] ? (kr > 4 ? 4 : (kr < 0 ? 0 : (int)kr)) : 0;
-                } else {
-                    nvalid = (k_[i] < k_rem) ? row_rem[i] : 0;
-                }
-                const float* q = nvalid > 0 ? p[i] : safe;
-                float4 v = *reinterpret_cast<const float4*>(q);
-                v.x = nvalid > 0 ? v.x : 0.f; v.y = nvalid > 1 ? v.y : 0.f;
-                v.z = nvalid > 2 ? v.z : 0.f; v.w = nvalid > 3 ? v.w : 0.f;
-                v4[SLOT][i] = v;
-            } else {
-                const bool ok = row_ok[i] && k_[i] < k_rem;
-                const float* q = ok ? p[i] : safe;
-                const float v = *q;
-                v1[SLOT][i] = ok ? v : 0.f;
-            }
+            const float* q = p[i];
+            if (MASKED) q = nvalid(i, k_rem) > 0 ? q : safe;      // never dereference beyond the last K row
+            if (VEC) v4[SLOT][i] = *reinterpret_cast<const float4*>(q);
+            else v1[SLOT][i] = *q;
             p[i] += step;
         }
     }
 
-    template <int SLOT>
-    __device__ __forceinline__ void store(float (*lds)[ROWS + PAD]) const {
+    // k_rem: the same value the matching load() was given
+    template <bool MASKED, int SLOT>
+    __device__ __forceinline__ void store(float* lds, long k_rem) const {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             if (VEC) {
-                if (KCONTIG) {
-                    lds[k_[i] + 0][r_[i]] = v4[SLOT][i].x; lds[k_[i] + 1][r_[i]] = v4[SLOT][i].y;
-                    lds[k_[i] + 2][r_[i]] = v4[SLOT][i].z; lds[k_[i] + 3][r_[i]] = v4[SLOT][i].w;
-                } else {
-                    *reinterpret_cast<float4*>(&lds[k_[i]][r_[i]]) = v4[SLOT][i];
+                float4 v = v4[SLOT][i];
+                if (MASKED) {
+                    const int nv = nvalid(i, k_rem);
+                    v.x = nv > 0 ? v.x : 0.f; v.y = nv > 1 ? v.y : 0.f;
+                    v.z = nv > 2 ? v.z : 0.f; v.w = nv > 3 ? v.w : 0.f;
                 }
+                *reinterpret_cast<float4*>(lds + off_[i]) = v;
             } else {
-                lds[k_[i]][r_[i]] = v1[SLOT][i];
+                lds[off_[i]] = (!MASKED || nvalid(i, k_rem) > 0) ? v1[SLOT][i] : 0.f;
             }
         }
     }
 };
 
-template <int BM, int BN, int BKT, bool TA, bool TB, bool VEC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][BKT][BM + PAD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BKT][BN + PAD];
+// the four operands (MFMA steps j = 0..3) of k-group q for the 32 rows starting at row0
+template <int ROWS, int BK, bool KCONTIG>
+__device__ __forceinline__ void fetch_group(const float* lds, int row, int q, int lhi, float (&f)[4]) {
+#ifdef ABL_NOREAD
+    f[0] = row; f[1] = q; f[2] = lhi; f[3] = 1.f; return;
+#endif
+    if (KCONTIG) {
+        const float4 v = *reinterpret_cast<const float4*>(lds + row * (BK + 4) + 8 * q + 4 * lhi);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = lds[(8 * q + 4 * lhi + j) * (ROWS + 4) + row];
+    }
+}
+
+template <int BM, int BN, int BK, bool TA, bool TB, bool VEC, int NS>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32, G = BK / 8;
+    using SA = Stager<BM, BK, !TA, VEC, NS>;
+    using SB = Stager<BN, BK, TB, VEC, NS>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // the ONLY LDS object of the kernel
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * SA::SIZE;
 
     const int bid = blockIdx.x;
-    const int tm = bid % g.tiles_m, tn = bid / g.tiles_m;
+    const int tile = bid % g.n_tiles, slice = bid / g.n_tiles;
+    const int tm = tile % g.tiles_m, tn = tile / g.tiles_m;
     const long m0 = (long)tm * BM, n0 = (long)tn * BN;
-    const long kbeg = (long)blockIdx.z * g.k_chunk;
+    const long kbeg = (long)slice * g.k_chunk;
     const long kend = min(g.K, kbeg + g.k_chunk);
+    const long klen = kend > kbeg ? kend - kbeg : 0;
+    const long nt = (klen + BK - 1) / BK;                 // K tiles of this slice
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -149,83 +170,147 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // A tile: "rows" = m; transA == 0 -> A[m][k], k contiguous.  B tile: "rows" = n; transB == 1 -> B[n][k].
-    Stager<BM, BKT, !TA, VEC> sa;
-    Stager<BN, BKT, TB, VEC> sb;
+    SA sa;
+    SB sb;
     sa.init(g.A, g.lda, m0, kbeg, g.M);
     sb.init(g.B, g.ldb, n0, kbeg, g.N);
 
-    auto compute = [&](int cur) {
-        if constexpr (TM * TN == 1) {
-            // one MFMA per k-step cannot cover the LDS latency of its own operands: fetch the whole
-            // tile's operands first (BKT ds_reads in flight), then issue the MFMAs back to back
-            float a[BKT / 2], b[BKT / 2];
+    // Register pipeline, NS K tiles in flight.  Iteration t (LDS buffer t&1 holds tile t):
+    //   1. tile t+1 leaves its register slot for the OTHER LDS buffer (free since the barrier that ended
+    //      iteration t-1) -- at the START of the iteration, so the ds_writes drain under the MFMAs and
+    //      the closing barrier never waits for them;
+    //   2. tile t+1+NS is requested into the slot just vacated (it has NS iterations of MFMA work to
+    //      hide behind, even when the CU holds this block alone);
+    //   3. tile t's MFMAs from LDS, operand groups double-buffered in registers;   4. one barrier.
+    // Prologue: tile 0 -> LDS buffer 0; tiles 1..NS in flight in slots 1 % NS .. NS % NS.
+    sa.template load<true, 0>(klen); sb.template load<true, 0>(klen);
+    sa.template store<true, 0>(As0, klen); sb.template store<true, 0>(Bs0, klen);
+    __builtin_amdgcn_sched_barrier(0);
+    auto preload = [&](auto tile_no) {
+        constexpr int J = decltype(tile_no)::value;
+        sa.template load<true, J % NS>(klen - J * BK); sb.template load<true, J % NS>(klen - J * BK);
+        __builtin_amdgcn_sched_barrier(0);     // keep the request order: the loop's vmcnt counts rely on it
+    };
+    preload(std::integral_constant<int, 1>{});
+    if constexpr (NS > 1) preload(std::integral_constant<int, 2>{});
+    if constexpr (NS > 2) preload(std::integral_constant<int, 3>{});
+    if constexpr (NS > 3) preload(std::integral_constant<int, 4>{});
+    __syncthreads();
+    int cur = 0;
+    // MASKED = the tiles staged may be partial or absent (zero fill); the steady state is unmasked.
+    auto k_tile = [&](auto masked, auto uslot, long t) {
+        constexpr bool MASKED = decltype(masked)::value;
+        constexpr int U = decltype(uslot)::value;             // = (t + 1) % NS
+        const float* as = As0 + cur * SA::SIZE;
+        const float* bs = Bs0 + cur * SB::SIZE;
+        // (after the last K tile this stores a zero tile nobody reads)
+#ifndef ABL_NOSTORE
+        sa.template store<MASKED, U>(As0 + (cur ^ 1) * SA::SIZE, klen - (t + 1) * BK);
+        sb.template store<MASKED, U>(Bs0 + (cur ^ 1) * SB::SIZE, klen - (t + 1) * BK);
+#endif
+#ifndef ABL_NOLOAD
+        sa.template load<MASKED, U>(klen - (t + 1 + NS) * BK); sb.template load<MASKED, U>(klen - (t + 1 + NS) * BK);
+#endif
+        __builtin_amdgcn_sched_barrier(0);     // hipcc otherwise sinks stores and loads down to the barrier
+        float fa[2][TM][4], fb[2][TN][4];
 #pragma unroll
-            for (int ks = 0; ks < BKT; ks += 2) {
-                a[ks / 2] = As[cur][ks + lhi][wm * WM + l31];
-                b[ks / 2] = Bs[cur][ks + lhi][wn * WN + l31];
+        for (int i = 0; i < TM; ++i) fetch_group<BM, BK, !TA>(as, wm * WM + i * 32 + l31, 0, lhi, fa[0][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fetch_group<BN, BK, TB>(bs, wn * WN + j * 32 + l31, 0, lhi, fb[0][j]);
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            if (q + 1 < G) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fetch_group<BM, BK, !TA>(as, wm * WM + i * 32 + l31, q + 1, lhi, fa[(q + 1) & 1][i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fetch_group<BN, BK, TB>(bs, wn * WN + j * 32 + l31, q + 1, lhi, fb[(q + 1) & 1][j]);
             }
 #pragma unroll
-            for (int ks = 0; ks < BKT / 2; ++ks)
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], b[ks], acc[0][0], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < BKT; ks += 2) {
-                float a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = As[cur][ks + lhi][wm * WM + i * 32 + l31];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = Bs[cur][ks + lhi][wn * WN + j * 32 + l31];
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][i][s], fb[q & 1][j][s],
+                                                                         acc[i][j], 0, 0, 0);
         }
+        __syncthreads();
+        cur ^= 1;
     };
+    auto k_group = [&](auto masked, long t) {            // NS consecutive tiles starting at a multiple of NS
+        constexpr bool MASKED = decltype(masked)::value;  // (an unmasked group is complete by construction)
+        k_tile(masked, std::integral_constant<int, 1 % NS>{}, t);
+        if constexpr (NS > 1) { if (!MASKED || t + 1 < nt) k_tile(masked, std::integral_constant<int, 2 % NS>{}, t + 1); }
+        if constexpr (NS > 2) { if (!MASKED || t + 2 < nt) k_tile(masked, std::integral_constant<int, 3 % NS>{}, t + 2); }
+        if constexpr (NS > 3) { if (!MASKED || t + 3 < nt) k_tile(masked, std::integral_constant<int, 4 % NS>{}, t + 3); }
+    };
+    long t = 0;
+    for (; (t + 2 * NS + 1) * BK <= klen; t += NS) k_group(std::false_type{}, t);   // every tile touched is full
+    for (; t < nt; t += NS) k_group(std::true_type{}, t);
 
-    if constexpr (BM == 64) {
-        // Software pipeline, two K tiles in flight in registers: tile t+2 is requested from L2 before the
-        // MFMAs of tile t, and lands in LDS (other buffer) only after the MFMAs of tile t+1 -- the global
-        // latency is covered by two compute phases even when a CU holds a single block (the small
-        // GEMMs of the step put ~1 block on a CU).
-        long krem = kend - kbeg;                       // remaining K from the next tile to LOAD
-        sa.template load<0>(krem); sb.template load<0>(krem); krem -= BKT;
-        sa.template load<1>(krem); sb.template load<1>(krem); krem -= BKT;
-        sa.template store<0>(As[0]); sb.template store<0>(Bs[0]);
+    // ---- split-K: publish the partial tile, the last arriver sums all slices in slice order ----------
+    // (cdna_hip_programming.md, in-launch split-K hand-off: plain slab stores -> per-wave vmcnt(0) ->
+    //  barrier -> one-lane agent-scope release -> ticket; reducer: one-lane agent-scope acquire ->
+    //  barrier -> plain loads.)  Slab layout = the register image: float4 #(i,j,r4) of thread t.
+    if (g.split > 1 && g.out_mode != 2) {
+        float4* slab = reinterpret_cast<float4*>(g.slabs) +
+                       ((size_t)tile * g.split + slice) * (size_t)(BM * BN / 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                {
+                    const float4 v = make_float4(acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2],
+                                                 acc[i][j][4 * r4 + 3]);
+                    float4* dst = slab + ((i * TN + j) * 4 + r4) * 256 + threadIdx.x;
+#ifndef NEMO_GEMM_PLAIN_SLABS
+                    // write-through (sc1) store: visible device-wide once vmcnt drains, no L2 write-back fence
+                    const f32x4v vv = {v.x, v.y, v.z, v.w};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(vv) : "memory");
+#else
+                    *dst = v;
+#endif
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (long k0 = kbeg; k0 < kend; k0 += 2 * BKT) {
-            // even tile (LDS buffer 0); register slot 0 is free again
-            sa.template load<0>(krem); sb.template load<0>(krem); krem -= BKT;
-            compute(0);
-            sa.template store<1>(As[1]); sb.template store<1>(Bs[1]);
-            __syncthreads();
-            // odd tile (LDS buffer 1): a zero tile when K is exhausted (adds nothing)
-            sa.template load<1>(krem); sb.template load<1>(krem); krem -= BKT;
-            compute(1);
-            sa.template store<0>(As[0]); sb.template store<0>(Bs[0]);
-            __syncthreads();
-        }
-    } else {
-        // big tiles: 2048 MFMA cycles per K tile already cover the L2 latency; one tile in flight
-        if (kbeg < kend) {
-            sa.template load<0>(kend - kbeg); sb.template load<0>(kend - kbeg);
-            sa.template store<0>(As[0]); sb.template store<0>(Bs[0]);
+        int* flag = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) {
+#ifdef NEMO_GEMM_PLAIN_SLABS
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            *flag = __hip_atomic_fetch_add(g.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        int cur = 0;
-        for (long k0 = kbeg; k0 < kend; k0 += BKT) {
-            const bool more = k0 + BKT < kend;
-            if (more) { sa.template load<0>(kend - k0 - BKT); sb.template load<0>(kend - k0 - BKT); }
-            compute(cur);
-            if (more) { sa.template store<0>(As[cur ^ 1]); sb.template store<0>(Bs[cur ^ 1]); }
-            __syncthreads();
-            cur ^= 1;
+        if (*flag != g.split - 1) return;
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(g.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
+        __syncthreads();
+        const float4* base = reinterpret_cast<const float4*>(g.slabs) + (size_t)tile * g.split * (size_t)(BM * BN / 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int sl = 0; sl < g.split; ++sl) {          // fixed order; own slice re-read like the others
+                        const float4 v = base[(size_t)sl * (BM * BN / 4) + ((i * TN + j) * 4 + r4) * 256 + threadIdx.x];
+                        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                    }
+                    acc[i][j][4 * r4] = sum.x; acc[i][j][4 * r4 + 1] = sum.y;
+                    acc[i][j][4 * r4 + 2] = sum.z; acc[i][j][4 * r4 + 3] = sum.w;
+                }
     }
 
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    const bool add_bias = g.bias != nullptr && blockIdx.z == 0;
+    const bool add_bias = g.bias != nullptr && (slice == 0 || g.out_mode != 2);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -253,17 +338,73 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
-template <int BM, int BN, int BKT, bool VEC>
-void launch(int ta, int tb, const GemmArgs& g, dim3 grid, hipStream_t s) {
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKT, false, false, VEC>), grid, dim3(256), 0, s, g);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKT, false, true, VEC>), grid, dim3(256), 0, s, g);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKT, true, false, VEC>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BKT, true, true, VEC>), grid, dim3(256), 0, s, g);
+#ifndef NS_SMALL
+#define NS_SMALL 3
+#endif
+#ifndef NS_BIG
+#define NS_BIG 2
+#endif
+template <int BM, int BN, int BK, bool TA, bool TB, bool VEC>
+hipError_t launch_one(const GemmArgs& g, int blocks, hipStream_t s) {
+    constexpr int NS = BM == 64 ? NS_SMALL : NS_BIG;
+    using SA = Stager<BM, BK, !TA, VEC, NS>;
+    using SB = Stager<BN, BK, TB, VEC, NS>;
+    constexpr size_t lds = 2 * (SA::SIZE + SB::SIZE) * sizeof(float);
+    static bool attr_set = false;        // > 64 KB of LDS needs the opt-in once per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, BK, TA, TB, VEC, NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, TA, TB, VEC, NS>), dim3(blocks), dim3(256), lds, s, g);
+    return hipSuccess;
 }
 
-constexpr int BK_BIG = 16, BK_SMALL = 32;
+template <int BM, int BN, int BK, bool VEC>
+hipError_t launch(int ta, int tb, const GemmArgs& g, int blocks, hipStream_t s) {
+    if (!ta && !tb) return launch_one<BM, BN, BK, false, false, VEC>(g, blocks, s);
+    if (!ta && tb) return launch_one<BM, BN, BK, false, true, VEC>(g, blocks, s);
+    if (ta && !tb) return launch_one<BM, BN, BK, true, false, VEC>(g, blocks, s);
+    return launch_one<BM, BN, BK, true, true, VEC>(g, blocks, s);
+}
+
+constexpr int BK = 32;
+constexpr long COUNTER_BYTES = 16384;       // 4096 tile tickets at the head of the workspace
+constexpr int N_CU = 256;
 
 inline bool aligned16(const void* p, long ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
+
+// Host cost model in microseconds, fitted to tools/bench_gemm.py --sweep on an MI355X (profiles/
+// r01c_gemm_sweep.md): the busiest CU runs ceil(blocks / 256) blocks one after (or beside) the other at
+// a fixed cost per K tile, and an in-launch combine costs a fixed hand-off plus the slab round trip.
+struct Plan { int tile; int split; double cost; };
+
+Plan plan_gemm(long M, long N, long K, bool can_split, long ws_bytes, bool atomic_mode, int forced_split,
+               bool big_ok) {
+    const long kiters = (K + BK - 1) / BK;
+    Plan best{64, 1, 1e30};
+    for (int tile : {128, 64}) {
+        if (tile == 128 && !big_ok) continue;
+        const long tiles = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
+        const double us_iter = tile == 128 ? 2.35 : 0.67;          // one K tile of one block
+        const int smax = forced_split > 0 ? forced_split : (can_split || atomic_mode ? 32 : 1);
+        for (int S = forced_split > 0 ? forced_split : 1; S <= smax; ++S) {
+            if (S > 1 && forced_split <= 0 && kiters / S < 4) break;
+            if (S > 1 && !atomic_mode) {
+                if (tiles > COUNTER_BYTES / 4) break;
+                if (COUNTER_BYTES + tiles * S * (long)tile * tile * 4 > ws_bytes) break;
+            }
+            const long it = (kiters + S - 1) / S;
+            const long blocks = tiles * S;
+            const long per_cu = (blocks + N_CU - 1) / N_CU;
+            double c = per_cu * it * us_iter;
+            if (S > 1) c += 3.0 + (atomic_mode ? 1.0 : 2.0) * blocks * (double)tile * tile * 4 / 3.0e6;
+            if (c < best.cost) best = Plan{tile, S, c};
+        }
+    }
+    return best;
+}
 
 }  // namespace
 
@@ -271,46 +412,62 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
                                  const float* A, int64_t lda, const float* B, int64_t ldb,
                                  float* C, int64_t ldc, const float* bias, int32_t act,
                                  const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
-                                 int32_t out_mode, int32_t split_k, void* stream) {
+                                 int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream) {
     if (M < 0 || N < 0 || K < 0 || !C) return NEMO_EINVAL;
     if (M == 0 || N == 0) return NEMO_OK;
     if (K > 0 && (!A || !B)) return NEMO_EINVAL;
     if (act < 0 || act > 2 || mask_mode < 0 || mask_mode > 2 || out_mode < 0 || out_mode > 2)
         return NEMO_EINVAL;
     if (mask_mode && !mask) return NEMO_EINVAL;
-    if (split_k < 1) split_k = 1;
-    // a K-split is only linear: no activation / mask, and the partial sums must be added atomically
-    if (split_k > 1 && (act || mask_mode || out_mode != 2)) return NEMO_EINVAL;
+    if (split_k < 0 || ws_bytes < 0 || (ws_bytes > 0 && !ws)) return NEMO_EINVAL;
+    // atomically accumulated slices are only linear: no activation / mask
+    if (out_mode == 2 && (act || mask_mode)) return NEMO_EINVAL;
+    const bool can_split = ws != nullptr && ws_bytes > COUNTER_BYTES && (((uintptr_t)ws) & 15) == 0;
+    if (split_k > 1 && out_mode != 2 && !can_split) return NEMO_EINVAL;
+
+    int force_tile = 0;
+    if (const char* f = getenv("NEMO_GEMM_TILE")) force_tile = atoi(f);          // tuning aids (tools/bench_gemm.py)
+    if (const char* f = getenv("NEMO_GEMM_SPLIT")) { if (split_k == 0 && atoi(f) > 0) split_k = atoi(f); }
+    // K-chunk starts are multiples of 32, so operand alignment only depends on the base and the ld
+    const bool vec = aligned16(A, lda) && aligned16(B, ldb);
+    // (the dword-staged variant exists for 64x64 tiles only: it serves the few small-K operands whose
+    //  rows are not 16-byte aligned, e.g. nn.Linear weights with in_features 105 / 63)
+    // (128x128 tiles pay off only with both operands k-contiguous: the k-major LDS image is fetched with
+    //  four ds_read_b32 per operand group instead of one ds_read_b128 and runs at ~half the rate there)
+    Plan pl = plan_gemm(M, N, K, can_split, ws_bytes, out_mode == 2, split_k, vec && !transA && transB);
+    if (vec && (force_tile == 64 || force_tile == 128)) {
+        pl.tile = force_tile;
+        if (split_k > 0) pl.split = split_k;
+    }
+    const int tile = pl.tile;
 
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.mask = mask;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldmask = ldmask;
     g.act = act; g.mask_mode = mask_mode; g.out_mode = out_mode; g.alpha = alpha;
-    // 128x128 tiles (BK 16) once they alone fill the 256 CUs a couple of times over; 64x64 (BK 32) otherwise
-    const long big_tiles = ((M + 127) / 128) * ((N + 127) / 128) * split_k;
-    const bool big = big_tiles >= 512;
-    const int bk = big ? BK_BIG : BK_SMALL;
-    long kc = (K + split_k - 1) / split_k;
-    kc = ((kc + bk - 1) / bk) * bk;
-    if (kc == 0) kc = bk;
+    g.counters = reinterpret_cast<int*>(ws);
+    g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
+    long kc = (K + pl.split - 1) / pl.split;
+    kc = ((kc + BK - 1) / BK) * BK;
+    if (kc == 0) kc = BK;
     g.k_chunk = kc;
     int nz = (int)((K + kc - 1) / kc);
     if (nz < 1) nz = 1;
+    g.split = nz;
+    g.tiles_m = (int)((M + tile - 1) / tile); g.tiles_n = (int)((N + tile - 1) / tile);
+    g.n_tiles = g.tiles_m * g.tiles_n;
+    if (nz > 1 && out_mode != 2 &&
+        (g.n_tiles > COUNTER_BYTES / 4 || COUNTER_BYTES + (long)g.n_tiles * nz * tile * tile * 4 > ws_bytes))
+        return NEMO_EINVAL;
+    const long blocks = (long)g.n_tiles * nz;
+    if (blocks > 0x7fffffffL) return NEMO_EINVAL;
 
-    // K-chunk starts are multiples of 16, so operand alignment only depends on the base and the ld
-    const bool vec = aligned16(A, lda) && aligned16(B, ldb);
     hipStream_t s = (hipStream_t)stream;
-    if (big) {
-        g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (int)((N + 127) / 128);
-        dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
-        if (vec) launch<128, 128, BK_BIG, true>(transA, transB, g, grid, s);
-        else launch<128, 128, BK_BIG, false>(transA, transB, g, grid, s);
-    } else {
-        g.tiles_m = (int)((M + 63) / 64); g.tiles_n = (int)((N + 63) / 64);
-        dim3 grid(g.tiles_m * g.tiles_n, 1, nz);
-        if (vec) launch<64, 64, BK_SMALL, true>(transA, transB, g, grid, s);
-        else launch<64, 64, BK_SMALL, false>(transA, transB, g, grid, s);
-    }
+    hipError_t e;
+    if (tile == 128) e = launch<128, 128, BK, true>(transA, transB, g, (int)blocks, s);
+    else e = vec ? launch<64, 64, BK, true>(transA, transB, g, (int)blocks, s)
+                 : launch<64, 64, BK, false>(transA, transB, g, (int)blocks, s);
+    if (e != hipSuccess) return (int32_t)e;
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -218,6 +218,8 @@ class FitEngine:
         self._scal_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.ws = {}
         self.side_stream = torch.cuda.Stream(device=self.device)   # prior branch of the step (see _forward_backward)
+        # split-K scratch of nemo_gemm_f32 (arrival tickets + partial tiles), one per stream that launches GEMMs
+        self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(2)]
         self._colsums = []
         self._seg_host = self._seg_dev = None
         self.timers = None
@@ -278,10 +280,14 @@ class FitEngine:
 
     # ------------------------------------------------------------------ kernel helpers
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias=None, act=0, mask=None, ldmask=0,
-             mask_mode=0, alpha=1.0, out_mode=0, split_k=1, tag=None):
+             mask_mode=0, alpha=1.0, out_mode=0, split_k=0, tag=None):
+        """split_k 0: the library picks the tile shape and the K split (combined inside the launch through
+        this stream's scratch)."""
         ev = self._event_begin(tag, 2.0 * M * N * K)
+        ws = self.gemm_ws[1 if torch.cuda.current_stream() == self.side_stream else 0]
         check(self.lib.nemo_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias, act, mask, ldmask,
-                                     mask_mode, alpha, out_mode, split_k, _stream()), 'nemo_gemm_f32')
+                                     mask_mode, alpha, out_mode, split_k, ws.data_ptr(), ws.numel() * 4,
+                                     _stream()), 'nemo_gemm_f32')
         self._event_end(ev)
 
     # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
@@ -306,9 +312,7 @@ class FitEngine:
     def _linear_bwd_params(self, rows, x, ldx, fin, dy, lddy, fout, gw, gb, nbias=None):
         """gw (fout,fin) += dy^T @ x ;  gb[:nbias] += colsum(dy) (skipped when gb is None).  K = rows
         is split for occupancy."""
-        tiles = ((fout + 63) // 64) * ((fin + 63) // 64)
-        split = max(1, min(64, (512 + tiles - 1) // tiles, (rows + 255) // 256))
-        self.gemm(1, 0, fout, fin, rows, dy, lddy, x, ldx, gw, fin, out_mode=2, split_k=split)
+        self.gemm(1, 0, fout, fin, rows, dy, lddy, x, ldx, gw, fin, out_mode=1)
         if gb is not None:       # bias gradients are batched into one launch (flush_colsums)
             self._colsums.append((dy, rows, fout if nbias is None else nbias, lddy, gb))
 
@@ -419,7 +423,7 @@ class FitEngine:
                 if c0 > 0:
                     w['dPF2'].zero_()
                 self.gemm(1, 1, n, 207, NV3, dptr(w['dVPt']), ldn, ctx.posedirs, ldP, dptr(w['dPF2']), 208,
-                          out_mode=2, split_k=8, tag='gemm_pose_blend_bwd')
+                          out_mode=1, tag='gemm_pose_blend_bwd')
                 check(L.nemo_fk_bwd(ctx.handle, n, dptr(w['R2']), dptr(w['A2']), dptr(w['dA2']), None,
                                     dptr(w['dPF2']), 208, w['dR2'].data_ptr() + 4 * c0 * 216, st), 'nemo_fk_bwd')
 

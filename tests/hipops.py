@@ -17,8 +17,17 @@ def dev(t, dtype=torch.float32):
     return torch.as_tensor(t).to(DEV, dtype).contiguous()
 
 
+_GEMM_WS = {}
+
+
+def gemm_ws(nbytes=64 << 20):
+    if nbytes not in _GEMM_WS:
+        _GEMM_WS[nbytes] = torch.zeros(nbytes // 4, device=DEV)
+    return _GEMM_WS[nbytes]
+
+
 def gemm(A, B, ta=0, tb=0, bias=None, act=0, mask=None, mask_mode=0, alpha=1.0, out_mode=0, split_k=1,
-         C=None):
+         C=None, ws=True):
     L = _lib.load()
     M = A.shape[1] if ta else A.shape[0]
     K = A.shape[0] if ta else A.shape[1]
@@ -27,5 +36,6 @@ def gemm(A, B, ta=0, tb=0, bias=None, act=0, mask=None, mask_mode=0, alpha=1.0, 
         C = torch.zeros(M, N, device=DEV)
     check(L.nemo_gemm_f32(ta, tb, M, N, K, dptr(A), A.stride(0), dptr(B), B.stride(0), dptr(C), C.stride(0),
                           dptr(bias), act, dptr(mask), mask.stride(0) if mask is not None else 0, mask_mode,
-                          alpha, out_mode, split_k, st()), 'gemm')
+                          alpha, out_mode, split_k, dptr(gemm_ws()) if ws else None,
+                          gemm_ws().numel() * 4 if ws else 0, st()), 'gemm')
     return C

@@ -25,14 +25,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/nemo_hip.h but not exported'
     assert sorted(_lib.SIGNATURES) == declared, set(_lib.SIGNATURES) ^ set(declared)
-    assert lib.nemo_abi_version() == 1
+    assert lib.nemo_abi_version() == 2
 
 
 def test_argument_validation_without_gpu():
     """Entry points validate before touching the device: bad arguments return <0 on any box."""
     from nemo_cvpr2023_amd import _lib
     lib = _lib.load()
-    assert lib.nemo_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, None, 0, 0, 1.0, 0, 1, None) < 0
+    assert lib.nemo_gemm_f32(0, 0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, None, 0, 0, 1.0, 0, 1, None, 0, None) < 0
     assert lib.nemo_rot6d_fwd(4, 0, None, 0, 1, None, None, None) < 0
     assert lib.nemo_adam_step(99, None, None, None, None, None, 0.9, 0.999, 1e-8, None) < 0
     assert lib.nemo_ctx_num_verts(None) == -1

@@ -45,7 +45,7 @@ def test_gemm_big_tile_path(L):
     g = torch.Generator().manual_seed(5)
     A, B = torch.randn(2600, 207, generator=g), torch.randn(207, 3000, generator=g)
     bias = torch.randn(3000, generator=g)
-    C = H.gemm(H.dev(A), H.dev(B), bias=H.dev(bias))       # >= 512 tiles of 128x128
+    C = H.gemm(H.dev(A), H.dev(B), bias=H.dev(bias), split_k=0)       # library-chosen plan
     assert rel_err(C, A.double() @ B.double() + bias.double()) < TOL
 
 
@@ -92,13 +92,56 @@ def test_gemm_vector_path(L, ta, tb, M, N, K):
     assert rel_err(C, ref) < TOL
 
 
+@pytest.mark.parametrize('tile', [64, 128])
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K,split', [(300, 1000, 1000, 3), (207, 2400, 2070, 8), (1000, 148, 2401, 5),
+                                         (70, 50, 64, 2)])
+def test_gemm_split_k_in_launch_combine(L, monkeypatch, tile, ta, tb, M, N, K, split):
+    """K slices combined by the last-arriving block (fixed order): fused bias + ReLU epilogue, C += mode,
+    bit-identical results run to run, tickets returned to zero (a second launch works)."""
+    H = _ops()
+    monkeypatch.setenv('NEMO_GEMM_TILE', str(tile))
+    g = torch.Generator().manual_seed(M + N + K + 2 * ta + tb)
+    lda = ((M if ta else K) + 3) // 4 * 4
+    ldb = ((K if tb else N) + 3) // 4 * 4
+    Af = torch.randn((K if ta else M), lda, generator=g)
+    Bf = torch.randn((N if tb else K), ldb, generator=g)
+    A, B = Af[:, :(M if ta else K)], Bf[:, :(K if tb else N)]
+    bias = torch.randn(N, generator=g)
+    pre = (A.T if ta else A).double() @ (B.T if tb else B).double() + bias.double()
+    dA, dB, db = H.dev(Af)[:, :A.shape[1]], H.dev(Bf)[:, :B.shape[1]], H.dev(bias)
+    C1 = H.gemm(dA, dB, ta, tb, bias=db, act=1, split_k=split)
+    assert rel_err(C1, torch.relu(pre)) < TOL
+    C2 = H.gemm(dA, dB, ta, tb, bias=db, act=1, split_k=split)
+    assert torch.equal(C1, C2)
+    C0 = torch.randn(M, N, generator=g)
+    C = H.dev(C0).clone()
+    H.gemm(dA, dB, ta, tb, bias=db, out_mode=1, split_k=split, C=C)
+    assert rel_err(C, C0.double() + pre) < TOL
+    assert int(H.gemm_ws()[:4096].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize('M,N,K', [(2400, 1000, 1000), (300, 1000, 1000), (1000, 1000, 300), (2400, 148, 1000),
+                                   (207, 2400, 20670), (600, 512, 512), (300, 64, 512)])
+def test_gemm_auto_plan(L, M, N, K):
+    """split_k = 0: whatever (tile, split) the host cost model picks must give the same product."""
+    H = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    C = H.gemm(H.dev(A), H.dev(B), 0, 1, split_k=0)
+    assert rel_err(C, A.double() @ B.double().T) < TOL
+
+
 def test_gemm_rejects_bad_args(L):
     x = torch.zeros(4, 4, device='cuda')
     rc = L.nemo_gemm_f32(0, 0, 4, 4, 4, x.data_ptr(), 4, x.data_ptr(), 4, x.data_ptr(), 4, None, 1, None, 0, 0,
-                         1.0, 0, 2, None)
-    assert rc < 0      # split-K with a non-linear epilogue
+                         1.0, 2, 2, None, 0, None)
+    assert rc < 0      # atomically accumulated slices with a non-linear epilogue
+    rc = L.nemo_gemm_f32(0, 0, 4, 4, 4, x.data_ptr(), 4, x.data_ptr(), 4, x.data_ptr(), 4, None, 0, None, 0, 0,
+                         1.0, 0, 2, None, 0, None)
+    assert rc < 0      # in-launch combine without a workspace
     assert L.nemo_gemm_f32(0, 0, 0, 4, 4, None, 4, None, 4, x.data_ptr(), 4, None, 0, None, 0, 0, 1.0, 0, 1,
-                           None) == 0   # empty problem is a no-op
+                           None, 0, None) == 0   # empty problem is a no-op
 
 
 def test_colsum(L):
@@ -302,7 +345,7 @@ def test_keypoint_path_forward_backward(L, num_verts, version):
     nq72 = ctx.nq * 72
     Mq = Z(N, nq72)
     assert L.nemo_gemm_f32(0, 0, N, nq72, 207, PF.data_ptr(), 207, ctx.C1, nq72, Mq.data_ptr(), nq72, ctx.c0, 0,
-                           None, 0, 0, 1.0, 0, 1, H.st()) == 0
+                           None, 0, 0, 1.0, 0, 1, None, 0, H.st()) == 0
     j3d, p2d, lall, vacc, norm, scal = Z(N, 25, 3), Z(N, 25, 2), Z(N, 25, 2), Z(V, 2), Z(1), Z(8)
     args = (ctx.handle, N, V, T, A.data_ptr(), Jp.data_ptr(), Mq.data_ptr(), nq72, dTR.data_ptr(), 3, 1,
             dvi.data_ptr(), dfi.data_ptr(), dc.data_ptr(), dt.data_ptr(), None, 5000.0, 540.0, 960.0, 0, 0)
@@ -318,7 +361,7 @@ def test_keypoint_path_forward_backward(L, num_verts, version):
     assert L.nemo_kp_bwd(*args, vacc.data_ptr(), norm.data_ptr(), 1.0, dA.data_ptr(), dJp.data_ptr(),
                          dMq.data_ptr(), dTRg.data_ptr(), 3, dcg.data_ptr(), H.st()) == 0
     assert L.nemo_gemm_f32(0, 1, N, 207, nq72, dMq.data_ptr(), nq72, ctx.C1, nq72, dPF.data_ptr(), 207, None, 0,
-                           None, 0, 0, 1.0, 0, 1, H.st()) == 0
+                           None, 0, 0, 1.0, 0, 1, None, 0, H.st()) == 0
     assert L.nemo_fk_bwd(ctx.handle, N, dR.data_ptr(), A.data_ptr(), dA.data_ptr(), dJp.data_ptr(),
                          dPF.data_ptr(), 207, dRg.data_ptr(), H.st()) == 0
     assert L.nemo_scale_neg_rowsum(N, 3, dTRg.data_ptr(), 3, dTRg.data_ptr() + 4 * 3 * N, H.st()) == 0
@@ -360,7 +403,7 @@ def test_keypoint_loss_types_and_camera_mode(L, loss_type, lid):
     nq72 = ctx.nq * 72
     Mq = Z(N, nq72)
     L.nemo_gemm_f32(0, 0, N, nq72, 207, PF.data_ptr(), 207, ctx.C1, nq72, Mq.data_ptr(), nq72, ctx.c0, 0, None,
-                    0, 0, 1.0, 0, 1, H.st())
+                    0, 0, 1.0, 0, 1, None, 0, H.st())
     W = la.shape[-1]
     lall, vacc, norm, scal, dcg = Z(N, 25, W), Z(V, 2), Z(1), Z(8), Z(V, 9)
     args = (ctx.handle, N, V, T, A.data_ptr(), Jp.data_ptr(), Mq.data_ptr(), nq72, None, 3, 0, dvi.data_ptr(),
@@ -399,7 +442,7 @@ def test_vertices_and_v2v(L, num_verts):
     assert L.nemo_fk_fwd(ctx.handle, 2 * N, dR2.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), 207,
                          H.st()) == 0
     assert L.nemo_gemm_f32(0, 0, 2 * N, NV3, 207, PF.data_ptr(), 207, ctx.posedirs, ldP, VP.data_ptr(), NV3,
-                           ctx.v_shaped, 0, None, 0, 0, 1.0, 0, 1, H.st()) == 0
+                           ctx.v_shaped, 0, None, 0, 0, 1.0, 0, 1, None, 0, H.st()) == 0
     verts = Z(2 * N, num_verts, 3)
     tr = H.dev(0.1 * torch.randn(2 * N, 3, generator=gen))
     assert L.nemo_skin_vertices(ctx.handle, 2 * N, VP.data_ptr(), NV3, A.data_ptr(), tr.data_ptr(), 3,
@@ -411,7 +454,7 @@ def test_vertices_and_v2v(L, num_verts):
                               NV3, dA.data_ptr(), H.st()) == 0
     assert rel_err(loss[0], l1.detach()) < 1e-5
     assert L.nemo_gemm_f32(0, 1, N, 207, NV3, dVP.data_ptr(), NV3, ctx.posedirs, ldP, dPF.data_ptr(), 207, None,
-                           0, None, 0, 0, 1.0, 2, 8, H.st()) == 0
+                           0, None, 0, 0, 1.0, 2, 8, None, 0, H.st()) == 0
     assert L.nemo_fk_bwd(ctx.handle, N, dR2.data_ptr(), A.data_ptr(), dA.data_ptr(), None, dPF.data_ptr(), 207,
                          dRg.data_ptr(), H.st()) == 0
     # |.| is non-smooth: a vertex coordinate within rounding of a tie flips a sign; compare in aggregate
@@ -447,7 +490,7 @@ def test_v2v_fused_mesh_kernel(L, num_verts, N):
     assert rel_err(loss[0], l1.detach()) < 1e-5
     assert float(dVPt[NV3:].abs().sum()) == 0.0 and float(dVPt[:, N:].abs().sum()) == 0.0   # pads stay zero
     assert L.nemo_gemm_f32(1, 1, N, 207, NV3, dVPt.data_ptr(), ldn, ctx.posedirs, ctx.ldP, dPF.data_ptr(), 208,
-                           None, 0, None, 0, 0, 1.0, 2, 8, H.st()) == 0
+                           None, 0, None, 0, 0, 1.0, 2, 8, None, 0, H.st()) == 0
     assert L.nemo_fk_bwd(ctx.handle, N, dR2.data_ptr(), A.data_ptr(), dA.data_ptr(), None, dPF.data_ptr(), 208,
                          dRg.data_ptr(), H.st()) == 0
     # |.| is non-smooth: a coordinate within rounding of a tie flips a sign; compare in aggregate
