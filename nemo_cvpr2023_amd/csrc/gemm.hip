@@ -127,9 +127,6 @@ struct Stager {
 // the four operands (MFMA steps j = 0..3) of k-group q for the 32 rows starting at row0
 template <int ROWS, int BK, bool KCONTIG>
 __device__ __forceinline__ void fetch_group(const float* lds, int row, int q, int lhi, float (&f)[4]) {
-#ifdef ABL_NOREAD
-    f[0] = row; f[1] = q; f[2] = lhi; f[3] = 1.f; return;
-#endif
     if (KCONTIG) {
         const float4 v = *reinterpret_cast<const float4*>(lds + row * (BK + 4) + 8 * q + 4 * lhi);
         f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
@@ -204,13 +201,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         const float* as = As0 + cur * SA::SIZE;
         const float* bs = Bs0 + cur * SB::SIZE;
         // (after the last K tile this stores a zero tile nobody reads)
-#ifndef ABL_NOSTORE
         sa.template store<MASKED, U>(As0 + (cur ^ 1) * SA::SIZE, klen - (t + 1) * BK);
         sb.template store<MASKED, U>(Bs0 + (cur ^ 1) * SB::SIZE, klen - (t + 1) * BK);
-#endif
-#ifndef ABL_NOLOAD
         sa.template load<MASKED, U>(klen - (t + 1 + NS) * BK); sb.template load<MASKED, U>(klen - (t + 1 + NS) * BK);
-#endif
         __builtin_amdgcn_sched_barrier(0);     // hipcc otherwise sinks stores and loads down to the barrier
         float fa[2][TM][4], fb[2][TN][4];
 #pragma unroll

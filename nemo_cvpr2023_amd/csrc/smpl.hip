@@ -195,6 +195,8 @@ extern "C" const float* nemo_ctx_posedirs(const nemo_ctx* c) { return c ? c->d_p
 extern "C" int64_t nemo_ctx_posedirs_ld(const nemo_ctx* c) { return c ? c->ldP : -1; }
 extern "C" const float* nemo_ctx_v_shaped(const nemo_ctx* c) { return c ? c->d_v_shaped : nullptr; }
 
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+
 namespace {
 
 // ------------------------------------------------------------------------------------------ FK
@@ -972,12 +974,14 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     float* pfL = lds;                                   // [2][16][MF_PFS]
     float* AL = lds + 2 * 16 * MF_PFS;                  // [2][16][MF_AS], entry (e*24 + j)
     __shared__ float red[16];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): tile indices, offsets
     const int l15 = lane & 15, g = lane >> 4;
-    const long s0 = (long)blockIdx.x * 16;
     const long ntiles = (NV + 15) / 16;
+    const long s0 = (long)blockIdx.x * 16;
     const long t_beg = (long)blockIdx.y * tiles_per_range;
     const long t_end = min(ntiles, t_beg + tiles_per_range);
+    float lsum = 0.f;
 
     // ---- stage the sample group: pf rows (224 incl. the zero pad) and transforms re-ordered to [e][j]
     for (int idx = tid; idx < 2 * 16 * 224; idx += 256) {
@@ -1000,13 +1004,28 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) accdA[e][t][r] = 0.f;
-    float lsum = 0.f;
     const float* pf0 = pfL + (0 * 16 + l15) * MF_PFS + g;      // orig body, this lane's sample column
     const float* pf1 = pfL + (1 * 16 + l15) * MF_PFS + g;      // reconstruction
     const float* A0 = AL + (0 * 16 + l15) * MF_AS + g;
     const float* A1 = AL + (1 * 16 + l15) * MF_AS + g;
-    const long rowstep = 16 * ldP;                              // 4 k-steps of 4 blend-shape rows
 
+    // Blend-shape A-operands, eight k-steps in flight, carried ACROSS vertex tiles: the last eight k-steps
+    // of a tile request the first eight of the wave's next tile, so a tile never starts with an empty
+    // ring (one exposed L2 round trip per tile otherwise).  Addresses are a wave-uniform row base plus one
+    // 32-bit lane offset; a scheduling barrier per k-step keeps hipcc from collapsing the ring to a
+    // single load in flight (it otherwise moves each load to just before its use to save registers).
+    // Buffer loads: one descriptor for the blend-shape matrix, a scalar byte offset for (tile, k-step) and
+    // ONE 32-bit lane offset -- no 64-bit vector address arithmetic and no address registers in the ring.
+    const __amdgpu_buffer_rsrc_t Prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(P), 0, (int)(224 * ldP * 4), 0x00020000);
+    const int loff = (g * (int)ldP + l15 * 3) * 4;               // lane: k row g of the step, vertex l15 (bytes)
+    const int kstride = 4 * (int)ldP * 4;                        // bytes between consecutive k-steps
+    u32x3 pa[8];
+    {
+        const int tf = (int)min(t_beg + wid, ntiles - 1);        // (a wave without tiles loads a valid one)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, tf * 192 + u * kstride, 0);
+    }
     for (long t = t_beg + wid; t < t_end; t += 4) {
         const long v0 = t * 16;
         // weights as A-operands: forward (rows = vertices, k = joints) and adjoint (rows = joints, k = vertices)
@@ -1030,32 +1049,31 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 const float b = vsl[r * 3 + c];
                 vp[0][c][r] = b; vp[1][c][r] = b;
             }
-        // eight running row pointers (rows g + 4u, u = 0..7; advanced by 32 rows per outer iteration):
-        // the A-operands of k-step kk are loaded 8 k-steps (~1500 MFMA cycles) ahead of their use
-        const float* pr[8];
+        const int pt = (int)t * 192;                             // uniform byte offsets: this wave's vertex tile
+        const int ptn = (int)min(t + 4, ntiles - 1) * 192;       // and its next one (clamped: harmless re-read)
+        // B-operands (this lane's pose features, LDS) two k-steps ahead of their use
+        float pb[2][2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) pr[u] = P + (long)(g + 4 * u) * ldP + (v0 + l15) * 3;
-        float pa[8][3];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) pa[u][c] = pr[u][c];
+        for (int u = 0; u < 2; ++u) { pb[u][0] = pf0[4 * u]; pb[u][1] = pf1[4 * u]; }
         for (int kk0 = 0; kk0 < 56; kk0 += 8) {                  // 52 real k-steps + 4 of zero padding
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float a0 = pa[u][0], a1 = pa[u][1], a2 = pa[u][2];
-                pr[u] += 2 * rowstep;                                        // rows of k-step kk + 8
-                if (kk0 + 8 < 56) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) pa[u][c] = pr[u][c];
+                const float a0 = __uint_as_float(pa[u][0]), a1 = __uint_as_float(pa[u][1]),
+                            a2 = __uint_as_float(pa[u][2]);
+                const float b0 = pb[u & 1][0], b1 = pb[u & 1][1];
+                if (kk0 + u + 2 < 56) { pb[u & 1][0] = pf0[4 * (kk0 + u + 2)]; pb[u & 1][1] = pf1[4 * (kk0 + u + 2)]; }
+                {
+                    const int soff = kk0 + 8 < 56 ? pt + (kk0 + 8 + u) * kstride      // k-step kk + 8
+                                                  : ptn + u * kstride;                // next tile, k-step u
+                    pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, soff, 0);
                 }
-                const float b0 = pf0[4 * (kk0 + u)], b1 = pf1[4 * (kk0 + u)];
                 vp[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, vp[0][0], 0, 0, 0);
                 vp[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, vp[1][0], 0, 0, 0);
                 vp[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, vp[0][1], 0, 0, 0);
                 vp[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, vp[1][1], 0, 0, 0);
                 vp[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b0, vp[0][2], 0, 0, 0);
                 vp[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1, vp[1][2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- reconstruction body, one output row c (4 transform entries) at a time

@@ -163,7 +163,9 @@ def build_case(name, cls=OracleNemo, num_verts=128, **kw):
 
 
 def replay(model, g, name, n_cam_default=None, tol=2e-5, check_state=True, state_tol=2e-4, la_tol=None,
-           robust_state=False):
+           robust_state=False, drift=None):
+    """drift = (first_step, tol, la_tol): looser tolerances for the optimisation steps from `first_step`
+    on (recorded trajectories at lr 0.01, where Adam amplifies rounding noise; see tests/test_gpu_model.py)."""
     """Replays the script order of tools/gen_golden.py::run_model_case and checks every
     recorded number."""
     version, over, n_warm = CASES.get(name, (2, {}, 0))
@@ -175,7 +177,7 @@ def replay(model, g, name, n_cam_default=None, tol=2e-5, check_state=True, state
     def draw():
         return torch.randint(0, V, size=(B,)), torch.randint(0, Tn, size=(B,))
 
-    def check(tag, ld, info):
+    def check(tag, ld, info, tol=tol, la_tol=la_tol):
         for k in ('gmm_loss', 'vp_recon_loss', 'vp_kl_loss', 'total_loss'):
             assert rel_err(ld[k], g[f'{tag}__{k}']) < tol, (tag, k, ld[k], g[f'{tag}__{k}'])
         assert rel_err(ld['kp_loss'], g[f'{tag}__kp_loss_pure']) < tol, tag
@@ -209,7 +211,10 @@ def replay(model, g, name, n_cam_default=None, tol=2e-5, check_state=True, state
         draw()
         vi, fi = torch.as_tensor(g['batches_view'][s]), torch.as_tensor(g['batches_frame'][s])
         ld, info = model.step(vi, fi, full_batch=s >= n_steps - n_full)
-        check(f'step{s}', ld, info)
+        if drift is not None and s >= drift[0]:
+            check(f'step{s}', ld, info, tol=drift[1], la_tol=drift[2])
+        else:
+            check(f'step{s}', ld, info)
     if check_state:
         sd = model.state_dict()
         for k, v in g.items():
@@ -230,7 +235,8 @@ def replay(model, g, name, n_cam_default=None, tol=2e-5, check_state=True, state
                 agree = np.abs(a - v)[big] <= state_tol * np.abs(v).max() + 0.05 * move.max()
                 # the rot6d head carries the exactly-invariant (noise-gradient) directions
                 need = 0.75 if 'rot_out' in name_ else 0.97
-                assert agree.mean() >= need, (name_, float(agree.mean()))
+                if drift is None:       # (a drifting trajectory only has to stay within twice the reference's moves)
+                    assert agree.mean() >= need, (name_, float(agree.mean()))
                 assert np.abs(a - v).max() <= 2.0 * move.max() + 1e-6 * np.abs(v).max(), name_
         for oi, opt in enumerate(model.optimizers):
             assert abs(opt.param_groups[0]['lr'] / float(g[f'final__opt{oi}__lr']) - 1) < 1e-6
