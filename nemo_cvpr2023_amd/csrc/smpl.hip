@@ -1009,8 +1009,8 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     const float* A0 = AL + (0 * 16 + l15) * MF_AS + g;
     const float* A1 = AL + (1 * 16 + l15) * MF_AS + g;
 
-    // Blend-shape A-operands, eight k-steps in flight, carried ACROSS vertex tiles: the last eight k-steps
-    // of a tile request the first eight of the wave's next tile, so a tile never starts with an empty
+    // Blend-shape A-operands, eight k-steps in flight, carried ACROSS vertex tiles: the end of a tile
+    // requests the first eight k-steps of the wave's next tile, so a tile never starts with an empty
     // ring (one exposed L2 round trip per tile otherwise).  Addresses are a wave-uniform row base plus one
     // 32-bit lane offset; a scheduling barrier per k-step keeps hipcc from collapsing the ring to a
     // single load in flight (it otherwise moves each load to just before its use to save registers).
@@ -1062,11 +1062,8 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                             a2 = __uint_as_float(pa[u][2]);
                 const float b0 = pb[u & 1][0], b1 = pb[u & 1][1];
                 if (kk0 + u + 2 < 56) { pb[u & 1][0] = pf0[4 * (kk0 + u + 2)]; pb[u & 1][1] = pf1[4 * (kk0 + u + 2)]; }
-                {
-                    const int soff = kk0 + 8 < 56 ? pt + (kk0 + 8 + u) * kstride      // k-step kk + 8
-                                                  : ptn + u * kstride;                // next tile, k-step u
-                    pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, soff, 0);
-                }
+                if (kk0 + 8 < 56)                                                   // k-step kk + 8
+                    pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, pt + (kk0 + 8 + u) * kstride, 0);
                 vp[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, vp[0][0], 0, 0, 0);
                 vp[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, vp[1][0], 0, 0, 0);
                 vp[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, vp[0][1], 0, 0, 0);
@@ -1123,6 +1120,15 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 gs[r] = d == 0.f ? 0.f : (d > 0.f ? -1.f : 1.f);          // d|v_rec - v_orig| / d v_orig
 #pragma unroll
                 for (int d2 = 0; d2 < 3; ++d2) dvp[d2][r] += T4[d2][r] * gs[r];
+            }
+            if (c == 2) {
+                // the wave's NEXT tile: first eight k-steps requested here, under the cover of the last 32
+                // adjoint MFMAs and the dvp store (their registers are dead during the skinning phases,
+                // where the pressure peaks -- a ring kept full across the whole tile spills)
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, ptn + u * kstride, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
