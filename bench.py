@@ -32,6 +32,10 @@ if ROOT not in sys.path:
 
 V0, T0 = 8, 300
 FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+# HBM-side bytes per launch of the roofline kernel at the default workload, from the committed PMC passes
+# (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, FETCH_SIZE doubled as the guide's
+# gfx950 note prescribes): profiles/r01b_pmc_traffic.md.  bench.py cannot collect counters itself.
+PMC_TRAFFIC = {'mesh_v2v_fused': (int((268.6 + 295.7) * 2 ** 20), 'profiles/r01b_pmc_traffic.md (FETCH_SIZE x2 + WRITE_SIZE)')}
 
 
 def main():
@@ -119,7 +123,9 @@ def main():
         _, tag, mean_ms, flops, n = best
         achieved = flops / (mean_ms * 1e-3) / 1e12
         roof = {'kernel': tag, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                'traffic': PMC_TRAFFIC[tag][0] if (tag in PMC_TRAFFIC and (V, T, world) == (V0, T0, 1)) else None,
+                'traffic_source': PMC_TRAFFIC[tag][1] if (tag in PMC_TRAFFIC and (V, T, world) == (V0, T0, 1)) else None,
                 'launches': n, 'mean_launch_ms': round(mean_ms, 4), 'flops_per_launch': flops,
                 'timed_in': f'{n_inst} instrumented (un-captured) steps after the timed region',
                 'per_kernel_ms_per_step': {t: round(sum(a.elapsed_time(b) for a, b, _ in e) / n_inst, 4)
