@@ -59,11 +59,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != opts.gpus and world > 1:
         raise SystemExit(f'--gpus {opts.gpus} but WORLD_SIZE={world}')
-    device = f'cuda:{local_rank}'
+    device = f'cuda:{local_rank % max(torch.cuda.device_count(), 1)}'
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl')          # RCCL on ROCm
+        # RCCL on ROCm.  (NEMO_DIST_BACKEND=gloo: test aid for boxes where several ranks must share one GPU,
+        # which RCCL refuses.)
+        dist.init_process_group(os.environ.get('NEMO_DIST_BACKEND', 'nccl'))
 
     args = syn.published_args(batch_size=512, out_dir='')
     seqs = syn.SyntheticSequences(V, T, seed=1234)

@@ -363,6 +363,9 @@ hipError_t launch(int ta, int tb, const GemmArgs& g, int blocks, hipStream_t s) 
 }
 
 constexpr int BK = 32;
+#ifndef BK_SMALL_VEC
+#define BK_SMALL_VEC 32
+#endif
 constexpr long COUNTER_BYTES = 16384;       // 4096 tile tickets at the head of the workspace
 constexpr int N_CU = 256;
 
@@ -374,13 +377,14 @@ inline bool aligned16(const void* p, long ld) { return (((uintptr_t)p) & 15) == 
 struct Plan { int tile; int split; double cost; };
 
 Plan plan_gemm(long M, long N, long K, bool can_split, long ws_bytes, bool atomic_mode, int forced_split,
-               bool big_ok) {
-    const long kiters = (K + BK - 1) / BK;
+               bool big_ok, bool vec) {
     Plan best{64, 1, 1e30};
     for (int tile : {128, 64}) {
         if (tile == 128 && !big_ok) continue;
+        const int bk = (tile == 64 && vec) ? BK_SMALL_VEC : BK;
+        const long kiters = (K + bk - 1) / bk;
         const long tiles = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
-        const double us_iter = tile == 128 ? 2.35 : 0.67;          // one K tile of one block
+        const double us_iter = tile == 128 ? 2.35 : 0.67 * bk / 32;   // one K tile of one block
         const int smax = forced_split > 0 ? forced_split : (can_split || atomic_mode ? 32 : 1);
         for (int S = forced_split > 0 ? forced_split : 1; S <= smax; ++S) {
             if (S > 1 && forced_split <= 0 && kiters / S < 4) break;
@@ -427,7 +431,7 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     //  rows are not 16-byte aligned, e.g. nn.Linear weights with in_features 105 / 63)
     // (128x128 tiles pay off only with both operands k-contiguous: the k-major LDS image is fetched with
     //  four ds_read_b32 per operand group instead of one ds_read_b128 and runs at ~half the rate there)
-    Plan pl = plan_gemm(M, N, K, can_split, ws_bytes, out_mode == 2, split_k, vec && !transA && transB);
+    Plan pl = plan_gemm(M, N, K, can_split, ws_bytes, out_mode == 2, split_k, vec && !transA && transB, vec);
     if (vec && (force_tile == 64 || force_tile == 128)) {
         pl.tile = force_tile;
         if (split_k > 0) pl.split = split_k;
@@ -441,8 +445,9 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     g.counters = reinterpret_cast<int*>(ws);
     g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
     long kc = (K + pl.split - 1) / pl.split;
-    kc = ((kc + BK - 1) / BK) * BK;
-    if (kc == 0) kc = BK;
+    const int bk = (tile == 64 && vec) ? BK_SMALL_VEC : BK;
+    kc = ((kc + bk - 1) / bk) * bk;
+    if (kc == 0) kc = bk;
     g.k_chunk = kc;
     int nz = (int)((K + kc - 1) / kc);
     if (nz < 1) nz = 1;
@@ -458,7 +463,7 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (tile == 128) e = launch<128, 128, BK, true>(transA, transB, g, (int)blocks, s);
-    else e = vec ? launch<64, 64, BK, true>(transA, transB, g, (int)blocks, s)
+    else e = vec ? launch<64, 64, BK_SMALL_VEC, true>(transA, transB, g, (int)blocks, s)
                  : launch<64, 64, BK, false>(transA, transB, g, (int)blocks, s);
     if (e != hipSuccess) return (int32_t)e;
     NEMO_LAUNCH_CHECK();

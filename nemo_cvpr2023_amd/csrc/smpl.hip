@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const
 __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     long N, long NV, const float* __restrict__ PF2, long ldpf, const float* __restrict__ A2,
     const float* __restrict__ P, long ldP, const float* __restrict__ vs, const float* __restrict__ W,
-    int tiles_per_range, float* __restrict__ loss_sum, float* __restrict__ dVPt, long ldn,
+    int tiles_per_range, int vec_stage, float* __restrict__ loss_sum, float* __restrict__ dVPt, long ldn,
     float* __restrict__ dA) {
     // All constants are zero-padded by nemo_ctx_create (P: 224 rows x 3*NVp columns, W / v_shaped: NVp
     // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
@@ -983,17 +983,62 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     const long t_end = min(ntiles, t_beg + tiles_per_range);
     float lsum = 0.f;
 
-    // ---- stage the sample group: pf rows (224 incl. the zero pad) and transforms re-ordered to [e][j]
-    for (int idx = tid; idx < 2 * 16 * 224; idx += 256) {
-        const int set = idx / (16 * 224), n = (idx / 224) % 16, p = idx % 224;
-        const long s = s0 + n;
-        pfL[(set * 16 + n) * MF_PFS + p] = (s < N && p < 207) ? PF2[(set * N + s) * ldpf + p] : 0.f;
-    }
-    for (int idx = tid; idx < 2 * 16 * 288; idx += 256) {
-        const int set = idx / (16 * 288), n = (idx / 288) % 16, je = idx % 288;
-        const int j = je / 12, e = je % 12;
-        const long s = s0 + n;
-        AL[(set * 16 + n) * MF_AS + e * 24 + j] = (s < N) ? A2[(set * N + s) * 288 + je] : 0.f;
+    // ---- stage the sample group: pf rows (224 incl. the zero pad) and transforms re-ordered to [e][j].
+    // Vector path (16-byte aligned rows): a fixed number of independent, branch-free dwordx4 loads per
+    // thread, all in flight together -- a block that owns only a few vertex tiles (small N: many vertex
+    // ranges per sample group) would otherwise spend more time in a scalar staging loop than in MFMAs.
+    if (vec_stage) {
+        float4 vpf[7], va[9];
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {                            // 2 x 16 x 52 float4 of pose features
+            const int idx = min(tid + 256 * it, 2 * 16 * 52 - 1);
+            const int set = idx / 832, n = (idx / 52) % 16, q = idx % 52;
+            const long sc = min(s0 + n, N - 1);
+            vpf[it] = *reinterpret_cast<const float4*>(PF2 + (set * N + sc) * ldpf + 4 * q);
+        }
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {                            // 2 x 16 x 72 float4 of transforms
+            const int idx = tid + 256 * it;
+            const int set = idx / 1152, n = (idx / 72) % 16, q = idx % 72;
+            const long sc = min(s0 + n, N - 1);
+            va[it] = *reinterpret_cast<const float4*>(A2 + (set * N + sc) * 288 + 4 * q);
+        }
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const int idx = min(tid + 256 * it, 2 * 16 * 52 - 1);
+            const int set = idx / 832, n = (idx / 52) % 16, q = idx % 52;
+            const bool live = s0 + n < N;
+            float4 v = vpf[it];
+            if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q == 51) v.w = 0.f;                                 // column 207 is padding
+            float* d = pfL + (set * 16 + n) * MF_PFS + 4 * q;       // 8-byte aligned (MF_PFS even)
+            *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+        }
+        for (int idx = tid; idx < 2 * 16 * 16; idx += 256)          // rows 208..223 of the k padding
+            pfL[(idx / 16) * MF_PFS + 208 + idx % 16] = 0.f;
+#pragma unroll
+        for (int it = 0; it < 9; ++it) {
+            const int idx = tid + 256 * it;
+            const int set = idx / 1152, n = (idx / 72) % 16, q = idx % 72;
+            const int j = q / 3, e = 4 * (q % 3);                   // a float4 never straddles a joint
+            const bool live = s0 + n < N;
+            float* d = AL + (set * 16 + n) * MF_AS + e * 24 + j;
+            d[0] = live ? va[it].x : 0.f; d[24] = live ? va[it].y : 0.f;
+            d[48] = live ? va[it].z : 0.f; d[72] = live ? va[it].w : 0.f;
+        }
+    } else {
+        for (int idx = tid; idx < 2 * 16 * 224; idx += 256) {
+            const int set = idx / (16 * 224), n = (idx / 224) % 16, p = idx % 224;
+            const long s = s0 + n;
+            pfL[(set * 16 + n) * MF_PFS + p] = (s < N && p < 207) ? PF2[(set * N + s) * ldpf + p] : 0.f;
+        }
+        for (int idx = tid; idx < 2 * 16 * 288; idx += 256) {
+            const int set = idx / (16 * 288), n = (idx / 288) % 16, je = idx % 288;
+            const int j = je / 12, e = je % 12;
+            const long s = s0 + n;
+            AL[(set * 16 + n) * MF_AS + e * 24 + j] = (s < N) ? A2[(set * N + s) * 288 + je] : 0.f;
+        }
     }
     __syncthreads();
 
@@ -1356,6 +1401,7 @@ extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* P
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set = true;
     }
+    const int vec_stage = (ldpf % 4 == 0) && (((uintptr_t)PF2 | (uintptr_t)A2) & 15) == 0 && ldpf >= 208;
     const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
     // at most 256 CUs x 2 resident blocks: the whole grid must be co-resident (a second, partially
     // filled wave of blocks costs up to 2x), and as close to that as the vertex ranges allow
@@ -1366,7 +1412,7 @@ extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* P
     nr = (ntiles + tpr - 1) / tpr;
     hipLaunchKernelGGL(mesh_v2v_fused_kernel, dim3((unsigned)groups, (unsigned)nr), dim3(256), lds_bytes,
                        (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, ctx->d_posedirs, ctx->ldP,
-                       ctx->d_v_shaped, ctx->d_W, tpr, loss_sum, dVPt, (long)ldn, dA);
+                       ctx->d_v_shaped, ctx->d_W, tpr, vec_stage, loss_sum, dVPt, (long)ldn, dA);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -162,11 +162,15 @@ class ParamLayout:
             reg('phase', f'phase_networks.{i}.scales', (K,))
         if C > 0:
             reg('instance', 'learned_instance_code', (V, C))
+        # every tensor starts on a 16-byte boundary (pads stay zero: zero gradient, zero Adam update), so
+        # the weight matrices qualify for the GEMM's dwordx4 staging whatever V is (9 camera floats per
+        # view would otherwise misalign every layer of a one-view shard)
         off = 0
         for name in order:
+            off = (off + 3) // 4 * 4
             self.entries[name] = (off, shapes[name])
             off += int(np.prod(shapes[name]))
-        self.total = off
+        self.total = (off + 3) // 4 * 4
 
     def span(self, names):
         a = min(self.entries[n][0] for n in names)

@@ -145,8 +145,9 @@ class FusedAdam(torch.optim.Optimizer):
                             wd=float(g['weight_decay']), adamw=self.adamw, step=self.steps[n]))
         segs = []
         for s in sorted(raw, key=lambda d: d['offset']):       # memory order: adjacent tensors merge
-            if segs and segs[-1]['offset'] + segs[-1]['numel'] == s['offset'] and segs[-1]['step'] == s['step']:
-                segs[-1]['numel'] += s['numel']
+            gap = s['offset'] - (segs[-1]['offset'] + segs[-1]['numel']) if segs else -1
+            if 0 <= gap < 4 and segs[-1]['step'] == s['step']:      # (gap: the layout's 16-byte alignment pad)
+                segs[-1]['numel'] += gap + s['numel']
             else:
                 segs.append(s)
         return segs

@@ -51,20 +51,24 @@ def test_param_layout_matches_reference_optimizer_order():
         'learned_motion.linear_out.weight', 'learned_motion.linear_out.bias', 'phase_rbf.log_sigmas']
     assert lay.groups['phase'][:4] == ['phase_networks.0.shifts', 'phase_networks.0.scales',
                                        'phase_networks.1.shifts', 'phase_networks.1.scales']
-    # contiguous, non-overlapping in MEMORY order (entries); the two MLP heads sit next to each other
+    # non-overlapping in MEMORY order (entries), every tensor on a 16-byte boundary with < 4 floats of
+    # padding in front; the two MLP heads sit next to each other
     end = 0
     for name, (off, shape) in lay.entries.items():
-        assert off == end, name
+        assert off % 4 == 0 and 0 <= off - end < 4, name
         end = off + int(np.prod(shape))
-    assert end == lay.total
+    assert 0 <= lay.total - end < 4
     e = lay.entries
     assert e['learned_motion.linear_out.weight'][0] == e['learned_motion.rot_out.weight'][0] + 144 * 48
     assert e['learned_motion.linear_out.bias'][0] == e['learned_motion.rot_out.bias'][0] + 144
     assert e['learned_motion.rot_out.bias'][0] == e['learned_motion.linear_out.weight'][0] + 3 * 48
     a, b = lay.span(lay.groups['motion'])
-    assert b - a == 48 * 21 + 48 + 2 * (48 * 48 + 48) + 144 * 48 + 144 + 3 * 48 + 3 + 16
+    assert b - a == 48 * 21 + 48 + 2 * (48 * 48 + 48) + 144 * 48 + 144 + 3 * 48 + (3 + 1) + 16   # 1 float of pad
     a2, b2 = lay.span(lay.groups['motion'] + lay.groups['comm'])
     assert (a2, b2) == (a, b + 8)          # one contiguous all-reduce slice
+    # the 16-byte alignment must hold for a one-view shard too (9 camera floats in front of the MLP)
+    lay1 = ParamLayout(V=1, K=20, D=16, C=5, h=48, din=21)
+    assert all(off % 4 == 0 for off, _ in lay1.entries.values())
 
 
 def test_product_never_imports_oracle():
