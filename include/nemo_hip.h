@@ -223,7 +223,8 @@ int32_t nemo_v2v_prep_bwd(int64_t N, const float* aa, const float* dR2, float sc
 int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int64_t ld, float* scalar_out,
                         float* d_mulv, int64_t ldd, void* stream);
 /* MaxMixturePrior (hmr/smplify/prior.py:181-196): per-sample min over M Gaussians, mean over N.
- * x (N, ldx) uses `dim` columns.  means (M,dim), precisions (M,dim,dim), log_nllw (M) = log(nll_weights).
+ * x (N, ldx) uses `dim` columns.  means (M,dim), precisions (M,dim,dim) SYMMETRIC (inverses of covariance
+ * matrices; symmetrise (P+P^T)/2 on the host if in doubt), log_nllw (M) = log(nll_weights).
  * ws: scratch of N*M floats (per-component log-likelihoods).
  * scalar_out += mean;  per_sample (N) optional;  d_x (N, lddx) += scale * d mean / d x. */
 int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const float* x, int64_t ldx,

@@ -126,8 +126,10 @@ __global__ __launch_bounds__(GMM_TS) void gmm_grad_kernel(long N, int M, const f
 
 
 // MaxMixturePrior on the matrix cores (M <= 8 components).  Block = 16 samples x all components,
-// wave w owns components w and w + 4.  y = Psym d with Psym = (P + P^T)/2 (the quadratic form is the
-// same, and Psym d is exactly its gradient) as v_mfma_f32_16x16x4_f32 tiles: rows = 16 of the 69 outputs
+// wave w owns components w and w + 4.  y = P^T d (the quadratic form d^T y is that of P; y is its exact
+// gradient for a symmetric P -- precisions are inverses of covariance matrices, and the engine
+// symmetrises them on the host; reading P row-wise only keeps every operand load coalesced, the
+// transposed read cost 25 us) as v_mfma_f32_16x16x4_f32 tiles: rows = 16 of the 69 outputs
 // (5 tiles), columns = the 16 samples, K = 69 -> 18 steps; operands straight from L2 (the 8 precision
 // matrices are 152 KB).  In the accumulator layout a lane holds y_i of ONE sample for 20 i's, so
 // d^T y is 20 lane-local FMAs + two cross-lane adds, the arg-min over components goes through 512 B of
@@ -178,19 +180,31 @@ __global__ __launch_bounds__(256) void gmm_mfma_kernel(long N, int M, const floa
         for (int ti = 0; ti < 5; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[c][ti][r] = 0.f;
+        // all 90 A-operands of the component first (180 independent L2 loads in flight: one latency), then
+        // the 90 MFMAs back to back
+        float a[18][5];
+#pragma unroll
         for (int kk = 0; kk < 18; ++kk) {
             const int k = 4 * kk + g;
             const bool kok = k < DIM;
             const int kc = kok ? k : 0;
-            const float b = kok ? xk[kk] - mu[kc] : 0.f;
 #pragma unroll
             for (int ti = 0; ti < 5; ++ti) {
                 const int i = 16 * ti + l15;
-                const bool ok = kok && i < DIM;
                 const int ic = i < DIM ? i : 0;
-                const float a = ok ? 0.5f * (P[ic * DIM + kc] + P[kc * DIM + ic]) : 0.f;
-                acc[c][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c][ti], 0, 0, 0);
+                const float v = P[kc * DIM + ic];       // row k, 16 consecutive columns per lane group: coalesced
+                a[kk][ti] = (kok && i < DIM) ? v : 0.f;
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);       // (hipcc otherwise re-sinks every load to its MFMA)
+#pragma unroll
+        for (int kk = 0; kk < 18; ++kk) {
+            const int k = 4 * kk + g;
+            const bool kok = k < DIM;
+            const float b = kok ? xk[kk] - mu[kok ? k : 0] : 0.f;
+#pragma unroll
+            for (int ti = 0; ti < 5; ++ti)
+                acc[c][ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][ti], b, acc[c][ti], 0, 0, 0);
         }
         float q = 0.f;
 #pragma unroll

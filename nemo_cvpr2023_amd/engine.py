@@ -119,6 +119,7 @@ def gmm_constants(gmm: dict, device):
     means = gmm['means'].astype(np.float32)
     covs = gmm['covars'].astype(np.float32)
     prec = np.stack([np.linalg.inv(c) for c in covs]).astype(np.float32)
+    prec = 0.5 * (prec + prec.transpose(0, 2, 1))      # exact symmetry (nemo_gmm_fwd_bwd's contract)
     sqrdets = np.array([np.sqrt(np.linalg.det(c)) for c in gmm['covars']])
     const = (2 * np.pi) ** (69 / 2.0)
     nllw = np.asarray(gmm['weights'] / (const * (sqrdets / sqrdets.min()))).astype(np.float32)
