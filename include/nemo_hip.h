@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 2
+#define NEMO_ABI_VERSION 3
 int32_t nemo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -203,9 +203,14 @@ int32_t nemo_v2v_skin_l1(const nemo_ctx* ctx, int64_t N, const float* VP, int64_
  * column 207 (if ldpf > 207) ZERO, A2 (2N,24,12).  loss_sum += sum|v_rec - v_orig|;
  * dVPt (3*NVp rows, NVp = NV rounded up to 16; ldn >= N rounded up to 16) = TRANSPOSED
  * d(sum)/dVP_orig (operand of the blend-shape adjoint GEMM with transA=1; pad rows/columns are
- * written with zeros); dA (N,24,12) += d(sum)/dA_orig (atomic accumulate: caller zeroes it). */
+ * written with zeros); dA (N,24,12) = d(sum)/dA_orig (OVERWRITTEN; summed over the vertex ranges in
+ * a fixed order, deterministic).  ws: caller-owned scratch of nemo_v2v_fused_ws_bytes(ctx, N) bytes,
+ * 16-byte aligned, zero-filled once at allocation (arrival tickets the kernel returns to zero), not
+ * shared by concurrent launches. */
+int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N);
 int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
-                       float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* stream);
+                       float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* ws, int64_t ws_bytes,
+                       void* stream);
 /* Builds the (2N,24,9) rotation set of the two bodies from the MLP pose:
  * rows<N: [R[:,0], Rodrigues(aa[:,3:72])], rows>=N: [R[:,0], Rodrigues(cat(aa_dec, aa[:,66:72]))]
  * (:2783-2791, hmr/geometry.py:9-45). */

@@ -63,7 +63,8 @@ SIGNATURES = {
     'nemo_project': (i32, [i64, i64, i64, ptr, ptr, ptr, f32, f32, f32, ptr, ptr]),
     'nemo_skin_vertices': (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, ptr]),
     'nemo_v2v_skin_l1': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr]),
-    'nemo_v2v_fused': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr]),
+    'nemo_v2v_fused_ws_bytes': (i64, [ptr, i64]),
+    'nemo_v2v_fused': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_prep_fwd': (i32, [i64, ptr, ptr, ptr, ptr, ptr]),
     'nemo_v2v_prep_bwd': (i32, [i64, ptr, ptr, f32, ptr, ptr, ptr]),
     'nemo_kl_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, i64, ptr]),
@@ -97,8 +98,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.nemo_abi_version()
-    if ver != 2:
-        raise NemoHipError(f'libnemo_hip.so ABI version {ver} != 2 (stale build?)')
+    if ver != 3:
+        raise NemoHipError(f'libnemo_hip.so ABI version {ver} != 3 (stale build?)')
     _lib = lib
     return lib
 

@@ -225,6 +225,7 @@ class FitEngine:
         self.side_stream = torch.cuda.Stream(device=self.device)   # prior branch of the step (see _forward_backward)
         # split-K scratch of nemo_gemm_f32 (arrival tickets + partial tiles), one per stream that launches GEMMs
         self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(2)]
+        self._mesh_ws = None
         self._colsums = []
         self._seg_host = self._seg_dev = None
         self.timers = None
@@ -402,6 +403,13 @@ class FitEngine:
         check(L.nemo_kl_fwd_bwd(N, 32, dptr(w['MULV']), 64, self.scal.data_ptr() + 4 * S_KL,
                                 dptr(w['dMULV']), 64, st), 'nemo_kl_fwd_bwd')
 
+    def mesh_ws(self, n):
+        """Scratch of nemo_v2v_fused (arrival tickets + per-vertex-range partial dA), zeroed at allocation."""
+        need = int(self.lib.nemo_v2v_fused_ws_bytes(self.ctx.handle, n))
+        if self._mesh_ws is None or self._mesh_ws.numel() * 4 < need:
+            self._mesh_ws = torch.zeros((need + 3) // 4, dtype=torch.float32, device=self.device)
+        return self._mesh_ws
+
     def forward_v2v(self, w, N, need_grad):
         """K10 + K11: the two full-mesh bodies, L1 sum and (same pass) its gradient wrt the pose.
         One fused MFMA kernel per chunk (pose blend + skinning + L1 + gradient, nothing of the
@@ -417,12 +425,11 @@ class FitEngine:
             check(L.nemo_v2v_prep_fwd(n, R, AA, AAd, dptr(w['R2']), st), 'nemo_v2v_prep_fwd')
             check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']),
                                 dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
-            if c0 > 0:
-                w['dA2'].zero_()
             ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * (2 * 3 * 207 + 2 * 288 + 288))
+            ws = self.mesh_ws(n)
             check(L.nemo_v2v_fused(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
                                    self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPt']), ldn, dptr(w['dA2']),
-                                   st), 'nemo_v2v_fused')
+                                   ws.data_ptr(), ws.numel() * 4, st), 'nemo_v2v_fused')
             self._event_end(ev)
             if need_grad:
                 if c0 > 0:

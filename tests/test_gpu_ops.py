@@ -485,8 +485,12 @@ def test_v2v_fused_mesh_kernel(L, num_verts, N):
                          H.st()) == 0
     ldn = (N + 15) // 16 * 16
     loss, dVPt, dA, dPF, dRg = Z(1), Z(3 * ctx.NVp, ldn), Z(N, 24, 12), Z(N, 208), Z(N, 24, 9)
-    assert L.nemo_v2v_fused(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss.data_ptr(), dVPt.data_ptr(),
-                            ldn, dA.data_ptr(), H.st()) == 0
+    ws = torch.zeros(int(L.nemo_v2v_fused_ws_bytes(ctx.handle, N)) // 4 + 1, device='cuda')
+    dA.fill_(7.0)                                       # dA is overwritten, not accumulated
+    for _ in range(2):                                  # second launch: tickets were returned to zero
+        loss.zero_()
+        assert L.nemo_v2v_fused(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss.data_ptr(), dVPt.data_ptr(),
+                                ldn, dA.data_ptr(), ws.data_ptr(), ws.numel() * 4, H.st()) == 0
     assert rel_err(loss[0], l1.detach()) < 1e-5
     assert float(dVPt[NV3:].abs().sum()) == 0.0 and float(dVPt[:, N:].abs().sum()) == 0.0   # pads stay zero
     assert L.nemo_gemm_f32(1, 1, N, 207, NV3, dVPt.data_ptr(), ldn, ctx.posedirs, ctx.ldP, dPF.data_ptr(), 208,
