@@ -111,7 +111,7 @@ class SyntheticSequences:
     """
 
     def __init__(self, num_views: int, num_frames: int, seed: int = 1234,
-                 img_d0: int = 1080, img_d1: int = 1920, empty_frac: float = 0.02):
+                 img_d0: int = 1080, img_d1: int = 1920, empty_frac: float = 0.02, with_eval: bool = False):
         rng = np.random.default_rng(seed)
         self.num_views = num_views
         self.num_frames = num_frames
@@ -133,6 +133,31 @@ class SyntheticSequences:
             pose[:, 72] = (rng.uniform(size=num_frames) > 0.1).astype(np.float32)
             seq['pose'] = [pose[t] for t in range(num_frames)]
             self.sequences.append(seq)
+        if with_eval:
+            self._add_eval_fields(seed)
+
+    def _add_eval_fields(self, seed):
+        """Ground-truth style fields the evaluation reads (nemo/neural_motion_model.py:522-710, :1056-1282):
+        ``pose_3d_gt`` (T x (72,) axis-angle), ``trans_3d_gt`` (T x (3,)), ``vibe_joints2d`` (T x (25,3)) and
+        ``framerate_multiplier`` (per view).  Drawn from a SEPARATE generator so the fit inputs above (and
+        every golden recorded from them) are unchanged.  The 3-D ground truth is a smooth motion that
+        stands still for the first and last eighth of the clip (a non-trivial 'dynamic range')."""
+        import torch
+        rng = np.random.default_rng(seed + 100003)
+        T = self.num_frames
+        self.framerate_multiplier = [1.0 + (v % 2) for v in range(self.num_views)]
+        for seq in self.sequences:
+            key = 0.35 * rng.standard_normal((4, 72)).astype(np.float32)
+            u = np.clip((np.arange(T) - T / 8.0) / max(T * 0.75, 1.0), 0.0, 1.0)[:, None]      # 0 .. 1, flat ends
+            pose = (key[0] + np.sin(np.pi * u) * key[1] + u * key[2] + np.sin(3 * np.pi * u) * 0.5 * key[3])
+            seq['pose_3d_gt'] = [torch.tensor(pose[t].astype(np.float32)) for t in range(T)]
+            trans = (0.3 * rng.standard_normal(3) + u * rng.standard_normal(3)).astype(np.float32)
+            seq['trans_3d_gt'] = [torch.tensor(trans[t]) for t in range(T)]
+            kp = np.empty((T, 25, 3), dtype=np.float32)
+            kp[..., 0] = rng.uniform(0, self.IMG_D1, (T, 25))
+            kp[..., 1] = rng.uniform(0, self.IMG_D0, (T, 25))
+            kp[..., 2] = rng.uniform(0, 1, (T, 25))
+            seq['vibe_joints2d'] = [kp[t] for t in range(T)]
 
     def get_image(self, v, t):  # rendering only; never used by the fit
         raise NotImplementedError('synthetic sequences carry no images')

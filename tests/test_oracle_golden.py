@@ -272,3 +272,58 @@ def test_full_mesh_6890_step():
     # of magnitude ~eps amplify summation-order noise, so post-update weights are compared
     # loosely; the loss trajectory (the parity gate) is compared at 2e-5.
     replay(model, g, 'v2_6890', state_tol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------ next rows (8f)
+def _build_eval_case():
+    g = load_golden('eval_eval_v2')
+    V, T = int(g['meta__V']), int(g['meta__T'])
+    args = syn.published_args(h_dim=48, monotonic_network_n_nodes=20, batch_size=8, out_dir='', phase_rbf_dim=16)
+    args.model_version = 2
+    seqs = syn.SyntheticSequences(V, T, seed=1234, with_eval=True)
+    state = {k[len('init__'):].replace('__', '.'): torch.tensor(v) for k, v in g.items() if k.startswith('init__')}
+    return g, args, seqs, state
+
+
+def test_eval_metrics_match_reference_csvs():
+    """oracle/evalmetrics.py == the eval_2d.csv / eval_3d.csv / eval_3d_dynamic.csv the real reference wrote."""
+    from oracle import evalmetrics as em
+    g, args, seqs, state = _build_eval_case()
+    o = OracleNemo(2, args, seqs, syn.make_smpl_assets(128, seed=1), syn.make_vposer_state(), syn.make_gmm(),
+                   state=state)
+    got = em.eval_2d(o, seqs)
+    for k, v in got.items():
+        assert rel_err(np.asarray(v), g['eval_2d__' + k]) < 1e-4, k
+    got = em.eval_3d(o, seqs)
+    for k, v in got.items():
+        assert rel_err(np.asarray(v), g['eval_3d__' + k]) < 1e-4, k
+    got = em.eval_3d(o, seqs, dynamic_only=True)
+    for k, v in got.items():
+        assert rel_err(np.asarray(v), g['eval_3d_dynamic__' + k]) < 1e-4, k
+    assert not np.allclose(g['eval_3d_dynamic__mpjpe-ours'], g['eval_3d__mpjpe-ours'])     # the mask is non-trivial
+
+
+def test_fit_driver_reproduces_script_order():
+    """nemo_cvpr2023_amd/fit.py::run_fit (duck-typed over the CPU oracle) == the loss curve the real
+    reference produces when driven in the order of scripts/learned_multi_view_recon_nn.py:211-308."""
+    from nemo_cvpr2023_amd.fit import run_fit
+    g = load_golden('script_script_v2')
+    V, T, B = int(g['meta__V']), int(g['meta__T']), int(g['meta__B'])
+    args = syn.published_args(h_dim=48, monotonic_network_n_nodes=20, batch_size=B, out_dir='', phase_rbf_dim=16,
+                              n_steps=len(g['total_loss']), warmup_step=int(g['meta__n_warm']),
+                              opt_cam_step=int(g['meta__n_cam']))
+    args.model_version = 2
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    state = {k[len('init__'):].replace('__', '.'): torch.tensor(v) for k, v in g.items() if k.startswith('init__')}
+    o = OracleNemo(2, args, seqs, syn.make_smpl_assets(128, seed=1), syn.make_vposer_state(), syn.make_gmm(),
+                   state=state)
+    o.num_views, o.num_frames = V, T
+    torch.manual_seed(2)
+    res = run_fit(o, args)
+    assert rel_err(np.float32(res['init']['total_loss']), g['init_total_loss']) < 2e-5
+    assert rel_err(np.asarray(res['warmup_losses']), g['warmup_losses']) < 1e-4
+    assert rel_err(np.asarray(res['cam_losses']), g['cam_losses']) < 1e-4
+    assert rel_err(np.asarray(res['losses']['total_loss']), g['total_loss']) < 1e-4
+    assert rel_err(np.asarray([float(x['total_loss']) for x in res['evals'].values()]), g['eval_total_loss']) < 1e-4
+    lrs = np.stack([res['learning_rates'][k] for k in ('lr_cam', 'lr_pose', 'lr_orient', 'lr_trans')][:g['lrs'].shape[1]], 1)
+    assert np.allclose(lrs, g['lrs'][:, :lrs.shape[1]])

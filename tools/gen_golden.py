@@ -420,9 +420,90 @@ def run_model_case(nmm, name, version, args_over, V, T, B, n_steps, n_warm, n_ca
     return model
 
 
+def run_script_order_case(nmm, name='script_v2', V=4, T=7, B=8, n_steps=6, n_warm=3, n_cam=3, seed=0):
+    """The phase / RNG order of scripts/learned_multi_view_recon_nn.py:211-308 itself (run_model_case
+    inserts a get_preds draw instead of the step-0 eval draw): eval at init, warmup, opt_cam, then per
+    step [save + eval draw + eval step at step 0 and every 500th] + training draw + step.  Pins
+    nemo_cvpr2023_amd/fit.py."""
+    over = dict(h_dim=48, monotonic_network_n_nodes=20, batch_size=B, out_dir='out_' + name, phase_rbf_dim=16)
+    args = syn.published_args(**over)
+    args.model_version = 2
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    torch.manual_seed(seed)
+    model = nmm.NemoV2(args, seqs, 'cpu')
+    pure = []
+    install_pure_kp_capture(model, pure)
+    rec = {}
+    for k, v in model_state(model).items():
+        rec['init__' + k.replace('.', '__')] = v
+    torch.manual_seed(2)
+
+    def draw():
+        return torch.randint(0, V, size=(B,)), torch.randint(0, T, size=(B,))
+
+    vi, fi = draw()
+    ld, _ = model.step(vi, fi, update=False, full_batch=False)
+    rec['init_total_loss'] = np.float32(ld['total_loss'])
+    rec['warmup_losses'] = np.asarray(model.warmup(n_warm), dtype=np.float32)
+    rec['cam_losses'] = np.asarray([float(x) for x in model.opt_cam(n_cam)], dtype=np.float32)
+    totals, kps, lrs, evals = [], [], [], []
+    for s in range(n_steps):
+        if s == 0 or (s + 1) % 500 == 0:
+            vi, fi = draw()
+            ld, _ = model.step(vi, fi, update=False, full_batch=False)
+            evals.append(np.float32(ld['total_loss']))
+        vi, fi = draw()
+        ld, _ = model.step(vi, fi)
+        totals.append(np.float32(ld['total_loss']))
+        kps.append(pure[-1])
+        lrs.append([o.param_groups[0]['lr'] for o in model.optimizers])
+    rec['total_loss'], rec['kp_loss_pure'] = np.asarray(totals), np.asarray(kps, dtype=np.float32)
+    rec['lrs'], rec['eval_total_loss'] = np.asarray(lrs, dtype=np.float64), np.asarray(evals)
+    rec['meta__V'], rec['meta__T'], rec['meta__B'] = V, T, B
+    rec['meta__n_warm'], rec['meta__n_cam'] = n_warm, n_cam
+    save('script_' + name, **rec)
+
+
+def run_eval_case(nmm, scratch, name='eval_v2', V=3, T=12, seed=0):
+    """eval_2d / eval_3d / eval_3d(dynamic_only) of the reference class itself
+    (nemo/neural_motion_model.py:522-710, :1056-1282) on the seeded init state.  The shipped eval_3d also
+    indexes 'vs_pose' / 'pare_pose' / 'glamr_pose', which the shipped loader no longer fills:
+    they are supplied here only so that the reference code runs; those columns are not recorded."""
+    import pandas as pd
+    over = dict(h_dim=48, monotonic_network_n_nodes=20, batch_size=8, out_dir='out_' + name, phase_rbf_dim=16)
+    args = syn.published_args(**over)
+    args.model_version = 2
+    seqs = syn.SyntheticSequences(V, T, seed=1234, with_eval=True)
+    rng = np.random.default_rng(7)
+    for s in seqs.sequences:
+        for key in ('vs_pose', 'pare_pose'):
+            s[key] = [np.concatenate([0.2 * rng.standard_normal(72), [1.0]]).astype(np.float32) for _ in range(T)]
+        s['glamr_pose'] = [np.concatenate([0.2 * rng.standard_normal(69), [1.0]]).astype(np.float32) for _ in range(T)]
+    torch.manual_seed(seed)
+    model = nmm.NemoV2(args, seqs, 'cpu')
+    rec = {}
+    for k, v in model_state(model).items():
+        rec['init__' + k.replace('.', '__')] = v
+    # a few optimisation steps would only move the numbers; the init state is enough to pin the formulas
+    out = os.path.join(scratch, 'eval_out')
+    model.eval_2d(out)
+    model.eval_3d(out)
+    model.eval_3d(out, dynamic_only=True)
+    for fn, cols in (('eval_2d.csv', ('recon_error_2d-ours', 'pck-ours', 'recon_error_2d-op', 'pck-op',
+                                      'recon_error_2d-vibe', 'pck-vibe')),
+                     ('eval_3d.csv', ('mpjpe-ours', 'mpvpe-ours', 'mpjpe-vibe', 'mpvpe-vibe')),
+                     ('eval_3d_dynamic.csv', ('mpjpe-ours', 'mpvpe-ours', 'mpjpe-vibe', 'mpvpe-vibe'))):
+        df = pd.read_csv(os.path.join(out, fn))
+        for c in cols:
+            rec[fn.replace('.csv', '') + '__' + c] = df[c].to_numpy(dtype=np.float64)
+    rec['meta__V'], rec['meta__T'] = V, T
+    save('eval_' + name, **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-6890', action='store_true')
+    ap.add_argument('--only', default='', help='comma list of: script, eval (skip everything else)')
     opts = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     scratch = tempfile.mkdtemp(prefix='nemo_golden_')
@@ -436,6 +517,13 @@ def main():
 
     assets_small = syn.make_smpl_assets(128, seed=1)
     install_synthetic_models(nmm, assets_small)
+    only = [x for x in opts.only.split(',') if x]
+    if not only or 'script' in only:
+        run_script_order_case(nmm)
+    if not only or 'eval' in only:
+        run_eval_case(nmm, scratch)
+    if only:
+        return
     gen_function_goldens(nmm, assets_small)
 
     # NemoV2, published-run structure (all loss terms on), tiny sizes
