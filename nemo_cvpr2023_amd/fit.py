@@ -106,6 +106,10 @@ def main(argv=None):
     from .neural_motion_model import NEMO_VERSIONS
     ap = argparse.ArgumentParser(description=__doc__.split('\n\n')[0])
     ap.add_argument('--synthetic', default='8x300', help='VxT synthetic Baseball-Pitch-shaped sequences')
+    ap.add_argument('--nemo-cfg', default='', help='nemo/config/*.yml of a NeMo-MoCap action: fit the real data '
+                    '(needs the SMPL / VPoser / GMM files under software/, see assets.py)')
+    ap.add_argument('--mocap-root', default='data/mocap')
+    ap.add_argument('--n-frames', type=int, default=1000000)
     ap.add_argument('--model-version', type=int, default=2)
     ap.add_argument('--n-steps', type=int, default=2000)
     ap.add_argument('--warmup-step', type=int, default=300)
@@ -121,11 +125,18 @@ def main(argv=None):
     args = base(batch_size=o.batch_size, out_dir=o.out_dir, n_steps=o.n_steps, warmup_step=o.warmup_step,
                 opt_cam_step=o.opt_cam_step)
     args.model_version = o.model_version
-    seqs = syn.SyntheticSequences(V, T, seed=1234, with_eval=True)
     torch.manual_seed(o.seed)
-    model = NEMO_VERSIONS[o.model_version](
-        args, seqs, 'cuda:0', smpl_assets=syn.make_smpl_assets(o.num_verts, seed=1),
-        vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
+    if o.nemo_cfg:
+        import yaml
+        from .multi_view_sequence import load_nemo_mocap
+        with open(o.nemo_cfg) as f:
+            seqs = load_nemo_mocap(yaml.safe_load(f), 0, o.n_frames, mocap_root=o.mocap_root)
+        model = NEMO_VERSIONS[o.model_version](args, seqs, 'cuda:0')       # model files from software/
+    else:
+        seqs = syn.SyntheticSequences(V, T, seed=1234, with_eval=True)
+        model = NEMO_VERSIONS[o.model_version](
+            args, seqs, 'cuda:0', smpl_assets=syn.make_smpl_assets(o.num_verts, seed=1),
+            vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
     evaluate = None
     if not o.no_eval:
         from .evaluation import evaluate_all

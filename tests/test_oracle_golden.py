@@ -1,4 +1,6 @@
 """Pins the oracle (oracle/) against golden vectors recorded from the real reference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -327,3 +329,28 @@ def test_fit_driver_reproduces_script_order():
     assert rel_err(np.asarray([float(x['total_loss']) for x in res['evals'].values()]), g['eval_total_loss']) < 1e-4
     lrs = np.stack([res['learning_rates'][k] for k in ('lr_cam', 'lr_pose', 'lr_orient', 'lr_trans')][:g['lrs'].shape[1]], 1)
     assert np.allclose(lrs, g['lrs'][:, :lrs.shape[1]])
+
+
+def test_data_layer_matches_reference_loader():
+    """nemo_cvpr2023_amd/multi_view_sequence.py::load_nemo_mocap on tests/golden/mocap_fixture == the arrays
+    the reference's MultiViewSequence produced from the same files (frame resampling, VIBE person selection,
+    scattering of partial tracks, empty OpenPose frames, image sizes, frame-rate multipliers)."""
+    import json
+    from nemo_cvpr2023_amd.multi_view_sequence import load_nemo_mocap, ArrayMultiViewSequence
+    g = load_golden('loader_mocap')
+    root = os.path.join(os.path.dirname(__file__), 'golden', 'mocap_fixture')
+    cfg = json.load(open(os.path.join(root, 'cfg.json')))
+    cfg['exp_dir'] = os.path.join(root, cfg['exp_dir'])
+    seqs = load_nemo_mocap(cfg, 0, 1000000, mocap_root=os.path.join(root, 'data', 'mocap'))
+    assert (seqs.num_views, seqs.num_frames, seqs.IMG_D0, seqs.IMG_D1) == tuple(
+        int(g[k]) for k in ('num_views', 'num_frames', 'IMG_D0', 'IMG_D1'))
+    assert np.allclose(seqs.framerate_multiplier, g['framerate_multiplier'])
+    for key in ('pose_2d_op', 'pose_2d_gt', 'pose', 'vibe_mask', 'vibe_joints2d', 'pose_3d_gt', 'trans_3d_gt'):
+        got = np.stack([np.stack([np.asarray(x, dtype=np.float64) for x in s[key]]) for s in seqs.sequences])
+        assert got.shape == g[key].shape and np.array_equal(got, g[key]), key
+    assert float(np.abs(g['pose_2d_op'][1]).sum(axis=(1, 2)).min()) == 0.0      # the undetected frame is in the clip
+    # the array constructor gives the same duck type
+    a = ArrayMultiViewSequence.from_arrays(g['pose_2d_op'], g['pose'], seqs.IMG_D0, seqs.IMG_D1,
+                                           pose_2d_gt=g['pose_2d_gt'])
+    assert a.num_views == seqs.num_views and a.num_frames == seqs.num_frames
+    assert np.array_equal(np.asarray(a.sequences[1]['pose'][2]), g['pose'][1, 2])

@@ -500,10 +500,35 @@ def run_eval_case(nmm, scratch, name='eval_v2', V=3, T=12, seed=0):
     save('eval_' + name, **rec)
 
 
+
+
+def run_loader_case(name='loader_mocap'):
+    """The reference's own MultiViewSequence (nemo/multi_view_sequence.py:250-483) on the committed
+    tests/golden/mocap_fixture dataset (tools/make_mocap_fixture.py).  cv2 is mocked in this container:
+    its imread is replaced by a PIL reader so the image sizes are the real ones of the fixture's PNGs."""
+    import json
+    import nemo.multi_view_sequence as mvs
+    from PIL import Image
+    root = os.path.join(OUT, 'mocap_fixture')
+    mvs.cv2.imread = lambda path: np.asarray(Image.open(path).convert('RGB'))[..., ::-1]
+    cwd = os.getcwd()
+    os.chdir(root)                     # MOCAP_ROOT and data/opt_cam_*.pt are cwd-relative (:28, :349-351)
+    try:
+        cfg = json.load(open('cfg.json'))
+        seqs = mvs.MultiViewSequence(cfg, 0, 1000000, run_hmr=False)
+    finally:
+        os.chdir(cwd)
+    rec = {'num_frames': seqs.num_frames, 'num_views': seqs.num_views, 'IMG_D0': seqs.IMG_D0, 'IMG_D1': seqs.IMG_D1,
+           'framerate_multiplier': np.asarray(seqs.framerate_multiplier, dtype=np.float64)}
+    for key in ('pose_2d_op', 'pose_2d_gt', 'pose', 'vibe_mask', 'vibe_joints2d', 'pose_3d_gt', 'trans_3d_gt'):
+        rec[key] = np.stack([np.stack([np.asarray(x, dtype=np.float64) for x in s[key]]) for s in seqs.sequences])
+    save(name, **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-6890', action='store_true')
-    ap.add_argument('--only', default='', help='comma list of: script, eval (skip everything else)')
+    ap.add_argument('--only', default='', help='comma list of: script, eval, loader (skip everything else)')
     opts = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     scratch = tempfile.mkdtemp(prefix='nemo_golden_')
@@ -522,6 +547,8 @@ def main():
         run_script_order_case(nmm)
     if not only or 'eval' in only:
         run_eval_case(nmm, scratch)
+    if not only or 'loader' in only:
+        run_loader_case()
     if only:
         return
     gen_function_goldens(nmm, assets_small)
