@@ -45,6 +45,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--no-torch-gpu-baseline', action='store_true')
     ap.add_argument('--instances', type=int, default=V0, help='exploration only; the judged workload is 8')
     ap.add_argument('--frames', type=int, default=T0, help='exploration only; the judged workload is 300')
     opts = ap.parse_args()
@@ -151,6 +152,31 @@ def main():
                          f'(plain PyTorch fp32 restatement of the reference step) after 1 warm-up, '
                          f'{ncores} threads'}
 
+    # The reference's own formulation (unfused PyTorch autograd, = the oracle) through PyTorch-ROCm's stock
+    # kernels on THIS GPU: what `north_star` calls "the reference single-GPU PyTorch iters/sec".
+    tgpu = None
+    if rank == 0 and world == 1 and not opts.no_torch_gpu_baseline:
+        from oracle.model import OracleNemo
+        try:
+            o = OracleNemo(2, args, seqs, assets['smpl_assets'], assets['vposer_state'], assets['gmm']).to(device)
+            with torch.device(device):
+                for _ in range(2):
+                    o.step(None, None, update=True, full_batch=True)
+                torch.cuda.synchronize()
+                g0 = time.perf_counter()
+                n_t = 5
+                for _ in range(n_t):
+                    o.step(None, None, update=True, full_batch=True)
+                torch.cuda.synchronize()
+                gdt = time.perf_counter() - g0
+            tgpu = {'value': round(n_t / gdt, 3), 'unit': 'iters/s', 'kind': 'port',
+                    'sample': f'{n_t} full-batch steps ({V}x{T}) of the oracle (unfused PyTorch restatement of the '
+                              f'reference step) on this GPU through PyTorch-ROCm, after 2 warm-up steps',
+                    'speedup_of_this_engine': round(iters_per_s / (n_t / gdt), 1)}
+            del o
+        except Exception as exc:                      # a baseline must never take the bench line down
+            tgpu = {'error': repr(exc)[:200]}
+
     if rank == 0:
         out = {
             'metric': 'NeMo fit iters/sec (instances x frames/step), Baseball-Pitch',
@@ -163,7 +189,7 @@ def main():
                        'instances': V, 'frames': T, 'samples_per_step': V * T, 'h_dim': args.h_dim,
                        'parallelism': f'instance-shard x{world}' if world > 1 else 'single GPU'},
             'final_total_loss': float(ld['total_loss']),
-            'roofline': roof, 'cpu_baseline': cpu,
+            'roofline': roof, 'cpu_baseline': cpu, 'torch_gpu_baseline': tgpu,
         }
         print(json.dumps(out))
     if world > 1:

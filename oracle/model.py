@@ -112,6 +112,24 @@ class OracleNemo:
         for k in self.P:
             self.P[k] = self.P[k].clone().requires_grad_(True)
 
+    def to(self, device):
+        """Moves every tensor of the oracle to `device` and rebuilds the optimisers (fresh Adam state).
+        Used by bench.py's `torch_gpu_baseline` leg: the same unfused PyTorch restatement of the reference
+        step, run through PyTorch-ROCm's stock kernels on the GPU the HIP engine is measured on.  Callers
+        wrap `step()` in `with torch.device(device):` so that the small tensors it creates land there."""
+        mv = lambda t: t.to(device) if torch.is_tensor(t) else t
+        self.P = OrderedDict((k, v.detach().to(device).requires_grad_(True)) for k, v in self.P.items())
+        if self.D > 0:
+            self.rbf_centres = mv(self.rbf_centres)
+        self.smpl.a = {k: mv(v) for k, v in self.smpl.a.items()}
+        self.vp.sd = {k: mv(v) for k, v in self.vp.sd.items()}
+        for k in ('means', 'precisions', 'nll_weights'):
+            setattr(self.prior, k, mv(getattr(self.prior, k)))
+        for k in ('points2d_gt_all', 'gt_bbox_size', 'hmr_theta', 'hmr_mask'):
+            setattr(self, k, mv(getattr(self, k)))
+        self._build_optimizers()
+        return self
+
     def load_state(self, state):
         for k, v in state.items():
             if k in self.P:
@@ -298,7 +316,7 @@ class OracleNemo:
             out['instance_loss'] = scal[5] if a.weight_instance_loss else 0
             if a.weight_3d_loss:
                 out['loss_3d'] = scal[4]
-        loss_dict = {k: np.asarray(v.numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
+        loss_dict = {k: np.asarray(v.cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
                      for k, v in out.items()}
         self.training = False
         return loss_dict, info
