@@ -26,6 +26,8 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
+ABI_VERSION = 3        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
     'nemo_abi_version': (i32, []),
@@ -98,8 +100,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.nemo_abi_version()
-    if ver != 3:
-        raise NemoHipError(f'libnemo_hip.so ABI version {ver} != 3 (stale build?)')
+    if ver != ABI_VERSION:
+        raise NemoHipError(f'libnemo_hip.so ABI version {ver} != {ABI_VERSION} (stale build?)')
     _lib = lib
     return lib
 

@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/nemo_hip.h but not exported'
     assert sorted(_lib.SIGNATURES) == declared, set(_lib.SIGNATURES) ^ set(declared)
-    assert lib.nemo_abi_version() == 3
+    header = open(os.path.join(ROOT, 'include', 'nemo_hip.h')).read()
+    assert lib.nemo_abi_version() == _lib.ABI_VERSION == int(re.search(r'#define NEMO_ABI_VERSION (\d+)', header).group(1))
 
 
 def test_argument_validation_without_gpu():
