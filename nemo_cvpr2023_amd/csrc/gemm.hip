@@ -339,7 +339,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #endif
 template <int BM, int BN, int BK, bool TA, bool TB, bool VEC>
 hipError_t launch_one(const GemmArgs& g, int blocks, hipStream_t s) {
-    constexpr int NS = BM == 64 ? NS_SMALL : NS_BIG;
+    // register-pipeline depth: 2 tiles in flight, 3 for the row-contiguous x row-contiguous layout (dW =
+    // dY^T X) -- measured per layout on MI355X (tools/bench_gemm.py): NN 77 -> 68 us, TT 294 -> 276 us at
+    // depth 2, TN 71 -> 67 us at depth 3
+    constexpr int NS = BM == 64 ? ((TA && !TB) ? 3 : 2) : NS_BIG;
     using SA = Stager<BM, BK, !TA, VEC, NS>;
     using SB = Stager<BN, BK, TB, VEC, NS>;
     constexpr size_t lds = 2 * (SA::SIZE + SB::SIZE) * sizeof(float);
