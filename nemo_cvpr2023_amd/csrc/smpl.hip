@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
                                                      const float* __restrict__ norm, float upstream,
                                                      float* __restrict__ dA, float* __restrict__ dJp,
                                                      float* __restrict__ dMq, float* __restrict__ dTR,
-                                                     long lddt, float* __restrict__ d_cams) {
+                                                     long lddt, float* __restrict__ d_cams, int nq) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long s = t / LANES;
     const int o = (int)(t % LANES);
@@ -729,16 +729,12 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
     // mesh functionals: pos = sum_j A_R[j] Mq[q][j] + A_t[j] w0[q][j].
     // d Mq[q][j] = A_R[j]^T dpos_q is private to the (sample, joint) lane; dA[j] sums over the mesh
     // joints of the sample: stage dpos in LDS and let every thread own output entries of dA.
-    __shared__ float dps[256 / LANES][NEMO_MAX_OUT][3];
-    __shared__ int qof[256 / LANES][NEMO_MAX_OUT];
+    __shared__ float dps[256 / LANES][NEMO_MAX_OUT][3];      // indexed by mesh functional q
     const int sl = threadIdx.x / LANES;
     const bool mesh = active && kind < 0;
-    if (o < NEMO_MAX_OUT) {
-        dps[sl][o][0] = mesh ? dpos[0] : 0.f; dps[sl][o][1] = mesh ? dpos[1] : 0.f; dps[sl][o][2] = mesh ? dpos[2] : 0.f;
-        qof[sl][o] = mesh ? (-kind - 1) : -1;
-    }
     if (mesh) {
         const int q = -kind - 1;
+        dps[sl][q][0] = dpos[0]; dps[sl][q][1] = dpos[1]; dps[sl][q][2] = dpos[2];
 #pragma unroll 8
         for (int j = 0; j < 24; ++j) {
             const float* Aj = Al[sl] + j * 12;
@@ -749,21 +745,26 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
         }
     }
     __syncthreads();
+    // dA[j][r][c] = sum_q dpos_q[r] * (c < 3 ? Mq[q][j][c] : w0[q][j]): a thread owns (sample, j, c) and its
+    // three rows r; the nq operand loads are independent of each other (unrolled: all in flight at once --
+    // a loop over the output joints with a look-up and a branch per iteration cost 32 us of dependent
+    // L2 round trips)
     constexpr int SPB = 256 / LANES;                  // samples per block
     const long sbase = (long)blockIdx.x * SPB;
-    for (int idx = threadIdx.x; idx < SPB * 288; idx += 256) {
-        const int ls = idx / 288, e = idx % 288;
+    for (int idx = threadIdx.x; idx < SPB * 96; idx += 256) {
+        const int ls = idx / 96, jc = idx % 96, j = jc / 4, c = jc % 4;
         const long ss = sbase + ls;
         if (ss >= a.N) continue;
-        const int j = e / 12, r = (e % 12) / 4, c = e % 4;
-        float acc = 0.f;
-        for (int oo = 0; oo < kc.n_out; ++oo) {
-            const int q = qof[ls][oo];
-            if (q < 0) continue;
-            const float m = c < 3 ? a.Mq[ss * a.ldq + q * 72 + j * 3 + c] : a.w0[q * 24 + j];
-            acc += dps[ls][oo][r] * m;
+        const float* Ms = c < 3 ? a.Mq + ss * a.ldq + j * 3 + c : a.w0 + j;
+        const int qs = c < 3 ? 72 : 24;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll 4
+        for (int q = 0; q < nq; ++q) {
+            const float m = Ms[q * qs];
+            a0 += dps[ls][q][0] * m; a1 += dps[ls][q][1] * m; a2 += dps[ls][q][2] * m;
         }
-        dA[ss * 288 + e] = acc;
+        float* o3 = dA + ss * 288 + j * 12 + c;
+        o3[0] = a0; o3[4] = a1; o3[8] = a2;
     }
 }
 
@@ -1391,7 +1392,7 @@ extern "C" int32_t nemo_kp_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_
     if (N == 0) return NEMO_OK;
     if (ctx->n_out > 32) return NEMO_EINVAL;
     hipLaunchKernelGGL(kp_bwd_kernel<32>, dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       ctx->kc, view_acc, norm, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams);
+                       ctx->kc, view_acc, norm, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams, (int)ctx->nq);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
