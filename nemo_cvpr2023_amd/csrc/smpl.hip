@@ -202,32 +202,36 @@ namespace {
 // ------------------------------------------------------------------------------------------ FK
 // 64 bodies per block, 256 threads.  The kinematic chain is inherently sequential per body (23
 // dependent 3x3 products), so one thread per body walks it -- but at LDS latency: phase 1 stages the
-// block's rotations (64 x 216 contiguous floats) with coalesced loads into LDS rows of stride 217
+// block's rotations (FK_TB x 216 contiguous floats) with coalesced loads into LDS rows of stride 217
 // (conflict-free per-body reads), phase 2 runs the chains with their state in LDS as
 // [joint*12 + e][lane], phase 3 writes transforms / posed joints back with coalesced stores.  A thread-
 // per-body kernel working directly on global memory issues ~50 scattered accesses per joint (64 cache
 // lines each) and was 4x slower.
-#define FK_TB 64
-#define FK_GS 65       // chain-state stride: [entry][lane] with +1 pad -> conflict-free for fixed entry (phase 2)
+#ifndef FK_TB
+#define FK_TB 16      // bodies per block (256 threads; 32 KB of LDS): measured 64 -> 32 -> 16 bodies:
+                      // fwd 18.7 -> 14.6 -> 12.6 us, bwd 29.9 -> 24.0 -> 22.0 us (more, smaller blocks: all CUs busy)
+#endif
+#define FK_GS (FK_TB + 1)       // chain-state stride: [entry][lane] with +1 pad -> conflict-free for fixed entry (phase 2)
                        // AND for consecutive entries of one body (coalesced phases 1/3)
 #define FK_RS 217
+#define FK_IT(n) (((n) + 255) / 256)        // compile-time trip count of a 256-thread copy loop over n items
 #define FK_LDS_BYTES ((24 * 12 * FK_GS + FK_TB * FK_RS) * (int)sizeof(float))
 
 // Copy loops have COMPILE-TIME trip counts and issue all their (unconditional, clamped) loads before
 // the first use: a rolled runtime-bound loop waits one full memory round trip per iteration, which
 // made the copy phases 5x longer than the kinematic chain itself.
 __device__ __forceinline__ void fk_load_R(const float* __restrict__ R, long row0, int nb, float* Rl) {
-    // 64 bodies x 216 floats = 3456 float4, 13.5 per thread
+    // FK_TB bodies x 216 floats = FK_TB * 54 float4
     const float4* src = reinterpret_cast<const float4*>(R + row0 * 216);
     const int lim = nb * 54;
-    float4 v[14];
+    float4 v[FK_IT(FK_TB * 54)];
 #pragma unroll
-    for (int it = 0; it < 14; ++it) {
+    for (int it = 0; it < FK_IT(FK_TB * 54); ++it) {
         const int i4 = it * 256 + threadIdx.x;
         v[it] = src[i4 < lim ? i4 : 0];
     }
 #pragma unroll
-    for (int it = 0; it < 14; ++it) {
+    for (int it = 0; it < FK_IT(FK_TB * 54); ++it) {
         const int i4 = it * 256 + threadIdx.x;
         if (i4 < lim) {
             const int bdy = i4 / 54, k = (i4 % 54) * 4;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void fk_fwd_kernel(long rows, const float* __r
     // pose feature (R[1:] - I), written from LDS with coalesced stores: 64 x 207 floats
     if (PF) {
 #pragma unroll
-        for (int it = 0; it < 52; ++it) {             // ceil(64*207 / 256)
+        for (int it = 0; it < FK_IT(FK_TB * 207); ++it) {
             const int idx = it * 256 + tid;
             const int bdy = idx / 207, k = idx % 207;
             if (bdy < nb) PF[(row0 + bdy) * ldpf + k] = Rl[bdy * FK_RS + 9 + k] - ((k % 9) % 4 == 0 ? 1.f : 0.f);
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) void fk_fwd_kernel(long rows, const float* __r
     // ---- phase 3: coalesced float4 write-out.  A[j] row r = [G_R[r] | G_t[r] - G_R[r].J_j] (lbs.py:399-402)
     float4* A4 = reinterpret_cast<float4*>(A + row0 * 288);
 #pragma unroll
-    for (int it = 0; it < 18; ++it) {                 // 64 x 72 float4
+    for (int it = 0; it < FK_IT(FK_TB * 72); ++it) {   // FK_TB x 72 float4
         const int i4 = it * 256 + tid;
         const int bdy = i4 / 72, jr = i4 % 72, j = jr / 3, r = jr % 3;
         const float* g = G + (j * 12) * FK_GS + bdy;
@@ -312,10 +316,10 @@ __global__ __launch_bounds__(256) void fk_fwd_kernel(long rows, const float* __r
     }
     float4* J4 = reinterpret_cast<float4*>(Jp + row0 * 72);
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {                  // 64 x 18 float4 = 1152
+    for (int it = 0; it < FK_IT(FK_TB * 18); ++it) {   // FK_TB x 18 float4
         const int i4 = it * 256 + tid;
         const int bdy = i4 / 18, e0 = (i4 % 18) * 4;
-        if (i4 < 1152 && bdy < nb) {
+        if (i4 < FK_TB * 18 && bdy < nb) {
             float v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = G[(((e0 + u) / 3) * 12 + 9 + (e0 + u) % 3) * FK_GS + bdy];
@@ -347,17 +351,17 @@ __global__ __launch_bounds__(256) void fk_bwd_kernel(long rows, const float* __r
     {
         const float4* dA4 = reinterpret_cast<const float4*>(dA + row0 * 288);
         const int lim = nb * 72;
-        float4 v[18];
-        float dj[18];
+        float4 v[FK_IT(FK_TB * 72)];
+        float dj[FK_IT(FK_TB * 72)];
 #pragma unroll
-        for (int it = 0; it < 18; ++it) {             // 64 x 72 float4: one (body, joint, row) each
+        for (int it = 0; it < FK_IT(FK_TB * 72); ++it) {   // FK_TB x 72 float4: one (body, joint, row) each
             const int i4 = it * 256 + tid;
             const int ic = i4 < lim ? i4 : 0;
             v[it] = dA4[ic];
             dj[it] = dJp ? dJp[row0 * 72 + ic] : 0.f;  // (body, joint, r) is the same linear index
         }
 #pragma unroll
-        for (int it = 0; it < 18; ++it) {
+        for (int it = 0; it < FK_IT(FK_TB * 72); ++it) {
             const int i4 = it * 256 + tid;
             if (i4 < lim) {
                 const int bdy = i4 / 72, jr = i4 % 72, j = jr / 3, r = jr % 3;
@@ -435,16 +439,16 @@ __global__ __launch_bounds__(256) void fk_bwd_kernel(long rows, const float* __r
     // ---- phase 3: coalesced write-out (+ the pose-feature gradient of joints 1..23)
     {
         const int lim = nb * 216;
-        float pfv[54];
+        float pfv[FK_IT(FK_TB * 216)];
 #pragma unroll
-        for (int it = 0; it < 54; ++it) {
+        for (int it = 0; it < FK_IT(FK_TB * 216); ++it) {
             const int idx = it * 256 + tid;
             const int ic = idx < lim ? idx : 0;
             const int bdy = ic / 216, k = ic % 216;
             pfv[it] = (dPF && k >= 9) ? dPF[(row0 + bdy) * lddpf + k - 9] : 0.f;
         }
 #pragma unroll
-        for (int it = 0; it < 54; ++it) {
+        for (int it = 0; it < FK_IT(FK_TB * 216); ++it) {
             const int idx = it * 256 + tid;
             if (idx < lim) dR[row0 * 216 + idx] = Rl[(idx / 216) * FK_RS + idx % 216] + pfv[it];
         }
