@@ -312,9 +312,11 @@ class MultiViewModel(nn.Module):
         return torch.as_tensor(t).to(self.device, torch.long).contiguous()
 
     def full_indices(self):
-        v = torch.arange(self.num_views, device=self.device).repeat_interleave(self.num_frames)
-        f = torch.arange(self.num_frames, device=self.device).repeat(self.num_views)
-        return v, f
+        if getattr(self, '_full_idx', None) is None:        # constant: built once, not per step
+            v = torch.arange(self.num_views, device=self.device).repeat_interleave(self.num_frames)
+            f = torch.arange(self.num_frames, device=self.device).repeat(self.num_views)
+            self._full_idx = (v, f)
+        return self._full_idx
 
     def frame_idx_to_raw_phase(self, frame_idx):
         return torch.linspace(0, 1, self.num_frames).to(frame_idx.device)[frame_idx]      # :2978-2984
@@ -500,8 +502,11 @@ class MultiViewModel(nn.Module):
         if graphable:
             key = (bool(update), sh.kr, sh.mr, sh.vr, sh.comm is not None,
                    tuple((s_['offset'], s_['numel']) for s_ in segs) if in_graph_adam else None)
-            w['vi_static'].copy_(vi)
-            w['fi_static'].copy_(fi)
+            src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N)
+            if w.get('_static_src') != src or vi is not w.get('_static_vi'):   # (full batch: cached, unchanged)
+                w['vi_static'].copy_(vi)
+                w['fi_static'].copy_(fi)
+                w['_static_src'], w['_static_vi'] = src, vi
             table = e.adam_table_upload(segs) if in_graph_adam else None
             entry = w['graphs'].get(key)
             if entry is None:                     # first sight: eager (sets kernel attributes, sizes pools)
