@@ -131,20 +131,22 @@ class FusedAdam(torch.optim.Optimizer):
         self.steps = {n: 0 for n in names}
         self._m = engine.exp_avg if exp_avg is None else exp_avg
         self._v = engine.exp_avg_sq if exp_avg_sq is None else exp_avg_sq
+        # (offset, numel) per tensor in MEMORY order -- this runs on the host every step, keep it cheap
+        geom = [(n,) + (engine.layout.entries[n][0], int(np.prod(engine.layout.entries[n][1]))) for n in names]
+        self._geom = sorted(geom, key=lambda t: t[1])
 
     def segments(self, active=None):
         """Advance the step counters of the active tensors and return merged launch segments."""
         g = self.param_groups[0]
+        lr, wd, steps = float(g['lr']), float(g['weight_decay']), self.steps
         raw = []
-        for n in self.names:
+        for n, off, numel in self._geom:
             if active is not None and n not in active:
                 continue
-            self.steps[n] += 1
-            off, shape = self._engine.layout.entries[n]
-            raw.append(dict(offset=off, numel=int(np.prod(shape)), lr=float(g['lr']),
-                            wd=float(g['weight_decay']), adamw=self.adamw, step=self.steps[n]))
+            steps[n] += 1
+            raw.append(dict(offset=off, numel=numel, lr=lr, wd=wd, adamw=self.adamw, step=steps[n]))
         segs = []
-        for s in sorted(raw, key=lambda d: d['offset']):       # memory order: adjacent tensors merge
+        for s in raw:                                          # memory order: adjacent tensors merge
             gap = s['offset'] - (segs[-1]['offset'] + segs[-1]['numel']) if segs else -1
             if 0 <= gap < 4 and segs[-1]['step'] == s['step']:      # (gap: the layout's 16-byte alignment pad)
                 segs[-1]['numel'] += gap + s['numel']
