@@ -256,7 +256,9 @@ class FitEngine:
         h, nq = self.h, self.ctx.nq
         Nc = min(N, 8192)
         # everything that must be zero at the start of a step lives in ONE arena (a single memset)
-        sizes = OrderedDict(view_acc=(self.V, 2), dAA=(N, 72), dJp=(N, 24, 3), dA2=(Nc, 24, 12), dPF2=(Nc, 208))
+        # (incl. this workspace's loss-scalar slots: FitEngine.scal points at the active workspace's)
+        sizes = OrderedDict(scal=(8,), view_acc=(self.V, 2), dAA=(N, 72), dJp=(N, 24, 3), dA2=(Nc, 24, 12),
+                            dPF2=(Nc, 208))
         arena = Z(sum(int(np.prod(v)) for v in sizes.values()))
         views, off = {}, 0
         for k, shp in sizes.items():

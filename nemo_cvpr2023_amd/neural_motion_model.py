@@ -414,8 +414,8 @@ class MultiViewModel(nn.Module):
         joins, runs the full-mesh v2v term alone, then the rot6d / MLP backward."""
         e, a = self.engine, self.args
         sh = sh or ShardInfo()
-        e.scal.zero_()
-        w['zero_arena'].zero_()          # view accumulators, dAA, dJp, dA2, dPF2 in one memset
+        e.scal = w['scal']               # loss-scalar slots of this workspace (part of the arena)
+        w['zero_arena'].zero_()          # loss scalars, view accumulators, dAA, dJp, dA2, dPF2 in one memset
         if update:
             e.grads.zero_()
         e.forward_pose(w, N, vi, fi, code_noise=self._noise(N))
@@ -473,6 +473,7 @@ class MultiViewModel(nn.Module):
             vi, fi = self.full_indices()
         N = vi.numel()
         w = e._ws(max(N, 1))
+        e.scal = w['scal']               # (a replayed graph wrote this workspace's slots)
         has_inst = bool(self.VERSION >= 3 and getattr(a, 'weight_instance_loss', 0) and e.C > 0)
 
         def body(vi_, fi_, adam_table):
