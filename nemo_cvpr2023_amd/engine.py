@@ -112,6 +112,7 @@ def fold_vposer(sd: dict, device):
         'd3w': g('decoder_net.3.weight'), 'd3b': g('decoder_net.3.bias'),
         'd5w': g('decoder_net.5.weight'), 'd5b': g('decoder_net.5.bias'),
     }
+    out['e2w_p'] = torch.cat([out['e2w'], torch.zeros(out['e2w'].shape[0], 1, dtype=out['e2w'].dtype)], 1)   # ld 64: 16-byte rows
     return {k: v.float().contiguous().to(device) for k, v in out.items()}
 
 
@@ -195,6 +196,7 @@ class FitEngine:
         self.D = args.phase_rbf_dim if version >= 2 else 0
         self.h = args.h_dim
         self.din = (self.D if self.D > 0 else 1) + self.C
+        self.ldx = (self.din + 3) // 4 * 4          # row stride of the MLP input / its gradient (16-byte rows)
         self.cx, self.cy = float(img_d0 // 2), float(img_d1 // 2)       # :3104-3106 (sic)
         self.kernel_id = RBF_KERNELS[args.rbf_kernel] if self.D > 0 else 0
         # 25 output joints out of the 49-joint map (:3662 / :3997)
@@ -266,7 +268,7 @@ class FitEngine:
             views[k] = arena[off:off + n_].view(shp)
             off += n_
         w = dict(
-            X=Z(N + 1, self.din), H1=Z(N + 1, h), H2=Z(N + 1, h), H3=Z(N + 1, h), HEAD=Z(N + 1, HEAD_LD),
+            X=Z(N + 1, self.ldx), H1=Z(N + 1, h), H2=Z(N + 1, h), H3=Z(N + 1, h), HEAD=Z(N + 1, HEAD_LD),
             phase=Z(N), phase_ws=Z(N, 4), gmm_ws=Z(N, self.gmm['M']), R=Z(N, 24, 9), AA=Z(N, 72), A=Z(N, 24, 12), Jp=Z(N, 24, 3),
             PF=Z(N, 208), Mq=Z(N, max(nq * 72, 1)), j3d=Z(N, self.ctx.n_out, 3), p2d=Z(N, self.ctx.n_out, 2),
             loss_all=Z(N, self.ctx.n_out, 2), norm=Z(1),
@@ -277,7 +279,7 @@ class FitEngine:
             dR2=Z(N, 24, 9),
             dR=Z(N, 24, 9), dA=Z(N, 24, 12), dMq=Z(N, max(nq * 72, 1)),
             dPF=Z(N, 208), dHEAD=Z(N + 1, HEAD_LD), dH=Z(N + 1, h), dH_b=Z(N + 1, h), dH_c=Z(N + 1, h),
-            dX=Z(N + 1, self.din), dMULV=Z(N, 64), dE_a=Z(N, 512), Nc=Nc,
+            dX=Z(N + 1, self.ldx), dMULV=Z(N, 64), dE_a=Z(N, 512), Nc=Nc,
             vi_static=torch.zeros(N, dtype=torch.long, device=self.device),
             fi_static=torch.zeros(N, dtype=torch.long, device=self.device), graphs={})
         w.update(views)
@@ -315,9 +317,9 @@ class FitEngine:
         if ev is not None:
             ev.record()
 
-    def _linear(self, rows, x, ldx, fin, w, b, fout, y, ldy, act=0, tag=None):
-        """y = act(x @ w^T + b), w stored (fout, fin) like nn.Linear."""
-        self.gemm(0, 1, rows, fout, fin, x, ldx, w, fin, y, ldy, bias=b, act=act, tag=tag)
+    def _linear(self, rows, x, ldx, fin, w, b, fout, y, ldy, act=0, tag=None, ldw=None):
+        """y = act(x @ w^T + b), w stored (fout, fin) like nn.Linear (row stride ldw, default fin)."""
+        self.gemm(0, 1, rows, fout, fin, x, ldx, w, fin if ldw is None else ldw, y, ldy, bias=b, act=act, tag=tag)
 
     def _linear_bwd_params(self, rows, x, ldx, fin, dy, lddy, fout, gw, gb, nbias=None):
         """gw (fout,fin) += dy^T @ x ;  gb[:nbias] += colsum(dy) (skipped when gb is None).  K = rows
@@ -346,10 +348,10 @@ class FitEngine:
             N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
             sh0, sc0, 2 * self.K, self.p('phase_rbf.log_sigmas') if self.D > 0 else None,
             self.p('learned_instance_code') if self.C > 0 else None, dptr(code_noise), self.kernel_id,
-            dptr(w['X']), self.din, dptr(w['phase']), st), 'nemo_phase_embed_fwd')
+            dptr(w['X']), self.ldx, dptr(w['phase']), st), 'nemo_phase_embed_fwd')
         h, r = self.h, N + 1
         lm = 'learned_motion.'
-        self._linear(r, dptr(w['X']), self.din, self.din, self.p(lm + 'net.net.0.weight'),
+        self._linear(r, dptr(w['X']), self.ldx, self.din, self.p(lm + 'net.net.0.weight'),
                      self.p(lm + 'net.net.0.bias'), h, dptr(w['H1']), h, act=1)
         self._linear(r, dptr(w['H1']), h, h, self.p(lm + 'net.net.2.weight'), self.p(lm + 'net.net.2.bias'),
                      h, dptr(w['H2']), h, act=1, tag='gemm_mlp_hidden_fwd')
@@ -396,7 +398,7 @@ class FitEngine:
         """K9 + K12: encode(mean) -> decode -> axis-angle; KL and its gradient."""
         L, st, vp = self.lib, _stream(), self.vp
         aa63 = w['AA'].data_ptr() + 4 * 3
-        self._linear(N, aa63, 72, 63, dptr(vp['e2w']), dptr(vp['e2b']), 512, dptr(w['E1']), 512, act=2)
+        self._linear(N, aa63, 72, 63, dptr(vp['e2w_p']), dptr(vp['e2b']), 512, dptr(w['E1']), 512, act=2, ldw=64)
         self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
         self._linear(N, dptr(w['MULV']), 64, 32, dptr(vp['d0w']), dptr(vp['d0b']), 512, dptr(w['D1']), 512,
                      act=2)
@@ -477,7 +479,7 @@ class FitEngine:
         vp = self.vp
         self.gemm(0, 0, N, 512, 64, dptr(w['dMULV']), 64, dptr(vp['emw']), 512, dptr(w['dE_a']), 512,
                   alpha=weight, mask=dptr(w['E1']), ldmask=512, mask_mode=2)
-        self.gemm(0, 0, N, 63, 512, dptr(w['dE_a']), 512, dptr(vp['e2w']), 63,
+        self.gemm(0, 0, N, 63, 512, dptr(w['dE_a']), 512, dptr(vp['e2w_p']), 64,
                   w['dAA'].data_ptr() + 4 * 3, 72, out_mode=1)
 
     def backward_mlp(self, w, N, view_idx, frame_idx, raw_phase, has_trans_grad=True):
@@ -521,10 +523,10 @@ class FitEngine:
         self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
                   mask=dptr(w['H1']), ldmask=h, mask_mode=1)
         ev = main.record_event() if overlap else None
-        params(ev, r, dptr(w['X']), self.din, self.din, dptr(w['dH_c']), h, h,
+        params(ev, r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h,
                self.g(lm + 'net.net.0.weight'), self.g(lm + 'net.net.0.bias'))
         self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
-                  dptr(w['dX']), self.din)
+                  dptr(w['dX']), self.ldx)
         if overlap:
             with torch.cuda.stream(side):
                 self.flush_colsums()
@@ -534,7 +536,7 @@ class FitEngine:
             N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
             self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), 2 * self.K,
             self.p('phase_rbf.log_sigmas') if self.D > 0 else None, self.kernel_id, dptr(w['phase']),
-            dptr(w['dX']), self.din, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
+            dptr(w['dX']), self.ldx, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
             self.g('phase_networks.0.scales'),
             self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
             self.g('learned_instance_code') if self.C > 0 else None, st), 'nemo_phase_embed_bwd')
