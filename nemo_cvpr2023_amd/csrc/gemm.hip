@@ -136,11 +136,11 @@ __device__ __forceinline__ void fetch_group(const float* lds, int row, int q, in
     }
 }
 
-template <int BM, int BN, int BK, bool TA, bool TB, bool VEC, int NS>
+template <int BM, int BN, int BK, bool TA, bool TB, bool VA, bool VB, int NS>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32, G = BK / 8;
-    using SA = Stager<BM, BK, !TA, VEC, NS>;
-    using SB = Stager<BN, BK, TB, VEC, NS>;
+    using SA = Stager<BM, BK, !TA, VA, NS>;
+    using SB = Stager<BN, BK, TB, VB, NS>;
     extern __shared__ __attribute__((aligned(16))) float smem[];      // the ONLY LDS object of the kernel
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * SA::SIZE;
@@ -331,44 +331,38 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
-#ifndef NS_SMALL
-#define NS_SMALL 3
-#endif
 #ifndef NS_BIG
 #define NS_BIG 2
 #endif
-template <int BM, int BN, int BK, bool TA, bool TB, bool VEC>
+template <int BM, int BN, int BK, bool TA, bool TB, bool VA, bool VB>
 hipError_t launch_one(const GemmArgs& g, int blocks, hipStream_t s) {
     // register-pipeline depth: 2 tiles in flight, 3 for the row-contiguous x row-contiguous layout (dW =
     // dY^T X) -- measured per layout on MI355X (tools/bench_gemm.py): NN 77 -> 68 us, TT 294 -> 276 us at
     // depth 2, TN 71 -> 67 us at depth 3
     constexpr int NS = BM == 64 ? ((TA && !TB) ? 3 : 2) : NS_BIG;
-    using SA = Stager<BM, BK, !TA, VEC, NS>;
-    using SB = Stager<BN, BK, TB, VEC, NS>;
+    using SA = Stager<BM, BK, !TA, VA, NS>;
+    using SB = Stager<BN, BK, TB, VB, NS>;
     constexpr size_t lds = 2 * (SA::SIZE + SB::SIZE) * sizeof(float);
     static bool attr_set = false;        // > 64 KB of LDS needs the opt-in once per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, BK, TA, TB, VEC, NS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, BK, TA, TB, VA, VB, NS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, TA, TB, VEC, NS>), dim3(blocks), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, TA, TB, VA, VB, NS>), dim3(blocks), dim3(256), lds, s, g);
     return hipSuccess;
 }
 
-template <int BM, int BN, int BK, bool VEC>
+template <int BM, int BN, int BK, bool VA, bool VB>
 hipError_t launch(int ta, int tb, const GemmArgs& g, int blocks, hipStream_t s) {
-    if (!ta && !tb) return launch_one<BM, BN, BK, false, false, VEC>(g, blocks, s);
-    if (!ta && tb) return launch_one<BM, BN, BK, false, true, VEC>(g, blocks, s);
-    if (ta && !tb) return launch_one<BM, BN, BK, true, false, VEC>(g, blocks, s);
-    return launch_one<BM, BN, BK, true, true, VEC>(g, blocks, s);
+    if (!ta && !tb) return launch_one<BM, BN, BK, false, false, VA, VB>(g, blocks, s);
+    if (!ta && tb) return launch_one<BM, BN, BK, false, true, VA, VB>(g, blocks, s);
+    if (ta && !tb) return launch_one<BM, BN, BK, true, false, VA, VB>(g, blocks, s);
+    return launch_one<BM, BN, BK, true, true, VA, VB>(g, blocks, s);
 }
 
 constexpr int BK = 32;
-#ifndef BK_SMALL_VEC
-#define BK_SMALL_VEC 32
-#endif
 constexpr long COUNTER_BYTES = 16384;       // 4096 tile tickets at the head of the workspace
 constexpr int N_CU = 256;
 
@@ -384,7 +378,7 @@ Plan plan_gemm(long M, long N, long K, bool can_split, long ws_bytes, bool atomi
     Plan best{64, 1, 1e30};
     for (int tile : {128, 64}) {
         if (tile == 128 && !big_ok) continue;
-        const int bk = (tile == 64 && vec) ? BK_SMALL_VEC : BK;
+        const int bk = BK;
         const long kiters = (K + bk - 1) / bk;
         const long tiles = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
         const double us_iter = tile == 128 ? 2.35 : 0.67 * bk / 32;   // one K tile of one block
@@ -428,10 +422,12 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     int force_tile = 0;
     if (const char* f = getenv("NEMO_GEMM_TILE")) force_tile = atoi(f);          // tuning aids (tools/bench_gemm.py)
     if (const char* f = getenv("NEMO_GEMM_SPLIT")) { if (split_k == 0 && atoi(f) > 0) split_k = atoi(f); }
-    // K-chunk starts are multiples of 32, so operand alignment only depends on the base and the ld
-    const bool vec = aligned16(A, lda) && aligned16(B, ldb);
-    // (the dword-staged variant exists for 64x64 tiles only: it serves the few small-K operands whose
-    //  rows are not 16-byte aligned, e.g. nn.Linear weights with in_features 105 / 63)
+    // K-chunk starts are multiples of 32, so operand alignment only depends on the base and the ld; each
+    // operand independently takes the dwordx4 or the dword staging path (64x64 tiles; the 128x128 tile
+    // needs both aligned).  Dword staging serves the few operands whose rows are not 16-byte aligned,
+    // e.g. nn.Linear weights with in_features = 105 or a view that starts 3 floats into a row.
+    const bool va = aligned16(A, lda), vb = aligned16(B, ldb);
+    const bool vec = va && vb;
     // (128x128 tiles pay off only with both operands k-contiguous: the k-major LDS image is fetched with
     //  four ds_read_b32 per operand group instead of one ds_read_b128 and runs at ~half the rate there)
     Plan pl = plan_gemm(M, N, K, can_split, ws_bytes, out_mode == 2, split_k, vec && !transA && transB, vec);
@@ -448,7 +444,7 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     g.counters = reinterpret_cast<int*>(ws);
     g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
     long kc = (K + pl.split - 1) / pl.split;
-    const int bk = (tile == 64 && vec) ? BK_SMALL_VEC : BK;
+    const int bk = BK;
     kc = ((kc + bk - 1) / bk) * bk;
     if (kc == 0) kc = bk;
     g.k_chunk = kc;
@@ -465,9 +461,11 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
 
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
-    if (tile == 128) e = launch<128, 128, BK, true>(transA, transB, g, (int)blocks, s);
-    else e = vec ? launch<64, 64, BK_SMALL_VEC, true>(transA, transB, g, (int)blocks, s)
-                 : launch<64, 64, BK, false>(transA, transB, g, (int)blocks, s);
+    if (tile == 128) e = launch<128, 128, BK, true, true>(transA, transB, g, (int)blocks, s);
+    else if (va && vb) e = launch<64, 64, BK, true, true>(transA, transB, g, (int)blocks, s);
+    else if (va) e = launch<64, 64, BK, true, false>(transA, transB, g, (int)blocks, s);
+    else if (vb) e = launch<64, 64, BK, false, true>(transA, transB, g, (int)blocks, s);
+    else e = launch<64, 64, BK, false, false>(transA, transB, g, (int)blocks, s);
     if (e != hipSuccess) return (int32_t)e;
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
