@@ -481,13 +481,29 @@ __device__ __forceinline__ void kp_joint(const KpArgs& a, const KpConst& kc, lon
     const float* M = a.Mq + s * a.ldq + q * 72;
     const float* w = a.w0 + q * 24;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if ((a.ldq & 3) == 0 && (((uintptr_t)a.Mq) & 15) == 0) {
+        // the functional's 72 floats as 18 independent dwordx4 loads (all in flight), not 72 dependent dwords
+        float4 m4[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) m4[i] = reinterpret_cast<const float4*>(M)[i];
+        const float* m = reinterpret_cast<const float*>(m4);
+#pragma unroll
+        for (int j = 0; j < 24; ++j) {
+            const float m0 = m[j * 3], m1 = m[j * 3 + 1], m2 = m[j * 3 + 2], wj = w[j];
+            const float* Aj = Al + j * 12;
+            p0 += Aj[0] * m0 + Aj[1] * m1 + Aj[2] * m2 + Aj[3] * wj;
+            p1 += Aj[4] * m0 + Aj[5] * m1 + Aj[6] * m2 + Aj[7] * wj;
+            p2 += Aj[8] * m0 + Aj[9] * m1 + Aj[10] * m2 + Aj[11] * wj;
+        }
+    } else {
 #pragma unroll 8
-    for (int j = 0; j < 24; ++j) {
-        const float m0 = M[j * 3], m1 = M[j * 3 + 1], m2 = M[j * 3 + 2], wj = w[j];
-        const float* Aj = Al + j * 12;
-        p0 += Aj[0] * m0 + Aj[1] * m1 + Aj[2] * m2 + Aj[3] * wj;
-        p1 += Aj[4] * m0 + Aj[5] * m1 + Aj[6] * m2 + Aj[7] * wj;
-        p2 += Aj[8] * m0 + Aj[9] * m1 + Aj[10] * m2 + Aj[11] * wj;
+        for (int j = 0; j < 24; ++j) {
+            const float m0 = M[j * 3], m1 = M[j * 3 + 1], m2 = M[j * 3 + 2], wj = w[j];
+            const float* Aj = Al + j * 12;
+            p0 += Aj[0] * m0 + Aj[1] * m1 + Aj[2] * m2 + Aj[3] * wj;
+            p1 += Aj[4] * m0 + Aj[5] * m1 + Aj[6] * m2 + Aj[7] * wj;
+            p2 += Aj[8] * m0 + Aj[9] * m1 + Aj[10] * m2 + Aj[11] * wj;
+        }
     }
     pos[0] = p0; pos[1] = p1; pos[2] = p2;
 }
