@@ -1461,6 +1461,7 @@ extern "C" int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N) {
     if (!ctx || N < 0) return -1;
     const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
     long nr = 500 / (groups > 0 ? groups : 1);
+    if (const char* e = getenv("NEMO_MESH_NR")) nr = atol(e);
     if (nr < 1) nr = 1;
     if (nr > (ntiles + 3) / 4) nr = (ntiles + 3) / 4;
     return 16384 + ((groups * 4 + 15) / 16) * 16 + groups * nr * 96 * 64 * 4;
@@ -1484,6 +1485,7 @@ extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* P
     // at most 256 CUs x 2 resident blocks: the whole grid must be co-resident (a second, partially
     // filled wave of blocks costs up to 2x), and as close to that as the vertex ranges allow
     long nr = 500 / groups;
+    if (const char* e = getenv("NEMO_MESH_NR")) nr = atol(e);      // tuning aid
     if (nr < 1) nr = 1;
     if (nr > (ntiles + 3) / 4) nr = (ntiles + 3) / 4;
     const int tpr = (int)((ntiles + nr - 1) / nr);
