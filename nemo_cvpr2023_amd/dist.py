@@ -106,6 +106,7 @@ class ShardedNemo:
         state = make_init_state(args, version, self.V, multi_view_seqs.IMG_D0)    # identical on all ranks
         local = SequenceSubset(multi_view_seqs, self.plan.lo, self.plan.hi)
         self.model = NEMO_VERSIONS[version](args, local, device, **assets)
+        self.model.GRAPH_AFTER = 2       # a rank's share of a random minibatch changes size from step to step
         self.model.load_state_dict({k: v for k, v in slice_state(state, self.plan.lo, self.plan.hi).items()},
                                    strict=False)
         torch.manual_seed(seed + 1)       # re-synchronise the index stream across ranks

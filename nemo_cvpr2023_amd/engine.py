@@ -249,10 +249,15 @@ class FitEngine:
         return self.view(name, self.grads).data_ptr()
 
     # ------------------------------------------------------------------ workspaces
+    MAX_WORKSPACES = 24      # distinct batch sizes kept alive (a rank of a sharded minibatch run sees many)
+
     def _ws(self, N):
         w = self.ws.get(N)
         if w is not None:
+            self.ws[N] = self.ws.pop(N)          # most recently used last
             return w
+        while len(self.ws) >= self.MAX_WORKSPACES:
+            self.ws.pop(next(iter(self.ws)))     # drop the least recently used workspace (and its graphs)
         f32 = dict(dtype=torch.float32, device=self.device)
         Z = lambda *s: torch.zeros(*s, **f32)
         h, nq = self.h, self.ctx.nq

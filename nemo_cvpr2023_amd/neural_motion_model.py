@@ -230,6 +230,7 @@ class MultiViewModel(nn.Module):
         self.training = False
         # capture each (batch size, mode) variant of the step as a HIP graph after one eager run
         self.use_graphs = os.environ.get('NEMO_GRAPHS', '1') != '0'
+        self.GRAPH_AFTER = 1             # eager runs of a (batch size, mode) variant before it is captured
         self._build_parameters()
         self._init_parameters()
         self._build_optimizers()
@@ -512,11 +513,13 @@ class MultiViewModel(nn.Module):
                 w['_static_src'], w['_static_vi'] = src, vi
             table = e.adam_table_upload(segs) if in_graph_adam else None
             entry = w['graphs'].get(key)
-            if entry is None:                     # first sight: eager (sets kernel attributes, sizes pools)
-                w['graphs'][key] = 'warm'
+            if not isinstance(entry, torch.cuda.CUDAGraph) and (entry or 0) < self.GRAPH_AFTER:
+                # first sights: eager (sets kernel attributes, sizes pools; a shape that shows up once or
+                # twice -- a rank's share of a random minibatch -- is not worth a capture)
+                w['graphs'][key] = (entry or 0) + 1
                 body(w['vi_static'], w['fi_static'], table)
             else:
-                if entry == 'warm':               # second sight: capture the ~70-launch step as one HIP graph
+                if not isinstance(entry, torch.cuda.CUDAGraph):   # capture the ~70-launch step as one HIP graph
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
