@@ -90,6 +90,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up: the first calls of a (batch size, mode) variant allocate its workspace and capture its HIP graph
+    # (like a compile step); they are not part of the warm-up / timed protocol below
+    for _ in range(3):
+        step()
     for _ in range(opts.warmup):
         step()
     barrier()
