@@ -1247,14 +1247,16 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     __syncthreads();
     if (wid == 1) put(0);
     __syncthreads();
+    // The nr = gridDim.y blocks of a sample group hold partial sums over their vertex ranges.  Each publishes
+    // its partial as a coalesced register image (write-through stores), takes a ticket, and the LAST
+    // arriver adds the partials and writes dA: a fixed order (deterministic), and none of the ~2 M
+    // same-address fp32 atomics this used to cost (44 us at N = 2400, 95 us at N = 300).  All four waves of
+    // the last arriver share the summation (wave w takes ranges w, w+4, ...: with 26 ranges per group at a
+    // one-instance shard a single wave spent ~35 us on 26 dependent memory round trips).
+    const int nr = gridDim.y;
+    __shared__ int ticket_old;
     if (wid == 0) {
         take(0);
-        // The nr = gridDim.y blocks of a sample group hold partial sums over their vertex ranges.  Each
-        // publishes its partial as a coalesced register image (write-through stores), takes a ticket, and
-        // the LAST arriver adds the partials in range order and writes dA: deterministic, and none of the
-        // ~2 M same-address fp32 atomics this used to cost (44 us at N = 2400, 95 us at N = 300).
-        const int nr = gridDim.y;
-        bool finish = true;
         if (nr > 1) {
             float* part = parts + ((size_t)blockIdx.x * nr + blockIdx.y) * (96 * 64);
 #pragma unroll
@@ -1266,49 +1268,55 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                         __hip_atomic_store(part + ((e * 2 + t) * 4 + r) * 64 + lane, accdA[e][t][r],
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1 store
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            int old = 0;
             if (lane == 0)
-                old = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            old = __builtin_amdgcn_readfirstlane(old);
-            finish = old == nr - 1;
-            if (finish) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                if (lane == 0)
-                    __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float* base = parts + (size_t)blockIdx.x * nr * (96 * 64) + lane;
-#pragma unroll
-                for (int e = 0; e < 12; ++e)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) accdA[e][t][r] = 0.f;
-                // range-major: the 96 coalesced loads of one partial are all in flight together (one
-                // memory round trip per vertex range, not per value)
-                for (int pz = 0; pz < nr; ++pz) {
-                    const float* pp = base + (size_t)pz * (96 * 64);
-                    float v[96];
-#pragma unroll
-                    for (int q = 0; q < 96; ++q) v[q] = pp[q * 64];
-#pragma unroll
-                    for (int e = 0; e < 12; ++e)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) accdA[e][t][r] += v[(e * 2 + t) * 4 + r];
-                }
-            }
+                ticket_old = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (finish && s0 + l15 < N) {
+    }
+    __syncthreads();
+    const bool finish = nr == 1 || ticket_old == nr - 1;      // block-uniform
+    if (nr > 1 && finish) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (tid == 0) __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float* base = parts + (size_t)blockIdx.x * nr * (96 * 64) + lane;
+#pragma unroll
+        for (int e = 0; e < 12; ++e)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accdA[e][t][r] = 0.f;
+        // range-major: the 96 coalesced loads of one partial are all in flight together (one memory round
+        // trip per vertex range, not per value)
+        for (int pz = wid; pz < nr; pz += 4) {
+            const float* pp = base + (size_t)pz * (96 * 64);
+            float v[96];
+#pragma unroll
+            for (int q = 0; q < 96; ++q) v[q] = pp[q * 64];
 #pragma unroll
             for (int e = 0; e < 12; ++e)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = 16 * t + 4 * g + r;
-                        if (j < 24) dA[(s0 + l15) * 288 + j * 12 + e] = accdA[e][t][r];
-                    }
+                    for (int r = 0; r < 4; ++r) accdA[e][t][r] += v[(e * 2 + t) * 4 + r];
         }
+        __syncthreads();                                   // (scr: the block's own cross-wave pass is over)
+        if (wid >= 2) put(wid - 2);
+        __syncthreads();
+        if (wid < 2) take(wid);
+        __syncthreads();
+        if (wid == 1) put(0);
+        __syncthreads();
+        if (wid == 0) take(0);
+    }
+    if (finish && wid == 0 && s0 + l15 < N) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = 16 * t + 4 * g + r;
+                    if (j < 24) dA[(s0 + l15) * 288 + j * 12 + e] = accdA[e][t][r];
+                }
     }
     const float tot = block_sum(lsum, red);
     if (tid == 0) atomicAdd(loss_sum, tot);
