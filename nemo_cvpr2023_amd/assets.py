@@ -1,8 +1,9 @@
 """Loaders for the real (licensed, not redistributable) model files the reference reads from
 ``software/`` (hmr/hmr_config.py:70-76, nemo/neural_motion_model.py:217-238).
 
-Nothing here is exercised by the tests or benchmarks (they use ``synthetic.py``); it exists so a
-user who owns the files can run the engine on them.  Every loader fails loudly.
+The benchmarks use ``synthetic.py``; these loaders exist so that a user who owns the files can run the
+engine on them (file formats covered by tests/test_abi_and_host.py with synthetic content).  Every
+loader fails loudly.
 """
 from __future__ import annotations
 

@@ -108,3 +108,41 @@ def test_vposer_folding_matches_unfolded():
     mean, scale = ops.VPoserOracle(sd).encode(x)
     assert float((ml[:, :32] - mean).abs().max()) < 1e-5
     assert float((torch.nn.functional.softplus(ml[:, 32:]) - scale).abs().max()) < 1e-5
+
+
+def test_real_asset_loaders_round_trip(tmp_path):
+    """assets.py reads the file formats the reference reads from software/ (SMPL .pkl with a sparse joint
+    regressor and (NV,3,207) pose blend shapes, a VPoser snapshot with the 'vp_model.' prefix, gmm_08.pkl);
+    files are written here from the synthetic assets and must come back identical."""
+    import pickle
+    import scipy.sparse as sp
+    import torch
+    from nemo_cvpr2023_amd import assets, synthetic as syn
+    a = syn.make_smpl_assets(64, seed=3)
+    nv = a['v_template'].shape[0]
+    smpl_dir = tmp_path / 'smpl'
+    smpl_dir.mkdir()
+    d = {'v_template': a['v_template'].numpy(), 'shapedirs': np.concatenate(
+            [a['shapedirs'].numpy(), np.zeros((nv, 3, 290), np.float32)], 2),          # 300 shape components on disk
+         'posedirs': a['posedirs'].numpy().T.reshape(nv, 3, 207),
+         'J_regressor': sp.csc_matrix(a['J_regressor'].numpy()), 'weights': a['lbs_weights'].numpy()}
+    with open(smpl_dir / 'basicModel_neutral_lbs_10_207_0_v1.0.0.pkl', 'wb') as f:
+        pickle.dump(d, f)
+    np.save(tmp_path / 'J_regressor_extra.npy', a['J_regressor_extra'].numpy())
+    got = assets.load_smpl_assets(str(smpl_dir), str(tmp_path / 'J_regressor_extra.npy'))
+    for k in ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'J_regressor_extra', 'lbs_weights'):
+        assert torch.equal(got[k], a[k].float()), k
+    assert got['parents'].tolist() == syn.SMPL_PARENTS and got['joint_map'].tolist() == syn.JOINT_MAP_49
+    vp = syn.make_vposer_state()
+    (tmp_path / 'V02_05' / 'snapshots').mkdir(parents=True)
+    torch.save({'state_dict': {'vp_model.' + k: v for k, v in vp.items()}},
+               tmp_path / 'V02_05' / 'snapshots' / 'V02_05_epoch=13.ckpt')
+    got = assets.load_vposer_state(str(tmp_path / 'V02_05'))
+    assert set(got) == set(vp) and all(torch.equal(got[k], vp[k]) for k in vp)
+    g = syn.make_gmm()
+    with open(tmp_path / 'gmm_08.pkl', 'wb') as f:
+        pickle.dump(g, f)
+    got = assets.load_gmm(str(tmp_path))
+    assert all(np.array_equal(got[k], g[k]) for k in ('means', 'covars', 'weights'))
+    with pytest.raises(FileNotFoundError):
+        assets.load_smpl_assets(str(tmp_path / 'nowhere'))
