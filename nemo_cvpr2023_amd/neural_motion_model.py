@@ -578,7 +578,15 @@ class MultiViewModel(nn.Module):
         e = self.engine
         if sh.comm is None:
             return e.read_scalars()
-        wv = torch.tensor([sh.kr, 1.0, sh.mr, sh.mr, sh.mr, sh.vr, 0.0, 0.0], device=self.device)
+        key = (sh.kr, sh.mr, sh.vr)
+        wv = self._shard_w.get(key) if hasattr(self, '_shard_w') else None
+        if wv is None:                       # (cached: a host-to-device upload per step otherwise)
+            if not hasattr(self, '_shard_w'):
+                self._shard_w = {}
+            if len(self._shard_w) > 256:
+                self._shard_w.clear()
+            wv = self._shard_w[key] = torch.tensor([sh.kr, 1.0, sh.mr, sh.mr, sh.mr, sh.vr, 0.0, 0.0],
+                                                   device=self.device)
         slot = e.view('_comm_scalars', e.grads)
         torch.mul(e.scal, wv, out=slot)
         sh.comm(e, update)
