@@ -334,3 +334,27 @@ def test_loss_curve_parity_200_steps():
     assert rel[:5].max() < 1e-4, rel[:5]                 # identical inputs, identical state: the 1e-4 gate
     assert rel.max() < 2e-3 and rel.mean() < 5e-4, (rel.max(), rel.mean())
     assert co[-20:].mean() < co[:20].mean()              # and the fit actually descends
+
+
+def test_loss_curve_parity_real_size():
+    """The same free-running comparison at the REAL sizes of the published run (h = 1000, RBF 100, 6890-vertex
+    mesh, every loss term) over 20 minibatch steps of 256 samples drawn from 8 x 300."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    from oracle.model import OracleNemo
+    V, T, B, steps = 8, 300, 256, 20
+    args = syn.published_args(batch_size=B, out_dir='')
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    torch.manual_seed(0)
+    m = NemoV2(args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+    o = OracleNemo(2, args, seqs, assets, vps, gmm, state={k: v.cpu() for k, v in m.state_dict().items()})
+    gen = torch.Generator().manual_seed(2)
+    rel = []
+    for _ in range(steps):
+        vi = torch.randint(0, V, (B,), generator=gen)
+        fi = torch.randint(0, T, (B,), generator=gen)
+        lm, lo = m.step(vi, fi)[0], o.step(vi, fi)[0]
+        rel.append(max(abs(float(lm[k]) - float(lo[k])) / max(abs(float(lo[k])), 1e-6)
+                       for k in ('kp_loss', 'gmm_loss', 'vp_recon_loss', 'vp_kl_loss', 'total_loss')))
+    assert max(rel[:3]) < 1e-4, rel[:3]
+    assert max(rel) < 1e-3, rel
