@@ -41,6 +41,7 @@ SIGNATURES = {
                                    ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr]),
     'nemo_rot6d_fwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr]),
     'nemo_rot6d_bwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr]),
+    'nemo_pose_bwd_fused': (i32, [i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, ptr]),
     'nemo_rotmat_to_aa': (i32, [i64, ptr, i32, ptr, ptr]),
     'nemo_rodrigues_fwd': (i32, [i64, ptr, i32, ptr, ptr]),
     'nemo_rodrigues_bwd': (i32, [i64, ptr, ptr, ptr, ptr]),

@@ -343,6 +343,68 @@ __global__ __launch_bounds__(256) void v2v_prep_bwd_kernel(long N, const float* 
     }
 }
 
+
+// rot6d backward of the fit step with its two small neighbours folded in (three launches -> one):
+//  * v2v_prep_bwd: the full-mesh term's gradient arrives as dR2 (per-joint rotation-matrix gradient of the
+//    "orig" body); joint 0 adds it to dR, joints 1..23 pull it back through Rodrigues to axis-angle -- both
+//    are consumed right here, so they are added in registers instead of round-tripping through dR / dAA;
+//  * neg_rowsum: d trans_0 = - sum_s d trans_s (row N of dTR) is an independent reduction done by one extra
+//    block at the end of the grid.
+__global__ __launch_bounds__(256) void pose_bwd_fused_kernel(long N, const float* __restrict__ rot6d, long ld6,
+                                                             int zero_nan, const float* __restrict__ dR,
+                                                             const float* __restrict__ daa,
+                                                             float* __restrict__ d_rot6d, long ldd,
+                                                             const float* __restrict__ aa,
+                                                             const float* __restrict__ dR2, float scale,
+                                                             float* __restrict__ dTR, long ldt) {
+    if (blockIdx.x == gridDim.x - 1) {                 // the reduction block
+        if (!dTR) return;
+        __shared__ float red[16];
+        for (int c = 0; c < 3; ++c) {
+            float s = 0.f;
+            for (long r = threadIdx.x; r < N; r += blockDim.x) s += dTR[r * ldt + c];
+            const float t = block_sum(s, red);
+            if (threadIdx.x == 0) dTR[N * ldt + c] = -t;
+        }
+        return;
+    }
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 24) return;
+    const long row = i / 24;
+    const int j = (int)(i % 24);
+    float x[6], Rm[9], g[9];
+    const float* src = rot6d + row * ld6 + j * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[k] = src[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = dR ? dR[i * 9 + k] : 0.f;
+    float ga[3] = {0.f, 0.f, 0.f};
+    if (daa) { ga[0] = daa[i * 3]; ga[1] = daa[i * 3 + 1]; ga[2] = daa[i * 3 + 2]; }
+    if (dR2) {
+        float G[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) G[k] = dR2[i * 9 + k];
+        if (j == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) g[k] += scale * G[k];
+        } else {
+            const float t[3] = {aa[row * 72 + j * 3], aa[row * 72 + j * 3 + 1], aa[row * 72 + j * 3 + 2]};
+            float d[3];
+            rodrigues_bwd(t, G, d);
+            ga[0] += scale * d[0]; ga[1] += scale * d[1]; ga[2] += scale * d[2];
+        }
+    }
+    if (ga[0] != 0.f || ga[1] != 0.f || ga[2] != 0.f) {
+        rot6d_fwd(x, Rm);
+        rotmat_to_aa_bwd(Rm, zero_nan, ga, g);
+    }
+    float dx[6];
+    rot6d_bwd(x, g, dx);
+    float* dst = d_rot6d + row * ldd + j * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dst[k] = dx[k];
+}
+
 __global__ __launch_bounds__(1024) void neg_rowsum_kernel(long N, int cols, const float* __restrict__ X,
                                                           long ldx, float* __restrict__ out) {
     __shared__ float red[16];
@@ -429,6 +491,21 @@ extern "C" int32_t nemo_rot6d_bwd(int64_t rows, int64_t J, const float* rot6d, i
     if (rows == 0) return NEMO_OK;
     hipLaunchKernelGGL(rot6d_bwd_kernel, GRID1D(rows * J), (long)(rows * J), (int)J, rot6d, (long)ld6,
                        (int)zero_nan, dR, daa, d_rot6d, (long)ldd);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+
+extern "C" int32_t nemo_pose_bwd_fused(int64_t N, const float* rot6d, int64_t ld6, int32_t zero_nan,
+                                       const float* dR, const float* daa, float* d_rot6d, int64_t ldd,
+                                       const float* aa, const float* dR2, float v2v_scale,
+                                       float* dTR, int64_t ldt, void* stream) {
+    if (N < 0 || !rot6d || !d_rot6d || ld6 < 144 || ldd < 144 || (dR2 && !aa) || (dTR && ldt < 3))
+        return NEMO_EINVAL;
+    if (N == 0) return NEMO_OK;
+    const unsigned blocks = (unsigned)nemo_cdiv(N * 24, 256) + 1;          // + the reduction block
+    hipLaunchKernelGGL(pose_bwd_fused_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)N, rot6d,
+                       (long)ld6, (int)zero_nan, dR, daa, d_rot6d, (long)ldd, aa, dR2, v2v_scale, dTR, (long)ldt);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -453,13 +453,16 @@ class MultiViewModel(nn.Module):
         if not update:
             return
         st = _stream()
-        if use_vposer and a.weight_vp_loss:
-            check(e.lib.nemo_v2v_prep_bwd(N, dptr(w['AA']), dptr(w['dR2']),
-                                          float(a.weight_vp_loss) * sh.mr / float(N * e.NV * 3),
-                                          dptr(w['dAA']), dptr(w['dR']), st), 'nemo_v2v_prep_bwd')
-        check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, dptr(w['dR']), dptr(w['dAA']),
-                                   dptr(w['dROT']), HEAD_LD, st), 'nemo_rot6d_bwd')
-        e.finish_trans_grad(w, N)
+        # v2v_prep_bwd + rot6d_bwd + the trans_0 row sum in one launch
+        v2v = bool(use_vposer and a.weight_vp_loss)
+        anchored = not e.start_global_traj_anywhere
+        check(e.lib.nemo_pose_bwd_fused(
+            N, dptr(w['ROT']), HEAD_LD, 1, dptr(w['dR']), dptr(w['dAA']), dptr(w['dROT']), HEAD_LD,
+            dptr(w['AA']) if v2v else None, dptr(w['dR2']) if v2v else None,
+            float(a.weight_vp_loss) * sh.mr / float(N * e.NV * 3) if v2v else 0.0,
+            dptr(w['dTR']) if anchored else None, HEAD_LD, st), 'nemo_pose_bwd_fused')
+        if not anchored:
+            e.finish_trans_grad(w, N)
         e.backward_mlp(w, N, vi, fi, None)
 
     def step(self, view_idx, frame_idx, update=True, full_batch=False, _shard=None):

@@ -592,3 +592,36 @@ def test_fused_adam_matches_torch(L, adamw, wd):
         assert L.nemo_adam_step(2, seg, p.data_ptr(), H.dev(gr).data_ptr(), m.data_ptr(), v.data_ptr(), 0.9,
                                 0.999, 1e-8, H.st()) == 0
     assert rel_err(p, pt.detach()) < 1e-6
+
+
+def test_pose_bwd_fused_equals_the_three_launches(L):
+    """nemo_pose_bwd_fused == nemo_v2v_prep_bwd -> nemo_rot6d_bwd -> nemo_scale_neg_rowsum on the same inputs,
+    with and without the optional parts (1e-6: two kernels compiled from the same expressions contract
+    their FMAs differently)."""
+    H = _ops()
+    g = torch.Generator().manual_seed(11)
+    N, LD = 37, 148
+    head = H.dev(torch.randn(N + 1, LD, generator=g))
+    head[:, :144] += H.dev(torch.tensor([1., 0, 0, 1, 0, 0]).repeat(24))
+    dR, dAA = H.dev(torch.randn(N, 24, 9, generator=g)), H.dev(torch.randn(N, 72, generator=g))
+    dAA[::3] = 0                                             # rows without an axis-angle gradient
+    AA, dR2 = H.dev(0.4 * torch.randn(N, 72, generator=g)), H.dev(torch.randn(N, 24, 9, generator=g))
+    dhead0 = H.dev(torch.randn(N + 1, LD, generator=g))
+    scale = 0.37
+    for v2v, anchored in ((True, True), (False, True), (True, False), (False, False)):
+        a_dR, a_dAA, a_dh = dR.clone(), dAA.clone(), dhead0.clone()
+        if v2v:
+            assert L.nemo_v2v_prep_bwd(N, AA.data_ptr(), dR2.data_ptr(), scale, a_dAA.data_ptr(), a_dR.data_ptr(),
+                                       H.st()) == 0
+        assert L.nemo_rot6d_bwd(N, 24, head.data_ptr(), LD, 1, a_dR.data_ptr(), a_dAA.data_ptr(), a_dh.data_ptr(),
+                                LD, H.st()) == 0
+        if anchored:
+            assert L.nemo_scale_neg_rowsum(N, 3, a_dh.data_ptr() + 4 * 144, LD,
+                                           a_dh.data_ptr() + 4 * (N * LD + 144), H.st()) == 0
+        b_dh = dhead0.clone()
+        assert L.nemo_pose_bwd_fused(N, head.data_ptr(), LD, 1, dR.data_ptr(), dAA.data_ptr(), b_dh.data_ptr(), LD,
+                                     AA.data_ptr() if v2v else None, dR2.data_ptr() if v2v else None, scale,
+                                     b_dh.data_ptr() + 4 * 144 if anchored else None, LD, H.st()) == 0
+        assert rel_err(b_dh[:N, :144], a_dh[:N, :144]) < 1e-6, (v2v, anchored)
+        assert rel_err(b_dh[N, 144:147], a_dh[N, 144:147]) < 1e-6
+        assert torch.equal(b_dh[:, 147:], dhead0[:, 147:]) and torch.equal(b_dh[:N, 144:147], dhead0[:N, 144:147])
