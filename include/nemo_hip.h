@@ -185,6 +185,21 @@ int32_t nemo_kp_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const 
                     int32_t loss_type, int32_t mean_mode, const float* view_acc, const float* norm,
                     float upstream, float* dA, float* dJp, float* dMq, float* dTR, int64_t lddt,
                     float* d_cams, void* stream);
+/* nemo_kp_bwd with an additional gradient dj3d_extra (N, n_out, 3) w.r.t. the 3-D output joints (world space,
+ * translation included) added before the pull-back through FK / the mesh functionals; cameras do not see it. */
+int32_t nemo_kp_bwd_ex(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A, const float* Jp,
+                       const float* Mq, int64_t ldq, const float* TR, int64_t ldt, int32_t add_trans,
+                       const int64_t* view_idx, const int64_t* frame_idx, const float* cams,
+                       const float* targets, const float* gt_size, float focal, float cx, float cy,
+                       int32_t loss_type, int32_t mean_mode, const float* view_acc, const float* norm,
+                       float upstream, float* dA, float* dJp, float* dMq, float* dTR, int64_t lddt,
+                       float* d_cams, const float* dj3d_extra, void* stream);
+/* Temporal smoothness of the output joints (an OPTIONAL term, not part of the published NemoV* step; formula
+ * of humor/humor/fitting/fitting_loss.py:366-370): j3d (V*T, J, 3) laid out (view, frame);
+ * *scalar_out += 0.5 * sum_{v,t<T-1,j} |j3d[v,t+1,j] - j3d[v,t,j]|^2;  dj3d (same shape, optional) = weight *
+ * its gradient (overwritten). */
+int32_t nemo_smooth_fwd_bwd(int64_t V, int64_t T, int64_t J, const float* j3d, float weight, float* scalar_out,
+                            float* dj3d, void* stream);
 /* Projection only (API parity: learned_camera_projection on arbitrary points (N,Jn,3)). */
 int32_t nemo_project(int64_t N, int64_t Jn, int64_t V, const float* pts, const int64_t* view_idx,
                      const float* cams, float focal, float cx, float cy, float* p2d, void* stream);

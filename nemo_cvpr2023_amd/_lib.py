@@ -63,6 +63,9 @@ SIGNATURES = {
     'nemo_kp_finalize': (i32, [i64, i64, i32, i32, ptr, ptr, ptr, ptr]),
     'nemo_kp_bwd': (i32, [ptr, i64, i64, i64, ptr, ptr, ptr, i64, ptr, i64, i32, ptr, ptr, ptr, ptr, ptr,
                           f32, f32, f32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i64, ptr, ptr]),
+    'nemo_kp_bwd_ex': (i32, [ptr, i64, i64, i64, ptr, ptr, ptr, i64, ptr, i64, i32, ptr, ptr, ptr, ptr, ptr,
+                             f32, f32, f32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr]),
+    'nemo_smooth_fwd_bwd': (i32, [i64, i64, i64, ptr, f32, ptr, ptr, ptr]),
     'nemo_project': (i32, [i64, i64, i64, ptr, ptr, ptr, f32, f32, f32, ptr, ptr]),
     'nemo_skin_vertices': (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, ptr]),
     'nemo_v2v_skin_l1': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr]),

@@ -649,7 +649,8 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
                                                      const float* __restrict__ norm, float upstream,
                                                      float* __restrict__ dA, float* __restrict__ dJp,
                                                      float* __restrict__ dMq, float* __restrict__ dTR,
-                                                     long lddt, float* __restrict__ d_cams, int nq) {
+                                                     long lddt, float* __restrict__ d_cams, int nq,
+                                                     const float* __restrict__ dj3d_extra) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long s = t / LANES;
     const int o = (int)(t % LANES);
@@ -699,6 +700,10 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
                               dpy * pos[2], dpz * pos[0], dpz * pos[1], dpz * pos[2]};
         dcam[0] = dpx; dcam[1] = dpy; dcam[2] = dpz;
         rot6d_bwd(cam + 3, dRc, dcam + 3);
+        if (dj3d_extra) {       // gradient of a world-space term on the output joints (temporal smoothness)
+            const float* x = dj3d_extra + (s * kc.n_out + o) * 3;
+            dpos[0] += x[0]; dpos[1] += x[1]; dpos[2] += x[2];
+        }
     }
     // camera gradient: reduce over the sample's joints (shuffles), then over the block's samples of the
     // same view (LDS), one atomic per (block, view, component)
@@ -1322,6 +1327,37 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     if (tid == 0) atomicAdd(loss_sum, tot);
 }
 
+
+// Temporal smoothness of the output joints, HuMoR's joints3d_smooth_loss
+// (humor/humor/fitting/fitting_loss.py:366-370): 0.5 * sum_{v,t,j} |J[v,t+1,j] - J[v,t,j]|^2 over complete
+// sequences laid out (view, frame).  One thread per (v, t, j): its share of the sum and the full gradient
+// of its own joint (both neighbours), no atomics except the block sums of the scalar.
+__global__ __launch_bounds__(256) void smooth_kernel(long V, long T, int J, const float* __restrict__ j3d,
+                                                     float weight, float* __restrict__ scalar_out,
+                                                     float* __restrict__ dj) {
+    __shared__ float red[16];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float part = 0.f;
+    if (i < V * T * J) {
+        const long t = (i / J) % T;
+        const float* c = j3d + i * 3;
+        float g[3] = {0.f, 0.f, 0.f};
+        if (t + 1 < T) {
+            const float* n = c + (long)J * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const float d = n[k] - c[k]; part += 0.5f * d * d; g[k] -= d; }
+        }
+        if (t > 0) {
+            const float* q = c - (long)J * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g[k] += c[k] - q[k];
+        }
+        if (dj) { dj[i * 3] = weight * g[0]; dj[i * 3 + 1] = weight * g[1]; dj[i * 3 + 2] = weight * g[2]; }
+    }
+    const float tot = block_sum(part, red);
+    if (threadIdx.x == 0 && tot != 0.f) atomicAdd(scalar_out, tot);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ C ABI
@@ -1403,14 +1439,14 @@ extern "C" int32_t nemo_kp_finalize(int64_t V, int64_t n_out, int32_t W, int32_t
     return NEMO_OK;
 }
 
-extern "C" int32_t nemo_kp_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A,
+static int32_t kp_bwd_impl(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A,
                                const float* Jp, const float* Mq, int64_t ldq, const float* TR, int64_t ldt,
                                int32_t add_trans, const int64_t* view_idx, const int64_t* frame_idx,
                                const float* cams, const float* targets, const float* gt_size, float focal,
                                float cx, float cy, int32_t loss_type, int32_t mean_mode,
                                const float* view_acc, const float* norm, float upstream, float* dA,
                                float* dJp, float* dMq, float* dTR, int64_t lddt, float* d_cams,
-                               void* stream) {
+                               const float* dj3d_extra, void* stream) {
     KpArgs a;
     const int rc = kp_args(ctx, a, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams,
                            targets, gt_size, focal, cx, cy, loss_type, mean_mode);
@@ -1420,7 +1456,42 @@ extern "C" int32_t nemo_kp_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_
     if (N == 0) return NEMO_OK;
     if (ctx->n_out > 32) return NEMO_EINVAL;
     hipLaunchKernelGGL(kp_bwd_kernel<32>, dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       ctx->kc, view_acc, norm, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams, (int)ctx->nq);
+                       ctx->kc, view_acc, norm, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams, (int)ctx->nq, dj3d_extra);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_kp_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A,
+                               const float* Jp, const float* Mq, int64_t ldq, const float* TR, int64_t ldt,
+                               int32_t add_trans, const int64_t* view_idx, const int64_t* frame_idx,
+                               const float* cams, const float* targets, const float* gt_size, float focal,
+                               float cx, float cy, int32_t loss_type, int32_t mean_mode,
+                               const float* view_acc, const float* norm, float upstream, float* dA,
+                               float* dJp, float* dMq, float* dTR, int64_t lddt, float* d_cams,
+                               void* stream) {
+    return kp_bwd_impl(ctx, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams, targets,
+                       gt_size, focal, cx, cy, loss_type, mean_mode, view_acc, norm, upstream, dA, dJp, dMq, dTR,
+                       lddt, d_cams, nullptr, stream);
+}
+
+extern "C" int32_t nemo_kp_bwd_ex(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A,
+                                  const float* Jp, const float* Mq, int64_t ldq, const float* TR, int64_t ldt,
+                                  int32_t add_trans, const int64_t* view_idx, const int64_t* frame_idx,
+                                  const float* cams, const float* targets, const float* gt_size, float focal,
+                                  float cx, float cy, int32_t loss_type, int32_t mean_mode,
+                                  const float* view_acc, const float* norm, float upstream, float* dA,
+                                  float* dJp, float* dMq, float* dTR, int64_t lddt, float* d_cams,
+                                  const float* dj3d_extra, void* stream) {
+    return kp_bwd_impl(ctx, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams, targets,
+                       gt_size, focal, cx, cy, loss_type, mean_mode, view_acc, norm, upstream, dA, dJp, dMq, dTR,
+                       lddt, d_cams, dj3d_extra, stream);
+}
+
+extern "C" int32_t nemo_smooth_fwd_bwd(int64_t V, int64_t T, int64_t J, const float* j3d, float weight,
+                                       float* scalar_out, float* dj3d, void* stream) {
+    if (V <= 0 || T <= 0 || J <= 0 || !j3d || !scalar_out) return NEMO_EINVAL;
+    hipLaunchKernelGGL(smooth_kernel, dim3(nemo_cdiv(V * T * J, 256)), dim3(256), 0, (hipStream_t)stream, (long)V,
+                       (long)T, (int)J, j3d, weight, scalar_out, dj3d);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

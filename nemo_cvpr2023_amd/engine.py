@@ -32,7 +32,7 @@ RBF_KERNELS = {'quadratic': 0, 'linear': 1, 'gaussian': 2, 'inverse_quadratic': 
                'inverse_multiquadric': 5, 'spline': 6, 'poisson_one': 7, 'poisson_two': 8, 'matern32': 9,
                'matern52': 10}
 # slots of the per-step device scalar buffer
-S_KP, S_V2V, S_KL, S_GMM, S_3D = 0, 1, 2, 3, 4
+S_KP, S_V2V, S_KL, S_GMM, S_3D = 0, 1, 2, 3, 4          # (5: instance-code term, 6: temporal smoothness)
 HEAD_LD = 148      # row stride of the merged MLP head output [rot6d 144 | trans 3 | pad]
 
 
@@ -276,7 +276,7 @@ class FitEngine:
             X=Z(N + 1, self.ldx), H1=Z(N + 1, h), H2=Z(N + 1, h), H3=Z(N + 1, h), HEAD=Z(N + 1, HEAD_LD),
             phase=Z(N), phase_ws=Z(N, 4), gmm_ws=Z(N, self.gmm['M']), R=Z(N, 24, 9), AA=Z(N, 72), A=Z(N, 24, 12), Jp=Z(N, 24, 3),
             PF=Z(N, 208), Mq=Z(N, max(nq * 72, 1)), j3d=Z(N, self.ctx.n_out, 3), p2d=Z(N, self.ctx.n_out, 2),
-            loss_all=Z(N, self.ctx.n_out, 2), norm=Z(1),
+            loss_all=Z(N, self.ctx.n_out, 2), norm=Z(1), dj3d=Z(N, self.ctx.n_out, 3),
             E1=Z(N, 512), MULV=Z(N, 64), D1=Z(N, 512), D2=Z(N, 512),
             D3=Z(N, 126), AAdec=Z(N, 63),
             R2=Z(2 * Nc, 24, 9), A2=Z(2 * Nc, 24, 12), Jp2=Z(2 * Nc, 24, 3), PF2=Z(2 * Nc, 208),
@@ -452,18 +452,19 @@ class FitEngine:
 
     # ------------------------------------------------------------------ backward pieces
     def backward_kp(self, w, N, view_idx, frame_idx, Mq, mean_mode, upstream, cams_only=False,
-                    detach_pose=False):
+                    detach_pose=False, dj3d_extra=None):
         L, st, ctx = self.lib, _stream(), self.ctx
         nq72 = max(ctx.nq * 72, 1)
         lt = LOSS_TYPES[self.args.loss]
         add_trans = 0 if self.start_global_traj_anywhere else 1
-        check(L.nemo_kp_bwd(
+        check(L.nemo_kp_bwd_ex(
             ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), nq72, dptr(w['TR']),
             HEAD_LD, add_trans, dptr(view_idx), dptr(frame_idx), self.p('learned_cameras'), dptr(self.targets),
             dptr(self.gt_size), FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode, dptr(w['view_acc']),
             dptr(w['norm']), upstream, None if cams_only else dptr(w['dA']),
             None if cams_only else dptr(w['dJp']), None if cams_only else dptr(w['dMq']),
-            None if cams_only else dptr(w['dTR']), HEAD_LD, self.g('learned_cameras'), st), 'nemo_kp_bwd')
+            None if cams_only else dptr(w['dTR']), HEAD_LD, self.g('learned_cameras'), dptr(dj3d_extra), st),
+            'nemo_kp_bwd_ex')
         if cams_only:
             return
         if self.detach_articulation:

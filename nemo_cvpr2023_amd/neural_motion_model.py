@@ -32,6 +32,7 @@ from ._lib import check, dptr
 from .engine import (FOCAL_LENGTH, HEAD_LD, LOSS_TYPES, S_3D, S_GMM, S_KL, S_KP, S_V2V, FitEngine, _stream)
 
 S_INST = 5
+S_SMOOTH = 6
 
 
 class _LazyInfo(dict):
@@ -406,7 +407,8 @@ class MultiViewModel(nn.Module):
         return {k: v.reshape(V, T, *v.shape[1:]) for k, v in p.items()}
 
     # ------------------------------------------------------------------ the hot path
-    def _forward_backward(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False, sh=None):
+    def _forward_backward(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False, sh=None,
+                          smooth_ok=False):
         """Forward of :3511-3584 (+V3 extras) and, when ``update``, the whole backward down to the
         parameter gradients.  After the pose MLP the step forks into two independent branches that
         run CONCURRENTLY on two HIP streams (most of their kernels are too small to fill 256 CUs):
@@ -443,8 +445,18 @@ class MultiViewModel(nn.Module):
                                                 float(a.weight_3d_loss) * sh.mr, daa69 if update else None,
                                                 72, st), 'nemo_pose3d_fwd_bwd')
         Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0)
+        # optional temporal smoothness of the output joints (not part of the published step; only defined on
+        # complete (view, frame) sequences, i.e. full-batch steps -- see DESIGN.md section 8, row f-4)
+        dj = None
+        w_s = float(getattr(a, 'weight_smooth', 0) or 0)
+        if w_s and N == e.V * e.T and smooth_ok:
+            check(e.lib.nemo_smooth_fwd_bwd(e.V, e.T, e.ctx.n_out, dptr(w['j3d']), w_s,
+                                            e.scal.data_ptr() + 4 * S_SMOOTH, dptr(w['dj3d']) if update else None,
+                                            _stream()), 'nemo_smooth_fwd_bwd')
+            dj = w['dj3d'] if update else None
         if update:
-            e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose)
+            e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose,
+                          dj3d_extra=dj)
         main.wait_stream(side)
         # the fused mesh kernel is sized to fill the machine in exactly one resident wave of blocks:
         # it runs alone (anything co-scheduled pushes part of its grid into a second wave, +60 %)
@@ -471,7 +483,8 @@ class MultiViewModel(nn.Module):
         sh = _shard or ShardInfo()
         if self.VERSION >= 3 and update:
             self.training = True
-        if a.batch_size > -1 and not full_batch:
+        is_full = not (a.batch_size > -1 and not full_batch)
+        if not is_full:
             vi, fi = self._idx(view_idx), self._idx(frame_idx)
         else:
             vi, fi = self.full_indices()
@@ -483,7 +496,7 @@ class MultiViewModel(nn.Module):
         def body(vi_, fi_, adam_table):
             """Everything of the step that runs on the device without host interaction."""
             if N > 0:
-                self._forward_backward(w, N, vi_, fi_, update, sh=sh)
+                self._forward_backward(w, N, vi_, fi_, update, sh=sh, smooth_ok=is_full)
             else:                       # a shard may own none of a minibatch's samples
                 e.scal.zero_()
                 if update:
@@ -507,7 +520,7 @@ class MultiViewModel(nn.Module):
         # the fused Adam runs inside the captured graph unless a gradient all-reduce must come first
         in_graph_adam = update and sh.comm is None
         if graphable:
-            key = (bool(update), sh.kr, sh.mr, sh.vr, sh.comm is not None,
+            key = (bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None,
                    tuple((s_['offset'], s_['numel']) for s_ in segs) if in_graph_adam else None)
             src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N)
             if w.get('_static_src') != src or vi is not w.get('_static_vi'):   # (full batch: cached, unchanged)
@@ -555,6 +568,10 @@ class MultiViewModel(nn.Module):
             loss_dict['loss_3d'] = np.asarray(l3d)
         if a.weight_gmm_loss:
             loss = f32(loss + f32(a.weight_gmm_loss) * gmm)
+        w_s = float(getattr(a, 'weight_smooth', 0) or 0)
+        if w_s and is_full:                  # optional term, an extra key only when it is switched on
+            loss = f32(loss + f32(w_s) * f32(s[S_SMOOTH]))
+            loss_dict['smooth_loss'] = np.asarray(f32(s[S_SMOOTH]))
         loss_dict.update(gmm_loss=np.asarray(gmm), vp_recon_loss=np.asarray(v2v), vp_kl_loss=np.asarray(kl),
                          total_loss=np.asarray(loss))
         # Non-scalar outputs.  Evaluation steps (update=False; what the script dumps with joblib)
@@ -588,7 +605,7 @@ class MultiViewModel(nn.Module):
                 self._shard_w = {}
             if len(self._shard_w) > 256:
                 self._shard_w.clear()
-            wv = self._shard_w[key] = torch.tensor([sh.kr, 1.0, sh.mr, sh.mr, sh.mr, sh.vr, 0.0, 0.0],
+            wv = self._shard_w[key] = torch.tensor([sh.kr, 1.0, sh.mr, sh.mr, sh.mr, sh.vr, 1.0, 0.0],
                                                    device=self.device)
         slot = e.view('_comm_scalars', e.grads)
         torch.mul(e.scal, wv, out=slot)

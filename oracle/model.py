@@ -255,9 +255,11 @@ class OracleNemo:
             kr, mr, vr, comm = shard['kr'], shard['mr'], shard['vr'], shard['comm']
         if self.version >= 3 and update:
             self.training = True
-        if not (a.batch_size > -1 and not full_batch):
+        is_full = not (a.batch_size > -1 and not full_batch)
+        if is_full:
             view_idx, frame_idx = self.full_indices()
         N = len(view_idx)
+        smooth = None
         zero = torch.zeros(())
         terms = dict(kp=zero, v2v=zero, kl=zero, gmm=zero, l3=zero, inst=zero)
         info = {'view_idx': view_idx, 'frame_idx': frame_idx}
@@ -273,6 +275,11 @@ class OracleNemo:
                                                      self.hmr_mask[view_idx, frame_idx], None,
                                                      'mse_robust').mean()
             terms['gmm'] = mr * self.prior(pd['poses']).mean()                          # :2758-2773
+            if is_full and getattr(a, 'weight_smooth', 0):
+                # OPTIONAL extension (not in the published NemoV* step): HuMoR's joints3d_smooth_loss,
+                # humor/humor/fitting/fitting_loss.py:366-370, on the 25 output joints of complete sequences
+                jj = pd['j'].reshape(self.V, self.T, -1, 3)
+                smooth = 0.5 * ((jj[:, 1:] - jj[:, :-1]) ** 2).sum()
             info.update(loss_all=loss_all.detach(), points2d_gt=gt, points2d=p2d.detach(),
                         j=pd['j'].detach())
         if self.version >= 3 and a.weight_instance_loss:
@@ -289,6 +296,8 @@ class OracleNemo:
                 loss = loss + a.weight_3d_loss * terms['l3']
         if a.weight_gmm_loss:
             loss = loss + a.weight_gmm_loss * terms['gmm']
+        if smooth is not None:
+            loss = loss + a.weight_smooth * smooth
         if update:
             for o in self.optimizers:
                 o.zero_grad()
@@ -316,6 +325,8 @@ class OracleNemo:
             out['instance_loss'] = scal[5] if a.weight_instance_loss else 0
             if a.weight_3d_loss:
                 out['loss_3d'] = scal[4]
+        if smooth is not None:
+            out['smooth_loss'] = smooth.detach().float()
         loss_dict = {k: np.asarray(v.cpu().numpy() if isinstance(v, torch.Tensor) else v, dtype=np.float32)
                      for k, v in out.items()}
         self.training = False

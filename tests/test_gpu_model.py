@@ -358,3 +358,34 @@ def test_loss_curve_parity_real_size():
                        for k in ('kp_loss', 'gmm_loss', 'vp_recon_loss', 'vp_kl_loss', 'total_loss')))
     assert max(rel[:3]) < 1e-4, rel[:3]
     assert max(rel) < 1e-3, rel
+
+
+def test_optional_temporal_smoothness_term():
+    """SURVEY 8f-4 (an extension, off by default): with args.weight_smooth > 0 a full-batch step adds
+    w * 0.5 * sum |J[v,t+1] - J[v,t]|^2 over the 25 output joints; value and every parameter gradient must
+    match the oracle's autograd, and minibatch steps / weight 0 must be untouched."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    from oracle.model import OracleNemo
+    V, T = 3, 9
+    args = syn.published_args(h_dim=48, monotonic_network_n_nodes=20, batch_size=8, out_dir='', phase_rbf_dim=16)
+    args.weight_smooth = 50.0
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(128, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    torch.manual_seed(0)
+    m = NemoV2(args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+    with torch.no_grad():                                   # make the motion non-trivial
+        for k, p in m.named_parameters():
+            if 'learned_motion' in k and 'weight' in k:
+                p.add_(0.05 * torch.randn_like(p))
+    o = OracleNemo(2, args, seqs, assets, vps, gmm, state={k: v.cpu() for k, v in m.state_dict().items()})
+    lm, _ = m.step(None, None, update=True, full_batch=True)
+    lo, _ = o.step(None, None, update=True, full_batch=True)
+    assert float(lo['smooth_loss']) > 0
+    for k in lo:
+        assert rel_err(lm[k], lo[k]) < 1e-4, (k, lm[k], lo[k])
+    named = dict(m.named_parameters())
+    for k, p in o.P.items():
+        if k != 'learned_betas' and p.grad is not None and float(p.grad.abs().max()) > 0:
+            assert rel_err(named[k].grad, p.grad) < 2e-3, k
+    vi, fi = torch.randint(0, V, (8,)), torch.randint(0, T, (8,))
+    assert 'smooth_loss' not in m.step(vi, fi)[0] and 'smooth_loss' not in o.step(vi, fi)[0]
