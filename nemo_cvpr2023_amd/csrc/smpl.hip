@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const
 __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     long N, long NV, const float* __restrict__ PF2, long ldpf, const float* __restrict__ A2,
     const float* __restrict__ P, long ldP, const float* __restrict__ vs, const float* __restrict__ W,
-    int tiles_per_range, int vec_stage, float* __restrict__ loss_sum, float* __restrict__ dVPt, long ldn,
+    int cpg, int total, int maxc, int vec_stage, float* __restrict__ loss_sum, float* __restrict__ dVPt, long ldn,
     float* __restrict__ dA, float* __restrict__ parts, int* __restrict__ tickets) {
     // All constants are zero-padded by nemo_ctx_create (P: 224 rows x 3*NVp columns, W / v_shaped: NVp
     // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
@@ -1000,14 +1000,36 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     float* pfL = lds;                                   // [2][16][MF_PFS]
     float* AL = lds + 2 * 16 * MF_PFS;                  // [2][16][MF_AS], entry (e*24 + j)
     __shared__ float red[16];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const long ntiles = (NV + 15) / 16;
+    // Work = (sample group, chunk of 4 vertex tiles) pairs, group-major (cpg chunks per group, `total` in
+    // all); block b of B takes the contiguous share [total*b/B, total*(b+1)/B) -- the same number of chunks
+    // +-1 for every block, so all resident slots finish together (a groups x ranges grid left 12 % of them
+    // idle at N = 2400).  A share is at most one group long (the host picks B), so it is one or two
+    // segments (group, tile range); the blocks that overlap a group are its partial-sum contributors.
+    const int B = gridDim.x, bid = blockIdx.x;
+    const int c_beg = (int)(((long)total * bid) / B), c_end = (int)(((long)total * (bid + 1)) / B);
+    float lsum = 0.f;
+#pragma unroll 1
+    for (int seg = 0; seg < 2; ++seg) {
+    // lane-derived offsets are re-derived per segment (the asm keeps hipcc from hoisting them -- and the
+    // address arithmetic that hangs off them -- out of the loop, which cost > 100 spilled VGPRs)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): tile indices, offsets
     const int l15 = lane & 15, g = lane >> 4;
-    const long ntiles = (NV + 15) / 16;
-    const long s0 = (long)blockIdx.x * 16;
-    const long t_beg = (long)blockIdx.y * tiles_per_range;
-    const long t_end = min(ntiles, t_beg + tiles_per_range);
-    float lsum = 0.f;
+    const int grp = c_beg / cpg + seg;
+    const int k_beg = seg == 0 ? c_beg - grp * cpg : 0;
+    const int k_end = min(cpg, c_end - grp * cpg);
+    if (k_end <= k_beg) break;                            // block-uniform
+    // contributors of this group: the blocks holding its first and its last chunk, and everything between
+    const int b_lo = (int)((((long)grp * cpg + 1) * B + total - 1) / total) - 1;
+    const int b_hi = (int)((((long)(grp + 1) * cpg) * B + total - 1) / total) - 1;
+    const int nr = b_hi - b_lo + 1, slot = bid - b_lo;
+    const long s0 = (long)grp * 16;
+    const long t_beg = 4 * (long)k_beg;
+    const long t_end = min(ntiles, 4 * (long)k_end);
+    if (seg) __syncthreads();                             // LDS of the previous segment fully consumed
 
     // ---- stage the sample group: pf rows (224 incl. the zero pad) and transforms re-ordered to [e][j].
     // Vector path (16-byte aligned rows): a fixed number of independent, branch-free dwordx4 loads per
@@ -1258,12 +1280,11 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     // same-address fp32 atomics this used to cost (44 us at N = 2400, 95 us at N = 300).  All four waves of
     // the last arriver share the summation (wave w takes ranges w, w+4, ...: with 26 ranges per group at a
     // one-instance shard a single wave spent ~35 us on 26 dependent memory round trips).
-    const int nr = gridDim.y;
     __shared__ int ticket_old;
     if (wid == 0) {
         take(0);
         if (nr > 1) {
-            float* part = parts + ((size_t)blockIdx.x * nr + blockIdx.y) * (96 * 64);
+            float* part = parts + ((size_t)grp * maxc + slot) * (96 * 64);
 #pragma unroll
             for (int e = 0; e < 12; ++e)
 #pragma unroll
@@ -1274,15 +1295,15 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1 store
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0)
-                ticket_old = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ticket_old = __hip_atomic_fetch_add(tickets + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
     const bool finish = nr == 1 || ticket_old == nr - 1;      // block-uniform
     if (nr > 1 && finish) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (tid == 0) __hip_atomic_store(tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float* base = parts + (size_t)blockIdx.x * nr * (96 * 64) + lane;
+        if (tid == 0) __hip_atomic_store(tickets + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float* base = parts + (size_t)grp * maxc * (96 * 64) + lane;
 #pragma unroll
         for (int e = 0; e < 12; ++e)
 #pragma unroll
@@ -1323,8 +1344,9 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                     if (j < 24) dA[(s0 + l15) * 288 + j * 12 + e] = accdA[e][t][r];
                 }
     }
+    }   // segment
     const float tot = block_sum(lsum, red);
-    if (tid == 0) atomicAdd(loss_sum, tot);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, tot);
 }
 
 
@@ -1536,14 +1558,29 @@ extern "C" int32_t nemo_v2v_skin_l1(const nemo_ctx* ctx, int64_t N, const float*
     return NEMO_OK;
 }
 
+// Grid of the fused mesh kernel: B blocks, each an equal share of the (group, 4-tile chunk) list, at most one
+// group long (so <= 2 segments per block); maxc = upper bound of the blocks overlapping one group.
+struct MeshPlan { int cpg, total, B, maxc; };
+static MeshPlan mesh_plan(long groups, long ntiles) {
+    MeshPlan p;
+    p.cpg = (int)((ntiles + 3) / 4);
+    p.total = (int)(groups * p.cpg);
+    long B = groups > 512 ? groups : 512;
+    if (B > p.total / 4) B = p.total / 4 > 0 ? p.total / 4 : 1;          // at least ~4 chunks (one tile per wave) each
+    if (const char* e = getenv("NEMO_MESH_BLOCKS")) B = atol(e);         // tuning aid
+    if (B < groups) B = groups;                                          // a share never exceeds one group
+    if (B > p.total) B = p.total;
+    p.B = (int)B;
+    p.maxc = (int)(B / groups) + 2;
+    return p;
+}
+
 extern "C" int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N) {
     if (!ctx || N < 0) return -1;
     const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
-    long nr = 500 / (groups > 0 ? groups : 1);
-    if (const char* e = getenv("NEMO_MESH_NR")) nr = atol(e);
-    if (nr < 1) nr = 1;
-    if (nr > (ntiles + 3) / 4) nr = (ntiles + 3) / 4;
-    return 16384 + ((groups * 4 + 15) / 16) * 16 + groups * nr * 96 * 64 * 4;
+    if (groups == 0) return 16384;
+    const MeshPlan pl = mesh_plan(groups, ntiles);
+    return 16384 + ((groups * 4 + 15) / 16) * 16 + groups * (long)pl.maxc * 96 * 64 * 4;
 }
 
 extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
@@ -1561,24 +1598,18 @@ extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* P
     }
     const int vec_stage = (ldpf % 4 == 0) && (((uintptr_t)PF2 | (uintptr_t)A2) & 15) == 0 && ldpf >= 208;
     const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
-    // at most 256 CUs x 2 resident blocks: the whole grid must be co-resident (a second, partially
-    // filled wave of blocks costs up to 2x), and as close to that as the vertex ranges allow
-    long nr = 500 / groups;
-    if (const char* e = getenv("NEMO_MESH_NR")) nr = atol(e);      // tuning aid
-    if (nr < 1) nr = 1;
-    if (nr > (ntiles + 3) / 4) nr = (ntiles + 3) / 4;
-    const int tpr = (int)((ntiles + nr - 1) / nr);
-    nr = (ntiles + tpr - 1) / tpr;
+    const MeshPlan pl = mesh_plan(groups, ntiles);
     // scratch: one arrival ticket per sample group (zero at allocation, returned to zero by the kernel) and
-    // the per-range partial dA images
+    // the partial dA images of the blocks that overlap a group
     const long ticket_bytes = ((groups * 4 + 15) / 16) * 16;
-    if (nr > 1 && (!ws || (((uintptr_t)ws) & 15) || ws_bytes < ticket_bytes + groups * nr * 96 * 64 * 4))
+    if (!ws || (((uintptr_t)ws) & 15) || ws_bytes < ticket_bytes + groups * (long)pl.maxc * 96 * 64 * 4)
         return NEMO_EINVAL;
     int* tickets = reinterpret_cast<int*>(ws);
     float* parts = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ticket_bytes);
-    hipLaunchKernelGGL(mesh_v2v_fused_kernel, dim3((unsigned)groups, (unsigned)nr), dim3(256), lds_bytes,
+    hipLaunchKernelGGL(mesh_v2v_fused_kernel, dim3((unsigned)pl.B), dim3(256), lds_bytes,
                        (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, ctx->d_posedirs, ctx->ldP,
-                       ctx->d_v_shaped, ctx->d_W, tpr, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets);
+                       ctx->d_v_shaped, ctx->d_W, pl.cpg, pl.total, pl.maxc, vec_stage, loss_sum, dVPt, (long)ldn,
+                       dA, parts, tickets);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
