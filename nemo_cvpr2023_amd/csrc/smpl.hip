@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const
 __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     long N, long NV, const float* __restrict__ PF2, long ldpf, const float* __restrict__ A2,
     const float* __restrict__ P, long ldP, const float* __restrict__ vs, const float* __restrict__ W,
-    int cpg, int total, int maxc, int vec_stage, float* __restrict__ loss_sum, float* __restrict__ dVPt, long ldn,
+    int G, int cpg, int RA, int CA, int nB, int vec_stage, float* __restrict__ loss_sum, float* __restrict__ dVPt, long ldn,
     float* __restrict__ dA, float* __restrict__ parts, int* __restrict__ tickets) {
     // All constants are zero-padded by nemo_ctx_create (P: 224 rows x 3*NVp columns, W / v_shaped: NVp
     // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
@@ -1001,16 +1001,30 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     float* AL = lds + 2 * 16 * MF_PFS;                  // [2][16][MF_AS], entry (e*24 + j)
     __shared__ float red[16];
     const long ntiles = (NV + 15) / 16;
-    // Work = (sample group, chunk of 4 vertex tiles) pairs, group-major (cpg chunks per group, `total` in
-    // all); block b of B takes the contiguous share [total*b/B, total*(b+1)/B) -- the same number of chunks
-    // +-1 for every block, so all resident slots finish together (a groups x ranges grid left 12 % of them
-    // idle at N = 2400).  A share is at most one group long (the host picks B), so it is one or two
-    // segments (group, tile range); the blocks that overlap a group are its partial-sum contributors.
-    const int B = gridDim.x, bid = blockIdx.x;
-    const int c_beg = (int)(((long)total * bid) / B), c_end = (int)(((long)total * (bid + 1)) / B);
+    // Work = (sample group, chunk of 4 vertex tiles) units, G groups x cpg chunks.  Two classes of blocks, all
+    // co-resident (<= 512 = 2 per CU), planned on the host (mesh_plan) so that every block gets the same
+    // number of chunks:
+    //   A: bid < G*RA      one segment: group bid % G, the r-th of RA equal ranges of the chunks [0, CA)
+    //   B: bid >= G*RA     the left-over range [CA, cpg) of up to k consecutive groups, one segment per group
+    // Blocks of one range sweep the same vertex tiles in lock step, so a blend-shape tile is fetched into
+    // an XCD's L2 once per range and hit by the other blocks (an earlier 1-D split at arbitrary chunk
+    // offsets had every block on its own tile position: 10x the L2 fill traffic).  A group's partial dA
+    // sums come from its RA range blocks + its left-over segment.
+    const int bid = blockIdx.x, GA = G * RA;
+    int g_lo, nseg, k_beg, k_end, slot;
+    if (bid < GA) {
+        const int r = bid / G;
+        g_lo = bid - r * G; nseg = 1; slot = r;
+        k_beg = (int)(((long)r * CA) / RA); k_end = (int)(((long)(r + 1) * CA) / RA);
+    } else {
+        const int j = bid - GA;
+        g_lo = (int)(((long)G * j) / nB); nseg = (int)(((long)G * (j + 1)) / nB) - g_lo; slot = RA;
+        k_beg = CA; k_end = cpg;
+    }
+    const int nr = RA + (CA < cpg ? 1 : 0), maxc = RA + 1;
     float lsum = 0.f;
 #pragma unroll 1
-    for (int seg = 0; seg < 2; ++seg) {
+    for (int seg = 0; seg < nseg; ++seg) {
     // lane-derived offsets are re-derived per segment (the asm keeps hipcc from hoisting them -- and the
     // address arithmetic that hangs off them -- out of the loop, which cost > 100 spilled VGPRs)
     int tid = threadIdx.x;
@@ -1018,14 +1032,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): tile indices, offsets
     const int l15 = lane & 15, g = lane >> 4;
-    const int grp = c_beg / cpg + seg;
-    const int k_beg = seg == 0 ? c_beg - grp * cpg : 0;
-    const int k_end = min(cpg, c_end - grp * cpg);
-    if (k_end <= k_beg) break;                            // block-uniform
-    // contributors of this group: the blocks holding its first and its last chunk, and everything between
-    const int b_lo = (int)((((long)grp * cpg + 1) * B + total - 1) / total) - 1;
-    const int b_hi = (int)((((long)(grp + 1) * cpg) * B + total - 1) / total) - 1;
-    const int nr = b_hi - b_lo + 1, slot = bid - b_lo;
+    const int grp = g_lo + seg;
     const long s0 = (long)grp * 16;
     const long t_beg = 4 * (long)k_beg;
     const long t_end = min(ntiles, 4 * (long)k_end);
@@ -1558,21 +1565,44 @@ extern "C" int32_t nemo_v2v_skin_l1(const nemo_ctx* ctx, int64_t N, const float*
     return NEMO_OK;
 }
 
-// Grid of the fused mesh kernel: B blocks, each an equal share of the (group, 4-tile chunk) list, at most one
-// group long (so <= 2 segments per block); maxc = upper bound of the blocks overlapping one group.
-struct MeshPlan { int cpg, total, B, maxc; };
+// Grid of the fused mesh kernel (see the kernel): RA range blocks per sample group over the chunks [0, CA)
+// + nB blocks that each take the left-over range [CA, cpg) of up to k groups, G*RA + nB <= 512 co-resident
+// blocks.  Cost in chunk units: the longest block, an extra segment charged MESH_SEG_OVH chunks (staging +
+// partial-sum flush); ties go to fewer blocks.
+struct MeshPlan { int G, cpg, RA, CA, nB; };
+constexpr double MESH_SEG_OVH = 1.0;
 static MeshPlan mesh_plan(long groups, long ntiles) {
-    MeshPlan p;
-    p.cpg = (int)((ntiles + 3) / 4);
-    p.total = (int)(groups * p.cpg);
-    long B = groups > 512 ? groups : 512;
-    if (B > p.total / 4) B = p.total / 4 > 0 ? p.total / 4 : 1;          // at least ~4 chunks (one tile per wave) each
-    if (const char* e = getenv("NEMO_MESH_BLOCKS")) B = atol(e);         // tuning aid
-    if (B < groups) B = groups;                                          // a share never exceeds one group
-    if (B > p.total) B = p.total;
-    p.B = (int)B;
-    p.maxc = (int)(B / groups) + 2;
-    return p;
+    const int G = (int)groups, C = (int)((ntiles + 3) / 4);
+    static thread_local MeshPlan last{0, 0, 0, 0, 0};     // the search below is ~1e4 steps: keep the last answer
+    if (last.G == G && last.cpg == C) return last;
+    MeshPlan best{G, C, 1, C, 0};
+    if (G > 512) return best;                             // one block per group, more than one resident wave
+    if (G < 1) return best;
+    double best_cost = 1e30;
+    for (int RA = 1; RA * (long)G <= 512 && RA <= C; ++RA) {
+        for (int k = 0; k <= 16; ++k) {                   // k = 0: no left-over blocks
+            const int nB = k ? (G + k - 1) / k : 0;
+            if ((long)G * RA + nB > 512) continue;
+            const int keff = nB ? (G + nB - 1) / nB : 0;
+            for (int Lr = k ? 1 : 0; Lr <= (k ? C - RA : 0); ++Lr) {
+                const int CA = C - Lr;
+                const double ca = (CA + RA - 1) / RA;                             // longest A range
+                const double cb = k ? keff * Lr + (keff - 1) * MESH_SEG_OVH : 0;
+                const double cost = (ca > cb ? ca : cb) + 1e-4 * ((long)G * RA + nB);
+                if (cost < best_cost) { best_cost = cost; best = MeshPlan{G, C, RA, CA, nB}; }
+            }
+        }
+    }
+    if (const char* e = getenv("NEMO_MESH_PLAN")) {       // tuning aid: "RA,Lr,k"
+        int RA = 0, Lr = 0, k = 0;
+        if (sscanf(e, "%d,%d,%d", &RA, &Lr, &k) == 3 && RA >= 1 && Lr >= 0 && Lr < C && RA <= C - Lr &&
+            (Lr == 0 || k >= 1)) {
+            const int nB = Lr ? (G + k - 1) / k : 0;
+            best = MeshPlan{G, C, RA, C - Lr, nB};
+        }
+    }
+    last = best;
+    return best;
 }
 
 extern "C" int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N) {
@@ -1580,7 +1610,7 @@ extern "C" int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N) {
     const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
     if (groups == 0) return 16384;
     const MeshPlan pl = mesh_plan(groups, ntiles);
-    return 16384 + ((groups * 4 + 15) / 16) * 16 + groups * (long)pl.maxc * 96 * 64 * 4;
+    return 16384 + ((groups * 4 + 15) / 16) * 16 + groups * (long)(pl.RA + 1) * 96 * 64 * 4;
 }
 
 extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
@@ -1602,13 +1632,13 @@ extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* P
     // scratch: one arrival ticket per sample group (zero at allocation, returned to zero by the kernel) and
     // the partial dA images of the blocks that overlap a group
     const long ticket_bytes = ((groups * 4 + 15) / 16) * 16;
-    if (!ws || (((uintptr_t)ws) & 15) || ws_bytes < ticket_bytes + groups * (long)pl.maxc * 96 * 64 * 4)
+    if (!ws || (((uintptr_t)ws) & 15) || ws_bytes < ticket_bytes + groups * (long)(pl.RA + 1) * 96 * 64 * 4)
         return NEMO_EINVAL;
     int* tickets = reinterpret_cast<int*>(ws);
     float* parts = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ticket_bytes);
-    hipLaunchKernelGGL(mesh_v2v_fused_kernel, dim3((unsigned)pl.B), dim3(256), lds_bytes,
+    hipLaunchKernelGGL(mesh_v2v_fused_kernel, dim3((unsigned)(pl.G * pl.RA + pl.nB)), dim3(256), lds_bytes,
                        (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, ctx->d_posedirs, ctx->ldP,
-                       ctx->d_v_shaped, ctx->d_W, pl.cpg, pl.total, pl.maxc, vec_stage, loss_sum, dVPt, (long)ldn,
+                       ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA, pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn,
                        dA, parts, tickets);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
