@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 3
+#define NEMO_ABI_VERSION 4
 int32_t nemo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -246,6 +246,12 @@ int32_t nemo_v2v_prep_bwd(int64_t N, const float* aa, const float* dR2, float sc
  * KL( N(mu, softplus(lv)) || N(0,1) ) summed over L, averaged over N
  * (vposer_model.py:48-56, nemo/neural_motion_model.py:2795-2802).  mulv (N, 2L) = [mu | lv].
  * scalar_out += kl;  d_mulv (N,2L) = upstream-free gradient (d kl / d [mu|lv]), overwritten. */
+/* Loss read-back without a stream synchronisation (replaces the `.cpu()` read-backs of
+ * neural_motion_model.py:3578-3584, which block the host until the optimiser step has finished): copies
+ * src[0..n) (device, n <= 64) to host_dst and then stores 1 to *host_flag, both in PINNED host memory that
+ * the device can address (hipHostMalloc; coherent), with system-scope release ordering.  The caller clears
+ * *host_flag before enqueueing and polls it; kernels enqueued after this one keep running meanwhile. */
+int32_t nemo_publish_scalars(const float* src, int32_t n, float* host_dst, int32_t* host_flag, void* stream);
 int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int64_t ld, float* scalar_out,
                         float* d_mulv, int64_t ldd, void* stream);
 /* MaxMixturePrior (hmr/smplify/prior.py:181-196): per-sample min over M Gaussians, mean over N.

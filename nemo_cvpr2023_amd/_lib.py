@@ -26,7 +26,7 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 3        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 4        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -74,6 +74,7 @@ SIGNATURES = {
     'nemo_v2v_prep_fwd': (i32, [i64, ptr, ptr, ptr, ptr, ptr]),
     'nemo_v2v_prep_bwd': (i32, [i64, ptr, ptr, f32, ptr, ptr, ptr]),
     'nemo_kl_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, i64, ptr]),
+    'nemo_publish_scalars': (i32, [ptr, i32, ptr, ptr, ptr]),
     'nemo_gmm_fwd_bwd': (i32, [i64, i64, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, f32, ptr, i64, ptr]),
     'nemo_pose3d_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, f32, ptr, i64, ptr]),
     'nemo_adam_step': (i32, [i32, POINTER(AdamSeg), ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),

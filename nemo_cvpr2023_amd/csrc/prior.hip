@@ -309,7 +309,28 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamSegs segs, const nemo_ada
     }
 }
 
+// Loss read-back without a host-side stream synchronisation: the values become final in the middle of the
+// step (after the mesh kernel; the MLP backward and Adam follow), so one wave copies them to pinned,
+// device-mapped host memory and raises a flag the host polls -- the host returns the losses and prepares
+// the next launch while the rest of the step is still running.
+__global__ void publish_kernel(const float* __restrict__ src, int n, float* __restrict__ host_dst,
+                               int* __restrict__ host_flag) {
+    const int t = threadIdx.x;
+    if (t < n) __hip_atomic_store(host_dst + t, src[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (t == 0) __hip_atomic_store(host_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
+
+extern "C" int32_t nemo_publish_scalars(const float* src, int32_t n, float* host_dst, int32_t* host_flag,
+                                        void* stream) {
+    if (!src || !host_dst || !host_flag || n < 1 || n > 64) return NEMO_EINVAL;
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, (int)n, host_dst,
+                       (int*)host_flag);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
 
 extern "C" int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int64_t ld, float* scalar_out,
                                    float* d_mulv, int64_t ldd, void* stream) {

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time
 import math
 from collections import OrderedDict
 
@@ -224,6 +225,11 @@ class FitEngine:
         self.betas = torch.zeros(1, 10, **f32)
         self.scal = torch.zeros(8, **f32)
         self._scal_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+        # early loss read-back (publish_scalars / wait_scalars): 8 values + a flag in pinned memory
+        self._pub_host = torch.zeros(16, dtype=torch.float32).pin_memory()
+        self._pub_np = self._pub_host.numpy()
+        self._pub_flag = self._pub_np.view(np.int32)[8:9]
+        self.early_readback = os.environ.get('NEMO_EARLY_READBACK', '1') != '0'
         self.ws = {}
         self.side_stream = torch.cuda.Stream(device=self.device)   # prior branch of the step (see _forward_backward)
         # split-K scratch of nemo_gemm_f32 (arrival tickets + partial tiles), one per stream that launches GEMMs
@@ -608,3 +614,23 @@ class FitEngine:
         self._scal_host.copy_(self.scal, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         return self._scal_host.numpy().copy()
+
+    def publish_scalars(self):
+        """Enqueue (or capture) the copy of the loss scalars to pinned host memory + flag; everything
+        enqueued afterwards (MLP backward, Adam) keeps running while the host reads them."""
+        check(self.lib.nemo_publish_scalars(self.scal.data_ptr(), 8, self._pub_host.data_ptr(),
+                                            self._pub_host.data_ptr() + 32, _stream()), 'nemo_publish_scalars')
+
+    def arm_scalars(self):
+        """Host side, BEFORE the launch that contains publish_scalars (no publish may be in flight)."""
+        self._pub_flag[0] = 0
+
+    def wait_scalars(self, timeout_s=120.0):
+        flag, t0, spins = self._pub_flag, None, 0
+        while flag[0] == 0:
+            spins += 1
+            if spins & 0xFFFF == 0:              # look at the clock every 64 k polls only
+                t0 = t0 or time.monotonic()
+                if time.monotonic() - t0 > timeout_s:
+                    raise _lib.NemoHipError('loss read-back flag never raised (device fault or hung kernel?)')
+        return self._pub_np[:8].copy()

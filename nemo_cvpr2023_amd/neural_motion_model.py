@@ -408,7 +408,7 @@ class MultiViewModel(nn.Module):
 
     # ------------------------------------------------------------------ the hot path
     def _forward_backward(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False, sh=None,
-                          smooth_ok=False):
+                          smooth_ok=False, extra_losses=None, publish=False):
         """Forward of :3511-3584 (+V3 extras) and, when ``update``, the whole backward down to the
         parameter gradients.  After the pose MLP the step forks into two independent branches that
         run CONCURRENTLY on two HIP streams (most of their kernels are too small to fill 256 CUs):
@@ -462,6 +462,10 @@ class MultiViewModel(nn.Module):
         # it runs alone (anything co-scheduled pushes part of its grid into a second wave, +60 %)
         if use_vposer:
             e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss))
+        if extra_losses is not None:
+            extra_losses()
+        if publish:      # every loss scalar is final here: hand them to the host, the backward goes on
+            e.publish_scalars()
         if not update:
             return
         st = _stream()
@@ -495,21 +499,26 @@ class MultiViewModel(nn.Module):
 
         def body(vi_, fi_, adam_table):
             """Everything of the step that runs on the device without host interaction."""
-            if N > 0:
-                self._forward_backward(w, N, vi_, fi_, update, sh=sh, smooth_ok=is_full)
-            else:                       # a shard may own none of a minibatch's samples
-                e.scal.zero_()
-                if update:
-                    e.grads.zero_()
-            if has_inst:
+            def inst_term():
                 code = self.learned_instance_code.detach()
                 e.scal[S_INST] = (code ** 2).mean()                                       # :3864-3867
                 if update:
                     e.view('learned_instance_code', e.grads).add_(
                         code, alpha=2.0 * float(a.weight_instance_loss) * sh.vr / code.numel())
+            if N > 0:
+                self._forward_backward(w, N, vi_, fi_, update, sh=sh, smooth_ok=is_full,
+                                       extra_losses=inst_term if has_inst else None, publish=early)
+            else:                       # a shard may own none of a minibatch's samples
+                e.scal.zero_()
+                if update:
+                    e.grads.zero_()
+                if has_inst:
+                    inst_term()
             if adam_table is not None:
                 e.adam_from_table(*adam_table)
 
+        # single-GPU steps hand the losses to the host as soon as they are final (engine.publish_scalars)
+        early = e.early_readback and sh.comm is None and N > 0
         noise = self.VERSION >= 3 and self.training and getattr(a, 'code_noise', 0) > 0
         graphable = self.use_graphs and N > 0 and e.timers is None and not noise
         segs = None
@@ -519,13 +528,27 @@ class MultiViewModel(nn.Module):
                 segs += o.segments(None)
         # the fused Adam runs inside the captured graph unless a gradient all-reduce must come first
         in_graph_adam = update and sh.comm is None
+        if early:
+            e.arm_scalars()
         if graphable:
             key = (bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None,
                    tuple((s_['offset'], s_['numel']) for s_ in segs) if in_graph_adam else None)
             src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N)
             if w.get('_static_src') != src or vi is not w.get('_static_vi'):   # (full batch: cached, unchanged)
-                w['vi_static'].copy_(vi)
-                w['fi_static'].copy_(fi)
+                if vi.device.type == 'cpu' and fi.device.type == 'cpu':
+                    # through pinned staging: a pageable H2D copy would block the host until the previous
+                    # step (still running, see `early`) has drained.  The staging buffer is free: the
+                    # previous copy out of it was enqueued before the launch whose losses we already hold.
+                    if '_idx_pin' not in w:
+                        w['_idx_pin'] = torch.empty(2, w['vi_static'].numel(), dtype=w['vi_static'].dtype).pin_memory()
+                    pin = w['_idx_pin']
+                    pin[0, :N].copy_(vi)
+                    pin[1, :N].copy_(fi)
+                    w['vi_static'].copy_(pin[0, :N], non_blocking=True)
+                    w['fi_static'].copy_(pin[1, :N], non_blocking=True)
+                else:
+                    w['vi_static'].copy_(vi)
+                    w['fi_static'].copy_(fi)
                 w['_static_src'], w['_static_vi'] = src, vi
             table = e.adam_table_upload(segs) if in_graph_adam else None
             entry = w['graphs'].get(key)
@@ -545,9 +568,14 @@ class MultiViewModel(nn.Module):
             vi, fi = w['vi_static'], w['fi_static']
         else:
             body(vi, fi, None)
-        s = self._reduce_and_read(sh, update)
-        if update and not (graphable and in_graph_adam):
-            e.adam(segs)
+        if early:        # the losses arrive while the backward / Adam launches above are still running
+            if update and not (graphable and in_graph_adam):
+                e.adam(segs)
+            s = e.wait_scalars()
+        else:
+            s = self._reduce_and_read(sh, update)
+            if update and not (graphable and in_graph_adam):
+                e.adam(segs)
         f32 = np.float32
         kp = f32(s[S_KP])
         v2v = f32(s[S_V2V]) / f32((sh.n_global or N) * e.NV * 3)
