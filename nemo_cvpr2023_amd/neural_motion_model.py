@@ -573,9 +573,8 @@ class MultiViewModel(nn.Module):
                 e.adam(segs)
             s = e.wait_scalars()
         else:
-            s = self._reduce_and_read(sh, update)
-            if update and not (graphable and in_graph_adam):
-                e.adam(segs)
+            s = self._reduce_and_read(sh, update, then=(lambda: e.adam(segs))
+                                      if update and not (graphable and in_graph_adam) else None)
         f32 = np.float32
         kp = f32(s[S_KP])
         v2v = f32(s[S_V2V]) / f32((sh.n_global or N) * e.NV * 3)
@@ -620,26 +619,36 @@ class MultiViewModel(nn.Module):
         self.training = False
         return loss_dict, info_dict
 
-    def _reduce_and_read(self, sh, update):
-        """Loss scalars to the host (one 32-byte copy per step).  Sharded: the scalars are weighted
-        into global terms, ride along the shared-gradient all-reduce, and are read back reduced."""
+    def _reduce_and_read(self, sh, update, then=None):
+        """Loss scalars to the host (one 32-byte transfer per step).  Sharded: the scalars are weighted
+        into global terms, ride along the shared-gradient all-reduce, and are read back reduced.
+        ``then`` (the Adam launch) is enqueued before the host waits for the values when they travel
+        through pinned memory (engine.publish_scalars), after the synchronisation otherwise."""
         e = self.engine
-        if sh.comm is None:
-            return e.read_scalars()
-        key = (sh.kr, sh.mr, sh.vr)
-        wv = self._shard_w.get(key) if hasattr(self, '_shard_w') else None
-        if wv is None:                       # (cached: a host-to-device upload per step otherwise)
-            if not hasattr(self, '_shard_w'):
-                self._shard_w = {}
-            if len(self._shard_w) > 256:
-                self._shard_w.clear()
-            wv = self._shard_w[key] = torch.tensor([sh.kr, 1.0, sh.mr, sh.mr, sh.mr, sh.vr, 1.0, 0.0],
-                                                   device=self.device)
-        slot = e.view('_comm_scalars', e.grads)
-        torch.mul(e.scal, wv, out=slot)
-        sh.comm(e, update)
-        e.scal.copy_(slot)
-        return e.read_scalars()
+        if sh.comm is not None:
+            key = (sh.kr, sh.mr, sh.vr)
+            wv = self._shard_w.get(key) if hasattr(self, '_shard_w') else None
+            if wv is None:                       # (cached: a host-to-device upload per step otherwise)
+                if not hasattr(self, '_shard_w'):
+                    self._shard_w = {}
+                if len(self._shard_w) > 256:
+                    self._shard_w.clear()
+                wv = self._shard_w[key] = torch.tensor([sh.kr, 1.0, sh.mr, sh.mr, sh.mr, sh.vr, 1.0, 0.0],
+                                                       device=self.device)
+            slot = e.view('_comm_scalars', e.grads)
+            torch.mul(e.scal, wv, out=slot)
+            sh.comm(e, update)
+            e.scal.copy_(slot)
+        if e.early_readback:
+            e.arm_scalars()
+            e.publish_scalars()
+            if then is not None:
+                then()
+            return e.wait_scalars()
+        s = e.read_scalars()
+        if then is not None:
+            then()
+        return s
 
     def _loss_all(self, w, N):
         Wd = 1 if LOSS_TYPES[self.args.loss] in (2, 3, 5) else 2

@@ -389,3 +389,48 @@ def test_optional_temporal_smoothness_term():
             assert rel_err(named[k].grad, p.grad) < 2e-3, k
     vi, fi = torch.randint(0, V, (8,)), torch.randint(0, T, (8,))
     assert 'smooth_loss' not in m.step(vi, fi)[0] and 'smooth_loss' not in o.step(vi, fi)[0]
+
+
+@pytest.mark.parametrize('version', [2, 3])
+def test_early_loss_readback_equals_synchronous_readback(version):
+    """The step hands its loss scalars to the host through pinned memory as soon as they are final
+    (engine.publish_scalars) while backward + Adam still run.  Losses, per-step info and the state
+    read right after every step must equal those of the synchronous read-back (up to the run-to-run
+    rounding of the atomically reduced loss terms), in eager and in graph mode, for minibatch and
+    full-batch steps."""
+    from nemo_cvpr2023_amd.neural_motion_model import NEMO_VERSIONS
+    V, T, B = 3, 12, 16
+    args = syn.published_args(h_dim=48, monotonic_network_n_nodes=20, batch_size=B, out_dir='', phase_rbf_dim=16)
+    if version == 3:
+        args.weight_instance_loss, args.weight_3d_loss, args.instance_code_size = 0.5, 1.0, 5
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(128, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    runs = []
+    for early in (True, False):
+        torch.manual_seed(0)
+        m = NEMO_VERSIONS[version](args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+        m.engine.early_readback = early
+        gen = torch.Generator().manual_seed(5)
+        log = []
+        for it in range(8):
+            if it % 3 == 2:
+                ld, info = m.step(None, None, update=True, full_batch=True)
+            else:
+                vi, fi = torch.randint(0, V, (B,), generator=gen), torch.randint(0, T, (B,), generator=gen)
+                ld, info = m.step(vi, fi)
+            sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}    # right after the step
+            log.append(({k: np.asarray(v).copy() for k, v in ld.items()}, info['loss_all'].cpu().numpy(), sd))
+        ld, info = m.step(None, None, update=False, full_batch=True)
+        log.append(({k: np.asarray(v).copy() for k, v in ld.items()}, info['loss_all'].cpu().numpy(), {}))
+        runs.append(log)
+    for (la, ia, sa), (lb, ib, sb) in zip(*runs):
+        assert la.keys() == lb.keys()
+        for k in la:
+            assert rel_err(la[k], lb[k]) < 1e-4, (k, la[k], lb[k])
+        assert rel_err(ia, ib) < 1e-4
+        for k in sa:         # (Adam turns rounding noise on noise-level gradients into +-lr steps: sanity bound)
+            assert rel_err(sa[k], sb[k]) < 2e-2, k
+    for log in runs:         # a state read right after step k already holds update k
+        for (_, _, s0), (_, _, s1) in zip(log[:-2], log[1:-1]):
+            k = 'learned_motion.net.net.2.weight'
+            assert not torch.equal(s0[k], s1[k])

@@ -625,3 +625,25 @@ def test_pose_bwd_fused_equals_the_three_launches(L):
         assert rel_err(b_dh[:N, :144], a_dh[:N, :144]) < 1e-6, (v2v, anchored)
         assert rel_err(b_dh[N, 144:147], a_dh[N, 144:147]) < 1e-6
         assert torch.equal(b_dh[:, 147:], dhead0[:, 147:]) and torch.equal(b_dh[:N, 144:147], dhead0[:N, 144:147])
+
+
+def test_publish_scalars_to_pinned_host_memory(L):
+    """nemo_publish_scalars: device values + flag land in pinned host memory without a stream sync."""
+    import time
+    from nemo_cvpr2023_amd._lib import check
+    H = _ops()
+    src = H.dev(torch.arange(8, dtype=torch.float32) * 1.5 + 0.25)
+    host = torch.zeros(16, dtype=torch.float32).pin_memory()
+    flag = host.numpy().view(np.int32)[8:9]
+    for rep in range(3):
+        src.mul_(2.0)
+        want = src.cpu().numpy()
+        flag[0] = 0
+        check(L.nemo_publish_scalars(src.data_ptr(), 8, host.data_ptr(), host.data_ptr() + 32, H.st()),
+              'nemo_publish_scalars')
+        t0 = time.monotonic()
+        while flag[0] == 0:
+            assert time.monotonic() - t0 < 10.0, 'flag never raised'
+        assert np.array_equal(host.numpy()[:8], want)
+    assert L.nemo_publish_scalars(None, 8, host.data_ptr(), host.data_ptr() + 32, H.st()) < 0
+    assert L.nemo_publish_scalars(src.data_ptr(), 65, host.data_ptr(), host.data_ptr() + 32, H.st()) < 0
