@@ -37,6 +37,7 @@ struct GemmArgs {
     long M, N, K, lda, ldb, ldc, ldmask;
     long k_chunk;           // K range per slice (multiple of the K tile)
     int tiles_m, tiles_n, n_tiles, split;
+    int t0;                 // tiles [0, t0) are computed whole by one block each, tiles [t0, n_tiles) in `split` K slices
     int act, mask_mode, out_mode;
     float alpha;
 };
@@ -145,12 +146,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     float* const As0 = smem;
     float* const Bs0 = smem + 2 * SA::SIZE;
 
+    // Block -> (tile, K slice).  The first t0 tiles are whole; only the tail [t0, n_tiles) -- the tiles beyond a
+    // multiple of the CU count, which would otherwise cost a full extra round of blocks -- is cut along K
+    // (t0 = 0: every tile is cut into `split` slices, the plain split-K launch).
     const int bid = blockIdx.x;
-    const int tile = bid % g.n_tiles, slice = bid / g.n_tiles;
+    const bool whole = bid < g.t0;
+    const int n_tail = g.n_tiles - g.t0;
+    const int tile = whole ? bid : g.t0 + (bid - g.t0) % n_tail;
+    const int slice = whole ? 0 : (bid - g.t0) / n_tail;
+    const int split = whole ? 1 : g.split;
     const int tm = tile % g.tiles_m, tn = tile / g.tiles_m;
     const long m0 = (long)tm * BM, n0 = (long)tn * BN;
-    const long kbeg = (long)slice * g.k_chunk;
-    const long kend = min(g.K, kbeg + g.k_chunk);
+    const long kbeg = whole ? 0 : (long)slice * g.k_chunk;
+    const long kend = whole ? g.K : min(g.K, kbeg + g.k_chunk);
     const long klen = kend > kbeg ? kend - kbeg : 0;
     const long nt = (klen + BK - 1) / BK;                 // K tiles of this slice
 
@@ -247,9 +255,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     // (cdna_hip_programming.md, in-launch split-K hand-off: plain slab stores -> per-wave vmcnt(0) ->
     //  barrier -> one-lane agent-scope release -> ticket; reducer: one-lane agent-scope acquire ->
     //  barrier -> plain loads.)  Slab layout = the register image: float4 #(i,j,r4) of thread t.
-    if (g.split > 1 && g.out_mode != 2) {
+    if (split > 1 && g.out_mode != 2) {
         float4* slab = reinterpret_cast<float4*>(g.slabs) +
-                       ((size_t)tile * g.split + slice) * (size_t)(BM * BN / 4);
+                       ((size_t)(tile - g.t0) * split + slice) * (size_t)(BM * BN / 4);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -279,13 +287,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
             *flag = __hip_atomic_fetch_add(g.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (*flag != g.split - 1) return;
+        if (*flag != split - 1) return;
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __hip_atomic_store(g.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
         __syncthreads();
-        const float4* base = reinterpret_cast<const float4*>(g.slabs) + (size_t)tile * g.split * (size_t)(BM * BN / 4);
+        const float4* base = reinterpret_cast<const float4*>(g.slabs) + (size_t)(tile - g.t0) * split * (size_t)(BM * BN / 4);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int sl = 0; sl < g.split; ++sl) {          // fixed order; own slice re-read like the others
+                    for (int sl = 0; sl < split; ++sl) {          // fixed order; own slice re-read like the others
                         const float4 v = base[(size_t)sl * (BM * BN / 4) + ((i * TN + j) * 4 + r4) * 256 + threadIdx.x];
                         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
                     }
@@ -371,11 +379,11 @@ inline bool aligned16(const void* p, long ld) { return (((uintptr_t)p) & 15) == 
 // Host cost model in microseconds, fitted to tools/bench_gemm.py --sweep on an MI355X (profiles/
 // r01c_gemm_sweep.md): the busiest CU runs ceil(blocks / 256) blocks one after (or beside) the other at
 // a fixed cost per K tile, and an in-launch combine costs a fixed hand-off plus the slab round trip.
-struct Plan { int tile; int split; double cost; };
+struct Plan { int tile; int split; double cost; long t0; };
 
 Plan plan_gemm(long M, long N, long K, bool can_split, long ws_bytes, bool atomic_mode, int forced_split,
                bool big_ok, bool vec) {
-    Plan best{64, 1, 1e30};
+    Plan best{64, 1, 1e30, 0};
     for (int tile : {128, 64}) {
         if (tile == 128 && !big_ok) continue;
         const int bk = BK;
@@ -394,7 +402,20 @@ Plan plan_gemm(long M, long N, long K, bool can_split, long ws_bytes, bool atomi
             const long per_cu = (blocks + N_CU - 1) / N_CU;
             double c = per_cu * it * us_iter;
             if (S > 1) c += 3.0 + (atomic_mode ? 1.0 : 2.0) * blocks * (double)tile * tile * 4 / 3.0e6;
-            if (c < best.cost) best = Plan{tile, S, c};
+            if (c < best.cost) best = Plan{tile, S, c, 0};
+        }
+        // whole tiles for every full round of 256, the remainder cut along K: 608 tiles cost what 768 cost
+        // (profiles/r01d_gemm_quantisation.md); the remainder's slices fill one more, short, round instead
+        if (tile == 64 && can_split && !atomic_mode && forced_split <= 0 && tiles > N_CU && tiles % N_CU) {
+            const long t0 = (tiles / N_CU) * N_CU, tail = tiles - t0;
+            for (int S = 2; S <= 16; ++S) {
+                if (kiters / S < 4) break;
+                if (COUNTER_BYTES + tail * S * (long)tile * tile * 4 > ws_bytes || tiles > COUNTER_BYTES / 4) break;
+                const long it = (kiters + S - 1) / S;
+                const double c = (t0 / N_CU) * kiters * us_iter + ((tail * S + N_CU - 1) / N_CU) * it * us_iter + 3.0 +
+                                 2.0 * tail * S * (double)tile * tile * 4 / 3.0e6;
+                if (c < best.cost) best = Plan{tile, S, c, t0};
+            }
         }
     }
     return best;
@@ -433,8 +454,10 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     Plan pl = plan_gemm(M, N, K, can_split, ws_bytes, out_mode == 2, split_k, vec && !transA && transB, vec);
     if (vec && (force_tile == 64 || force_tile == 128)) {
         pl.tile = force_tile;
+        pl.t0 = 0;
         if (split_k > 0) pl.split = split_k;
     }
+    if (const char* f = getenv("NEMO_GEMM_T0")) { if (atol(f) >= 0 && pl.tile == 64 && can_split && out_mode != 2) pl.t0 = atol(f); }   // tuning aid
     const int tile = pl.tile;
 
     GemmArgs g;
@@ -453,10 +476,11 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     g.split = nz;
     g.tiles_m = (int)((M + tile - 1) / tile); g.tiles_n = (int)((N + tile - 1) / tile);
     g.n_tiles = g.tiles_m * g.tiles_n;
+    g.t0 = (nz > 1 && out_mode != 2 && pl.t0 > 0 && pl.t0 < g.n_tiles) ? (int)pl.t0 : 0;
     if (nz > 1 && out_mode != 2 &&
-        (g.n_tiles > COUNTER_BYTES / 4 || COUNTER_BYTES + (long)g.n_tiles * nz * tile * tile * 4 > ws_bytes))
+        (g.n_tiles > COUNTER_BYTES / 4 || COUNTER_BYTES + (long)(g.n_tiles - g.t0) * nz * tile * tile * 4 > ws_bytes))
         return NEMO_EINVAL;
-    const long blocks = (long)g.n_tiles * nz;
+    const long blocks = g.t0 + (long)(g.n_tiles - g.t0) * nz;
     if (blocks > 0x7fffffffL) return NEMO_EINVAL;
 
     hipStream_t s = (hipStream_t)stream;
