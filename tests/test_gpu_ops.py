@@ -132,6 +132,31 @@ def test_gemm_auto_plan(L, M, N, K):
     assert rel_err(C, A.double() @ B.double().T) < TOL
 
 
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(2401, 1000, 1000), (1100, 1000, 512)])
+def test_gemm_whole_tiles_plus_split_tail(L, ta, tb, M, N, K):
+    """More than 256 tiles and not a multiple of 256: the plan keeps whole tiles for every full round of CUs and
+    cuts only the remainder along K (GemmArgs::t0).  Fused epilogues, accumulation, determinism and the ticket
+    counters are checked on that path."""
+    H = _ops()
+    g = torch.Generator().manual_seed(M + 3 * N + K + ta + 2 * tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias, mask = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = (A.T if ta else A).double() @ (B.T if tb else B).double()
+    dA, dB = H.dev(A), H.dev(B)
+    C1 = H.gemm(dA, dB, ta, tb, split_k=0, bias=H.dev(bias), act=1)
+    assert rel_err(C1, torch.relu(ref + bias.double())) < TOL
+    C2 = H.gemm(dA, dB, ta, tb, split_k=0, bias=H.dev(bias), act=1)
+    assert torch.equal(C1, C2)                                   # slices are summed in a fixed order
+    assert rel_err(H.gemm(dA, dB, ta, tb, split_k=0, mask=H.dev(mask), mask_mode=1), ref * (mask > 0)) < TOL
+    C0 = torch.randn(M, N, generator=g)
+    C = H.dev(C0).clone()
+    H.gemm(dA, dB, ta, tb, split_k=0, alpha=0.5, out_mode=1, C=C)
+    assert rel_err(C, C0.double() + 0.5 * ref) < TOL
+    assert int(H.gemm_ws()[:4096].view(torch.int32).abs().sum()) == 0
+
+
 def test_gemm_rejects_bad_args(L):
     x = torch.zeros(4, 4, device='cuda')
     rc = L.nemo_gemm_f32(0, 0, 4, 4, 4, x.data_ptr(), 4, x.data_ptr(), 4, x.data_ptr(), 4, None, 1, None, 0, 0,
