@@ -20,6 +20,7 @@ Deliberate deviations from the reference (documented in DESIGN.md):
 from __future__ import annotations
 
 import os
+import warnings
 from collections import OrderedDict, defaultdict
 from copy import deepcopy
 
@@ -552,7 +553,9 @@ class MultiViewModel(nn.Module):
                 w['_static_src'], w['_static_vi'] = src, vi
             table = e.adam_table_upload(segs) if in_graph_adam else None
             entry = w['graphs'].get(key)
-            if not isinstance(entry, torch.cuda.CUDAGraph) and (entry or 0) < self.GRAPH_AFTER:
+            if entry == 'eager':
+                body(w['vi_static'], w['fi_static'], table)
+            elif not isinstance(entry, torch.cuda.CUDAGraph) and (entry or 0) < self.GRAPH_AFTER:
                 # first sights: eager (sets kernel attributes, sizes pools; a shape that shows up once or
                 # twice -- a rank's share of a random minibatch -- is not worth a capture)
                 w['graphs'][key] = (entry or 0) + 1
@@ -561,10 +564,21 @@ class MultiViewModel(nn.Module):
                 if not isinstance(entry, torch.cuda.CUDAGraph):   # capture the ~70-launch step as one HIP graph
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    try:
+                        with torch.cuda.graph(g):
+                            body(w['vi_static'], w['fi_static'], table)
+                    except RuntimeError as ex:
+                        # e.g. a capture invalidated by another thread of the process (a collective's
+                        # watchdog): nothing of the body has run; keep launching this variant kernel by
+                        # kernel -- same HIP kernels, only the launch overhead comes back
+                        warnings.warn(f'HIP graph capture failed ({ex}); this step variant runs un-captured')
+                        torch.cuda.synchronize()
+                        w['graphs'][key] = entry = 'eager'
                         body(w['vi_static'], w['fi_static'], table)
-                    w['graphs'][key] = entry = g
-                entry.replay()
+                    else:
+                        w['graphs'][key] = entry = g
+                if entry != 'eager':
+                    entry.replay()
             vi, fi = w['vi_static'], w['fi_static']
         else:
             body(vi, fi, None)

@@ -434,3 +434,37 @@ def test_early_loss_readback_equals_synchronous_readback(version):
         for (_, _, s0), (_, _, s1) in zip(log[:-2], log[1:-1]):
             k = 'learned_motion.net.net.2.weight'
             assert not torch.equal(s0[k], s1[k])
+
+
+def test_failed_graph_capture_falls_back_to_uncaptured_launches(monkeypatch):
+    """If the HIP-graph capture of a step variant fails (e.g. invalidated by another thread), the variant keeps
+    running kernel by kernel through the same engine and the results do not change."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    V, T, B = 2, 8, 8
+    args = syn.published_args(h_dim=48, monotonic_network_n_nodes=20, batch_size=B, out_dir='', phase_rbf_dim=16)
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(128, seed=1), syn.make_vposer_state(), syn.make_gmm()
+
+    class Boom:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            raise RuntimeError('capture invalidated (test)')
+
+        def __exit__(self, *a):
+            return False
+    runs = []
+    for broken in (False, True):
+        torch.manual_seed(0)
+        m = NemoV2(args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+        if broken:
+            monkeypatch.setattr(torch.cuda, 'graph', Boom)
+        with pytest.warns(UserWarning) if broken else __import__('contextlib').nullcontext():
+            runs.append([{k: float(v) for k, v in m.step(None, None, update=True, full_batch=True)[0].items()}
+                         for _ in range(5)])
+        if broken:
+            assert 'eager' in m.engine._ws(V * T)['graphs'].values()
+    for a, b in zip(*runs):
+        for k in a:
+            assert rel_err(a[k], b[k]) < 1e-4, (k, a[k], b[k])
