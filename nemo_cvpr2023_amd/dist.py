@@ -121,8 +121,12 @@ class ShardedNemo:
         buf = engine.grads[a:b] if update else engine.view('_comm_scalars', engine.grads)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
 
+    def _comm_small(self, buf):
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+
     def _info(self, d):
-        return ShardInfo(kr=d['kr'], mr=d['mr'], vr=d['vr'], n_global=d['n_global'], comm=self._comm)
+        return ShardInfo(kr=d['kr'], mr=d['mr'], vr=d['vr'], n_global=d['n_global'], comm=self._comm,
+                         comm_small=self._comm_small)
 
     def _sharder(self):
         """Draw the GLOBAL (view, frame) batch from the CPU RNG (identical on every rank) and keep

@@ -615,10 +615,10 @@ class FitEngine:
         torch.cuda.current_stream().synchronize()
         return self._scal_host.numpy().copy()
 
-    def publish_scalars(self):
+    def publish_scalars(self, src=None):
         """Enqueue (or capture) the copy of the loss scalars to pinned host memory + flag; everything
         enqueued afterwards (MLP backward, Adam) keeps running while the host reads them."""
-        check(self.lib.nemo_publish_scalars(self.scal.data_ptr(), 8, self._pub_host.data_ptr(),
+        check(self.lib.nemo_publish_scalars((self.scal if src is None else src).data_ptr(), 8, self._pub_host.data_ptr(),
                                             self._pub_host.data_ptr() + 32, _stream()), 'nemo_publish_scalars')
 
     def arm_scalars(self):

@@ -63,8 +63,9 @@ class ShardInfo:
     V_local / V_global the instance-code regulariser.  ``comm(engine)`` all-reduces the shared
     gradients together with the loss scalars.  The single-process default is the identity."""
 
-    def __init__(self, kr=1.0, mr=1.0, vr=1.0, n_global=None, comm=None):
+    def __init__(self, kr=1.0, mr=1.0, vr=1.0, n_global=None, comm=None, comm_small=None):
         self.kr, self.mr, self.vr, self.n_global, self.comm = kr, mr, vr, n_global, comm
+        self.comm_small = comm_small          # all-reduce of a small device tensor (the loss scalars)
 
 
 
@@ -409,7 +410,7 @@ class MultiViewModel(nn.Module):
 
     # ------------------------------------------------------------------ the hot path
     def _forward_backward(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False, sh=None,
-                          smooth_ok=False, extra_losses=None, publish=False):
+                          smooth_ok=False, extra_losses=None, publish=False, part='all'):
         """Forward of :3511-3584 (+V3 extras) and, when ``update``, the whole backward down to the
         parameter gradients.  After the pose MLP the step forks into two independent branches that
         run CONCURRENTLY on two HIP streams (most of their kernels are too small to fill 256 CUs):
@@ -419,6 +420,10 @@ class MultiViewModel(nn.Module):
         e, a = self.engine, self.args
         sh = sh or ShardInfo()
         e.scal = w['scal']               # loss-scalar slots of this workspace (part of the arena)
+        # part: 'all', or the two halves a sharded step launches separately -- 'head' = everything up to the
+        # point where the loss scalars are final, 'tail' = the rest of the backward (see step())
+        if part == 'tail':
+            return self._backward_tail(w, N, vi, fi, update, use_vposer, sh)
         w['zero_arena'].zero_()          # loss scalars, view accumulators, dAA, dJp, dA2, dPF2 in one memset
         if update:
             e.grads.zero_()
@@ -467,8 +472,12 @@ class MultiViewModel(nn.Module):
             extra_losses()
         if publish:      # every loss scalar is final here: hand them to the host, the backward goes on
             e.publish_scalars()
-        if not update:
+        if not update or part == 'head':
             return
+        self._backward_tail(w, N, vi, fi, update, use_vposer, sh)
+
+    def _backward_tail(self, w, N, vi, fi, update, use_vposer, sh):
+        e, a = self.engine, self.args
         st = _stream()
         # v2v_prep_bwd + rot6d_bwd + the trans_0 row sum in one launch
         v2v = bool(use_vposer and a.weight_vp_loss)
@@ -498,8 +507,8 @@ class MultiViewModel(nn.Module):
         e.scal = w['scal']               # (a replayed graph wrote this workspace's slots)
         has_inst = bool(self.VERSION >= 3 and getattr(a, 'weight_instance_loss', 0) and e.C > 0)
 
-        def body(vi_, fi_, adam_table):
-            """Everything of the step that runs on the device without host interaction."""
+        def body(vi_, fi_, adam_table, part='all'):
+            """Everything of the step (or of one half of it) that runs on the device without host interaction."""
             def inst_term():
                 code = self.learned_instance_code.detach()
                 e.scal[S_INST] = (code ** 2).mean()                                       # :3864-3867
@@ -508,8 +517,8 @@ class MultiViewModel(nn.Module):
                         code, alpha=2.0 * float(a.weight_instance_loss) * sh.vr / code.numel())
             if N > 0:
                 self._forward_backward(w, N, vi_, fi_, update, sh=sh, smooth_ok=is_full,
-                                       extra_losses=inst_term if has_inst else None, publish=early)
-            else:                       # a shard may own none of a minibatch's samples
+                                       extra_losses=inst_term if has_inst else None, publish=early, part=part)
+            elif part != 'tail':        # a shard may own none of a minibatch's samples
                 e.scal.zero_()
                 if update:
                     e.grads.zero_()
@@ -520,6 +529,13 @@ class MultiViewModel(nn.Module):
 
         # single-GPU steps hand the losses to the host as soon as they are final (engine.publish_scalars)
         early = e.early_readback and sh.comm is None and N > 0
+        # sharded update steps run in two halves: the loss scalars are final after the first, so their (tiny)
+        # all-reduce and the hand-over to the host go to the side stream while the main stream continues with
+        # the rest of the backward, the gradient all-reduce and Adam -- the host has the global losses long
+        # before the step ends and prepares the next launch meanwhile.  (Every rank takes this route whatever
+        # its share of the batch, so the collectives line up.)
+        split = bool(update and sh.comm is not None and sh.comm_small is not None and e.early_readback
+                     and os.environ.get('NEMO_SHARD_SPLIT', '1') != '0')
         noise = self.VERSION >= 3 and self.training and getattr(a, 'code_noise', 0) > 0
         graphable = self.use_graphs and N > 0 and e.timers is None and not noise
         segs = None
@@ -529,44 +545,51 @@ class MultiViewModel(nn.Module):
                 segs += o.segments(None)
         # the fused Adam runs inside the captured graph unless a gradient all-reduce must come first
         in_graph_adam = update and sh.comm is None
-        if early:
+        if early or split:
             e.arm_scalars()
-        if graphable:
-            key = (bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None,
+
+        def run(part):
+            """One launch of `part` of the body: a replayed HIP graph once the variant has been seen often enough."""
+            nonlocal vi, fi
+            if not graphable:
+                body(vi, fi, None, part)
+                return
+            key = (bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, part,
                    tuple((s_['offset'], s_['numel']) for s_ in segs) if in_graph_adam else None)
-            src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N)
-            if w.get('_static_src') != src or vi is not w.get('_static_vi'):   # (full batch: cached, unchanged)
-                if vi.device.type == 'cpu' and fi.device.type == 'cpu':
-                    # through pinned staging: a pageable H2D copy would block the host until the previous
-                    # step (still running, see `early`) has drained.  The staging buffer is free: the
-                    # previous copy out of it was enqueued before the launch whose losses we already hold.
-                    if '_idx_pin' not in w:
-                        w['_idx_pin'] = torch.empty(2, w['vi_static'].numel(), dtype=w['vi_static'].dtype).pin_memory()
-                    pin = w['_idx_pin']
-                    pin[0, :N].copy_(vi)
-                    pin[1, :N].copy_(fi)
-                    w['vi_static'].copy_(pin[0, :N], non_blocking=True)
-                    w['fi_static'].copy_(pin[1, :N], non_blocking=True)
-                else:
-                    w['vi_static'].copy_(vi)
-                    w['fi_static'].copy_(fi)
-                w['_static_src'], w['_static_vi'] = src, vi
-            table = e.adam_table_upload(segs) if in_graph_adam else None
+            if part != 'tail':
+                src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N)
+                if w.get('_static_src') != src or vi is not w.get('_static_vi'):   # (full batch: cached, unchanged)
+                    if vi.device.type == 'cpu' and fi.device.type == 'cpu':
+                        # through pinned staging: a pageable H2D copy would block the host until the previous
+                        # step (still running, see `early`) has drained.  The staging buffer is free: the
+                        # previous copy out of it was enqueued before the launch whose losses we already hold.
+                        if '_idx_pin' not in w:
+                            w['_idx_pin'] = torch.empty(2, w['vi_static'].numel(), dtype=w['vi_static'].dtype).pin_memory()
+                        pin = w['_idx_pin']
+                        pin[0, :N].copy_(vi)
+                        pin[1, :N].copy_(fi)
+                        w['vi_static'].copy_(pin[0, :N], non_blocking=True)
+                        w['fi_static'].copy_(pin[1, :N], non_blocking=True)
+                    else:
+                        w['vi_static'].copy_(vi)
+                        w['fi_static'].copy_(fi)
+                    w['_static_src'], w['_static_vi'] = src, vi
+            table = e.adam_table_upload(segs) if (in_graph_adam and part != 'head') else None
             entry = w['graphs'].get(key)
             if entry == 'eager':
-                body(w['vi_static'], w['fi_static'], table)
+                body(w['vi_static'], w['fi_static'], table, part)
             elif not isinstance(entry, torch.cuda.CUDAGraph) and (entry or 0) < self.GRAPH_AFTER:
                 # first sights: eager (sets kernel attributes, sizes pools; a shape that shows up once or
                 # twice -- a rank's share of a random minibatch -- is not worth a capture)
                 w['graphs'][key] = (entry or 0) + 1
-                body(w['vi_static'], w['fi_static'], table)
+                body(w['vi_static'], w['fi_static'], table, part)
             else:
                 if not isinstance(entry, torch.cuda.CUDAGraph):   # capture the ~70-launch step as one HIP graph
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
                     try:
                         with torch.cuda.graph(g):
-                            body(w['vi_static'], w['fi_static'], table)
+                            body(w['vi_static'], w['fi_static'], table, part)
                     except RuntimeError as ex:
                         # e.g. a capture invalidated by another thread of the process (a collective's
                         # watchdog): nothing of the body has run; keep launching this variant kernel by
@@ -574,21 +597,31 @@ class MultiViewModel(nn.Module):
                         warnings.warn(f'HIP graph capture failed ({ex}); this step variant runs un-captured')
                         torch.cuda.synchronize()
                         w['graphs'][key] = entry = 'eager'
-                        body(w['vi_static'], w['fi_static'], table)
+                        body(w['vi_static'], w['fi_static'], table, part)
                     else:
                         w['graphs'][key] = entry = g
                 if entry != 'eager':
                     entry.replay()
-            vi, fi = w['vi_static'], w['fi_static']
-        else:
-            body(vi, fi, None)
-        if early:        # the losses arrive while the backward / Adam launches above are still running
-            if update and not (graphable and in_graph_adam):
-                e.adam(segs)
+            if part != 'head':
+                vi, fi = w['vi_static'], w['fi_static']
+
+        need_adam = update and not (graphable and in_graph_adam)
+        if split:
+            run('head')
+            self._reduce_scalars_on_side_stream(sh)         # weights -> small all-reduce -> publish
+            if N > 0:
+                run('tail')
+            sh.comm(e, update)                              # shared-gradient all-reduce (main stream)
+            e.adam(segs)
             s = e.wait_scalars()
         else:
-            s = self._reduce_and_read(sh, update, then=(lambda: e.adam(segs))
-                                      if update and not (graphable and in_graph_adam) else None)
+            run('all')
+            if early:    # the losses arrive while the backward / Adam launches above are still running
+                if need_adam:
+                    e.adam(segs)
+                s = e.wait_scalars()
+            else:
+                s = self._reduce_and_read(sh, update, then=(lambda: e.adam(segs)) if need_adam else None)
         f32 = np.float32
         kp = f32(s[S_KP])
         v2v = f32(s[S_V2V]) / f32((sh.n_global or N) * e.NV * 3)
@@ -633,6 +666,33 @@ class MultiViewModel(nn.Module):
         self.training = False
         return loss_dict, info_dict
 
+    def _shard_weights(self, sh):
+        """Per-rank weights that turn the local loss scalars into this rank's share of the global ones."""
+        key = (sh.kr, sh.mr, sh.vr)
+        if not hasattr(self, '_shard_w'):
+            self._shard_w = {}
+        wv = self._shard_w.get(key)
+        if wv is None:                       # (cached: a host-to-device upload per step otherwise)
+            if len(self._shard_w) > 256:
+                self._shard_w.clear()
+            wv = self._shard_w[key] = torch.tensor([sh.kr, 1.0, sh.mr, sh.mr, sh.mr, sh.vr, 1.0, 0.0],
+                                                   device=self.device)
+        return wv
+
+    def _reduce_scalars_on_side_stream(self, sh):
+        """Sharded step, after its first half: weight the local loss scalars, all-reduce the 8 floats and
+        publish them to the host -- all on the side stream, the main stream goes on with the backward."""
+        e = self.engine
+        main, side = torch.cuda.current_stream(), e.side_stream
+        wv = self._shard_weights(sh)
+        if not hasattr(self, '_scal_red'):
+            self._scal_red = torch.zeros(8, dtype=torch.float32, device=self.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            torch.mul(e.scal, wv, out=self._scal_red)
+            sh.comm_small(self._scal_red)
+            e.publish_scalars(self._scal_red)
+
     def _reduce_and_read(self, sh, update, then=None):
         """Loss scalars to the host (one 32-byte transfer per step).  Sharded: the scalars are weighted
         into global terms, ride along the shared-gradient all-reduce, and are read back reduced.
@@ -640,15 +700,7 @@ class MultiViewModel(nn.Module):
         through pinned memory (engine.publish_scalars), after the synchronisation otherwise."""
         e = self.engine
         if sh.comm is not None:
-            key = (sh.kr, sh.mr, sh.vr)
-            wv = self._shard_w.get(key) if hasattr(self, '_shard_w') else None
-            if wv is None:                       # (cached: a host-to-device upload per step otherwise)
-                if not hasattr(self, '_shard_w'):
-                    self._shard_w = {}
-                if len(self._shard_w) > 256:
-                    self._shard_w.clear()
-                wv = self._shard_w[key] = torch.tensor([sh.kr, 1.0, sh.mr, sh.mr, sh.mr, sh.vr, 1.0, 0.0],
-                                                       device=self.device)
+            wv = self._shard_weights(sh)
             slot = e.view('_comm_scalars', e.grads)
             torch.mul(e.scal, wv, out=slot)
             sh.comm(e, update)

@@ -159,7 +159,10 @@ def _hip_worker(rank, world, port, q):
     cl = m.opt_cam(2)
     for vi, fi in _draws(3):
         losses.append({k: float(v) for k, v in m.step(vi, fi)[0].items()})
-    losses.append({k: float(v) for k, v in m.step(None, None, full_batch=True)[0].items()})
+    for _ in range(5):      # the same variant five times: its two halves are captured as HIP graphs and replayed
+        losses.append({k: float(v) for k, v in m.step(None, None, full_batch=True)[0].items()})
+    graphs = [v for w in m.model.engine.ws.values() for v in w['graphs'].values()]
+    assert sum(isinstance(g, torch.cuda.CUDAGraph) for g in graphs) >= 2, graphs
     sd = {k: v.numpy() for k, v in m.gather_state_dict().items()}
     q.put((rank, losses, sd, wl, [float(x) for x in cl]))
     dist.barrier()
@@ -192,7 +195,8 @@ def test_sharded_hip_equals_single_process_hip(tmp_path):
     wl = m.warmup(2)
     cl = m.opt_cam(2)
     ref = [{k: float(v) for k, v in m.step(vi, fi)[0].items()} for vi, fi in _draws(3)]
-    ref.append({k: float(v) for k, v in m.step(None, None, full_batch=True)[0].items()})
+    for _ in range(5):
+        ref.append({k: float(v) for k, v in m.step(None, None, full_batch=True)[0].items()})
     for r in res:
         assert rel_err(r[3], wl) < 1e-4 and rel_err(r[4], [float(x) for x in cl]) < 1e-4
         for got, want in zip(r[1], ref):
