@@ -1573,6 +1573,12 @@ struct MeshPlan { int G, cpg, RA, CA, nB; };
 constexpr double MESH_SEG_OVH = 1.0;
 static MeshPlan mesh_plan(long groups, long ntiles) {
     const int G = (int)groups, C = (int)((ntiles + 3) / 4);
+    if (const char* e = getenv("NEMO_MESH_PLAN")) {       // tuning / test aid: "RA,Lr,k" (not cached)
+        int RA = 0, Lr = 0, k = 0;
+        if (G >= 1 && sscanf(e, "%d,%d,%d", &RA, &Lr, &k) == 3 && RA >= 1 && Lr >= 0 && Lr < C && RA <= C - Lr &&
+            (Lr == 0 || k >= 1))
+            return MeshPlan{G, C, RA, C - Lr, Lr ? (G + k - 1) / k : 0};
+    }
     static thread_local MeshPlan last{0, 0, 0, 0, 0};     // the search below is ~1e4 steps: keep the last answer
     if (last.G == G && last.cpg == C) return last;
     MeshPlan best{G, C, 1, C, 0};
@@ -1591,14 +1597,6 @@ static MeshPlan mesh_plan(long groups, long ntiles) {
                 const double cost = (ca > cb ? ca : cb) + 1e-4 * ((long)G * RA + nB);
                 if (cost < best_cost) { best_cost = cost; best = MeshPlan{G, C, RA, CA, nB}; }
             }
-        }
-    }
-    if (const char* e = getenv("NEMO_MESH_PLAN")) {       // tuning aid: "RA,Lr,k"
-        int RA = 0, Lr = 0, k = 0;
-        if (sscanf(e, "%d,%d,%d", &RA, &Lr, &k) == 3 && RA >= 1 && Lr >= 0 && Lr < C && RA <= C - Lr &&
-            (Lr == 0 || k >= 1)) {
-            const int nB = Lr ? (G + k - 1) / k : 0;
-            best = MeshPlan{G, C, RA, C - Lr, nB};
         }
     }
     last = best;

@@ -486,10 +486,16 @@ def test_vertices_and_v2v(L, num_verts):
     assert rel_err(dRg.reshape(N, 24, 3, 3), Ro.grad) < 2e-3
 
 
-@pytest.mark.parametrize('num_verts,N', [(128, 6), (100, 37), (6890, 20)])
-def test_v2v_fused_mesh_kernel(L, num_verts, N):
+@pytest.mark.parametrize('num_verts,N,plan', [(128, 6, ''), (100, 37, ''), (6890, 20, ''),
+                                              # forced grid plans "RA,Lr,k" (the shapes N = 600 ... 6000 get
+                                              # by themselves): left-over blocks over 2 / 3 sample groups
+                                              (6890, 40, '3,9,3'), (6890, 40, '1,36,2'), (100, 37, '1,1,2'),
+                                              (128, 50, '1,1,3'), (6890, 20, '5,0,0')])
+def test_v2v_fused_mesh_kernel(L, num_verts, N, plan, monkeypatch):
     """Fused pose blend + skinning + L1 + gradient (MFMA accumulator layout end to end) against the
     oracle's unfused lbs + autograd; ragged vertex tiles (100, 6890 = 430*16+10) and sample groups."""
+    if plan:
+        monkeypatch.setenv('NEMO_MESH_PLAN', plan)
     from oracle import ops
     H = _ops()
     assets, ctx, idx = _ctx(num_verts, 2)
