@@ -15,6 +15,18 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+@pytest.fixture(autouse=True)
+def _bounded_cpu_threads():
+    """The oracle side of most tests is thousands of tiny CPU ops: on a many-core box torch's default thread pool
+    makes them several times slower (hand-off per op) and their run time erratic.  Eight threads keep the few
+    real-size oracle steps (N = 256 ... 512, 6890 vertices) fast enough; the small cases gain."""
+    import torch
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(n, 8))
+    yield
+    torch.set_num_threads(n)
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + '.npz')))
 
