@@ -198,6 +198,42 @@ def test_published_config_step_vs_oracle(tmp_path):
         assert rel_err(ld_h[k], ld_o[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize('version', [2, 3, 4])
+def test_benchmark_config_full_batch_step_vs_oracle(version):
+    """THE benchmark workload (8 x 300 full batch, N = 2400, h = 1000, RBF 100, 6890 vertices, every loss term) --
+    and the same sizes for NemoV3 / NemoV4 with their extra terms on: one update step and one evaluation step
+    against the CPU oracle from the same state.  At this size the mesh kernel runs its 3-range + left-over-block
+    grid (150 sample groups) and the hidden-layer GEMMs their whole-tiles + split-tail schedule."""
+    from nemo_cvpr2023_amd.neural_motion_model import NEMO_VERSIONS
+    from oracle.model import OracleNemo
+    V, T = 8, 300
+    args = syn.published_args(batch_size=512, out_dir='')
+    if version >= 3:
+        args.weight_instance_loss, args.weight_3d_loss = 0.1, 0.5
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    torch.manual_seed(0)
+    m = NEMO_VERSIONS[version](args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+    with torch.no_grad():                      # leave the near-identity regime so that every term is exercised
+        m.learned_motion.rot_out.weight.mul_(2e3)
+    o = OracleNemo(version, args, seqs, assets, vps, gmm,
+                   state={k: v.detach().cpu() for k, v in m.state_dict().items()})
+    ld_o, info_o = o.step(None, None, update=True, full_batch=True)
+    ld_h, info_h = m.step(None, None, update=True, full_batch=True)
+    assert ld_h.keys() == ld_o.keys()
+    for k in ld_o:
+        assert rel_err(ld_h[k], ld_o[k]) < 1e-4, (k, ld_h[k], ld_o[k])
+    assert rel_err(info_h['loss_all'], info_o['loss_all']) < 1e-4
+    named = dict(m.named_parameters())
+    for k in ('learned_motion.net.net.0.weight', 'learned_motion.net.net.2.weight', 'learned_motion.rot_out.weight',
+              'learned_cameras', 'phase_rbf.log_sigmas', 'phase_networks.5.scales'):
+        assert rel_err(named[k].grad, o.P[k].grad) < 2e-3, k
+    ld_o, _ = o.step(None, None, update=False, full_batch=True)      # the updated state
+    ld_h, _ = m.step(None, None, update=False, full_batch=True)
+    for k in ld_o:
+        assert rel_err(ld_h[k], ld_o[k]) < 2e-4, (k, ld_h[k], ld_o[k])
+
+
 def test_full_batch_properties_at_benchmark_size(tmp_path):
     """Size-independent properties at the BASELINE configuration (8 x 300 full batch, N = 2400):
     (i) the full-batch step equals the same indices passed explicitly, (ii) the per-view
