@@ -54,8 +54,15 @@ struct GemmArgs {
 template <int ROWS, int BK, bool KCONTIG, bool VEC, int NS>
 struct Stager {
     static constexpr int NV = VEC ? ROWS * BK / 1024 : ROWS * BK / 256;   // float4 / float per thread per tile
-    static constexpr int LD = KCONTIG ? BK + 4 : ROWS + 4;
-    static constexpr int SIZE = KCONTIG ? ROWS * LD : BK * LD;
+    // LDS image: [row][BK+4] (k-contiguous: ONE ds_read_b128 per operand group) for k-contiguous sources and,
+    // TRANSPOSED ON THE WAY IN, for row-contiguous sources staged with dwordx4 (64-row tiles): a wave's
+    // load covers 4 row chunks x 16 k rows, so the four ds_write_b32 of a float4 (rows 4c..4c+3, one k) hit
+    // banks 16a + 36j + k -- all 64 distinct.  Row-contiguous sources otherwise stay k-major ([k][ROWS+4],
+    // four ds_read_b32 per group: the parameter-gradient GEMMs ran at ~0.9 of the NT rate's time per K tile).
+    static constexpr bool TRANSP = !KCONTIG && VEC && ROWS == 64 && BK == 32;
+    static constexpr bool LK = KCONTIG || TRANSP;                         // LDS image is k-contiguous
+    static constexpr int LD = LK ? BK + 4 : ROWS + 4;
+    static constexpr int SIZE = LK ? ROWS * LD : BK * LD;
     const float* p[NV];           // per-element pointers (advanced every K tile)
     int off_[NV], k_[NV];         // LDS offset / k position inside the tile
     float4 v4[NS][VEC ? NV : 1];  // NS register slots = NS K tiles in flight
@@ -72,13 +79,14 @@ struct Stager {
             int r, kk;
             if (VEC) {
                 if (KCONTIG) { kk = 4 * (t % (BK / 4)); r = t / (BK / 4) + (1024 / BK) * i; }
+                else if (TRANSP) { r = 4 * ((t & 3) + 4 * (t >> 6)); kk = ((t >> 2) & 15) + 16 * i; }
                 else { r = 4 * (t % (ROWS / 4)); kk = t / (ROWS / 4) + (1024 / ROWS) * i; }
             } else {
                 if (KCONTIG) { kk = t % BK; r = t / BK + (256 / BK) * i; }
                 else { r = t % ROWS; kk = t / ROWS + (256 / ROWS) * i; }
             }
             k_[i] = kk;
-            off_[i] = KCONTIG ? r * LD + kk : kk * LD + r;
+            off_[i] = LK ? r * LD + kk : kk * LD + r;
             long gr = row0 + r;
             // a dwordx4 along rows that straddles row_lim stays inside the row storage (ld % 4 == 0)
             if (gr >= row_lim) gr = 0;
@@ -117,7 +125,12 @@ struct Stager {
                     v.x = nv > 0 ? v.x : 0.f; v.y = nv > 1 ? v.y : 0.f;
                     v.z = nv > 2 ? v.z : 0.f; v.w = nv > 3 ? v.w : 0.f;
                 }
-                *reinterpret_cast<float4*>(lds + off_[i]) = v;
+                if (TRANSP) {
+                    float* d = lds + off_[i];
+                    d[0] = v.x; d[LD] = v.y; d[2 * LD] = v.z; d[3 * LD] = v.w;
+                } else {
+                    *reinterpret_cast<float4*>(lds + off_[i]) = v;
+                }
             } else {
                 lds[off_[i]] = (!MASKED || nvalid(i, k_rem) > 0) ? v1[SLOT][i] : 0.f;
             }
@@ -215,18 +228,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);     // hipcc otherwise sinks stores and loads down to the barrier
         float fa[2][TM][4], fb[2][TN][4];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fetch_group<BM, BK, !TA>(as, wm * WM + i * 32 + l31, 0, lhi, fa[0][i]);
+        for (int i = 0; i < TM; ++i) fetch_group<BM, BK, SA::LK>(as, wm * WM + i * 32 + l31, 0, lhi, fa[0][i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fetch_group<BN, BK, TB>(bs, wn * WN + j * 32 + l31, 0, lhi, fb[0][j]);
+        for (int j = 0; j < TN; ++j) fetch_group<BN, BK, SB::LK>(bs, wn * WN + j * 32 + l31, 0, lhi, fb[0][j]);
 #pragma unroll
         for (int q = 0; q < G; ++q) {
             if (q + 1 < G) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    fetch_group<BM, BK, !TA>(as, wm * WM + i * 32 + l31, q + 1, lhi, fa[(q + 1) & 1][i]);
+                    fetch_group<BM, BK, SA::LK>(as, wm * WM + i * 32 + l31, q + 1, lhi, fa[(q + 1) & 1][i]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    fetch_group<BN, BK, TB>(bs, wn * WN + j * 32 + l31, q + 1, lhi, fb[(q + 1) & 1][j]);
+                    fetch_group<BN, BK, SB::LK>(bs, wn * WN + j * 32 + l31, q + 1, lhi, fb[(q + 1) & 1][j]);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -342,12 +355,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #ifndef NS_BIG
 #define NS_BIG 2
 #endif
+#ifndef NS_TN
+#define NS_TN 2
+#endif
 template <int BM, int BN, int BK, bool TA, bool TB, bool VA, bool VB>
 hipError_t launch_one(const GemmArgs& g, int blocks, hipStream_t s) {
-    // register-pipeline depth: 2 tiles in flight, 3 for the row-contiguous x row-contiguous layout (dW =
-    // dY^T X) -- measured per layout on MI355X (tools/bench_gemm.py): NN 77 -> 68 us, TT 294 -> 276 us at
-    // depth 2, TN 71 -> 67 us at depth 3
-    constexpr int NS = BM == 64 ? ((TA && !TB) ? 3 : 2) : NS_BIG;
+    // register-pipeline depth: 2 K tiles in flight (measured per layout on MI355X, tools/bench_gemm.py; the
+    // row-contiguous x row-contiguous layout ran deeper, 3, while its LDS image was k-major)
+    constexpr int NS = BM == 64 ? ((TA && !TB) ? NS_TN : 2) : NS_BIG;
     using SA = Stager<BM, BK, !TA, VA, NS>;
     using SB = Stager<BN, BK, TB, VB, NS>;
     constexpr size_t lds = 2 * (SA::SIZE + SB::SIZE) * sizeof(float);
