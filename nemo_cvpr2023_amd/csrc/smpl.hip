@@ -1155,14 +1155,16 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         float pb[2][2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) { pb[u][0] = pf0[4 * u]; pb[u][1] = pf1[4 * u]; }
-        for (int kk0 = 0; kk0 < 56; kk0 += 8) {                  // 52 real k-steps + 4 of zero padding
 #pragma unroll
+        for (int kk0 = 0; kk0 < 56; kk0 += 8) {                  // 52 k-steps (207 blend shapes + one zero row):
+#pragma unroll                                                   // fully unrolled, the last group is half a group
             for (int u = 0; u < 8; ++u) {
+                if (kk0 + u >= 52) continue;
                 const float a0 = __uint_as_float(pa[u][0]), a1 = __uint_as_float(pa[u][1]),
                             a2 = __uint_as_float(pa[u][2]);
                 const float b0 = pb[u & 1][0], b1 = pb[u & 1][1];
-                if (kk0 + u + 2 < 56) { pb[u & 1][0] = pf0[4 * (kk0 + u + 2)]; pb[u & 1][1] = pf1[4 * (kk0 + u + 2)]; }
-                if (kk0 + 8 < 56)                                                   // k-step kk + 8
+                if (kk0 + u + 2 < 52) { pb[u & 1][0] = pf0[4 * (kk0 + u + 2)]; pb[u & 1][1] = pf1[4 * (kk0 + u + 2)]; }
+                if (kk0 + 8 + u < 52)                                               // k-step kk + 8
                     pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, pt + (kk0 + 8 + u) * kstride, 0);
                 vp[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, vp[0][0], 0, 0, 0);
                 vp[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, vp[1][0], 0, 0, 0);
