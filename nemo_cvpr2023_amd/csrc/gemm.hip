@@ -56,8 +56,8 @@ struct Stager {
     static constexpr int NV = VEC ? ROWS * BK / 1024 : ROWS * BK / 256;   // float4 / float per thread per tile
     // LDS image: [row][BK+4] (k-contiguous: ONE ds_read_b128 per operand group) for k-contiguous sources and,
     // TRANSPOSED ON THE WAY IN, for row-contiguous sources staged with dwordx4 (64-row tiles): a wave's
-    // load covers 4 row chunks x 16 k rows, so the four ds_write_b32 of a float4 (rows 4c..4c+3, one k) hit
-    // banks 16a + 36j + k -- all 64 distinct.  Row-contiguous sources otherwise stay k-major ([k][ROWS+4],
+    // load covers 4 row chunks x 16 k rows, a half-wave two chunks (one even, one odd) x 16 k, so the four
+    // ds_write_b32 of a float4 (rows 4c..4c+3, one k) hit banks (16 c + 4 j + k) mod 32 -- 32 distinct per half-wave.  Row-contiguous sources otherwise stay k-major ([k][ROWS+4],
     // four ds_read_b32 per group: the parameter-gradient GEMMs ran at ~0.9 of the NT rate's time per K tile).
     static constexpr bool TRANSP = !KCONTIG && VEC && ROWS == 64 && BK == 32;
     static constexpr bool LK = KCONTIG || TRANSP;                         // LDS image is k-contiguous
@@ -79,7 +79,7 @@ struct Stager {
             int r, kk;
             if (VEC) {
                 if (KCONTIG) { kk = 4 * (t % (BK / 4)); r = t / (BK / 4) + (1024 / BK) * i; }
-                else if (TRANSP) { r = 4 * ((t & 3) + 4 * (t >> 6)); kk = ((t >> 2) & 15) + 16 * i; }
+                else if (TRANSP) { r = 4 * (((t >> 4) & 3) + 4 * (t >> 6)); kk = (t & 15) + 16 * i; }
                 else { r = 4 * (t % (ROWS / 4)); kk = t / (ROWS / 4) + (1024 / ROWS) * i; }
             } else {
                 if (KCONTIG) { kk = t % BK; r = t / BK + (256 / BK) * i; }
