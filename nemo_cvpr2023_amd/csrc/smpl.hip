@@ -1254,7 +1254,8 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 
     // ---- cross-wave reduction of dA through LDS (the staged sample data is dead now)
     __syncthreads();
-    float* scr = lds;                                   // 2 x [16 samples][288] floats
+    float* scr = lds;                                   // 2 x [16 samples][289] floats (odd stride: a half-wave's
+                                                        // 16 samples x 2 joint groups land in 32 different banks)
     auto put = [&](int slot) {
 #pragma unroll
         for (int e = 0; e < 12; ++e)
@@ -1263,7 +1264,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = 16 * t + 4 * g + r;
-                    if (j < 24) scr[(slot * 16 + l15) * 288 + j * 12 + e] = accdA[e][t][r];
+                    if (j < 24) scr[(slot * 16 + l15) * 289 + j * 12 + e] = accdA[e][t][r];
                 }
     };
     auto take = [&](int slot) {
@@ -1274,7 +1275,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = 16 * t + 4 * g + r;
-                    if (j < 24) accdA[e][t][r] += scr[(slot * 16 + l15) * 288 + j * 12 + e];
+                    if (j < 24) accdA[e][t][r] += scr[(slot * 16 + l15) * 289 + j * 12 + e];
                 }
     };
     if (wid >= 2) put(wid - 2);
