@@ -35,7 +35,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mf
 # HBM-side bytes per launch of the roofline kernel at the default workload, from the committed PMC passes
 # (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this bench, FETCH_SIZE doubled as the guide's
 # gfx950 note prescribes): profiles/r01b_pmc_traffic.md.  bench.py cannot collect counters itself.
-PMC_TRAFFIC = {'mesh_v2v_fused': (int((294.0 + 206.1) * 2 ** 20), 'profiles/r01b_pmc_traffic.md (FETCH_SIZE x2 + WRITE_SIZE)')}
+PMC_TRAFFIC = {'mesh_v2v_fused': (int((291.7 + 206.1) * 2 ** 20), 'profiles/r01b_pmc_traffic.md (FETCH_SIZE x2 + WRITE_SIZE)')}
 
 
 def main():
