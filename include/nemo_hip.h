@@ -225,9 +225,12 @@ int32_t nemo_v2v_skin_l1(const nemo_ctx* ctx, int64_t N, const float* VP, int64_
  * dVPt (3*NVp rows, NVp = NV rounded up to 16; ldn >= N rounded up to 16) = TRANSPOSED
  * d(sum)/dVP_orig (operand of the blend-shape adjoint GEMM with transA=1; pad rows/columns are
  * written with zeros); dA (N,24,12) = d(sum)/dA_orig (OVERWRITTEN; summed over the vertex ranges in
- * a fixed order, deterministic).  ws: caller-owned scratch of nemo_v2v_fused_ws_bytes(ctx, N) bytes,
- * 16-byte aligned, zero-filled once at allocation (arrival tickets the kernel returns to zero), not
- * shared by concurrent launches. */
+ * a fixed order, deterministic).  loss_sum is accumulated by ONE thread of the launch (the last block to
+ * arrive adds the per-block partials in block order, in float64): bit-reproducible run to run.
+ * ws: caller-owned scratch of nemo_v2v_fused_ws_bytes(ctx, N) bytes, 16-byte aligned, zero-filled once at
+ * allocation (arrival tickets the kernel returns to zero), not shared by concurrent launches.  The tickets sit at
+ * fixed offsets, so launches of DIFFERENT N may share one buffer of the largest size (the chunks of a big batch).
+ * N <= 16 * 65536 per launch. */
 int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N);
 int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
                        float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* ws, int64_t ws_bytes,

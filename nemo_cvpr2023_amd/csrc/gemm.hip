@@ -22,7 +22,10 @@
 // 16-lane service groups of a b128 read cover all 64 banks); an operand whose source is
 // row-contiguous is staged k-major ([k][row]) and fetched with four ds_read_b32.
 #include <type_traits>
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
+#include "gemm_glds.h"
 #include "../../include/nemo_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -30,17 +33,8 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
-struct GemmArgs {
-    const float* A; const float* B; float* C;
-    const float* bias; const float* mask;
-    float* slabs; int* counters;
-    long M, N, K, lda, ldb, ldc, ldmask;
-    long k_chunk;           // K range per slice (multiple of the K tile)
-    int tiles_m, tiles_n, n_tiles, split;
-    int t0;                 // tiles [0, t0) are computed whole by one block each, tiles [t0, n_tiles) in `split` K slices
-    int act, mask_mode, out_mode;
-    float alpha;
-};
+// (shared with the LDS-DMA generation of the kernel, gemm_glds.h: same tile / slice bookkeeping, same slab layout)
+using GemmArgs = glds::Args;
 
 // Per-thread staging of one (ROWS x BK) operand tile.  Element (r, kk) of a tile is
 //   KCONTIG : src[(row0 + r) * ld + k0 + kk]      (k is the contiguous axis)  -> LDS [r][BK+4]
@@ -385,22 +379,64 @@ hipError_t launch(int ta, int tb, const GemmArgs& g, int blocks, hipStream_t s) 
     return launch_one<BM, BN, BK, true, true, VA, VB>(g, blocks, s);
 }
 
-constexpr int BK = 32;
-constexpr long COUNTER_BYTES = 16384;       // 4096 tile tickets at the head of the workspace
-constexpr int N_CU = 256;
 
 inline bool aligned16(const void* p, long ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
 
 // Host cost model in microseconds, fitted to tools/bench_gemm.py --sweep on an MI355X (profiles/
 // r01c_gemm_sweep.md): the busiest CU runs ceil(blocks / 256) blocks one after (or beside) the other at
 // a fixed cost per K tile, and an in-launch combine costs a fixed hand-off plus the slab round trip.
+constexpr int BK = 32;
+constexpr long COUNTER_BYTES = 16384;       // 4096 tile tickets at the head of the workspace
+constexpr int N_CU = 256;
+
 struct Plan { int tile; int split; double cost; long t0; };
 
+// LDS-DMA kernel, 64x64 tiles (tools/gemm_glds_dev calib, profiles/r02_gemm_glds.md): up to three blocks are resident
+// per CU (48 KB of LDS each) and share its matrix pipes -- a K tile of every one of r co-resident blocks takes
+// GLDS_US[r] microseconds (0.66 alone, 1.10 for a pair, 1.4 - 1.75 for three depending on what the operands are; 1.75 keeps the plan from leaning on three-way residency).
+// `blocks` blocks of `it` K tiles each: whole rounds of 768, then the remainder at its own residency.
+constexpr double GLDS_US[4] = {0.0, 0.66, 1.10, 1.75};
+double glds_time(long blocks, long it) {
+    double t = 0.0;
+    while (blocks > 0) {
+        const long g = blocks < 3 * N_CU ? blocks : 3 * N_CU;
+        t += it * GLDS_US[(g + N_CU - 1) / N_CU];
+        blocks -= g;
+    }
+    return t;
+}
+
 Plan plan_gemm(long M, long N, long K, bool can_split, long ws_bytes, bool atomic_mode, int forced_split,
-               bool big_ok, bool vec) {
+               bool big_ok, bool vec, bool glds_ok) {
     Plan best{64, 1, 1e30, 0};
+    if (glds_ok) {
+        const long kiters = (K + BK - 1) / BK;
+        const long tiles = ((M + 63) / 64) * ((N + 63) / 64);
+        const int smax = forced_split > 0 ? forced_split : (can_split || atomic_mode ? 32 : 1);
+        auto combine = [&](long slabs) { return 2.0 + (atomic_mode ? 1.0 : 2.0) * slabs * 16384.0 / 3.0e6; };
+        for (int S = forced_split > 0 ? forced_split : 1; S <= smax; ++S) {
+            if (S > 1 && forced_split <= 0 && kiters / S < 4) break;
+            if (S > 1 && !atomic_mode && (tiles > COUNTER_BYTES / 4 || COUNTER_BYTES + tiles * S * 16384L > ws_bytes)) break;
+            double c = glds_time(tiles * S, (kiters + S - 1) / S);
+            if (S > 1) c += combine(tiles * S);
+            if (c < best.cost) best = Plan{64, S, c, 0};
+        }
+        // whole tiles for every full set of co-resident blocks, only the remaining tiles cut along K
+        if (can_split && !atomic_mode && forced_split <= 0 && tiles <= COUNTER_BYTES / 4)
+            for (long per : {(long)N_CU, 2L * N_CU, 3L * N_CU}) {
+                if (tiles <= per || tiles % per == 0) continue;
+                const long t0 = (tiles / per) * per, tail = tiles - t0;
+                for (int S = 2; S <= 16; ++S) {
+                    if (kiters / S < 4 || COUNTER_BYTES + tail * S * 16384L > ws_bytes) break;
+                    const double c = glds_time(t0, kiters) + glds_time(tail * S, (kiters + S - 1) / S) + combine(tail * S);
+                    if (c < best.cost) best = Plan{64, S, c, t0};
+                }
+            }
+        if (!big_ok) return best;
+    }
     for (int tile : {128, 64}) {
         if (tile == 128 && !big_ok) continue;
+        if (tile == 64 && glds_ok) continue;
         const int bk = BK;
         const long kiters = (K + bk - 1) / bk;
         const long tiles = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
@@ -466,7 +502,11 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     const bool vec = va && vb;
     // (128x128 tiles pay off only with both operands k-contiguous: the k-major LDS image is fetched with
     //  four ds_read_b32 per operand group instead of one ds_read_b128 and runs at ~half the rate there)
-    Plan pl = plan_gemm(M, N, K, can_split, ws_bytes, out_mode == 2, split_k, vec && !transA && transB, vec);
+    static const bool use_glds = [] { const char* f = getenv("NEMO_GEMM_GLDS"); return !(f && atoi(f) == 0); }();
+    unsigned a_bytes = 0, b_bytes = 0;
+    const bool glds_ok = vec && use_glds && force_tile != 128 &&
+                         glds::extents(transA, transB, M, N, K, lda, ldb, &a_bytes, &b_bytes);
+    Plan pl = plan_gemm(M, N, K, can_split, ws_bytes, out_mode == 2, split_k, vec && !transA && transB, vec, glds_ok);
     if (vec && (force_tile == 64 || force_tile == 128)) {
         pl.tile = force_tile;
         pl.t0 = 0;
@@ -474,6 +514,11 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     }
     if (const char* f = getenv("NEMO_GEMM_T0")) { if (atol(f) >= 0 && pl.tile == 64 && can_split && out_mode != 2) pl.t0 = atol(f); }   // tuning aid
     const int tile = pl.tile;
+    static const bool debug_plans = getenv("NEMO_GEMM_DEBUG") != nullptr;          // tuning aid: the plan of every call
+    if (debug_plans)
+        fprintf(stderr, "nemo_gemm_f32 ta=%d tb=%d M=%ld N=%ld K=%ld out=%d -> %s tile %d split %d t0 %ld (model %.1f us)\n",
+                transA, transB, (long)M, (long)N, (long)K, out_mode, glds_ok && tile == 64 ? "glds" : "v1", tile, pl.split,
+                pl.t0, pl.cost);
 
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.mask = mask;
@@ -500,6 +545,21 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
 
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
+    // Second-generation kernel for the common case (64x64 tiles, both operands 16-byte aligned, extents that fit a
+    // 32-bit buffer descriptor): operand tiles go global -> LDS by LDS-DMA, three stages, the pieces of the tile being
+    // requested issued between the MFMAs of the tile being multiplied.  Same tiles, slices, slabs and epilogue as the
+    // register-staged kernel below, which keeps the unaligned operands, the 128x128 tile and very large operands.
+    if (tile == 64 && glds_ok) {
+        g.a_bytes = a_bytes; g.b_bytes = b_bytes;
+        const bool akc = !transA, bkc = transB != 0;
+        if (akc && bkc) e = glds::launch<64, 64, 32, 32, 32, true, true, 3, true>(g, (int)blocks, s);
+        else if (akc) e = glds::launch<64, 64, 32, 32, 32, true, false, 3, true>(g, (int)blocks, s);
+        else if (bkc) e = glds::launch<64, 64, 32, 32, 32, false, true, 3, true>(g, (int)blocks, s);
+        else e = glds::launch<64, 64, 32, 32, 32, false, false, 3, true>(g, (int)blocks, s);
+        if (e != hipSuccess) return (int32_t)e;
+        NEMO_LAUNCH_CHECK();
+        return NEMO_OK;
+    }
     if (tile == 128) e = launch<128, 128, BK, true, true>(transA, transB, g, (int)blocks, s);
     else if (va && vb) e = launch<64, 64, BK, true, true>(transA, transB, g, (int)blocks, s);
     else if (va) e = launch<64, 64, BK, true, false>(transA, transB, g, (int)blocks, s);

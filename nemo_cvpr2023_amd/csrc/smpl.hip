@@ -992,7 +992,8 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     long N, long NV, const float* __restrict__ PF2, long ldpf, const float* __restrict__ A2,
     const float* __restrict__ P, long ldP, const float* __restrict__ vs, const float* __restrict__ W,
     int G, int cpg, int RA, int CA, int nB, int vec_stage, float* __restrict__ loss_sum, float* __restrict__ dVPt, long ldn,
-    float* __restrict__ dA, float* __restrict__ parts, int* __restrict__ tickets) {
+    float* __restrict__ dA, float* __restrict__ parts, int* __restrict__ tickets, float* __restrict__ loss_parts,
+    int* __restrict__ grid_ticket) {
     // All constants are zero-padded by nemo_ctx_create (P: 224 rows x 3*NVp columns, W / v_shaped: NVp
     // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
     // predicate: padded vertices / samples produce v_rec == v_orig == 0, i.e. zero loss and gradient.
@@ -1355,8 +1356,29 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 }
     }
     }   // segment
+    // L1 sum: every block publishes its partial (write-through), the LAST block to arrive adds all of them in block
+    // order in float64 and accumulates the result into the loss slot -- one writer per launch, launches of a
+    // chunked batch are stream-ordered: the reported loss is bit-reproducible run to run and does not lose digits
+    // at N = 262 144 (16 k fp32 atomics onto a 1e9 running sum used to cost 1e-4 relative).
     const float tot = block_sum(lsum, red);
-    if (threadIdx.x == 0) atomicAdd(loss_sum, tot);
+    __shared__ int grid_last;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(loss_parts + blockIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        grid_last = __hip_atomic_fetch_add(grid_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (grid_last && threadIdx.x < 64) {
+        double acc = 0.0;
+        for (unsigned i = threadIdx.x; i < gridDim.x; i += 64)       // sc1 loads: served by L2, never a stale L1 line
+            acc += (double)__hip_atomic_load(loss_parts + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (threadIdx.x == 0) {
+            *loss_sum += (float)acc;
+            __hip_atomic_store(grid_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        }
+    }
 }
 
 
@@ -1573,6 +1595,15 @@ extern "C" int32_t nemo_v2v_skin_l1(const nemo_ctx* ctx, int64_t N, const float*
 // blocks.  Cost in chunk units: the longest block, an extra segment charged MESH_SEG_OVH chunks (staging +
 // partial-sum flush); ties go to fewer blocks.
 struct MeshPlan { int G, cpg, RA, CA, nB; };
+// Scratch layout of nemo_v2v_fused -- FIXED offsets, whatever the launch size: a caller may run launches of different
+// sizes over one scratch buffer (the chunks of a large batch: 8192 + a ragged rest), and everything that must be zero
+// between launches (the tickets) has to stay clear of what another launch size uses as plain data.
+//   [0, 16)                         grid arrival ticket of the L1-sum reduction
+//   [16, 16 + 4 MAX_BLOCKS)         one L1 partial per block
+//   [.., + 4 MAX_GROUPS)            one arrival ticket per sample group
+//   [MESH_HEADER_BYTES, ...)        partial dA images, groups x (RA + 1) x 96 x 64 floats
+constexpr long MESH_MAX_BLOCKS = 65536, MESH_MAX_GROUPS = 65536;
+constexpr long MESH_HEADER_BYTES = 16 + MESH_MAX_BLOCKS * 4 + MESH_MAX_GROUPS * 4;
 constexpr double MESH_SEG_OVH = 1.0;
 static MeshPlan mesh_plan(long groups, long ntiles) {
     const int G = (int)groups, C = (int)((ntiles + 3) / 4);
@@ -1609,9 +1640,10 @@ static MeshPlan mesh_plan(long groups, long ntiles) {
 extern "C" int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N) {
     if (!ctx || N < 0) return -1;
     const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
-    if (groups == 0) return 16384;
+    if (groups == 0) return MESH_HEADER_BYTES;
+    if (groups > MESH_MAX_GROUPS) return -1;
     const MeshPlan pl = mesh_plan(groups, ntiles);
-    return 16384 + ((groups * 4 + 15) / 16) * 16 + groups * (long)(pl.RA + 1) * 96 * 64 * 4;
+    return MESH_HEADER_BYTES + groups * (long)(pl.RA + 1) * 96 * 64 * 4;
 }
 
 extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
@@ -1632,15 +1664,19 @@ extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* P
     const MeshPlan pl = mesh_plan(groups, ntiles);
     // scratch: one arrival ticket per sample group (zero at allocation, returned to zero by the kernel) and
     // the partial dA images of the blocks that overlap a group
-    const long ticket_bytes = ((groups * 4 + 15) / 16) * 16;
-    if (!ws || (((uintptr_t)ws) & 15) || ws_bytes < ticket_bytes + groups * (long)(pl.RA + 1) * 96 * 64 * 4)
+    const long blocks = (long)pl.G * pl.RA + pl.nB;
+    if (!ws || (((uintptr_t)ws) & 15) || blocks > MESH_MAX_BLOCKS || groups > MESH_MAX_GROUPS ||
+        ws_bytes < MESH_HEADER_BYTES + groups * (long)(pl.RA + 1) * 96 * 64 * 4)
         return NEMO_EINVAL;
-    int* tickets = reinterpret_cast<int*>(ws);
-    float* parts = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ticket_bytes);
-    hipLaunchKernelGGL(mesh_v2v_fused_kernel, dim3((unsigned)(pl.G * pl.RA + pl.nB)), dim3(256), lds_bytes,
+    char* wsb = reinterpret_cast<char*>(ws);
+    int* grid_ticket = reinterpret_cast<int*>(wsb);
+    float* loss_parts = reinterpret_cast<float*>(wsb + 16);
+    int* tickets = reinterpret_cast<int*>(wsb + 16 + MESH_MAX_BLOCKS * 4);
+    float* parts = reinterpret_cast<float*>(wsb + MESH_HEADER_BYTES);
+    hipLaunchKernelGGL(mesh_v2v_fused_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes,
                        (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, ctx->d_posedirs, ctx->ldP,
                        ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA, pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn,
-                       dA, parts, tickets);
+                       dA, parts, tickets, loss_parts, grid_ticket);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -15,9 +15,17 @@ SURVEY.md 8(e):
   fused Adam to the same reduced buffer.
 
 ``backend='nccl'`` is RCCL on ROCm.  xGMI is point-to-point: a 9 MB buffer is latency-, not
-bandwidth-bound, so there is exactly one collective per step and nothing else on the data path.
+bandwidth-bound, so the default is exactly one collective per step and nothing else on the data path.
+
+Opt-in ``shard_mode='split'`` (``ShardedNemo.set_shard_mode`` / ``NEMO_SHARD_SPLIT=1``): a second, 32-byte
+all-reduce of the loss scalars is issued on a side stream as soon as they are final (a third of a step before
+the gradient is), so the host holds the global losses early and prepares the next launch under the rest of the
+backward.  Which of the two is faster depends on the machine's small-message all-reduce latency against the host's
+launch latency; ``bench.py --gpus N`` times both on the box it runs on and reports the choice.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -114,6 +122,15 @@ class ShardedNemo:
         a, b = e.layout.span(e.layout.groups['motion'] + e.layout.groups['comm'])
         self._span = (a, b)
         self.args, self.optimizers = args, self.model.optimizers
+        self.shard_mode = 'single'
+        self.set_shard_mode('split' if os.environ.get('NEMO_SHARD_SPLIT', '0') == '1' else 'single')
+
+    def set_shard_mode(self, mode):
+        """'single': one all-reduce per step (gradient + loss scalars).  'split': + an early 32-byte all-reduce
+        of the loss scalars on the side stream.  Must be the same on every rank."""
+        if mode not in ('single', 'split'):
+            raise ValueError(mode)
+        self.shard_mode = mode
 
     # one collective per Adam step: [d motion MLP | d RBF | loss scalars]
     def _comm(self, engine, update):
@@ -126,7 +143,7 @@ class ShardedNemo:
 
     def _info(self, d):
         return ShardInfo(kr=d['kr'], mr=d['mr'], vr=d['vr'], n_global=d['n_global'], comm=self._comm,
-                         comm_small=self._comm_small)
+                         comm_small=self._comm_small if self.shard_mode == 'split' else None)
 
     def _sharder(self):
         """Draw the GLOBAL (view, frame) batch from the CPU RNG (identical on every rank) and keep

@@ -234,7 +234,6 @@ class FitEngine:
         self.side_stream = torch.cuda.Stream(device=self.device)   # prior branch of the step (see _forward_backward)
         # split-K scratch of nemo_gemm_f32 (arrival tickets + partial tiles), one per stream that launches GEMMs
         self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(2)]
-        self._mesh_ws = None
         self.overlap_dw = os.environ.get('NEMO_OVERLAP_DW', '0') != '0'
         self._colsums = []
         self._seg_host = self._seg_dev = None
@@ -295,6 +294,12 @@ class FitEngine:
             fi_static=torch.zeros(N, dtype=torch.long, device=self.device), graphs={})
         w.update(views)
         w['zero_arena'] = arena
+        # scratch of nemo_v2v_fused (arrival tickets, zero at allocation and returned to zero by the kernel, +
+        # per-vertex-range partial dA): owned by THIS workspace and sized for every chunk length it launches, so a
+        # HIP graph captured over the workspace never sees the buffer replaced under it
+        tail = N - (N // Nc) * Nc
+        need = max(int(self.lib.nemo_v2v_fused_ws_bytes(self.ctx.handle, n_)) for n_ in {Nc, tail or Nc})
+        w['mesh_ws'] = torch.zeros((need + 3) // 4, dtype=torch.float32, device=self.device)
         # strided views into the merged MLP-head buffers
         w['ROT'], w['TR'] = w['HEAD'][:, :144], w['HEAD'][:, 144:147]
         w['dROT'], w['dTR'] = w['dHEAD'][:, :144], w['dHEAD'][:, 144:147]
@@ -379,9 +384,7 @@ class FitEngine:
         """K6-K8: FK, mesh-functional joints, projection, 2-D loss accumulators."""
         L, st = self.lib, _stream()
         ctx = ctx or self.ctx
-        if self.betas._version != getattr(ctx, '_betas_version', None):   # no D2H sync in the steady state
-            ctx.set_betas(self.betas.detach().cpu().numpy())
-            ctx._betas_version = self.betas._version
+        self.sync_betas(ctx)
         check(L.nemo_fk_fwd(ctx.handle, N, dptr(w['R']), dptr(w['A']), dptr(w['Jp']), dptr(w['PF']), 208, st),
               'nemo_fk_fwd')
         nq72 = ctx.nq * 72
@@ -405,6 +408,15 @@ class FitEngine:
                                      self.scal.data_ptr() + 4 * S_KP, dptr(w['norm']), st), 'nemo_kp_finalize')
         return Mq
 
+    def sync_betas(self, ctx=None):
+        """Host-side: push ``learned_betas`` into the SMPL context when the tensor has been written since the
+        last push (checkpoint load, user assignment).  Costs a version compare in the steady state.  ``step()``
+        calls it BEFORE replaying a captured graph -- a replay skips the Python body that used to do it."""
+        ctx = ctx or self.ctx
+        if self.betas._version != getattr(ctx, '_betas_version', None):   # no D2H sync in the steady state
+            ctx.set_betas(self.betas.detach().cpu().numpy())
+            ctx._betas_version = self.betas._version
+
     def forward_vposer(self, w, N):
         """K9 + K12: encode(mean) -> decode -> axis-angle; KL and its gradient."""
         L, st, vp = self.lib, _stream(), self.vp
@@ -419,13 +431,6 @@ class FitEngine:
         check(L.nemo_rot6d_fwd(N, 21, dptr(w['D3']), 126, 0, None, dptr(w['AAdec']), st), 'nemo_rot6d_fwd')
         check(L.nemo_kl_fwd_bwd(N, 32, dptr(w['MULV']), 64, self.scal.data_ptr() + 4 * S_KL,
                                 dptr(w['dMULV']), 64, st), 'nemo_kl_fwd_bwd')
-
-    def mesh_ws(self, n):
-        """Scratch of nemo_v2v_fused (arrival tickets + per-vertex-range partial dA), zeroed at allocation."""
-        need = int(self.lib.nemo_v2v_fused_ws_bytes(self.ctx.handle, n))
-        if self._mesh_ws is None or self._mesh_ws.numel() * 4 < need:
-            self._mesh_ws = torch.zeros((need + 3) // 4, dtype=torch.float32, device=self.device)
-        return self._mesh_ws
 
     def forward_v2v(self, w, N, need_grad):
         """K10 + K11: the two full-mesh bodies, L1 sum and (same pass) its gradient wrt the pose.
@@ -443,7 +448,7 @@ class FitEngine:
             check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']),
                                 dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
             ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * (2 * 3 * 207 + 2 * 288 + 288))
-            ws = self.mesh_ws(n)
+            ws = w['mesh_ws']
             check(L.nemo_v2v_fused(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
                                    self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPt']), ldn, dptr(w['dA2']),
                                    ws.data_ptr(), ws.numel() * 4, st), 'nemo_v2v_fused')
@@ -626,11 +631,18 @@ class FitEngine:
         self._pub_flag[0] = 0
 
     def wait_scalars(self, timeout_s=120.0):
-        flag, t0, spins = self._pub_flag, None, 0
+        """Poll the pinned flag.  A short spin covers the common case (the scalars land within tens of
+        microseconds of the host getting here); after that the thread yields its time slice between polls
+        (``sleep(0)``: one rank per GPU must not pin eight host cores at 100 %), and sleeps 50 us per poll once the
+        wait is long (a C4-size step takes > 100 ms)."""
+        flag = self._pub_flag
+        for _ in range(2000):
+            if flag[0]:
+                return self._pub_np[:8].copy()
+        t0, polls = time.monotonic(), 0
         while flag[0] == 0:
-            spins += 1
-            if spins & 0xFFFF == 0:              # look at the clock every 64 k polls only
-                t0 = t0 or time.monotonic()
-                if time.monotonic() - t0 > timeout_s:
-                    raise _lib.NemoHipError('loss read-back flag never raised (device fault or hung kernel?)')
+            polls += 1
+            time.sleep(0 if polls < 512 else 5e-5)
+            if polls & 0x3FF == 0 and time.monotonic() - t0 > timeout_s:
+                raise _lib.NemoHipError('loss read-back flag never raised (device fault or hung kernel?)')
         return self._pub_np[:8].copy()

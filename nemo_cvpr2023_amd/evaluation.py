@@ -96,7 +96,7 @@ def smpl_from_aa(model, body_aa, chunk=2048):
     zero_betas = not bool(torch.any(e.betas != 0))
     if not zero_betas:                                      # eval always uses betas = None (zeros)
         ctx.set_betas(np.zeros(10, dtype=np.float32))
-        ctx._betas_version = None                           # the next fit step restores the learned betas
+        ctx._betas_version = None                           # (restored below, before returning)
     theta = torch.zeros(n, 72, device=dev)
     theta[:, 3:] = body_aa.to(dev, torch.float32).reshape(n, 69)
     R = torch.empty(n, 24, 9, device=dev)
@@ -121,7 +121,10 @@ def smpl_from_aa(model, body_aa, chunk=2048):
             cols.append(verts[:, vids[idx - 24]])
         else:
             raise NotImplementedError('regressor joints are not among the first 15 of the map')
-    return verts, torch.stack(cols, 1)
+    joints = torch.stack(cols, 1)
+    if not zero_betas:
+        e.sync_betas()            # the learned betas go back into the context (captured step graphs read it)
+    return verts, joints
 
 
 def _recon_error(a, b):

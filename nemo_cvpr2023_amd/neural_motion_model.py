@@ -498,13 +498,24 @@ class MultiViewModel(nn.Module):
         if self.VERSION >= 3 and update:
             self.training = True
         is_full = not (a.batch_size > -1 and not full_batch)
+        noise = self.VERSION >= 3 and self.training and getattr(a, 'code_noise', 0) > 0
         if not is_full:
-            vi, fi = self._idx(view_idx), self._idx(frame_idx)
+            vi, fi = torch.as_tensor(view_idx), torch.as_tensor(frame_idx)
+            # Host-resident indices (what the script draws, scripts/learned_multi_view_recon_nn.py:291-296) stay on
+            # the host when the step replays a graph: they reach the device through the workspace's pinned staging
+            # buffer below.  A plain ``.to(device)`` of pageable memory would park the host until the previous step
+            # -- still running, see `early` -- has drained.
+            stage = (self.use_graphs and e.timers is None and not noise and vi.numel() > 0
+                     and vi.device.type == 'cpu' and fi.device.type == 'cpu'
+                     and vi.dtype == torch.long and fi.dtype == torch.long)
+            if not stage:
+                vi, fi = self._idx(vi), self._idx(fi)
         else:
             vi, fi = self.full_indices()
         N = vi.numel()
         w = e._ws(max(N, 1))
         e.scal = w['scal']               # (a replayed graph wrote this workspace's slots)
+        e.sync_betas()                   # host-side state a captured graph cannot re-read (checkpoint load, eval)
         has_inst = bool(self.VERSION >= 3 and getattr(a, 'weight_instance_loss', 0) and e.C > 0)
 
         def body(vi_, fi_, adam_table, part='all'):
@@ -529,14 +540,14 @@ class MultiViewModel(nn.Module):
 
         # single-GPU steps hand the losses to the host as soon as they are final (engine.publish_scalars)
         early = e.early_readback and sh.comm is None and N > 0
-        # sharded update steps run in two halves: the loss scalars are final after the first, so their (tiny)
-        # all-reduce and the hand-over to the host go to the side stream while the main stream continues with
-        # the rest of the backward, the gradient all-reduce and Adam -- the host has the global losses long
-        # before the step ends and prepares the next launch meanwhile.  (Every rank takes this route whatever
+        # Sharded update steps: by default ONE collective per step -- the loss scalars ride in the last 8 floats of
+        # the shared-gradient all-reduce (_reduce_and_read).  Opt-in (ShardedNemo.set_shard_mode('split'), which
+        # hands a `comm_small` to the step): two halves -- the loss scalars are final after the first, so their
+        # (tiny) all-reduce and the hand-over to the host go to the side stream while the main stream continues
+        # with the rest of the backward, the gradient all-reduce and Adam; the host then has the global losses
+        # before the step ends and prepares the next launch meanwhile.  (Every rank takes the same route whatever
         # its share of the batch, so the collectives line up.)
-        split = bool(update and sh.comm is not None and sh.comm_small is not None and e.early_readback
-                     and os.environ.get('NEMO_SHARD_SPLIT', '1') != '0')
-        noise = self.VERSION >= 3 and self.training and getattr(a, 'code_noise', 0) > 0
+        split = bool(update and sh.comm is not None and sh.comm_small is not None and e.early_readback)
         graphable = self.use_graphs and N > 0 and e.timers is None and not noise
         segs = None
         if update:
@@ -554,7 +565,10 @@ class MultiViewModel(nn.Module):
             if not graphable:
                 body(vi, fi, None, part)
                 return
-            key = (bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, part,
+            # everything the captured launches bake in besides device-resident inputs: the mode, the shard
+            # normalisers, the engine switches of the public NemoV2 setters, the loss weights and loss type
+            key = (bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, part, early,
+                   e.detach_articulation, e.start_global_traj_anywhere, has_inst, self._weights_key(),
                    tuple((s_['offset'], s_['numel']) for s_ in segs) if in_graph_adam else None)
             if part != 'tail':
                 src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N)
@@ -665,6 +679,12 @@ class MultiViewModel(nn.Module):
                 sch.step(float(loss))
         self.training = False
         return loss_dict, info_dict
+
+    def _weights_key(self):
+        a = self.args
+        return (a.loss, float(a.weight_vp_loss), float(a.weight_vp_z_loss), float(a.weight_gmm_loss),
+                float(getattr(a, 'weight_3d_loss', 0) or 0), float(getattr(a, 'weight_instance_loss', 0) or 0),
+                float(getattr(a, 'weight_smooth', 0) or 0))
 
     def _shard_weights(self, sh):
         """Per-rank weights that turn the local loss scalars into this rank's share of the global ones."""

@@ -1,0 +1,124 @@
+"""bench.py as the scaling harness invokes it: ``python bench.py --gpus N`` must produce an N-rank number or fail.
+
+CPU: the self-launch path (parent -> ``torch.distributed.run`` -> N ranks) under gloo, and the refusal when the
+node has fewer GPUs than asked for.  GPU: the sharded step over a REAL RCCL communicator (world size 1 -- the
+only RCCL world a one-GPU box offers), in both collective layouts, equals the single-process step."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _run(*argv, env=None, timeout=300):
+    e = dict(os.environ)
+    e.pop('WORLD_SIZE', None)
+    e.pop('RANK', None)
+    e.pop('LOCAL_RANK', None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH, *argv], capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def test_bench_self_launch_reaches_n_ranks_under_gloo():
+    r = _run('--gpus', '2', '--spawn-selftest')
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1, r.stdout                       # rank 0 alone prints
+    out = json.loads(line[0])
+    assert out == {'selftest': True, 'n_gpus': 2, 'ranks_seen': [0, 1]}
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    have = torch.cuda.device_count()
+    r = _run('--gpus', str(have + 1) if have else '2', '--steps', '1', '--warmup', '0')
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    assert 'GPU(s) visible' in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]      # and no JSON line at all
+
+
+def test_bench_rejects_world_size_mismatch():
+    """Under a launcher (WORLD_SIZE set) the world must be what --gpus says -- in both directions."""
+    r = _run('--gpus', '1', '--spawn-selftest', env={'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr
+    r = _run('--gpus', '4', '--spawn-selftest', env={'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr
+
+
+def test_step_flops_accounting():
+    sys.path.insert(0, ROOT)
+    import bench
+    tot, parts = bench.step_flops(2400)
+    assert abs(parts['mesh'] - 69.649632e9) < 1e6           # the roofline kernel's algorithmic work
+    assert abs(parts['blend_adjoint'] - 20.54e9) < 0.01e9
+    assert 120e9 < tot < 135e9
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _rccl_world1(mode, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from nemo_cvpr2023_amd import synthetic as syn
+    from nemo_cvpr2023_amd.dist import ShardedNemo
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % q['port'], rank=0, world_size=1)
+    assert dist.get_backend() == 'nccl'
+    V, T, B = 3, 10, 16
+    args = syn.published_args(h_dim=48, monotonic_network_n_nodes=20, batch_size=B, out_dir='', phase_rbf_dim=16)
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets = dict(smpl_assets=syn.make_smpl_assets(128, seed=1), vposer_state=syn.make_vposer_state(),
+                  gmm=syn.make_gmm())
+    m = ShardedNemo(2, args, seqs, 'cuda:0', rank=0, world=1, seed=0, **assets)
+    m.set_shard_mode(mode)
+    g = torch.Generator().manual_seed(7)
+    out = []
+    for it in range(8):
+        if it % 2:
+            ld, _ = m.step(None, None, full_batch=True)
+        else:
+            ld, _ = m.step(torch.randint(0, V, (B,), generator=g), torch.randint(0, T, (B,), generator=g))
+        out.append({k: float(v) for k, v in ld.items()})
+    graphs = [v for w in m.model.engine.ws.values() for v in w['graphs'].values()]
+    q['res'] = (out, sum(isinstance(x, torch.cuda.CUDAGraph) for x in graphs))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['single', 'split'])
+def test_sharded_step_over_rccl_world_of_one(mode):
+    """RCCL (backend 'nccl') on hardware: communicator creation, the all-reduce(s) of the sharded step on their
+    streams, the watchdog thread next to HIP-graph capture and replay.  Numerically a 1-rank all-reduce is the
+    identity, so the run must reproduce the plain single-process model."""
+    import socket
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from nemo_cvpr2023_amd import synthetic as syn
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2, make_init_state
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    q = {'port': s.getsockname()[1]}
+    s.close()
+    _rccl_world1(mode, q)
+    got, n_graphs = q['res']
+    assert n_graphs >= 1
+    V, T, B = 3, 10, 16
+    args = syn.published_args(h_dim=48, monotonic_network_n_nodes=20, batch_size=B, out_dir='', phase_rbf_dim=16)
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    torch.manual_seed(0)
+    state = make_init_state(args, 2, V, seqs.IMG_D0)
+    m = NemoV2(args, seqs, 'cuda:0', smpl_assets=syn.make_smpl_assets(128, seed=1),
+               vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
+    m.load_state_dict(state, strict=False)
+    g = torch.Generator().manual_seed(7)
+    for it in range(8):
+        if it % 2:
+            ld, _ = m.step(None, None, full_batch=True)
+        else:
+            ld, _ = m.step(torch.randint(0, V, (B,), generator=g), torch.randint(0, T, (B,), generator=g))
+        for k, v in ld.items():
+            assert abs(got[it][k] - float(v)) <= 1e-4 * max(abs(float(v)), 1e-6), (it, k, got[it][k], float(v))

@@ -248,15 +248,16 @@ def test_more_than_one_mesh_chunk_vs_oracle():
     with torch.no_grad():
         m.learned_motion.rot_out.weight.mul_(2e3)
     o = OracleNemo(2, args, seqs, assets, vps, gmm, state={k: v.detach().cpu() for k, v in m.state_dict().items()})
-    for it in range(2):
+    for it in range(3):
         ld_o, _ = o.step(None, None, update=True, full_batch=True)
         ld_h, _ = m.step(None, None, update=True, full_batch=True)
         for k in ld_o:
             assert rel_err(ld_h[k], ld_o[k]) < 1e-4, (it, k, ld_h[k], ld_o[k])
-        if it == 0:
-            named = dict(m.named_parameters())
-            for k in ('learned_motion.net.net.2.weight', 'learned_motion.rot_out.weight', 'learned_cameras'):
-                assert rel_err(named[k].grad, o.P[k].grad) < 2e-3, k
+        # gradients on BOTH steps: the second one runs over scratch the first one's ragged last chunk has used (a
+        # launch-size dependent scratch layout once left that chunk's data where the next step expected zeroed tickets)
+        named = dict(m.named_parameters())
+        for k in ('learned_motion.net.net.2.weight', 'learned_motion.rot_out.weight', 'learned_cameras'):
+            assert rel_err(named[k].grad, o.P[k].grad) < (2e-3 if it == 0 else 1e-2), (it, k)
 
 
 @pytest.mark.parametrize('B,one_view', [(1, False), (5, False), (17, True), (33, False)])
@@ -560,3 +561,23 @@ def test_failed_graph_capture_falls_back_to_uncaptured_launches(monkeypatch):
     for a, b in zip(*runs):
         for k in a:
             assert rel_err(a[k], b[k]) < 1e-4, (k, a[k], b[k])
+
+
+def test_checkpoint_written_by_the_reference_loads_into_the_hip_model():
+    """`load()` (:268-280) of a file produced by the reference's own `save()` (:257-266) -- model keys, four
+    torch-format Adam states with their step counts -- and the run the reference itself continued from it."""
+    import os
+    from conftest import GOLDEN
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    from test_oracle_golden import _ckpt_case, check_resumed_run
+    g, V, T, B, args, seqs = _ckpt_case()
+    torch.manual_seed(321)                                     # a different init: everything must come from the file
+    m = NemoV2(args, seqs, DEV, smpl_assets=syn.make_smpl_assets(128, seed=1), vposer_state=syn.make_vposer_state(),
+               gmm=syn.make_gmm())
+    m.load(os.path.join(GOLDEN, 'ckpt_ref_v2.pt'))
+    assert [float(next(iter(o.state_dict()['state'].values()))['step']) for o in m.optimizers] == [3.0, 5.0, 5.0, 3.0]
+    check_resumed_run(m.step, g)
+    sd = m.state_dict()
+    for k in ('learned_cameras', 'learned_motion.net.net.2.weight', 'learned_motion.rot_out.bias',
+              'phase_networks.1.scales', 'learned_instance_code'):
+        assert rel_err(sd[k], g['final__' + k.replace('.', '__')]) < 5e-3, k

@@ -1,0 +1,210 @@
+// Stand-alone numerics + timing harness of the LDS-DMA GEMM core (nemo_cvpr2023_amd/csrc/gemm_glds.h).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize tools/gemm_glds_dev.hip -o tools/gemm_glds_dev
+//   ./tools/gemm_glds_dev check        every configuration against a float64 host product (ragged M / N / K, split-K)
+//   ./tools/gemm_glds_dev time         the step's shapes at N = 2400 and N = 300, per configuration and split
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+#include "../nemo_cvpr2023_amd/csrc/gemm_glds.h"
+
+using glds::Args;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+enum Cfg { C64 = 0, C128x64, C64x128, C128, C64x208, S64, S128x64, S64x128, S128, S128x224, NCFG };
+static const char* cfg_name[] = {"64x64", "128x64", "64x128", "128x128", "64x208/16", "64x64 spread", "128x64 spread",
+                                 "64x128 spread", "128x128 spread", "128x224 spread"};
+static const int cfg_bm[] = {64, 128, 64, 128, 64, 64, 128, 64, 128, 128}, cfg_bn[] = {64, 64, 128, 128, 208, 64, 64, 128, 128, 224};
+
+template <bool AKC, bool BKC>
+hipError_t launch_cfg(int cfg, const Args& g, int blocks, hipStream_t s) {
+    switch (cfg) {
+        case C64: return glds::launch<64, 64, 32, 32, 32, AKC, BKC, 3>(g, blocks, s);
+        case C128x64: return glds::launch<128, 64, 64, 32, 32, AKC, BKC, 3>(g, blocks, s);
+        case C64x128: return glds::launch<64, 128, 32, 64, 32, AKC, BKC, 3>(g, blocks, s);
+        case C128: return glds::launch<128, 128, 64, 64, 32, AKC, BKC, 2>(g, blocks, s);
+        case S64: return glds::launch<64, 64, 32, 32, 32, AKC, BKC, 3, true>(g, blocks, s);
+        case S128x64: return glds::launch<128, 64, 64, 32, 32, AKC, BKC, 3, true>(g, blocks, s);
+        case S64x128: return glds::launch<64, 128, 32, 64, 32, AKC, BKC, 3, true>(g, blocks, s);
+        case S128: return glds::launch<128, 128, 64, 64, 32, AKC, BKC, 3, true>(g, blocks, s);
+        case S128x224:
+            if constexpr (BKC) return glds::launch<128, 224, 32, 224, 32, AKC, true, 3, true>(g, blocks, s);
+            return hipErrorInvalidValue;
+        case C64x208:
+            if constexpr (BKC) return glds::launch<64, 208, 16, 208, 16, AKC, true, 2>(g, blocks, s);
+            return hipErrorInvalidValue;
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t run(int cfg, int ta, int tb, long M, long N, long K, const float* A, long lda, const float* B, long ldb, float* C,
+               long ldc, const float* bias, int act, int out_mode, int split, int t0_whole, float* ws, hipStream_t s) {
+    Args g{};
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.mask = nullptr; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.ldmask = 0; g.act = act; g.mask_mode = 0; g.out_mode = out_mode; g.alpha = 1.f;
+    g.counters = reinterpret_cast<int*>(ws); g.slabs = ws + 4096;
+    if (!glds::extents(ta, tb, M, N, K, lda, ldb, &g.a_bytes, &g.b_bytes)) return hipErrorInvalidValue;
+    const int BM = cfg_bm[cfg], BN = cfg_bn[cfg];
+    long kc = (K + split - 1) / split; kc = (kc + 31) / 32 * 32; if (kc == 0) kc = 32;
+    g.k_chunk = kc; g.split = (int)((K + kc - 1) / kc);
+    g.tiles_m = (int)((M + BM - 1) / BM); g.tiles_n = (int)((N + BN - 1) / BN); g.n_tiles = g.tiles_m * g.tiles_n;
+    g.t0 = (g.split > 1 && t0_whole > 0 && t0_whole < g.n_tiles) ? t0_whole : 0;
+    const int blocks = g.t0 + (g.n_tiles - g.t0) * g.split;
+    const bool akc = !ta, bkc = tb;
+    if (akc && bkc) return launch_cfg<true, true>(cfg, g, blocks, s);
+    if (akc && !bkc) return launch_cfg<true, false>(cfg, g, blocks, s);
+    if (!akc && bkc) return launch_cfg<false, true>(cfg, g, blocks, s);
+    return launch_cfg<false, false>(cfg, g, blocks, s);
+}
+
+struct Prob { int ta, tb; long M, N, K; };
+
+static float frand() { return (float)(rand() % 2001 - 1000) / 1000.f; }
+
+int check() {
+    const Prob probs[] = {{0, 1, 130, 70, 100}, {0, 1, 64, 64, 32}, {0, 1, 301, 147, 1000}, {0, 0, 301, 105, 1000},
+                          {0, 0, 257, 200, 147}, {1, 0, 147, 1000, 301}, {1, 0, 200, 105, 333}, {1, 1, 300, 207, 2070},
+                          {1, 1, 77, 207, 515}, {0, 1, 513, 512, 63}, {0, 1, 1, 9, 5}};
+    float* ws; CK(hipMalloc(&ws, 64 << 20)); CK(hipMemset(ws, 0, 64 << 20));
+    int bad = 0;
+    for (const Prob& p : probs) {
+        const long lda = p.ta ? (p.M + 3) / 4 * 4 + 4 : (p.K + 3) / 4 * 4 + 4, ldb = p.tb ? (p.K + 3) / 4 * 4 + 8 : (p.N + 3) / 4 * 4;
+        const long ar = p.ta ? p.K : p.M, br = p.tb ? p.N : p.K, ldc = p.N + 3;
+        std::vector<float> hA(ar * lda), hB(br * ldb), hC(p.M * ldc), hbias(p.N);
+        for (auto& x : hA) x = frand();
+        for (auto& x : hB) x = frand();
+        for (auto& x : hbias) x = frand();
+        // poison the pads with NaN: nothing outside the logical operands may reach a result
+        for (long r = 0; r < ar; ++r) for (long c = (p.ta ? p.M : p.K); c < lda; ++c) hA[r * lda + c] = NAN;
+        for (long r = 0; r < br; ++r) for (long c = (p.tb ? p.K : p.N); c < ldb; ++c) hB[r * ldb + c] = NAN;
+        std::vector<double> ref(p.M * p.N);
+        for (long m = 0; m < p.M; ++m) for (long n = 0; n < p.N; ++n) {
+            double s = 0;
+            for (long k = 0; k < p.K; ++k) s += (double)(p.ta ? hA[k * lda + m] : hA[m * lda + k]) * (p.tb ? hB[n * ldb + k] : hB[k * ldb + n]);
+            ref[m * p.N + n] = s + hbias[n];
+        }
+        float *dA, *dB, *dC, *dbias;
+        // exact-size allocations: an out-of-bounds read would fault
+        CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, hC.size() * 4)); CK(hipMalloc(&dbias, p.N * 4));
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dbias, hbias.data(), p.N * 4, hipMemcpyHostToDevice));
+        for (int cfg = 0; cfg < NCFG; ++cfg) {
+            if ((cfg == C64x208 || cfg == S128x224) && !p.tb) continue;
+            for (int split : {1, 3}) {
+                if (split > 1 && p.K < 96) continue;
+                for (int t0 : {0, 1}) {
+                    if (t0 && split == 1) continue;
+                    CK(hipMemset(dC, 0xff, hC.size() * 4));
+                    hipError_t e = run(cfg, p.ta, p.tb, p.M, p.N, p.K, dA, lda, dB, ldb, dC, ldc, dbias, 0, 0, split, t0, ws, 0);
+                    if (e != hipSuccess) { printf("launch failed %s\n", hipGetErrorString(e)); ++bad; continue; }
+                    CK(hipDeviceSynchronize());
+                    CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+                    double err = 0, scale = 0;
+                    for (long m = 0; m < p.M; ++m) for (long n = 0; n < p.N; ++n) {
+                        const double d = fabs((double)hC[m * ldc + n] - ref[m * p.N + n]);
+                        if (!(d <= err)) err = d;
+                        scale = fmax(scale, fabs(ref[m * p.N + n]));
+                    }
+                    const bool ok = err <= 2e-5 * scale + 1e-6;
+                    if (!ok) ++bad;
+                    printf("%-10s ta=%d tb=%d M=%4ld N=%4ld K=%5ld split=%d t0=%d  max err %.3g (scale %.3g) %s\n", cfg_name[cfg], p.ta,
+                           p.tb, p.M, p.N, p.K, split, t0, err, scale, ok ? "ok" : "FAIL");
+                }
+            }
+        }
+        CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dbias));
+    }
+    printf(bad ? "CHECK FAILED (%d)\n" : "CHECK OK\n", bad);
+    return bad;
+}
+
+void timeit(long Nb) {
+    struct Shape { const char* name; int ta, tb; long M, N, K; };
+    const Shape shapes[] = {{"mlp_hidden_fwd", 0, 1, Nb + 1, 1000, 1000}, {"mlp_hidden_dx", 0, 0, Nb + 1, 1000, 1000},
+                            {"mlp_hidden_dw", 1, 0, 1000, 1000, Nb + 1}, {"head_fwd", 0, 1, Nb + 1, 147, 1000},
+                            {"head_dx", 0, 0, Nb + 1, 1000, 147}, {"head_dw", 1, 0, 147, 1000, Nb + 1},
+                            {"vposer_512", 0, 1, Nb, 512, 512}, {"mq", 0, 0, Nb, 792, 207}, {"dpf_kp", 0, 1, Nb, 207, 792},
+                            {"blend_adjoint", 1, 1, Nb, 207, 20670}};
+    float* ws; CK(hipMalloc(&ws, 256 << 20)); CK(hipMemset(ws, 0, 256 << 20));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (const Shape& p : shapes) {
+        const long lda = p.ta ? (p.M + 15) / 16 * 16 : (p.K + 3) / 4 * 4, ldb = p.tb ? (p.K + 3) / 4 * 4 : (p.N + 3) / 4 * 4;
+        const long ar = p.ta ? p.K : p.M, br = p.tb ? p.N : p.K, ldc = (p.N + 3) / 4 * 4;
+        std::vector<float> hA(ar * lda), hB(br * ldb);
+        for (auto& x : hA) x = frand();
+        for (auto& x : hB) x = frand();
+        float *dA, *dB, *dC;
+        CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, p.M * ldc * 4));
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+        printf("%-14s ta=%d tb=%d M=%5ld N=%5ld K=%5ld  (%.2f GFLOP, %.1f us at 157.3 TF)\n", p.name, p.ta, p.tb, p.M, p.N, p.K,
+               2e-9 * p.M * p.N * p.K, 2e-6 * p.M * p.N * p.K / 157.3);
+        for (int cfg = 0; cfg < NCFG; ++cfg) {
+            if ((cfg == C64x208 || cfg == S128x224) && (!p.tb || p.N > 224)) continue;
+            const long tiles = ((p.M + cfg_bm[cfg] - 1) / cfg_bm[cfg]) * ((p.N + cfg_bn[cfg] - 1) / cfg_bn[cfg]);
+            std::string line = std::string("   ") + cfg_name[cfg] + " (" + std::to_string(tiles) + " tiles):";
+            for (int split : {1, 2, 3, 4, 6, 8, 13, 16, 26}) {
+                if (split > 1 && (p.K / 32 / split < 2 || tiles * split > 2048)) continue;
+                if (tiles * split * (long)cfg_bm[cfg] * cfg_bn[cfg] * 4 > (200L << 20)) continue;
+                for (int t0mode = 0; t0mode < 2; ++t0mode) {
+                    int t0 = 0;
+                    if (t0mode) { if (split == 1 || tiles <= 256 || tiles % 256 == 0) continue; t0 = (int)(tiles / 256 * 256); }
+                    auto go = [&]() { return run(cfg, p.ta, p.tb, p.M, p.N, p.K, dA, lda, dB, ldb, dC, ldc, nullptr, 0, 0, split, t0, ws, 0); };
+                    if (go() != hipSuccess) { line += " n/a"; continue; }
+                    go(); CK(hipDeviceSynchronize());
+                    const int reps = 20;
+                    CK(hipEventRecord(e0));
+                    for (int r = 0; r < reps; ++r) go();
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    char buf[64]; snprintf(buf, sizeof buf, " s%d%s=%.1f", split, t0 ? "t" : "", ms * 1e3 / reps);
+                    line += buf;
+                }
+            }
+            printf("%s\n", line.c_str());
+        }
+        CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
+    }
+}
+
+// time(r, it): 256 r tiles of 64x64 (r co-resident blocks per CU while r <= 3), `it` K tiles each, no split: the data the
+// host cost model of gemm.hip is fitted to
+void calib() {
+    float* ws; CK(hipMalloc(&ws, 64 << 20)); CK(hipMemset(ws, 0, 64 << 20));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int lay[3][2] = {{0, 1}, {0, 0}, {1, 0}};
+    for (auto& l : lay)
+        for (int cfg : {(int)S64, (int)C64}) {
+            printf("layout ta=%d tb=%d  %s\n", l[0], l[1], cfg_name[cfg]);
+            for (int r : {1, 2, 3, 4, 5, 6, 8}) {
+                std::string line = "   r=" + std::to_string(r) + ":";
+                for (int it : {2, 4, 8, 16, 32, 64, 128}) {
+                    const long M = 1024L * r, N = 1024, K = 32L * it;
+                    const long lda = l[0] ? M : K, ldb = l[1] ? K : N;
+                    float *dA, *dB, *dC;
+                    CK(hipMalloc(&dA, (l[0] ? K : M) * lda * 4)); CK(hipMalloc(&dB, (l[1] ? N : K) * ldb * 4)); CK(hipMalloc(&dC, M * N * 4));
+                    CK(hipMemset(dA, 0x3c, (l[0] ? K : M) * lda * 4)); CK(hipMemset(dB, 0x3c, (l[1] ? N : K) * ldb * 4));
+                    auto go = [&]() { return run(cfg, l[0], l[1], M, N, K, dA, lda, dB, ldb, dC, N, nullptr, 0, 0, 1, 0, ws, 0); };
+                    go(); go(); CK(hipDeviceSynchronize());
+                    const int reps = 20;
+                    CK(hipEventRecord(e0));
+                    for (int q = 0; q < reps; ++q) go();
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    char buf[48]; snprintf(buf, sizeof buf, " it%d=%.1f", it, ms * 1e3 / reps);
+                    line += buf;
+                    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
+                }
+                printf("%s\n", line.c_str());
+            }
+        }
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "check";
+    if (mode == "check") return check();
+    if (mode == "calib") { calib(); return 0; }
+    timeit(argc > 2 ? atol(argv[2]) : 2400);
+    return 0;
+}

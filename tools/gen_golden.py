@@ -464,6 +464,61 @@ def run_script_order_case(nmm, name='script_v2', V=4, T=7, B=8, n_steps=6, n_war
     save('script_' + name, **rec)
 
 
+def run_checkpoint_case(nmm, scratch, name='ckpt_ref_v2', V=3, T=6, B=8, seed=0):
+    """A checkpoint written by the reference's OWN ``save()`` (nemo/neural_motion_model.py:257-266) in mid-run
+    (after warm-up, camera fit and three steps: every optimiser has state), and what the reference does after
+    ``load()``-ing it into a FRESH model (:268-280): the losses of the next steps.  The committed file is the
+    reference's ``torch.save`` output minus the frozen ``vp.`` / ``smpl.`` / ``pose_prior.`` / ``renderer.``
+    entries (3.9 MB of VPoser / SMPL constants that the reference's own ``load()`` throws away, :270-276)."""
+    over = dict(h_dim=48, monotonic_network_n_nodes=20, batch_size=B, out_dir='out_' + name, phase_rbf_dim=16)
+    args = syn.published_args(**over)
+    args.model_version = 2
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    torch.manual_seed(seed)
+    model = nmm.NemoV2(args, seqs, 'cpu')
+    torch.manual_seed(2)
+
+    def draw():
+        return torch.randint(0, V, size=(B,)), torch.randint(0, T, size=(B,))
+    model.warmup(2)
+    model.opt_cam(2)
+    for _ in range(3):
+        model.step(*draw())
+    raw = os.path.join(scratch, name + '_raw.pt')
+    model.save(raw)                                          # <- the reference's own writer
+    saved = torch.load(raw, weights_only=False)
+    n_all = len(saved['model_sd'])
+    saved['model_sd'] = type(saved['model_sd'])(
+        (k, v) for k, v in saved['model_sd'].items() if not k.startswith(('vp.', 'smpl.', 'pose_prior.', 'renderer.')))
+    path = os.path.join(OUT, name + '.pt')
+    torch.save(saved, path)
+    print('wrote', path, '%.1f KB (%d of %d model_sd entries kept)' % (os.path.getsize(path) / 1024,
+                                                                         len(saved['model_sd']), n_all))
+    # resume in a fresh reference model (different seed: everything must come from the file)
+    torch.manual_seed(seed + 17)
+    fresh = nmm.NemoV2(args, seqs, 'cpu')
+    fresh.load(raw)
+    pure = []
+    install_pure_kp_capture(fresh, pure)
+    torch.manual_seed(5)
+    rec = {'meta__V': V, 'meta__T': T, 'meta__B': B}
+    bv, bf, tot, kps = [], [], [], []
+    for s in range(4):
+        vi, fi = draw()
+        bv.append(vi); bf.append(fi)
+        ld, _ = fresh.step(vi, fi, full_batch=(s == 3))
+        tot.append(np.float32(ld['total_loss'])); kps.append(pure[-1])
+        for k in ('gmm_loss', 'vp_recon_loss', 'vp_kl_loss'):
+            rec.setdefault(k, []).append(np.float32(ld[k]))
+    rec['batches_view'], rec['batches_frame'] = torch.stack(bv), torch.stack(bf)
+    rec['total_loss'], rec['kp_loss_pure'] = np.asarray(tot), np.asarray(kps, dtype=np.float32)
+    rec['lrs'] = np.asarray([o.param_groups[0]['lr'] for o in fresh.optimizers])
+    rec['opt_steps'] = np.asarray([float(next(iter(o.state_dict()['state'].values()))['step']) for o in fresh.optimizers])
+    for k, v in model_state(fresh).items():
+        rec['final__' + k.replace('.', '__')] = v
+    save(name, **rec)
+
+
 def run_eval_case(nmm, scratch, name='eval_v2', V=3, T=12, seed=0):
     """eval_2d / eval_3d / eval_3d(dynamic_only) of the reference class itself
     (nemo/neural_motion_model.py:522-710, :1056-1282) on the seeded init state.  The shipped eval_3d also
@@ -528,7 +583,7 @@ def run_loader_case(name='loader_mocap'):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-6890', action='store_true')
-    ap.add_argument('--only', default='', help='comma list of: script, eval, loader (skip everything else)')
+    ap.add_argument('--only', default='', help='comma list of: script, eval, loader, ckpt (skip everything else)')
     opts = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     scratch = tempfile.mkdtemp(prefix='nemo_golden_')
@@ -549,6 +604,8 @@ def main():
         run_eval_case(nmm, scratch)
     if not only or 'loader' in only:
         run_loader_case()
+    if not only or 'ckpt' in only:
+        run_checkpoint_case(nmm, scratch)
     if only:
         return
     gen_function_goldens(nmm, assets_small)
