@@ -218,6 +218,10 @@ class FitEngine:
         # flat parameter / gradient / Adam-moment buffers
         self.layout = ParamLayout(V, self.K, self.D, self.C, self.h, self.din)
         n = self.layout.total
+        # row stride between the phase networks of consecutive views inside the flat buffer (NOT 2K: every tensor
+        # starts on a 16-byte boundary, so K % 4 != 0 leaves pads between them)
+        ent = self.layout.entries
+        self.ldp = (ent['phase_networks.1.shifts'][0] - ent['phase_networks.0.shifts'][0]) if V > 1 else 2 * self.K + 8
         self.params = torch.zeros(n, **f32)
         self.grads = torch.zeros(n, **f32)
         self.exp_avg = torch.zeros(n, **f32)
@@ -231,10 +235,11 @@ class FitEngine:
         self._pub_flag = self._pub_np.view(np.int32)[8:9]
         self.early_readback = os.environ.get('NEMO_EARLY_READBACK', '1') != '0'
         self.ws = {}
-        self.side_stream = torch.cuda.Stream(device=self.device)   # prior branch of the step (see _forward_backward)
+        self.side_stream = torch.cuda.Stream(device=self.device)   # prior branches of the step (see _forward_backward)
+        self.side_stream2 = torch.cuda.Stream(device=self.device)
         # split-K scratch of nemo_gemm_f32 (arrival tickets + partial tiles), one per stream that launches GEMMs
-        self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(2)]
-        self.overlap_dw = os.environ.get('NEMO_OVERLAP_DW', '0') != '0'
+        self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(3)]
+        self.overlap_bwd = os.environ.get('NEMO_SERIAL_BWD', '0') == '0'
         self._colsums = []
         self._seg_host = self._seg_dev = None
         self.timers = None
@@ -312,7 +317,8 @@ class FitEngine:
         """split_k 0: the library picks the tile shape and the K split (combined inside the launch through
         this stream's scratch)."""
         ev = self._event_begin(tag, 2.0 * M * N * K)
-        ws = self.gemm_ws[1 if torch.cuda.current_stream() == self.side_stream else 0]
+        cur = torch.cuda.current_stream()
+        ws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]
         check(self.lib.nemo_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias, act, mask, ldmask,
                                      mask_mode, alpha, out_mode, split_k, ws.data_ptr(), ws.numel() * 4,
                                      _stream()), 'nemo_gemm_f32')
@@ -362,7 +368,7 @@ class FitEngine:
         sc0 = self.p('phase_networks.0.scales')
         check(L.nemo_phase_embed_fwd(
             N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
-            sh0, sc0, 2 * self.K, self.p('phase_rbf.log_sigmas') if self.D > 0 else None,
+            sh0, sc0, self.ldp, self.p('phase_rbf.log_sigmas') if self.D > 0 else None,
             self.p('learned_instance_code') if self.C > 0 else None, dptr(code_noise), self.kernel_id,
             dptr(w['X']), self.ldx, dptr(w['phase']), st), 'nemo_phase_embed_fwd')
         h, r = self.h, N + 1
@@ -418,19 +424,25 @@ class FitEngine:
             ctx._betas_version = self.betas._version
 
     def forward_vposer(self, w, N):
-        """K9 + K12: encode(mean) -> decode -> axis-angle; KL and its gradient."""
+        """K9: encode(mean) -> decode -> axis-angle.  Returns the event recorded once the encoder output (mu | logvar)
+        exists: the KL term and its backward (vposer_kl / backward_vposer_kl) run from there on another stream."""
         L, st, vp = self.lib, _stream(), self.vp
         aa63 = w['AA'].data_ptr() + 4 * 3
         self._linear(N, aa63, 72, 63, dptr(vp['e2w_p']), dptr(vp['e2b']), 512, dptr(w['E1']), 512, act=2, ldw=64)
         self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
+        enc_done = torch.cuda.current_stream().record_event()
         self._linear(N, dptr(w['MULV']), 64, 32, dptr(vp['d0w']), dptr(vp['d0b']), 512, dptr(w['D1']), 512,
                      act=2)
         self._linear(N, dptr(w['D1']), 512, 512, dptr(vp['d3w']), dptr(vp['d3b']), 512, dptr(w['D2']), 512,
                      act=2)
         self._linear(N, dptr(w['D2']), 512, 512, dptr(vp['d5w']), dptr(vp['d5b']), 126, dptr(w['D3']), 126)
         check(L.nemo_rot6d_fwd(N, 21, dptr(w['D3']), 126, 0, None, dptr(w['AAdec']), st), 'nemo_rot6d_fwd')
-        check(L.nemo_kl_fwd_bwd(N, 32, dptr(w['MULV']), 64, self.scal.data_ptr() + 4 * S_KL,
-                                dptr(w['dMULV']), 64, st), 'nemo_kl_fwd_bwd')
+        return enc_done
+
+    def vposer_kl(self, w, N):
+        """K12: KL( N(mu, softplus(logvar)) || N(0, 1) ) and its gradient w.r.t. (mu | logvar)."""
+        check(self.lib.nemo_kl_fwd_bwd(N, 32, dptr(w['MULV']), 64, self.scal.data_ptr() + 4 * S_KL,
+                                       dptr(w['dMULV']), 64, _stream()), 'nemo_kl_fwd_bwd')
 
     def forward_v2v(self, w, N, need_grad):
         """K10 + K11: the two full-mesh bodies, L1 sum and (same pass) its gradient wrt the pose.
@@ -508,57 +520,54 @@ class FitEngine:
         # exact 0 there), so its column sum is skipped unless the global trajectory is un-anchored.
         nout = 147 if has_trans_grad else 144
         nbias = 147 if (has_trans_grad and self.start_global_traj_anywhere) else 144
-        # Each layer's dY keeps its own buffer; the bias column sums are one batched launch at the end.
-        # NEMO_OVERLAP_DW=1 runs every parameter-gradient GEMM on the side stream as soon as its layer's
-        # dY exists (off the dependent activation-gradient chain).  Measured on MI355X: no gain at any
-        # batch size (2.063 vs 2.055 ms at N = 2400, 0.876 vs 0.862 ms at N = 300) -- the chain's GEMMs
-        # already keep the machine busy enough that a concurrent GEMM only takes CUs from them -- so it
-        # is off by default.
+        # Schedule: the activation-gradient chain (dX GEMMs) and the parameter-gradient GEMMs stay on the main stream
+        # (each of them fills the machine; co-scheduling two of them measured no gain).  The SMALL kernels leave the
+        # chain: the batched bias column sums run on the side stream as soon as the last dY exists (under the layer-0
+        # dX GEMM), and the three phase / RBF / code backward kernels, which only need dX, run there under the
+        # layer-0 dW GEMM.  (NEMO_SERIAL_BWD=1: everything on the main stream, for A/B timing.)
         main, side = torch.cuda.current_stream(), self.side_stream
-        overlap = self.overlap_dw
-
-        def params(ready_after, *a, **k):
-            if not overlap:
-                return self._linear_bwd_params(*a, **k)
-            side.wait_event(ready_after)
-            with torch.cuda.stream(side):
-                self._linear_bwd_params(*a, **k)
-
-        ev = main.record_event() if overlap else None
-        params(ev, r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
-               self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
+        overlap = self.overlap_bwd
+        self._linear_bwd_params(r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
+                                self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
         self.gemm(0, 0, r, h, nout, dptr(w['dHEAD']), HEAD_LD, self.p(lm + 'rot_out.weight'), h,
                   dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1)
-        ev = main.record_event() if overlap else None
-        params(ev, r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'),
-               self.g(lm + 'net.net.4.bias'))
+        self._linear_bwd_params(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'),
+                                self.g(lm + 'net.net.4.bias'))
         self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
                   mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx')
-        ev = main.record_event() if overlap else None
-        params(ev, r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h,
-               self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+        self._linear_bwd_params(r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h,
+                                self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
         self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
                   mask=dptr(w['H1']), ldmask=h, mask_mode=1)
-        ev = main.record_event() if overlap else None
-        params(ev, r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h,
-               self.g(lm + 'net.net.0.weight'), self.g(lm + 'net.net.0.bias'))
-        self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
-                  dptr(w['dX']), self.ldx)
+        # (queue the layer-0 bias sum now: every dY of the batched column sums exists from here on)
+        self._colsums.append((dptr(w['dH_c']), r, h, h, self.g(lm + 'net.net.0.bias')))
         if overlap:
+            side.wait_stream(main)
             with torch.cuda.stream(side):
                 self.flush_colsums()
-        else:
-            self.flush_colsums()
-        check(L.nemo_phase_embed_bwd(
-            N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
-            self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), 2 * self.K,
-            self.p('phase_rbf.log_sigmas') if self.D > 0 else None, self.kernel_id, dptr(w['phase']),
-            dptr(w['dX']), self.ldx, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
-            self.g('phase_networks.0.scales'),
-            self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
-            self.g('learned_instance_code') if self.C > 0 else None, st), 'nemo_phase_embed_bwd')
+        self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
+                  dptr(w['dX']), self.ldx)
+
+        def phase_bwd():
+            check(L.nemo_phase_embed_bwd(
+                N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
+                self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), self.ldp,
+                self.p('phase_rbf.log_sigmas') if self.D > 0 else None, self.kernel_id, dptr(w['phase']),
+                dptr(w['dX']), self.ldx, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
+                self.g('phase_networks.0.scales'),
+                self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
+                self.g('learned_instance_code') if self.C > 0 else None, _stream()), 'nemo_phase_embed_bwd')
+        if overlap:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                phase_bwd()
+        self.gemm(1, 0, h, self.din, r, dptr(w['dH_c']), h, dptr(w['X']), self.ldx,
+                  self.g(lm + 'net.net.0.weight'), self.din, out_mode=1)
         if overlap:
             main.wait_stream(side)
+        else:
+            self.flush_colsums()
+            phase_bwd()
 
     def finish_trans_grad(self, w, N):
         """d trans_0 = - sum_s d trans_s  (row N of dTR), :3764-3766."""

@@ -429,13 +429,21 @@ class MultiViewModel(nn.Module):
             e.grads.zero_()
         e.forward_pose(w, N, vi, fi, code_noise=self._noise(N))
         main = torch.cuda.current_stream()
-        side = e.side_stream
+        side, side2 = e.side_stream, e.side_stream2
         side.wait_stream(main)
+        side2.wait_stream(main)
         aa69, daa69 = w['AA'].data_ptr() + 12, w['dAA'].data_ptr() + 12
+        # side : VPoser encode -> decode -> axis-angle (the mesh term waits for it)
+        # side2: everything that accumulates into dAA -- GMM prior, 3-D pose term (they only need the pose), then, once
+        #        the encoder output exists, KL and its backward through the frozen encoder.  One stream for all of
+        #        them: their `+=` into dAA are plain read-modify-writes.
+        enc_done = None
         with torch.cuda.stream(side):
+            if use_vposer:
+                enc_done = e.forward_vposer(w, N)                             # always evaluated, :3569
+        with torch.cuda.stream(side2):
             st = _stream()
             if use_vposer:
-                e.forward_vposer(w, N)                                        # always evaluated, :3569
                 g = e.gmm
                 check(e.lib.nemo_gmm_fwd_bwd(N, g['M'], 69, aa69, 72, dptr(g['means']), dptr(g['prec']),
                                              dptr(g['log_nllw']), dptr(w['gmm_ws']),
@@ -443,13 +451,16 @@ class MultiViewModel(nn.Module):
                                              float(a.weight_gmm_loss) * sh.mr,
                                              daa69 if (update and a.weight_gmm_loss) else None, 72, st),
                       'nemo_gmm_fwd_bwd')
-                if update and a.weight_vp_z_loss:
-                    e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
             if self.VERSION >= 3 and getattr(a, 'weight_3d_loss', 0):
                 check(e.lib.nemo_pose3d_fwd_bwd(N, 69, aa69, 72, dptr(e.hmr_theta), dptr(e.hmr_mask),
                                                 dptr(vi), dptr(fi), e.T, e.scal.data_ptr() + 4 * S_3D,
                                                 float(a.weight_3d_loss) * sh.mr, daa69 if update else None,
                                                 72, st), 'nemo_pose3d_fwd_bwd')
+            if use_vposer:
+                side2.wait_event(enc_done)
+                e.vposer_kl(w, N)
+                if update and a.weight_vp_z_loss:
+                    e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
         Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0)
         # optional temporal smoothness of the output joints (not part of the published step; only defined on
         # complete (view, frame) sequences, i.e. full-batch steps -- see DESIGN.md section 8, row f-4)
@@ -464,6 +475,7 @@ class MultiViewModel(nn.Module):
             e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose,
                           dj3d_extra=dj)
         main.wait_stream(side)
+        main.wait_stream(side2)
         # the fused mesh kernel is sized to fill the machine in exactly one resident wave of blocks:
         # it runs alone (anything co-scheduled pushes part of its grid into a second wave, +60 %)
         if use_vposer:

@@ -228,7 +228,7 @@ def _c5_worker(rank, world, port, q):
     from nemo_cvpr2023_amd.dist import ShardedNemo
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
     args = syn.published_args(batch_size=512, out_dir='')
-    args.weight_smooth = 3.0
+    args.weight_smooth = 1e5
     seqs = syn.SyntheticSequences(8, 300, seed=1234)
     m = ShardedNemo(2, args, seqs, 'cuda:0', rank=rank, world=world, seed=0,
                     smpl_assets=syn.make_smpl_assets(6890, seed=1), vposer_state=syn.make_vposer_state(),
@@ -260,7 +260,7 @@ def test_sharded_c5_real_size_equals_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     args = syn.published_args(batch_size=512, out_dir='')
-    args.weight_smooth = 3.0
+    args.weight_smooth = 1e5
     seqs = syn.SyntheticSequences(8, 300, seed=1234)
     torch.manual_seed(0)
     state = make_init_state(args, 2, 8, seqs.IMG_D0)

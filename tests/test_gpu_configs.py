@@ -108,12 +108,12 @@ def test_c5_all_terms_and_smoothness_full_mesh_vs_oracle(version):
     from oracle.model import OracleNemo
     over = dict(weight_instance_loss=0.1, weight_3d_loss=0.5) if version >= 3 else {}
     m, args, seqs, assets, vps, gmm = _build(8, 300, version=version, **over)
-    args.weight_smooth = 3.0
+    args.weight_smooth = 1e5
     o = OracleNemo(version, args, seqs, assets, vps, gmm, state={k: v.detach().cpu() for k, v in m.state_dict().items()})
     ld_o, info_o = o.step(None, None, update=True, full_batch=True)
     ld_h, info_h = m.step(None, None, update=True, full_batch=True)
     assert ld_h.keys() == ld_o.keys() and float(ld_o['smooth_loss']) > 0
-    assert float(args.weight_smooth * ld_o['smooth_loss']) > 1e-2 * float(ld_o['total_loss'])    # the term matters
+    assert float(args.weight_smooth * ld_o["smooth_loss"]) > 5e-3 * float(ld_o["total_loss"])    # the term matters
     for k in ld_o:
         assert rel_err(ld_h[k], ld_o[k]) < 1e-4, (k, ld_h[k], ld_o[k])
     assert rel_err(info_h['loss_all'], info_o['loss_all']) < 1e-4 and rel_err(info_h['j'], info_o['j']) < 1e-4
@@ -187,3 +187,32 @@ def test_graph_replay_sees_host_side_switches():
         o.P['learned_betas'].copy_(new)
     both(3)
     both(2, update=False)
+
+
+@pytest.mark.parametrize('K', [10, 7])
+def test_phase_networks_with_node_counts_that_are_not_a_multiple_of_four(K):
+    """The V phase networks sit [shifts_0 | scales_0 | shifts_1 | ...] in the flat parameter buffer with every tensor
+    on a 16-byte boundary: for K % 4 != 0 the stride between two views' networks is NOT 2K (a round-1 bug that the
+    sharded-vs-unsharded comparison of round 2 exposed: views >= 1 read their neighbours' nodes)."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    from oracle.model import OracleNemo
+    V, T, B = 4, 9, 16
+    args = syn.published_args(h_dim=32, monotonic_network_n_nodes=K, batch_size=B, out_dir='', phase_rbf_dim=8,
+                              phase_init='rand')
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(128, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    torch.manual_seed(0)
+    m = NemoV2(args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+    with torch.no_grad():
+        m.learned_motion.rot_out.weight.mul_(2e3)
+    o = OracleNemo(2, args, seqs, assets, vps, gmm, state={k: v.detach().cpu() for k, v in m.state_dict().items()})
+    for it in range(3):
+        ld_o, info_o = o.step(None, None, update=True, full_batch=True)
+        ld_h, info_h = m.step(None, None, update=True, full_batch=True)
+        for k in ld_o:
+            assert rel_err(ld_h[k], ld_o[k]) < 1e-4, (it, k, ld_h[k], ld_o[k])
+        assert rel_err(info_h['j'], info_o['j']) < 1e-4
+        if it == 0:
+            named = dict(m.named_parameters())
+            for k in ('phase_networks.0.shifts', 'phase_networks.3.shifts', 'phase_networks.2.scales'):
+                assert rel_err(named[k].grad, o.P[k].grad) < 2e-3, k
