@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 4
+#define NEMO_ABI_VERSION 5
 int32_t nemo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -285,7 +285,7 @@ typedef struct {
     float step_size;        /* lr / (1 - beta1^t), computed in double on the host */
     float bias_corr2_sqrt;  /* sqrt(1 - beta2^t) */
     int32_t adamw;                                        /* 0: coupled L2 (Adam), 1: decoupled */
-    int32_t pad;
+    int32_t step;           /* t: updates applied to this segment so far (device tables: advanced by nemo_step_begin) */
 } nemo_adam_seg;
 int32_t nemo_adam_step(int32_t n_seg, const nemo_adam_seg* segs /* HOST */, float* params,
                        const float* grads, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
@@ -296,6 +296,16 @@ int32_t nemo_adam_step(int32_t n_seg, const nemo_adam_seg* segs /* HOST */, floa
 int32_t nemo_adam_step_dev(int32_t n_seg, const nemo_adam_seg* segs_dev, int64_t max_numel, float* params,
                            const float* grads, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
                            float eps, void* stream);
+
+/* First launch of a step (replaces two memsets and the per-step host-to-device copy of the Adam table of the
+ * graph-replayed step, `zero_grad()` x k + the bias corrections of :3586-3592): zero-fills the byte ranges
+ * [z0, z0 + bytes0) and [z1, z1 + bytes1) (either may be NULL / 0; 16-byte aligned, multiples of 4 bytes) and, when
+ * segs_dev != NULL, advances the n_seg entries of a DEVICE segment table by one update: step += 1,
+ * step_size = lr / (1 - beta1^step), bias_corr2_sqrt = sqrt(1 - beta2^step) (float64 arithmetic, as torch computes
+ * them on the host).  A later nemo_adam_step_dev of the same stream then applies update number `step`; the host only
+ * re-uploads the table when a learning rate, the segment list or the step counts change under it. */
+int32_t nemo_step_begin(void* z0, int64_t bytes0, void* z1, int64_t bytes1, nemo_adam_seg* segs_dev, int32_t n_seg,
+                        double beta1, double beta2, void* stream);
 
 /* Small utilities. */
 int32_t nemo_scale_neg_rowsum(int64_t N, int64_t cols, const float* X, int64_t ldx, float* out_row,

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_float, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_double, c_float, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NEMO_HIP_LIB') or os.path.join(_HERE, 'libnemo_hip.so')    # env: kernel-variant A/B runs
@@ -21,12 +21,12 @@ class ColsumDesc(Structure):
 
 class AdamSeg(Structure):
     _fields_ = [('offset', c_int64), ('numel', c_int64), ('lr', c_float), ('weight_decay', c_float),
-                ('step_size', c_float), ('bias_corr2_sqrt', c_float), ('adamw', c_int32), ('pad', c_int32)]
+                ('step_size', c_float), ('bias_corr2_sqrt', c_float), ('adamw', c_int32), ('step', c_int32)]
 
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 4        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 5        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -79,6 +79,7 @@ SIGNATURES = {
     'nemo_pose3d_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, f32, ptr, i64, ptr]),
     'nemo_adam_step': (i32, [i32, POINTER(AdamSeg), ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),
     'nemo_adam_step_dev': (i32, [i32, ptr, i64, ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),
+    'nemo_step_begin': (i32, [ptr, i64, ptr, i64, ptr, i32, c_double, c_double, ptr]),
     'nemo_scale_neg_rowsum': (i32, [i64, i64, ptr, i64, ptr, ptr]),
 }
 

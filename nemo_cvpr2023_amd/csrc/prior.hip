@@ -309,6 +309,28 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamSegs segs, const nemo_ada
     }
 }
 
+// First launch of a step: the two zero-fills of the step (gradient buffer, per-workspace accumulator arena) and the
+// per-update bookkeeping of the device-resident Adam table in ONE launch.
+__global__ __launch_bounds__(256) void step_begin_kernel(float4* __restrict__ z0, long n0, float4* __restrict__ z1,
+                                                         long n1, float* __restrict__ t0, int r0,
+                                                         float* __restrict__ t1, int r1, nemo_adam_seg* segs, int n_seg,
+                                                         double b1, double b2) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long i = i0; i < n0; i += stride) z0[i] = z;
+    for (long i = i0; i < n1; i += stride) z1[i] = z;
+    if (i0 < r0) t0[i0] = 0.f;                                  // (< 4 trailing floats each)
+    if (i0 < r1) t1[i0] = 0.f;
+    if (segs && blockIdx.x == 0 && threadIdx.x < n_seg) {
+        nemo_adam_seg sg = segs[threadIdx.x];
+        sg.step += 1;
+        sg.step_size = (float)((double)sg.lr / (1.0 - pow(b1, (double)sg.step)));
+        sg.bias_corr2_sqrt = (float)sqrt(1.0 - pow(b2, (double)sg.step));
+        segs[threadIdx.x] = sg;
+    }
+}
+
 // Loss read-back without a host-side stream synchronisation: the values become final in the middle of the
 // step (after the mesh kernel; the MLP backward and Adam follow), so one wave copies them to pinned,
 // device-mapped host memory and raises a flag the host polls -- the host returns the losses and prepares
@@ -322,6 +344,24 @@ __global__ void publish_kernel(const float* __restrict__ src, int n, float* __re
 }
 
 }  // namespace
+
+extern "C" int32_t nemo_step_begin(void* z0, int64_t bytes0, void* z1, int64_t bytes1, nemo_adam_seg* segs_dev,
+                                   int32_t n_seg, double beta1, double beta2, void* stream) {
+    if (bytes0 < 0 || bytes1 < 0 || (bytes0 && !z0) || (bytes1 && !z1) || ((bytes0 | bytes1) & 3) ||
+        (((uintptr_t)z0 | (uintptr_t)z1) & 15) || n_seg < 0 || n_seg > NEMO_ADAM_MAX_SEG)
+        return NEMO_EINVAL;
+    if (!segs_dev) n_seg = 0;
+    if (bytes0 == 0 && bytes1 == 0 && n_seg == 0) return NEMO_OK;
+    const long n0 = bytes0 / 16, n1 = bytes1 / 16;
+    int blocks = nemo_cdiv((n0 > n1 ? n0 : n1), 256 * 4);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(step_begin_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)z0, n0, (float4*)z1, n1,
+                       (float*)z0 + 4 * n0, (int)((bytes0 & 15) / 4), (float*)z1 + 4 * n1, (int)((bytes1 & 15) / 4),
+                       n_seg ? segs_dev : nullptr, (int)n_seg, beta1, beta2);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
 
 extern "C" int32_t nemo_publish_scalars(const float* src, int32_t n, float* host_dst, int32_t* host_flag,
                                         void* stream) {

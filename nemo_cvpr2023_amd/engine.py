@@ -259,6 +259,7 @@ class FitEngine:
         return self.view(name, self.grads).data_ptr()
 
     # ------------------------------------------------------------------ workspaces
+    SMALL_BATCH_ROWS = 1024  # backward_mlp: below this many rows the dW GEMMs run beside the dX chain
     MAX_WORKSPACES = 24      # distinct batch sizes kept alive (a rank of a sharded minibatch run sees many)
 
     def _ws(self, N):
@@ -520,33 +521,35 @@ class FitEngine:
         # exact 0 there), so its column sum is skipped unless the global trajectory is un-anchored.
         nout = 147 if has_trans_grad else 144
         nbias = 147 if (has_trans_grad and self.start_global_traj_anywhere) else 144
-        # Schedule: the activation-gradient chain (dX GEMMs) and the parameter-gradient GEMMs stay on the main stream
-        # (each of them fills the machine; co-scheduling two of them measured no gain).  The SMALL kernels leave the
-        # chain: the batched bias column sums run on the side stream as soon as the last dY exists (under the layer-0
-        # dX GEMM), and the three phase / RBF / code backward kernels, which only need dX, run there under the
-        # layer-0 dW GEMM.  (NEMO_SERIAL_BWD=1: everything on the main stream, for A/B timing.)
+        # Schedule.  Large batches (each GEMM fills the machine; co-scheduling two of them measured no gain): the
+        # activation-gradient chain (dX) and the parameter-gradient GEMMs (dW) alternate on the main stream and only the
+        # SMALL kernels leave it -- the batched bias column sums run on a side stream as soon as the last dY exists
+        # (under the layer-0 dX GEMM), the three phase / RBF / code backward kernels, which only need dX, under the
+        # layer-0 dW GEMM.  Small batches (one rank's share at 8 GPUs: a GEMM is ~80 tiles, a third of the CUs): the dW
+        # GEMMs are off the dependency chain, so they ALL go to the side stream, each as soon as its dY exists, and
+        # the chain dX_head -> dX4 -> dX2 -> dX0 -> phase backward runs uninterrupted on the main stream.
+        # (NEMO_SERIAL_BWD=1: everything on the main stream, for A/B timing.)
         main, side = torch.cuda.current_stream(), self.side_stream
         overlap = self.overlap_bwd
-        self._linear_bwd_params(r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
-                                self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
+        small = overlap and r <= self.SMALL_BATCH_ROWS
+
+        def dW(*a, **k):
+            if not small:
+                return self._linear_bwd_params(*a, **k)
+            side.wait_stream(main)                      # (its dY was the last thing enqueued on the main stream)
+            with torch.cuda.stream(side):
+                self._linear_bwd_params(*a, **k)
+
+        dW(r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
+           self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
         self.gemm(0, 0, r, h, nout, dptr(w['dHEAD']), HEAD_LD, self.p(lm + 'rot_out.weight'), h,
                   dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1)
-        self._linear_bwd_params(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'),
-                                self.g(lm + 'net.net.4.bias'))
+        dW(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
         self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
                   mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx')
-        self._linear_bwd_params(r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h,
-                                self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+        dW(r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
         self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
                   mask=dptr(w['H1']), ldmask=h, mask_mode=1)
-        # (queue the layer-0 bias sum now: every dY of the batched column sums exists from here on)
-        self._colsums.append((dptr(w['dH_c']), r, h, h, self.g(lm + 'net.net.0.bias')))
-        if overlap:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self.flush_colsums()
-        self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
-                  dptr(w['dX']), self.ldx)
 
         def phase_bwd():
             check(L.nemo_phase_embed_bwd(
@@ -557,15 +560,35 @@ class FitEngine:
                 self.g('phase_networks.0.scales'),
                 self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
                 self.g('learned_instance_code') if self.C > 0 else None, _stream()), 'nemo_phase_embed_bwd')
-        if overlap:
+
+        def dX0():
+            self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
+                      dptr(w['dX']), self.ldx)
+        w0 = (r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h,
+              self.g(lm + 'net.net.0.weight'), self.g(lm + 'net.net.0.bias'))
+        if small:
+            dW(*w0)
+            with torch.cuda.stream(side):
+                self.flush_colsums()
+            dX0()
+            phase_bwd()
+            main.wait_stream(side)
+        elif overlap:
+            # (queue the layer-0 bias sum now: every dY of the batched column sums exists from here on)
+            self._colsums.append((dptr(w['dH_c']), r, h, h, self.g(lm + 'net.net.0.bias')))
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.flush_colsums()
+            dX0()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 phase_bwd()
-        self.gemm(1, 0, h, self.din, r, dptr(w['dH_c']), h, dptr(w['X']), self.ldx,
-                  self.g(lm + 'net.net.0.weight'), self.din, out_mode=1)
-        if overlap:
+            self.gemm(1, 0, h, self.din, r, dptr(w['dH_c']), h, dptr(w['X']), self.ldx,
+                      self.g(lm + 'net.net.0.weight'), self.din, out_mode=1)
             main.wait_stream(side)
         else:
+            self._linear_bwd_params(*w0)
+            dX0()
             self.flush_colsums()
             phase_bwd()
 
@@ -603,20 +626,40 @@ class FitEngine:
                                           self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(),
                                           v.data_ptr(), 0.9, 0.999, 1e-8, _stream()), 'nemo_adam_step')
 
-    # ---- graph-capturable variant: the segment table lives in device memory
-    def adam_table_upload(self, segments):
-        """Write this step's segment table (async H2D on the current stream).  The table layout
-        (count, offsets, sizes) must not change between a captured graph and its replays."""
+    # ---- graph-capturable variant: the segment table lives in device memory and is advanced ON the device
+    def adam_table_sync(self, segments):
+        """Make the device-resident segment table describe the update BEFORE this step's (step counts t - 1):
+        ``step_begin`` inside the captured step advances it to t and refreshes the bias corrections, so in the steady
+        state nothing is uploaded.  A (pinned, async) upload happens only when a learning rate, the segment list or
+        the step counts differ from what the device holds -- first use, a plateau-scheduler drop, a loaded optimiser
+        state, steps taken meanwhile by another path (warm-up, camera fit, eager steps)."""
         n = len(segments)
         assert 0 < n <= _lib.ADAM_MAX_SEG
         if self._seg_host is None:
             nbytes = ctypes.sizeof(AdamSeg) * _lib.ADAM_MAX_SEG
             self._seg_host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
             self._seg_dev = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
-        arr = (AdamSeg * n).from_address(self._seg_host.data_ptr())
-        self._fill_segs(arr, segments)
-        self._seg_dev.copy_(self._seg_host, non_blocking=True)
-        return n, max(s['numel'] for s in segments)
+            self._seg_shadow = None
+        want = [(s_['offset'], s_['numel'], s_['lr'], s_['wd'], bool(s_['adamw']), s_['step'] - 1) for s_ in segments]
+        if want != self._seg_shadow:
+            arr = (AdamSeg * n).from_address(self._seg_host.data_ptr())
+            for i, (off, numel, lr, wd, adamw, t_prev) in enumerate(want):
+                arr[i].offset, arr[i].numel, arr[i].lr, arr[i].weight_decay = off, numel, lr, wd
+                arr[i].adamw, arr[i].step = 1 if adamw else 0, t_prev
+                arr[i].step_size, arr[i].bias_corr2_sqrt = 0.0, 1.0          # (written by step_begin)
+            self._seg_dev.copy_(self._seg_host, non_blocking=True)
+        # what the table holds once this step's step_begin has run
+        self._seg_shadow = [(off, numel, lr, wd, adamw, t_prev + 1) for off, numel, lr, wd, adamw, t_prev in want]
+        return n, max(s_['numel'] for s_ in segments)
+
+    def step_begin(self, arena, zero_grads, n_seg=0):
+        """First launch of a step: zero the workspace's accumulator arena (+ the flat gradient buffer) and, for a
+        captured update step, advance the device Adam table -- one kernel instead of two memsets and a copy."""
+        check(self.lib.nemo_step_begin(arena.data_ptr(), arena.numel() * 4,
+                                       self.grads.data_ptr() if zero_grads else None,
+                                       self.grads.numel() * 4 if zero_grads else 0,
+                                       self._seg_dev.data_ptr() if n_seg else None, n_seg, 0.9, 0.999, _stream()),
+              'nemo_step_begin')
 
     def adam_from_table(self, n, max_numel):
         check(self.lib.nemo_adam_step_dev(n, self._seg_dev.data_ptr(), max_numel, self.params.data_ptr(),
@@ -640,18 +683,19 @@ class FitEngine:
         self._pub_flag[0] = 0
 
     def wait_scalars(self, timeout_s=120.0):
-        """Poll the pinned flag.  A short spin covers the common case (the scalars land within tens of
-        microseconds of the host getting here); after that the thread yields its time slice between polls
-        (``sleep(0)``: one rank per GPU must not pin eight host cores at 100 %), and sleeps 50 us per poll once the
-        wait is long (a C4-size step takes > 100 ms)."""
+        """Poll the pinned flag.  Steps of the sizes this engine is built for last 0.3 - 2 ms and the next launch is
+        latency-critical, so the thread spins for the first 2 ms (measured: yielding the core between polls --
+        ``sleep(0)`` -- makes the step time jitter by 3 - 8 %); a wait that outlasts that (a C4-size step takes
+        > 100 ms) backs off to one poll per 50 us so that one rank per GPU does not pin eight host cores."""
         flag = self._pub_flag
-        for _ in range(2000):
-            if flag[0]:
-                return self._pub_np[:8].copy()
-        t0, polls = time.monotonic(), 0
+        t0, polls = None, 0
         while flag[0] == 0:
             polls += 1
-            time.sleep(0 if polls < 512 else 5e-5)
-            if polls & 0x3FF == 0 and time.monotonic() - t0 > timeout_s:
-                raise _lib.NemoHipError('loss read-back flag never raised (device fault or hung kernel?)')
+            if polls & 0xFF == 0:
+                now = time.monotonic()
+                t0 = t0 or now
+                if now - t0 > 2e-3:
+                    time.sleep(5e-5)
+                    if now - t0 > timeout_s:
+                        raise _lib.NemoHipError('loss read-back flag never raised (device fault or hung kernel?)')
         return self._pub_np[:8].copy()

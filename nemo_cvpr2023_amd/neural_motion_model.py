@@ -410,7 +410,7 @@ class MultiViewModel(nn.Module):
 
     # ------------------------------------------------------------------ the hot path
     def _forward_backward(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False, sh=None,
-                          smooth_ok=False, extra_losses=None, publish=False, part='all'):
+                          smooth_ok=False, extra_losses=None, publish=False, part='all', adam_segs=0):
         """Forward of :3511-3584 (+V3 extras) and, when ``update``, the whole backward down to the
         parameter gradients.  After the pose MLP the step forks into two independent branches that
         run CONCURRENTLY on two HIP streams (most of their kernels are too small to fill 256 CUs):
@@ -424,9 +424,8 @@ class MultiViewModel(nn.Module):
         # point where the loss scalars are final, 'tail' = the rest of the backward (see step())
         if part == 'tail':
             return self._backward_tail(w, N, vi, fi, update, use_vposer, sh)
-        w['zero_arena'].zero_()          # loss scalars, view accumulators, dAA, dJp, dA2, dPF2 in one memset
-        if update:
-            e.grads.zero_()
+        # loss scalars, view accumulators, dAA, dJp, dA2, dPF2, the gradient buffer (and the device Adam table's step)
+        e.step_begin(w['zero_arena'], bool(update), adam_segs)
         e.forward_pose(w, N, vi, fi, code_noise=self._noise(N))
         main = torch.cuda.current_stream()
         side, side2 = e.side_stream, e.side_stream2
@@ -540,7 +539,8 @@ class MultiViewModel(nn.Module):
                         code, alpha=2.0 * float(a.weight_instance_loss) * sh.vr / code.numel())
             if N > 0:
                 self._forward_backward(w, N, vi_, fi_, update, sh=sh, smooth_ok=is_full,
-                                       extra_losses=inst_term if has_inst else None, publish=early, part=part)
+                                       extra_losses=inst_term if has_inst else None, publish=early, part=part,
+                                       adam_segs=adam_table[0] if adam_table is not None else 0)
             elif part != 'tail':        # a shard may own none of a minibatch's samples
                 e.scal.zero_()
                 if update:
@@ -600,7 +600,7 @@ class MultiViewModel(nn.Module):
                         w['vi_static'].copy_(vi)
                         w['fi_static'].copy_(fi)
                     w['_static_src'], w['_static_vi'] = src, vi
-            table = e.adam_table_upload(segs) if (in_graph_adam and part != 'head') else None
+            table = e.adam_table_sync(segs) if (in_graph_adam and part != 'head') else None
             entry = w['graphs'].get(key)
             if entry == 'eager':
                 body(w['vi_static'], w['fi_static'], table, part)
