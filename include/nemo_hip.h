@@ -53,6 +53,14 @@ int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int6
                       const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
                       int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream);
 #define NEMO_GEMM_WS_MIN (16384 + 65536)
+/* Same contraction, arguments and epilogues with both operands rounded to bf16 (RNE) on their way from LDS into the
+ * matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulate, fp32 in memory on both sides -- BASELINE configs[2].
+ * Operands that do not qualify for the LDS-DMA kernel (rows not 16-byte aligned) are multiplied in fp32 instead. */
+int32_t nemo_gemm_bf16(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
+                       const float* A, int64_t lda, const float* B, int64_t ldb,
+                       float* C, int64_t ldc, const float* bias, int32_t act,
+                       const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
+                       int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream);
 /* out[n] += sum_m X[m*ldx+n]   (bias gradients). */
 int32_t nemo_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* stream);
 /* The same for up to NEMO_COLSUM_MAX matrices in ONE launch (all bias gradients of the MLP backward). */
@@ -235,6 +243,12 @@ int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N);
 int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
                        float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* ws, int64_t ws_bytes,
                        void* stream);
+/* The same with the pose blend (lbs.py:229-233, K = 207) on the bf16 matrix cores: blend shapes rounded to bf16 once
+ * at nemo_ctx_create, pose features rounded when staged, fp32 accumulate; skinning, L1 and the adjoints in fp32.
+ * BASELINE configs[2] ("bf16"); not covered by the 1e-4 parity gate (tests state the bf16 tolerance). */
+int32_t nemo_v2v_fused_bf16(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
+                            float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* ws, int64_t ws_bytes,
+                            void* stream);
 /* Builds the (2N,24,9) rotation set of the two bodies from the MLP pose:
  * rows<N: [R[:,0], Rodrigues(aa[:,3:72])], rows>=N: [R[:,0], Rodrigues(cat(aa_dec, aa[:,66:72]))]
  * (:2783-2791, hmr/geometry.py:9-45). */

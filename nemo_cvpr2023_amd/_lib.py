@@ -33,6 +33,8 @@ SIGNATURES = {
     'nemo_abi_version': (i32, []),
     'nemo_gemm_f32': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32,
                             f32, i32, i32, ptr, i64, ptr]),
+    'nemo_gemm_bf16': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32,
+                             f32, i32, i32, ptr, i64, ptr]),
     'nemo_colsum_f32': (i32, [ptr, i64, i64, i64, ptr, ptr]),
     'nemo_colsum_multi': (i32, [i32, POINTER(ColsumDesc), ptr]),
     'nemo_phase_embed_fwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
@@ -71,6 +73,7 @@ SIGNATURES = {
     'nemo_v2v_skin_l1': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr]),
     'nemo_v2v_fused_ws_bytes': (i64, [ptr, i64]),
     'nemo_v2v_fused': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
+    'nemo_v2v_fused_bf16': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_prep_fwd': (i32, [i64, ptr, ptr, ptr, ptr, ptr]),
     'nemo_v2v_prep_bwd': (i32, [i64, ptr, ptr, f32, ptr, ptr, ptr]),
     'nemo_kl_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, i64, ptr]),

@@ -474,11 +474,11 @@ Plan plan_gemm(long M, long N, long K, bool can_split, long ws_bytes, bool atomi
 
 }  // namespace
 
-extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
-                                 const float* A, int64_t lda, const float* B, int64_t ldb,
-                                 float* C, int64_t ldc, const float* bias, int32_t act,
-                                 const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
-                                 int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream) {
+static int32_t gemm_impl(bool bf16, int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
+                         const float* A, int64_t lda, const float* B, int64_t ldb,
+                         float* C, int64_t ldc, const float* bias, int32_t act,
+                         const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
+                         int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream) {
     if (M < 0 || N < 0 || K < 0 || !C) return NEMO_EINVAL;
     if (M == 0 || N == 0) return NEMO_OK;
     if (K > 0 && (!A || !B)) return NEMO_EINVAL;
@@ -506,7 +506,8 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     unsigned a_bytes = 0, b_bytes = 0;
     const bool glds_ok = vec && use_glds && force_tile != 128 &&
                          glds::extents(transA, transB, M, N, K, lda, ldb, &a_bytes, &b_bytes);
-    Plan pl = plan_gemm(M, N, K, can_split, ws_bytes, out_mode == 2, split_k, vec && !transA && transB, vec, glds_ok);
+    Plan pl = plan_gemm(M, N, K, can_split, ws_bytes, out_mode == 2, split_k,
+                        vec && !transA && transB && !(bf16 && glds_ok), vec, glds_ok);
     if (vec && (force_tile == 64 || force_tile == 128)) {
         pl.tile = force_tile;
         pl.t0 = 0;
@@ -552,6 +553,12 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     if (tile == 64 && glds_ok) {
         g.a_bytes = a_bytes; g.b_bytes = b_bytes;
         const bool akc = !transA, bkc = transB != 0;
+        if (bf16) {
+            if (akc && bkc) e = glds::launch<64, 64, 32, 32, 32, true, true, 3, true, true>(g, (int)blocks, s);
+            else if (akc) e = glds::launch<64, 64, 32, 32, 32, true, false, 3, true, true>(g, (int)blocks, s);
+            else if (bkc) e = glds::launch<64, 64, 32, 32, 32, false, true, 3, true, true>(g, (int)blocks, s);
+            else e = glds::launch<64, 64, 32, 32, 32, false, false, 3, true, true>(g, (int)blocks, s);
+        } else
         if (akc && bkc) e = glds::launch<64, 64, 32, 32, 32, true, true, 3, true>(g, (int)blocks, s);
         else if (akc) e = glds::launch<64, 64, 32, 32, 32, true, false, 3, true>(g, (int)blocks, s);
         else if (bkc) e = glds::launch<64, 64, 32, 32, 32, false, true, 3, true>(g, (int)blocks, s);
@@ -568,6 +575,24 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
     if (e != hipSuccess) return (int32_t)e;
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
+}
+
+extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
+                                 const float* A, int64_t lda, const float* B, int64_t ldb,
+                                 float* C, int64_t ldc, const float* bias, int32_t act,
+                                 const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
+                                 int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream) {
+    return gemm_impl(false, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, mask, ldmask, mask_mode, alpha,
+                     out_mode, split_k, ws, ws_bytes, stream);
+}
+
+extern "C" int32_t nemo_gemm_bf16(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
+                                  const float* A, int64_t lda, const float* B, int64_t ldb,
+                                  float* C, int64_t ldc, const float* bias, int32_t act,
+                                  const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
+                                  int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream) {
+    return gemm_impl(true, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, mask, ldmask, mask_mode, alpha,
+                     out_mode, split_k, ws, ws_bytes, stream);
 }
 
 // Column sums of a row-major (M x N) matrix: out[n] (+)= sum_m X[m][n].  Bias gradients.

@@ -32,6 +32,7 @@ namespace glds {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // One LDS-DMA piece: 64 lanes x 16 B from buffer `rs` at byte offset voff (per lane) + soff (uniform) to LDS bytes
 // [lds_byte, lds_byte + 1024).  Issued from inline asm on purpose: hipcc orders every later ds_read behind an LDS-DMA
@@ -136,6 +137,25 @@ struct Operand {
         }
     }
 
+    // bf16 path: the eight consecutive k (16 s + 8 h .. + 7) of `row`, rounded to bf16 (RNE) -- one operand of
+    // v_mfma_f32_32x32x16_bf16 (k-step s of the tile, lane half h)
+    static __device__ __forceinline__ bf16x8 fetch8(const float* tile, int row, int s, int h) {
+        float f[8];
+        if (KC) {
+            const int c0 = 4 * s + 2 * h, sw = (row >> 1) & 7;
+            const float4 a = *reinterpret_cast<const float4*>(tile + row * BK + ((c0 ^ sw) << 2));
+            const float4 b = *reinterpret_cast<const float4*>(tile + row * BK + (((c0 + 1) ^ sw) << 2));
+            f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = tile[(16 * s + 8 * h + i) * ROWS + row];
+        }
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];
+        return v;
+    }
+
     // four operands (MFMA steps 0..3) of group q for `row`, k-slice h
     template <int KG>      // 8 (32x32x2) or 16 (16x16x4)
     static __device__ __forceinline__ void fetch(const float* tile, int row, int q, int h, float (&f)[4]) {
@@ -153,7 +173,9 @@ struct Operand {
 // ------------------------------------------------------------------------------------------ kernel
 // 256 threads = 4 waves as (BM/WM) x (BN/WN); a wave owns WM x WN of the block tile as (WM/T) x (WN/T) accumulators of
 // the T x T MFMA (T = 32: v_mfma_f32_32x32x2_f32, T = 16: v_mfma_f32_16x16x4_f32).  NST LDS stages.
-template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false>
+// BF16: operands are rounded to bf16 on their way from LDS into the matrix cores (v_mfma_f32_32x32x16_bf16, fp32
+// accumulate; memory stays fp32 on both sides) -- BASELINE configs[2].
+template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(Args g) {
     constexpr int TM = WM / T, TN = WN / T, WGN = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves");
@@ -168,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(Args g) {
     // burst of 4-8 of them at the top of an iteration leaves the matrix pipe idle for most of it).  The last piece
     // then leaves late in iteration t, so the tile needs two more iterations to land: NST >= 3.
     static_assert(!SPREAD || (UNIFORM && NST >= 3 && T == 32), "spread issue: uniform piece counts, >= 3 stages");
+    static_assert(!BF16 || T == 32, "bf16 path uses the 32x32x16 MFMA");
     constexpr int G = OA::PER_WAVE + OB::PER_WAVE;                           // pieces per wave and tile (UNIFORM)
     typedef float accv __attribute__((ext_vector_type(AR)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -216,7 +239,31 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(Args g) {
         const float* bs = st + OA::FLOATS;
         const unsigned nb = smem_byte + (unsigned)(((t_next < 0 ? 0 : t_next) % NST) * STAGE * 4);
         const long nk = kbeg + (long)(t_next < 0 ? 0 : t_next) * BK;
-        if constexpr (T == 32) {
+        if constexpr (BF16) {
+            // two MFMA k-steps of 16 per tile; the tile being requested goes out in two halves behind them
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = OA::fetch8(as, wm * WM + i * 32 + lr, ks, lh);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = OB::fetch8(bs, wn * WN + j * 32 + lr, ks, lh);
+                if constexpr (SPREAD) {
+                    if (t_next >= 0) {
+#pragma unroll
+                        for (int p = ks * (G / 2); p < (ks == 0 ? G / 2 : G); ++p) {
+                            if (p < OA::PER_WAVE) oa.dma_one(nb, m0, nk, wid, p);
+                            else ob.dma_one(nb + OA::FLOATS * 4, n0, nk, wid, p - OA::PER_WAVE);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else if constexpr (T == 32) {
             float fa[2][TM][4], fb[2][TN][4];
 #pragma unroll
             for (int i = 0; i < TM; ++i) OA::template fetch<KG>(as, wm * WM + i * 32 + lr, 0, lh, fa[0][i]);
@@ -395,11 +442,11 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(Args g) {
         }
 }
 
-template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false>
+template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>
 hipError_t launch(const Args& g, int blocks, hipStream_t s) {
     constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(float);
     static bool attr_set = false;
-    auto kern = &gemm_glds_kernel<BM, BN, WM, WN, T, AKC, BKC, NST, SPREAD>;
+    auto kern = &gemm_glds_kernel<BM, BN, WM, WN, T, AKC, BKC, NST, SPREAD, BF16>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -37,6 +37,9 @@ struct nemo_ctx {
     KpConst kc;
     // device constants
     float *d_posedirs, *d_v_shaped, *d_W, *d_Wt, *d_Jrest, *d_C1, *d_c0, *d_w0;
+    // blend shapes rounded to bf16 (RNE) in MFMA-operand order for nemo_v2v_fused_bf16: [k-step S = 0..6][lane group
+    // g = 0..3][vertex][component][8 consecutive k = 32 S + 8 g ..], zero for k >= 207 and for pad vertices
+    unsigned short* d_posedirs_bf16;
     // host copies needed to re-derive the shape-dependent constants
     std::vector<float> h_v_template, h_shapedirs, h_Jreg, h_W;
     std::vector<std::vector<std::pair<long, float>>> q_rows;   // sparse rows of the nq functionals
@@ -169,6 +172,24 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
                        sizeof(float) * NV * 3, 207, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_W, lbs_weights, sizeof(float) * NV * 24, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_Wt, Wt.data(), sizeof(float) * NV * 24, hipMemcpyHostToDevice));
+    {
+        auto bf16 = [](float f) -> unsigned short {
+            unsigned int u; memcpy(&u, &f, 4);
+            if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);      // NaN
+            return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);                    // round to nearest even
+        };
+        std::vector<unsigned short> pb((size_t)28 * c->NVp * 24, 0);
+        for (int k = 0; k < 207; ++k) {
+            const int S = k / 32, g = (k % 32) / 8, i = k % 8;
+            const float* Pk = posedirs + (size_t)k * NV * 3;
+            for (long v = 0; v < NV; ++v)
+                for (int cc = 0; cc < 3; ++cc)
+                    pb[((((size_t)(S * 4 + g) * c->NVp + v) * 3 + cc) * 8) + i] = bf16(Pk[v * 3 + cc]);
+        }
+        c->d_posedirs_bf16 = nullptr;
+        HIPCHK(hipMalloc((void**)&c->d_posedirs_bf16, pb.size() * 2));
+        HIPCHK(hipMemcpy(c->d_posedirs_bf16, pb.data(), pb.size() * 2, hipMemcpyHostToDevice));
+    }
     if (nq) {
         HIPCHK(hipMemcpy(c->d_C1, C1.data(), sizeof(float) * 207 * nq * 72, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_w0, w0.data(), sizeof(float) * nq * 24, hipMemcpyHostToDevice));
@@ -184,6 +205,7 @@ extern "C" int32_t nemo_ctx_destroy(nemo_ctx* c) {
     float* ptrs[] = {c->d_posedirs, c->d_v_shaped, c->d_W, c->d_Wt, c->d_Jrest, c->d_C1, c->d_c0, c->d_w0};
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->d_posedirs_bf16) (void)hipFree(c->d_posedirs_bf16);
     delete c;
     return NEMO_OK;
 }
@@ -987,7 +1009,15 @@ __global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const
 // alternating vertex tiles.
 #define MF_PFS 226      // pose-feature row stride in LDS (>= 208, == 2 mod 32)
 #define MF_AS 290       // transform row stride in LDS   (>= 288, == 2 mod 32)
+#define MF_PFB 232      // bf16 variant: pose-feature row stride in bf16 elements (464 B: the 16 rows a ds_read_b128 lane
+                        // group touches land in 16 different 16-byte bank quads)
+typedef __bf16 mbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
 
+// BF16: the pose blend (K = 207, 57 % of the kernel's MFMAs) runs on v_mfma_f32_16x16x32_bf16 -- blend shapes rounded
+// to bf16 once in nemo_ctx_create, pose features rounded when they are staged, fp32 accumulate; skinning, L1, and both
+// adjoints stay fp32.  BASELINE configs[2].  P then points at nemo_ctx::d_posedirs_bf16 and ldP is NVp.
+template <bool BF16>
 __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     long N, long NV, const float* __restrict__ PF2, long ldpf, const float* __restrict__ A2,
     const float* __restrict__ P, long ldP, const float* __restrict__ vs, const float* __restrict__ W,
@@ -998,8 +1028,9 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
     // predicate: padded vertices / samples produce v_rec == v_orig == 0, i.e. zero loss and gradient.
     extern __shared__ float lds[];
-    float* pfL = lds;                                   // [2][16][MF_PFS]
-    float* AL = lds + 2 * 16 * MF_PFS;                  // [2][16][MF_AS], entry (e*24 + j)
+    float* pfL = lds;                                   // [2][16][MF_PFS] floats  (BF16: [2][16][MF_PFB] bf16)
+    __bf16* pfB = reinterpret_cast<__bf16*>(lds);
+    float* AL = lds + (BF16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS);     // [2][16][MF_AS], entry (e*24 + j)
     __shared__ float red[16];
     const long ntiles = (NV + 15) / 16;
     // Work = (sample group, chunk of 4 vertex tiles) units, G groups x cpg chunks.  Two classes of blocks, all
@@ -1067,12 +1098,20 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             float4 v = vpf[it];
             if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q == 51) v.w = 0.f;                                 // column 207 is padding
-            float* d = pfL + (set * 16 + n) * MF_PFS + 4 * q;       // 8-byte aligned (MF_PFS even)
-            *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
-            *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+            if (BF16) {
+                typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                const bf4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                *reinterpret_cast<bf4*>(pfB + (set * 16 + n) * MF_PFB + 4 * q) = h;          // 8-byte store
+            } else {
+                float* d = pfL + (set * 16 + n) * MF_PFS + 4 * q;       // 8-byte aligned (MF_PFS even)
+                *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+            }
         }
-        for (int idx = tid; idx < 2 * 16 * 16; idx += 256)          // rows 208..223 of the k padding
-            pfL[(idx / 16) * MF_PFS + 208 + idx % 16] = 0.f;
+        for (int idx = tid; idx < 2 * 16 * 16; idx += 256) {        // rows 208..223 of the k padding
+            if (BF16) pfB[(idx / 16) * MF_PFB + 208 + idx % 16] = (__bf16)0.f;
+            else pfL[(idx / 16) * MF_PFS + 208 + idx % 16] = 0.f;
+        }
 #pragma unroll
         for (int it = 0; it < 9; ++it) {
             const int idx = tid + 256 * it;
@@ -1087,7 +1126,9 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         for (int idx = tid; idx < 2 * 16 * 224; idx += 256) {
             const int set = idx / (16 * 224), n = (idx / 224) % 16, p = idx % 224;
             const long s = s0 + n;
-            pfL[(set * 16 + n) * MF_PFS + p] = (s < N && p < 207) ? PF2[(set * N + s) * ldpf + p] : 0.f;
+            const float val = (s < N && p < 207) ? PF2[(set * N + s) * ldpf + p] : 0.f;
+            if (BF16) pfB[(set * 16 + n) * MF_PFB + p] = (__bf16)val;
+            else pfL[(set * 16 + n) * MF_PFS + p] = val;
         }
         for (int idx = tid; idx < 2 * 16 * 288; idx += 256) {
             const int set = idx / (16 * 288), n = (idx / 288) % 16, je = idx % 288;
@@ -1117,15 +1158,26 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     // single load in flight (it otherwise moves each load to just before its use to save registers).
     // Buffer loads: one descriptor for the blend-shape matrix, a scalar byte offset for (tile, k-step) and
     // ONE 32-bit lane offset -- no 64-bit vector address arithmetic and no address registers in the ring.
+    // (BF16: P = bf16 blend shapes [S][g][vertex][component][8 k], ldP = NVp; one dwordx4 per lane, component and MFMA)
     const __amdgpu_buffer_rsrc_t Prs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(P), 0, (int)(224 * ldP * 4), 0x00020000);
-    const int loff = (g * (int)ldP + l15 * 3) * 4;               // lane: k row g of the step, vertex l15 (bytes)
-    const int kstride = 4 * (int)ldP * 4;                        // bytes between consecutive k-steps
-    u32x3 pa[8];
+        const_cast<float*>(P), 0, BF16 ? (int)(28 * ldP * 48) : (int)(224 * ldP * 4), 0x00020000);
+    const int loff = BF16 ? (g * (int)ldP + l15) * 48 : (g * (int)ldP + l15 * 3) * 4;   // lane part of the address (bytes)
+    const int kstride = BF16 ? 4 * (int)ldP * 48 : 4 * (int)ldP * 4;                    // bytes between consecutive k-steps
+    constexpr int TILE_B = BF16 ? 16 * 48 : 192;                 // bytes between consecutive vertex tiles
+    u32x3 pa[8];                                                 // fp32: eight k-steps (of 4) in flight
+    u32x4m pq[2][3];                                             // bf16: two k-steps (of 32) x 3 components in flight
     {
         const int tf = (int)min(t_beg + wid, ntiles - 1);        // (a wave without tiles loads a valid one)
+        if (BF16) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, tf * 192 + u * kstride, 0);
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    pq[u][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff + 16 * c, tf * TILE_B + u * kstride, 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, tf * 192 + u * kstride, 0);
+        }
     }
     for (long t = t_beg + wid; t < t_end; t += 4) {
         const long v0 = t * 16;
@@ -1150,8 +1202,32 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 const float b = vsl[r * 3 + c];
                 vp[0][c][r] = b; vp[1][c][r] = b;
             }
-        const int pt = (int)t * 192;                             // uniform byte offsets: this wave's vertex tile
-        const int ptn = (int)min(t + 4, ntiles - 1) * 192;       // and its next one (clamped: harmless re-read)
+        const int pt = (int)t * TILE_B;                          // uniform byte offsets: this wave's vertex tile
+        const int ptn = (int)min(t + 4, ntiles - 1) * TILE_B;    // and its next one (clamped: harmless re-read)
+        if constexpr (BF16) {
+            // 7 k-steps of 32 (207 blend shapes + zero rows) x 3 components x 2 bodies = 42 MFMAs
+            const __bf16* pb0 = pfB + (0 * 16 + l15) * MF_PFB + 8 * g;
+            const __bf16* pb1 = pfB + (1 * 16 + l15) * MF_PFB + 8 * g;
+#pragma unroll
+            for (int S = 0; S < 7; ++S) {
+                const mbf16x8 b0 = *reinterpret_cast<const mbf16x8*>(pb0 + 32 * S);
+                const mbf16x8 b1 = *reinterpret_cast<const mbf16x8*>(pb1 + 32 * S);
+                mbf16x8 a[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a[c] = __builtin_bit_cast(mbf16x8, pq[S & 1][c]);
+                if (S + 2 < 7) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        pq[S & 1][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff + 16 * c, pt + (S + 2) * kstride, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    vp[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c], b0, vp[0][c], 0, 0, 0);
+                    vp[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[c], b1, vp[1][c], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
         // B-operands (this lane's pose features, LDS) two k-steps ahead of their use
         float pb[2][2];
 #pragma unroll
@@ -1175,6 +1251,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 vp[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b1, vp[1][2], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
         // ---- reconstruction body, one output row c (4 transform entries) at a time
         float vrec[3][4];
@@ -1228,9 +1305,17 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 // the wave's NEXT tile: first eight k-steps requested here, under the cover of the last 32
                 // adjoint MFMAs and the dvp store (their registers are dead during the skinning phases,
                 // where the pressure peaks -- a ring kept full across the whole tile spills)
+                if (BF16) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, ptn + u * kstride, 0);
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int c2 = 0; c2 < 3; ++c2)
+                            pq[u][c2] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff + 16 * c2, ptn + u * kstride, 0);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, ptn + u * kstride, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -1646,18 +1731,18 @@ extern "C" int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N) {
     return MESH_HEADER_BYTES + groups * (long)(pl.RA + 1) * 96 * 64 * 4;
 }
 
-extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
-                                  const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
-                                  void* ws, int64_t ws_bytes, void* stream) {
+static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const float* PF2, int64_t ldpf,
+                              const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
+                              void* ws, int64_t ws_bytes, void* stream) {
     if (!ctx || N < 0 || !PF2 || !A2 || !loss_sum || !dVPt || !dA || ldpf < 207 || ldn < ((N + 15) / 16) * 16)
         return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
-    const int lds_bytes = (2 * 16 * MF_PFS + 2 * 16 * MF_AS) * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute((const void*)mesh_v2v_fused_kernel,
+    const int lds_bytes = ((bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * MF_AS) * (int)sizeof(float);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[bf16]) {
+        HIPCHK(hipFuncSetAttribute(bf16 ? (const void*)mesh_v2v_fused_kernel<true> : (const void*)mesh_v2v_fused_kernel<false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set = true;
+        attr_set[bf16] = true;
     }
     const int vec_stage = (ldpf % 4 == 0) && (((uintptr_t)PF2 | (uintptr_t)A2) & 15) == 0 && ldpf >= 208;
     const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
@@ -1673,10 +1758,29 @@ extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* P
     float* loss_parts = reinterpret_cast<float*>(wsb + 16);
     int* tickets = reinterpret_cast<int*>(wsb + 16 + MESH_MAX_BLOCKS * 4);
     float* parts = reinterpret_cast<float*>(wsb + MESH_HEADER_BYTES);
-    hipLaunchKernelGGL(mesh_v2v_fused_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes,
-                       (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, ctx->d_posedirs, ctx->ldP,
-                       ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA, pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn,
-                       dA, parts, tickets, loss_parts, grid_ticket);
+    if (bf16)
+        hipLaunchKernelGGL(mesh_v2v_fused_kernel<true>, dim3((unsigned)blocks), dim3(256), lds_bytes,
+                           (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2,
+                           reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp, ctx->d_v_shaped, ctx->d_W, pl.G,
+                           pl.cpg, pl.RA, pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets, loss_parts,
+                           grid_ticket);
+    else
+        hipLaunchKernelGGL(mesh_v2v_fused_kernel<false>, dim3((unsigned)blocks), dim3(256), lds_bytes,
+                           (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, ctx->d_posedirs, ctx->ldP,
+                           ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA, pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn,
+                           dA, parts, tickets, loss_parts, grid_ticket);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
+}
+
+extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
+                                  const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
+                                  void* ws, int64_t ws_bytes, void* stream) {
+    return v2v_fused_impl(ctx, false, N, PF2, ldpf, A2, loss_sum, dVPt, ldn, dA, ws, ws_bytes, stream);
+}
+
+extern "C" int32_t nemo_v2v_fused_bf16(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
+                                       const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
+                                       void* ws, int64_t ws_bytes, void* stream) {
+    return v2v_fused_impl(ctx, true, N, PF2, ldpf, A2, loss_sum, dVPt, ldn, dA, ws, ws_bytes, stream);
 }

@@ -196,6 +196,13 @@ class FitEngine:
         self.C = args.instance_code_size
         self.D = args.phase_rbf_dim if version >= 2 else 0
         self.h = args.h_dim
+        # 'bf16' (BASELINE configs[2]): the dense contractions -- MotionNet / VPoser linear layers forward and backward,
+        # the pose blend of the mesh term and its adjoint -- run on the bf16 matrix cores with fp32 accumulation, fp32
+        # master weights and fp32 activations in memory.  Default 'f32': the reference's arithmetic (1e-4 parity gate).
+        dt = getattr(args, 'gemm_dtype', 'f32') or 'f32'
+        if dt not in ('f32', 'bf16'):
+            raise ValueError(f"args.gemm_dtype must be 'f32' or 'bf16', got {dt!r}")
+        self.bf16 = dt == 'bf16'
         self.din = (self.D if self.D > 0 else 1) + self.C
         self.ldx = (self.din + 3) // 4 * 4          # row stride of the MLP input / its gradient (16-byte rows)
         self.cx, self.cy = float(img_d0 // 2), float(img_d1 // 2)       # :3104-3106 (sic)
@@ -314,16 +321,22 @@ class FitEngine:
 
     # ------------------------------------------------------------------ kernel helpers
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias=None, act=0, mask=None, ldmask=0,
-             mask_mode=0, alpha=1.0, out_mode=0, split_k=0, tag=None):
+             mask_mode=0, alpha=1.0, out_mode=0, split_k=0, tag=None, dense=False):
         """split_k 0: the library picks the tile shape and the K split (combined inside the launch through
-        this stream's scratch)."""
+        this stream's scratch).  dense=True marks the contractions that ``args.gemm_dtype = 'bf16'`` moves to the
+        bf16 matrix cores (nn.Linear forward / backward of MotionNet and VPoser, the blend-shape adjoint); the joint
+        functionals (PF @ C1, millimetre-sensitive) always stay fp32."""
         ev = self._event_begin(tag, 2.0 * M * N * K)
         cur = torch.cuda.current_stream()
         ws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]
-        check(self.lib.nemo_gemm_f32(ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias, act, mask, ldmask,
-                                     mask_mode, alpha, out_mode, split_k, ws.data_ptr(), ws.numel() * 4,
-                                     _stream()), 'nemo_gemm_f32')
+        fn = self.lib.nemo_gemm_bf16 if (dense and self.bf16) else self.lib.nemo_gemm_f32
+        check(fn(ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias, act, mask, ldmask, mask_mode, alpha, out_mode,
+                 split_k, ws.data_ptr(), ws.numel() * 4, _stream()), 'nemo_gemm')
         self._event_end(ev)
+
+    def kernel_dtype(self, tag):
+        """Arithmetic type of a tagged (bench-timed) kernel's matrix-core work: bench.py prices it against that peak."""
+        return 'bf16' if self.bf16 else 'f32'
 
     # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
     # recorded on the stream the kernels are launched on (torch's current stream).
@@ -342,12 +355,13 @@ class FitEngine:
 
     def _linear(self, rows, x, ldx, fin, w, b, fout, y, ldy, act=0, tag=None, ldw=None):
         """y = act(x @ w^T + b), w stored (fout, fin) like nn.Linear (row stride ldw, default fin)."""
-        self.gemm(0, 1, rows, fout, fin, x, ldx, w, fin if ldw is None else ldw, y, ldy, bias=b, act=act, tag=tag)
+        self.gemm(0, 1, rows, fout, fin, x, ldx, w, fin if ldw is None else ldw, y, ldy, bias=b, act=act, tag=tag,
+                  dense=True)
 
     def _linear_bwd_params(self, rows, x, ldx, fin, dy, lddy, fout, gw, gb, nbias=None):
         """gw (fout,fin) += dy^T @ x ;  gb[:nbias] += colsum(dy) (skipped when gb is None).  K = rows
         is split for occupancy."""
-        self.gemm(1, 0, fout, fin, rows, dy, lddy, x, ldx, gw, fin, out_mode=1)
+        self.gemm(1, 0, fout, fin, rows, dy, lddy, x, ldx, gw, fin, out_mode=1, dense=True)
         if gb is not None:       # bias gradients are batched into one launch (flush_colsums)
             self._colsums.append((dy, rows, fout if nbias is None else nbias, lddy, gb))
 
@@ -462,15 +476,16 @@ class FitEngine:
                                 dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
             ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * (2 * 3 * 207 + 2 * 288 + 288))
             ws = w['mesh_ws']
-            check(L.nemo_v2v_fused(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
-                                   self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPt']), ldn, dptr(w['dA2']),
-                                   ws.data_ptr(), ws.numel() * 4, st), 'nemo_v2v_fused')
+            fused = L.nemo_v2v_fused_bf16 if self.bf16 else L.nemo_v2v_fused
+            check(fused(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
+                        self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPt']), ldn, dptr(w['dA2']),
+                        ws.data_ptr(), ws.numel() * 4, st), 'nemo_v2v_fused')
             self._event_end(ev)
             if need_grad:
                 if c0 > 0:
                     w['dPF2'].zero_()
                 self.gemm(1, 1, n, 207, NV3, dptr(w['dVPt']), ldn, ctx.posedirs, ldP, dptr(w['dPF2']), 208,
-                          out_mode=1, tag='gemm_pose_blend_bwd')
+                          out_mode=1, tag='gemm_pose_blend_bwd', dense=True)
                 check(L.nemo_fk_bwd(ctx.handle, n, dptr(w['R2']), dptr(w['A2']), dptr(w['dA2']), None,
                                     dptr(w['dPF2']), 208, w['dR2'].data_ptr() + 4 * c0 * 216, st), 'nemo_fk_bwd')
 
@@ -508,9 +523,9 @@ class FitEngine:
         """d(weight*KL)/d poses[:, :63] through the frozen encoder, accumulated into dAA[:, 3:66]."""
         vp = self.vp
         self.gemm(0, 0, N, 512, 64, dptr(w['dMULV']), 64, dptr(vp['emw']), 512, dptr(w['dE_a']), 512,
-                  alpha=weight, mask=dptr(w['E1']), ldmask=512, mask_mode=2)
+                  alpha=weight, mask=dptr(w['E1']), ldmask=512, mask_mode=2, dense=True)
         self.gemm(0, 0, N, 63, 512, dptr(w['dE_a']), 512, dptr(vp['e2w_p']), 64,
-                  w['dAA'].data_ptr() + 4 * 3, 72, out_mode=1)
+                  w['dAA'].data_ptr() + 4 * 3, 72, out_mode=1, dense=True)
 
     def backward_mlp(self, w, N, view_idx, frame_idx, raw_phase, has_trans_grad=True):
         """dROT (N+1,144), dTR (N+1,3) -> all MLP / RBF / phase / code gradients."""
@@ -543,13 +558,13 @@ class FitEngine:
         dW(r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
            self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
         self.gemm(0, 0, r, h, nout, dptr(w['dHEAD']), HEAD_LD, self.p(lm + 'rot_out.weight'), h,
-                  dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1)
+                  dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1, dense=True)
         dW(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
         self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
-                  mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx')
+                  mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx', dense=True)
         dW(r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
         self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
-                  mask=dptr(w['H1']), ldmask=h, mask_mode=1)
+                  mask=dptr(w['H1']), ldmask=h, mask_mode=1, dense=True)
 
         def phase_bwd():
             check(L.nemo_phase_embed_bwd(
@@ -563,7 +578,7 @@ class FitEngine:
 
         def dX0():
             self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
-                      dptr(w['dX']), self.ldx)
+                      dptr(w['dX']), self.ldx, dense=True)
         w0 = (r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h,
               self.g(lm + 'net.net.0.weight'), self.g(lm + 'net.net.0.bias'))
         if small:
@@ -584,7 +599,7 @@ class FitEngine:
             with torch.cuda.stream(side):
                 phase_bwd()
             self.gemm(1, 0, h, self.din, r, dptr(w['dH_c']), h, dptr(w['X']), self.ldx,
-                      self.g(lm + 'net.net.0.weight'), self.din, out_mode=1)
+                      self.g(lm + 'net.net.0.weight'), self.din, out_mode=1, dense=True)
             main.wait_stream(side)
         else:
             self._linear_bwd_params(*w0)

@@ -13,10 +13,10 @@
 using glds::Args;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-enum Cfg { C64 = 0, C128x64, C64x128, C128, C64x208, S64, S128x64, S64x128, S128, S128x224, NCFG };
+enum Cfg { C64 = 0, C128x64, C64x128, C128, C64x208, S64, S128x64, S64x128, S128, S128x224, B64, B128, NCFG };
 static const char* cfg_name[] = {"64x64", "128x64", "64x128", "128x128", "64x208/16", "64x64 spread", "128x64 spread",
-                                 "64x128 spread", "128x128 spread", "128x224 spread"};
-static const int cfg_bm[] = {64, 128, 64, 128, 64, 64, 128, 64, 128, 128}, cfg_bn[] = {64, 64, 128, 128, 208, 64, 64, 128, 128, 224};
+                                 "64x128 spread", "128x128 spread", "128x224 spread", "64x64 bf16", "128x128 bf16"};
+static const int cfg_bm[] = {64, 128, 64, 128, 64, 64, 128, 64, 128, 128, 64, 128}, cfg_bn[] = {64, 64, 128, 128, 208, 64, 64, 128, 128, 224, 64, 128};
 
 template <bool AKC, bool BKC>
 hipError_t launch_cfg(int cfg, const Args& g, int blocks, hipStream_t s) {
@@ -29,6 +29,8 @@ hipError_t launch_cfg(int cfg, const Args& g, int blocks, hipStream_t s) {
         case S128x64: return glds::launch<128, 64, 64, 32, 32, AKC, BKC, 3, true>(g, blocks, s);
         case S64x128: return glds::launch<64, 128, 32, 64, 32, AKC, BKC, 3, true>(g, blocks, s);
         case S128: return glds::launch<128, 128, 64, 64, 32, AKC, BKC, 3, true>(g, blocks, s);
+        case B64: return glds::launch<64, 64, 32, 32, 32, AKC, BKC, 3, true, true>(g, blocks, s);
+        case B128: return glds::launch<128, 128, 64, 64, 32, AKC, BKC, 3, true, true>(g, blocks, s);
         case S128x224:
             if constexpr (BKC) return glds::launch<128, 224, 32, 224, 32, AKC, true, 3, true>(g, blocks, s);
             return hipErrorInvalidValue;
@@ -107,7 +109,7 @@ int check() {
                         if (!(d <= err)) err = d;
                         scale = fmax(scale, fabs(ref[m * p.N + n]));
                     }
-                    const bool ok = err <= 2e-5 * scale + 1e-6;
+                    const bool ok = err <= ((cfg == B64 || cfg == B128) ? 2e-2 : 2e-5) * scale + 1e-6;
                     if (!ok) ++bad;
                     printf("%-10s ta=%d tb=%d M=%4ld N=%4ld K=%5ld split=%d t0=%d  max err %.3g (scale %.3g) %s\n", cfg_name[cfg], p.ta,
                            p.tb, p.M, p.N, p.K, split, t0, err, scale, ok ? "ok" : "FAIL");
