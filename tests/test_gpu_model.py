@@ -56,6 +56,45 @@ def test_reference_trajectory(name, tmp_path):
            drift=TRAJ_DRIFT.get(name))
 
 
+def test_v1_small_every_recorded_step_from_the_reference_state(tmp_path):
+    """The default-v1 trajectory (30 recorded steps at lr_human = 0.01, plateau schedulers on) step by step: the CPU
+    oracle replays the recording (it tracks the reference to 2e-5 on every number, tests/test_oracle_golden.py), and
+    before EVERY step the HIP model takes over the oracle's parameters, Adam moments, step counts, learning rates
+    and scheduler state -- i.e. (to 2e-5) the reference's own state at that step.  From there the HIP step must
+    reproduce the numbers the REFERENCE recorded for that step to 1e-4: every loss term and every per-joint loss of
+    all 30 steps, not only the first one (the free-running replay above can only hold steps >= 1 to a drift bound,
+    because Adam turns rounding noise on noise-level gradients into +-lr moves)."""
+    from test_oracle_golden import build_case
+    name = 'v1_small'
+    m, g = build_hip_case(name, tmp_path=tmp_path)
+    o, _, (V, Tn, B) = build_case(name)
+    torch.manual_seed(2)
+    o.opt_cam(2)                                        # (eval-at-init / get_preds draw nothing from the model state)
+    n_steps = g['batches_view'].shape[0]
+    assert n_steps == 30 and len(m.schedulers) == len(o.schedulers) > 0
+    for s in range(n_steps):
+        m.load_state_dict({k: v for k, v in o.state_dict().items()}, strict=False)
+        for mo, oo in zip(m.optimizers, o.optimizers):
+            sd = oo.state_dict()
+            if sd['state']:
+                mo.load_state_dict(sd)
+            mo.param_groups[0]['lr'] = oo.param_groups[0]['lr']
+        for ms, os_ in zip(m.schedulers, o.schedulers):
+            ms.load_state_dict({k: v for k, v in os_.state_dict().items() if k != 'optimizer'})
+        vi, fi = torch.as_tensor(g['batches_view'][s]), torch.as_tensor(g['batches_frame'][s])
+        ld_h, info_h = m.step(vi, fi)
+        ld_o, _ = o.step(vi, fi)
+        tag = f'step{s}'
+        for k in ('gmm_loss', 'vp_recon_loss', 'vp_kl_loss', 'total_loss'):
+            assert rel_err(ld_h[k], g[f'{tag}__{k}']) < 1e-4, (s, k, ld_h[k], g[f'{tag}__{k}'])
+            assert rel_err(ld_o[k], g[f'{tag}__{k}']) < 2e-5, (s, k)          # the oracle is still on the recording
+        assert rel_err(ld_h['kp_loss'], g[f'{tag}__kp_loss_pure']) < 1e-4, s
+        assert rel_err(info_h['loss_all'], g[f'{tag}__loss_all']) < 1e-4, s
+    lrs = [o_.param_groups[0]['lr'] for o_ in o.optimizers]
+    for i, lr in enumerate(lrs):                         # (the plateau schedulers dropped the rates on the way)
+        assert abs(lr / float(g[f'final__opt{i}__lr']) - 1) < 1e-6
+
+
 def test_reference_trajectory_full_mesh(tmp_path):
     m, g = build_hip_case('v2_6890', num_verts=6890, tmp_path=tmp_path)
     replay(m, g, 'v2_6890', tol=1e-4, state_tol=2e-2, robust_state=True)
@@ -430,11 +469,21 @@ def test_loss_curve_parity_200_steps():
 
 
 def test_loss_curve_parity_real_size():
-    """The same free-running comparison at the REAL sizes of the published run (h = 1000, RBF 100, 6890-vertex
-    mesh, every loss term) over 12 minibatch steps of 256 samples drawn from 8 x 300."""
+    """the free-running comparison at the REAL sizes of the published run (h = 1000, RBF 100, 6890-vertex
+    mesh, every loss term): minibatches of 512 drawn from 8 x 300 in the script's order, HIP model and CPU oracle from
+    the same state, no re-synchronisation.  40 steps in the default suite; NEMO_LONG_TESTS=1 runs the full 200 steps
+    (about three minutes of oracle time; the curve of that run is committed as profiles/r02_loss_curve_200.json).
+    Measured (profiles/r02_loss_curve_200.json, maxima per 20-step window): every loss term agrees to 1e-6 over the
+    first 20 steps, to 1e-4 through step 80 (vp_recon 1.8e-4), then the two free-running fits separate slowly -- Adam
+    turns rounding-level differences of noise-level gradients into +-lr moves -- to 2e-3 (kp, total) / 1e-2
+    (vp_recon) by step 200.  Gate: 1e-4 on every term over the first 40 steps (3e-4 up to step 80), and the envelope
+    max 3e-2 / mean 5e-3 on every term over the whole run; the fit descends."""
+    import json
+    import os
     from nemo_cvpr2023_amd.neural_motion_model import NemoV2
     from oracle.model import OracleNemo
-    V, T, B, steps = 8, 300, 256, 12
+    V, T, B = 8, 300, 512
+    steps = 200 if os.environ.get('NEMO_LONG_TESTS') else 40
     args = syn.published_args(batch_size=B, out_dir='')
     seqs = syn.SyntheticSequences(V, T, seed=1234)
     assets, vps, gmm = syn.make_smpl_assets(6890, seed=1), syn.make_vposer_state(), syn.make_gmm()
@@ -442,15 +491,26 @@ def test_loss_curve_parity_real_size():
     m = NemoV2(args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
     o = OracleNemo(2, args, seqs, assets, vps, gmm, state={k: v.cpu() for k, v in m.state_dict().items()})
     gen = torch.Generator().manual_seed(2)
-    rel = []
+    keys = ('kp_loss', 'gmm_loss', 'vp_recon_loss', 'vp_kl_loss', 'total_loss')
+    cm, co = {k: [] for k in keys}, {k: [] for k in keys}
     for _ in range(steps):
         vi = torch.randint(0, V, (B,), generator=gen)
         fi = torch.randint(0, T, (B,), generator=gen)
         lm, lo = m.step(vi, fi)[0], o.step(vi, fi)[0]
-        rel.append(max(abs(float(lm[k]) - float(lo[k])) / max(abs(float(lo[k])), 1e-6)
-                       for k in ('kp_loss', 'gmm_loss', 'vp_recon_loss', 'vp_kl_loss', 'total_loss')))
-    assert max(rel[:3]) < 1e-4, rel[:3]
-    assert max(rel) < 1e-3, rel
+        for k in keys:
+            cm[k].append(float(lm[k]))
+            co[k].append(float(lo[k]))
+    rel = {k: np.abs(np.asarray(cm[k]) - np.asarray(co[k])) / np.maximum(np.abs(np.asarray(co[k])), 1e-6) for k in keys}
+    out = os.environ.get('NEMO_CURVE_OUT')
+    if out:
+        json.dump({'steps': steps, 'batch': B, 'hip': cm, 'oracle': co,
+                   'rel_max': {k: float(v.max()) for k, v in rel.items()},
+                   'rel_mean': {k: float(v.mean()) for k, v in rel.items()}}, open(out, 'w'))
+    for k in keys:
+        assert rel[k][:40].max() < 1e-4, (k, float(rel[k][:40].max()))
+        assert rel[k][:80].max() < 3e-4, (k, float(rel[k][:80].max()))
+        assert rel[k].max() < 3e-2 and rel[k].mean() < 5e-3, (k, float(rel[k].max()), float(rel[k].mean()))
+    assert np.mean(co['total_loss'][-10:]) < np.mean(co['total_loss'][:10])
 
 
 def test_optional_temporal_smoothness_term():
