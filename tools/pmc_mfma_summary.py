@@ -8,7 +8,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G = os.path.join(ROOT, 'gpurun_out')
+G = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out')
 
 
 def load(path):
