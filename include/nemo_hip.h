@@ -215,7 +215,6 @@ int32_t nemo_project(int64_t N, int64_t Jn, int64_t V, const float* pts, const i
 /* ------------------------------------------------------------------------------------------
  * Full-mesh skinning (lbs.py:238-252) on a pose-blended mesh VP = PF @ posedirs + v_shaped.
  * nemo_skin_vertices: verts (rows,NV,3) (+ trans (rows,3), may be NULL) -- get_preds()['v'].
- * nemo_joints_from_verts: the 45+n_extra joint superset from explicit vertices (eval / API parity).
  */
 int32_t nemo_skin_vertices(const nemo_ctx* ctx, int64_t rows, const float* VP, int64_t ldvp,
                            const float* A, const float* trans, int64_t ldt, float* verts, void* stream);
