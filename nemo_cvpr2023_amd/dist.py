@@ -107,6 +107,8 @@ class ShardedNemo:
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.V, self.T = multi_view_seqs.num_views, multi_view_seqs.num_frames
+        if version == 0:
+            raise ValueError('instance sharding covers NemoV1..V4 (NemoV0 has no shared motion MLP group)')
         if self.world > self.V:
             raise ValueError(f'{self.world} ranks for {self.V} instances: shard by instance needs world <= V')
         self.plan = ShardPlan(self.V, self.T, self.rank, self.world)

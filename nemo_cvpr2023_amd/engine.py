@@ -137,7 +137,7 @@ class ParamLayout:
     the rot_out / linear_out weights are adjacent and so are their biases, so the two MLP heads run as
     ONE (h -> 147) GEMM forward and backward."""
 
-    def __init__(self, V, K, D, C, h, din):
+    def __init__(self, V, K, D, C, h, din, version=2):
         self.entries = OrderedDict()
         self.groups = OrderedDict()    # optimiser name -> [names] in optimiser order
         lm = 'learned_motion.'
@@ -150,6 +150,28 @@ class ParamLayout:
             if place:
                 order.append(name)
         reg('cameras', 'learned_cameras', (V, 9))
+        if version == 0:
+            # NemoV0 (:3148-3206): RotNet poses / RotNet orient / FCNN translation on the bare warped phase, one
+            # optimiser each; no instance code, no RBF
+            for net, nout in (('learned_poses', 138), ('learned_orient', 6)):
+                for lname, (fo, fi) in (('net.net.0', (h, 1)), ('net.net.2', (h, h)), ('net.net.4', (h, h)),
+                                        ('linear', (nout, h))):
+                    reg(net[len('learned_'):], f'{net}.{lname}.weight', (fo, fi))
+                    reg(net[len('learned_'):], f'{net}.{lname}.bias', (fo,))
+            for lname, (fo, fi) in (('net.0', (h, 1)), ('net.2', (h, h)), ('net.4', (3, h))):
+                reg('trans', f'learned_trans.{lname}.weight', (fo, fi))
+                reg('trans', f'learned_trans.{lname}.bias', (fo,))
+            reg('comm', '_comm_scalars', (8,))
+            for i in range(V):
+                reg('phase', f'phase_networks.{i}.shifts', (K,))
+                reg('phase', f'phase_networks.{i}.scales', (K,))
+            off = 0
+            for name in order:
+                off = (off + 3) // 4 * 4
+                self.entries[name] = (off, shapes[name])
+                off += int(np.prod(shapes[name]))
+            self.total = (off + 3) // 4 * 4
+            return
         for lname, (fo, fi) in (('net.net.0', (h, din)), ('net.net.2', (h, h)), ('net.net.4', (h, h))):
             reg('motion', f'{lm}{lname}.weight', (fo, fi))
             reg('motion', f'{lm}{lname}.bias', (fo,))
@@ -193,7 +215,7 @@ class FitEngine:
         torch.cuda.set_device(self.device)
         self.V, self.T = V, T
         self.K = args.monotonic_network_n_nodes
-        self.C = args.instance_code_size
+        self.C = args.instance_code_size if version >= 1 else 0
         self.D = args.phase_rbf_dim if version >= 2 else 0
         self.h = args.h_dim
         # 'bf16' (BASELINE configs[2]): the dense contractions -- MotionNet / VPoser linear layers forward and backward,
@@ -223,7 +245,7 @@ class FitEngine:
         self.hmr_theta = hmr_theta.to(**f32).contiguous()
         self.hmr_mask = hmr_mask.to(**f32).contiguous()
         # flat parameter / gradient / Adam-moment buffers
-        self.layout = ParamLayout(V, self.K, self.D, self.C, self.h, self.din)
+        self.layout = ParamLayout(V, self.K, self.D, self.C, self.h, self.din, version)
         n = self.layout.total
         # row stride between the phase networks of consecutive views inside the flat buffer (NOT 2K: every tensor
         # starts on a 16-byte boundary, so K % 4 != 0 leaves pads between them)
@@ -307,6 +329,8 @@ class FitEngine:
             fi_static=torch.zeros(N, dtype=torch.long, device=self.device), graphs={})
         w.update(views)
         w['zero_arena'] = arena
+        if self.version == 0:            # hidden activations of the orient and translation networks (poses: H1..H3)
+            w.update(O1=Z(N + 1, h), O2=Z(N + 1, h), O3=Z(N + 1, h), T1=Z(N + 1, h), T2=Z(N + 1, h))
         # scratch of nemo_v2v_fused (arrival tickets, zero at allocation and returned to zero by the kernel, +
         # per-vertex-range partial dA): owned by THIS workspace and sized for every chunk length it launches, so a
         # HIP graph captured over the workspace never sees the buffer replaced under it
@@ -387,6 +411,8 @@ class FitEngine:
             self.p('learned_instance_code') if self.C > 0 else None, dptr(code_noise), self.kernel_id,
             dptr(w['X']), self.ldx, dptr(w['phase']), st), 'nemo_phase_embed_fwd')
         h, r = self.h, N + 1
+        if self.version == 0:
+            return self._forward_nets_v0(w, N)
         lm = 'learned_motion.'
         self._linear(r, dptr(w['X']), self.ldx, self.din, self.p(lm + 'net.net.0.weight'),
                      self.p(lm + 'net.net.0.bias'), h, dptr(w['H1']), h, act=1)
@@ -399,6 +425,70 @@ class FitEngine:
                      147, dptr(w['HEAD']), HEAD_LD)
         check(L.nemo_rot6d_fwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, dptr(w['R']), dptr(w['AA']), st),
               'nemo_rot6d_fwd')
+
+    # ---- NemoV0: three networks on the warped phase (:3005-3034).  Their outputs land in the columns of the merged head
+    # buffer the later NemoV* write ([orient 6 | poses 138 | trans 3]), so everything downstream is shared.
+    V0_NETS = (('learned_poses', 6, 138, ('H1', 'H2', 'H3')), ('learned_orient', 0, 6, ('O1', 'O2', 'O3')))
+
+    def _forward_nets_v0(self, w, N):
+        h, r, X = self.h, N + 1, dptr(w['X'])
+        head = w['HEAD'].data_ptr()
+        for net, col, nout, (a1, a2, a3) in self.V0_NETS:
+            q = net + '.net.net.'
+            self._linear(r, X, self.ldx, 1, self.p(q + '0.weight'), self.p(q + '0.bias'), h, dptr(w[a1]), h, act=1)
+            self._linear(r, dptr(w[a1]), h, h, self.p(q + '2.weight'), self.p(q + '2.bias'), h, dptr(w[a2]), h, act=1)
+            self._linear(r, dptr(w[a2]), h, h, self.p(q + '4.weight'), self.p(q + '4.bias'), h, dptr(w[a3]), h, act=1)
+            self._linear(r, dptr(w[a3]), h, h, self.p(net + '.linear.weight'), self.p(net + '.linear.bias'), nout,
+                         head + 4 * col, HEAD_LD)
+        q = 'learned_trans.net.'
+        self._linear(r, X, self.ldx, 1, self.p(q + '0.weight'), self.p(q + '0.bias'), h, dptr(w['T1']), h, act=1)
+        self._linear(r, dptr(w['T1']), h, h, self.p(q + '2.weight'), self.p(q + '2.bias'), h, dptr(w['T2']), h, act=1)
+        self._linear(r, dptr(w['T2']), h, h, self.p(q + '4.weight'), self.p(q + '4.bias'), 3, head + 4 * 144, HEAD_LD)
+        check(self.lib.nemo_rot6d_fwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, dptr(w['R']), dptr(w['AA']), _stream()),
+              'nemo_rot6d_fwd')
+
+    def _backward_nets_v0(self, w, N, view_idx, frame_idx, raw_phase, has_trans_grad=True):
+        """dHEAD (N+1, [orient 6 | poses 138 | trans 3]) -> gradients of the three networks and of the phase networks."""
+        h, r, X = self.h, N + 1, dptr(w['X'])
+        dhead = w['dHEAD'].data_ptr()
+        first = True
+        for net, col, nout, (a1, a2, a3) in self.V0_NETS:
+            q = net + '.net.net.'
+            dY = dhead + 4 * col
+            self._linear_bwd_params(r, dptr(w[a3]), h, h, dY, HEAD_LD, nout, self.g(net + '.linear.weight'),
+                                    self.g(net + '.linear.bias'))
+            self.gemm(0, 0, r, h, nout, dY, HEAD_LD, self.p(net + '.linear.weight'), h, dptr(w['dH']), h,
+                      mask=dptr(w[a3]), ldmask=h, mask_mode=1, dense=True)
+            self._linear_bwd_params(r, dptr(w[a2]), h, h, dptr(w['dH']), h, h, self.g(q + '4.weight'), self.g(q + '4.bias'))
+            self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(q + '4.weight'), h, dptr(w['dH_b']), h,
+                      mask=dptr(w[a2]), ldmask=h, mask_mode=1, dense=True)
+            self._linear_bwd_params(r, dptr(w[a1]), h, h, dptr(w['dH_b']), h, h, self.g(q + '2.weight'), self.g(q + '2.bias'))
+            self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(q + '2.weight'), h, dptr(w['dH_c']), h,
+                      mask=dptr(w[a1]), ldmask=h, mask_mode=1, dense=True)
+            self._linear_bwd_params(r, X, self.ldx, 1, dptr(w['dH_c']), h, h, self.g(q + '0.weight'), self.g(q + '0.bias'))
+            self.gemm(0, 0, r, 1, h, dptr(w['dH_c']), h, self.p(q + '0.weight'), 1, dptr(w['dX']), self.ldx,
+                      out_mode=0 if first else 1)
+            first = False
+            self.flush_colsums()            # (dH .. dH_c are reused by the next network)
+        if has_trans_grad:
+            q = 'learned_trans.net.'
+            dY = dhead + 4 * 144
+            # trans - trans_0 cancels the last bias exactly (the reference's autograd yields an exact 0 there)
+            self._linear_bwd_params(r, dptr(w['T2']), h, h, dY, HEAD_LD, 3, self.g(q + '4.weight'),
+                                    self.g(q + '4.bias') if self.start_global_traj_anywhere else None)
+            self.gemm(0, 0, r, h, 3, dY, HEAD_LD, self.p(q + '4.weight'), h, dptr(w['dH']), h,
+                      mask=dptr(w['T2']), ldmask=h, mask_mode=1)
+            self._linear_bwd_params(r, dptr(w['T1']), h, h, dptr(w['dH']), h, h, self.g(q + '2.weight'), self.g(q + '2.bias'))
+            self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(q + '2.weight'), h, dptr(w['dH_b']), h,
+                      mask=dptr(w['T1']), ldmask=h, mask_mode=1, dense=True)
+            self._linear_bwd_params(r, X, self.ldx, 1, dptr(w['dH_b']), h, h, self.g(q + '0.weight'), self.g(q + '0.bias'))
+            self.gemm(0, 0, r, 1, h, dptr(w['dH_b']), h, self.p(q + '0.weight'), 1, dptr(w['dX']), self.ldx, out_mode=1)
+            self.flush_colsums()
+        check(self.lib.nemo_phase_embed_bwd(
+            N, self.V, self.T, self.K, 0, 0, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
+            self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), self.ldp, None, 0,
+            dptr(w['phase']), dptr(w['dX']), self.ldx, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
+            self.g('phase_networks.0.scales'), None, None, _stream()), 'nemo_phase_embed_bwd')
 
     def forward_joints(self, w, N, view_idx, frame_idx, with_loss, mean_mode=0, add_trans=True, ctx=None,
                        j3d=None, p2d=None):
@@ -530,6 +620,8 @@ class FitEngine:
     def backward_mlp(self, w, N, view_idx, frame_idx, raw_phase, has_trans_grad=True):
         """dROT (N+1,144), dTR (N+1,3) -> all MLP / RBF / phase / code gradients."""
         L, st, h, r = self.lib, _stream(), self.h, N + 1
+        if self.version == 0:
+            return self._backward_nets_v0(w, N, view_idx, frame_idx, raw_phase, has_trans_grad)
         lm = 'learned_motion.'
         # merged heads: dHEAD (N+1, [rot6d 144 | trans 3]) against [rot_out.weight ; linear_out.weight].
         # trans - trans_0 cancels the linear_out bias exactly (the reference's autograd also yields an

@@ -253,17 +253,30 @@ class MultiViewModel(nn.Module):
         self.learned_cameras = self._param('learned_cameras')
         if e.C > 0:
             self.learned_instance_code = self._param('learned_instance_code')
-        lm = _Holder()
-        lm.net = _Holder()
-        lm.net.net = _Holder()
-        for k in ('0', '2', '4'):
-            lm.net.net.add_module(k, _Linear(self._param(f'learned_motion.net.net.{k}.weight'),
-                                             self._param(f'learned_motion.net.net.{k}.bias')))
-        lm.rot_out = _Linear(self._param('learned_motion.rot_out.weight'),
-                             self._param('learned_motion.rot_out.bias'))
-        lm.linear_out = _Linear(self._param('learned_motion.linear_out.weight'),
-                                self._param('learned_motion.linear_out.bias'))
-        self.learned_motion = lm
+        lin = lambda name: _Linear(self._param(name + '.weight'), self._param(name + '.bias'))
+        if self.VERSION == 0:                                   # RotNet x 2 + FCNN (:58-104, :3148-3162)
+            for net in ('learned_poses', 'learned_orient'):
+                rn = _Holder()
+                rn.net = _Holder()
+                rn.net.net = _Holder()
+                for k in ('0', '2', '4'):
+                    rn.net.net.add_module(k, lin(f'{net}.net.net.{k}'))
+                rn.linear = lin(f'{net}.linear')
+                setattr(self, net, rn)
+            tn = _Holder()
+            tn.net = _Holder()
+            for k in ('0', '2', '4'):
+                tn.net.add_module(k, lin(f'learned_trans.net.{k}'))
+            self.learned_trans = tn
+        else:
+            lm = _Holder()
+            lm.net = _Holder()
+            lm.net.net = _Holder()
+            for k in ('0', '2', '4'):
+                lm.net.net.add_module(k, lin(f'learned_motion.net.net.{k}'))
+            lm.rot_out = lin('learned_motion.rot_out')
+            lm.linear_out = lin('learned_motion.linear_out')
+            self.learned_motion = lm
         self.learned_betas = nn.Parameter(e.betas)
         self.phase_networks = nn.ModuleList([
             MonotonicNetwork(e, i, self._param(f'phase_networks.{i}.shifts'),
@@ -284,9 +297,16 @@ class MultiViewModel(nn.Module):
         mk = lambda grp, lr, wd=0.0, adamw=False: FusedAdam(e, G[grp], [named[n] for n in G[grp]], lr, wd,
                                                             adamw)
         self.opt_cameras = mk('cameras', a.lr_camera)
-        self.opt_motion = mk('motion', a.lr_human, a.wd_human, a.opt_human == 'adamw')
         self.opt_phase = mk('phase', a.lr_phase)
-        self.optimizers = [self.opt_cameras, self.opt_motion, self.opt_phase]
+        if self.VERSION == 0:                                   # :3171-3198
+            aw = a.opt_human == 'adamw'
+            self.opt_poses = mk('poses', a.lr_pose, a.wd_human, aw)
+            self.opt_orient = mk('orient', a.lr_orient, a.wd_human, aw)
+            self.opt_trans = mk('trans', a.lr_trans)
+            self.optimizers = [self.opt_cameras, self.opt_poses, self.opt_orient, self.opt_trans, self.opt_phase]
+        else:
+            self.opt_motion = mk('motion', a.lr_human, a.wd_human, a.opt_human == 'adamw')
+            self.optimizers = [self.opt_cameras, self.opt_motion, self.opt_phase]
         if e.C > 0:
             self.opt_instance = mk('instance', a.lr_instance)
             self.optimizers.append(self.opt_instance)
@@ -410,7 +430,7 @@ class MultiViewModel(nn.Module):
 
     # ------------------------------------------------------------------ the hot path
     def _forward_backward(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False, sh=None,
-                          smooth_ok=False, extra_losses=None, publish=False, part='all', adam_segs=0):
+                          smooth_ok=False, extra_losses=None, publish=False, part='all', adam_segs=0, use_gmm=None):
         """Forward of :3511-3584 (+V3 extras) and, when ``update``, the whole backward down to the
         parameter gradients.  After the pose MLP the step forks into two independent branches that
         run CONCURRENTLY on two HIP streams (most of their kernels are too small to fill 256 CUs):
@@ -419,6 +439,7 @@ class MultiViewModel(nn.Module):
         joins, runs the full-mesh v2v term alone, then the rot6d / MLP backward."""
         e, a = self.engine, self.args
         sh = sh or ShardInfo()
+        use_gmm = use_vposer if use_gmm is None else use_gmm
         e.scal = w['scal']               # loss-scalar slots of this workspace (part of the arena)
         # part: 'all', or the two halves a sharded step launches separately -- 'head' = everything up to the
         # point where the loss scalars are final, 'tail' = the rest of the backward (see step())
@@ -442,7 +463,7 @@ class MultiViewModel(nn.Module):
                 enc_done = e.forward_vposer(w, N)                             # always evaluated, :3569
         with torch.cuda.stream(side2):
             st = _stream()
-            if use_vposer:
+            if use_gmm:
                 g = e.gmm
                 check(e.lib.nemo_gmm_fwd_bwd(N, g['M'], 69, aa69, 72, dptr(g['means']), dptr(g['prec']),
                                              dptr(g['log_nllw']), dptr(w['gmm_ws']),
@@ -506,6 +527,9 @@ class MultiViewModel(nn.Module):
         """:3511-3598 (V1/V2), :3796-3909 (V3/V4)."""
         e, a = self.engine, self.args
         sh = _shard or ShardInfo()
+        if self.VERSION == 0 and a.weight_vp_loss:
+            # the reference multiplies weight_vp_loss with the (v2v, kl) TUPLE vposer_loss returns (:3330-3332)
+            raise TypeError("NemoV0 cannot run with weight_vp_loss != 0 (can't multiply sequence by non-int in the reference)")
         if self.VERSION >= 3 and update:
             self.training = True
         is_full = not (a.batch_size > -1 and not full_batch)
@@ -540,7 +564,8 @@ class MultiViewModel(nn.Module):
             if N > 0:
                 self._forward_backward(w, N, vi_, fi_, update, sh=sh, smooth_ok=is_full,
                                        extra_losses=inst_term if has_inst else None, publish=early, part=part,
-                                       adam_segs=adam_table[0] if adam_table is not None else 0)
+                                       adam_segs=adam_table[0] if adam_table is not None else 0,
+                                       use_vposer=self.VERSION >= 1, use_gmm=True)
             elif part != 'tail':        # a shard may own none of a minibatch's samples
                 e.scal.zero_()
                 if update:
@@ -653,9 +678,9 @@ class MultiViewModel(nn.Module):
         v2v = f32(s[S_V2V]) / f32((sh.n_global or N) * e.NV * 3)
         kl, gmm, l3d = f32(s[S_KL]), f32(s[S_GMM]), f32(s[S_3D])
         loss = kp
-        if a.weight_vp_loss:
+        if a.weight_vp_loss and self.VERSION >= 1:
             loss = f32(loss + f32(a.weight_vp_loss) * v2v)
-        if a.weight_vp_z_loss:
+        if a.weight_vp_z_loss and self.VERSION >= 1:
             loss = f32(loss + f32(a.weight_vp_z_loss) * kl)
         loss_dict = {'kp_loss': np.asarray(kp)}
         if self.VERSION >= 3:
@@ -672,8 +697,11 @@ class MultiViewModel(nn.Module):
         if w_s and is_full:                  # optional term, an extra key only when it is switched on
             loss = f32(loss + f32(w_s) * f32(s[S_SMOOTH]))
             loss_dict['smooth_loss'] = np.asarray(f32(s[S_SMOOTH]))
-        loss_dict.update(gmm_loss=np.asarray(gmm), vp_recon_loss=np.asarray(v2v), vp_kl_loss=np.asarray(kl),
-                         total_loss=np.asarray(loss))
+        if self.VERSION == 0:             # :3325-3340: kp_loss, gmm_loss, total_loss
+            loss_dict.update(gmm_loss=np.asarray(gmm), total_loss=np.asarray(loss))
+        else:
+            loss_dict.update(gmm_loss=np.asarray(gmm), vp_recon_loss=np.asarray(v2v), vp_kl_loss=np.asarray(kl),
+                             total_loss=np.asarray(loss))
         # Non-scalar outputs.  Evaluation steps (update=False; what the script dumps with joblib)
         # get private copies as in the reference; on training steps the script discards info_dict
         # (`loss_dict, _ = model.step(...)`), so the tensors are materialised only if accessed --
@@ -762,6 +790,10 @@ class MultiViewModel(nn.Module):
         if warmup_steps == 0:
             return []
         e, a = self.engine, self.args
+        if self.VERSION == 0:
+            # :3207-3269 fits learned_poses to sequences[v]['spin_theta'], which the shipped loader no longer produces
+            # (nemo/multi_view_sequence.py:336-392 commented out): the reference raises KeyError there
+            raise NotImplementedError("NemoV0.warmup needs 'spin_theta' tracks, which the reference's loader no longer fills")
         if a.batch_size <= -1:
             raise NotImplementedError()
         lm = 'learned_motion.'
@@ -818,6 +850,13 @@ class MultiViewModel(nn.Module):
             cam_opt.step()
             log.append(np.asarray(self._reduce_and_read(ShardInfo(kr=sh.mr, comm=sh.comm), False)[S_KP]))
         return log
+
+
+class NemoV0(MultiViewModel):
+    """:3127-3362 (legacy): separate RotNet pose / RotNet orient / FCNN translation networks on the bare warped phase,
+    five optimisers, 2-D keypoint + GMM terms (the reference can only run it with weight_vp_loss == 0, and its
+    warm-up needs 'spin_theta' tracks the shipped loader no longer produces)."""
+    VERSION = 0
 
 
 class NemoV1(MultiViewModel):
@@ -884,7 +923,7 @@ def make_init_state(args, version, V, img_d0):
     drawn from the CPU global RNG (bit-identical initial states are obtained by loading a reference
     ``state_dict``).  Returned on the CPU under the reference's state_dict names, so a
     sharded run can build the global state on every rank and keep its slice."""
-    C = args.instance_code_size
+    C = args.instance_code_size if version >= 1 else 0
     D = args.phase_rbf_dim if version >= 2 else 0
     h, K = args.h_dim, args.monotonic_network_n_nodes
     din = (D if D > 0 else 1) + C
@@ -896,8 +935,22 @@ def make_init_state(args, version, V, img_d0):
     st['learned_cameras'] = cams
     if C > 0:
         st['learned_instance_code'] = 1e-4 * torch.randn(V, C)
-    for name, (fo, fi) in (('net.net.0', (h, din)), ('net.net.2', (h, h)), ('net.net.4', (h, h)),
-                           ('rot_out', (144, h)), ('linear_out', (3, h))):
+    if version == 0:                                    # RotNet(1, h, 23), RotNet(1, h, 1), FCNN(1, h, 3): :3148-3162
+        for net, nj in (('learned_poses', 23), ('learned_orient', 1)):
+            for name, (fo, fi) in (('net.net.0', (h, 1)), ('net.net.2', (h, h)), ('net.net.4', (h, h)),
+                                   ('linear', (nj * 6, h))):
+                lin = nn.Linear(fi, fo)
+                if name == 'linear':                    # init_last_layer_zero, :86-92
+                    nn.init.xavier_uniform_(lin.weight, gain=0.00001)
+                    lin.bias.data = torch.tensor([1., 0, 0, 1, 0, 0]).repeat(nj)
+                st[f'{net}.{name}.weight'] = lin.weight.data.clone()
+                st[f'{net}.{name}.bias'] = lin.bias.data.clone()
+        for name, (fo, fi) in (('net.0', (h, 1)), ('net.2', (h, h)), ('net.4', (3, h))):
+            lin = nn.Linear(fi, fo)
+            st[f'learned_trans.{name}.weight'] = lin.weight.data.clone()
+            st[f'learned_trans.{name}.bias'] = lin.bias.data.clone()
+    for name, (fo, fi) in (() if version == 0 else (('net.net.0', (h, din)), ('net.net.2', (h, h)), ('net.net.4', (h, h)),
+                                                    ('rot_out', (144, h)), ('linear_out', (3, h)))):
         lin = nn.Linear(fi, fo)
         if name == 'rot_out':
             nn.init.xavier_uniform_(lin.weight, gain=0.00001)
@@ -938,4 +991,4 @@ def collate_gt_2d(seqs, label_type='op', thr=30.0):
     return pts, torch.sqrt(d0 ** 2 + d1 ** 2) + 1e-4
 
 
-NEMO_VERSIONS = {1: NemoV1, 2: NemoV2, 3: NemoV3, 4: NemoV4}
+NEMO_VERSIONS = {0: NemoV0, 1: NemoV1, 2: NemoV2, 3: NemoV3, 4: NemoV4}

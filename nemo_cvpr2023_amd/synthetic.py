@@ -189,6 +189,7 @@ def default_v1_args(**overrides) -> SimpleNamespace:
              batch_size=128, weight_vp_loss=0, weight_vp_z_loss=0,
              weight_gmm_loss=0.5, weight_instance_loss=0, weight_3d_loss=0,
              code_noise=0, label_intersection_threshold=50,
-             n_steps=5000, warmup_step=0, opt_cam_step=1000)
+             n_steps=5000, warmup_step=0, opt_cam_step=1000,
+             lr_pose=1e-2, lr_orient=1e-2, lr_trans=1e-2)   # (NemoV0's three networks; the script's defaults, :61-65)
     a.update(overrides)
     return SimpleNamespace(**a)

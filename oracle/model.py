@@ -58,7 +58,7 @@ def collate_gt_2d(seqs, label_type='op', thr=50.0):
 
 class OracleNemo:
     def __init__(self, version, args, seqs, assets, vposer_sd, gmm, state=None, seed=0):
-        assert version in (1, 2, 3, 4)
+        assert version in (0, 1, 2, 3, 4)
         self.version, self.args = version, args
         self.V, self.T = seqs.num_views, seqs.num_frames
         self.num_views, self.num_frames = self.V, self.T
@@ -70,7 +70,7 @@ class OracleNemo:
             seqs, args.label_type, getattr(args, 'label_intersection_threshold', 50.0))
         pose = torch.tensor(np.array([np.array(seqs.sequences[v]['pose']) for v in range(self.V)])).float()
         self.hmr_theta, self.hmr_mask = pose[..., 3:-1], pose[..., -1:]              # :3441-3453
-        self.C = args.instance_code_size
+        self.C = args.instance_code_size if version >= 1 else 0       # (NemoV0: no instance code, :3144-3146)
         self.D = args.phase_rbf_dim if version >= 2 else 0
         self.training = False
         self.P = OrderedDict()
@@ -93,13 +93,26 @@ class OracleNemo:
             self.P['learned_instance_code'] = 1e-4 * torch.randn(self.V, self.C, generator=g)
         din = (self.D if self.D > 0 else 1) + self.C
         h = a.h_dim
-        for name, (fi, fo) in (('net.net.0', (din, h)), ('net.net.2', (h, h)), ('net.net.4', (h, h)),
-                               ('rot_out', (h, 144)), ('linear_out', (h, 3))):
-            w, b = _linear_default(fi, fo, g)
-            self.P[f'learned_motion.{name}.weight'] = w
-            self.P[f'learned_motion.{name}.bias'] = b
-        self.P['learned_motion.rot_out.weight'] = _xavier_uniform((144, h), 1e-5, g)
-        self.P['learned_motion.rot_out.bias'] = torch.tensor([1., 0, 0, 1, 0, 0]).repeat(24)
+        if self.version == 0:
+            # :3148-3162: RotNet(1, h, 23) poses, RotNet(1, h, 1) orient (FCNN + Linear, last layer xavier(1e-5) and an
+            # identity-6d bias, :74-94), FCNN(1, h, 3) translation
+            for net, nj in (('learned_poses', 23), ('learned_orient', 1)):
+                for name, (fi, fo) in (('net.net.0', (1, h)), ('net.net.2', (h, h)), ('net.net.4', (h, h))):
+                    w, b = _linear_default(fi, fo, g)
+                    self.P[f'{net}.{name}.weight'], self.P[f'{net}.{name}.bias'] = w, b
+                self.P[f'{net}.linear.weight'] = _xavier_uniform((nj * 6, h), 1e-5, g)
+                self.P[f'{net}.linear.bias'] = torch.tensor([1., 0, 0, 1, 0, 0]).repeat(nj)
+            for name, (fi, fo) in (('net.0', (1, h)), ('net.2', (h, h)), ('net.4', (h, 3))):
+                w, b = _linear_default(fi, fo, g)
+                self.P[f'learned_trans.{name}.weight'], self.P[f'learned_trans.{name}.bias'] = w, b
+        else:
+            for name, (fi, fo) in (('net.net.0', (din, h)), ('net.net.2', (h, h)), ('net.net.4', (h, h)),
+                                   ('rot_out', (h, 144)), ('linear_out', (h, 3))):
+                w, b = _linear_default(fi, fo, g)
+                self.P[f'learned_motion.{name}.weight'] = w
+                self.P[f'learned_motion.{name}.bias'] = b
+            self.P['learned_motion.rot_out.weight'] = _xavier_uniform((144, h), 1e-5, g)
+            self.P['learned_motion.rot_out.bias'] = torch.tensor([1., 0, 0, 1, 0, 0]).repeat(24)
         self.P['learned_betas'] = torch.zeros(1, 10)
         K = a.monotonic_network_n_nodes
         for i in range(self.V):
@@ -144,6 +157,20 @@ class OracleNemo:
 
     def _build_optimizers(self):
         a, P = self.args, self.P
+        if self.version == 0:                                                          # :3171-3206
+            cls = torch.optim.Adam if a.opt_human == 'adam' else torch.optim.AdamW
+            grp = lambda pre: [P[k] for k in P if k.startswith(pre)]
+            self.opt_cameras = torch.optim.Adam([P['learned_cameras']], lr=a.lr_camera, weight_decay=0)
+            self.opt_poses = cls(grp('learned_poses.'), lr=a.lr_pose, weight_decay=a.wd_human)
+            self.opt_orient = cls(grp('learned_orient.'), lr=a.lr_orient, weight_decay=a.wd_human)
+            self.opt_trans = torch.optim.Adam(grp('learned_trans.'), lr=a.lr_trans, weight_decay=0.0)
+            self.opt_phase = torch.optim.Adam(grp('phase_networks.'), lr=a.lr_phase, weight_decay=0.0)
+            self.optimizers = [self.opt_cameras, self.opt_poses, self.opt_orient, self.opt_trans, self.opt_phase]
+            self.schedulers = []
+            if a.lr_factor < 1:
+                self.schedulers = [torch.optim.lr_scheduler.ReduceLROnPlateau(o, factor=a.lr_factor, min_lr=1e-6)
+                                   for o in self.optimizers]
+            return
         motion = [P[k] for k in P if k.startswith('learned_motion.')]
         if self.D > 0:
             motion.append(P['phase_rbf.log_sigmas'])                                   # :3706-3711
@@ -180,6 +207,19 @@ class OracleNemo:
                                    self.args.rbf_kernel)
         return phases
 
+    def _v0_nets(self, x):
+        """NemoV0 (:3005-3034): three networks on the warped phase -- RotNet poses (23 x 6), RotNet orient (6), FCNN
+        translation.  Returns rot6d (N, 144) = [orient | poses] and trans (N, 3) like the merged MotionNet."""
+        import torch.nn.functional as F
+        P = self.P
+
+        def fcnn(pre, x_):
+            h_ = F.relu(F.linear(x_, P[pre + '0.weight'], P[pre + '0.bias']))
+            h_ = F.relu(F.linear(h_, P[pre + '2.weight'], P[pre + '2.bias']))
+            return F.linear(h_, P[pre + '4.weight'], P[pre + '4.bias'])
+        rot = lambda net: F.linear(F.relu(fcnn(net + '.net.net.', x)), P[net + '.linear.weight'], P[net + '.linear.bias'])
+        return torch.cat([rot('learned_orient'), rot('learned_poses')], 1), fcnn('learned_trans.net.', x)
+
     def _smpl(self, body_rotmats, orient6d):
         """:2963-2976 with pose_type='rotmat'."""
         R0 = ops.rot6d_to_rotmat(orient6d).unsqueeze(1)
@@ -194,14 +234,17 @@ class OracleNemo:
             if self.version >= 3 and self.training and self.args.code_noise > 0:
                 codes = codes + self.args.code_noise * torch.randn_like(codes)
             x = torch.cat([x, codes], 1)
-        rot6d, trans = ops.motionnet_forward(self.P, 'learned_motion.', x)
+        if self.version == 0:
+            rot6d, trans = self._v0_nets(x)
+        else:
+            rot6d, trans = ops.motionnet_forward(self.P, 'learned_motion.', x)
         rotmat = ops.rot6d_to_rotmat(rot6d).view(N, 24, 3, 3)
         pose_aa = ops.rotmat_to_aa(rotmat.reshape(-1, 3, 3)).reshape(N, 72)
         body = rotmat[:, 1:].detach() if detach_pose else rotmat[:, 1:]
         verts, j49, _ = self._smpl(body, rot6d[:, :6])
         x0 = torch.zeros(1, 1)
         x0 = torch.cat([self._embed(x0), torch.zeros(1, self.C)], 1) if self.C > 0 else self._embed(x0)
-        trans0 = ops.motionnet_forward(self.P, 'learned_motion.', x0)[1]
+        trans0 = self._v0_nets(x0)[1] if self.version == 0 else ops.motionnet_forward(self.P, 'learned_motion.', x0)[1]
         trans = trans - trans0
         if add_trans:
             verts, j49 = verts + trans.unsqueeze(1), j49 + trans.unsqueeze(1)
@@ -268,8 +311,9 @@ class OracleNemo:
             p2d = self.learned_camera_projection(pd['j'], view_idx)
             loss_all, gt = self.kp_loss(p2d, view_idx, frame_idx)
             terms['kp'] = kr * ops.per_view_mean_loss(loss_all, gt[..., -1:], view_idx)
-            v2v, kl = self.vposer_loss(pd['poses'], pd['orient'])
-            terms['v2v'], terms['kl'] = mr * v2v, mr * kl
+            if self.version >= 1:       # (NemoV0 calls vposer_loss too, :3330, but can only run with weight_vp_loss == 0)
+                v2v, kl = self.vposer_loss(pd['poses'], pd['orient'])
+                terms['v2v'], terms['kl'] = mr * v2v, mr * kl
             if self.version >= 3 and a.weight_3d_loss:
                 terms['l3'] = mr * ops.keypoint_loss(pd['poses'], self.hmr_theta[view_idx, frame_idx],
                                                      self.hmr_mask[view_idx, frame_idx], None,
@@ -285,9 +329,11 @@ class OracleNemo:
         if self.version >= 3 and a.weight_instance_loss:
             terms['inst'] = vr * (self.P['learned_instance_code'] ** 2).mean()
         loss = terms['kp']
-        if a.weight_vp_loss:
+        if self.version == 0 and a.weight_vp_loss:
+            raise TypeError('NemoV0 multiplies weight_vp_loss with the (v2v, kl) tuple of vposer_loss (:3330-3332)')
+        if a.weight_vp_loss and self.version >= 1:
             loss = loss + a.weight_vp_loss * terms['v2v']
-        if a.weight_vp_z_loss:
+        if a.weight_vp_z_loss and self.version >= 1:
             loss = loss + a.weight_vp_z_loss * terms['kl']
         if self.version >= 3:
             if a.weight_instance_loss:
@@ -321,6 +367,8 @@ class OracleNemo:
                 s_.step(float(scal[6]))
         out = {'kp_loss': scal[0], 'gmm_loss': scal[3], 'vp_recon_loss': scal[1], 'vp_kl_loss': scal[2],
                'total_loss': scal[6]}
+        if self.version == 0:                                                          # :3325-3340
+            out = {'kp_loss': scal[0], 'gmm_loss': scal[3], 'total_loss': scal[6]}
         if self.version >= 3:
             out['instance_loss'] = scal[5] if a.weight_instance_loss else 0
             if a.weight_3d_loss:

@@ -136,6 +136,7 @@ CASES = {
     'v2_small': (2, {}, 3),
     'v1_small': (1, {'lr_human': 0.01}, 0),
     'v1_fullbatch': (1, {'batch_size': -1, 'lr_factor': 1}, 0),
+    'v0_small': (0, {'lr_factor': 1}, 0),
     'v3_small': (3, {'weight_instance_loss': 0.1, 'weight_3d_loss': 0.5, 'opt_human': 'adamw'}, 2),
     'v4_small': (4, {'weight_3d_loss': 0.5}, 2),
     'v2_loss_mse': (2, {'loss': 'mse', 'weight_vp_loss': 0, 'weight_vp_z_loss': 0}, 0),
@@ -181,7 +182,10 @@ def replay(model, g, name, n_cam_default=None, tol=2e-5, check_state=True, state
 
     def check(tag, ld, info, tol=tol, la_tol=la_tol):
         for k in ('gmm_loss', 'vp_recon_loss', 'vp_kl_loss', 'total_loss'):
-            assert rel_err(ld[k], g[f'{tag}__{k}']) < tol, (tag, k, ld[k], g[f'{tag}__{k}'])
+            if f'{tag}__{k}' in g:            # (NemoV0 reports kp_loss, gmm_loss and total_loss only, :3325-3340)
+                assert rel_err(ld[k], g[f'{tag}__{k}']) < tol, (tag, k, ld[k], g[f'{tag}__{k}'])
+            else:
+                assert k not in ld, k
         assert rel_err(ld['kp_loss'], g[f'{tag}__kp_loss_pure']) < tol, tag
         assert rel_err(info['loss_all'], g[f'{tag}__loss_all']) < la_tol, tag
         for k in ('instance_loss', 'loss_3d'):
@@ -208,7 +212,7 @@ def replay(model, g, name, n_cam_default=None, tol=2e-5, check_state=True, state
             assert rel_err(cl, g['cam_losses']) < 1e-4
         assert rel_err(model.state_dict()['learned_cameras'], g['aftercam__learned_cameras']) < 1e-4
     n_steps = g['batches_view'].shape[0]
-    n_full = 1 if name == 'v2_small' else 0
+    n_full = 1 if name in ('v2_small', 'v0_small') else 0
     for s in range(n_steps):
         draw()
         vi, fi = torch.as_tensor(g['batches_view'][s]), torch.as_tensor(g['batches_frame'][s])
@@ -247,7 +251,12 @@ def replay(model, g, name, n_cam_default=None, tol=2e-5, check_state=True, state
 @pytest.mark.parametrize('name', list(CASES))
 def test_trajectory(name):
     model, g, _ = build_case(name)
-    replay(model, g, name, n_cam_default=3)
+    # NemoV0 runs three networks at lr 1e-2 on a one-dimensional input: dead ReLU units give many exactly-noise gradients,
+    # which Adam turns into +-lr moves (step-0 gradients equal the reference's to the last bit, every loss of the five
+    # steps to 2e-5): its final state is only held to the bound the drifting GPU replays use
+    v0 = name == 'v0_small'       # (drift with a first step beyond the run: only switches the final-state check to the bound)
+    replay(model, g, name, n_cam_default=3, robust_state=v0, state_tol=5e-3 if v0 else 2e-4,
+           drift=(10 ** 9, 2e-5, 2e-5) if v0 else None)
 
 
 def test_step0_gradients():

@@ -606,6 +606,9 @@ def main():
         run_loader_case()
     if not only or 'ckpt' in only:
         run_checkpoint_case(nmm, scratch)
+    if 'v0' in only:
+        run_model_case(nmm, 'v0_small', 0, {'lr_factor': 1}, V=2, T=5, B=6, n_steps=5, n_warm=0, n_cam=2,
+                       full_batch_steps=1)
     if only:
         return
     gen_function_goldens(nmm, assets_small)
@@ -623,6 +626,10 @@ def main():
     # NemoV1 true full-batch mode (batch_size == -1) -- step ignores the indices
     run_model_case(nmm, 'v1_fullbatch', 1, {'batch_size': -1, 'lr_factor': 1}, V=2, T=5, B=4,
                    n_steps=3, n_warm=0, n_cam=2)
+    # NemoV0 (legacy: separate pose / orient / translation networks on the bare warped phase; runs only with
+    # weight_vp_loss == 0 and without its spin_theta warm-up, see oracle/model.py)
+    run_model_case(nmm, 'v0_small', 0, {'lr_factor': 1}, V=2, T=5, B=6, n_steps=5, n_warm=0, n_cam=2,
+                   full_batch_steps=1)
     # NemoV3: instance-code regulariser + 3-D loss + AdamW
     run_model_case(nmm, 'v3_small', 3, {'weight_instance_loss': 0.1, 'weight_3d_loss': 0.5,
                                         'opt_human': 'adamw'}, V=2, T=5, B=6, n_steps=4, n_warm=2, n_cam=2)
