@@ -291,7 +291,16 @@ class FitEngine:
     SMALL_BATCH_ROWS = 1024  # backward_mlp: below this many rows the dW GEMMs run beside the dX chain
     MAX_WORKSPACES = 24      # distinct batch sizes kept alive (a rank of a sharded minibatch run sees many)
 
-    def _ws(self, N):
+    @staticmethod
+    def ws_capacity(N):
+        """Workspaces are shared by batch sizes: below 2048 samples a size is rounded up to a multiple of 64 (one rank's
+        share of a random minibatch takes 60 - 80 different values around B / world: a workspace -- ~50 allocations --
+        per value would be evicted and rebuilt all the time).  Every kernel takes the actual N; only the captured
+        graphs are per N (they are keyed by it inside the shared workspace)."""
+        return N if N >= 2048 else max(64, (N + 63) // 64 * 64)
+
+    def _ws(self, n_samples):
+        N = self.ws_capacity(n_samples)
         w = self.ws.get(N)
         if w is not None:
             self.ws[N] = self.ws.pop(N)          # most recently used last
@@ -334,8 +343,11 @@ class FitEngine:
         # scratch of nemo_v2v_fused (arrival tickets, zero at allocation and returned to zero by the kernel, +
         # per-vertex-range partial dA): owned by THIS workspace and sized for every chunk length it launches, so a
         # HIP graph captured over the workspace never sees the buffer replaced under it
+        # (every launch size this workspace can see: whole chunks + the ragged rest of an exact large batch, or any
+        #  number of 16-sample groups up to the capacity of a shared small one)
         tail = N - (N // Nc) * Nc
-        need = max(int(self.lib.nemo_v2v_fused_ws_bytes(self.ctx.handle, n_)) for n_ in {Nc, tail or Nc})
+        sizes_seen = {Nc, tail or Nc} if N >= 2048 else set(range(16, N + 1, 16))
+        need = max(int(self.lib.nemo_v2v_fused_ws_bytes(self.ctx.handle, n_)) for n_ in sizes_seen)
         w['mesh_ws'] = torch.zeros((need + 3) // 4, dtype=torch.float32, device=self.device)
         # strided views into the merged MLP-head buffers
         w['ROT'], w['TR'] = w['HEAD'][:, :144], w['HEAD'][:, 144:147]

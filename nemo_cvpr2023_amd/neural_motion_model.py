@@ -399,8 +399,8 @@ class MultiViewModel(nn.Module):
         j3d = torch.empty(N, e.ctx.n_out, 3, device=self.device)
         e.forward_joints(w, N, vi, fi, with_loss=False, add_trans=add_trans, j3d=j3d)
         trans = w['TR'][:N] - w['TR'][N:N + 1] if not e.start_global_traj_anywhere else w['TR'][:N].clone()
-        out = {'view_idx': view_idx, 'frame_idx': frame_idx, 'j': j3d, 'poses': w['AA'][:, 3:].clone(),
-               'orient': w['ROT'][:N, :6].clone(), 'orient_aa': w['AA'][:, :3].clone(), 'trans': trans}
+        out = {'view_idx': view_idx, 'frame_idx': frame_idx, 'j': j3d, 'poses': w['AA'][:N, 3:].clone(),
+               'orient': w['ROT'][:N, :6].clone(), 'orient_aa': w['AA'][:N, :3].clone(), 'trans': trans}
         if with_vertices:
             out['v'] = self._vertices(w, N, trans if add_trans else None)
         return out
@@ -604,7 +604,7 @@ class MultiViewModel(nn.Module):
                 return
             # everything the captured launches bake in besides device-resident inputs: the mode, the shard
             # normalisers, the engine switches of the public NemoV2 setters, the loss weights and loss type
-            key = (bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, part, early,
+            key = (N, bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, part, early,
                    e.detach_articulation, e.start_global_traj_anywhere, has_inst, self._weights_key(),
                    tuple((s_['offset'], s_['numel']) for s_ in segs) if in_graph_adam else None)
             if part != 'tail':
@@ -619,28 +619,29 @@ class MultiViewModel(nn.Module):
                         pin = w['_idx_pin']
                         pin[0, :N].copy_(vi)
                         pin[1, :N].copy_(fi)
-                        w['vi_static'].copy_(pin[0, :N], non_blocking=True)
-                        w['fi_static'].copy_(pin[1, :N], non_blocking=True)
+                        w['vi_static'][:N].copy_(pin[0, :N], non_blocking=True)
+                        w['fi_static'][:N].copy_(pin[1, :N], non_blocking=True)
                     else:
-                        w['vi_static'].copy_(vi)
-                        w['fi_static'].copy_(fi)
+                        w['vi_static'][:N].copy_(vi)
+                        w['fi_static'][:N].copy_(fi)
                     w['_static_src'], w['_static_vi'] = src, vi
             table = e.adam_table_sync(segs) if (in_graph_adam and part != 'head') else None
+            svi, sfi = w['vi_static'][:N], w['fi_static'][:N]      # (the workspace may be larger than this batch)
             entry = w['graphs'].get(key)
             if entry == 'eager':
-                body(w['vi_static'], w['fi_static'], table, part)
+                body(svi, sfi, table, part)
             elif not isinstance(entry, torch.cuda.CUDAGraph) and (entry or 0) < self.GRAPH_AFTER:
                 # first sights: eager (sets kernel attributes, sizes pools; a shape that shows up once or
                 # twice -- a rank's share of a random minibatch -- is not worth a capture)
                 w['graphs'][key] = (entry or 0) + 1
-                body(w['vi_static'], w['fi_static'], table, part)
+                body(svi, sfi, table, part)
             else:
                 if not isinstance(entry, torch.cuda.CUDAGraph):   # capture the ~70-launch step as one HIP graph
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
                     try:
                         with torch.cuda.graph(g):
-                            body(w['vi_static'], w['fi_static'], table, part)
+                            body(svi, sfi, table, part)
                     except RuntimeError as ex:
                         # e.g. a capture invalidated by another thread of the process (a collective's
                         # watchdog): nothing of the body has run; keep launching this variant kernel by
@@ -648,13 +649,13 @@ class MultiViewModel(nn.Module):
                         warnings.warn(f'HIP graph capture failed ({ex}); this step variant runs un-captured')
                         torch.cuda.synchronize()
                         w['graphs'][key] = entry = 'eager'
-                        body(w['vi_static'], w['fi_static'], table, part)
+                        body(svi, sfi, table, part)
                     else:
                         w['graphs'][key] = entry = g
                 if entry != 'eager':
                     entry.replay()
             if part != 'head':
-                vi, fi = w['vi_static'], w['fi_static']
+                vi, fi = svi, sfi
 
         need_adam = update and not (graphable and in_graph_adam)
         if split:
@@ -709,7 +710,7 @@ class MultiViewModel(nn.Module):
         info_dict = _LazyInfo({'view_idx': vi, 'frame_idx': fi})
         if N > 0:
             makers = dict(loss_all=lambda: self._loss_all(w, N), points2d_gt=lambda: e.targets[vi, fi],
-                          points2d=lambda: w['p2d'].clone(), j=lambda: w['j3d'].clone())
+                          points2d=lambda: w['p2d'][:N].clone(), j=lambda: w['j3d'][:N].clone())
             if update:
                 info_dict.lazy.update(makers)
             else:
