@@ -514,6 +514,39 @@ static int32_t gemm_impl(bool bf16, int32_t transA, int32_t transB, int64_t M, i
         if (split_k > 0) pl.split = split_k;
     }
     if (const char* f = getenv("NEMO_GEMM_T0")) { if (atol(f) >= 0 && pl.tile == 64 && can_split && out_mode != 2) pl.t0 = atol(f); }   // tuning aid
+    // The blend-shape adjoint at large batch (dPF = dVP P^T: M = samples, N = 207, K = 3 NV = 20670, both operands
+    // "transposed"): a 64 x 208 tile on v_mfma_f32_16x16x4_f32 (13 accumulators per wave) reads the (K x M) operand ONCE
+    // instead of once per 64-column tile.  At M = 2400 that ties with the 64x64 plan (the narrow MFMA needs twice the LDS
+    // operand reads per FLOP), from M ~ 3000 on the saved memory traffic wins: 563 vs 678 us at M = 8192, 307 vs 344 us at
+    // M = 3808 (profiles/r02_experiments.md).  K slices so that ~512 blocks are resident (two per CU).
+    if (glds_ok && !bf16 && transA && transB && N > 128 && N <= 208 && M >= 3072 && K >= 2048 && split_k == 0 &&
+        out_mode != 2 && force_tile == 0 && can_split) {
+        const long tiles_m = (M + 63) / 64;
+        int S = (int)((512 + tiles_m - 1) / tiles_m);
+        if (S < 1) S = 1;
+        while (S > 1 && ((K + 31) / 32 / S < 8 || COUNTER_BYTES + tiles_m * S * 64L * 208 * 4 > ws_bytes)) --S;
+        if (tiles_m <= COUNTER_BYTES / 4) {
+            GemmArgs g;
+            g.A = A; g.B = B; g.C = C; g.bias = bias; g.mask = mask;
+            g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldmask = ldmask;
+            g.act = act; g.mask_mode = mask_mode; g.out_mode = out_mode; g.alpha = alpha;
+            g.counters = reinterpret_cast<int*>(ws);
+            g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
+            long kc = (K + S - 1) / S;
+            kc = ((kc + 31) / 32) * 32;
+            g.k_chunk = kc;
+            g.split = (int)((K + kc - 1) / kc);
+            g.tiles_m = (int)tiles_m; g.tiles_n = 1; g.n_tiles = (int)tiles_m; g.t0 = 0;
+            g.a_bytes = a_bytes; g.b_bytes = b_bytes; g.xcd_order = 0;
+            static const bool debug_wide = getenv("NEMO_GEMM_DEBUG") != nullptr;
+            if (debug_wide)
+                fprintf(stderr, "nemo_gemm_f32 ta=1 tb=1 M=%ld N=%ld K=%ld -> glds 64x208/16 split %d\n", (long)M, (long)N, (long)K, g.split);
+            hipError_t e = glds::launch<64, 208, 16, 208, 16, false, true, 2>(g, g.n_tiles * g.split, (hipStream_t)stream);
+            if (e != hipSuccess) return (int32_t)e;
+            NEMO_LAUNCH_CHECK();
+            return NEMO_OK;
+        }
+    }
     const int tile = pl.tile;
     static const bool debug_plans = getenv("NEMO_GEMM_DEBUG") != nullptr;          // tuning aid: the plan of every call
     if (debug_plans)
@@ -550,19 +583,26 @@ static int32_t gemm_impl(bool bf16, int32_t transA, int32_t transB, int64_t M, i
     // 32-bit buffer descriptor): operand tiles go global -> LDS by LDS-DMA, three stages, the pieces of the tile being
     // requested issued between the MFMAs of the tile being multiplied.  Same tiles, slices, slabs and epilogue as the
     // register-staged kernel below, which keeps the unaligned operands, the 128x128 tile and very large operands.
+    g.xcd_order = 0;
     if (tile == 64 && glds_ok) {
         g.a_bytes = a_bytes; g.b_bytes = b_bytes;
+        static const bool xcd_ok = [] { const char* f = getenv("NEMO_GEMM_XCD"); return !(f && atoi(f) == 0); }();
+        long nblocks = blocks;
+        if (nz == 1 && g.n_tiles >= 2048 && xcd_ok) {          // XCD-aware tile order for the large whole-tile launches
+            g.xcd_order = 1;
+            nblocks = 8L * ((g.tiles_m + 7) / 8) * g.tiles_n;
+        }
         const bool akc = !transA, bkc = transB != 0;
         if (bf16) {
-            if (akc && bkc) e = glds::launch<64, 64, 32, 32, 32, true, true, 3, true, true>(g, (int)blocks, s);
-            else if (akc) e = glds::launch<64, 64, 32, 32, 32, true, false, 3, true, true>(g, (int)blocks, s);
-            else if (bkc) e = glds::launch<64, 64, 32, 32, 32, false, true, 3, true, true>(g, (int)blocks, s);
-            else e = glds::launch<64, 64, 32, 32, 32, false, false, 3, true, true>(g, (int)blocks, s);
+            if (akc && bkc) e = glds::launch<64, 64, 32, 32, 32, true, true, 3, true, true>(g, (int)nblocks, s);
+            else if (akc) e = glds::launch<64, 64, 32, 32, 32, true, false, 3, true, true>(g, (int)nblocks, s);
+            else if (bkc) e = glds::launch<64, 64, 32, 32, 32, false, true, 3, true, true>(g, (int)nblocks, s);
+            else e = glds::launch<64, 64, 32, 32, 32, false, false, 3, true, true>(g, (int)nblocks, s);
         } else
-        if (akc && bkc) e = glds::launch<64, 64, 32, 32, 32, true, true, 3, true>(g, (int)blocks, s);
-        else if (akc) e = glds::launch<64, 64, 32, 32, 32, true, false, 3, true>(g, (int)blocks, s);
-        else if (bkc) e = glds::launch<64, 64, 32, 32, 32, false, true, 3, true>(g, (int)blocks, s);
-        else e = glds::launch<64, 64, 32, 32, 32, false, false, 3, true>(g, (int)blocks, s);
+        if (akc && bkc) e = glds::launch<64, 64, 32, 32, 32, true, true, 3, true>(g, (int)nblocks, s);
+        else if (akc) e = glds::launch<64, 64, 32, 32, 32, true, false, 3, true>(g, (int)nblocks, s);
+        else if (bkc) e = glds::launch<64, 64, 32, 32, 32, false, true, 3, true>(g, (int)nblocks, s);
+        else e = glds::launch<64, 64, 32, 32, 32, false, false, 3, true>(g, (int)nblocks, s);
         if (e != hipSuccess) return (int32_t)e;
         NEMO_LAUNCH_CHECK();
         return NEMO_OK;

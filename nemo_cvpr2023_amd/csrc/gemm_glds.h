@@ -62,6 +62,7 @@ struct Args {
     int act, mask_mode, out_mode;
     float alpha;
     unsigned a_bytes, b_bytes;      // buffer extents (last valid byte + 1) of the two operands
+    int xcd_order;                  // 1: whole-tile launch of 8 * ceil(tiles_m / 8) * tiles_n blocks in XCD-aware order
 };
 
 constexpr int BK = 32;
@@ -196,12 +197,23 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(Args g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int bid = blockIdx.x;
-    const bool whole = bid < g.t0;
+    const bool whole = bid < g.t0 || g.xcd_order;
     const int n_tail = g.n_tiles - g.t0;
-    const int tile = whole ? bid : g.t0 + (bid - g.t0) % n_tail;
+    int tile = whole ? bid : g.t0 + (bid - g.t0) % n_tail;
     const int slice = whole ? 0 : (bid - g.t0) / n_tail;
     const int split = whole ? 1 : g.split;
-    const int tm = tile % g.tiles_m, tn = tile / g.tiles_m;
+    int tm = tile % g.tiles_m, tn = tile / g.tiles_m;
+    if (g.xcd_order) {
+        // Large launches (thousands of tiles, no K split): block b runs on XCD b % 8 (observed dispatch order; only
+        // speed depends on it).  Give every XCD its own row blocks of the A operand -- tm = 8 i + xcd -- and walk all
+        // column tiles of a row block before the next one, so the ~96 blocks an XCD holds at a time share 6 row blocks of
+        // A and the whole (small) B in that XCD's L2 instead of every L2 streaming all of A once per column tile.
+        const int xcd = bid & 7, i = bid >> 3;
+        tm = (i / g.tiles_n) * 8 + xcd;
+        tn = i % g.tiles_n;
+        if (tm >= g.tiles_m) return;
+        tile = tn * g.tiles_m + tm;
+    }
     const long m0 = (long)tm * BM, n0 = (long)tn * BN;
     const long kbeg = whole ? 0 : (long)slice * g.k_chunk;
     const long kend = whole ? g.K : min(g.K, kbeg + g.k_chunk);

@@ -678,3 +678,20 @@ def test_publish_scalars_to_pinned_host_memory(L):
         assert np.array_equal(host.numpy()[:8], want)
     assert L.nemo_publish_scalars(None, 8, host.data_ptr(), host.data_ptr() + 32, H.st()) < 0
     assert L.nemo_publish_scalars(src.data_ptr(), 65, host.data_ptr(), host.data_ptr() + 32, H.st()) < 0
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0)])
+def test_gemm_xcd_ordered_large_launch(L, ta, tb):
+    """Launches of >= 2048 whole tiles walk the tiles in an XCD-aware order (8 * ceil(tiles_m / 8) * tiles_n blocks,
+    the surplus ones exit): every tile must still be computed exactly once, ragged edges included."""
+    H = _ops()
+    M, N, K = 4100 + 13, 2100 + 5, 72
+    g = torch.Generator().manual_seed(M + ta + 2 * tb)
+    pad = lambda n: (n + 3) // 4 * 4
+    A = H.dev(torch.randn((K, pad(M)) if ta else (M, pad(K)), generator=g))[:, :(M if ta else K)]
+    B = H.dev(torch.randn((N, pad(K)) if tb else (K, pad(N)), generator=g))[:, :(K if tb else N)]
+    bias = H.dev(torch.randn(N, generator=g))
+    C = torch.full((M, N), float('nan'), device='cuda')
+    H.gemm(A, B, ta, tb, bias=bias, act=1, C=C, split_k=0)
+    a, b = (A.double().T if ta else A.double()), (B.double().T if tb else B.double())
+    assert rel_err(C, torch.relu(a @ b + bias.double())) < TOL

@@ -45,7 +45,7 @@ hipError_t run(int cfg, int ta, int tb, long M, long N, long K, const float* A, 
                long ldc, const float* bias, int act, int out_mode, int split, int t0_whole, float* ws, hipStream_t s) {
     Args g{};
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.mask = nullptr; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.ldmask = 0; g.act = act; g.mask_mode = 0; g.out_mode = out_mode; g.alpha = 1.f;
+    g.ldmask = 0; g.act = act; g.mask_mode = 0; g.out_mode = out_mode; g.alpha = 1.f; g.xcd_order = 0;
     g.counters = reinterpret_cast<int*>(ws); g.slabs = ws + 4096;
     if (!glds::extents(ta, tb, M, N, K, lda, ldb, &g.a_bytes, &g.b_bytes)) return hipErrorInvalidValue;
     const int BM = cfg_bm[cfg], BN = cfg_bn[cfg];
