@@ -640,11 +640,10 @@ class FitEngine:
         # exact 0 there), so its column sum is skipped unless the global trajectory is un-anchored.
         nout = 147 if has_trans_grad else 144
         nbias = 147 if (has_trans_grad and self.start_global_traj_anywhere) else 144
-        # Schedule.  Large batches (each GEMM fills the machine; co-scheduling two of them measured no gain): the
-        # activation-gradient chain (dX) and the parameter-gradient GEMMs (dW) alternate on the main stream and only the
-        # SMALL kernels leave it -- the batched bias column sums run on a side stream as soon as the last dY exists
-        # (under the layer-0 dX GEMM), the three phase / RBF / code backward kernels, which only need dX, under the
-        # layer-0 dW GEMM.  Small batches (one rank's share at 8 GPUs: a GEMM is ~80 tiles, a third of the CUs): the dW
+        # Schedule.  Large batches (each hidden-layer GEMM fills the machine; co-scheduling two of them measured no gain):
+        # the activation-gradient chain (dX) and the parameter-gradient GEMMs (dW) alternate on the main stream up to
+        # layer 2; then one fork: the (small) layer-0 dW GEMM and the batched bias column sums on the side stream, the
+        # layer-0 dX GEMM and the three phase / RBF / code backward kernels that consume it on the main stream.  Small batches (one rank's share at 8 GPUs: a GEMM is ~80 tiles, a third of the CUs): the dW
         # GEMMs are off the dependency chain, so they ALL go to the side stream, each as soon as its dY exists, and
         # the chain dX_head -> dX4 -> dX2 -> dX0 -> phase backward runs uninterrupted on the main stream.
         # (NEMO_SERIAL_BWD=1: everything on the main stream, for A/B timing.)
@@ -693,17 +692,15 @@ class FitEngine:
             phase_bwd()
             main.wait_stream(side)
         elif overlap:
-            # (queue the layer-0 bias sum now: every dY of the batched column sums exists from here on)
-            self._colsums.append((dptr(w['dH_c']), r, h, h, self.g(lm + 'net.net.0.bias')))
+            # ONE fork, one join (each costs 5 - 25 us of idle time inside a replayed graph): the side stream takes the
+            # layer-0 parameter gradient and the batched bias column sums (every dY exists from here on), the main stream
+            # the layer-0 dX GEMM and the three phase / RBF / code kernels that consume it
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                self._linear_bwd_params(*w0)
                 self.flush_colsums()
             dX0()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                phase_bwd()
-            self.gemm(1, 0, h, self.din, r, dptr(w['dH_c']), h, dptr(w['X']), self.ldx,
-                      self.g(lm + 'net.net.0.weight'), self.din, out_mode=1, dense=True)
+            phase_bwd()
             main.wait_stream(side)
         else:
             self._linear_bwd_params(*w0)
