@@ -138,12 +138,14 @@ def check_world(opts, dist, torch, rank, world, local_rank):
 # ----------------------------------------------------------------------------------------------- CPU leg
 def cpu_child(spec):
     """``--cpu-child name,V,T,B,threads,warmup,steps``: time the CPU oracle (child process, no GPU)."""
-    name, V, T, B, threads, warm, steps = spec.split(',')
+    name, V, T, B, threads, warm, steps, *dev = spec.split(',')
     V, T, B, threads, warm, steps = int(V), int(T), int(B), int(threads), int(warm), int(steps)
+    dev = dev[0] if dev else 'cpu'            # 'cuda': the same unfused step through PyTorch-ROCm (torch_gpu_baseline)
     import torch
     from nemo_cvpr2023_amd import synthetic as syn
     from oracle.model import OracleNemo
-    torch.set_num_threads(threads)
+    if threads > 0:
+        torch.set_num_threads(threads)
     if name == 'c1':
         version, args, nv = 1, syn.default_v1_args(batch_size=-1, out_dir=''), 6890
     else:
@@ -152,6 +154,10 @@ def cpu_child(spec):
     torch.manual_seed(0)
     o = OracleNemo(version, args, seqs, syn.make_smpl_assets(nv, seed=1), syn.make_vposer_state(), syn.make_gmm())
     gen = torch.Generator().manual_seed(2)
+    sync = (lambda: None) if dev == 'cpu' else torch.cuda.synchronize
+    if dev != 'cpu':
+        o = o.to(dev)
+        torch.set_default_device(dev)
 
     def one():
         if B > 0:
@@ -160,9 +166,11 @@ def cpu_child(spec):
             o.step(None, None, update=True, full_batch=True)
     for _ in range(warm):
         one()
+    sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         one()
+    sync()
     dt = time.perf_counter() - t0
     print(json.dumps({'value': round(steps / dt, 4), 'seconds': round(dt, 2)}))
 
@@ -354,26 +362,24 @@ def main():
     # kernels on THIS GPU: what `north_star` calls "the reference single-GPU PyTorch iters/sec".
     tgpu = None
     if rank == 0 and world == 1 and not opts.no_torch_gpu_baseline:
-        from oracle.model import OracleNemo
+        # in a child process: the stock kernels fault on this GPU from ~24 x 300 samples on (32-bit indexing of the
+        # (N, 6890, 24, ...) skinning intermediates), and a baseline must never take the bench line down
+        n_t = 5
+        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-child', f'c2,{V},{T},-1,0,2,{n_t},cuda']
         try:
-            o = OracleNemo(2, args, seqs, assets['smpl_assets'], assets['vposer_state'], assets['gmm']).to(device)
-            with torch.device(device):
-                for _ in range(2):
-                    o.step(None, None, update=True, full_batch=True)
-                torch.cuda.synchronize()
-                g0 = time.perf_counter()
-                n_t = 5
-                for _ in range(n_t):
-                    o.step(None, None, update=True, full_batch=True)
-                torch.cuda.synchronize()
-                gdt = time.perf_counter() - g0
-            tgpu = {'value': round(n_t / gdt, 3), 'unit': 'iters/s', 'kind': 'port',
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            gval = json.loads(r.stdout.strip().splitlines()[-1])['value']
+            tgpu = {'value': round(gval, 3), 'unit': 'iters/s', 'kind': 'port',
                     'sample': f'{n_t} full-batch steps ({V}x{T}) of the oracle (unfused PyTorch restatement of the '
-                              f'reference step) on this GPU through PyTorch-ROCm, after 2 warm-up steps',
-                    'speedup_of_this_engine': round(iters_per_s / (n_t / gdt), 1)}
-            del o
-        except Exception as exc:                      # a baseline must never take the bench line down
-            tgpu = {'error': repr(exc)[:200]}
+                              f'reference step) on this GPU through PyTorch-ROCm (child process), after 2 warm-up steps',
+                    'speedup_of_this_engine': round(iters_per_s / gval, 1)}
+        except Exception as exc:
+            tail = ''
+            try:
+                tail = (r.stderr or '').strip().splitlines()[-1][:160]
+            except Exception:
+                pass
+            tgpu = {'error': (repr(exc)[:120] + ' | ' + tail).strip(' |')}
 
     if rank == 0:
         out = {

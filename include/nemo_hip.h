@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 5
+#define NEMO_ABI_VERSION 6
 int32_t nemo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -319,6 +319,10 @@ int32_t nemo_adam_step_dev(int32_t n_seg, const nemo_adam_seg* segs_dev, int64_t
  * re-uploads the table when a learning rate, the segment list or the step counts change under it. */
 int32_t nemo_step_begin(void* z0, int64_t bytes0, void* z1, int64_t bytes1, nemo_adam_seg* segs_dev, int32_t n_seg,
                         double beta1, double beta2, void* stream);
+
+/* Instance-code regulariser of NemoV3 / V4 (nemo/neural_motion_model.py:3864-3867):
+ * scalar_out += mean(x[0..n)^2);  grad (may be NULL) += gscale * x. */
+int32_t nemo_sqmean_fwd_bwd(int64_t n, const float* x, float* scalar_out, float* grad, float gscale, void* stream);
 
 /* Small utilities. */
 int32_t nemo_scale_neg_rowsum(int64_t N, int64_t cols, const float* X, int64_t ldx, float* out_row,

@@ -26,7 +26,7 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 5        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 6        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -82,6 +82,7 @@ SIGNATURES = {
     'nemo_pose3d_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, f32, ptr, i64, ptr]),
     'nemo_adam_step': (i32, [i32, POINTER(AdamSeg), ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),
     'nemo_adam_step_dev': (i32, [i32, ptr, i64, ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),
+    'nemo_sqmean_fwd_bwd': (i32, [i64, ptr, ptr, ptr, f32, ptr]),
     'nemo_step_begin': (i32, [ptr, i64, ptr, i64, ptr, i32, c_double, c_double, ptr]),
     'nemo_scale_neg_rowsum': (i32, [i64, i64, ptr, i64, ptr, ptr]),
 }

@@ -553,6 +553,32 @@ extern "C" int32_t nemo_v2v_prep_bwd(int64_t N, const float* aa, const float* dR
     return NEMO_OK;
 }
 
+// Instance-code regulariser of NemoV3 / V4 (nemo/neural_motion_model.py:3864-3867): scalar_out += mean(x^2) and, when
+// grad != NULL, grad += gscale * x  (gscale = 2 * weight / numel, times the shard's share of the views).  One block: the
+// code table is V x C floats.  The sum is taken in thread order (deterministic).
+namespace {
+__global__ __launch_bounds__(256) void sqmean_kernel(long n, const float* __restrict__ x, float* __restrict__ scalar_out,
+                                                     float* __restrict__ grad, float gscale) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const float v = x[i];
+        acc += v * v;
+        if (grad) grad[i] += gscale * v;
+    }
+    const float t = block_sum(acc, red);
+    if (threadIdx.x == 0) *scalar_out += t / (float)n;
+}
+}  // namespace
+
+extern "C" int32_t nemo_sqmean_fwd_bwd(int64_t n, const float* x, float* scalar_out, float* grad, float gscale,
+                                       void* stream) {
+    if (n <= 0 || !x || !scalar_out) return NEMO_EINVAL;
+    hipLaunchKernelGGL(sqmean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (long)n, x, scalar_out, grad, gscale);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
 extern "C" int32_t nemo_scale_neg_rowsum(int64_t N, int64_t cols, const float* X, int64_t ldx, float* out_row,
                                          void* stream) {
     if (N < 0 || cols <= 0 || !X || !out_row) return NEMO_EINVAL;

@@ -555,12 +555,12 @@ class MultiViewModel(nn.Module):
 
         def body(vi_, fi_, adam_table, part='all'):
             """Everything of the step (or of one half of it) that runs on the device without host interaction."""
-            def inst_term():
-                code = self.learned_instance_code.detach()
-                e.scal[S_INST] = (code ** 2).mean()                                       # :3864-3867
-                if update:
-                    e.view('learned_instance_code', e.grads).add_(
-                        code, alpha=2.0 * float(a.weight_instance_loss) * sh.vr / code.numel())
+            def inst_term():                                                              # :3864-3867
+                n_code = e.V * e.C
+                check(e.lib.nemo_sqmean_fwd_bwd(n_code, e.p('learned_instance_code'), e.scal.data_ptr() + 4 * S_INST,
+                                                e.g('learned_instance_code') if update else None,
+                                                2.0 * float(a.weight_instance_loss) * sh.vr / n_code, _stream()),
+                      'nemo_sqmean_fwd_bwd')
             if N > 0:
                 self._forward_backward(w, N, vi_, fi_, update, sh=sh, smooth_ok=is_full,
                                        extra_losses=inst_term if has_inst else None, publish=early, part=part,

@@ -695,3 +695,60 @@ def test_gemm_xcd_ordered_large_launch(L, ta, tb):
     H.gemm(A, B, ta, tb, bias=bias, act=1, C=C, split_k=0)
     a, b = (A.double().T if ta else A.double()), (B.double().T if tb else B.double())
     assert rel_err(C, torch.relu(a @ b + bias.double())) < TOL
+
+
+@pytest.mark.parametrize('n', [5, 8 * 5, 256 * 10])
+def test_sqmean_instance_regulariser(L, n):
+    """nemo_sqmean_fwd_bwd == (code ** 2).mean() and its gradient (nemo/neural_motion_model.py:3864-3867), added onto
+    what the outputs already held; bit-identical from run to run (fixed summation order)."""
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g).cuda()
+    out = torch.full((1,), 0.25, device='cuda')
+    grad = torch.ones(n, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.nemo_sqmean_fwd_bwd(n, x.data_ptr(), out.data_ptr(), grad.data_ptr(), 0.5, st) == 0
+    torch.testing.assert_close(out.cpu(), 0.25 + (x.cpu().double() ** 2).mean().float().reshape(1), rtol=2e-6, atol=0)
+    torch.testing.assert_close(grad.cpu(), 1.0 + 0.5 * x.cpu(), rtol=1e-6, atol=0)
+    out2 = torch.full((1,), 0.25, device='cuda')
+    assert L.nemo_sqmean_fwd_bwd(n, x.data_ptr(), out2.data_ptr(), None, 0.0, st) == 0
+    assert torch.equal(out2, out)
+    assert L.nemo_sqmean_fwd_bwd(0, x.data_ptr(), out.data_ptr(), None, 0.0, st) != 0
+
+
+@pytest.mark.parametrize('ta,tb,M,N,K,pad', [
+    (0, 1, 300, 1000, 1000, 4),      # forward, 32 x 64 tiles on 8 waves
+    (0, 1, 301, 147, 1000, 4),       # forward head, 32 x 32 tiles on 4 waves
+    (0, 1, 300, 1000, 105, 0),       # weights with in_features = 105: rows not 16-byte aligned
+    (0, 1, 30, 512, 63, 0),          # C1-sized batch, K not a multiple of 8, unaligned
+    (0, 0, 301, 1000, 147, 4),       # input gradient
+    (0, 0, 1200, 1000, 1000, 4),     # input gradient of a 4-instance shard
+    (1, 0, 1000, 1000, 333, 4),      # parameter gradient, 64 x 64 tiles on 8 waves (128 KiB reduction buffer)
+    (1, 0, 1000, 1000, 2401, 4),
+    (1, 0, 147, 1000, 301, 4),
+    (1, 0, 1000, 105, 300, 1),       # dW of the first layer (odd ld on both sides)
+    (1, 1, 77, 207, 515, 4),
+])
+def test_gemm_skinny_paths(L, ta, tb, M, N, K, pad):
+    """Problems the auto plan sends to the intra-block K-split kernel (csrc/gemm_skinny.h): product, fused bias + ReLU,
+    masked C += (the MLP backward's epilogue), bit-identical repeat, nothing written outside C's logical columns."""
+    H = _ops()
+    g = torch.Generator().manual_seed(M + 3 * N + 5 * K + ta + 2 * tb)
+    lda = (M if ta else K) + pad
+    ldb = (K if tb else N) + pad
+    Af = torch.randn((K if ta else M), lda, generator=g)
+    Bf = torch.randn((N if tb else K), ldb, generator=g)
+    Af[:, (M if ta else K):] = float('nan')                 # pads must never reach a result
+    Bf[:, (K if tb else N):] = float('nan')
+    A, B = Af[:, :(M if ta else K)], Bf[:, :(K if tb else N)]
+    bias, mask = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = (A.T if ta else A).double() @ (B.T if tb else B).double()
+    dA, dB = H.dev(Af)[:, :A.shape[1]], H.dev(Bf)[:, :B.shape[1]]
+    C1 = H.gemm(dA, dB, ta, tb, split_k=0, bias=H.dev(bias), act=1)
+    assert rel_err(C1, torch.relu(ref + bias.double())) < TOL
+    C2 = H.gemm(dA, dB, ta, tb, split_k=0, bias=H.dev(bias), act=1)
+    assert torch.equal(C1, C2)
+    C0 = torch.randn(M, N + 3, generator=g)
+    Cw = H.dev(C0).clone()
+    H.gemm(dA, dB, ta, tb, split_k=0, mask=H.dev(mask), mask_mode=1, out_mode=1, C=Cw[:, :N])
+    assert rel_err(Cw[:, :N], C0[:, :N].double() + torch.where(mask > 0, ref, torch.zeros_like(ref))) < TOL
+    assert torch.equal(Cw[:, N:].cpu(), C0[:, N:])
