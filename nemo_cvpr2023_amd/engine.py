@@ -651,23 +651,42 @@ class FitEngine:
         overlap = self.overlap_bwd
         small = overlap and r <= self.SMALL_BATCH_ROWS
 
-        def dW(*a, **k):
+        # (Enqueue order in small mode: the chain's next GEMM BEFORE the parameter-gradient GEMM that branches off -- a
+        #  replayed graph keeps a node's first successor on its hardware queue and pays a 15 - 30 us cross-queue barrier
+        #  for the others; that must not be the chain.)
+        def dW(ready, *a, **k):
             if not small:
                 return self._linear_bwd_params(*a, **k)
-            side.wait_stream(main)                      # (its dY was the last thing enqueued on the main stream)
+            side.wait_event(ready)
             with torch.cuda.stream(side):
                 self._linear_bwd_params(*a, **k)
 
-        dW(r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
-           self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
+        def dY_ready():
+            return main.record_event() if small else None
+
+        ev = dY_ready()
+        if not small:
+            dW(None, r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
+               self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
         self.gemm(0, 0, r, h, nout, dptr(w['dHEAD']), HEAD_LD, self.p(lm + 'rot_out.weight'), h,
                   dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1, dense=True)
-        dW(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
+        if small:
+            dW(ev, r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
+               self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
+        ev = dY_ready()
+        if not small:
+            dW(None, r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
         self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
                   mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx', dense=True)
-        dW(r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+        if small:
+            dW(ev, r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
+        ev = dY_ready()
+        if not small:
+            dW(None, r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
         self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
                   mask=dptr(w['H1']), ldmask=h, mask_mode=1, dense=True)
+        if small:
+            dW(ev, r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
 
         def phase_bwd():
             check(L.nemo_phase_embed_bwd(
@@ -684,23 +703,17 @@ class FitEngine:
                       dptr(w['dX']), self.ldx, dense=True)
         w0 = (r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h,
               self.g(lm + 'net.net.0.weight'), self.g(lm + 'net.net.0.bias'))
-        if small:
-            dW(*w0)
-            with torch.cuda.stream(side):
-                self.flush_colsums()
+        if small or overlap:
+            # ONE more fork, one join: the side stream takes the layer-0 parameter gradient and the batched bias column
+            # sums (every dY exists from here on), the main stream -- enqueued first, see above -- the layer-0 dX GEMM and
+            # the three phase / RBF / code kernels that consume it
+            ev = main.record_event()
             dX0()
             phase_bwd()
-            main.wait_stream(side)
-        elif overlap:
-            # ONE fork, one join (each costs 5 - 25 us of idle time inside a replayed graph): the side stream takes the
-            # layer-0 parameter gradient and the batched bias column sums (every dY exists from here on), the main stream
-            # the layer-0 dX GEMM and the three phase / RBF / code kernels that consume it
-            side.wait_stream(main)
+            side.wait_event(ev)
             with torch.cuda.stream(side):
                 self._linear_bwd_params(*w0)
                 self.flush_colsums()
-            dX0()
-            phase_bwd()
             main.wait_stream(side)
         else:
             self._linear_bwd_params(*w0)

@@ -450,13 +450,30 @@ class MultiViewModel(nn.Module):
         e.forward_pose(w, N, vi, fi, code_noise=self._noise(N))
         main = torch.cuda.current_stream()
         side, side2 = e.side_stream, e.side_stream2
-        side.wait_stream(main)
-        side2.wait_stream(main)
+        pose_done = main.record_event()
         aa69, daa69 = w['AA'].data_ptr() + 12, w['dAA'].data_ptr() + 12
+        # The main-stream branch (the longest of the three) is ENQUEUED FIRST: a replayed HIP graph keeps a node's first
+        # successor on the hardware queue of the node and starts the others on further queues behind a cross-queue
+        # barrier that costs 15 - 30 us (profiles/r02_kernel_trace_v1.md) -- that delay has to land on the short branches.
+        Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0)
+        # optional temporal smoothness of the output joints (not part of the published step; only defined on
+        # complete (view, frame) sequences, i.e. full-batch steps -- see DESIGN.md section 8, row f-4)
+        dj = None
+        w_s = float(getattr(a, 'weight_smooth', 0) or 0)
+        if w_s and N == e.V * e.T and smooth_ok:
+            check(e.lib.nemo_smooth_fwd_bwd(e.V, e.T, e.ctx.n_out, dptr(w['j3d']), w_s,
+                                            e.scal.data_ptr() + 4 * S_SMOOTH, dptr(w['dj3d']) if update else None,
+                                            _stream()), 'nemo_smooth_fwd_bwd')
+            dj = w['dj3d'] if update else None
+        if update:
+            e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose,
+                          dj3d_extra=dj)
         # side : VPoser encode -> decode -> axis-angle (the mesh term waits for it)
         # side2: everything that accumulates into dAA -- GMM prior, 3-D pose term (they only need the pose), then, once
         #        the encoder output exists, KL and its backward through the frozen encoder.  One stream for all of
         #        them: their `+=` into dAA are plain read-modify-writes.
+        side.wait_event(pose_done)
+        side2.wait_event(pose_done)
         enc_done = None
         with torch.cuda.stream(side):
             if use_vposer:
@@ -481,19 +498,6 @@ class MultiViewModel(nn.Module):
                 e.vposer_kl(w, N)
                 if update and a.weight_vp_z_loss:
                     e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
-        Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0)
-        # optional temporal smoothness of the output joints (not part of the published step; only defined on
-        # complete (view, frame) sequences, i.e. full-batch steps -- see DESIGN.md section 8, row f-4)
-        dj = None
-        w_s = float(getattr(a, 'weight_smooth', 0) or 0)
-        if w_s and N == e.V * e.T and smooth_ok:
-            check(e.lib.nemo_smooth_fwd_bwd(e.V, e.T, e.ctx.n_out, dptr(w['j3d']), w_s,
-                                            e.scal.data_ptr() + 4 * S_SMOOTH, dptr(w['dj3d']) if update else None,
-                                            _stream()), 'nemo_smooth_fwd_bwd')
-            dj = w['dj3d'] if update else None
-        if update:
-            e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose,
-                          dj3d_extra=dj)
         main.wait_stream(side)
         main.wait_stream(side2)
         # the fused mesh kernel is sized to fill the machine in exactly one resident wave of blocks:
