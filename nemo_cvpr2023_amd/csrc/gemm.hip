@@ -477,13 +477,15 @@ Plan plan_gemm(long M, long N, long K, bool can_split, long ws_bytes, bool atomi
 
 // Skinny problems (gemm_skinny.h): K split inside the block, no cross-block hand-off.  kind 0: 32 x 32 tiles on 4 waves
 // (per-operand dword fall-backs for unaligned image-K operands), 1: 32 x 64 tiles on 8 waves, 2: 64 x 64 tiles on 8 waves
-// (the 1000 x 1000 parameter gradients); 1 and 2 need 16-byte aligned image-K operands.
+// (the 1000 x 1000 parameter gradients), 3: 32 x 32 tiles on 8 waves with K also cut across blocks (Args::split; the
+// blend-shape adjoint of a one-instance shard); 1 - 3 need 16-byte aligned image-K operands.
 static hipError_t skinny_launch(bool akc, bool bkc, bool va, bool vb, int kind, const GemmArgs& g, hipStream_t s) {
     // alignment only matters for image-K operands
     const bool av = va || !akc, bv = vb || !bkc;
 #define SK(AKC, BKC)                                                                                    \
     do {                                                                                                \
-        if (kind == 2) e = skinny::launch<AKC, BKC, true, true, 2, 2, 8, 3>(g, s);                      \
+        if (kind == 3) e = skinny::launch<AKC, BKC, true, true, 1, 1, 8, 4>(g, s);                      \
+        else if (kind == 2) e = skinny::launch<AKC, BKC, true, true, 2, 2, 8, 3>(g, s);                 \
         else if (kind == 1) e = skinny::launch<AKC, BKC, true, true, 1, 2, 8, 4>(g, s);                 \
         else if (av && bv) e = skinny::launch<AKC, BKC, true, true, 1, 1, 4, 4>(g, s);                  \
         else if (av) e = skinny::launch<AKC, BKC, true, !(BKC), 1, 1, 4, 4>(g, s);                      \
@@ -503,7 +505,7 @@ static hipError_t skinny_launch(bool akc, bool bkc, bool va, bool vb, int kind, 
 // (profiles/r02_gemm_skinny.md).  Image-M operands (dword loads, two full cache lines per instruction) stream well at any
 // size; image-K operands cost the texture path 32 lines per dwordx4 instruction, so the layouts that have them hand over
 // to the LDS-staged kernel (whose LDS-DMA pieces are whole lines) once its 64 x 64 grid fills the chip.
-static int skinny_kind(bool akc, bool bkc, bool aligned, long M, long N, long K) {
+static int skinny_kind(bool akc, bool bkc, bool aligned, bool can_split, long M, long N, long K) {
     const long t64 = ((M + 63) / 64) * ((N + 63) / 64), t3264 = ((M + 31) / 32) * ((N + 63) / 64);
     bool use;
     if (!akc && !bkc) {                     // parameter gradients dW = dY^T X
@@ -513,7 +515,12 @@ static int skinny_kind(bool akc, bool bkc, bool aligned, long M, long N, long K)
         use = t64 <= 192 && K <= 4096;
     } else if (akc && !bkc) use = M <= 1536 && t64 <= 320 && K <= 4096;       // input gradients dX = dY W
     else if (akc && bkc) use = M <= 1024 && t64 <= 192 && K <= 4096;         // forward Y = X W^T
-    else use = t64 <= 192 && K <= 4096;
+    else {
+        // dPF = dVP P^T of a one-instance shard (K = 20 670 over 70 tiles): 58 us with 16 K slices across blocks against
+        // 68 us for the LDS-staged kernel's best plan; from ~600 samples on that kernel wins (profiles/r02_gemm_skinny.md)
+        if (K > 4096) return aligned && can_split && t64 <= 24 ? 3 : -1;
+        use = t64 <= 192;
+    }
     if (!use) return -1;
     return aligned && K >= 512 && t3264 >= 128 && t3264 <= 256 ? 1 : 0;
 }
@@ -597,18 +604,27 @@ static int32_t gemm_impl(bool bf16, int32_t transA, int32_t transB, int64_t M, i
     // LDS-staged kernel: a wave's K slice would be thousands of steps.
     static const bool use_skinny = [] { const char* f = getenv("NEMO_GEMM_SKINNY"); return !(f && atoi(f) == 0); }();
     const int sk_kind = use_skinny && !bf16 && split_k == 0 && force_tile == 0 && K >= 1
-                            ? skinny_kind(!transA, transB != 0, (va || transA) && (vb || !transB), M, N, K) : -1;
+                            ? skinny_kind(!transA, transB != 0, (va || transA) && (vb || !transB),
+                                          can_split && out_mode != 2 && ws_bytes >= COUNTER_BYTES + (8L << 20), M, N, K) : -1;
     if (sk_kind >= 0 && (glds_ok || glds::extents(transA, transB, M, N, K, lda, ldb, &a_bytes, &b_bytes))) {
         GemmArgs g;
         g.A = A; g.B = B; g.C = C; g.bias = bias; g.mask = mask;
         g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldmask = ldmask;
         g.act = act; g.mask_mode = mask_mode; g.out_mode = out_mode; g.alpha = alpha;
-        g.counters = nullptr; g.slabs = nullptr; g.k_chunk = K; g.split = 1; g.n_tiles = 0; g.t0 = 0; g.xcd_order = 0;
+        g.counters = nullptr; g.slabs = nullptr; g.k_chunk = (K + 7) / 8 * 8; g.split = 1; g.n_tiles = 0; g.t0 = 0; g.xcd_order = 0;
         g.a_bytes = a_bytes; g.b_bytes = b_bytes;
+        if (sk_kind == 3) {         // 16 K slices: <= 96 tiles of 32 x 32 x 16 slabs of 4 KiB = 6 MiB of the workspace
+            long kc = (K + 15) / 16;
+            kc = (kc + 7) / 8 * 8;
+            g.k_chunk = kc;
+            g.split = (int)((K + kc - 1) / kc);
+            g.counters = reinterpret_cast<int*>(ws);
+            g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
+        }
         static const bool debug_skinny = getenv("NEMO_GEMM_DEBUG") != nullptr;
         if (debug_skinny)
             fprintf(stderr, "nemo_gemm_f32 ta=%d tb=%d M=%ld N=%ld K=%ld out=%d -> skinny %s\n", transA, transB, (long)M, (long)N,
-                    (long)K, out_mode, sk_kind == 2 ? "64x64 w8" : sk_kind == 1 ? "32x64 w8" : "32x32 w4");
+                    (long)K, out_mode, sk_kind == 3 ? "32x32 w8 x 16 K slices" : sk_kind == 2 ? "64x64 w8" : sk_kind == 1 ? "32x64 w8" : "32x32 w4");
         const hipError_t e = skinny_launch(!transA, transB != 0, va, vb, sk_kind, g, (hipStream_t)stream);
         if (e != hipSuccess) return (int32_t)e;
         NEMO_LAUNCH_CHECK();

@@ -5,6 +5,8 @@
 //   * output tile (32 NI) x (32 NJ); the W waves of a block each own a K slice of the whole tile and multiply straight
 //     from global memory (no LDS staging: nothing is shared between waves, a wave's operand fragment is exactly what
 //     one buffer load returns -- see the k permutation below), D steps of 8 k in flight per wave;
+//   * (optionally K is ALSO cut across blocks -- Args::split slices, write-through slabs and a ticket per tile as in
+//     gemm_glds.h -- for very long K over few tiles: the blend-shape adjoint dPF = dVP P^T of a one-instance shard);
 //   * the W partial tiles meet in LDS (W NI NJ 4 KiB), every wave sums 16 NI NJ / W accumulator rows in wave order
 //     (deterministic) and runs the epilogue.
 // Same operations as gemm_glds.h / gemm.hip: nn.Linear forward / backward of MotionNet and VPoser
@@ -61,7 +63,10 @@ template <bool AKC, bool BKC, bool AV, bool BV, int NI, int NJ, int W, int D>
 __global__ __launch_bounds__(64 * W) void gemm_skinny_kernel(Args g) {
     extern __shared__ __attribute__((aligned(16))) float red[];       // [W][NI * NJ][16][64]
     constexpr int NA = NI * NJ;
-    const int bid = blockIdx.x, xcd = bid & 7, bi = bid >> 3;
+    // g.split > 1: K is also cut across blocks (long K over few tiles: the blend-shape adjoint of a one-instance shard);
+    // slice-major block ids, a tile's slices 8 * tiles_m * ceil(tiles_n / 8) blocks apart: the same XCD.
+    const int per_slice = (int)gridDim.x / g.split;
+    const int slice = (int)blockIdx.x / per_slice, bid = (int)blockIdx.x - slice * per_slice, xcd = bid & 7, bi = bid >> 3;
     const int tm = bi % g.tiles_m, tn = (bi / g.tiles_m) * 8 + xcd;
     if (tn >= g.tiles_n) return;
     const long m0 = (long)tm * (32 * NI), n0 = (long)tn * (32 * NJ);
@@ -76,8 +81,10 @@ __global__ __launch_bounds__(64 * W) void gemm_skinny_kernel(Args g) {
     for (int j = 0; j < NJ; ++j) sb[j].init(g.B, g.b_bytes, g.ldb, n0 + 32 * j, lane);
 
     // K slice of this wave, in steps of 8 k; a partial last step is kept out of the pipeline
-    const int nfull = (int)(g.K / 8);
-    const int s_beg = (int)((long)nfull * wid / W), s_end = (int)((long)nfull * (wid + 1) / W);
+    // (g.k_chunk, the K range of a slice, is a multiple of 8)
+    const long kbeg = (long)slice * g.k_chunk, kend = min(g.K, kbeg + g.k_chunk);
+    const int s0 = (int)(kbeg / 8), nfull = (int)(kend / 8) - s0;
+    const int s_beg = s0 + (int)((long)nfull * wid / W), s_end = s0 + (int)((long)nfull * (wid + 1) / W);
     const int rounds = (s_end - s_beg + D - 1) / D;
 
     f32x16 acc[NI][NJ];
@@ -113,9 +120,9 @@ __global__ __launch_bounds__(64 * W) void gemm_skinny_kernel(Args g) {
             request(d, s_beg + (r + 1) * D + d);
         }
     }
-    if (wid == W - 1 && (g.K & 7)) {
+    if (wid == W - 1 && (g.K & 7) && kend == g.K) {
         // the partial last step: k = k0 + 4 h + q >= K contributes nothing
-        const long k0 = 8L * nfull;
+        const long k0 = 8L * (s0 + nfull);
         const int h = lane >> 5;
         float ta[NI][4], tb[NJ][4];
 #pragma unroll
@@ -144,12 +151,49 @@ __global__ __launch_bounds__(64 * W) void gemm_skinny_kernel(Args g) {
     constexpr int RPW = 16 * NA / W;                // accumulator rows per wave
     static_assert(16 * NA % W == 0, "accumulator rows must divide over the waves");
     const int lr = lane & 31, lh = lane >> 5;
+    float part[RPW];
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) {
+        const int ar = wid * RPW + u;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < W; ++w) v += red[((w * NA + ar / 16) * 16 + ar % 16) * 64 + lane];   // wave order: deterministic
+        part[u] = v;
+    }
+    if (g.split > 1) {
+        // publish the slice's tile (write-through), take a ticket; the last arriver sums all slices in slice order
+        const int tile = tn * g.tiles_m + tm;
+        float* slab = g.slabs + ((size_t)tile * g.split + slice) * (size_t)(NA * 1024);
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            float* dst = slab + (wid * RPW + u) * 64 + lane;
+            asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(part[u]) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(red);
+        if (threadIdx.x == 0)
+            *flag = __hip_atomic_fetch_add(g.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != g.split - 1) return;
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(g.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const float* base = g.slabs + (size_t)tile * g.split * (size_t)(NA * 1024);
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) {
+            float v = 0.f;
+            for (int sl = 0; sl < g.split; ++sl)          // fixed order: deterministic
+                v += base[(size_t)sl * (NA * 1024) + (wid * RPW + u) * 64 + lane];
+            part[u] = v;
+        }
+    }
 #pragma unroll
     for (int u = 0; u < RPW; ++u) {
         const int ar = wid * RPW + u, a = ar / 16, r = ar % 16, i = a / NJ, j = a % NJ;
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < W; ++w) v += red[((w * NA + a) * 16 + r) * 64 + lane];      // wave order: deterministic
+        float v = part[u];
         const long n = n0 + 32 * j + lr;
         const long m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (n >= g.N || m >= g.M) continue;
@@ -182,7 +226,8 @@ hipError_t launch(Args g, hipStream_t s) {
     }
     g.tiles_m = (int)((g.M + 32 * NI - 1) / (32 * NI));
     g.tiles_n = (int)((g.N + 32 * NJ - 1) / (32 * NJ));
-    const int blocks = 8 * g.tiles_m * ((g.tiles_n + 7) / 8);
+    if (g.split < 1) g.split = 1;
+    const int blocks = 8 * g.tiles_m * ((g.tiles_n + 7) / 8) * g.split;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), lds, s, g);
     return hipSuccess;
 }

@@ -1047,7 +1047,10 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     if (bid < GA) {
         const int r = bid / G;
         g_lo = bid - r * G; nseg = 1; slot = r;
-        k_beg = (int)(((long)r * CA) / RA); k_end = (int)(((long)(r + 1) * CA) / RA);
+        // CA % RA ranges are one chunk longer; they come FIRST, so that (blocks b and b + 256 sharing a CU) a long range
+        // is never paired with another long one
+        const int q = CA / RA, rem = CA - q * RA;
+        k_beg = r * q + min(r, rem); k_end = k_beg + q + (r < rem ? 1 : 0);
     } else {
         const int j = bid - GA;
         g_lo = (int)(((long)G * j) / nB); nseg = (int)(((long)G * (j + 1)) / nB) - g_lo; slot = RA;
@@ -1703,7 +1706,22 @@ static MeshPlan mesh_plan(long groups, long ntiles) {
     MeshPlan best{G, C, 1, C, 0};
     if (G > 512) return best;                             // one block per group, more than one resident wave
     if (G < 1) return best;
-    double best_cost = 1e30;
+    // ties in the longest block go to the plan whose busiest CU (blocks b and b + 256 land on the same CU: round-robin
+    // placement of one resident wave of blocks) carries least, then to fewer blocks
+    auto busiest_cu = [&](int RA, int CA, int nB, int Lr) {
+        const int q = CA / RA, rem = CA - q * RA, GA = G * RA;
+        auto len = [&](int b) -> double {
+            if (b < GA) return q + (b / G < rem ? 1 : 0);
+            if (b >= GA + nB) return 0;
+            const int j = b - GA;
+            const int nseg = (int)(((long)G * (j + 1)) / nB) - (int)(((long)G * j) / nB);
+            return nseg * (double)Lr + (nseg - 1) * MESH_SEG_OVH;
+        };
+        double m = 0;
+        for (int c = 0; c < 256; ++c) { const double v = len(c) + len(c + 256); if (v > m) m = v; }
+        return m;
+    };
+    double best_cost = 1e30, best_cu = 1e30;
     for (int RA = 1; RA * (long)G <= 512 && RA <= C; ++RA) {
         for (int k = 0; k <= 16; ++k) {                   // k = 0: no left-over blocks
             const int nB = k ? (G + k - 1) / k : 0;
@@ -1713,8 +1731,10 @@ static MeshPlan mesh_plan(long groups, long ntiles) {
                 const int CA = C - Lr;
                 const double ca = (CA + RA - 1) / RA;                             // longest A range
                 const double cb = k ? keff * Lr + (keff - 1) * MESH_SEG_OVH : 0;
-                const double cost = (ca > cb ? ca : cb) + 1e-4 * ((long)G * RA + nB);
-                if (cost < best_cost) { best_cost = cost; best = MeshPlan{G, C, RA, CA, nB}; }
+                const double cost = (ca > cb ? ca : cb);
+                if (cost > best_cost) continue;
+                const double cu = busiest_cu(RA, CA, nB, Lr) + 1e-4 * ((long)G * RA + nB);
+                if (cost < best_cost || cu < best_cu) { best_cost = cost; best_cu = cu; best = MeshPlan{G, C, RA, CA, nB}; }
             }
         }
     }

@@ -474,6 +474,8 @@ class MultiViewModel(nn.Module):
         #        them: their `+=` into dAA are plain read-modify-writes.
         side.wait_event(pose_done)
         side2.wait_event(pose_done)
+        # (Variants measured and dropped, profiles/r02_experiments.md section 5: priors enqueued before the VPoser chain,
+        #  KL + its backward appended to the VPoser chain or to the main chain -- equal or slower un-profiled.)
         enc_done = None
         with torch.cuda.stream(side):
             if use_vposer:

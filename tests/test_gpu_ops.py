@@ -727,6 +727,7 @@ def test_sqmean_instance_regulariser(L, n):
     (1, 0, 147, 1000, 301, 4),
     (1, 0, 1000, 105, 300, 1),       # dW of the first layer (odd ld on both sides)
     (1, 1, 77, 207, 515, 4),
+    (1, 1, 300, 207, 20670, 4),      # blend-shape adjoint of a one-instance shard: K also cut across blocks (16 slices)
 ])
 def test_gemm_skinny_paths(L, ta, tb, M, N, K, pad):
     """Problems the auto plan sends to the intra-block K-split kernel (csrc/gemm_skinny.h): product, fused bias + ReLU,
@@ -752,3 +753,4 @@ def test_gemm_skinny_paths(L, ta, tb, M, N, K, pad):
     H.gemm(dA, dB, ta, tb, split_k=0, mask=H.dev(mask), mask_mode=1, out_mode=1, C=Cw[:, :N])
     assert rel_err(Cw[:, :N], C0[:, :N].double() + torch.where(mask > 0, ref, torch.zeros_like(ref))) < TOL
     assert torch.equal(Cw[:, N:].cpu(), C0[:, N:])
+    assert int(H.gemm_ws()[:4096].view(torch.int32).abs().sum()) == 0        # tickets of the sliced launches back at zero

@@ -41,7 +41,16 @@ static Args make_args(int ta, int tb, long M, long N, long K, const float* A, lo
     return g;
 }
 
-void run_sk(int cfg, int ta, int tb, const Args& g, hipStream_t s) {
+static float* g_ws = nullptr;          // tickets (16 KiB, zero) + slabs
+static int g_split = 1;                // K slices across blocks for run_sk
+
+void run_sk(int cfg, int ta, int tb, const Args& g0, hipStream_t s) {
+    Args g = g0;
+    if (g_split > 1) {
+        long kc = (g.K + g_split - 1) / g_split; kc = (kc + 7) / 8 * 8;
+        g.k_chunk = kc; g.split = (int)((g.K + kc - 1) / kc);
+        g.counters = reinterpret_cast<int*>(g_ws); g.slabs = g_ws + 4096;
+    } else { g.split = 1; g.k_chunk = (g.K + 7) / 8 * 8; }
     const bool akc = !ta, bkc = tb;
     if (akc && bkc) launch_sk<true, true>(cfg, g, s);
     else if (akc && !bkc) launch_sk<true, false>(cfg, g, s);
@@ -69,10 +78,14 @@ struct Prob { int ta, tb; long M, N, K; };
 static float frand() { return (float)(rand() % 2001 - 1000) / 1000.f; }
 
 int check() {
-    const Prob probs[] = {{0, 1, 130, 70, 100}, {0, 1, 64, 64, 32}, {0, 1, 301, 147, 1000}, {0, 0, 301, 105, 1000},
+    const Prob probs_all[] = {{0, 1, 130, 70, 100}, {0, 1, 64, 64, 32}, {0, 1, 301, 147, 1000}, {0, 0, 301, 105, 1000},
                           {0, 0, 257, 200, 147}, {1, 0, 147, 1000, 301}, {1, 0, 200, 105, 333}, {1, 1, 300, 207, 2070},
                           {1, 1, 77, 207, 515}, {0, 1, 513, 512, 63}, {0, 1, 1, 9, 5}, {0, 1, 33, 300, 8}, {1, 0, 40, 40, 7}, {1, 0, 1000, 1000, 12000}};
+    std::vector<Prob> probs(std::begin(probs_all), std::end(probs_all));
+    if (getenv("SK_DEBUG")) probs.assign(1, probs_all[13]);
     int bad = 0;
+    CK(hipMalloc(&g_ws, 64 << 20)); CK(hipMemset(g_ws, 0, 64 << 20));
+    for (int split : {1, 3, 16})
     for (int odd = 0; odd < 3; ++odd)         // 1: rows that are not 16-byte aligned (+1), 2: rows with no pad at all
     for (const Prob& p : probs) {
         long lda = p.ta ? (p.M + 3) / 4 * 4 + 4 : (p.K + 3) / 4 * 4 + 4, ldb = p.tb ? (p.K + 3) / 4 * 4 + 8 : (p.N + 3) / 4 * 4;
@@ -101,8 +114,15 @@ int check() {
         CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dM, hM.data(), hM.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dbias, hbias.data(), p.N * 4, hipMemcpyHostToDevice));
+        g_split = split;
+        if (split > 1 && (p.K < 64 * split || odd == 1)) continue;
+        if (split > 1 && ((p.M + 31) / 32) * ((p.N + 31) / 32) * split * 4096L > (48L << 20)) continue;   // slabs must fit g_ws
+        if (getenv("SK_DEBUG"))
+            printf("A %p..%p B %p..%p C %p..%p M %p ws %p..%p\n", dA, dA + hA.size(), dB, dB + hB.size(), dC, dC + hC.size(), dM, g_ws, g_ws + (16 << 20));
         for (int cfg = odd ? (int)K_1x4u : 0; cfg < NSK; ++cfg)
             for (int variant = 0; variant < 3; ++variant) {
+                if (split > 1 && cfg != K_1x4 && cfg != K_2x8 && cfg != K_1x4u && cfg != K_22x8d3) continue;
+                if (getenv("SK_DEBUG")) { printf("cfg %d variant %d split %d\n", cfg, variant, split); fflush(stdout); }
                 // 0: C = relu(AB + bias)   1: C += AB masked by M > 0   2: C = AB (no bias)
                 CK(hipMemcpy(dC, hC0.data(), hC.size() * 4, hipMemcpyHostToDevice));
                 const Args g = make_args(p.ta, p.tb, p.M, p.N, p.K, dA, lda, dB, ldb, dC, ldc, variant == 0 ? dbias : nullptr,
@@ -126,11 +146,17 @@ int check() {
                 }
                 const bool ok = err <= 2e-5 * scale + 1e-6 && pad_ok;
                 if (!ok) ++bad;
-                printf("%-22s ta=%d tb=%d M=%4ld N=%4ld K=%5ld variant %d  max err %.3g (scale %.3g) %s%s\n", sk_name[cfg], p.ta, p.tb,
+                printf("%-22s s%-2d ta=%d tb=%d M=%4ld N=%4ld K=%5ld variant %d  max err %.3g (scale %.3g) %s%s\n", sk_name[cfg], split, p.ta, p.tb,
                        p.M, p.N, p.K, variant, err, scale, ok ? "ok" : "FAIL", pad_ok ? "" : " (wrote outside C)");
             }
         CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dM)); CK(hipFree(dbias));
     }
+    {   // every ticket is back at zero
+        std::vector<int> t(4096);
+        CK(hipMemcpy(t.data(), g_ws, 4096 * 4, hipMemcpyDeviceToHost));
+        for (int x : t) if (x) { ++bad; printf("ticket left at %d\n", x); break; }
+    }
+    g_split = 1;
     printf(bad ? "CHECK FAILED (%d)\n" : "CHECK OK\n", bad);
     return bad;
 }
@@ -195,6 +221,19 @@ void timeit(long Nb) {
             line += buf;
         }
         printf("%s\n", line.c_str());
+        if (p.K > 4096) {
+            g_ws = ws;
+            for (int cfg : {(int)K_1x8, (int)K_2x8, (int)K_22x8d3}) {
+                line = std::string("   skinny [") + sk_name[cfg] + "] x K slices:";
+                for (int split : {4, 8, 12, 13, 16, 24}) {
+                    g_split = split;
+                    char buf[64]; snprintf(buf, sizeof buf, " s%d=%.1f", split, graph_time([&] { run_sk(cfg, p.ta, p.tb, g, s); }, s));
+                    line += buf;
+                }
+                printf("%s\n", line.c_str());
+            }
+            g_split = 1;
+        }
         CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
     }
 }
