@@ -513,7 +513,7 @@ static int skinny_kind(bool akc, bool bkc, bool aligned, bool can_split, long M,
         //  reduction buffer would keep the other stream's blocks off the CU)
         if (t64 >= 200 && t64 <= 256 && K >= 1024) return 2;
         use = t64 <= 192 && K <= 4096;
-    } else if (akc && !bkc) use = M <= 1536 && t64 <= 320 && K <= 4096;       // input gradients dX = dY W
+    } else if (akc && !bkc) use = ((M <= 1536 && t64 <= 320) || t64 <= 192) && K <= 4096;   // input gradients dX = dY W
     else if (akc && bkc) use = M <= 1024 && t64 <= 192 && K <= 4096;         // forward Y = X W^T
     else {
         // dPF = dVP P^T of a one-instance shard (K = 20 670 over 70 tiles): 58 us with 16 K slices across blocks against

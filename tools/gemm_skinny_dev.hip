@@ -187,7 +187,7 @@ __global__ void touch_kernel(float* p) { if (threadIdx.x == 0) p[blockIdx.x] = 1
 void timeit(long Nb) {
     struct Shape { const char* name; int ta, tb; long M, N, K; };
     const Shape shapes[] = {{"mlp_hidden_fwd", 0, 1, Nb, 1000, 1000}, {"mlp_hidden_dx", 0, 0, Nb, 1000, 1000},
-                            {"mlp_hidden_dw", 1, 0, 1000, 1000, Nb}, {"mlp_in_fwd", 0, 1, Nb, 1000, 105},
+                            {"mlp_hidden_dw", 1, 0, 1000, 1000, Nb}, {"mlp_in_fwd", 0, 1, Nb, 1000, 105}, {"mlp_in_dx", 0, 0, Nb, 105, 1000}, {"mlp_in_dw", 1, 0, 1000, 105, Nb},
                             {"head_fwd", 0, 1, Nb, 147, 1000}, {"head_dx", 0, 0, Nb, 1000, 147}, {"head_dw", 1, 0, 147, 1000, Nb},
                             {"vposer_512", 0, 1, Nb, 512, 512}, {"vposer_512_dx", 0, 0, Nb, 512, 512}, {"vposer_in", 0, 1, Nb, 512, 63},
                             {"vposer_mulv", 0, 1, Nb, 64, 512}, {"vposer_dec_out", 0, 1, Nb, 126, 512},
