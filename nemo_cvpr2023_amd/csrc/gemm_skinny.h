@@ -51,7 +51,7 @@ struct Src {
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                f[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (int)(so + j * ld4), 0));
+                f[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (int)(live ? so + j * ld4 : 0u), 0));
         }
     }
 };
