@@ -241,6 +241,16 @@ def main():
     device = f'cuda:{local_rank % have}'
     torch.cuda.set_device(device)
     ranks_seen = [0]
+    # diagnostic: NEMO_BENCH_SHARD_OF_ONE=1 runs the SHARDED code path (ShardedNemo, the all-reduce, Adam after it, both
+    # shard modes) in a process group of one rank -- what the sharded host / launch structure costs by itself on one GPU
+    sharded = world > 1
+    if world == 1 and os.environ.get('NEMO_BENCH_SHARD_OF_ONE') == '1':
+        sharded = True
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        dist.init_process_group(backend, rank=0, world_size=1)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         # RCCL on ROCm.  (NEMO_DIST_BACKEND=gloo: test aid for boxes where several ranks must share one GPU,
@@ -254,7 +264,7 @@ def main():
     assets = dict(smpl_assets=syn.make_smpl_assets(6890, seed=1), vposer_state=syn.make_vposer_state(),
                   gmm=syn.make_gmm())
     torch.manual_seed(0)
-    if world > 1:
+    if sharded:
         from nemo_cvpr2023_amd.dist import ShardedNemo
         model = ShardedNemo(2, args, seqs, device, rank=rank, world=world, seed=0, **assets)
         engine = model.model.engine
@@ -287,7 +297,7 @@ def main():
     # set-up: the first calls of a (batch size, mode) variant allocate its workspace and capture its HIP graph
     # (like a compile step); they are not part of the warm-up / timed protocol below
     shard_modes = None
-    if world > 1:
+    if sharded:
         modes = ['single', 'split'] if opts.shard_mode == 'auto' else [opts.shard_mode]
         shard_modes = {}
         for mode in modes:
@@ -391,17 +401,18 @@ def main():
             'config': {'workload': f'Baseball-Pitch-shaped fit, {V} instances x {T} frames full batch (N={V * T}), '
                                    'NemoV2 published hyper-parameters, all loss terms, 6890-vertex SMPL',
                        'instances': V, 'frames': T, 'samples_per_step': V * T, 'h_dim': args.h_dim,
-                       'parallelism': f'instance-shard x{world}' if world > 1 else 'single GPU'},
+                       'parallelism': f'instance-shard x{world}' if world > 1 else
+                       ('sharded code path in a process group of ONE rank (diagnostic)' if sharded else 'single GPU')},
             'ranks_seen': ranks_seen,
             'final_total_loss': float(ld['total_loss']),
             'roofline': roof, 'cpu_baseline': cpu, 'torch_gpu_baseline': tgpu,
         }
-        if world > 1:
+        if sharded:
             out['backend'] = dist.get_backend()
             out['shard_modes_ms'] = shard_modes
             out['collectives_per_step'] = 2 if model.shard_mode == 'split' else 1
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

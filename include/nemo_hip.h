@@ -87,8 +87,9 @@ int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t
                              const float* log_sigmas, const float* codes, const float* code_noise,
                              int32_t kernel_id, float* X, int64_t ldx, float* phase_out, void* stream);
 /* dX (N+1, ldx) -> d_shifts,d_scales (V rows of stride ldp), d_log_sigmas (D), d_codes (V,C); all
- * accumulated.  ws: scratch of 4*N floats.  Reductions over the samples are per (view, node) /
- * per column blocks -- no same-address atomic contention. */
+ * accumulated.  One launch: blocks of 32 samples reduce their per-sample coefficients per (view, node) in
+ * LDS and add one partial per run of samples of a view; further blocks reduce the log_sigma / code columns.
+ * ws: unused since round 2 (scratch of the former three-launch version), may be NULL. */
 int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
                              const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
                              const float* shifts, const float* scales, int64_t ldp,

@@ -104,113 +104,6 @@ __global__ __launch_bounds__(256) void phase_embed_fwd_kernel(
     }
 }
 
-// Backward, stage A (one wave per sample): d phase = sum_d dX[s][d] d rbf_d / d phase, then the three
-// coefficients that multiply the per-node sigmoid derivatives of the y / z / o passes.
-// ws[s] = { x, dy/K, dz/K, do/K }.
-__global__ __launch_bounds__(256) void phase_bwd_sample_kernel(
-    long N, long T, int K, int D, const int64_t* __restrict__ view_idx,
-    const int64_t* __restrict__ frame_idx, const float* __restrict__ raw_phase,
-    const float* __restrict__ shifts, const float* __restrict__ scales, long ldp,
-    const float* __restrict__ log_sigmas, int kid, const float* __restrict__ phase,
-    const float* __restrict__ dX, long ldx, float* __restrict__ ws) {
-    const long s = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (s >= N) return;
-    const float ph = phase[s];
-    const float* g = dX + s * ldx;
-    float dph = 0.f;
-    if (D > 0) {
-        for (int d = lane; d < D; d += 64) {
-            const float diff = ph - lin01(d, D);
-            const float es = expf(log_sigmas[d]);
-            dph += g[d] * rbf_dphi(kid, (diff * diff) / es) * 2.f * diff / es;
-        }
-        dph = wave_sum(dph);
-    } else {
-        dph = g[0];
-    }
-    const long v = view_idx[s];
-    const float x = raw_phase ? raw_phase[s] : lin01(frame_idx[s], T);
-    const float* sh = shifts + v * ldp;
-    const float* sc = scales + v * ldp;
-    float y = 0.f, z = 0.f, o = 0.f;
-    for (int k = lane; k < K; k += 64) {
-        const float shp = fmaxf(sh[k], 0.f), scp = fmaxf(sc[k], 0.f);
-        y += sigmoidf_(scp * (x - shp));
-        z += sigmoidf_(scp * (0.f - shp));
-        o += sigmoidf_(scp * (1.f - shp));
-    }
-    y = wave_sum(y) / (float)K; z = wave_sum(z) / (float)K; o = wave_sum(o) / (float)K;
-    const float den = o - z + 1e-6f, num = y - z;
-    const float dy = dph / den;                          // ph = num / den
-    const float dden = -dph * num / (den * den);
-    if (lane == 0) {
-        const float invK = 1.f / (float)K;
-        ws[s * 4 + 0] = x;
-        ws[s * 4 + 1] = dy * invK;
-        ws[s * 4 + 2] = (-dy - dden) * invK;
-        ws[s * 4 + 3] = dden * invK;
-    }
-}
-
-// Stage B: block (view v, sample chunk) -- threads own the nodes k; samples of other views are skipped
-// block-uniformly.  One atomic per (v, k, chunk): no same-address contention.
-__global__ __launch_bounds__(256) void phase_bwd_nodes_kernel(
-    long N, int K, long chunk, const int64_t* __restrict__ view_idx, const float* __restrict__ shifts,
-    const float* __restrict__ scales, long ldp, const float* __restrict__ ws,
-    float* __restrict__ d_shifts, float* __restrict__ d_scales) {
-    const long v = blockIdx.x;
-    const long s0 = (long)blockIdx.y * chunk, s1 = min(N, s0 + chunk);
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        const float shr = shifts[v * ldp + k], scr = scales[v * ldp + k];
-        const float shp = fmaxf(shr, 0.f), scp = fmaxf(scr, 0.f);
-        const float s0v = sigmoidf_(scp * (0.f - shp)), s1v = sigmoidf_(scp * (1.f - shp));
-        const float d0 = s0v * (1.f - s0v), d1 = s1v * (1.f - s1v);
-        float gsh = 0.f, gsc = 0.f;
-        for (long s = s0; s < s1; ++s) {
-            if (view_idx[s] != v) continue;
-            const float x = ws[s * 4], cy = ws[s * 4 + 1], cz = ws[s * 4 + 2], co = ws[s * 4 + 3];
-            const float sx = sigmoidf_(scp * (x - shp));
-            const float wy = cy * sx * (1.f - sx), wz = cz * d0, wo = co * d1;
-            gsc += wy * (x - shp) + wz * (0.f - shp) + wo * (1.f - shp);
-            gsh -= (wy + wz + wo) * scp;
-        }
-        if (shr > 0.f && gsh != 0.f) atomicAdd(d_shifts + v * ldp + k, gsh);   // relu'(0) = 0 as in torch
-        if (scr > 0.f && gsc != 0.f) atomicAdd(d_scales + v * ldp + k, gsc);
-    }
-}
-
-// Stage C: one block per reduced column.  blockIdx.x < D: d log_sigma_d over all N+1 rows;
-// otherwise (c, v): d code[v][c] over the samples of view v.
-__global__ __launch_bounds__(256) void phase_bwd_cols_kernel(
-    long N, long V, int D, int C, const int64_t* __restrict__ view_idx, const float* __restrict__ log_sigmas,
-    int kid, const float* __restrict__ phase, const float* __restrict__ dX, long ldx,
-    float* __restrict__ d_log_sigmas, float* __restrict__ d_codes) {
-    __shared__ float red[16];
-    const int b = blockIdx.x;
-    float acc = 0.f;
-    if (b < D) {
-        const int d = b;
-        const float es = expf(log_sigmas[d]), c = lin01(d, D);
-        for (long s = threadIdx.x; s <= N; s += blockDim.x) {
-            const float diff = (s < N ? phase[s] : 0.f) - c;
-            const float a = (diff * diff) / es;
-            acc -= dX[s * ldx + d] * rbf_dphi(kid, a) * a;      // d a / d log_sigma = -a
-        }
-        const float t = block_sum(acc, red);
-        if (threadIdx.x == 0 && d_log_sigmas) d_log_sigmas[d] += t;
-    } else {
-        const int idx = b - D;
-        const int c = idx % C;
-        const long v = idx / C;
-        const int off = D > 0 ? D : 1;
-        for (long s = threadIdx.x; s < N; s += blockDim.x)
-            if (view_idx[s] == v) acc += dX[s * ldx + off + c];
-        const float t = block_sum(acc, red);
-        if (threadIdx.x == 0) d_codes[v * C + c] += t;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rot6d_fwd_kernel(long total, int J, const float* __restrict__ rot6d,
                                                         long ld6, int zero_nan, float* __restrict__ R,
@@ -438,6 +331,124 @@ extern "C" int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t
     return NEMO_OK;
 }
 
+// The whole phase / RBF / code backward in ONE launch (it sits at the end of the dX chain of every update step, and three
+// dependent launches of 4 - 12 us each were 24 us of it).  Blocks [0, nAB): stage A + B for PH_SPB consecutive samples --
+// the per-sample coefficients of stage A stay in LDS and the block reduces them per (view, node) itself: thread groups
+// of Kp >= K lanes take every (256 / Kp)-th sample, a run of samples of one view is flushed with one atomic per
+// (view, node, group).  Blocks [nAB, ...): stage C (independent of A and B: column sums of dX).
+namespace {
+constexpr int PH_SPB = 32;
+__global__ __launch_bounds__(256) void phase_bwd_fused_kernel(
+    long N, long V, long T, int K, int D, int C, const int64_t* __restrict__ view_idx,
+    const int64_t* __restrict__ frame_idx, const float* __restrict__ raw_phase, const float* __restrict__ shifts,
+    const float* __restrict__ scales, long ldp, const float* __restrict__ log_sigmas, int kid,
+    const float* __restrict__ phase, const float* __restrict__ dX, long ldx, float* __restrict__ d_shifts,
+    float* __restrict__ d_scales, float* __restrict__ d_log_sigmas, float* __restrict__ d_codes, int nAB) {
+    __shared__ float red[16];
+    __shared__ float cx[PH_SPB], cy[PH_SPB], cz[PH_SPB], co[PH_SPB];
+    __shared__ long cv[PH_SPB];
+    if ((int)blockIdx.x >= nAB) {
+        // ---- stage C: one block per reduced column.  b < D: d log_sigma_d over all N + 1 rows; otherwise (c, v):
+        // d code[v][c] over the samples of view v
+        const int b = (int)blockIdx.x - nAB;
+        float acc = 0.f;
+        if (b < D) {
+            if (!d_log_sigmas) return;
+            const int d = b;
+            const float es = expf(log_sigmas[d]), c = lin01(d, D);
+            for (long s = threadIdx.x; s <= N; s += blockDim.x) {
+                const float diff = (s < N ? phase[s] : 0.f) - c;
+                const float a = (diff * diff) / es;
+                acc -= dX[s * ldx + d] * rbf_dphi(kid, a) * a;      // d a / d log_sigma = -a
+            }
+            const float t = block_sum(acc, red);
+            if (threadIdx.x == 0) d_log_sigmas[d] += t;
+        } else {
+            const int idx = b - D;
+            const int c = idx % C;
+            const long v = idx / C;
+            const int off = D > 0 ? D : 1;
+            for (long s = threadIdx.x; s < N; s += blockDim.x)
+                if (view_idx[s] == v) acc += dX[s * ldx + off + c];
+            const float t = block_sum(acc, red);
+            if (threadIdx.x == 0) d_codes[v * C + c] += t;
+        }
+        return;
+    }
+    // ---- stage A: a wave per sample -- d phase, then the coefficients of the three sigmoid sums of the phase network
+    const long s0 = (long)blockIdx.x * PH_SPB;
+    const int ns = (int)min((long)PH_SPB, N - s0);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int i = wid; i < ns; i += 4) {
+        const long s = s0 + i;
+        const float ph = phase[s];
+        const float* g = dX + s * ldx;
+        float dph = 0.f;
+        if (D > 0) {
+            for (int d = lane; d < D; d += 64) {
+                const float diff = ph - lin01(d, D);
+                const float es = expf(log_sigmas[d]);
+                dph += g[d] * rbf_dphi(kid, (diff * diff) / es) * 2.f * diff / es;
+            }
+            dph = wave_sum(dph);
+        } else {
+            dph = g[0];
+        }
+        const long v = view_idx[s];
+        const float x = raw_phase ? raw_phase[s] : lin01(frame_idx[s], T);
+        const float* sh = shifts + v * ldp;
+        const float* sc = scales + v * ldp;
+        float y = 0.f, z = 0.f, o = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float shp = fmaxf(sh[k], 0.f), scp = fmaxf(sc[k], 0.f);
+            y += sigmoidf_(scp * (x - shp));
+            z += sigmoidf_(scp * (0.f - shp));
+            o += sigmoidf_(scp * (1.f - shp));
+        }
+        y = wave_sum(y) / (float)K; z = wave_sum(z) / (float)K; o = wave_sum(o) / (float)K;
+        const float den = o - z + 1e-6f, num = y - z;
+        const float dy = dph / den;                          // ph = num / den
+        const float dden = -dph * num / (den * den);
+        if (lane == 0) {
+            const float invK = 1.f / (float)K;
+            cx[i] = x; cy[i] = dy * invK; cz[i] = (-dy - dden) * invK; co[i] = dden * invK; cv[i] = v;
+        }
+    }
+    __syncthreads();
+    // ---- stage B: lanes own the nodes; relu'(0) = 0 as in torch
+    int Kp = 16;
+    while (Kp < K && Kp < 256) Kp <<= 1;
+    const int ngrp = 256 / Kp, grp = threadIdx.x / Kp;
+    for (int k = threadIdx.x % Kp; k < K; k += Kp) {
+        long cur = -1;
+        float shr = 0.f, scr = 0.f, shp = 0.f, scp = 0.f, d0 = 0.f, d1 = 0.f, gsh = 0.f, gsc = 0.f;
+        for (int i = grp; i < ns; i += ngrp) {
+            const long v = cv[i];
+            if (v != cur) {
+                if (cur >= 0) {
+                    if (shr > 0.f && gsh != 0.f) atomicAdd(d_shifts + cur * ldp + k, gsh);
+                    if (scr > 0.f && gsc != 0.f) atomicAdd(d_scales + cur * ldp + k, gsc);
+                }
+                cur = v; gsh = 0.f; gsc = 0.f;
+                shr = shifts[v * ldp + k]; scr = scales[v * ldp + k];
+                shp = fmaxf(shr, 0.f); scp = fmaxf(scr, 0.f);
+                const float s0v = sigmoidf_(scp * (0.f - shp)), s1v = sigmoidf_(scp * (1.f - shp));
+                d0 = s0v * (1.f - s0v); d1 = s1v * (1.f - s1v);
+            }
+            const float x = cx[i];
+            const float sx = sigmoidf_(scp * (x - shp));
+            const float wy = cy[i] * sx * (1.f - sx), wz = cz[i] * d0, wo = co[i] * d1;
+            gsc += wy * (x - shp) + wz * (0.f - shp) + wo * (1.f - shp);
+            gsh -= (wy + wz + wo) * scp;
+        }
+        if (cur >= 0) {
+            if (shr > 0.f && gsh != 0.f) atomicAdd(d_shifts + cur * ldp + k, gsh);
+            if (scr > 0.f && gsc != 0.f) atomicAdd(d_scales + cur * ldp + k, gsc);
+        }
+    }
+}
+}  // namespace
+
 extern "C" int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
                                         const int64_t* view_idx, const int64_t* frame_idx,
                                         const float* raw_phase, const float* shifts, const float* scales,
@@ -447,30 +458,17 @@ extern "C" int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t
                                         float* d_codes, void* stream) {
     if (N < 0 || V <= 0 || K <= 0 || D < 0 || C < 0 || !dX || !shifts || !scales || !phase) return NEMO_EINVAL;
     if ((d_shifts == nullptr) != (d_scales == nullptr)) return NEMO_EINVAL;
-    if (d_shifts && N > 0 && !ws) return NEMO_EINVAL;
+    (void)ws;                           // (scratch of the former three-launch version; may be NULL)
     hipStream_t st = (hipStream_t)stream;
-    if (d_shifts && N > 0) {
-        hipLaunchKernelGGL(phase_bwd_sample_kernel, dim3(nemo_cdiv(N, 4)), dim3(256), 0, st, (long)N, (long)T,
-                           (int)K, (int)D, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp,
-                           log_sigmas, (int)kernel_id, phase, dX, (long)ldx, ws);
-        NEMO_LAUNCH_CHECK();
-        // ~2 blocks per CU: V * ceil(N / chunk) blocks, each atomic address touched once per chunk
-        long chunk = (N * V + 511) / 512;
-        if (chunk < 32) chunk = 32;
-        if (chunk > 512) chunk = 512;
-        hipLaunchKernelGGL(phase_bwd_nodes_kernel, dim3((unsigned)V, nemo_cdiv(N, chunk)), dim3(256), 0, st,
-                           (long)N, (int)K, chunk, view_idx, shifts, scales, (long)ldp, ws, d_shifts, d_scales);
-        NEMO_LAUNCH_CHECK();
-    }
-    const long nblk = (d_log_sigmas ? D : 0) + (d_codes ? V * C : 0);
-    if (nblk > 0) {
-        // blocks [0, D) reduce log_sigma columns; if d_log_sigmas is NULL they are still launched as
-        // no-ops so that the block -> column map stays fixed
-        hipLaunchKernelGGL(phase_bwd_cols_kernel, dim3((unsigned)(D + (d_codes ? V * C : 0))), dim3(256), 0, st,
-                           (long)N, (long)V, (int)D, (int)C, view_idx, log_sigmas, (int)kernel_id, phase, dX,
-                           (long)ldx, d_log_sigmas, d_codes);
-        NEMO_LAUNCH_CHECK();
-    }
+    const long nAB = (d_shifts && N > 0) ? nemo_cdiv(N, PH_SPB) : 0;
+    // blocks [nAB, nAB + D) reduce log_sigma columns; if d_log_sigmas is NULL they are still launched (as no-ops) so
+    // that the block -> column map stays fixed
+    const long nC = (d_log_sigmas || d_codes) ? D + (d_codes ? V * C : 0) : 0;
+    if (nAB + nC == 0) return NEMO_OK;
+    hipLaunchKernelGGL(phase_bwd_fused_kernel, dim3((unsigned)(nAB + nC)), dim3(256), 0, st, (long)N, (long)V, (long)T,
+                       (int)K, (int)D, (int)C, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp, log_sigmas,
+                       (int)kernel_id, phase, dX, (long)ldx, d_shifts, d_scales, d_log_sigmas, d_codes, (int)nAB);
+    NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
 

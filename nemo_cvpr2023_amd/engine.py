@@ -561,7 +561,7 @@ class FitEngine:
         check(self.lib.nemo_kl_fwd_bwd(N, 32, dptr(w['MULV']), 64, self.scal.data_ptr() + 4 * S_KL,
                                        dptr(w['dMULV']), 64, _stream()), 'nemo_kl_fwd_bwd')
 
-    def forward_v2v(self, w, N, need_grad):
+    def forward_v2v(self, w, N, need_grad, after_loss=None):
         """K10 + K11: the two full-mesh bodies, L1 sum and (same pass) its gradient wrt the pose.
         One fused MFMA kernel per chunk (pose blend + skinning + L1 + gradient, nothing of the
         blended mesh goes to HBM); the blend-shape adjoint is one GEMM on the transposed dVP."""
@@ -583,6 +583,8 @@ class FitEngine:
                         self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPt']), ldn, dptr(w['dA2']),
                         ws.data_ptr(), ws.numel() * 4, st), 'nemo_v2v_fused')
             self._event_end(ev)
+            if after_loss is not None and c0 + Nc >= N:
+                after_loss()        # the L1 sum is final once the last chunk's mesh kernel has run
             if need_grad:
                 if c0 > 0:
                     w['dPF2'].zero_()

@@ -504,15 +504,27 @@ class MultiViewModel(nn.Module):
         main.wait_stream(side2)
         # the fused mesh kernel is sized to fill the machine in exactly one resident wave of blocks:
         # it runs alone (anything co-scheduled pushes part of its grid into a second wave, +60 %)
-        if use_vposer:
-            e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss))
         if extra_losses is not None:
             extra_losses()
-        if publish:      # every loss scalar is final here: hand them to the host, the backward goes on
+        # Every loss scalar is final once the mesh kernel has run: hand them to the host from there (nemo_publish_scalars)
+        # while the backward goes on.  When the whole backward follows in this launch, the hand-over leaves the main
+        # chain: a branch on side2 that forks right behind the mesh kernel -- before the blend-shape adjoint -- and is
+        # enqueued LAST (a replayed graph keeps the first-enqueued successor on the queue, see above), joined before Adam.
+        loss_final = []
+        pub_aside = bool(publish and update and part == 'all' and use_vposer and e.overlap_bwd)
+        if use_vposer:
+            e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss),
+                          after_loss=(lambda: loss_final.append(main.record_event())) if pub_aside else None)
+        if publish and not pub_aside:
             e.publish_scalars()
         if not update or part == 'head':
             return
         self._backward_tail(w, N, vi, fi, update, use_vposer, sh)
+        if pub_aside:
+            side2.wait_event(loss_final[0])
+            with torch.cuda.stream(side2):
+                e.publish_scalars()
+            main.wait_stream(side2)
 
     def _backward_tail(self, w, N, vi, fi, update, use_vposer, sh):
         e, a = self.engine, self.args

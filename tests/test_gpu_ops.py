@@ -754,3 +754,31 @@ def test_gemm_skinny_paths(L, ta, tb, M, N, K, pad):
     assert rel_err(Cw[:, :N], C0[:, :N].double() + torch.where(mask > 0, ref, torch.zeros_like(ref))) < TOL
     assert torch.equal(Cw[:, N:].cpu(), C0[:, N:])
     assert int(H.gemm_ws()[:4096].view(torch.int32).abs().sum()) == 0        # tickets of the sliced launches back at zero
+
+
+def test_gemm_auto_plan_random_shapes(L):
+    """split_k = 0 over random problems on both sides of every kernel-selection threshold (skinny 32x32 / 32x64 /
+    64x64 / sliced, LDS-DMA tiles, first-generation kernel for unaligned rows): product, bias + ReLU, determinism."""
+    H = _ops()
+    rng = np.random.default_rng(20230)
+    dims_m = [1, 30, 31, 300, 301, 512, 600, 1024, 1100, 1537, 2400]
+    dims_n = [3, 64, 105, 147, 207, 512, 1000]
+    dims_k = [5, 63, 105, 207, 300, 512, 1000, 2401]
+    for case in range(40):
+        ta, tb = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        M, N, K = int(rng.choice(dims_m)), int(rng.choice(dims_n)), int(rng.choice(dims_k))
+        if M * N * K > 1.3e9:
+            K = 300
+        pad_a, pad_b = int(rng.choice([0, 1, 4])), int(rng.choice([0, 3, 4]))
+        g = torch.Generator().manual_seed(1000 + case)
+        Af = torch.randn((K if ta else M), (M if ta else K) + pad_a, generator=g)
+        Bf = torch.randn((N if tb else K), (K if tb else N) + pad_b, generator=g)
+        A, B = Af[:, :(M if ta else K)], Bf[:, :(K if tb else N)]
+        bias = torch.randn(N, generator=g)
+        ref = torch.relu((A.T if ta else A).double() @ (B.T if tb else B).double() + bias.double())
+        dA, dB = H.dev(Af)[:, :A.shape[1]], H.dev(Bf)[:, :B.shape[1]]
+        C1 = H.gemm(dA, dB, ta, tb, split_k=0, bias=H.dev(bias), act=1)
+        assert rel_err(C1, ref) < TOL, (case, ta, tb, M, N, K, pad_a, pad_b)
+        C2 = H.gemm(dA, dB, ta, tb, split_k=0, bias=H.dev(bias), act=1)
+        assert torch.equal(C1, C2), (case, ta, tb, M, N, K)
+    assert int(H.gemm_ws()[:4096].view(torch.int32).abs().sum()) == 0
