@@ -186,7 +186,8 @@ int32_t nemo_kp_finalize(int64_t V, int64_t n_out, int32_t W, int32_t mean_mode,
 /* upstream = d total / d kp_loss.  Outputs: dA (N,24,12) and dMq (N,ldq) overwritten; dJp (N,24,3)
  * accumulated (caller zeroes it); dTR (N, lddt) rows overwritten (row N, the trans_0 gradient, is
  * -sum of the rows: nemo_scale_neg_rowsum); d_cams (V,9) accumulated.  dA==NULL skips the body
- * gradients (camera-only fitting, :2869-2906). */
+ * gradients (camera-only fitting, :2869-2906).  norm==NULL: the normaliser is derived from view_acc
+ * inside the launch (nemo_kp_finalize then only produces the loss scalar and can run concurrently). */
 int32_t nemo_kp_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A, const float* Jp,
                     const float* Mq, int64_t ldq, const float* TR, int64_t ldt, int32_t add_trans,
                     const int64_t* view_idx, const int64_t* frame_idx, const float* cams,

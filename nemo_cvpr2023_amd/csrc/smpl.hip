@@ -680,6 +680,24 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
     const bool active = live && o < kc.n_out;
     __shared__ float Al[256 / LANES][288];
     kp_stage_A<LANES>(a, Al);
+    // norm == NULL: the normaliser nemo_kp_finalize would write (number of views present / total confidence count) is
+    // derived here from the per-view accumulators, so that kp_finalize is off the dependency chain of the step
+    float nrm;
+    if (norm) {
+        nrm = norm[0];
+    } else {
+        __shared__ float nred[4];
+        float part = 0.f;
+        for (long vv = threadIdx.x; vv < a.V; vv += 256) {
+            const float c = view_acc[vv * 2 + 1];
+            part += a.mean_mode == 0 ? (c > 0.f ? 1.f : 0.f) : c;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if ((threadIdx.x & 63) == 0) nred[threadIdx.x >> 6] = part;
+        __syncthreads();
+        nrm = nred[0] + nred[1] + nred[2] + nred[3];
+    }
     long v = 0;
     if (live) v = a.view_idx[s];
     float dpos[3] = {0.f, 0.f, 0.f};
@@ -709,8 +727,8 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
         const int W = loss_width(a.loss_type);
         // d total / d loss_all element
         float coef;
-        if (a.mean_mode == 0) coef = upstream * g[2] / (norm[0] * view_acc[v * 2 + 1] * (float)(kc.n_out * W));
-        else coef = upstream / (norm[0] * (float)(kc.n_out * W));
+        if (a.mean_mode == 0) coef = upstream * g[2] / (nrm * view_acc[v * 2 + 1] * (float)(kc.n_out * W));
+        else coef = upstream / (nrm * (float)(kc.n_out * W));
         du *= coef; dv *= coef;
         // u = f*px/pz + cx*(pz/pz)
         const float dpx = du * a.focal / pz, dpy = dv * a.focal / pz;
@@ -1593,7 +1611,7 @@ static int32_t kp_bwd_impl(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T,
     const int rc = kp_args(ctx, a, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams,
                            targets, gt_size, focal, cx, cy, loss_type, mean_mode);
     if (rc) return rc;
-    if (!targets || !view_acc || !norm) return NEMO_EINVAL;
+    if (!targets || !view_acc) return NEMO_EINVAL;            // (norm may be NULL: derived from view_acc)
     if (dA && (!dJp || (ctx->nq > 0 && !dMq))) return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
     if (ctx->n_out > 32) return NEMO_EINVAL;

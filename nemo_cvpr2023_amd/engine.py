@@ -503,8 +503,9 @@ class FitEngine:
             self.g('phase_networks.0.scales'), None, None, _stream()), 'nemo_phase_embed_bwd')
 
     def forward_joints(self, w, N, view_idx, frame_idx, with_loss, mean_mode=0, add_trans=True, ctx=None,
-                       j3d=None, p2d=None):
-        """K6-K8: FK, mesh-functional joints, projection, 2-D loss accumulators."""
+                       j3d=None, p2d=None, finalize=True):
+        """K6-K8: FK, mesh-functional joints, projection, 2-D loss accumulators.  ``finalize=False``: the caller runs
+        ``finalize_kp`` itself (off the main chain: ``backward_kp(norm_from_acc=True)`` does not need its output)."""
         L, st = self.lib, _stream()
         ctx = ctx or self.ctx
         self.sync_betas(ctx)
@@ -525,11 +526,16 @@ class FitEngine:
             dptr(j3d if j3d is not None else w['j3d']), dptr(p2d if p2d is not None else w['p2d']),
             dptr(w['loss_all']) if with_loss else None, dptr(w['view_acc']) if with_loss else None, st),
             'nemo_kp_fwd')
-        if with_loss:
-            Wd = 1 if lt in (2, 3, 5) else 2
-            check(L.nemo_kp_finalize(self.V, ctx.n_out, Wd, mean_mode, dptr(w['view_acc']),
-                                     self.scal.data_ptr() + 4 * S_KP, dptr(w['norm']), st), 'nemo_kp_finalize')
+        if with_loss and finalize:
+            self.finalize_kp(w, mean_mode, ctx)
         return Mq
+
+    def finalize_kp(self, w, mean_mode=0, ctx=None):
+        """Per-view accumulators -> the keypoint loss scalar (+ the normaliser, for callers of nemo_kp_bwd that pass it)."""
+        ctx = ctx or self.ctx
+        Wd = 1 if LOSS_TYPES[self.args.loss] in (2, 3, 5) else 2
+        check(self.lib.nemo_kp_finalize(self.V, ctx.n_out, Wd, mean_mode, dptr(w['view_acc']),
+                                        self.scal.data_ptr() + 4 * S_KP, dptr(w['norm']), _stream()), 'nemo_kp_finalize')
 
     def sync_betas(self, ctx=None):
         """Host-side: push ``learned_betas`` into the SMPL context when the tensor has been written since the
@@ -595,7 +601,7 @@ class FitEngine:
 
     # ------------------------------------------------------------------ backward pieces
     def backward_kp(self, w, N, view_idx, frame_idx, Mq, mean_mode, upstream, cams_only=False,
-                    detach_pose=False, dj3d_extra=None):
+                    detach_pose=False, dj3d_extra=None, norm_from_acc=False):
         L, st, ctx = self.lib, _stream(), self.ctx
         nq72 = max(ctx.nq * 72, 1)
         lt = LOSS_TYPES[self.args.loss]
@@ -604,7 +610,7 @@ class FitEngine:
             ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), nq72, dptr(w['TR']),
             HEAD_LD, add_trans, dptr(view_idx), dptr(frame_idx), self.p('learned_cameras'), dptr(self.targets),
             dptr(self.gt_size), FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode, dptr(w['view_acc']),
-            dptr(w['norm']), upstream, None if cams_only else dptr(w['dA']),
+            None if norm_from_acc else dptr(w['norm']), upstream, None if cams_only else dptr(w['dA']),
             None if cams_only else dptr(w['dJp']), None if cams_only else dptr(w['dMq']),
             None if cams_only else dptr(w['dTR']), HEAD_LD, self.g('learned_cameras'), dptr(dj3d_extra), st),
             'nemo_kp_bwd_ex')

@@ -455,7 +455,8 @@ class MultiViewModel(nn.Module):
         # The main-stream branch (the longest of the three) is ENQUEUED FIRST: a replayed HIP graph keeps a node's first
         # successor on the hardware queue of the node and starts the others on further queues behind a cross-queue
         # barrier that costs 15 - 30 us (profiles/r02_kernel_trace_v1.md) -- that delay has to land on the short branches.
-        Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0)
+        Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0, finalize=False)
+        kp_done = main.record_event()        # (view accumulators complete: the loss scalar is finalised on side2, below)
         # optional temporal smoothness of the output joints (not part of the published step; only defined on
         # complete (view, frame) sequences, i.e. full-batch steps -- see DESIGN.md section 8, row f-4)
         dj = None
@@ -467,7 +468,7 @@ class MultiViewModel(nn.Module):
             dj = w['dj3d'] if update else None
         if update:
             e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose,
-                          dj3d_extra=dj)
+                          dj3d_extra=dj, norm_from_acc=True)
         # side : VPoser encode -> decode -> axis-angle (the mesh term waits for it)
         # side2: everything that accumulates into dAA -- GMM prior, 3-D pose term (they only need the pose), then, once
         #        the encoder output exists, KL and its backward through the frozen encoder.  One stream for all of
@@ -500,6 +501,8 @@ class MultiViewModel(nn.Module):
                 e.vposer_kl(w, N)
                 if update and a.weight_vp_z_loss:
                     e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
+            side2.wait_event(kp_done)
+            e.finalize_kp(w, mean_mode=0)
         main.wait_stream(side)
         main.wait_stream(side2)
         # the fused mesh kernel is sized to fill the machine in exactly one resident wave of blocks:
