@@ -289,40 +289,34 @@ __global__ __launch_bounds__(256) void fk_fwd_kernel(long rows, const float* __r
             if (bdy < nb) PF[(row0 + bdy) * ldpf + k] = Rl[bdy * FK_RS + 9 + k] - ((k % 9) % 4 == 0 ? 1.f : 0.f);
         }
     }
-    // ---- phase 2: one thread per body walks the chain
-    if (tid < nb) {
-        const int lane = tid;
-        const float* Rr = Rl + lane * FK_RS;
-#define GL(j, e) G[((j) * 12 + (e)) * FK_GS + lane]
-        for (int i = 0; i < 24; ++i) {
-            float Ri[9], Gi[9], gt[3];
+    // ---- phase 2: the chain, 16 lanes per body (12 active: one per element of [G_R | G_t]); a body's lanes sit in one
+    // wave, so a joint's elements are visible to the next joint's reads by LDS program order alone -- no block barrier
+    // inside the chain.  (One thread per body spent ~550 cycles per joint on 21 dependent LDS reads and 12 writes:
+    // 5.6 of the kernel's 10.4 us; tools/bench_fk_graph.py.)
+    static_assert(FK_TB * 16 == 256, "16 lanes per body");
+    {
+        const int bdy = tid >> 4, e = tid & 15;
+        if (bdy < nb && e < 12) {
+            const float* Rr = Rl + bdy * FK_RS;
+            const int r = e < 9 ? e / 3 : e - 9, c = e % 3;
+#define GL(j, k) G[((j) * 12 + (k)) * FK_GS + bdy]
+            GL(0, e) = e < 9 ? Rr[e] : Js[e - 9];
+            // (fully unrolled: the parent ids, rest offsets and the lane's column of every R_i are loaded ahead of the
+            //  chain -- only the parent's row read, three FMAs and the write remain dependent)
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
-            const float ji[3] = {Js[i * 3], Js[i * 3 + 1], Js[i * 3 + 2]};
-            if (i == 0) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) Gi[k] = Ri[k];
-                gt[0] = ji[0]; gt[1] = ji[1]; gt[2] = ji[2];
-            } else {
+            for (int i = 1; i < 24; ++i) {
                 const int p = Ps[i];
-                float Gp[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) Gp[k] = GL(p, k);
-                const float rel[3] = {ji[0] - Js[p * 3], ji[1] - Js[p * 3 + 1], ji[2] - Js[p * 3 + 2]};
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        Gi[r * 3 + c] = Gp[r * 3] * Ri[c] + Gp[r * 3 + 1] * Ri[3 + c] + Gp[r * 3 + 2] * Ri[6 + c];
-                    gt[r] = Gp[r * 3] * rel[0] + Gp[r * 3 + 1] * rel[1] + Gp[r * 3 + 2] * rel[2] + GL(p, 9 + r);
-                }
+                const float g0 = GL(p, r * 3), g1 = GL(p, r * 3 + 1), g2 = GL(p, r * 3 + 2);
+                float val;
+                if (e < 9) val = g0 * Rr[i * 9 + c] + g1 * Rr[i * 9 + 3 + c] + g2 * Rr[i * 9 + 6 + c];
+                else val = g0 * (Js[i * 3] - Js[p * 3]) + g1 * (Js[i * 3 + 1] - Js[p * 3 + 1]) +
+                           g2 * (Js[i * 3 + 2] - Js[p * 3 + 2]) + GL(p, 9 + r);
+                GL(i, e) = val;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
-#pragma unroll
-            for (int k = 0; k < 9; ++k) GL(i, k) = Gi[k];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) GL(i, 9 + r) = gt[r];
-        }
 #undef GL
+        }
     }
     __syncthreads();
     // ---- phase 3: coalesced float4 write-out.  A[j] row r = [G_R[r] | G_t[r] - G_R[r].J_j] (lbs.py:399-402)
@@ -396,66 +390,53 @@ __global__ __launch_bounds__(256) void fk_bwd_kernel(long rows, const float* __r
         }
     }
     __syncthreads();
-    // ---- phase 2: reverse sweep, one thread per body
-    if (tid < nb) {
-        const int lane = tid;
-        float* Rr = Rl + lane * FK_RS;
-        const float* Ar = A + (row0 + lane) * 288;
-#define DL(j, e) D[((j) * 12 + (e)) * FK_GS + lane]
-        // parent transforms come from global memory but do not depend on the sweep: keep the loads of
-        // the next two iterations in flight (register ring indexed by i & 1; the loop is fully unrolled)
-        float Gq[2][9];
+    // ---- phase 2: reverse sweep, 16 lanes per body (one wave holds a body's lanes: LDS program order instead of
+    // barriers, as in fk_fwd).  Lane e < 9 = element (r, c): dR_i[r][c] = sum_k Gp[k][r] dG_i[k][c] and the parent's
+    // dG_R[p][r][c] += sum_k dG_i[r][k] Ri[c][k] + dgt_i[r] rel_i[c]; lanes 9..11: dG_t[p][r] += dgt_i[r].
+    {
+        const int bdy = tid >> 4, e = tid & 15;
+        if (bdy < nb && e < 12) {
+            float* Rr = Rl + bdy * FK_RS;
+            const float* Ar = A + (row0 + bdy) * 288;
+            const int r = e < 9 ? e / 3 : e - 9, c = e % 3;
+#define DL(j, k) D[((j) * 12 + (k)) * FK_GS + bdy]
+            // column r of the parent's rotation comes from global memory but does not depend on the sweep: the loads
+            // of the next two joints stay in flight (register ring indexed by i & 1; the loop is fully unrolled)
+            float Gq[2][3];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int pi = Ps[23 - u];
+            for (int u = 0; u < 2; ++u) {
+                const int pi = Ps[23 - u];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) Gq[(23 - u) & 1][r * 3 + c] = Ar[pi * 12 + r * 4 + c];
-        }
-#pragma unroll
-        for (int i = 23; i >= 1; --i) {
-            const int p = Ps[i];
-            float Gp[9], Ri[9], dG[9], dgt[3];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Gp[k] = Gq[i & 1][k];
-            if (i >= 3) {
-                const int pn = Ps[i - 2];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) Gq[i & 1][r * 3 + c] = Ar[pn * 12 + r * 4 + c];
+                for (int k = 0; k < 3; ++k) Gq[(23 - u) & 1][k] = Ar[pi * 12 + k * 4 + r];
             }
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int i = 23; i >= 1; --i) {
+                const int p = Ps[i];
+                float Gp[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) dG[r * 3 + c] = DL(i, r * 4 + c);
-                dgt[r] = DL(i, r * 4 + 3);
+                for (int k = 0; k < 3; ++k) Gp[k] = Gq[i & 1][k];
+                if (i >= 3) {
+                    const int pn = Ps[i - 2];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) Gq[i & 1][k] = Ar[pn * 12 + k * 4 + r];
+                }
+                const float dgt = DL(i, r * 4 + 3);
+                if (e < 9) {
+                    const float dr = Gp[0] * DL(i, c) + Gp[1] * DL(i, 4 + c) + Gp[2] * DL(i, 8 + c);
+                    const float up = DL(i, r * 4) * Rr[i * 9 + c * 3] + DL(i, r * 4 + 1) * Rr[i * 9 + c * 3 + 1] +
+                                     DL(i, r * 4 + 2) * Rr[i * 9 + c * 3 + 2] + dgt * (Js[i * 3 + c] - Js[p * 3 + c]);
+                    // (every lane of the body has read R_i by now -- lockstep -- so dR_i can take its place)
+                    Rr[i * 9 + r * 3 + c] = dr;
+                    DL(p, r * 4 + c) += up;
+                } else {
+                    DL(p, r * 4 + 3) += dgt;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Ri[k] = Rr[i * 9 + k];
-            const float rel[3] = {Js[i * 3] - Js[p * 3], Js[i * 3 + 1] - Js[p * 3 + 1], Js[i * 3 + 2] - Js[p * 3 + 2]};
-            // dR_i = Gp^T dG_i   (stored in place of R_i, which is not needed again)
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    Rr[i * 9 + r * 3 + c] = Gp[r] * dG[c] + Gp[3 + r] * dG[3 + c] + Gp[6 + r] * dG[6 + c];
-            // dG_R[p] += dG_i Ri^T + dgt (x) rel ;  dG_t[p] += dgt
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    DL(p, r * 4 + c) += dG[r * 3] * Ri[c * 3] + dG[r * 3 + 1] * Ri[c * 3 + 1] +
-                                        dG[r * 3 + 2] * Ri[c * 3 + 2] + dgt[r] * rel[c];
-                DL(p, r * 4 + 3) += dgt[r];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) Rr[r * 3 + c] = DL(0, r * 4 + c);
+            if (e < 9) Rr[r * 3 + c] = DL(0, r * 4 + c);
 #undef DL
+        }
     }
     __syncthreads();
     // ---- phase 3: coalesced write-out (+ the pose-feature gradient of joints 1..23)
