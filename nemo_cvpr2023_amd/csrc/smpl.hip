@@ -1399,39 +1399,41 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     __syncthreads();
     const bool finish = nr == 1 || ticket_old == nr - 1;      // block-uniform
     if (nr > 1 && finish) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (the partials are read with device-scope loads -- served by the memory side, never by a stale line of this XCD's
+        //  L2 -- instead of behind an acquire fence: `buffer_inv sc1` walks the whole L2)
         if (tid == 0) __hip_atomic_store(tickets + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float* base = parts + (size_t)grp * maxc * (96 * 64) + lane;
+        // Wave w owns image rows [24 w, 24 w + 24) of EVERY partial (complete sums, no cross-wave pass afterwards) and
+        // keeps eight partials -- 192 coalesced loads -- in flight: three memory round trips for the 24 partials of a
+        // one-instance shard, where a wave summing whole partials one after the other took six (+27 us on the
+        // launch's tail, tools/mesh_timeline.py).  Partials are added in range order: deterministic.
+        const float* base = parts + (size_t)grp * maxc * (96 * 64) + (size_t)(24 * wid) * 64 + lane;
+        float acc[24];
 #pragma unroll
-        for (int e = 0; e < 12; ++e)
+        for (int q = 0; q < 24; ++q) acc[q] = 0.f;
+        for (int pz0 = 0; pz0 < nr; pz0 += 8) {
+            float v[8][24];
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int u = 0; u < 8; ++u) {
+                const float* pp = base + (size_t)min(pz0 + u, nr - 1) * (96 * 64);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) accdA[e][t][r] = 0.f;
-        // range-major: the 96 coalesced loads of one partial are all in flight together (one memory round
-        // trip per vertex range, not per value)
-        for (int pz = wid; pz < nr; pz += 4) {
-            const float* pp = base + (size_t)pz * (96 * 64);
-            float v[96];
+                for (int q = 0; q < 24; ++q) v[u][q] = __hip_atomic_load(pp + q * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #pragma unroll
-            for (int q = 0; q < 96; ++q) v[q] = pp[q * 64];
+            for (int u = 0; u < 8; ++u)
+                if (pz0 + u < nr) {
 #pragma unroll
-            for (int e = 0; e < 12; ++e)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) accdA[e][t][r] += v[(e * 2 + t) * 4 + r];
+                    for (int q = 0; q < 24; ++q) acc[q] += v[u][q];
+                }
         }
-        __syncthreads();                                   // (scr: the block's own cross-wave pass is over)
-        if (wid >= 2) put(wid - 2);
-        __syncthreads();
-        if (wid < 2) take(wid);
-        __syncthreads();
-        if (wid == 1) put(0);
-        __syncthreads();
-        if (wid == 0) take(0);
-    }
-    if (finish && wid == 0 && s0 + l15 < N) {
+        if (s0 + l15 < N) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                const int qq = 24 * wid + q, e = qq >> 3, t = (qq >> 2) & 1, r = qq & 3;
+                const int j = 16 * t + 4 * g + r;
+                if (j < 24) dA[(s0 + l15) * 288 + j * 12 + e] = acc[q];
+            }
+        }
+    } else if (finish && wid == 0 && s0 + l15 < N) {
 #pragma unroll
         for (int e = 0; e < 12; ++e)
 #pragma unroll

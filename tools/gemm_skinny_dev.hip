@@ -14,9 +14,9 @@
 using glds::Args;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-enum { K_1x4 = 0, K_2x8, K_2x4, K_1x8, K_22x8, K_22x8d3, K_22x16, K_1x4u, NSK };
+enum { K_1x4 = 0, K_2x8, K_2x4, K_1x8, K_22x8, K_22x8d3, K_22x16, K_1x4u, K_2x8d8, K_1x4d8, NSK };
 static const char* sk_name[] = {"32x32 w4 d4", "32x64 w8 d4", "32x64 w4 d4", "32x32 w8 d4", "64x64 w8 d4", "64x64 w8 d3", "64x64 w4 d4",
-                                "32x32 w4 d4 unaligned"};
+                                "32x32 w4 d4 unaligned", "32x64 w8 d8", "32x32 w4 d8"};
 
 template <bool AKC, bool BKC>
 void launch_sk(int cfg, const Args& g, hipStream_t s) {
@@ -29,6 +29,8 @@ void launch_sk(int cfg, const Args& g, hipStream_t s) {
         case K_22x8d3: CK((skinny::launch<AKC, BKC, true, true, 2, 2, 8, 3>(g, s))); break;
         case K_22x16: CK((skinny::launch<AKC, BKC, true, true, 2, 2, 4, 4>(g, s))); break;
         case K_1x4u: CK((skinny::launch<AKC, BKC, false, false, 1, 1, 4, 4>(g, s))); break;
+        case K_2x8d8: CK((skinny::launch<AKC, BKC, true, true, 1, 2, 8, 8>(g, s))); break;
+        case K_1x4d8: CK((skinny::launch<AKC, BKC, true, true, 1, 1, 4, 8>(g, s))); break;
     }
 }
 
@@ -161,13 +163,22 @@ int check() {
     return bad;
 }
 
+// streams `n` floats through every L2 (read + write back): what the operands of a GEMM inside the step look like --
+// written by the previous kernel on other XCDs, not resident in the reader's L2
+__global__ void evict_kernel(float* p, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] += 1.f;
+}
+static float* g_evict = nullptr;
+static bool g_cold = false;
+static void evict(hipStream_t s) { hipLaunchKernelGGL(evict_kernel, dim3(2048), dim3(256), 0, s, g_evict, (long)(48 << 20)); }
+
 // microseconds per launch: 20 launches captured into one graph, the graph replayed
 template <class F>
 static double graph_time(F&& go, hipStream_t s) {
     hipGraph_t graph; hipGraphExec_t exec;
     CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
     const int reps = 20;
-    for (int r = 0; r < reps; ++r) go();
+    for (int r = 0; r < reps; ++r) { if (g_cold) evict(s); go(); }
     CK(hipStreamEndCapture(s, &graph));
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -194,6 +205,14 @@ void timeit(long Nb) {
                             {"mq", 0, 0, Nb, 792, 207}, {"dpf_kp", 0, 1, Nb, 207, 792}, {"blend_adjoint", 1, 1, Nb, 207, 20670}};
     hipStream_t s; CK(hipStreamCreate(&s));
     float* ws; CK(hipMalloc(&ws, 256 << 20)); CK(hipMemset(ws, 0, 256 << 20));
+    g_cold = getenv("SK_COLD") != nullptr;
+    if (g_cold) {
+        CK(hipMalloc(&g_evict, 192 << 20)); CK(hipMemset(g_evict, 0, 192 << 20));
+        g_cold = false;
+        const double base = graph_time([&] { evict(s); }, s);
+        g_cold = true;
+        printf("COLD mode: a 192 MB read-modify-write sweep before every launch (%.1f us, included in every number below)\n", base);
+    }
     printf("empty 256-block kernel in the same graph: %.2f us per launch\n", graph_time([&] { hipLaunchKernelGGL(touch_kernel, dim3(256), dim3(256), 0, s, ws + 8192); }, s));
     for (const Shape& p : shapes) {
         const long lda = p.ta ? (p.M + 15) / 16 * 16 : (p.K + 3) / 4 * 4, ldb = p.tb ? (p.K + 3) / 4 * 4 : (p.N + 3) / 4 * 4;
