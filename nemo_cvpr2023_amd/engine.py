@@ -567,7 +567,16 @@ class FitEngine:
         check(self.lib.nemo_kl_fwd_bwd(N, 32, dptr(w['MULV']), 64, self.scal.data_ptr() + 4 * S_KL,
                                        dptr(w['dMULV']), 64, _stream()), 'nemo_kl_fwd_bwd')
 
-    def forward_v2v(self, w, N, need_grad, after_loss=None):
+    def forward_v2v_pre(self, w, N):
+        """The part of forward_v2v's first chunk that only needs the poses: both bodies' rotations (v2v_prep) and their
+        FK.  The step runs it at the end of the VPoser stream, off the main chain (``forward_v2v(pre_done=True)``)."""
+        L, st, ctx = self.lib, _stream(), self.ctx
+        n = min(w['Nc'], N)
+        check(L.nemo_v2v_prep_fwd(n, dptr(w['R']), dptr(w['AA']), dptr(w['AAdec']), dptr(w['R2']), st), 'nemo_v2v_prep_fwd')
+        check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']), dptr(w['PF2']), 208, st),
+              'nemo_fk_fwd')
+
+    def forward_v2v(self, w, N, need_grad, after_loss=None, pre_done=False):
         """K10 + K11: the two full-mesh bodies, L1 sum and (same pass) its gradient wrt the pose.
         One fused MFMA kernel per chunk (pose blend + skinning + L1 + gradient, nothing of the
         blended mesh goes to HBM); the blend-shape adjoint is one GEMM on the transposed dVP."""
@@ -579,9 +588,10 @@ class FitEngine:
             R = w['R'].data_ptr() + 4 * c0 * 216
             AA = w['AA'].data_ptr() + 4 * c0 * 72
             AAd = w['AAdec'].data_ptr() + 4 * c0 * 63
-            check(L.nemo_v2v_prep_fwd(n, R, AA, AAd, dptr(w['R2']), st), 'nemo_v2v_prep_fwd')
-            check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']),
-                                dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
+            if not (pre_done and c0 == 0):
+                check(L.nemo_v2v_prep_fwd(n, R, AA, AAd, dptr(w['R2']), st), 'nemo_v2v_prep_fwd')
+                check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']),
+                                    dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
             ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * (2 * 3 * 207 + 2 * 288 + 288))
             ws = w['mesh_ws']
             fused = L.nemo_v2v_fused_bf16 if self.bf16 else L.nemo_v2v_fused

@@ -481,6 +481,7 @@ class MultiViewModel(nn.Module):
         with torch.cuda.stream(side):
             if use_vposer:
                 enc_done = e.forward_vposer(w, N)                             # always evaluated, :3569
+                e.forward_v2v_pre(w, N)          # rotations + FK of both mesh bodies: only the poses are needed
         with torch.cuda.stream(side2):
             st = _stream()
             if use_gmm:
@@ -516,7 +517,7 @@ class MultiViewModel(nn.Module):
         loss_final = []
         pub_aside = bool(publish and update and part == 'all' and use_vposer and e.overlap_bwd)
         if use_vposer:
-            e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss),
+            e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss), pre_done=True,
                           after_loss=(lambda: loss_final.append(main.record_event())) if pub_aside else None)
         if publish and not pub_aside:
             e.publish_scalars()
