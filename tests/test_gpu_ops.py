@@ -394,6 +394,13 @@ def test_keypoint_path_forward_backward(L, num_verts, version):
     assert rel_err(dTRg, TRo.grad) < 1e-4
     assert rel_err(dcg, co.grad) < 1e-4
     assert float(dcg[1].abs().max()) == 0.0
+    # norm == NULL: nemo_kp_bwd derives the normaliser from the view accumulators itself (the step runs kp_finalize off
+    # the main chain) -- bit-identical outputs
+    dA2, dJp2, dMq2, dTR2, dc2 = Z(N, 24, 12), Z(N, 24, 3), Z(N, nq72), Z(N + 1, 3), Z(V, 9)
+    assert L.nemo_kp_bwd(*args, vacc.data_ptr(), None, 1.0, dA2.data_ptr(), dJp2.data_ptr(), dMq2.data_ptr(),
+                         dTR2.data_ptr(), 3, dc2.data_ptr(), H.st()) == 0
+    assert torch.equal(dA2, dA) and torch.equal(dMq2, dMq) and torch.equal(dTR2[:N], dTRg[:N])
+    assert rel_err(dJp2, dJp) < 1e-6 and rel_err(dc2, dcg) < 1e-6          # (atomic accumulations: order may differ)
 
 
 @pytest.mark.parametrize('loss_type,lid', [('mse', 1), ('rmse', 2), ('rmse_robust', 3),
