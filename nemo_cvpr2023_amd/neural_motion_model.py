@@ -782,15 +782,17 @@ class MultiViewModel(nn.Module):
         ``then`` (the Adam launch) is enqueued before the host waits for the values when they travel
         through pinned memory (engine.publish_scalars), after the synchronisation otherwise."""
         e = self.engine
+        slot = None
         if sh.comm is not None:
             wv = self._shard_weights(sh)
             slot = e.view('_comm_scalars', e.grads)
             torch.mul(e.scal, wv, out=slot)
             sh.comm(e, update)
-            e.scal.copy_(slot)
+            if not e.early_readback:
+                e.scal.copy_(slot)
         if e.early_readback:
             e.arm_scalars()
-            e.publish_scalars()
+            e.publish_scalars(slot)          # (reduced scalars straight from the all-reduced buffer: no copy back)
             if then is not None:
                 then()
             return e.wait_scalars()
