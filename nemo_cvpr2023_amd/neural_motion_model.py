@@ -514,12 +514,18 @@ class MultiViewModel(nn.Module):
         # while the backward goes on.  When the whole backward follows in this launch, the hand-over leaves the main
         # chain: a branch on side2 that forks right behind the mesh kernel -- before the blend-shape adjoint -- and is
         # enqueued LAST (a replayed graph keeps the first-enqueued successor on the queue, see above), joined before Adam.
+        # Measured (same box, three runs each): 0.494 ms at one instance / 1.557 ms at C2 against 0.512 / 1.576 with the
+        # hand-over on the main stream, before or after the adjoint -- its system-scope release stalls the queue it is on.
+        # (NEMO_PUBLISH=main_early | main_late: A/B aid.)
         loss_final = []
-        pub_aside = bool(publish and update and part == 'all' and use_vposer and e.overlap_bwd)
+        pub_mode = os.environ.get('NEMO_PUBLISH', 'aside')
+        pub_aside = bool(publish and update and part == 'all' and use_vposer and e.overlap_bwd and pub_mode == 'aside')
+        pub_early = bool(publish and use_vposer and pub_mode == 'main_early')
         if use_vposer:
             e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss), pre_done=True,
-                          after_loss=(lambda: loss_final.append(main.record_event())) if pub_aside else None)
-        if publish and not pub_aside:
+                          after_loss=(lambda: loss_final.append(main.record_event())) if pub_aside else
+                          (e.publish_scalars if pub_early else None))
+        if publish and not pub_aside and not pub_early:
             e.publish_scalars()
         if not update or part == 'head':
             return
