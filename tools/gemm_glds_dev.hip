@@ -13,10 +13,10 @@
 using glds::Args;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-enum Cfg { C64 = 0, C128x64, C64x128, C128, C64x208, S64, S128x64, S64x128, S128, S128x224, B64, B128, NCFG };
+enum Cfg { C64 = 0, C128x64, C64x128, C128, C64x208, S64, S128x64, S64x128, S128, S128x224, B64, B128, C64x16, NCFG };
 static const char* cfg_name[] = {"64x64", "128x64", "64x128", "128x128", "64x208/16", "64x64 spread", "128x64 spread",
-                                 "64x128 spread", "128x128 spread", "128x224 spread", "64x64 bf16", "128x128 bf16"};
-static const int cfg_bm[] = {64, 128, 64, 128, 64, 64, 128, 64, 128, 128, 64, 128}, cfg_bn[] = {64, 64, 128, 128, 208, 64, 64, 128, 128, 224, 64, 128};
+                                 "64x128 spread", "128x128 spread", "128x224 spread", "64x64 bf16", "128x128 bf16", "64x16/16"};
+static const int cfg_bm[] = {64, 128, 64, 128, 64, 64, 128, 64, 128, 128, 64, 128, 64}, cfg_bn[] = {64, 64, 128, 128, 208, 64, 64, 128, 128, 224, 64, 128, 16};
 
 template <bool AKC, bool BKC>
 hipError_t launch_cfg(int cfg, const Args& g, int blocks, hipStream_t s) {
@@ -36,6 +36,9 @@ hipError_t launch_cfg(int cfg, const Args& g, int blocks, hipStream_t s) {
             return hipErrorInvalidValue;
         case C64x208:
             if constexpr (BKC) return glds::launch<64, 208, 16, 208, 16, AKC, true, 2>(g, blocks, s);
+            return hipErrorInvalidValue;
+        case C64x16:
+            if constexpr (BKC) return glds::launch<64, 16, 16, 16, 16, AKC, true, 2>(g, blocks, s);
             return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
@@ -93,7 +96,7 @@ int check() {
         CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dbias, hbias.data(), p.N * 4, hipMemcpyHostToDevice));
         for (int cfg = 0; cfg < NCFG; ++cfg) {
-            if ((cfg == C64x208 || cfg == S128x224) && !p.tb) continue;
+            if ((cfg == C64x208 || cfg == S128x224 || cfg == C64x16) && !p.tb) continue;
             for (int split : {1, 3}) {
                 if (split > 1 && p.K < 96) continue;
                 for (int t0 : {0, 1}) {
@@ -128,7 +131,7 @@ void timeit(long Nb) {
                             {"mlp_hidden_dw", 1, 0, 1000, 1000, Nb + 1}, {"head_fwd", 0, 1, Nb + 1, 147, 1000},
                             {"head_dx", 0, 0, Nb + 1, 1000, 147}, {"head_dw", 1, 0, 147, 1000, Nb + 1},
                             {"vposer_512", 0, 1, Nb, 512, 512}, {"mq", 0, 0, Nb, 792, 207}, {"dpf_kp", 0, 1, Nb, 207, 792},
-                            {"blend_adjoint", 1, 1, Nb, 207, 20670}};
+                            {"blend_adjoint", 1, 1, Nb, 207, 20670}, {"blend_adjoint_192", 1, 1, Nb, 192, 20670}, {"blend_adjoint_15", 1, 1, Nb, 15, 20670}};
     float* ws; CK(hipMalloc(&ws, 256 << 20)); CK(hipMemset(ws, 0, 256 << 20));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Shape& p : shapes) {
@@ -144,6 +147,7 @@ void timeit(long Nb) {
                2e-9 * p.M * p.N * p.K, 2e-6 * p.M * p.N * p.K / 157.3);
         for (int cfg = 0; cfg < NCFG; ++cfg) {
             if ((cfg == C64x208 || cfg == S128x224) && (!p.tb || p.N > 224)) continue;
+            if (cfg == C64x16 && (!p.tb || p.N > 16)) continue;
             const long tiles = ((p.M + cfg_bm[cfg] - 1) / cfg_bm[cfg]) * ((p.N + cfg_bn[cfg] - 1) / cfg_bn[cfg]);
             std::string line = std::string("   ") + cfg_name[cfg] + " (" + std::to_string(tiles) + " tiles):";
             for (int split : {1, 2, 3, 4, 6, 8, 13, 16, 26}) {
