@@ -1,6 +1,6 @@
 import os, sys, ctypes
-os.environ['NEMO_HIP_LIB'] = '/root/repo/nemo_cvpr2023_amd/libnemo_hip_abl.so'
-sys.path.insert(0, '/root/repo')
+os.environ['NEMO_HIP_LIB'] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'nemo_cvpr2023_amd', 'libnemo_hip_abl.so')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from nemo_cvpr2023_amd import synthetic as syn, _lib
 from nemo_cvpr2023_amd.neural_motion_model import NemoV2

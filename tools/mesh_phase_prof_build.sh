@@ -1,12 +1,12 @@
 #!/bin/bash
 # builds nemo_cvpr2023_amd/libnemo_hip_abl.so = current smpl.hip + cycle-counter probes
-cd /root/repo/nemo_cvpr2023_amd/csrc && python - <<'PY'
+cd "$(dirname "$0")/../nemo_cvpr2023_amd/csrc" && python - <<'PY'
 s=open('smpl.hip').read()
 def rep(a,b):
     global s
     assert a in s, a[:50]
     s=s.replace(a,b,1)
-rep("__global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(","__device__ unsigned long long mesh_prof[8 * 1024];\n__global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(")
+rep("template <bool BF16>\n__global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(","__device__ unsigned long long mesh_prof[8 * 1024];\ntemplate <bool BF16>\n__global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(")
 rep("    for (long t = t_beg + wid; t < t_end; t += 4) {\n        const long v0 = t * 16;","    unsigned long long pr_blend = 0, pr_rec = 0, pr_orig = 0, pr_tiles = 0, pr_sk = 0, pr_va = 0, pr_ad = 0, pr_st = 0, pr_t0 = __builtin_readcyclecounter();\n    for (long t = t_beg + wid; t < t_end; t += 4) {\n        unsigned long long c0 = __builtin_readcyclecounter();\n        const long v0 = t * 16;")
 rep("        // ---- reconstruction body, one output row c (4 transform entries) at a time\n        float vrec[3][4];","        unsigned long long c1 = __builtin_readcyclecounter();\n        // ---- reconstruction body, one output row c (4 transform entries) at a time\n        float vrec[3][4];")
 rep("        // ---- original body: row c of the transform -> vertex coordinate c -> sign -> its share of dvp and","        unsigned long long c2 = __builtin_readcyclecounter();\n        // ---- original body: row c of the transform -> vertex coordinate c -> sign -> its share of dvp and")
