@@ -512,7 +512,9 @@ static int skinny_kind(bool akc, bool bkc, bool aligned, bool can_split, long M,
         // (at small K these run beside the input-gradient chain on a second stream: the 64 x 64 configuration's 128 KiB
         //  reduction buffer would keep the other stream's blocks off the CU)
         if (t64 >= 200 && t64 <= 256 && K >= 1024) return 2;
-        use = t64 <= 192 && K <= 4096;
+        // (the 1000 x 1000 gradients of a two-instance shard, K = 600: 0.642 -> 0.635 ms per step on the 32 x 32
+        //  configuration; at K = 300 the LDS-DMA kernel is 3 us ahead)
+        use = (t64 <= 192 || (t64 <= 256 && K >= 512)) && K <= 4096;
     } else if (akc && !bkc) use = ((M <= 1536 && t64 <= 320) || t64 <= 192) && K <= 4096;   // input gradients dX = dY W
     else if (akc && bkc) use = M <= 1024 && t64 <= 192 && K <= 4096;         // forward Y = X W^T
     else {
