@@ -105,7 +105,7 @@ def test_sharded_step_over_rccl_world_of_one(mode):
     s.close()
     _rccl_world1(mode, q)
     got, n_graphs = q['res']
-    assert n_graphs >= 1
+    assert n_graphs >= (0 if os.environ.get('NEMO_GRAPHS', '1') == '0' else 1)
     V, T, B = 3, 10, 16
     args = syn.published_args(h_dim=48, monotonic_network_n_nodes=20, batch_size=B, out_dir='', phase_rbf_dim=16)
     seqs = syn.SyntheticSequences(V, T, seed=1234)

@@ -146,6 +146,14 @@ def test_sharded_oracle_equals_single_process(version):
 
 # ------------------------------------------------------------------------------------------ GPU
 def _hip_worker(rank, world, port, q, mode):
+    try:
+        _hip_worker_body(rank, world, port, q, mode)
+    except BaseException as exc:          # the parent would otherwise sit in q.get() until its timeout
+        q.put((rank, repr(exc)))
+        raise
+
+
+def _hip_worker_body(rank, world, port, q, mode):
     from nemo_cvpr2023_amd.dist import ShardedNemo
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
     args = _args(3)
@@ -167,7 +175,10 @@ def _hip_worker(rank, world, port, q, mode):
     for _ in range(5):      # the same variant five times: captured as HIP graph(s) (split: two halves) and replayed
         losses.append({k: float(v) for k, v in m.step(None, None, full_batch=True)[0].items()})
     graphs = [v for w in m.model.engine.ws.values() for v in w['graphs'].values()]
-    assert sum(isinstance(g, torch.cuda.CUDAGraph) for g in graphs) >= (2 if mode == 'split' else 1), graphs
+    # (the A/B switches change what is captured: no graphs at all, or no second half without the early read-back)
+    want = 0 if os.environ.get('NEMO_GRAPHS', '1') == '0' else \
+        (2 if mode == 'split' and os.environ.get('NEMO_EARLY_READBACK', '1') != '0' else 1)
+    assert sum(isinstance(g, torch.cuda.CUDAGraph) for g in graphs) >= want, graphs
     sd = {k: v.numpy() for k, v in m.gather_state_dict().items()}
     q.put((rank, losses, sd, wl, [float(x) for x in cl]))
     dist.barrier()
@@ -189,7 +200,9 @@ def test_sharded_hip_equals_single_process_hip(tmp_path, mode):
     procs = [ctx.Process(target=_hip_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    res = [q.get(timeout=600) for _ in range(world)]
+    assert all(len(r) == 5 for r in res), [r for r in res if len(r) != 5]       # (rank, repr(exception)) on failure
+    res = sorted(res, key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -10,6 +10,7 @@ accumulation, fp32 master weights.  Not covered by the 1e-4 fp32 parity gate; th
   ones (entries within 0.15 of the gradient's scale after three bf16 layers of backward), and the
   fit still descends."""
 import numpy as np
+import os
 import pytest
 import torch
 
@@ -44,6 +45,8 @@ def _gemm(L, fn, A, B, ta, tb, **kw):
 @pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize('M,N,K', [(301, 1000, 1000), (2401, 147, 1000), (130, 70, 100), (300, 207, 2070)])
 def test_gemm_bf16_is_the_fp32_kernel_on_rounded_operands(L, ta, tb, M, N, K):
+    if os.environ.get('NEMO_GEMM_GLDS', '1') == '0':
+        pytest.skip('NEMO_GEMM_GLDS=0 (A/B aid) takes every GEMM to the first-generation fp32 kernel, which has no bf16 path')
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K + ta + 2 * tb)
     pad = lambda n: (n + 3) // 4 * 4
     A = torch.randn((K, pad(M)) if ta else (M, pad(K)), generator=g).to(DEV)[:, :(M if ta else K)]
@@ -113,6 +116,8 @@ def test_c3_bf16_step_vs_fp32_oracle():
     """BASELINE configs[2] at its real size: 40 instances x 300 frames, h = 1000, 6890 vertices, every loss term,
     gemm_dtype = 'bf16'.  Rows of ~300 samples against the fp32 oracle (bf16 tolerance), the full-batch losses against
     the fp32 HIP path from the same state, MLP gradients, and three descending update steps."""
+    if os.environ.get('NEMO_GEMM_GLDS', '1') == '0':
+        pytest.skip('NEMO_GEMM_GLDS=0 (A/B aid): the first-generation GEMM kernel has no bf16 path')
     from nemo_cvpr2023_amd.neural_motion_model import NemoV2
     from oracle.model import OracleNemo
     V, T = 40, 300

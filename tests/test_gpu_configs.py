@@ -11,6 +11,7 @@ oracle evaluated on just those samples -- samples are independent given the para
 full-batch losses and shared-parameter gradients equal the mean over a partition into view blocks of the
 minibatch path's losses / gradients (which test_gpu_model.py pins to the oracle at N = 512 ... 2400)."""
 import numpy as np
+import os
 import pytest
 import torch
 
@@ -131,6 +132,8 @@ def test_captured_graphs_survive_other_batch_sizes():
     engine-wide buffer that was re-allocated when a larger batch arrived -- graphs captured earlier then wrote into
     freed memory.  Capture the step at N = a, run larger and ragged sizes (more 16-sample groups, other chunk
     plans, sizes that share a's workspace and sizes that do not), replay N = a: every step must still match the oracle."""
+    if os.environ.get('NEMO_GRAPHS', '1') == '0':
+        pytest.skip('NEMO_GRAPHS=0: nothing is captured')
     from nemo_cvpr2023_amd.neural_motion_model import NemoV2
     from oracle.model import OracleNemo
     V, T = 4, 60

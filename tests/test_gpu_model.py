@@ -1,6 +1,7 @@
 """GPU parity of the drop-in NemoV* classes: the trajectories recorded from the real reference
 (tests/golden/model_*.npz) replayed through the HIP engine, plus full-size checks against the oracle."""
 import numpy as np
+import os
 import pytest
 import torch
 
@@ -595,6 +596,8 @@ def test_early_loss_readback_equals_synchronous_readback(version):
 def test_failed_graph_capture_falls_back_to_uncaptured_launches(monkeypatch):
     """If the HIP-graph capture of a step variant fails (e.g. invalidated by another thread), the variant keeps
     running kernel by kernel through the same engine and the results do not change."""
+    if os.environ.get('NEMO_GRAPHS', '1') == '0':
+        pytest.skip('NEMO_GRAPHS=0: nothing is captured')
     from nemo_cvpr2023_amd.neural_motion_model import NemoV2
     V, T, B = 2, 8, 8
     args = syn.published_args(h_dim=48, monotonic_network_n_nodes=20, batch_size=B, out_dir='', phase_rbf_dim=16)
