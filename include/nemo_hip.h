@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 6
+#define NEMO_ABI_VERSION 7
 int32_t nemo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -112,10 +112,13 @@ int32_t nemo_rot6d_bwd(int64_t rows, int64_t J, const float* rot6d, int64_t ld6,
                        const float* dR, const float* daa, float* d_rot6d, int64_t ldd, void* stream);
 /* The step's backward of the pose head in ONE launch = nemo_v2v_prep_bwd (when dR2 != NULL; its results are
  * consumed in registers, dR / daa are NOT modified) + nemo_rot6d_bwd over N rows of 24 joints +
- * nemo_scale_neg_rowsum (when dTR != NULL: dTR[N][0..2] = - sum_{s<N} dTR[s][0..2], :3764-3766). */
+ * nemo_scale_neg_rowsum (when dTR != NULL: dTR[N][0..2] = - sum_{s<N} dTR[s][0..2], :3764-3766).
+ * zero_row != 0: d_rot6d has N + 1 rows and the 144 rotation columns of row N -- the "phase 0 / zero code" row that
+ * only yields trans_0 (:3755-3766) and so carries no rotation gradient -- are set to zero (a buffer shared by several
+ * batch sizes otherwise keeps an earlier, larger batch's row there). */
 int32_t nemo_pose_bwd_fused(int64_t N, const float* rot6d, int64_t ld6, int32_t zero_nan, const float* dR,
                             const float* daa, float* d_rot6d, int64_t ldd, const float* aa, const float* dR2,
-                            float v2v_scale, float* dTR, int64_t ldt, void* stream);
+                            float v2v_scale, float* dTR, int64_t ldt, int32_t zero_row, void* stream);
 /* Stand-alone conversions (API parity with hmr/geometry.py). */
 int32_t nemo_rotmat_to_aa(int64_t M, const float* R, int32_t zero_nan, float* aa, void* stream);
 /* hmr/geometry.py:9-45: quaternion-form Rodrigues, angle = ||theta + 1e-8||; form=1 selects the

@@ -26,7 +26,7 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 6        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 7        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -43,7 +43,7 @@ SIGNATURES = {
                                    ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr]),
     'nemo_rot6d_fwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr]),
     'nemo_rot6d_bwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr]),
-    'nemo_pose_bwd_fused': (i32, [i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, ptr]),
+    'nemo_pose_bwd_fused': (i32, [i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, i32, ptr]),
     'nemo_rotmat_to_aa': (i32, [i64, ptr, i32, ptr, ptr]),
     'nemo_rodrigues_fwd': (i32, [i64, ptr, i32, ptr, ptr]),
     'nemo_rodrigues_bwd': (i32, [i64, ptr, ptr, ptr, ptr]),

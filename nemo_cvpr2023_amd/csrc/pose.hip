@@ -249,8 +249,11 @@ __global__ __launch_bounds__(256) void pose_bwd_fused_kernel(long N, const float
                                                              float* __restrict__ d_rot6d, long ldd,
                                                              const float* __restrict__ aa,
                                                              const float* __restrict__ dR2, float scale,
-                                                             float* __restrict__ dTR, long ldt) {
+                                                             float* __restrict__ dTR, long ldt, int zero_row) {
     if (blockIdx.x == gridDim.x - 1) {                 // the reduction block
+        // row N of the head gradient belongs to the "phase 0 / zero code" row of the MLP: its rotation columns carry no
+        // gradient.  Workspaces are shared by batch sizes, so whatever an earlier, larger batch left there is cleared
+        if (zero_row && threadIdx.x < 144) d_rot6d[N * ldd + threadIdx.x] = 0.f;
         if (!dTR) return;
         __shared__ float red[16];
         for (int c = 0; c < 3; ++c) {
@@ -497,13 +500,14 @@ extern "C" int32_t nemo_rot6d_bwd(int64_t rows, int64_t J, const float* rot6d, i
 extern "C" int32_t nemo_pose_bwd_fused(int64_t N, const float* rot6d, int64_t ld6, int32_t zero_nan,
                                        const float* dR, const float* daa, float* d_rot6d, int64_t ldd,
                                        const float* aa, const float* dR2, float v2v_scale,
-                                       float* dTR, int64_t ldt, void* stream) {
+                                       float* dTR, int64_t ldt, int32_t zero_row, void* stream) {
     if (N < 0 || !rot6d || !d_rot6d || ld6 < 144 || ldd < 144 || (dR2 && !aa) || (dTR && ldt < 3))
         return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
     const unsigned blocks = (unsigned)nemo_cdiv(N * 24, 256) + 1;          // + the reduction block
     hipLaunchKernelGGL(pose_bwd_fused_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)N, rot6d,
-                       (long)ld6, (int)zero_nan, dR, daa, d_rot6d, (long)ldd, aa, dR2, v2v_scale, dTR, (long)ldt);
+                       (long)ld6, (int)zero_nan, dR, daa, d_rot6d, (long)ldd, aa, dR2, v2v_scale, dTR, (long)ldt,
+                       (int)zero_row);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -199,6 +199,8 @@ class MultiViewModel(nn.Module):
 
     def __init__(self, args, multi_view_seqs, device, smpl_assets=None, vposer_state=None, gmm=None):
         super().__init__()
+        out_dir = getattr(args, 'out_dir', None)
+        args, multi_view_seqs = self._saved_config(args, multi_view_seqs)         # :155-192
         self.args = args
         if not hasattr(self.args, 'include_vs'):
             self.args.include_vs = False
@@ -209,8 +211,7 @@ class MultiViewModel(nn.Module):
         self.device = torch.device(device)
         self.multi_view_seqs = multi_view_seqs
         self.num_views, self.num_frames = multi_view_seqs.num_views, multi_view_seqs.num_frames
-        out_dir = getattr(args, 'out_dir', None)
-        if out_dir and getattr(args, 'write_config', True):                 # :199-202
+        if out_dir and getattr(args, 'write_config', True):                 # :199-202 (the NEW run's out_dir, :190)
             try:
                 import joblib
                 os.makedirs(out_dir, exist_ok=True)
@@ -241,6 +242,70 @@ class MultiViewModel(nn.Module):
     @property
     def engine(self) -> FitEngine:
         return self._engine[0]
+
+    @staticmethod
+    def _saved_config(args, multi_view_seqs):
+        """:155-192: with ``args.load_ckpt_path = <run>/ckpt/sd_xxxxxx.pt`` the model is built from the ``args`` the
+        run saved in ``<run>/model_config.p`` (what ``--test`` / resumed runs of the script rely on, scripts:313-314),
+        and the sequences are re-read for THOSE arguments: the 'generic' loader through this package's data layer
+        (``include_vs / include_pare`` set as the reference does); 'penn_action' / 'demo' loaders are outside this
+        package, so the sequences the caller passed are kept.  No config file: the arguments as given (:186-187)."""
+        path = getattr(args, 'load_ckpt_path', '') or ''
+        if not path:
+            return args, multi_view_seqs
+        base = os.path.dirname(os.path.dirname(path))
+        cfg_path = os.path.join(base, 'model_config.p')
+        if not os.path.exists(cfg_path):
+            print('Cannot find saved config .... ')
+            return args, multi_view_seqs
+        import joblib
+        saved = joblib.load(cfg_path)['args']
+        kind = getattr(saved, 'data_loader_type', None)
+        if kind == 'generic':
+            saved.include_vs, saved.include_pare = True, True
+            if getattr(saved, 'nemo_cfg', None) is not None:
+                from .multi_view_sequence import load_nemo_mocap
+                try:
+                    multi_view_seqs = load_nemo_mocap(saved.nemo_cfg, saved.start_phase, saved.n_frames)
+                except (OSError, KeyError) as ex:        # the data of the saved run is not on this machine
+                    warnings.warn(f'saved config: could not re-read its sequences ({ex!r}); using the ones passed in')
+        elif kind == 'penn_action':
+            saved.include_vs, saved.include_pare = True, False
+        elif kind is not None and kind != 'demo':
+            raise ValueError('Unsupported `data_loader_type`.')
+        return saved, multi_view_seqs
+
+    # ------------------------------------------------------------------ evaluation / rendering surface of the script
+    def eval_2d(self, out_dir, num_frames=-1, num_views=-1, view_idxs=[]):
+        """:522-710 (called by scripts/learned_multi_view_recon_nn.py:333): writes ``<out_dir>/eval_2d.csv``."""
+        from . import evaluation
+        return evaluation.eval_2d(self, out_dir, num_frames, num_views, list(view_idxs))
+
+    def eval_3d(self, out_dir, num_frames=-1, num_views=-1, view_idxs=[], dynamic_only=False):
+        """:1056-1282 (scripts:334-335): ``eval_3d.csv`` / ``eval_3d_dynamic.csv``."""
+        from . import evaluation
+        return evaluation.eval_3d(self, out_dir, num_frames, num_views, list(view_idxs), dynamic_only)
+
+    def render_rollout_keypoint_figure(self, fpath=None, *a, **k):
+        """:422-520 draws key points over video frames with matplotlib / OpenCV.  Rendering is outside this package
+        (out of scope), but the script calls this one unconditionally right after building the model
+        (scripts:199-202), so it warns and returns instead of failing the run."""
+        warnings.warn('render_rollout_keypoint_figure: rendering is not part of nemo_cvpr2023_amd (nothing written to '
+                      f'{fpath!r}); use the reference class on get_preds() outputs for figures')
+        return None
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            if name.startswith('render_'):
+                def _no_render(*a, **k):
+                    raise NotImplementedError(
+                        f'{type(self).__name__}.{name}: rendering is out of scope of nemo_cvpr2023_amd -- run the script '
+                        'with --render_rollout_figure / --render_video off (scripts/learned_multi_view_recon_nn.py:242, '
+                        ':284, :331), or render get_preds() outputs with the reference class')
+                return _no_render
+            raise
 
     # ------------------------------------------------------------------ parameters
     def _param(self, name):
@@ -546,7 +611,7 @@ class MultiViewModel(nn.Module):
             N, dptr(w['ROT']), HEAD_LD, 1, dptr(w['dR']), dptr(w['dAA']), dptr(w['dROT']), HEAD_LD,
             dptr(w['AA']) if v2v else None, dptr(w['dR2']) if v2v else None,
             float(a.weight_vp_loss) * sh.mr / float(N * e.NV * 3) if v2v else 0.0,
-            dptr(w['dTR']) if anchored else None, HEAD_LD, st), 'nemo_pose_bwd_fused')
+            dptr(w['dTR']) if anchored else None, HEAD_LD, 1, st), 'nemo_pose_bwd_fused')
         if not anchored:
             e.finish_trans_grad(w, N)
         e.backward_mlp(w, N, vi, fi, None)
@@ -851,6 +916,7 @@ class MultiViewModel(nn.Module):
                                                 w['dAA'].data_ptr() + 12, 72, st), 'nemo_pose3d_fwd_bwd')
                 check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, None, dptr(w['dAA']),
                                            dptr(w['dROT']), HEAD_LD, st), 'nemo_rot6d_bwd')
+                w['dHEAD'][N].zero_()     # the phase-0 row: a workspace shared with larger batches keeps their row here
                 e.backward_mlp(w, N, vi, fi, None, has_trans_grad=False)
             s = self._reduce_and_read(sh, True)
             if bool(torch.isnan(e.grads).any()):

@@ -146,3 +146,59 @@ def test_real_asset_loaders_round_trip(tmp_path):
     assert all(np.array_equal(got[k], g[k]) for k in ('means', 'covars', 'weights'))
     with pytest.raises(FileNotFoundError):
         assets.load_smpl_assets(str(tmp_path / 'nowhere'))
+
+
+# What scripts/learned_multi_view_recon_nn.py touches on the model object (:192-335) and nemo/utils/render_utils.py:90-158
+SCRIPT_METHODS = ['to', 'render_rollout_keypoint_figure', 'step', 'warmup', 'opt_cam', 'save', 'load', 'eval_2d', 'eval_3d',
+                  'get_preds', 'get_preds_batch', 'learned_camera_projection', 'state_dict', 'load_state_dict']
+SCRIPT_ATTRIBUTES = ['optimizers', 'phase_networks', 'num_views', 'num_frames', 'args', 'device']
+
+
+def test_script_surface_resolves_on_every_model_class():
+    """The one-line swap of INTEGRATION.md section A: every method the reference script calls on the model object exists
+    on NemoV0..V4 with the reference's signature (argument names and defaults of eval_2d / eval_3d, :522 / :1056-1061);
+    the instance attributes are assigned in the constructor (checked on a constructed model by the GPU suite,
+    tests/test_gpu_model.py::test_script_surface_on_a_constructed_model)."""
+    import inspect
+    from nemo_cvpr2023_amd import neural_motion_model as nm
+    for k in range(5):
+        cls = nm.NEMO_VERSIONS[k]
+        assert cls.__name__ == f'NemoV{k}'
+        for name in SCRIPT_METHODS:
+            assert callable(getattr(cls, name)), (cls, name)
+        sig = inspect.signature(cls.eval_3d)
+        assert list(sig.parameters) == ['self', 'out_dir', 'num_frames', 'num_views', 'view_idxs', 'dynamic_only']
+        assert sig.parameters['dynamic_only'].default is False and sig.parameters['num_frames'].default == -1
+        assert list(inspect.signature(cls.eval_2d).parameters) == ['self', 'out_dir', 'num_frames', 'num_views', 'view_idxs']
+        src = inspect.getsource(nm.MultiViewModel)
+        for name in SCRIPT_ATTRIBUTES:
+            assert re.search(rf'self\.{name}\b[^=\n]*=[^=]', src), name
+
+
+def test_constructor_takes_the_saved_config_of_a_checkpointed_run(tmp_path):
+    """nemo/neural_motion_model.py:155-192: args.load_ckpt_path = <run>/ckpt/sd.pt -> the model is built from the args
+    saved in <run>/model_config.p (--test / resumed runs, scripts:313-314); without that file, from the args given."""
+    import joblib
+    from types import SimpleNamespace
+    from nemo_cvpr2023_amd.neural_motion_model import MultiViewModel
+    run = tmp_path / 'run'
+    (run / 'ckpt').mkdir(parents=True)
+    saved = SimpleNamespace(h_dim=123, data_loader_type='generic', nemo_cfg=None, start_phase=0, n_frames=10, run_hmr=False)
+    joblib.dump({'args': saved}, str(run / 'model_config.p'))
+    seqs = object()
+    given = SimpleNamespace(h_dim=7, load_ckpt_path=str(run / 'ckpt' / 'sd_000499.pt'), out_dir=str(tmp_path / 'new'))
+    a, s = MultiViewModel._saved_config(given, seqs)
+    assert a.h_dim == 123 and a.include_vs is True and a.include_pare is True and s is seqs
+    saved.data_loader_type = 'penn_action'
+    joblib.dump({'args': saved}, str(run / 'model_config.p'))
+    a, _ = MultiViewModel._saved_config(given, seqs)
+    assert a.include_vs is True and a.include_pare is False
+    saved.data_loader_type = 'nonsense'
+    joblib.dump({'args': saved}, str(run / 'model_config.p'))
+    with pytest.raises(ValueError):
+        MultiViewModel._saved_config(given, seqs)
+    (run / 'model_config.p').unlink()
+    a, _ = MultiViewModel._saved_config(given, seqs)
+    assert a is given
+    given.load_ckpt_path = ''
+    assert MultiViewModel._saved_config(given, seqs)[0] is given

@@ -659,10 +659,14 @@ def test_pose_bwd_fused_equals_the_three_launches(L):
         b_dh = dhead0.clone()
         assert L.nemo_pose_bwd_fused(N, head.data_ptr(), LD, 1, dR.data_ptr(), dAA.data_ptr(), b_dh.data_ptr(), LD,
                                      AA.data_ptr() if v2v else None, dR2.data_ptr() if v2v else None, scale,
-                                     b_dh.data_ptr() + 4 * 144 if anchored else None, LD, H.st()) == 0
+                                     b_dh.data_ptr() + 4 * 144 if anchored else None, LD, 1 if v2v else 0, H.st()) == 0
+        # zero_row: the rotation columns of row N are cleared (else untouched)
+        assert torch.equal(b_dh[N, :144], torch.zeros_like(b_dh[N, :144]) if v2v else dhead0[N, :144])
         assert rel_err(b_dh[:N, :144], a_dh[:N, :144]) < 1e-6, (v2v, anchored)
         assert rel_err(b_dh[N, 144:147], a_dh[N, 144:147]) < 1e-6
         assert torch.equal(b_dh[:, 147:], dhead0[:, 147:]) and torch.equal(b_dh[:N, 144:147], dhead0[:N, 144:147])
+        if not anchored:
+            assert torch.equal(b_dh[N, 144:147], dhead0[N, 144:147])
 
 
 def test_publish_scalars_to_pinned_host_memory(L):
