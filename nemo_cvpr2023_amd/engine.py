@@ -270,7 +270,7 @@ class FitEngine:
         self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(3)]
         self.overlap_bwd = os.environ.get('NEMO_SERIAL_BWD', '0') == '0'
         self._colsums = []
-        self._seg_host = self._seg_dev = None
+        self._seg_host = self._seg_dev = self._seg_pending = None
         self.timers = None
         self.detach_articulation = False
         self.start_global_traj_anywhere = False
@@ -370,9 +370,17 @@ class FitEngine:
                  split_k, ws.data_ptr(), ws.numel() * 4, _stream()), 'nemo_gemm')
         self._event_end(ev)
 
-    def kernel_dtype(self, tag):
-        """Arithmetic type of a tagged (bench-timed) kernel's matrix-core work: bench.py prices it against that peak."""
-        return 'bf16' if self.bf16 else 'f32'
+    def kernel_flops_by_pipe(self, tag, flops):
+        """Split a tagged (bench-timed) kernel's algorithmic FLOPs by the matrix pipe they run on, so that bench.py can
+        price each part against its own peak.  fp32 build: everything on the fp32 MFMA pipe.  gemm_dtype='bf16': the
+        tagged GEMMs run on the bf16 pipe; of the fused mesh kernel only the two pose blends do (2 x 3 x 207 of its
+        2 x 3 x 207 + 2 x 288 + 288 multiply-adds per vertex and sample) -- skinning, L1 and both adjoints stay fp32."""
+        if not self.bf16:
+            return {'f32': flops}
+        if tag == 'mesh_v2v_fused':
+            blend = flops * (2 * 3 * 207) / (2 * 3 * 207 + 2 * 288 + 288)
+            return {'bf16': blend, 'f32': flops - blend}
+        return {'bf16': flops}
 
     # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
     # recorded on the stream the kernels are launched on (torch's current stream).
@@ -795,9 +803,19 @@ class FitEngine:
                 arr[i].adamw, arr[i].step = 1 if adamw else 0, t_prev
                 arr[i].step_size, arr[i].bias_corr2_sqrt = 0.0, 1.0          # (written by step_begin)
             self._seg_dev.copy_(self._seg_host, non_blocking=True)
-        # what the table holds once this step's step_begin has run
-        self._seg_shadow = [(off, numel, lr, wd, adamw, t_prev + 1) for off, numel, lr, wd, adamw, t_prev in want]
+            self._seg_shadow = want
+        # what the table holds once this step's step_begin has run: the caller confirms with adam_table_commit() AFTER the
+        # launch / replay has been enqueued (a body that raises in between leaves the shadow describing what the device
+        # really holds, and the next step re-uploads)
+        self._seg_pending = [(off, numel, lr, wd, adamw, t_prev + 1) for off, numel, lr, wd, adamw, t_prev in want]
         return n, max(s_['numel'] for s_ in segments)
+
+    def adam_table_commit(self):
+        self._seg_shadow, self._seg_pending = self._seg_pending, None
+
+    def adam_table_invalidate(self):
+        """The device table may have been advanced by a launch the host did not see complete: upload it next time."""
+        self._seg_shadow = None
 
     def step_begin(self, arena, zero_grads, n_seg=0):
         """First launch of a step: zero the workspace's accumulator arena (+ the flat gradient buffer) and, for a
@@ -832,17 +850,17 @@ class FitEngine:
     def wait_scalars(self, timeout_s=120.0):
         """Poll the pinned flag.  Steps of the sizes this engine is built for last 0.3 - 2 ms and the next launch is
         latency-critical, so the thread spins for the first 2 ms (measured: yielding the core between polls --
-        ``sleep(0)`` -- makes the step time jitter by 3 - 8 %); a wait that outlasts that (a C4-size step takes
-        > 100 ms) backs off to one poll per 50 us so that one rank per GPU does not pin eight host cores."""
+        ``sleep(0)`` -- makes the step time jitter by 3 - 8 %; the clock is read every 256th poll only); a wait that
+        outlasts that (a C4-size step takes > 100 ms) sleeps 50 us between polls so that one rank per GPU does not pin
+        eight host cores."""
         flag = self._pub_flag
-        t0, polls = None, 0
+        t0, polls = time.monotonic(), 0
         while flag[0] == 0:
             polls += 1
-            if polls & 0xFF == 0:
-                now = time.monotonic()
-                t0 = t0 or now
-                if now - t0 > 2e-3:
-                    time.sleep(5e-5)
-                    if now - t0 > timeout_s:
-                        raise _lib.NemoHipError('loss read-back flag never raised (device fault or hung kernel?)')
+            if polls & 0xFF == 0 and time.monotonic() - t0 > 2e-3:
+                break
+        while flag[0] == 0:
+            time.sleep(5e-5)
+            if time.monotonic() - t0 > timeout_s:
+                raise _lib.NemoHipError('loss read-back flag never raised (device fault or hung kernel?)')
         return self._pub_np[:8].copy()

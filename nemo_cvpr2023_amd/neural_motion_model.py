@@ -720,6 +720,18 @@ class MultiViewModel(nn.Module):
                     w['_static_src'], w['_static_vi'] = src, vi
             table = e.adam_table_sync(segs) if (in_graph_adam and part != 'head') else None
             svi, sfi = w['vi_static'][:N], w['fi_static'][:N]      # (the workspace may be larger than this batch)
+            try:
+                launch(key, svi, sfi, table, part)
+            except BaseException:
+                if table is not None:
+                    e.adam_table_invalidate()     # step_begin may or may not have advanced the device table
+                raise
+            if table is not None:
+                e.adam_table_commit()
+            if part != 'head':
+                vi, fi = svi, sfi
+
+        def launch(key, svi, sfi, table, part):
             entry = w['graphs'].get(key)
             if entry == 'eager':
                 body(svi, sfi, table, part)
@@ -747,8 +759,6 @@ class MultiViewModel(nn.Module):
                         w['graphs'][key] = entry = g
                 if entry != 'eager':
                     entry.replay()
-            if part != 'head':
-                vi, fi = svi, sfi
 
         need_adam = update and not (graphable and in_graph_adam)
         if split:
