@@ -77,7 +77,8 @@ int32_t nemo_colsum_multi(int32_t n, const nemo_colsum_desc* descs /* HOST array
  * evaluated per sample.  raw_phase (N) optional: overrides linspace(0,1,T)[frame_idx].
  * kernel_id: 0 quadratic 1 linear 2 gaussian 3 inverse_quadratic 4 multiquadric
  *            5 inverse_multiquadric 6 spline 7 poisson_one 8 poisson_two 9 matern32 10 matern52.
- * phase_out (N) receives the warped phase (saved for backward).  shifts/scales row v starts at
+ * phase_out (N) receives the warped phase (saved for backward); den_out (N, optional) the denominator
+ * o - z + 1e-6 of monotonic_network.py:39 (what nemo_phase_embed_bwd takes as `ws`).  shifts/scales row v starts at
  * shifts + v*ldp / scales + v*ldp (ldp = 2K when the V networks are stored [sh_0|sc_0|sh_1|...]).
  * code_noise (N,C) optional: additive instance-code noise of NemoV3/V4 (:3921-3923).
  */
@@ -85,11 +86,13 @@ int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t
                              const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
                              const float* shifts, const float* scales, int64_t ldp,
                              const float* log_sigmas, const float* codes, const float* code_noise,
-                             int32_t kernel_id, float* X, int64_t ldx, float* phase_out, void* stream);
+                             int32_t kernel_id, float* X, int64_t ldx, float* phase_out, float* den_out,
+                             void* stream);
 /* dX (N+1, ldx) -> d_shifts,d_scales (V rows of stride ldp), d_log_sigmas (D), d_codes (V,C); all
  * accumulated.  One launch: blocks of 32 samples reduce their per-sample coefficients per (view, node) in
  * LDS and add one partial per run of samples of a view; further blocks reduce the log_sigma / code columns.
- * ws: unused since round 2 (scratch of the former three-launch version), may be NULL. */
+ * ws (N floats, optional): the `den_out` the forward call wrote for the SAME inputs (the backward then skips two
+ * K-long sigmoid sums per sample); NULL: they are re-evaluated here. */
 int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
                              const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
                              const float* shifts, const float* scales, int64_t ldp,
@@ -173,13 +176,21 @@ int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R, const flo
  * (V,T,25,3) = (x, y, conf); gt_size (V,T).  loss_type: 0 mse_robust 1 mse 2 rmse 3 rmse_robust
  * 4 mse_robust_resized 5 rmse_resized.  Outputs (each may be NULL): j3d (N,n_out,3), p2d (N,n_out,2),
  * loss_all (N,n_out,W) with W=2 (mse*) or 1 (rmse*); view_acc (V,2) += [sum(loss*conf), #samples].
+ *
+ * PADDED BATCHES (n_valid, also on nemo_kp_bwd_ex / nemo_kl_fwd_bwd / nemo_gmm_fwd_bwd / nemo_pose3d_fwd_bwd /
+ * nemo_v2v_prep_fwd): a DEVICE scalar or NULL.  Samples s >= *n_valid are padding (a rank's share of a random
+ * minibatch rounded up to a fixed launch size, so that one captured HIP graph serves every share of that size,
+ * scripts/learned_multi_view_recon_nn.py:291-296 sharded by instance): they carry valid indices, run through every
+ * kernel, but contribute no loss, are not counted in any per-view / per-sample normaliser's sample count, and
+ * receive exactly-zero gradients.  Kernels that divide by N keep dividing by the N they are launched with: the caller
+ * folds N_launch / N_global into the weight it passes.
  */
 int32_t nemo_kp_fwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A, const float* Jp,
                     const float* Mq, int64_t ldq, const float* TR, int64_t ldt, int32_t add_trans,
                     const int64_t* view_idx, const int64_t* frame_idx, const float* cams,
                     const float* targets, const float* gt_size, float focal, float cx, float cy,
                     int32_t loss_type, int32_t mean_mode, float* j3d, float* p2d, float* loss_all,
-                    float* view_acc, void* stream);
+                    float* view_acc, const int64_t* n_valid, void* stream);
 /* mean_mode 0 (step, :3551-3558): *scalar_out += (1/n_U) sum_{v present} view_acc[v,0] /
  * (view_acc[v,1]*n_out*W), norm[0] = n_U.  mean_mode 1 (camera_fitting_loss, :2845-2867): plain mean
  * over all N*n_out*W elements of loss_all (no confidence weight), norm[0] = N.  norm is a device
@@ -206,7 +217,7 @@ int32_t nemo_kp_bwd_ex(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, con
                        const float* targets, const float* gt_size, float focal, float cx, float cy,
                        int32_t loss_type, int32_t mean_mode, const float* view_acc, const float* norm,
                        float upstream, float* dA, float* dJp, float* dMq, float* dTR, int64_t lddt,
-                       float* d_cams, const float* dj3d_extra, void* stream);
+                       float* d_cams, const float* dj3d_extra, const int64_t* n_valid, void* stream);
 /* Temporal smoothness of the output joints (an OPTIONAL term, not part of the published NemoV* step; formula
  * of humor/humor/fitting/fitting_loss.py:366-370): j3d (V*T, J, 3) laid out (view, frame);
  * *scalar_out += 0.5 * sum_{v,t<T-1,j} |j3d[v,t+1,j] - j3d[v,t,j]|^2;  dj3d (same shape, optional) = weight *
@@ -255,9 +266,10 @@ int32_t nemo_v2v_fused_bf16(const nemo_ctx* ctx, int64_t N, const float* PF2, in
                             void* stream);
 /* Builds the (2N,24,9) rotation set of the two bodies from the MLP pose:
  * rows<N: [R[:,0], Rodrigues(aa[:,3:72])], rows>=N: [R[:,0], Rodrigues(cat(aa_dec, aa[:,66:72]))]
- * (:2783-2791, hmr/geometry.py:9-45). */
+ * (:2783-2791, hmr/geometry.py:9-45).  Padding samples (see nemo_kp_fwd) get the FIRST body twice: the full-mesh
+ * L1 term and its gradient are then exactly zero for them. */
 int32_t nemo_v2v_prep_fwd(int64_t N, const float* R, const float* aa, const float* aa_dec, float* R2,
-                          void* stream);
+                          const int64_t* n_valid, void* stream);
 /* dR2 (N,24,9) -> d_aa (N,72) += scale * J^T dR2[:,1:],  dR (N,24,9)[:,0] += scale * dR2[:,0]. */
 int32_t nemo_v2v_prep_bwd(int64_t N, const float* aa, const float* dR2, float scale, float* d_aa,
                           float* dR, void* stream);
@@ -274,7 +286,7 @@ int32_t nemo_v2v_prep_bwd(int64_t N, const float* aa, const float* dR2, float sc
  * *host_flag before enqueueing and polls it; kernels enqueued after this one keep running meanwhile. */
 int32_t nemo_publish_scalars(const float* src, int32_t n, float* host_dst, int32_t* host_flag, void* stream);
 int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int64_t ld, float* scalar_out,
-                        float* d_mulv, int64_t ldd, void* stream);
+                        float* d_mulv, int64_t ldd, const int64_t* n_valid, void* stream);
 /* MaxMixturePrior (hmr/smplify/prior.py:181-196): per-sample min over M Gaussians, mean over N.
  * x (N, ldx) uses `dim` columns.  means (M,dim), precisions (M,dim,dim) SYMMETRIC (inverses of covariance
  * matrices; symmetrise (P+P^T)/2 on the host if in doubt), log_nllw (M) = log(nll_weights).
@@ -283,13 +295,13 @@ int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int64_t ld, flo
 int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const float* x, int64_t ldx,
                          const float* means, const float* precisions, const float* log_nllw,
                          float* ws, float* scalar_out, float* per_sample, float scale, float* d_x,
-                         int64_t lddx, void* stream);
+                         int64_t lddx, const int64_t* n_valid, void* stream);
 /* Robust 3-D pose loss used by warmup / NemoV3+ (:3489-3491, :3870-3882): mean over (N*dim) of
  * (mask>0.5) * GMoF(x - target).  scalar_out += mean; d_x += scale * grad. */
 int32_t nemo_pose3d_fwd_bwd(int64_t N, int64_t dim, const float* x, int64_t ldx, const float* target,
                             const float* mask, const int64_t* view_idx, const int64_t* frame_idx,
                             int64_t T, float* scalar_out, float scale, float* d_x, int64_t lddx,
-                            void* stream);
+                            const int64_t* n_valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused multi-segment Adam / AdamW over one flat parameter buffer (torch.optim.Adam semantics,

@@ -38,7 +38,7 @@ SIGNATURES = {
     'nemo_colsum_f32': (i32, [ptr, i64, i64, i64, ptr, ptr]),
     'nemo_colsum_multi': (i32, [i32, POINTER(ColsumDesc), ptr]),
     'nemo_phase_embed_fwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
-                                   i32, ptr, i64, ptr, ptr]),
+                                   i32, ptr, i64, ptr, ptr, ptr]),
     'nemo_phase_embed_bwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i32, ptr,
                                    ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr]),
     'nemo_rot6d_fwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr]),
@@ -61,12 +61,12 @@ SIGNATURES = {
     'nemo_fk_fwd': (i32, [ptr, i64, ptr, ptr, ptr, ptr, i64, ptr]),
     'nemo_fk_bwd': (i32, [ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr]),
     'nemo_kp_fwd': (i32, [ptr, i64, i64, i64, ptr, ptr, ptr, i64, ptr, i64, i32, ptr, ptr, ptr, ptr, ptr,
-                          f32, f32, f32, i32, i32, ptr, ptr, ptr, ptr, ptr]),
+                          f32, f32, f32, i32, i32, ptr, ptr, ptr, ptr, ptr, ptr]),
     'nemo_kp_finalize': (i32, [i64, i64, i32, i32, ptr, ptr, ptr, ptr]),
     'nemo_kp_bwd': (i32, [ptr, i64, i64, i64, ptr, ptr, ptr, i64, ptr, i64, i32, ptr, ptr, ptr, ptr, ptr,
                           f32, f32, f32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i64, ptr, ptr]),
     'nemo_kp_bwd_ex': (i32, [ptr, i64, i64, i64, ptr, ptr, ptr, i64, ptr, i64, i32, ptr, ptr, ptr, ptr, ptr,
-                             f32, f32, f32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr]),
+                             f32, f32, f32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, ptr]),
     'nemo_smooth_fwd_bwd': (i32, [i64, i64, i64, ptr, f32, ptr, ptr, ptr]),
     'nemo_project': (i32, [i64, i64, i64, ptr, ptr, ptr, f32, f32, f32, ptr, ptr]),
     'nemo_skin_vertices': (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, ptr]),
@@ -74,12 +74,12 @@ SIGNATURES = {
     'nemo_v2v_fused_ws_bytes': (i64, [ptr, i64]),
     'nemo_v2v_fused': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_fused_bf16': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
-    'nemo_v2v_prep_fwd': (i32, [i64, ptr, ptr, ptr, ptr, ptr]),
+    'nemo_v2v_prep_fwd': (i32, [i64, ptr, ptr, ptr, ptr, ptr, ptr]),
     'nemo_v2v_prep_bwd': (i32, [i64, ptr, ptr, f32, ptr, ptr, ptr]),
-    'nemo_kl_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, i64, ptr]),
+    'nemo_kl_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, i64, ptr, ptr]),
     'nemo_publish_scalars': (i32, [ptr, i32, ptr, ptr, ptr]),
-    'nemo_gmm_fwd_bwd': (i32, [i64, i64, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, f32, ptr, i64, ptr]),
-    'nemo_pose3d_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, f32, ptr, i64, ptr]),
+    'nemo_gmm_fwd_bwd': (i32, [i64, i64, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, f32, ptr, i64, ptr, ptr]),
+    'nemo_pose3d_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, f32, ptr, i64, ptr, ptr]),
     'nemo_adam_step': (i32, [i32, POINTER(AdamSeg), ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),
     'nemo_adam_step_dev': (i32, [i32, ptr, i64, ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),
     'nemo_sqmean_fwd_bwd': (i32, [i64, ptr, ptr, ptr, f32, ptr]),

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void phase_embed_fwd_kernel(
     const float* __restrict__ shifts, const float* __restrict__ scales, long ldp,
     const float* __restrict__ log_sigmas, const float* __restrict__ codes,
     const float* __restrict__ code_noise, int kid, float* __restrict__ X, long ldx,
-    float* __restrict__ phase_out) {
+    float* __restrict__ phase_out, float* __restrict__ den_out) {
     const long s = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (s > N) return;                      // wave-uniform
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void phase_embed_fwd_kernel(
         y = wave_sum(y) / (float)K; z = wave_sum(z) / (float)K; o = wave_sum(o) / (float)K;
         ph = (y - z) / (o - z + 1e-6f);                 // monotonic_network.py:33-39
         if (phase_out && lane == 0) phase_out[s] = ph;
+        if (den_out && lane == 0) den_out[s] = o - z + 1e-6f;
     }
     float* xr = X + s * ldx;
     if (D > 0) {
@@ -194,18 +195,22 @@ __global__ __launch_bounds__(256) void rodrigues_bwd_kernel(long M, const float*
 __global__ __launch_bounds__(256) void v2v_prep_fwd_kernel(long N, const float* __restrict__ R,
                                                            const float* __restrict__ aa,
                                                            const float* __restrict__ aa_dec,
-                                                           float* __restrict__ R2) {
+                                                           float* __restrict__ R2,
+                                                           const int64_t* __restrict__ n_valid) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * N * 24) return;
     const long row = i / 24;
     const int j = (int)(i % 24);
     const long s = row < N ? row : row - N;
+    // padding samples (s >= *n_valid): the second body repeats the first, so the full-mesh L1 term and its gradient
+    // are exactly zero for them (same arithmetic on the same inputs; sign(0) = 0)
+    const bool dec = !n_valid || s < *n_valid;
     float Rm[9];
     if (j == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rm[k] = R[s * 216 + k];
     } else {
-        const float* src = (row >= N && j <= 21) ? aa_dec + s * 63 + (j - 1) * 3 : aa + s * 72 + j * 3;
+        const float* src = (row >= N && j <= 21 && dec) ? aa_dec + s * 63 + (j - 1) * 3 : aa + s * 72 + j * 3;
         const float t[3] = {src[0], src[1], src[2]};
         rodrigues_fwd(t, Rm);
     }
@@ -321,7 +326,7 @@ extern "C" int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t
                                         const float* raw_phase, const float* shifts, const float* scales,
                                         int64_t ldp, const float* log_sigmas, const float* codes,
                                         const float* code_noise, int32_t kernel_id, float* X, int64_t ldx,
-                                        float* phase_out, void* stream) {
+                                        float* phase_out, float* den_out, void* stream) {
     if (N < 0 || V <= 0 || K <= 0 || D < 0 || C < 0 || !X || !shifts || !scales) return NEMO_EINVAL;
     if (N > 0 && (!view_idx || (!frame_idx && !raw_phase))) return NEMO_EINVAL;
     if ((D > 0 && !log_sigmas) || (C > 0 && !codes) || kernel_id < 0 || kernel_id > 10) return NEMO_EINVAL;
@@ -329,7 +334,7 @@ extern "C" int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t
     hipLaunchKernelGGL(phase_embed_fwd_kernel, dim3(nemo_cdiv(N + 1, 4)), dim3(256), 0, (hipStream_t)stream,
                        (long)N, (long)V, (long)T, (int)K, (int)D, (int)C, view_idx, frame_idx, raw_phase,
                        shifts, scales, (long)ldp, log_sigmas, codes, code_noise, (int)kernel_id, X, (long)ldx,
-                       phase_out);
+                       phase_out, den_out);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -345,8 +350,9 @@ __global__ __launch_bounds__(256) void phase_bwd_fused_kernel(
     long N, long V, long T, int K, int D, int C, const int64_t* __restrict__ view_idx,
     const int64_t* __restrict__ frame_idx, const float* __restrict__ raw_phase, const float* __restrict__ shifts,
     const float* __restrict__ scales, long ldp, const float* __restrict__ log_sigmas, int kid,
-    const float* __restrict__ phase, const float* __restrict__ dX, long ldx, float* __restrict__ d_shifts,
-    float* __restrict__ d_scales, float* __restrict__ d_log_sigmas, float* __restrict__ d_codes, int nAB) {
+    const float* __restrict__ phase, const float* __restrict__ den_ws, const float* __restrict__ dX, long ldx,
+    float* __restrict__ d_shifts, float* __restrict__ d_scales, float* __restrict__ d_log_sigmas,
+    float* __restrict__ d_codes, int nAB, int spb) {
     __shared__ float red[16];
     __shared__ float cx[PH_SPB], cy[PH_SPB], cz[PH_SPB], co[PH_SPB];
     __shared__ long cv[PH_SPB];
@@ -378,41 +384,50 @@ __global__ __launch_bounds__(256) void phase_bwd_fused_kernel(
         }
         return;
     }
-    // ---- stage A: a wave per sample -- d phase, then the coefficients of the three sigmoid sums of the phase network
-    const long s0 = (long)blockIdx.x * PH_SPB;
-    const int ns = (int)min((long)PH_SPB, N - s0);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int i = wid; i < ns; i += 4) {
-        const long s = s0 + i;
+    // ---- stage A: EIGHT LANES per sample, all spb <= PH_SPB samples of the block at once -- d phase, then the coefficients
+    // of the three sigmoid sums of the phase network.  With ph = num / den saved by the forward pass the backward needs
+    // den = o - z + 1e-6 only (a per-view constant: the forward kernel hands it over in den_ws; without it the two sums
+    // are re-evaluated here).  (Round 2 walked a wave's eight samples one after the other, each behind its own chain of
+    // dependent global loads and three K-long sigmoid sums: 35 us whatever N was.)
+    const long s0 = (long)blockIdx.x * spb;
+    const int ns = (int)min((long)spb, N - s0);
+    {
+        const int i = threadIdx.x >> 3, l = threadIdx.x & 7;
+        const bool live = i < ns;
+        const long s = s0 + (live ? i : 0);
+        const long v = view_idx[s];
+        const float x = raw_phase ? raw_phase[s] : lin01(frame_idx[s], T);
         const float ph = phase[s];
         const float* g = dX + s * ldx;
         float dph = 0.f;
         if (D > 0) {
-            for (int d = lane; d < D; d += 64) {
+            for (int d = l; d < D; d += 8) {
                 const float diff = ph - lin01(d, D);
-                const float es = expf(log_sigmas[d]);
-                dph += g[d] * rbf_dphi(kid, (diff * diff) / es) * 2.f * diff / es;
+                const float ies = 1.f / expf(log_sigmas[d]);
+                dph += g[d] * rbf_dphi(kid, (diff * diff) * ies) * 2.f * diff * ies;
             }
-            dph = wave_sum(dph);
-        } else {
+        } else if (l == 0) {
             dph = g[0];
         }
-        const long v = view_idx[s];
-        const float x = raw_phase ? raw_phase[s] : lin01(frame_idx[s], T);
-        const float* sh = shifts + v * ldp;
-        const float* sc = scales + v * ldp;
-        float y = 0.f, z = 0.f, o = 0.f;
-        for (int k = lane; k < K; k += 64) {
-            const float shp = fmaxf(sh[k], 0.f), scp = fmaxf(sc[k], 0.f);
-            y += sigmoidf_(scp * (x - shp));
-            z += sigmoidf_(scp * (0.f - shp));
-            o += sigmoidf_(scp * (1.f - shp));
+        float z = 0.f, o = 0.f;
+        if (!den_ws) {
+            const float* sh = shifts + v * ldp;
+            const float* sc = scales + v * ldp;
+            for (int k = l; k < K; k += 8) {
+                const float shp = fmaxf(sh[k], 0.f), scp = fmaxf(sc[k], 0.f);
+                z += sigmoidf_(scp * (0.f - shp));
+                o += sigmoidf_(scp * (1.f - shp));
+            }
         }
-        y = wave_sum(y) / (float)K; z = wave_sum(z) / (float)K; o = wave_sum(o) / (float)K;
-        const float den = o - z + 1e-6f, num = y - z;
+#pragma unroll
+        for (int off = 4; off > 0; off >>= 1) {
+            dph += __shfl_xor(dph, off, 64);
+            z += __shfl_xor(z, off, 64);     o += __shfl_xor(o, off, 64);
+        }
+        const float den = den_ws ? den_ws[s] : o / (float)K - z / (float)K + 1e-6f;
         const float dy = dph / den;                          // ph = num / den
-        const float dden = -dph * num / (den * den);
-        if (lane == 0) {
+        const float dden = -dy * ph;                         // -dph * num / den^2
+        if (l == 0 && live) {
             const float invK = 1.f / (float)K;
             cx[i] = x; cy[i] = dy * invK; cz[i] = (-dy - dden) * invK; co[i] = dden * invK; cv[i] = v;
         }
@@ -461,16 +476,19 @@ extern "C" int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t
                                         float* d_codes, void* stream) {
     if (N < 0 || V <= 0 || K <= 0 || D < 0 || C < 0 || !dX || !shifts || !scales || !phase) return NEMO_EINVAL;
     if ((d_shifts == nullptr) != (d_scales == nullptr)) return NEMO_EINVAL;
-    (void)ws;                           // (scratch of the former three-launch version; may be NULL)
     hipStream_t st = (hipStream_t)stream;
-    const long nAB = (d_shifts && N > 0) ? nemo_cdiv(N, PH_SPB) : 0;
+    // samples per stage-A/B block: short node loops for small batches (a one-instance shard: 38 blocks of 8 samples
+    // instead of 10 blocks whose threads walk 32 samples each), fewer atomics for large ones
+    const int spb = N <= 1024 ? 8 : PH_SPB;
+    const long nAB = (d_shifts && N > 0) ? nemo_cdiv(N, spb) : 0;
     // blocks [nAB, nAB + D) reduce log_sigma columns; if d_log_sigmas is NULL they are still launched (as no-ops) so
     // that the block -> column map stays fixed
     const long nC = (d_log_sigmas || d_codes) ? D + (d_codes ? V * C : 0) : 0;
     if (nAB + nC == 0) return NEMO_OK;
     hipLaunchKernelGGL(phase_bwd_fused_kernel, dim3((unsigned)(nAB + nC)), dim3(256), 0, st, (long)N, (long)V, (long)T,
                        (int)K, (int)D, (int)C, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp, log_sigmas,
-                       (int)kernel_id, phase, dX, (long)ldx, d_shifts, d_scales, d_log_sigmas, d_codes, (int)nAB);
+                       (int)kernel_id, phase, (const float*)ws, dX, (long)ldx, d_shifts, d_scales, d_log_sigmas, d_codes,
+                       (int)nAB, spb);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -538,10 +556,10 @@ extern "C" int32_t nemo_rodrigues_bwd(int64_t M, const float* theta, const float
 }
 
 extern "C" int32_t nemo_v2v_prep_fwd(int64_t N, const float* R, const float* aa, const float* aa_dec,
-                                     float* R2, void* stream) {
+                                     float* R2, const int64_t* n_valid, void* stream) {
     if (N < 0 || !R || !aa || !aa_dec || !R2) return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
-    hipLaunchKernelGGL(v2v_prep_fwd_kernel, GRID1D(2 * N * 24), (long)N, R, aa, aa_dec, R2);
+    hipLaunchKernelGGL(v2v_prep_fwd_kernel, GRID1D(2 * N * 24), (long)N, R, aa, aa_dec, R2, n_valid);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -8,14 +8,20 @@ namespace {
 // KL(N(mu, s) || N(0,1)) = 0.5 (s^2 + mu^2 - 1 - log s^2),  s = softplus(lv)
 // (torch.distributions.kl._kl_normal_normal; vposer_model.py:55; nemo/neural_motion_model.py:2795-2802)
 __global__ __launch_bounds__(256) void kl_kernel(long N, int L, const float* __restrict__ mulv, long ld,
-                                                 float* __restrict__ out, float* __restrict__ d, long ldd) {
+                                                 float* __restrict__ out, float* __restrict__ d, long ldd,
+                                                 const int64_t* __restrict__ n_valid) {
     __shared__ float red[16];
     float acc = 0.f;
     const long total = N * L;
     const float invN = 1.f / (float)N;
+    const long nv = n_valid ? min((long)*n_valid, N) : N;      // rows >= nv are padding: no loss, zero gradient
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long s = i / L;
         const int k = (int)(i % L);
+        if (s >= nv) {
+            if (d) { d[s * ldd + k] = 0.f; d[s * ldd + L + k] = 0.f; }
+            continue;
+        }
         const float mu = mulv[s * ld + k], lv = mulv[s * ld + L + k];
         // F.softplus (beta=1, threshold=20)
         const float sp = lv > 20.f ? lv : log1pf(expf(lv));
@@ -81,14 +87,15 @@ __global__ __launch_bounds__(GMM_TS) void gmm_grad_kernel(long N, int M, const f
                                                           const float* __restrict__ ll,
                                                           float* __restrict__ out,
                                                           float* __restrict__ per_sample, float coef,
-                                                          float* __restrict__ dx, long lddx) {
+                                                          float* __restrict__ dx, long lddx,
+                                                          const int64_t* __restrict__ n_valid) {
     __shared__ __attribute__((aligned(16))) float Ps[DIM][72];
     __shared__ float xs[DIM][GMM_TS];
     __shared__ float red[16];
     __shared__ int any_sel;
     const int tid = threadIdx.x, m = blockIdx.y;
     const long s = (long)blockIdx.x * GMM_TS + tid;
-    const bool live = s < N;
+    const bool live = s < (n_valid ? min((long)*n_valid, N) : N);     // (padding rows: no loss, no gradient)
     float best = 0.f;
     int best_m = -1;
     if (live) {
@@ -142,14 +149,15 @@ __global__ __launch_bounds__(256) void gmm_mfma_kernel(long N, int M, const floa
                                                        const float* __restrict__ prec,
                                                        const float* __restrict__ log_nllw,
                                                        float* __restrict__ out, float* __restrict__ per_sample,
-                                                       float coef, float* __restrict__ dx, long lddx) {
+                                                       float coef, float* __restrict__ dx, long lddx,
+                                                       const int64_t* __restrict__ n_valid) {
     constexpr int DIM = 69;
     __shared__ float llw[8][16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
     const long s = (long)blockIdx.x * 16 + l15;
-    const bool live = s < N;
+    const bool live = s < (n_valid ? min((long)*n_valid, N) : N);     // (padding rows: no loss, no gradient)
     const float* xr = x + (live ? s : 0) * ldx;
     // B-operand source: d[k][n] for k = 4 kk + g (zero beyond DIM); also d_i in the accumulator layout
     float xk[18];
@@ -254,15 +262,18 @@ __global__ __launch_bounds__(256) void pose3d_kernel(long N, int dim, const floa
                                                      const int64_t* __restrict__ view_idx,
                                                      const int64_t* __restrict__ frame_idx, long T,
                                                      float* __restrict__ out, float scale,
-                                                     float* __restrict__ dx, long lddx) {
+                                                     float* __restrict__ dx, long lddx,
+                                                     const int64_t* __restrict__ n_valid) {
     __shared__ float red[16];
     const long total = N * dim;
     const float inv = 1.f / (float)total;
     const float rho2 = 10000.f;
+    const long nv = n_valid ? min((long)*n_valid, N) : N;
     float acc = 0.f;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long s = i / dim;
         const int k = (int)(i % dim);
+        if (s >= nv) continue;                                  // padding row
         const long vt = view_idx[s] * T + frame_idx[s];
         const float m = mask[vt] > 0.5f ? 1.f : 0.f;
         const float r = x[s * ldx + k] - target[vt * dim + k];
@@ -373,12 +384,12 @@ extern "C" int32_t nemo_publish_scalars(const float* src, int32_t n, float* host
 }
 
 extern "C" int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int64_t ld, float* scalar_out,
-                                   float* d_mulv, int64_t ldd, void* stream) {
+                                   float* d_mulv, int64_t ldd, const int64_t* n_valid, void* stream) {
     if (N <= 0 || L <= 0 || !mulv || !scalar_out || ld < 2 * L || (d_mulv && ldd < 2 * L)) return NEMO_EINVAL;
     int blocks = nemo_cdiv(N * L, 256);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(kl_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)N, (int)L, mulv,
-                       (long)ld, scalar_out, d_mulv, (long)ldd);
+                       (long)ld, scalar_out, d_mulv, (long)ldd, n_valid);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -386,7 +397,7 @@ extern "C" int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int6
 extern "C" int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const float* x, int64_t ldx,
                                     const float* means, const float* precisions, const float* log_nllw,
                                     float* ws, float* scalar_out, float* per_sample, float scale, float* d_x,
-                                    int64_t lddx, void* stream) {
+                                    int64_t lddx, const int64_t* n_valid, void* stream) {
     if (N <= 0 || M <= 0 || !x || !means || !precisions || !log_nllw || !scalar_out || !ws || ldx < dim)
         return NEMO_EINVAL;
     if (dim != 69) return NEMO_EINVAL;   // SMPL body pose (23 joints x 3), prior.py:150
@@ -394,7 +405,7 @@ extern "C" int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const flo
     if (M <= 8) {
         hipLaunchKernelGGL(gmm_mfma_kernel, dim3(nemo_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, (long)N,
                            (int)M, x, (long)ldx, means, precisions, log_nllw, scalar_out, per_sample,
-                           scale / (float)N, d_x, (long)lddx);
+                           scale / (float)N, d_x, (long)lddx, n_valid);
         NEMO_LAUNCH_CHECK();
         return NEMO_OK;
     }
@@ -404,7 +415,7 @@ extern "C" int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const flo
     NEMO_LAUNCH_CHECK();
     hipLaunchKernelGGL(gmm_grad_kernel<69>, grid, dim3(GMM_TS), 0, (hipStream_t)stream, (long)N, (int)M, x,
                        (long)ldx, means, precisions, ws, scalar_out, per_sample, scale / (float)N, d_x,
-                       (long)lddx);
+                       (long)lddx, n_valid);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -412,13 +423,13 @@ extern "C" int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const flo
 extern "C" int32_t nemo_pose3d_fwd_bwd(int64_t N, int64_t dim, const float* x, int64_t ldx,
                                        const float* target, const float* mask, const int64_t* view_idx,
                                        const int64_t* frame_idx, int64_t T, float* scalar_out, float scale,
-                                       float* d_x, int64_t lddx, void* stream) {
+                                       float* d_x, int64_t lddx, const int64_t* n_valid, void* stream) {
     if (N <= 0 || dim <= 0 || !x || !target || !mask || !view_idx || !frame_idx || !scalar_out) return NEMO_EINVAL;
     int blocks = nemo_cdiv(N * dim, 256);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(pose3d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)N, (int)dim, x,
                        (long)ldx, target, mask, view_idx, frame_idx, (long)T, scalar_out, scale, d_x,
-                       (long)lddx);
+                       (long)lddx, n_valid);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -467,6 +467,7 @@ struct KpArgs {
     const float *cams, *targets, *gt_size;
     float focal, cx, cy;
     int add_trans, loss_type, mean_mode;
+    const int64_t* n_valid;      // device scalar (or NULL): samples >= *n_valid are padding -- no loss, not counted, no gradient
 };
 
 __device__ __forceinline__ int loss_width(int loss_type) { return (loss_type == 2 || loss_type == 3 || loss_type == 5) ? 1 : 2; }
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(256) void kp_fwd_kernel(KpArgs a, KpConst kc, float
     float wsum = 0.f;
     long v = 0;
     if (s < a.N) v = a.view_idx[s];
+    const bool pad = a.n_valid && s >= *a.n_valid;
     if (active) {
         float pos[3];
         kp_joint(a, kc, s, o, Al[threadIdx.x / LANES], pos);
@@ -601,6 +603,7 @@ __global__ __launch_bounds__(256) void kp_fwd_kernel(KpArgs a, KpConst kc, float
             const float size = a.gt_size ? a.gt_size[v * a.T + f] : 1.f;
             float l[2], du, dv;
             kp_loss_eval(a.loss_type, u, w, g[0], g[1], g[2], size, l, &du, &dv);
+            if (pad) { l[0] = 0.f; l[1] = 0.f; }
             const int W = loss_width(a.loss_type);
             if (loss_all) {
                 loss_all[(s * kc.n_out + o) * W] = l[0];
@@ -617,7 +620,7 @@ __global__ __launch_bounds__(256) void kp_fwd_kernel(KpArgs a, KpConst kc, float
         __shared__ long bview[SPB];
         if (LANES == 32) wsum = group32_sum(wsum);
         const int sl = threadIdx.x / LANES;
-        if (o == 0) { bsum[sl] = wsum; bview[sl] = s < a.N ? v : -1; }
+        if (o == 0) { bsum[sl] = wsum; bview[sl] = (s < a.N && !pad) ? v : -1; }
         __syncthreads();
         if (threadIdx.x < SPB && bview[threadIdx.x] >= 0) {
             const long mv = bview[threadIdx.x];
@@ -681,11 +684,12 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
     }
     long v = 0;
     if (live) v = a.view_idx[s];
+    const bool pad = a.n_valid && s >= *a.n_valid;
     float dpos[3] = {0.f, 0.f, 0.f};
     float dcam[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int kind = 0;
-    if (active) {
-        kind = kc.out_kind[o];
+    if (active) kind = kc.out_kind[o];
+    if (active && !pad) {
         float pos[3];
         kp_joint(a, kc, s, o, Al[threadIdx.x / LANES], pos);
         if (a.add_trans) {
@@ -1552,6 +1556,7 @@ static int kp_args(const nemo_ctx* ctx, KpArgs& a, int64_t N, int64_t V, int64_t
     a.ldq = ldq; a.ldt = ldt; a.view_idx = view_idx; a.frame_idx = frame_idx; a.cams = cams;
     a.targets = targets; a.gt_size = gt_size; a.focal = focal; a.cx = cx; a.cy = cy;
     a.add_trans = add_trans; a.loss_type = loss_type; a.mean_mode = mean_mode;
+    a.n_valid = nullptr;
     return NEMO_OK;
 }
 
@@ -1560,11 +1565,12 @@ extern "C" int32_t nemo_kp_fwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_
                                int32_t add_trans, const int64_t* view_idx, const int64_t* frame_idx,
                                const float* cams, const float* targets, const float* gt_size, float focal,
                                float cx, float cy, int32_t loss_type, int32_t mean_mode, float* j3d,
-                               float* p2d, float* loss_all, float* view_acc, void* stream) {
+                               float* p2d, float* loss_all, float* view_acc, const int64_t* n_valid, void* stream) {
     KpArgs a;
     const int rc = kp_args(ctx, a, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams,
                            targets, gt_size, focal, cx, cy, loss_type, mean_mode);
     if (rc) return rc;
+    a.n_valid = n_valid;
     if (N == 0) return NEMO_OK;
     if (ctx->n_out > 32) return NEMO_EINVAL;
     hipLaunchKernelGGL(kp_fwd_kernel<32>, dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
@@ -1589,11 +1595,12 @@ static int32_t kp_bwd_impl(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T,
                                float cx, float cy, int32_t loss_type, int32_t mean_mode,
                                const float* view_acc, const float* norm, float upstream, float* dA,
                                float* dJp, float* dMq, float* dTR, int64_t lddt, float* d_cams,
-                               const float* dj3d_extra, void* stream) {
+                               const float* dj3d_extra, const int64_t* n_valid, void* stream) {
     KpArgs a;
     const int rc = kp_args(ctx, a, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams,
                            targets, gt_size, focal, cx, cy, loss_type, mean_mode);
     if (rc) return rc;
+    a.n_valid = n_valid;
     if (!targets || !view_acc) return NEMO_EINVAL;            // (norm may be NULL: derived from view_acc)
     if (dA && (!dJp || (ctx->nq > 0 && !dMq))) return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
@@ -1614,7 +1621,7 @@ extern "C" int32_t nemo_kp_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_
                                void* stream) {
     return kp_bwd_impl(ctx, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams, targets,
                        gt_size, focal, cx, cy, loss_type, mean_mode, view_acc, norm, upstream, dA, dJp, dMq, dTR,
-                       lddt, d_cams, nullptr, stream);
+                       lddt, d_cams, nullptr, nullptr, stream);
 }
 
 extern "C" int32_t nemo_kp_bwd_ex(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A,
@@ -1624,10 +1631,10 @@ extern "C" int32_t nemo_kp_bwd_ex(const nemo_ctx* ctx, int64_t N, int64_t V, int
                                   float cx, float cy, int32_t loss_type, int32_t mean_mode,
                                   const float* view_acc, const float* norm, float upstream, float* dA,
                                   float* dJp, float* dMq, float* dTR, int64_t lddt, float* d_cams,
-                                  const float* dj3d_extra, void* stream) {
+                                  const float* dj3d_extra, const int64_t* n_valid, void* stream) {
     return kp_bwd_impl(ctx, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams, targets,
                        gt_size, focal, cx, cy, loss_type, mean_mode, view_acc, norm, upstream, dA, dJp, dMq, dTR,
-                       lddt, d_cams, dj3d_extra, stream);
+                       lddt, d_cams, dj3d_extra, n_valid, stream);
 }
 
 extern "C" int32_t nemo_smooth_fwd_bwd(int64_t V, int64_t T, int64_t J, const float* j3d, float weight,

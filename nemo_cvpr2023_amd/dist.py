@@ -17,6 +17,21 @@ SURVEY.md 8(e):
 ``backend='nccl'`` is RCCL on ROCm.  xGMI is point-to-point: a 9 MB buffer is latency-, not
 bandwidth-bound, so the default is exactly one collective per step and nothing else on the data path.
 
+``shard_mode='buckets'`` (round 3): the shared gradient is reduced in THREE buckets -- [heads + layer 4], [layer 2],
+[layer 0 + RBF widths + the 8 loss scalars]: contiguous slices of the flat gradient buffer, laid out in the order the
+backward completes them (``engine.ParamLayout.buckets``) -- each issued on a communication stream as soon as its
+parameter-gradient GEMMs and bias column sums have run, with the fused Adam of the bucket right behind its collective
+on that stream, while the main stream goes on with the rest of the backward.  The step is then three launches (graphs
+cut at the bucket boundaries).  What this buys depends on the machine: the MLP backward is the LAST ~15 % of a step, so
+at most the first two collectives hide under compute, against two more launch boundaries -- ``bench.py --shard-mode
+auto`` times all modes on the box it runs on.
+
+Random minibatches (the published run's mode: batch 512, ``run_scripts_examples/nemomocap-example.sh:17``): a rank's
+share of a global draw changes size every step, and a captured HIP graph is per launch size.  Shares are therefore
+LAUNCHED at the next multiple of ``pad`` (default 32) samples with masked padding rows (``include/nemo_hip.h``,
+nemo_kp_fwd: valid indices, no loss, not counted, exactly-zero gradients) and the per-sample means are taken with
+``mr = N_launch / N_global``: two or three graphs serve a whole run at any world size.
+
 Opt-in ``shard_mode='split'`` (``ShardedNemo.set_shard_mode`` / ``NEMO_SHARD_SPLIT=1``): a second, 32-byte
 all-reduce of the loss scalars is issued on a side stream as soon as they are final (a third of a step before
 the gradient is), so the host holds the global losses early and prepares the next launch under the rest of the
@@ -116,7 +131,8 @@ class ShardedNemo:
         state = make_init_state(args, version, self.V, multi_view_seqs.IMG_D0)    # identical on all ranks
         local = SequenceSubset(multi_view_seqs, self.plan.lo, self.plan.hi)
         self.model = NEMO_VERSIONS[version](args, local, device, **assets)
-        self.model.GRAPH_AFTER = 2       # a rank's share of a random minibatch changes size from step to step
+        # a rank's share of a random minibatch changes size from step to step: launched at multiples of `pad` samples
+        self.pad = int(os.environ.get('NEMO_SHARD_PAD', '32'))
         self.model.load_state_dict({k: v for k, v in slice_state(state, self.plan.lo, self.plan.hi).items()},
                                    strict=False)
         torch.manual_seed(seed + 1)       # re-synchronise the index stream across ranks
@@ -129,8 +145,9 @@ class ShardedNemo:
 
     def set_shard_mode(self, mode):
         """'single': one all-reduce per step (gradient + loss scalars).  'split': + an early 32-byte all-reduce
-        of the loss scalars on the side stream.  Must be the same on every rank."""
-        if mode not in ('single', 'split'):
+        of the loss scalars on the side stream.  'buckets': three gradient buckets, each reduced (and Adam-stepped) on a
+        communication stream as soon as the backward has completed it.  Must be the same on every rank."""
+        if mode not in ('single', 'split', 'buckets'):
             raise ValueError(mode)
         self.shard_mode = mode
 
@@ -143,9 +160,10 @@ class ShardedNemo:
     def _comm_small(self, buf):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
 
-    def _info(self, d):
+    def _info(self, d, pad=0):
         return ShardInfo(kr=d['kr'], mr=d['mr'], vr=d['vr'], n_global=d['n_global'], comm=self._comm,
-                         comm_small=self._comm_small if self.shard_mode == 'split' else None)
+                         comm_small=self._comm_small if self.shard_mode == 'split' else None,
+                         comm_bucket=self._comm_small if self.shard_mode == 'buckets' else None, pad=pad)
 
     def _sharder(self):
         """Draw the GLOBAL (view, frame) batch from the CPU RNG (identical on every rank) and keep
@@ -157,7 +175,7 @@ class ShardedNemo:
     def step(self, view_idx, frame_idx, update=True, full_batch=False):
         if self.args.batch_size > -1 and not full_batch:
             lv, lf, d = self.plan.route(view_idx, frame_idx)
-            return self.model.step(lv, lf, update=update, _shard=self._info(d))
+            return self.model.step(lv, lf, update=update, _shard=self._info(d, pad=self.pad))
         return self.model.step(None, None, update=update, full_batch=True,
                                _shard=self._info(self.plan.full_batch()))
 

@@ -172,6 +172,11 @@ class ParamLayout:
                 off += int(np.prod(shapes[name]))
             self.total = (off + 3) // 4 * 4
             return
+        # Memory order of the shared (all-reduced) block = the order in which the backward FINISHES its gradients, last
+        # first: [log_sigmas | 8 comm scalars | layer 0 | layer 2 | layer 4 | heads].  The three gradient buckets of the
+        # overlapped all-reduce (dist.py) are then contiguous slices: heads + layer 4 (ready first), layer 2, and
+        # layer 0 + RBF widths + the loss scalars (ready last) -- see `buckets()`.
+        front = len(order)
         for lname, (fo, fi) in (('net.net.0', (h, din)), ('net.net.2', (h, h)), ('net.net.4', (h, h))):
             reg('motion', f'{lm}{lname}.weight', (fo, fi))
             reg('motion', f'{lm}{lname}.bias', (fo,))
@@ -180,9 +185,12 @@ class ParamLayout:
             reg('motion', f'{lm}{lname}.bias', (fo,), place=False)
         order += [lm + 'rot_out.weight', lm + 'linear_out.weight', lm + 'rot_out.bias', lm + 'linear_out.bias']
         if D > 0:
-            reg('motion', 'phase_rbf.log_sigmas', (D,))
+            reg('motion', 'phase_rbf.log_sigmas', (D,), place=False)
+            order.insert(front, 'phase_rbf.log_sigmas')
+            front += 1
         # 8 floats that travel with the shared-gradient all-reduce (loss scalars); no optimiser owns them
-        reg('comm', '_comm_scalars', (8,))
+        reg('comm', '_comm_scalars', (8,), place=False)
+        order.insert(front, '_comm_scalars')
         for i in range(V):
             reg('phase', f'phase_networks.{i}.shifts', (K,))
             reg('phase', f'phase_networks.{i}.scales', (K,))
@@ -197,6 +205,20 @@ class ParamLayout:
             self.entries[name] = (off, shapes[name])
             off += int(np.prod(shapes[name]))
         self.total = (off + 3) // 4 * 4
+
+    def buckets(self):
+        """Contiguous [start, end) slices of the shared gradient block in the order the backward completes them."""
+        lm = 'learned_motion.'
+        first = [lm + 'net.net.4.weight', lm + 'net.net.4.bias', lm + 'rot_out.weight', lm + 'linear_out.weight',
+                 lm + 'rot_out.bias', lm + 'linear_out.bias']
+        mid = [lm + 'net.net.2.weight', lm + 'net.net.2.bias']
+        last = [n for n in ('phase_rbf.log_sigmas',) if n in self.entries] + \
+               ['_comm_scalars', lm + 'net.net.0.weight', lm + 'net.net.0.bias']
+        out = [self.span(first), self.span(mid), self.span(last)]
+        a, b = self.span(self.groups['motion'] + self.groups['comm'])
+        pad = lambda x: (x + 3) // 4 * 4
+        assert out[2][0] == a and pad(out[2][1]) == out[1][0] and pad(out[1][1]) == out[0][0] and out[0][1] == b, out
+        return out
 
     def span(self, names):
         a = min(self.entries[n][0] for n in names)
@@ -266,6 +288,7 @@ class FitEngine:
         self.ws = {}
         self.side_stream = torch.cuda.Stream(device=self.device)   # prior branches of the step (see _forward_backward)
         self.side_stream2 = torch.cuda.Stream(device=self.device)
+        self.comm_stream = torch.cuda.Stream(device=self.device)    # bucketed gradient all-reduces + their Adam (dist.py)
         # split-K scratch of nemo_gemm_f32 (arrival tickets + partial tiles), one per stream that launches GEMMs
         self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(3)]
         self.overlap_bwd = os.environ.get('NEMO_SERIAL_BWD', '0') == '0'
@@ -274,6 +297,9 @@ class FitEngine:
         self.timers = None
         self.detach_articulation = False
         self.start_global_traj_anywhere = False
+        # device scalar 'number of real samples' of a PADDED step (include/nemo_hip.h, nemo_kp_fwd), else None; set by
+        # MultiViewModel.step around its launches only
+        self.nvalid = None
 
     # ------------------------------------------------------------------ parameter views
     def view(self, name, buf=None):
@@ -323,7 +349,7 @@ class FitEngine:
             off += n_
         w = dict(
             X=Z(N + 1, self.ldx), H1=Z(N + 1, h), H2=Z(N + 1, h), H3=Z(N + 1, h), HEAD=Z(N + 1, HEAD_LD),
-            phase=Z(N), phase_ws=Z(N, 4), gmm_ws=Z(N, self.gmm['M']), R=Z(N, 24, 9), AA=Z(N, 72), A=Z(N, 24, 12), Jp=Z(N, 24, 3),
+            phase=Z(N), phase_ws=Z(N), gmm_ws=Z(N, self.gmm['M']), R=Z(N, 24, 9), AA=Z(N, 72), A=Z(N, 24, 12), Jp=Z(N, 24, 3),
             PF=Z(N, 208), Mq=Z(N, max(nq * 72, 1)), j3d=Z(N, self.ctx.n_out, 3), p2d=Z(N, self.ctx.n_out, 2),
             loss_all=Z(N, self.ctx.n_out, 2), norm=Z(1), dj3d=Z(N, self.ctx.n_out, 3),
             E1=Z(N, 512), MULV=Z(N, 64), D1=Z(N, 512), D2=Z(N, 512),
@@ -334,8 +360,10 @@ class FitEngine:
             dR=Z(N, 24, 9), dA=Z(N, 24, 12), dMq=Z(N, max(nq * 72, 1)),
             dPF=Z(N, 208), dHEAD=Z(N + 1, HEAD_LD), dH=Z(N + 1, h), dH_b=Z(N + 1, h), dH_c=Z(N + 1, h),
             dX=Z(N + 1, self.ldx), dMULV=Z(N, 64), dE_a=Z(N, 512), Nc=Nc,
-            vi_static=torch.zeros(N, dtype=torch.long, device=self.device),
-            fi_static=torch.zeros(N, dtype=torch.long, device=self.device), graphs={})
+            # device-resident step inputs of a captured graph: the indices and (last element of vi_static) the number of
+            # real samples of a padded step
+            vi_static=torch.zeros(N + 1, dtype=torch.long, device=self.device),
+            fi_static=torch.zeros(N + 1, dtype=torch.long, device=self.device), graphs={}, cap=N)
         w.update(views)
         w['zero_arena'] = arena
         if self.version == 0:            # hidden activations of the orient and translation networks (poses: H1..H3)
@@ -369,6 +397,14 @@ class FitEngine:
         check(fn(ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias, act, mask, ldmask, mask_mode, alpha, out_mode,
                  split_k, ws.data_ptr(), ws.numel() * 4, _stream()), 'nemo_gemm')
         self._event_end(ev)
+
+    def prior_mode(self, N):
+        """How the step lays the prior terms out over the HIP streams (MultiViewModel._forward_backward): 0 = a third
+        stream for GMM / 3-D / KL (the default at every size), 1 = two streams (GMM / 3-D open the VPoser stream, KL closes
+        the main chain).  Measured at a one-instance shard, same box, un-profiled: 0.508 ms with 1 against 0.495 with 0
+        (profiles/r03_experiments.md) -- the kernel trace's late start of the third queue is a profiler artefact.
+        NEMO_PRIOR_MODE: A/B override."""
+        return int(os.environ.get('NEMO_PRIOR_MODE', '0'))
 
     def kernel_flops_by_pipe(self, tag, flops):
         """Split a tagged (bench-timed) kernel's algorithmic FLOPs by the matrix pipe they run on, so that bench.py can
@@ -429,7 +465,8 @@ class FitEngine:
             N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
             sh0, sc0, self.ldp, self.p('phase_rbf.log_sigmas') if self.D > 0 else None,
             self.p('learned_instance_code') if self.C > 0 else None, dptr(code_noise), self.kernel_id,
-            dptr(w['X']), self.ldx, dptr(w['phase']), st), 'nemo_phase_embed_fwd')
+            dptr(w['X']), self.ldx, dptr(w['phase']), dptr(w['phase_ws']), st),
+              'nemo_phase_embed_fwd')
         h, r = self.h, N + 1
         if self.version == 0:
             return self._forward_nets_v0(w, N)
@@ -532,7 +569,7 @@ class FitEngine:
             dptr(self.targets) if with_loss else None, dptr(self.gt_size) if with_loss else None,
             FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode,
             dptr(j3d if j3d is not None else w['j3d']), dptr(p2d if p2d is not None else w['p2d']),
-            dptr(w['loss_all']) if with_loss else None, dptr(w['view_acc']) if with_loss else None, st),
+            dptr(w['loss_all']) if with_loss else None, dptr(w['view_acc']) if with_loss else None, self.nvalid, st),
             'nemo_kp_fwd')
         if with_loss and finalize:
             self.finalize_kp(w, mean_mode, ctx)
@@ -573,14 +610,15 @@ class FitEngine:
     def vposer_kl(self, w, N):
         """K12: KL( N(mu, softplus(logvar)) || N(0, 1) ) and its gradient w.r.t. (mu | logvar)."""
         check(self.lib.nemo_kl_fwd_bwd(N, 32, dptr(w['MULV']), 64, self.scal.data_ptr() + 4 * S_KL,
-                                       dptr(w['dMULV']), 64, _stream()), 'nemo_kl_fwd_bwd')
+                                       dptr(w['dMULV']), 64, self.nvalid, _stream()), 'nemo_kl_fwd_bwd')
 
     def forward_v2v_pre(self, w, N):
         """The part of forward_v2v's first chunk that only needs the poses: both bodies' rotations (v2v_prep) and their
         FK.  The step runs it at the end of the VPoser stream, off the main chain (``forward_v2v(pre_done=True)``)."""
         L, st, ctx = self.lib, _stream(), self.ctx
         n = min(w['Nc'], N)
-        check(L.nemo_v2v_prep_fwd(n, dptr(w['R']), dptr(w['AA']), dptr(w['AAdec']), dptr(w['R2']), st), 'nemo_v2v_prep_fwd')
+        check(L.nemo_v2v_prep_fwd(n, dptr(w['R']), dptr(w['AA']), dptr(w['AAdec']), dptr(w['R2']), self.nvalid, st),
+              'nemo_v2v_prep_fwd')
         check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']), dptr(w['PF2']), 208, st),
               'nemo_fk_fwd')
 
@@ -597,7 +635,7 @@ class FitEngine:
             AA = w['AA'].data_ptr() + 4 * c0 * 72
             AAd = w['AAdec'].data_ptr() + 4 * c0 * 63
             if not (pre_done and c0 == 0):
-                check(L.nemo_v2v_prep_fwd(n, R, AA, AAd, dptr(w['R2']), st), 'nemo_v2v_prep_fwd')
+                check(L.nemo_v2v_prep_fwd(n, R, AA, AAd, dptr(w['R2']), self.nvalid if c0 == 0 else None, st), 'nemo_v2v_prep_fwd')
                 check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']),
                                     dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
             ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * (2 * 3 * 207 + 2 * 288 + 288))
@@ -630,7 +668,7 @@ class FitEngine:
             dptr(self.gt_size), FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode, dptr(w['view_acc']),
             None if norm_from_acc else dptr(w['norm']), upstream, None if cams_only else dptr(w['dA']),
             None if cams_only else dptr(w['dJp']), None if cams_only else dptr(w['dMq']),
-            None if cams_only else dptr(w['dTR']), HEAD_LD, self.g('learned_cameras'), dptr(dj3d_extra), st),
+            None if cams_only else dptr(w['dTR']), HEAD_LD, self.g('learned_cameras'), dptr(dj3d_extra), self.nvalid, st),
             'nemo_kp_bwd_ex')
         if cams_only:
             return
@@ -655,8 +693,14 @@ class FitEngine:
         self.gemm(0, 0, N, 63, 512, dptr(w['dE_a']), 512, dptr(vp['e2w_p']), 64,
                   w['dAA'].data_ptr() + 4 * 3, 72, out_mode=1, dense=True)
 
-    def backward_mlp(self, w, N, view_idx, frame_idx, raw_phase, has_trans_grad=True):
-        """dROT (N+1,144), dTR (N+1,3) -> all MLP / RBF / phase / code gradients."""
+    def backward_mlp(self, w, N, view_idx, frame_idx, raw_phase, has_trans_grad=True, stages=(0, 1, 2), bucketed=False):
+        """dROT (N+1,144), dTR (N+1,3) -> all MLP / RBF / phase / code gradients.
+
+        ``stages``: the backward in the order it completes parameter gradients -- 0: heads + layer 4 (and the dX GEMMs
+        down to layer 4's input gradient), 1: layer 2, 2: layer 0, RBF widths, instance codes, phase networks.
+        ``bucketed``: the bias column sums of a stage are flushed and the side stream is joined at the END OF EVERY STAGE
+        (each stage can then be a launch of its own with a gradient all-reduce behind it, dist.py); otherwise one batched
+        column-sum launch at the very end, as the single-GPU step wants it."""
         L, st, h, r = self.lib, _stream(), self.h, N + 1
         if self.version == 0:
             return self._backward_nets_v0(w, N, view_idx, frame_idx, raw_phase, has_trans_grad)
@@ -690,29 +734,46 @@ class FitEngine:
         def dY_ready():
             return main.record_event() if small else None
 
-        ev = dY_ready()
-        if not small:
-            dW(None, r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
-               self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
-        self.gemm(0, 0, r, h, nout, dptr(w['dHEAD']), HEAD_LD, self.p(lm + 'rot_out.weight'), h,
-                  dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1, dense=True)
-        if small:
-            dW(ev, r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
-               self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
-        ev = dY_ready()
-        if not small:
-            dW(None, r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
-        self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
-                  mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx', dense=True)
-        if small:
-            dW(ev, r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
-        ev = dY_ready()
-        if not small:
-            dW(None, r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
-        self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
-                  mask=dptr(w['H1']), ldmask=h, mask_mode=1, dense=True)
-        if small:
-            dW(ev, r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+        def end_of_stage():
+            """bucketed: this stage's parameter gradients (incl. the bias column sums) are complete on `main`."""
+            if not bucketed:
+                return
+            if small:
+                with torch.cuda.stream(side):
+                    self.flush_colsums()
+                main.wait_stream(side)
+            else:
+                self.flush_colsums()
+
+        if 0 in stages:
+            ev = dY_ready()
+            if not small:
+                dW(None, r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
+                   self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
+            self.gemm(0, 0, r, h, nout, dptr(w['dHEAD']), HEAD_LD, self.p(lm + 'rot_out.weight'), h,
+                      dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1, dense=True)
+            if small:
+                dW(ev, r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
+                   self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
+            ev = dY_ready()
+            if not small:
+                dW(None, r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
+            self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
+                      mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx', dense=True)
+            if small:
+                dW(ev, r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
+            end_of_stage()
+        if 1 in stages:
+            ev = dY_ready()
+            if not small:
+                dW(None, r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+            self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
+                      mask=dptr(w['H1']), ldmask=h, mask_mode=1, dense=True)
+            if small:
+                dW(ev, r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+            end_of_stage()
+        if 2 not in stages:
+            return
 
         def phase_bwd():
             check(L.nemo_phase_embed_bwd(

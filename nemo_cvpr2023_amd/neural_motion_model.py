@@ -63,10 +63,25 @@ class ShardInfo:
     V_local / V_global the instance-code regulariser.  ``comm(engine)`` all-reduces the shared
     gradients together with the loss scalars.  The single-process default is the identity."""
 
-    def __init__(self, kr=1.0, mr=1.0, vr=1.0, n_global=None, comm=None, comm_small=None):
+    def __init__(self, kr=1.0, mr=1.0, vr=1.0, n_global=None, comm=None, comm_small=None, comm_bucket=None, pad=0):
         self.kr, self.mr, self.vr, self.n_global, self.comm = kr, mr, vr, n_global, comm
         self.comm_small = comm_small          # all-reduce of a small device tensor (the loss scalars)
+        # all-reduce of ONE gradient bucket (a contiguous slice of the flat gradient buffer): when set, update steps
+        # reduce the shared gradient in three buckets, each as soon as the backward has completed it (dist.py 'buckets')
+        self.comm_bucket = comm_bucket
+        # > 0: a minibatch share of n samples is LAUNCHED as ceil(n / pad) * pad samples (masked padding rows, see
+        # include/nemo_hip.h nemo_kp_fwd), so that a handful of captured graphs serve every share size
+        self.pad = int(pad)
 
+
+def clip_segments(segs, lo, hi):
+    """The parts of Adam launch segments (FusedAdam.segments) that fall inside [lo, hi) of the flat buffer."""
+    out = []
+    for s_ in segs:
+        a, b = max(s_['offset'], lo), min(s_['offset'] + s_['numel'], hi)
+        if b > a:
+            out.append(dict(s_, offset=a, numel=b - a))
+    return out
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -100,7 +115,7 @@ class MonotonicNetwork(nn.Module):
         vi = torch.zeros(n, dtype=torch.long, device=e.device)
         check(e.lib.nemo_phase_embed_fwd(n, 1, e.T, e.K, 0, 0, dptr(vi), None, dptr(x),
                                          self.shifts.data_ptr(), self.scales.data_ptr(), 2 * e.K, None, None,
-                                         None, 0, dptr(out), 1, dptr(ph), _stream()), 'nemo_phase_embed_fwd')
+                                         None, 0, dptr(out), 1, dptr(ph), None, _stream()), 'nemo_phase_embed_fwd')
         return ph.unsqueeze(1)
 
 
@@ -235,6 +250,7 @@ class MultiViewModel(nn.Module):
         # capture each (batch size, mode) variant of the step as a HIP graph after one eager run
         self.use_graphs = os.environ.get('NEMO_GRAPHS', '1') != '0'
         self.GRAPH_AFTER = 1             # eager runs of a (batch size, mode) variant before it is captured
+        self.launch_stats = {'replayed': 0, 'other': 0}     # launches that replayed an existing graph / ran eagerly or captured
         self._build_parameters()
         self._init_parameters()
         self._build_optimizers()
@@ -510,6 +526,8 @@ class MultiViewModel(nn.Module):
         # point where the loss scalars are final, 'tail' = the rest of the backward (see step())
         if part == 'tail':
             return self._backward_tail(w, N, vi, fi, update, use_vposer, sh)
+        if part in ('k1', 'k2'):             # bucketed sharded step: the later stages of the MLP backward (see step())
+            return e.backward_mlp(w, N, vi, fi, None, stages=(int(part[1]),), bucketed=True)
         # loss scalars, view accumulators, dAA, dJp, dA2, dPF2, the gradient buffer (and the device Adam table's step)
         e.step_begin(w['zero_arena'], bool(update), adam_segs)
         e.forward_pose(w, N, vi, fi, code_noise=self._noise(N))
@@ -538,16 +556,15 @@ class MultiViewModel(nn.Module):
         # side2: everything that accumulates into dAA -- GMM prior, 3-D pose term (they only need the pose), then, once
         #        the encoder output exists, KL and its backward through the frozen encoder.  One stream for all of
         #        them: their `+=` into dAA are plain read-modify-writes.
-        side.wait_event(pose_done)
-        side2.wait_event(pose_done)
         # (Variants measured and dropped, profiles/r02_experiments.md section 5: priors enqueued before the VPoser chain,
         #  KL + its backward appended to the VPoser chain or to the main chain -- equal or slower un-profiled.)
-        enc_done = None
-        with torch.cuda.stream(side):
-            if use_vposer:
-                enc_done = e.forward_vposer(w, N)                             # always evaluated, :3569
-                e.forward_v2v_pre(w, N)          # rotations + FK of both mesh bodies: only the poses are needed
-        with torch.cuda.stream(side2):
+        # Small batches (one rank's share at 8 GPUs; `e.prior_mode(N)` = 1): TWO queues instead of three -- a replayed
+        # graph starts the third hardware queue ~70 us after its dependency is met (profiles/r02_kernel_trace_v1.md), which
+        # made the prior branch the last arriver in front of the mesh kernel.  The GMM prior and the 3-D term open the
+        # VPoser stream (they need the pose only), KL and its backward close the main chain behind the keypoint backward.
+        mode = e.prior_mode(N)
+
+        def priors():
             st = _stream()
             if use_gmm:
                 g = e.gmm
@@ -555,22 +572,49 @@ class MultiViewModel(nn.Module):
                                              dptr(g['log_nllw']), dptr(w['gmm_ws']),
                                              e.scal.data_ptr() + 4 * S_GMM, None,
                                              float(a.weight_gmm_loss) * sh.mr,
-                                             daa69 if (update and a.weight_gmm_loss) else None, 72, st),
+                                             daa69 if (update and a.weight_gmm_loss) else None, 72, e.nvalid, st),
                       'nemo_gmm_fwd_bwd')
             if self.VERSION >= 3 and getattr(a, 'weight_3d_loss', 0):
                 check(e.lib.nemo_pose3d_fwd_bwd(N, 69, aa69, 72, dptr(e.hmr_theta), dptr(e.hmr_mask),
                                                 dptr(vi), dptr(fi), e.T, e.scal.data_ptr() + 4 * S_3D,
                                                 float(a.weight_3d_loss) * sh.mr, daa69 if update else None,
-                                                72, st), 'nemo_pose3d_fwd_bwd')
+                                                72, e.nvalid, st), 'nemo_pose3d_fwd_bwd')
+
+        def kl_terms():
+            e.vposer_kl(w, N)
+            if update and a.weight_vp_z_loss:
+                e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
+
+        side.wait_event(pose_done)
+        enc_done = None
+        if mode == 0:
+            side2.wait_event(pose_done)
+            with torch.cuda.stream(side):
+                if use_vposer:
+                    enc_done = e.forward_vposer(w, N)                             # always evaluated, :3569
+                    e.forward_v2v_pre(w, N)          # rotations + FK of both mesh bodies: only the poses are needed
+            with torch.cuda.stream(side2):
+                priors()
+                if use_vposer:
+                    side2.wait_event(enc_done)
+                    kl_terms()
+                side2.wait_event(kp_done)
+                e.finalize_kp(w, mean_mode=0)
+            main.wait_stream(side)
+            main.wait_stream(side2)
+        else:
+            with torch.cuda.stream(side):
+                priors()
+                priors_done = side.record_event()
+                if use_vposer:
+                    enc_done = e.forward_vposer(w, N)
+                    e.forward_v2v_pre(w, N)
             if use_vposer:
-                side2.wait_event(enc_done)
-                e.vposer_kl(w, N)
-                if update and a.weight_vp_z_loss:
-                    e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
-            side2.wait_event(kp_done)
+                main.wait_event(enc_done)
+                main.wait_event(priors_done)             # (`+=` into dAA: after the prior terms)
+                kl_terms()
             e.finalize_kp(w, mean_mode=0)
-        main.wait_stream(side)
-        main.wait_stream(side2)
+            main.wait_stream(side)
         # the fused mesh kernel is sized to fill the machine in exactly one resident wave of blocks:
         # it runs alone (anything co-scheduled pushes part of its grid into a second wave, +60 %)
         if extra_losses is not None:
@@ -594,14 +638,15 @@ class MultiViewModel(nn.Module):
             e.publish_scalars()
         if not update or part == 'head':
             return
-        self._backward_tail(w, N, vi, fi, update, use_vposer, sh)
+        self._backward_tail(w, N, vi, fi, update, use_vposer, sh, stages=(0,) if part == 'k0' else (0, 1, 2),
+                            bucketed=part == 'k0')
         if pub_aside:
             side2.wait_event(loss_final[0])
             with torch.cuda.stream(side2):
                 e.publish_scalars()
             main.wait_stream(side2)
 
-    def _backward_tail(self, w, N, vi, fi, update, use_vposer, sh):
+    def _backward_tail(self, w, N, vi, fi, update, use_vposer, sh, stages=(0, 1, 2), bucketed=False):
         e, a = self.engine, self.args
         st = _stream()
         # v2v_prep_bwd + rot6d_bwd + the trans_0 row sum in one launch
@@ -614,7 +659,7 @@ class MultiViewModel(nn.Module):
             dptr(w['dTR']) if anchored else None, HEAD_LD, 1, st), 'nemo_pose_bwd_fused')
         if not anchored:
             e.finish_trans_grad(w, N)
-        e.backward_mlp(w, N, vi, fi, None)
+        e.backward_mlp(w, N, vi, fi, None, stages=stages, bucketed=bucketed)
 
     def step(self, view_idx, frame_idx, update=True, full_batch=False, _shard=None):
         """:3511-3598 (V1/V2), :3796-3909 (V3/V4)."""
@@ -640,7 +685,19 @@ class MultiViewModel(nn.Module):
                 vi, fi = self._idx(vi), self._idx(fi)
         else:
             vi, fi = self.full_indices()
-        N = vi.numel()
+        Nv = N = vi.numel()              # Nv: real samples; N: samples the kernels are launched with
+        # Padded launch (a rank's share of a sharded random minibatch, scripts:291-296 / nemomocap-example.sh:17): the
+        # share size changes every step, a captured graph is per launch size -- so the share is rounded up to a multiple
+        # of sh.pad with masked rows (valid indices, no loss, no count, zero gradient: include/nemo_hip.h) and the
+        # per-sample means are taken over the launch size with mr = N_launch / N_global.
+        padded = bool(sh.pad and not is_full and Nv > 0 and sh.n_global)
+        if padded:
+            N = -(-Nv // sh.pad) * sh.pad
+            assert N <= 8192, 'padded launches are single-chunk (minibatch shares)'
+            vi = torch.nn.functional.pad(vi, (0, N - Nv))         # (view 0, frame 0): valid memory, masked out
+            fi = torch.nn.functional.pad(fi, (0, N - Nv))
+            sh = ShardInfo(kr=sh.kr, mr=N / float(sh.n_global), vr=sh.vr, n_global=sh.n_global, comm=sh.comm,
+                           comm_small=sh.comm_small, comm_bucket=sh.comm_bucket, pad=sh.pad)
         w = e._ws(max(N, 1))
         e.scal = w['scal']               # (a replayed graph wrote this workspace's slots)
         e.sync_betas()                   # host-side state a captured graph cannot re-read (checkpoint load, eval)
@@ -677,7 +734,8 @@ class MultiViewModel(nn.Module):
         # with the rest of the backward, the gradient all-reduce and Adam; the host then has the global losses
         # before the step ends and prepares the next launch meanwhile.  (Every rank takes the same route whatever
         # its share of the batch, so the collectives line up.)
-        split = bool(update and sh.comm is not None and sh.comm_small is not None and e.early_readback)
+        bucketed = bool(update and sh.comm is not None and sh.comm_bucket is not None and self.VERSION >= 1)
+        split = bool(update and sh.comm is not None and sh.comm_small is not None and e.early_readback and not bucketed)
         graphable = self.use_graphs and N > 0 and e.timers is None and not noise
         segs = None
         if update:
@@ -686,21 +744,22 @@ class MultiViewModel(nn.Module):
                 segs += o.segments(None)
         # the fused Adam runs inside the captured graph unless a gradient all-reduce must come first
         in_graph_adam = update and sh.comm is None
-        if early or split:
+        if early or split or (bucketed and e.early_readback):
             e.arm_scalars()
 
         def run(part):
             """One launch of `part` of the body: a replayed HIP graph once the variant has been seen often enough."""
             nonlocal vi, fi
-            if not graphable:
+            if not graphable and not padded:
                 body(vi, fi, None, part)
                 return
             # everything the captured launches bake in besides device-resident inputs: the mode, the shard
             # normalisers, the engine switches of the public NemoV2 setters, the loss weights and loss type
-            key = (N, bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, part, early,
+            key = (N, bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, part, early, padded,
                    e.detach_articulation, e.start_global_traj_anywhere, has_inst, self._weights_key(),
                    tuple((s_['offset'], s_['numel']) for s_ in segs) if in_graph_adam else None)
-            if part != 'tail':
+            cap = w['cap']
+            if part in ('all', 'head', 'k0'):          # the first launch of a step stages its inputs
                 src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N)
                 if w.get('_static_src') != src or vi is not w.get('_static_vi'):   # (full batch: cached, unchanged)
                     if vi.device.type == 'cpu' and fi.device.type == 'cpu':
@@ -708,18 +767,28 @@ class MultiViewModel(nn.Module):
                         # step (still running, see `early`) has drained.  The staging buffer is free: the
                         # previous copy out of it was enqueued before the launch whose losses we already hold.
                         if '_idx_pin' not in w:
-                            w['_idx_pin'] = torch.empty(2, w['vi_static'].numel(), dtype=w['vi_static'].dtype).pin_memory()
+                            w['_idx_pin'] = torch.zeros(2, cap + 1, dtype=w['vi_static'].dtype).pin_memory()
                         pin = w['_idx_pin']
                         pin[0, :N].copy_(vi)
                         pin[1, :N].copy_(fi)
-                        w['vi_static'][:N].copy_(pin[0, :N], non_blocking=True)
+                        if padded:                       # + the number of real samples, behind the view indices
+                            pin[0, cap] = Nv
+                            w['vi_static'].copy_(pin[0], non_blocking=True)
+                        else:
+                            w['vi_static'][:N].copy_(pin[0, :N], non_blocking=True)
                         w['fi_static'][:N].copy_(pin[1, :N], non_blocking=True)
                     else:
                         w['vi_static'][:N].copy_(vi)
                         w['fi_static'][:N].copy_(fi)
+                        if padded:
+                            w['vi_static'][cap:].fill_(Nv)
                     w['_static_src'], w['_static_vi'] = src, vi
-            table = e.adam_table_sync(segs) if (in_graph_adam and part != 'head') else None
             svi, sfi = w['vi_static'][:N], w['fi_static'][:N]      # (the workspace may be larger than this batch)
+            if not graphable:
+                body(svi, sfi, None, part)
+                vi, fi = svi, sfi
+                return
+            table = e.adam_table_sync(segs) if (in_graph_adam and part != 'head') else None
             try:
                 launch(key, svi, sfi, table, part)
             except BaseException:
@@ -733,6 +802,7 @@ class MultiViewModel(nn.Module):
 
         def launch(key, svi, sfi, table, part):
             entry = w['graphs'].get(key)
+            self.launch_stats['replayed' if isinstance(entry, torch.cuda.CUDAGraph) else 'other'] += 1
             if entry == 'eager':
                 body(svi, sfi, table, part)
             elif not isinstance(entry, torch.cuda.CUDAGraph) and (entry or 0) < self.GRAPH_AFTER:
@@ -761,22 +831,34 @@ class MultiViewModel(nn.Module):
                     entry.replay()
 
         need_adam = update and not (graphable and in_graph_adam)
-        if split:
-            run('head')
-            self._reduce_scalars_on_side_stream(sh)         # weights -> small all-reduce -> publish
-            if N > 0:
-                run('tail')
-            sh.comm(e, update)                              # shared-gradient all-reduce (main stream)
-            e.adam(segs)
-            s = e.wait_scalars()
-        else:
-            run('all')
-            if early:    # the losses arrive while the backward / Adam launches above are still running
-                if need_adam:
-                    e.adam(segs)
+        e.nvalid = w['vi_static'][w['cap']:].data_ptr() if padded else None
+        try:
+            if bucketed:
+                s = self._bucketed_update(sh, segs, run, N, has_inst)
+            elif split:
+                run('head')
+                self._reduce_scalars_on_side_stream(sh)         # weights -> small all-reduce -> publish
+                if N > 0:
+                    run('tail')
+                sh.comm(e, update)                              # shared-gradient all-reduce (main stream)
+                e.adam(segs)
                 s = e.wait_scalars()
             else:
-                s = self._reduce_and_read(sh, update, then=(lambda: e.adam(segs)) if need_adam else None)
+                run('all')
+                if early:    # the losses arrive while the backward / Adam launches above are still running
+                    if need_adam:
+                        e.adam(segs)
+                    s = e.wait_scalars()
+                else:
+                    s = self._reduce_and_read(sh, update, then=(lambda: e.adam(segs)) if need_adam else None)
+        finally:
+            e.nvalid = None
+        if padded:
+            if sh.comm is None:          # (with a collective the scalars come back weighted: _shard_weights)
+                s = np.array(s, dtype=np.float32)
+                s[[S_KL, S_GMM, S_3D]] *= np.float32(N / Nv)          # kernel means are over the launch size
+            vi, fi = vi[:Nv], fi[:Nv]
+        N = Nv                           # (everything below speaks about the real samples)
         f32 = np.float32
         kp = f32(s[S_KP])
         v2v = f32(s[S_V2V]) / f32((sh.n_global or N) * e.NV * 3)
@@ -823,6 +905,56 @@ class MultiViewModel(nn.Module):
                 sch.step(float(loss))
         self.training = False
         return loss_dict, info_dict
+
+    def _bucketed_update(self, sh, segs, run, N, has_inst):
+        """Sharded update step with the shared gradient reduced in THREE buckets, each as soon as the backward has
+        completed it (engine.ParamLayout.buckets: heads + layer 4, layer 2, layer 0 + RBF widths + the loss scalars),
+        on the engine's communication stream, with the fused Adam of a bucket right behind its collective there.  The
+        step is three launches (captured graphs k0 / k1 / k2, cut where a bucket completes); the main stream only joins
+        the communication stream at the end of the step.  Every rank issues the same three collectives whatever its
+        share of the batch (a rank without samples reduces zeros)."""
+        e = self.engine
+        main, cs = torch.cuda.current_stream(), e.comm_stream
+        bk = e.layout.buckets()
+        lo, hi = bk[2][0], bk[0][1]
+        wv = self._shard_weights(sh)
+        slot = e.view('_comm_scalars', e.grads)
+
+        def reduce(i, last=False):
+            cs.wait_event(main.record_event())
+            with torch.cuda.stream(cs):
+                if last:
+                    torch.mul(e.scal, wv, out=slot)           # local loss scalars -> this rank's share of the global ones
+                sh.comm_bucket(e.grads[bk[i][0]:bk[i][1]])
+                if last and e.early_readback:
+                    e.publish_scalars(slot)
+                e.adam(clip_segments(segs, *bk[i]))
+
+        if N > 0:
+            run('k0')
+        else:                    # a shard may own none of a minibatch's samples
+            e.scal.zero_()
+            e.grads.zero_()
+            if has_inst:
+                n_code = e.V * e.C
+                check(e.lib.nemo_sqmean_fwd_bwd(n_code, e.p('learned_instance_code'), e.scal.data_ptr() + 4 * S_INST,
+                                                e.g('learned_instance_code'),
+                                                2.0 * float(self.args.weight_instance_loss) * sh.vr / n_code, _stream()),
+                      'nemo_sqmean_fwd_bwd')
+        reduce(0)
+        if N > 0:
+            run('k1')
+        reduce(1)
+        if N > 0:
+            run('k2')
+        reduce(2, last=True)
+        # this rank's private parameters (cameras, phase networks, instance codes) on the main stream meanwhile
+        e.adam(clip_segments(segs, 0, lo) + clip_segments(segs, hi, e.layout.total))
+        main.wait_stream(cs)              # (the next step's forward reads the updated shared parameters)
+        if e.early_readback:
+            return e.wait_scalars()
+        e.scal.copy_(slot)
+        return e.read_scalars()
 
     def _weights_key(self):
         a = self.args
@@ -923,7 +1055,7 @@ class MultiViewModel(nn.Module):
                 check(e.lib.nemo_pose3d_fwd_bwd(N, 69, w['AA'].data_ptr() + 12, 72, dptr(e.hmr_theta),
                                                 dptr(e.hmr_mask), dptr(vi), dptr(fi), e.T,
                                                 e.scal.data_ptr() + 4 * S_3D, float(sh.mr),
-                                                w['dAA'].data_ptr() + 12, 72, st), 'nemo_pose3d_fwd_bwd')
+                                                w['dAA'].data_ptr() + 12, 72, None, st), 'nemo_pose3d_fwd_bwd')
                 check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, None, dptr(w['dAA']),
                                            dptr(w['dROT']), HEAD_LD, st), 'nemo_rot6d_bwd')
                 w['dHEAD'][N].zero_()     # the phase-0 row: a workspace shared with larger batches keeps their row here

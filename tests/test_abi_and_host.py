@@ -64,9 +64,15 @@ def test_param_layout_matches_reference_optimizer_order():
     assert e['learned_motion.linear_out.bias'][0] == e['learned_motion.rot_out.bias'][0] + 144
     assert e['learned_motion.rot_out.bias'][0] == e['learned_motion.linear_out.weight'][0] + 3 * 48
     a, b = lay.span(lay.groups['motion'])
-    assert b - a == 48 * 21 + 48 + 2 * (48 * 48 + 48) + 144 * 48 + 144 + 3 * 48 + (3 + 1) + 16   # 1 float of pad
+    assert b - a == 48 * 21 + 48 + 2 * (48 * 48 + 48) + 144 * 48 + 144 + 3 * 48 + 3 + 16 + 8   # (8 comm scalars inside)
     a2, b2 = lay.span(lay.groups['motion'] + lay.groups['comm'])
-    assert (a2, b2) == (a, b + 8)          # one contiguous all-reduce slice
+    assert (a2, b2) == (a, b)              # one contiguous all-reduce slice: the 8 loss scalars sit inside it
+    # ... cut into three contiguous gradient buckets in the order the backward completes them (dist.py):
+    # [heads + layer 4] is the LAST slice in memory, [layer 0 + RBF widths + loss scalars] the first
+    bk = lay.buckets()
+    assert bk[2][0] == a and bk[0][1] == b and bk[2][1] <= bk[1][0] <= bk[1][1] <= bk[0][0]
+    assert e['_comm_scalars'][0] >= bk[2][0] and e['_comm_scalars'][0] + 8 <= bk[2][1]
+    assert e['learned_motion.rot_out.bias'][0] >= bk[0][0] and e['learned_motion.net.net.2.weight'][0] == bk[1][0]
     # the 16-byte alignment must hold for a one-view shard too (9 camera floats in front of the MLP)
     lay1 = ParamLayout(V=1, K=20, D=16, C=5, h=48, din=21)
     assert all(off % 4 == 0 for off, _ in lay1.entries.values())

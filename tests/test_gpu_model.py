@@ -394,6 +394,48 @@ def test_smaller_batch_after_a_larger_one_in_a_shared_workspace(mode):
         assert rel_err(named[k].grad, p.grad) < 2e-3, k
 
 
+@pytest.mark.parametrize('version', [2, 3])
+def test_padded_launch_equals_the_unpadded_step(version):
+    """A minibatch launched with masked padding rows (what a rank of a sharded run does with its share of a random
+    draw, so that one captured graph serves every share size that rounds up to the same multiple of 32) is the same
+    step: losses, per-joint losses, every gradient and the updated parameters equal the unpadded launch of the same
+    samples -- for batches with an absent view, for a batch that is already a multiple of the pad, and for NemoV3's
+    extra terms -- and three different sizes that round up to 32 share ONE captured graph."""
+    from nemo_cvpr2023_amd.neural_motion_model import ShardInfo
+    over = dict(weight_instance_loss=0.1, weight_3d_loss=0.5) if version >= 3 else {}
+    a, _ = _tiny_v2(version=version, **over)
+    b, _ = _tiny_v2(version=version, **over)
+    with torch.no_grad():
+        a.learned_motion.rot_out.weight.mul_(2e3)
+    _copy_model_state(b, a)
+    gen = torch.Generator().manual_seed(9)
+    sizes = [19, 27, 23, 19, 32, 27, 40, 5, 45]
+    for it, n in enumerate(sizes):
+        vi, fi = torch.randint(0, 3, (n,), generator=gen), torch.randint(0, 10, (n,), generator=gen)
+        if it == 2:
+            vi[vi == 1] = 2                                  # a view absent from the batch
+        # (as one rank of a sharded run sees it: its n samples out of a global batch of 64 -- per-sample means are
+        #  scaled by n / 64 on both sides, so both models compute the same gradients)
+        ld_a, info_a = a.step(vi, fi, _shard=ShardInfo(mr=n / 64.0, n_global=64))
+        ld_b, info_b = b.step(vi, fi, _shard=ShardInfo(n_global=64, pad=32))
+        for k in ld_a:
+            assert rel_err(ld_b[k], ld_a[k]) < 1e-5 or abs(float(ld_a[k])) < 1e-12, (it, n, k, ld_a[k], ld_b[k])
+        assert info_b['loss_all'].shape == info_a['loss_all'].shape and info_b['j'].shape[0] == n
+        assert rel_err(info_b['loss_all'], info_a['loss_all']) < 1e-5
+        assert torch.equal(info_b['view_idx'].cpu(), vi)
+        ga, gb = a.engine.grads, b.engine.grads
+        named_a, named_b = dict(a.named_parameters()), dict(b.named_parameters())
+        for k in named_a:
+            if k == 'learned_betas':
+                continue
+            sc = float(named_a[k].grad.abs().max())
+            assert float((named_a[k].grad - named_b[k].grad).abs().max()) <= 2e-5 * sc + 1e-12, (it, n, k)
+        _copy_model_state(b, a)           # (keep the two in lock step: Adam amplifies rounding-level differences)
+    keys = [k for w in b.engine.ws.values() for k, g in w['graphs'].items() if isinstance(g, torch.cuda.CUDAGraph)]
+    assert sorted(k[0] for k in keys) == [32, 64], keys      # launch sizes 32 (19, 27, 23, 32, 5 samples) and 64 (40, 45)
+    assert b.launch_stats['replayed'] >= 5
+
+
 def test_full_batch_properties_at_benchmark_size(tmp_path):
     """Size-independent properties at the BASELINE configuration (8 x 300 full batch, N = 2400):
     (i) the full-batch step equals the same indices passed explicitly, (ii) the per-view

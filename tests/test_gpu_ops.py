@@ -294,27 +294,28 @@ def test_phase_embed_vs_oracle(L, kern):
     # HIP: the V networks are stored interleaved [sh_0 | sc_0 | sh_1 | ...]
     pn = H.dev(torch.stack([sh, sc], 1).reshape(-1))
     Xd = torch.zeros(N + 1, D + C, device='cuda')
-    phd = torch.zeros(N, device='cuda')
+    phd, den = torch.zeros(N, device='cuda'), torch.zeros(N, device='cuda')
     dvi, dfi, dls, dco = H.dev(vi, torch.long), H.dev(fi, torch.long), H.dev(ls), H.dev(codes)
     kid = RBF_KERNELS[kern]
     assert L.nemo_phase_embed_fwd(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
                                   pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), dco.data_ptr(), None, kid,
-                                  Xd.data_ptr(), D + C, phd.data_ptr(), H.st()) == 0
+                                  Xd.data_ptr(), D + C, phd.data_ptr(), den.data_ptr(), H.st()) == 0
     assert rel_err(phd, ph.detach().squeeze(1)) < 1e-5
     assert rel_err(Xd, Xo.detach()) < 1e-5
-    gpn = torch.zeros_like(pn)
-    gls, gco = torch.zeros(D, device='cuda'), torch.zeros(V, C, device='cuda')
-    assert L.nemo_phase_embed_bwd(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
-                                  pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), kid, phd.data_ptr(),
-                                  H.dev(ct).data_ptr(), D + C, torch.zeros(N, 4, device='cuda').data_ptr(),
-                                  gpn.data_ptr(), gpn.data_ptr() + 4 * K,
-                                  gls.data_ptr(), gco.data_ptr(), H.st()) == 0
-    gpn = gpn.reshape(V, 2, K)
-    assert rel_err(gls, lso.grad) < 1e-4
-    assert rel_err(gco, co.grad) < 1e-5
-    assert rel_err(gpn[:, 0], sho.grad) < 1e-4
-    assert rel_err(gpn[:, 1], sco.grad) < 1e-4
-    assert float(gpn[1].abs().max()) == 0.0
+    for ws in (den, None):          # with the forward pass's denominators, and re-evaluating them
+        gpn = torch.zeros_like(pn)
+        gls, gco = torch.zeros(D, device='cuda'), torch.zeros(V, C, device='cuda')
+        assert L.nemo_phase_embed_bwd(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
+                                      pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), kid, phd.data_ptr(),
+                                      H.dev(ct).data_ptr(), D + C, ws.data_ptr() if ws is not None else None,
+                                      gpn.data_ptr(), gpn.data_ptr() + 4 * K,
+                                      gls.data_ptr(), gco.data_ptr(), H.st()) == 0
+        gpn = gpn.reshape(V, 2, K)
+        assert rel_err(gls, lso.grad) < 1e-4
+        assert rel_err(gco, co.grad) < 1e-5
+        assert rel_err(gpn[:, 0], sho.grad) < 1e-4
+        assert rel_err(gpn[:, 1], sco.grad) < 1e-4
+        assert float(gpn[1].abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------------------------------ SMPL pieces
@@ -374,7 +375,7 @@ def test_keypoint_path_forward_backward(L, num_verts, version):
     j3d, p2d, lall, vacc, norm, scal = Z(N, 25, 3), Z(N, 25, 2), Z(N, 25, 2), Z(V, 2), Z(1), Z(8)
     args = (ctx.handle, N, V, T, A.data_ptr(), Jp.data_ptr(), Mq.data_ptr(), nq72, dTR.data_ptr(), 3, 1,
             dvi.data_ptr(), dfi.data_ptr(), dc.data_ptr(), dt.data_ptr(), None, 5000.0, 540.0, 960.0, 0, 0)
-    assert L.nemo_kp_fwd(*args, j3d.data_ptr(), p2d.data_ptr(), lall.data_ptr(), vacc.data_ptr(), H.st()) == 0
+    assert L.nemo_kp_fwd(*args, j3d.data_ptr(), p2d.data_ptr(), lall.data_ptr(), vacc.data_ptr(), None, H.st()) == 0
     assert L.nemo_kp_finalize(V, 25, 2, 0, vacc.data_ptr(), scal.data_ptr(), norm.data_ptr(), H.st()) == 0
     assert rel_err(j3d, j.detach()) < 1e-5
     assert rel_err(p2d, p2.detach()) < 1e-5
@@ -440,7 +441,7 @@ def test_keypoint_loss_types_and_camera_mode(L, loss_type, lid):
     lall, vacc, norm, scal, dcg = Z(N, 25, W), Z(V, 2), Z(1), Z(8), Z(V, 9)
     args = (ctx.handle, N, V, T, A.data_ptr(), Jp.data_ptr(), Mq.data_ptr(), nq72, None, 3, 0, dvi.data_ptr(),
             dfi.data_ptr(), dc.data_ptr(), dt.data_ptr(), dsz.data_ptr(), 5000.0, 540.0, 960.0, lid, 1)
-    assert L.nemo_kp_fwd(*args, None, None, lall.data_ptr(), vacc.data_ptr(), H.st()) == 0
+    assert L.nemo_kp_fwd(*args, None, None, lall.data_ptr(), vacc.data_ptr(), None, H.st()) == 0
     assert L.nemo_kp_finalize(V, 25, W, 1, vacc.data_ptr(), scal.data_ptr(), norm.data_ptr(), H.st()) == 0
     assert rel_err(lall, la.detach()) < 1e-4
     assert rel_err(scal[0], mean.detach()) < 1e-5
@@ -548,7 +549,7 @@ def test_v2v_prep(L):
     aa, aad = 0.5 * torch.randn(N, 72, generator=gen), 0.5 * torch.randn(N, 63, generator=gen)
     R2 = torch.zeros(2 * N, 24, 9, device='cuda')
     assert L.nemo_v2v_prep_fwd(N, H.dev(R).data_ptr(), H.dev(aa).data_ptr(), H.dev(aad).data_ptr(),
-                               R2.data_ptr(), H.st()) == 0
+                               R2.data_ptr(), None, H.st()) == 0
     aao = aa.clone().requires_grad_(True)
     Ro = ops.batch_rodrigues(aao[:, 3:].reshape(-1, 3)).reshape(N, 23, 9)
     Rr = ops.batch_rodrigues(torch.cat([aad, aa[:, 66:]], 1).reshape(-1, 3)).reshape(N, 23, 9)
@@ -576,7 +577,7 @@ def test_kl_gmm_pose3d(L):
     kl = ops.kl_to_std_normal(mo[:, :32], torch.nn.functional.softplus(mo[:, 32:]))
     kl.backward()
     out, d = torch.zeros(8, device='cuda'), torch.zeros(N, 64, device='cuda')
-    assert L.nemo_kl_fwd_bwd(N, 32, H.dev(mulv).data_ptr(), 64, out.data_ptr(), d.data_ptr(), 64, H.st()) == 0
+    assert L.nemo_kl_fwd_bwd(N, 32, H.dev(mulv).data_ptr(), 64, out.data_ptr(), d.data_ptr(), 64, None, H.st()) == 0
     assert rel_err(out[0], kl.detach()) < 1e-5 and rel_err(d, mo.grad) < 1e-4
 
     g = syn.make_gmm()
@@ -591,7 +592,7 @@ def test_kl_gmm_pose3d(L):
     assert L.nemo_gmm_fwd_bwd(N, 8, 69, dxp.data_ptr() + 12, 72, c['means'].data_ptr(), c['prec'].data_ptr(),
                               c['log_nllw'].data_ptr(), torch.zeros(N, 8, device='cuda').data_ptr(),
                               out.data_ptr() + 4, per.data_ptr(), 2.0,
-                              dx.data_ptr() + 12, 72, H.st()) == 0
+                              dx.data_ptr() + 12, 72, None, H.st()) == 0
     assert rel_err(per, ll.detach()) < 1e-5 and rel_err(out[1], ll.mean().detach()) < 1e-5
     assert rel_err(dx, 2.0 * xo.grad) < 1e-4
 
@@ -604,7 +605,7 @@ def test_kl_gmm_pose3d(L):
     dx.zero_()
     assert L.nemo_pose3d_fwd_bwd(N, 69, dxp.data_ptr() + 12, 72, H.dev(theta).data_ptr(), H.dev(mask).data_ptr(),
                                  H.dev(vi, torch.long).data_ptr(), H.dev(fi, torch.long).data_ptr(), T,
-                                 out.data_ptr() + 8, 1.0, dx.data_ptr() + 12, 72, H.st()) == 0
+                                 out.data_ptr() + 8, 1.0, dx.data_ptr() + 12, 72, None, H.st()) == 0
     assert rel_err(out[2], l3.detach()) < 1e-5 and rel_err(dx, xo.grad) < 1e-4
 
 
