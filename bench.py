@@ -90,8 +90,15 @@ def parse():
     ap.add_argument('--frames', type=int, default=T0, help='exploration only; the judged workload is 300')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
                     help="GEMM operand type; 'bf16' = BASELINE configs[2] (fp32 accumulate, fp32 master weights)")
-    ap.add_argument('--shard-mode', choices=['auto', 'single', 'split'], default='auto',
-                    help='N > 1: collectives per step (single = library default; auto = time both, keep the faster)')
+    ap.add_argument('--shard-mode', choices=['auto', 'single', 'split', 'buckets'], default='auto',
+                    help='N > 1: how the shared gradient is reduced (single = one collective, the library default; split = + an '
+                         'early 32-byte one for the losses; buckets = three buckets behind the backward; auto = time all, keep '
+                         'the fastest)')
+    ap.add_argument('--repeat', type=int, default=5,
+                    help='timed regions of --steps steps each; `value` is the MEDIAN region (a region lasts ~30 - 50 ms at the '
+                         'default --steps: one region alone is at the mercy of a single scheduling hiccup)')
+    ap.add_argument('--minibatch-steps', type=int, default=60,
+                    help='extra, separately reported leg: random minibatches of 512 samples (the published run\'s mode); 0 = skip')
     ap.add_argument('--spawn-selftest', action='store_true',
                     help='test aid: the N ranks only rendezvous (gloo, no GPU) and report ranks_seen')
     ap.add_argument('--cpu-child', default='', help=argparse.SUPPRESS)
@@ -298,7 +305,7 @@ def main():
     # (like a compile step); they are not part of the warm-up / timed protocol below
     shard_modes = None
     if sharded:
-        modes = ['single', 'split'] if opts.shard_mode == 'auto' else [opts.shard_mode]
+        modes = ['single', 'split', 'buckets'] if opts.shard_mode == 'auto' else [opts.shard_mode]
         shard_modes = {}
         for mode in modes:
             model.set_shard_mode(mode)
@@ -311,7 +318,79 @@ def main():
         step()
     for _ in range(opts.warmup):
         step()
-    elapsed, (ld, _) = timed(opts.steps)
+    # EXACTLY --steps steps per timed region (barrier + synchronize on both sides, max over ranks); --repeat regions, the
+    # median one is reported (all of them are listed in `repeat_ms_per_step`)
+    regions = []
+    for _ in range(max(1, opts.repeat)):
+        regions.append(timed(opts.steps))
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    elapsed, (ld, _) = regions[order[len(order) // 2]]
+    repeat_ms = [round(1e3 * r[0] / opts.steps, 4) for r in regions]
+
+    # ---- sharded runs: what one rank computes per step without any collective, and what the collective costs alone -- so
+    # that a multi-GPU number can be read as  step = compute + (un-hidden part of the) collective
+    shard_info = None
+    if sharded:
+        n_probe = max(10, min(50, opts.steps))
+        try:
+            model.collectives = False                             # the sharded code path with the collectives skipped
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_probe):
+                step()
+            torch.cuda.synchronize()
+            compute_ms = 1e3 * (time.perf_counter() - t0) / n_probe
+        finally:
+            model.collectives = True
+        a_, b_ = model._span
+        buf = torch.zeros(b_ - a_, device=device)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        coll_ms = 1e3 * (time.perf_counter() - t0) / 20
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {'rank': rank, 'compute_ms': round(compute_ms, 4), 'collective_ms': round(coll_ms, 4),
+                                          'instances': model.plan.v_local, 'device': torch.cuda.current_device()})
+        worst = max(p_['compute_ms'] for p_ in per_rank)
+        shard_info = {'per_rank': per_rank, 'allreduce_bytes': int((b_ - a_) * 4),
+                      'scaling_model': {'shard_step_ms': worst, 'allreduce_ms': max(p_['collective_ms'] for p_ in per_rank),
+                                        'predicted_ms_per_step_no_overlap': round(worst + max(p_['collective_ms'] for p_ in per_rank), 4),
+                                        'note': 'compute_ms = this rank\'s step with every collective stubbed out; collective_ms = '
+                                                'the all-reduce of the shared-gradient slice alone (back-to-back, synchronised); '
+                                                'the measured ms_per_step lies between max(compute) and compute + collective'}}
+
+    # ---- the published run's mode: random minibatches of 512 samples drawn like the script does (CPU RNG, views then frames)
+    mini = None
+    if opts.minibatch_steps > 0 and V * T >= 512:
+        gen = torch.Generator().manual_seed(1234)
+        draws = [(torch.randint(0, V, (512,), generator=gen), torch.randint(0, T, (512,), generator=gen))
+                 for _ in range(opts.minibatch_steps + 12)]
+        mm = model.model if sharded else model
+        for vi_, fi_ in draws[:12]:                     # set-up: workspaces + graph captures of the launch sizes
+            model.step(vi_, fi_)
+        stats0 = dict(mm.launch_stats)
+        barrier()
+        t0 = time.perf_counter()
+        for vi_, fi_ in draws[12:]:
+            model.step(vi_, fi_)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax)
+        rep = mm.launch_stats['replayed'] - stats0['replayed']
+        oth = mm.launch_stats['other'] - stats0['other']
+        mini = {'value': round(opts.minibatch_steps / dt, 2), 'unit': 'iters/s', 'ms_per_step': round(1e3 * dt / opts.minibatch_steps, 4),
+                'batch': 512, 'steps': opts.minibatch_steps, 'graph_replay_fraction': round(rep / max(rep + oth, 1), 3),
+                'note': 'random (view, frame) minibatches of 512 out of %d x %d, drawn on the host like '
+                        'scripts/learned_multi_view_recon_nn.py:291-296; rank 0\'s launches' % (V, T)}
     # Roofline leg: the production step replays a captured HIP graph (events cannot be recorded inside
     # one), so the same steps are run once more, un-captured, with HIP events around the tagged kernels
     # on their launch streams.  These instrumented steps are not part of `value`.
@@ -417,13 +496,17 @@ def main():
                        'parallelism': f'instance-shard x{world}' if world > 1 else
                        ('sharded code path in a process group of ONE rank (diagnostic)' if sharded else 'single GPU')},
             'ranks_seen': ranks_seen,
+            'repeat': len(repeat_ms), 'repeat_ms_per_step': repeat_ms,
+            'minibatch512': mini,
             'final_total_loss': float(ld['total_loss']),
             'roofline': roof, 'cpu_baseline': cpu, 'torch_gpu_baseline': tgpu,
         }
         if sharded:
             out['backend'] = dist.get_backend()
             out['shard_modes_ms'] = shard_modes
-            out['collectives_per_step'] = 2 if model.shard_mode == 'split' else 1
+            out['shard_mode'] = model.shard_mode
+            out['collectives_per_step'] = {'single': 1, 'split': 2, 'buckets': 3}[model.shard_mode]
+            out.update(shard_info)
         print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()

@@ -116,6 +116,33 @@ def load():
     return lib
 
 
+class Ablated:
+    """Measurement aid (NEMO_ABLATE=name1,name2,...): a view of the library in which the named entry points do nothing
+    and return 0.  The step then computes garbage -- the only meaningful output is its TIME: the difference to the full
+    step is what the kernel contributes to the un-profiled critical path (kernel traces over-state cross-queue
+    latencies inside replayed graphs).  `nemo_gemm_f32@<M>x<N>x<K>` ablates one GEMM shape."""
+
+    def __init__(self, lib, names):
+        self._lib, self._names = lib, set(names)
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name in self._names:
+            return lambda *a, **k: 0
+        shapes = {n.split('@')[1] for n in self._names if n.startswith(name + '@')}
+        if shapes:
+            def gated(*a, **k):
+                return 0 if f'{a[2]}x{a[3]}x{a[4]}' in shapes else fn(*a, **k)
+            return gated
+        return fn
+
+
+def load_for_engine():
+    lib = load()
+    names = [n for n in os.environ.get('NEMO_ABLATE', '').split(',') if n]
+    return Ablated(lib, names) if names else lib
+
+
 def check(rc: int, what: str):
     if rc != 0:
         kind = 'invalid argument' if rc < 0 else f'hipError_t {rc}'

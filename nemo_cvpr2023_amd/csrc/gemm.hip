@@ -493,6 +493,7 @@ static hipError_t skinny_launch(bool akc, bool bkc, bool va, bool vb, int kind, 
         else e = skinny::launch<AKC, BKC, !(AKC), !(BKC), 1, 1, 4, 4>(g, s);                            \
     } while (0)
     hipError_t e = hipSuccess;
+    if (kind == 4) return skinny::launch<false, true, true, true, 1, 7, 4, 2>(g, s);        // (TT adjoint only)
     if (akc && bkc) SK(true, true);
     else if (akc) SK(true, false);
     else if (bkc) SK(false, true);
@@ -520,6 +521,11 @@ static int skinny_kind(bool akc, bool bkc, bool aligned, bool can_split, long M,
     else {
         // dPF = dVP P^T of a one-instance shard (K = 20 670 over 70 tiles): 58 us with 16 K slices across blocks against
         // 68 us for the LDS-staged kernel's best plan; from ~600 samples on that kernel wins (profiles/r02_gemm_skinny.md)
+        // two-instance shards (400 - 1000 samples; round 3): ONE column tile of 224 -- 8 % padding instead of the 24 % of
+        // four 64-wide tiles -- on 4 waves, K cut into 256 / row-tiles slices: 72 us at 600 samples against 91 (kind 3)
+        // and 84 (LDS-staged kernel, 6 slices); at 300 samples all three meet at 53 - 58 us, from 1200 on the LDS-staged
+        // kernel is level (tools/gemm_skinny_dev adj, profiles/r03_experiments.md)
+        if (K > 4096 && aligned && can_split && N > 192 && N <= 224 && M > 384 && M <= 1000) return 4;
         if (K > 4096) return aligned && can_split && t64 <= 24 ? 3 : -1;
         use = t64 <= 192;
     }
@@ -615,7 +621,15 @@ static int32_t gemm_impl(bool bf16, int32_t transA, int32_t transB, int64_t M, i
         g.act = act; g.mask_mode = mask_mode; g.out_mode = out_mode; g.alpha = alpha;
         g.counters = nullptr; g.slabs = nullptr; g.k_chunk = (K + 7) / 8 * 8; g.split = 1; g.n_tiles = 0; g.t0 = 0; g.xcd_order = 0;
         g.a_bytes = a_bytes; g.b_bytes = b_bytes;
-        if (sk_kind == 3) {         // 16 K slices: <= 96 tiles of 32 x 32 x 16 slabs of 4 KiB = 6 MiB of the workspace
+        if (sk_kind == 4) {         // 256 / row-tiles K slices of a 32 x 224 tile: <= 256 slabs of 28 KiB = 7 MiB
+            const long tiles = (M + 31) / 32;
+            long kc = (K + 256 / tiles - 1) / (256 / tiles);
+            kc = (kc + 7) / 8 * 8;
+            g.k_chunk = kc;
+            g.split = (int)((K + kc - 1) / kc);
+            g.counters = reinterpret_cast<int*>(ws);
+            g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
+        } else if (sk_kind == 3) {  // 16 K slices: <= 96 tiles of 32 x 32 x 16 slabs of 4 KiB = 6 MiB of the workspace
             long kc = (K + 15) / 16;
             kc = (kc + 7) / 8 * 8;
             g.k_chunk = kc;
@@ -626,7 +640,7 @@ static int32_t gemm_impl(bool bf16, int32_t transA, int32_t transB, int64_t M, i
         static const bool debug_skinny = getenv("NEMO_GEMM_DEBUG") != nullptr;
         if (debug_skinny)
             fprintf(stderr, "nemo_gemm_f32 ta=%d tb=%d M=%ld N=%ld K=%ld out=%d -> skinny %s\n", transA, transB, (long)M, (long)N,
-                    (long)K, out_mode, sk_kind == 3 ? "32x32 w8 x 16 K slices" : sk_kind == 2 ? "64x64 w8" : sk_kind == 1 ? "32x64 w8" : "32x32 w4");
+                    (long)K, out_mode, sk_kind == 4 ? "32x224 w4 x K slices" : sk_kind == 3 ? "32x32 w8 x 16 K slices" : sk_kind == 2 ? "64x64 w8" : sk_kind == 1 ? "32x64 w8" : "32x32 w4");
         const hipError_t e = skinny_launch(!transA, transB != 0, va, vb, sk_kind, g, (hipStream_t)stream);
         if (e != hipSuccess) return (int32_t)e;
         NEMO_LAUNCH_CHECK();

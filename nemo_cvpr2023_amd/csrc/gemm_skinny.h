@@ -67,7 +67,11 @@ __global__ __launch_bounds__(64 * W) void gemm_skinny_kernel(Args g) {
     // slice-major block ids, a tile's slices 8 * tiles_m * ceil(tiles_n / 8) blocks apart: the same XCD.
     const int per_slice = (int)gridDim.x / g.split;
     const int slice = (int)blockIdx.x / per_slice, bid = (int)blockIdx.x - slice * per_slice, xcd = bid & 7, bi = bid >> 3;
-    const int tm = bi % g.tiles_m, tn = (bi / g.tiles_m) * 8 + xcd;
+    // fewer than 8 column tiles: a compact grid (the XCD-striped one would launch up to 7/8 empty blocks, each of which
+    // still waits for a CU with this kernel's LDS allocation free -- with a 112 KiB reduction buffer that serialises them
+    // behind the working blocks: 10x the run time of a 32 x 224 tile)
+    const bool compact = g.tiles_n < 8;
+    const int tm = compact ? bid / g.tiles_n : bi % g.tiles_m, tn = compact ? bid % g.tiles_n : (bi / g.tiles_m) * 8 + xcd;
     if (tn >= g.tiles_n) return;
     const long m0 = (long)tm * (32 * NI), n0 = (long)tn * (32 * NJ);
     const int lane = threadIdx.x & 63;
@@ -182,12 +186,14 @@ __global__ __launch_bounds__(64 * W) void gemm_skinny_kernel(Args g) {
         }
         __syncthreads();
         const float* base = g.slabs + (size_t)tile * g.split * (size_t)(NA * 1024);
+        // slice-major: the RPW loads of a slice are independent and in flight together (row-major, a wide tile's 28 rows
+        // x `split` slices were one dependent load chain per row: ~100 us for 25 slices of a 32 x 224 tile)
 #pragma unroll
-        for (int u = 0; u < RPW; ++u) {
-            float v = 0.f;
-            for (int sl = 0; sl < g.split; ++sl)          // fixed order: deterministic
-                v += base[(size_t)sl * (NA * 1024) + (wid * RPW + u) * 64 + lane];
-            part[u] = v;
+        for (int u = 0; u < RPW; ++u) part[u] = 0.f;
+        for (int sl = 0; sl < g.split; ++sl) {            // fixed order: deterministic
+            const float* sb_ = base + (size_t)sl * (NA * 1024) + wid * RPW * 64 + lane;
+#pragma unroll
+            for (int u = 0; u < RPW; ++u) part[u] += sb_[u * 64];
         }
     }
 #pragma unroll
@@ -227,7 +233,7 @@ hipError_t launch(Args g, hipStream_t s) {
     g.tiles_m = (int)((g.M + 32 * NI - 1) / (32 * NI));
     g.tiles_n = (int)((g.N + 32 * NJ - 1) / (32 * NJ));
     if (g.split < 1) g.split = 1;
-    const int blocks = 8 * g.tiles_m * ((g.tiles_n + 7) / 8) * g.split;
+    const int blocks = (g.tiles_n < 8 ? g.tiles_m * g.tiles_n : 8 * g.tiles_m * ((g.tiles_n + 7) / 8)) * g.split;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * W), lds, s, g);
     return hipSuccess;
 }

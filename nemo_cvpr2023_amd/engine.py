@@ -231,7 +231,7 @@ class FitEngine:
                  targets, gt_size, hmr_theta, hmr_mask):
         if not torch.cuda.is_available():
             raise _lib.NemoHipError('FitEngine needs an MI355X (no CPU fallback by design)')
-        self.lib = _lib.load()
+        self.lib = _lib.load_for_engine()
         self.version, self.args = version, args
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)

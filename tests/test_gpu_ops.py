@@ -740,6 +740,8 @@ def test_sqmean_instance_regulariser(L, n):
     (1, 0, 1000, 105, 300, 1),       # dW of the first layer (odd ld on both sides)
     (1, 1, 77, 207, 515, 4),
     (1, 1, 300, 207, 20670, 4),      # blend-shape adjoint of a one-instance shard: K also cut across blocks (16 slices)
+    (1, 1, 600, 207, 20670, 4),      # ... of a two-instance shard: ONE 32 x 224 column tile, 13 K slices (round 3)
+    (1, 1, 450, 207, 4100, 0),       # same kernel, ragged rows, K not a multiple of 8 x slices
 ])
 def test_gemm_skinny_paths(L, ta, tb, M, N, K, pad):
     """Problems the auto plan sends to the intra-block K-split kernel (csrc/gemm_skinny.h): product, fused bias + ReLU,

@@ -14,9 +14,12 @@
 using glds::Args;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-enum { K_1x4 = 0, K_2x8, K_2x4, K_1x8, K_22x8, K_22x8d3, K_22x16, K_1x4u, K_2x8d8, K_1x4d8, NSK };
+enum { K_1x4 = 0, K_2x8, K_2x4, K_1x8, K_22x8, K_22x8d3, K_22x16, K_1x4u, K_2x8d8, K_1x4d8, NSK,
+       // wide tiles for the blend-shape adjoint (N = 207 -> one column tile of 224): only in the `adj` mode
+       K_17x4d3, K_17x4d2, K_17x4d4, K_27x2d2, K_14x4d3, K_14x8d3, NALL };
 static const char* sk_name[] = {"32x32 w4 d4", "32x64 w8 d4", "32x64 w4 d4", "32x32 w8 d4", "64x64 w8 d4", "64x64 w8 d3", "64x64 w4 d4",
-                                "32x32 w4 d4 unaligned", "32x64 w8 d8", "32x32 w4 d8"};
+                                "32x32 w4 d4 unaligned", "32x64 w8 d8", "32x32 w4 d8", "-",
+                                "32x224 w4 d3", "32x224 w4 d2", "32x224 w4 d4", "64x224 w2 d2", "32x128 w4 d3", "32x128 w8 d3"};
 
 template <bool AKC, bool BKC>
 void launch_sk(int cfg, const Args& g, hipStream_t s) {
@@ -31,6 +34,12 @@ void launch_sk(int cfg, const Args& g, hipStream_t s) {
         case K_1x4u: CK((skinny::launch<AKC, BKC, false, false, 1, 1, 4, 4>(g, s))); break;
         case K_2x8d8: CK((skinny::launch<AKC, BKC, true, true, 1, 2, 8, 8>(g, s))); break;
         case K_1x4d8: CK((skinny::launch<AKC, BKC, true, true, 1, 1, 4, 8>(g, s))); break;
+        case K_17x4d3: CK((skinny::launch<AKC, BKC, true, true, 1, 7, 4, 3>(g, s))); break;
+        case K_17x4d2: CK((skinny::launch<AKC, BKC, true, true, 1, 7, 4, 2>(g, s))); break;
+        case K_17x4d4: CK((skinny::launch<AKC, BKC, true, true, 1, 7, 4, 4>(g, s))); break;
+        case K_27x2d2: CK((skinny::launch<AKC, BKC, true, true, 2, 7, 2, 2>(g, s))); break;
+        case K_14x4d3: CK((skinny::launch<AKC, BKC, true, true, 1, 4, 4, 3>(g, s))); break;
+        case K_14x8d3: CK((skinny::launch<AKC, BKC, true, true, 1, 4, 8, 3>(g, s))); break;
     }
 }
 
@@ -73,6 +82,22 @@ void run_glds(int ta, int tb, Args g, int split, float* ws, hipStream_t s) {
     else if (akc && !bkc) e = glds::launch<64, 64, 32, 32, 32, true, false, 3, true>(g, blocks, s);
     else if (!akc && bkc) e = glds::launch<64, 64, 32, 32, 32, false, true, 3, true>(g, blocks, s);
     else e = glds::launch<64, 64, 32, 32, 32, false, false, 3, true>(g, blocks, s);
+    CK(e);
+}
+
+// the 64x64 LDS-DMA kernel with NST stages of 32 k (one block per CU from 6 stages on): the whole K panel of a
+// one-instance shard's parameter gradient (K = 301) requested up front
+template <int NST>
+void run_glds_deep(int ta, int tb, Args g, float* ws, hipStream_t s) {
+    g.counters = reinterpret_cast<int*>(ws); g.slabs = ws + 4096;
+    g.k_chunk = (g.K + 31) / 32 * 32; g.split = 1;
+    g.tiles_m = (int)((g.M + 63) / 64); g.tiles_n = (int)((g.N + 63) / 64); g.n_tiles = g.tiles_m * g.tiles_n; g.t0 = 0;
+    const bool akc = !ta, bkc = tb;
+    hipError_t e;
+    if (akc && bkc) e = glds::launch<64, 64, 32, 32, 32, true, true, NST, true>(g, g.n_tiles, s);
+    else if (akc && !bkc) e = glds::launch<64, 64, 32, 32, 32, true, false, NST, true>(g, g.n_tiles, s);
+    else if (!akc && bkc) e = glds::launch<64, 64, 32, 32, 32, false, true, NST, true>(g, g.n_tiles, s);
+    else e = glds::launch<64, 64, 32, 32, 32, false, false, NST, true>(g, g.n_tiles, s);
     CK(e);
 }
 
@@ -234,6 +259,10 @@ void timeit(long Nb) {
             line += buf;
         }
         printf("%s\n", line.c_str());
+        if (p.K <= 700 && tiles <= 512) {
+            printf("   glds 64x64 deep pipeline: NST4=%.1f NST6=%.1f NST9=%.1f\n", graph_time([&] { run_glds_deep<4>(p.ta, p.tb, g, ws, s); }, s),
+                   graph_time([&] { run_glds_deep<6>(p.ta, p.tb, g, ws, s); }, s), graph_time([&] { run_glds_deep<9>(p.ta, p.tb, g, ws, s); }, s));
+        }
         line = "   skinny:";
         for (int cfg = 0; cfg < NSK; ++cfg) {
             char buf[64]; snprintf(buf, sizeof buf, "  [%s] %.1f", sk_name[cfg], graph_time([&] { run_sk(cfg, p.ta, p.tb, g, s); }, s));
@@ -257,9 +286,62 @@ void timeit(long Nb) {
     }
 }
 
+// the blend-shape adjoint dPF = dVP P^T (TT, N = 207, K = 20 670) at M = Nb: wide-tile configurations x K slices, checked
+// against the 64x64 LDS-DMA kernel's result
+void adjoint(long Nb, int tb) {
+    const int ta = 1;
+    const long M = Nb, N = 207, K = 20670;
+    hipStream_t s; CK(hipStreamCreate(&s));
+    float* ws; CK(hipMalloc(&ws, 256 << 20)); CK(hipMemset(ws, 0, 256 << 20));
+    g_ws = ws;
+    const long lda = (M + 15) / 16 * 16, ldb = tb ? 20672 : 208, ldc = 208;
+    std::vector<float> hA(K * lda), hB((tb ? N : K) * ldb);
+    for (auto& x : hA) x = frand();
+    for (auto& x : hB) x = frand();
+    float *dA, *dB, *dC, *dR;
+    CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, M * ldc * 4)); CK(hipMalloc(&dR, M * ldc * 4));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    Args g = make_args(ta, tb, M, N, K, dA, lda, dB, ldb, dR, ldc, nullptr, 0, nullptr, 0, 0);
+    run_glds(ta, tb, g, 4, ws, s);
+    CK(hipStreamSynchronize(s));
+    std::vector<float> ref(M * ldc), got(M * ldc);
+    CK(hipMemcpy(ref.data(), dR, ref.size() * 4, hipMemcpyDeviceToHost));
+    g.C = dC;
+    printf("blend adjoint (B %s) M=%ld N=%ld K=%ld: %.2f GFLOP, %.1f us at 157.3 TF\n", tb ? "[n][k]" : "[k][n]", M, N, K, 2e-9 * M * N * K, 2e-6 * M * N * K / 157.3);
+    std::string line = "   glds 64x64:";
+    for (int split : {1, 2, 3, 4, 6, 8, 13}) {
+        if (((M + 63) / 64) * 4 * split > 1024) continue;
+        char buf[64]; snprintf(buf, sizeof buf, " s%d=%.1f", split, graph_time([&] { run_glds(ta, tb, g, split, ws, s); }, s));
+        line += buf;
+    }
+    printf("%s\n", line.c_str());
+    for (int cfg : {(int)K_1x8, (int)K_17x4d3, (int)K_17x4d2, (int)K_17x4d4, (int)K_27x2d2, (int)K_14x4d3, (int)K_14x8d3}) {
+        const int tn = (int)((N + (cfg == K_1x8 ? 31 : cfg >= K_14x4d3 ? 127 : 223)) / (cfg == K_1x8 ? 32 : cfg >= K_14x4d3 ? 128 : 224));
+        const int tm = (int)((M + (cfg == K_27x2d2 ? 63 : 31)) / (cfg == K_27x2d2 ? 64 : 32));
+        line = std::string("   skinny [") + sk_name[cfg] + "] tiles " + std::to_string(tm * tn) + " x K slices:";
+        for (int split : {1, 2, 3, 4, 6, 8, 10, 13, 16, 20, 25, 32}) {
+            if ((long)tm * tn * split > 2048 || (long)tm * tn * split < 64) continue;
+            g_split = split;
+            CK(hipMemsetAsync(dC, 0, M * ldc * 4, s));
+            run_sk(cfg, ta, tb, g, s);
+            CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(got.data(), dC, got.size() * 4, hipMemcpyDeviceToHost));
+            double err = 0, scale = 0;
+            for (long m = 0; m < M; ++m) for (long n = 0; n < N; ++n) {
+                err = fmax(err, fabs((double)got[m * ldc + n] - ref[m * ldc + n])); scale = fmax(scale, fabs((double)ref[m * ldc + n]));
+            }
+            char buf[96]; snprintf(buf, sizeof buf, " s%d=%.1f%s", split, graph_time([&] { run_sk(cfg, ta, tb, g, s); }, s), err <= 1e-4 * scale ? "" : "(WRONG)");
+            line += buf;
+        }
+        printf("%s\n", line.c_str());
+    }
+    g_split = 1;
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "check";
     if (mode == "check") return check();
+    if (mode == "adj") { adjoint(argc > 2 ? atol(argv[2]) : 300, argc > 3 ? atoi(argv[3]) : 1); return 0; }
     timeit(argc > 2 ? atol(argv[2]) : 300);
     return 0;
 }
