@@ -261,6 +261,12 @@ int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t
 /* The same with the pose blend (lbs.py:229-233, K = 207) on the bf16 matrix cores: blend shapes rounded to bf16 once
  * at nemo_ctx_create, pose features rounded when staged, fp32 accumulate; skinning, L1 and the adjoints in fp32.
  * BASELINE configs[2] ("bf16"); not covered by the 1e-4 parity gate (tests state the bf16 tolerance). */
+/* dA == NULL in nemo_v2v_fused(_bf16): DEFERRED combine -- the launch leaves the per-block partial dA images in `ws`
+ * and nemo_v2v_combine (same ctx, N, ws; any stream ordered behind the fused launch) sums them into dA (N,24,12),
+ * overwriting.  The step runs it beside the blend-shape adjoint GEMM: the last-arriver reduction inside the fused
+ * launch (three dependent memory round trips at the very end of a launch that fills the machine) leaves the critical
+ * path.  Same summation order as the in-launch path: bit-identical dA. */
+int32_t nemo_v2v_combine(const nemo_ctx* ctx, int64_t N, float* dA, const void* ws, int64_t ws_bytes, void* stream);
 int32_t nemo_v2v_fused_bf16(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
                             float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* ws, int64_t ws_bytes,
                             void* stream);

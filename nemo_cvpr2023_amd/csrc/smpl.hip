@@ -1383,9 +1383,13 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     // the last arriver share the summation (wave w takes ranges w, w+4, ...: with 26 ranges per group at a
     // one-instance shard a single wave spent ~35 us on 26 dependent memory round trips).
     __shared__ int ticket_old;
+    // dA == NULL: DEFERRED combine -- every block leaves its partial image in the scratch and is done; nemo_v2v_combine
+    // (a launch of its own, which the caller can run beside the blend-shape adjoint GEMM: nothing before the FK adjoint
+    // needs dA) sums them.  Otherwise the group's last-arriving block does, below.
+    const bool defer = dA == nullptr;
     if (wid == 0) {
         take(0);
-        if (nr > 1) {
+        if (nr > 1 || defer) {
             float* part = parts + ((size_t)grp * maxc + slot) * (96 * 64);
 #pragma unroll
             for (int e = 0; e < 12; ++e)
@@ -1395,13 +1399,15 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                     for (int r = 0; r < 4; ++r)
                         __hip_atomic_store(part + ((e * 2 + t) * 4 + r) * 64 + lane, accdA[e][t][r],
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1 store
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                ticket_old = __hip_atomic_fetch_add(tickets + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!defer) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    ticket_old = __hip_atomic_fetch_add(tickets + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     __syncthreads();
-    const bool finish = nr == 1 || ticket_old == nr - 1;      // block-uniform
+    const bool finish = !defer && (nr == 1 || ticket_old == nr - 1);      // block-uniform
     if (nr > 1 && finish) {
         // (the partials are read with device-scope loads -- served by the memory side, never by a stale line of this XCD's
         //  L2 -- instead of behind an acquire fence: `buffer_inv sc1` walks the whole L2)
@@ -1474,6 +1480,41 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     }
 }
 
+
+// Deferred combine of nemo_v2v_fused(dA = NULL): block = one group of 16 samples; wave w owns image rows [24 w, 24 w + 24)
+// of every partial, eight partials in flight, added in range order (deterministic, the same order as the in-kernel path).
+__global__ __launch_bounds__(256) void mesh_combine_kernel(long N, int nr, int maxc, const float* __restrict__ parts,
+                                                           float* __restrict__ dA) {
+    const int grp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    const long s0 = (long)grp * 16;
+    const float* base = parts + (size_t)grp * maxc * (96 * 64) + (size_t)(24 * wid) * 64 + lane;
+    float acc[24];
+#pragma unroll
+    for (int q = 0; q < 24; ++q) acc[q] = 0.f;
+    for (int pz0 = 0; pz0 < nr; pz0 += 8) {
+        float v[8][24];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* pp = base + (size_t)min(pz0 + u, nr - 1) * (96 * 64);
+#pragma unroll
+            for (int q = 0; q < 24; ++q) v[u][q] = pp[q * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (pz0 + u < nr) {
+#pragma unroll
+                for (int q = 0; q < 24; ++q) acc[q] += v[u][q];
+            }
+    }
+    if (s0 + l15 < N) {
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            const int qq = 24 * wid + q, e = qq >> 3, t = (qq >> 2) & 1, r = qq & 3;
+            const int j = 16 * t + 4 * g + r;
+            if (j < 24) dA[(s0 + l15) * 288 + j * 12 + e] = acc[q];
+        }
+    }
+}
 
 // Temporal smoothness of the output joints, HuMoR's joints3d_smooth_loss
 // (humor/humor/fitting/fitting_loss.py:366-370): 0.5 * sum_{v,t,j} |J[v,t+1,j] - J[v,t,j]|^2 over complete
@@ -1762,8 +1803,8 @@ extern "C" int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N) {
 static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const float* PF2, int64_t ldpf,
                               const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
                               void* ws, int64_t ws_bytes, void* stream) {
-    if (!ctx || N < 0 || !PF2 || !A2 || !loss_sum || !dVPt || !dA || ldpf < 207 || ldn < ((N + 15) / 16) * 16)
-        return NEMO_EINVAL;
+    if (!ctx || N < 0 || !PF2 || !A2 || !loss_sum || !dVPt || ldpf < 207 || ldn < ((N + 15) / 16) * 16)
+        return NEMO_EINVAL;                                    // (dA == NULL: deferred combine, nemo_v2v_combine)
     if (N == 0) return NEMO_OK;
     const int lds_bytes = ((bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * MF_AS) * (int)sizeof(float);
     static bool attr_set[2] = {false, false};
@@ -1797,6 +1838,21 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const f
                            (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, ctx->d_posedirs, ctx->ldP,
                            ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA, pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn,
                            dA, parts, tickets, loss_parts, grid_ticket);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_v2v_combine(const nemo_ctx* ctx, int64_t N, float* dA, const void* ws, int64_t ws_bytes,
+                                    void* stream) {
+    if (!ctx || N < 0 || !dA || !ws) return NEMO_EINVAL;
+    if (N == 0) return NEMO_OK;
+    const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
+    if (groups > MESH_MAX_GROUPS) return NEMO_EINVAL;
+    const MeshPlan pl = mesh_plan(groups, ntiles);             // the plan the fused launch of the same N used
+    if (ws_bytes < MESH_HEADER_BYTES + groups * (long)(pl.RA + 1) * 96 * 64 * 4) return NEMO_EINVAL;
+    const float* parts = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ws) + MESH_HEADER_BYTES);
+    hipLaunchKernelGGL(mesh_combine_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, (long)N,
+                       pl.RA + (pl.CA < pl.cpg ? 1 : 0), pl.RA + 1, parts, dA);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

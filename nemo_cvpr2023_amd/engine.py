@@ -292,6 +292,7 @@ class FitEngine:
         # split-K scratch of nemo_gemm_f32 (arrival tickets + partial tiles), one per stream that launches GEMMs
         self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(3)]
         self.overlap_bwd = os.environ.get('NEMO_SERIAL_BWD', '0') == '0'
+        self.defer_combine = self.overlap_bwd and os.environ.get('NEMO_DEFER_COMBINE', '1') != '0'
         self._colsums = []
         self._seg_host = self._seg_dev = self._seg_pending = None
         self.timers = None
@@ -641,10 +642,16 @@ class FitEngine:
             ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * (2 * 3 * 207 + 2 * 288 + 288))
             ws = w['mesh_ws']
             fused = L.nemo_v2v_fused_bf16 if self.bf16 else L.nemo_v2v_fused
+            # single-chunk batches: the per-group sum of the blocks' partial dA images runs as a launch of its own on the
+            # second side stream, beside the blend-shape adjoint GEMM (only the FK adjoint behind that GEMM needs dA)
+            # (large batches only: at a one-instance shard the extra fork / join of the replayed graph costs more than the
+            #  reduction's tail -- 0.509 against 0.503 ms, same box; 8 x 300: 1.557 against 1.564 ms)
+            defer = self.defer_combine and need_grad and self.SMALL_BATCH_ROWS < N <= Nc and self.timers is None
             check(fused(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
-                        self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPt']), ldn, dptr(w['dA2']),
+                        self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPt']), ldn, None if defer else dptr(w['dA2']),
                         ws.data_ptr(), ws.numel() * 4, st), 'nemo_v2v_fused')
             self._event_end(ev)
+            mesh_done = torch.cuda.current_stream().record_event() if defer else None
             if after_loss is not None and c0 + Nc >= N:
                 after_loss()        # the L1 sum is final once the last chunk's mesh kernel has run
             if need_grad:
@@ -652,6 +659,13 @@ class FitEngine:
                     w['dPF2'].zero_()
                 self.gemm(1, 1, n, 207, NV3, dptr(w['dVPt']), ldn, ctx.posedirs, ldP, dptr(w['dPF2']), 208,
                           out_mode=1, tag='gemm_pose_blend_bwd', dense=True)
+                if defer:           # (enqueued AFTER the GEMM: a replayed graph keeps the first successor on the queue)
+                    side2 = self.side_stream2
+                    side2.wait_event(mesh_done)
+                    with torch.cuda.stream(side2):
+                        check(L.nemo_v2v_combine(ctx.handle, n, dptr(w['dA2']), ws.data_ptr(), ws.numel() * 4, _stream()),
+                              'nemo_v2v_combine')
+                    torch.cuda.current_stream().wait_stream(side2)
                 check(L.nemo_fk_bwd(ctx.handle, n, dptr(w['R2']), dptr(w['A2']), dptr(w['dA2']), None,
                                     dptr(w['dPF2']), 208, w['dR2'].data_ptr() + 4 * c0 * 216, st), 'nemo_fk_bwd')
 

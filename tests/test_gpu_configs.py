@@ -223,3 +223,42 @@ def test_phase_networks_with_node_counts_that_are_not_a_multiple_of_four(K):
             named = dict(m.named_parameters())
             for k in ('phase_networks.0.shifts', 'phase_networks.3.shifts', 'phase_networks.2.scales'):
                 assert rel_err(named[k].grad, o.P[k].grad) < 2e-3, k
+
+
+@pytest.mark.parametrize('version', [3, 4])
+def test_c4_rows_for_nemo_v3_v4(version):
+    """BASELINE configs[3] (256 x 1024) through NemoV3 / NemoV4 with their extra terms on (instance-code regulariser,
+    3-D pose term; V4: joints 0..24): the full-batch update step is finite and decomposes per view, the full-batch
+    evaluation equals the explicit-index path, and ~300 random rows + both sides of every 8192-sample mesh-chunk boundary
+    of j / points2d / loss_all equal the oracle evaluated on just those samples."""
+    from oracle.model import OracleNemo
+    V, T = 256, 1024
+    m, args, seqs, assets, vps, gmm = _build(V, T, version=version, weight_instance_loss=0.1, weight_3d_loss=0.5)
+    N = V * T
+    for o in m.optimizers:
+        o.param_groups[0]['lr'] = 0.0
+    state0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ld_full, info = m.step(None, None, update=True, full_batch=True)
+    assert set(ld_full) >= {'kp_loss', 'instance_loss', 'loss_3d', 'vp_recon_loss', 'vp_kl_loss', 'gmm_loss', 'total_loss'}
+    assert all(np.isfinite(float(v)) for v in ld_full.values()), ld_full
+    assert float(ld_full['loss_3d']) > 0 and float(ld_full['instance_loss']) > 0
+    j, p2d, la, gt = info['j'], info['points2d'], info['loss_all'], info['points2d_gt']
+    assert torch.isfinite(m.engine.grads).all()
+    per_view = (la * gt[..., -1:]).reshape(V, T, -1).mean(dim=(1, 2)).mean()
+    assert rel_err(ld_full['kp_loss'], per_view) < 2e-5
+    gen = torch.Generator().manual_seed(13 + version)
+    rows = torch.randint(0, N, (300,), generator=gen).tolist() + [0, N - 1]
+    for b in range(8192, N, 8192):
+        rows += [b - 1, b]
+    rows = torch.tensor(sorted(set(rows))[:360])
+    vs, fs = rows // T, rows % T
+    o = OracleNemo(version, args, seqs, assets, vps, gmm, state={k: v.cpu() for k, v in state0.items()})
+    ld_o, info_o = o.step(vs, fs, update=False)
+    r = rows.to(DEV)
+    assert rel_err(j[r], info_o['j']) < 1e-4
+    assert rel_err(p2d[r], info_o['points2d']) < 1e-4
+    assert rel_err(la[r], info_o['loss_all']) < 1e-4
+    # the same rows as a minibatch through the HIP model: every loss term incl. the V3 / V4 extras against the oracle
+    ld_h, _ = m.step(vs, fs, update=False)
+    for k in ld_o:
+        assert rel_err(ld_h[k], ld_o[k]) < 1e-4, (k, ld_h[k], ld_o[k])

@@ -277,6 +277,113 @@ def test_benchmark_config_full_batch_step_vs_oracle(version):
         assert rel_err(ld_h[k], ld_o[k]) < 2e-4, (k, ld_h[k], ld_o[k])
 
 
+def _grad_table(m, o, o64=None):
+    """(name, HIP-vs-oracle error, tensor scale, oracle-fp32-vs-float64 error or None) for every parameter with a gradient."""
+    named = dict(m.named_parameters())
+    out = []
+    for k, p in o.P.items():
+        if k == 'learned_betas' or p.grad is None:
+            continue
+        gh = named[k].grad.detach().cpu().double()
+        out.append((k, float((gh - p.grad.double()).abs().max()), float(p.grad.abs().max()),
+                    None if o64 is None else float((p.grad.double() - o64.P[k].grad).abs().max())))
+    return out
+
+
+@pytest.mark.parametrize('B', [512, 2400])
+def test_every_gradient_at_real_size_with_the_mesh_term_off(B):
+    """SURVEY 8(d)'s gradient bar at the REAL sizes (h = 1000, RBF 100, K = 200, 6890 vertices; a minibatch of 512 and
+    the full 8 x 300 batch): with weight_vp_loss = 0 -- no L1 term, whose sign(0) ties are the one place where two
+    correct fp32 evaluations may differ by more than rounding -- EVERY parameter gradient of one update step is within
+    1e-4 of the oracle's (relative to the tensor's largest entry) plus the oracle's own fp32-vs-float64 distance -- which is
+    what lets the ill-conditioned phase-network gradients (differences of saturated sigmoids) in --, and no shared, camera
+    or code gradient is further than 2e-4 in any case."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    from oracle.model import OracleNemo
+    V, T = 8, 300
+    args = syn.published_args(batch_size=512, out_dir='', weight_vp_loss=0)
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    torch.manual_seed(0)
+    m = NemoV2(args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+    with torch.no_grad():
+        m.learned_motion.rot_out.weight.mul_(2e3)
+    o = OracleNemo(2, args, seqs, assets, vps, gmm, state={k: v.detach().cpu() for k, v in m.state_dict().items()})
+    torch.manual_seed(4)
+    if B == 2400:
+        call = lambda mdl: mdl.step(None, None, update=True, full_batch=True)
+    else:
+        vi, fi = torch.randint(0, V, (B,)), torch.randint(0, T, (B,))
+        call = lambda mdl: mdl.step(vi, fi, update=True)
+    o64 = _float64_twin(o)
+    torch.set_default_dtype(torch.float64)
+    try:
+        call(o64)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    ld_o, _ = call(o)
+    ld_h, _ = call(m)
+    for k in ld_o:
+        assert rel_err(ld_h[k], ld_o[k]) < 1e-4 or abs(float(ld_o[k])) < 1e-12, (k, ld_h[k], ld_o[k])
+    table = _grad_table(m, o, o64)
+    assert len(table) >= 28
+    worst = max(err / scale for k, err, scale, _ in table if not k.startswith('phase_networks.') and scale > 0)
+    print('worst non-phase gradient error / scale:', worst)
+    for k, err, scale, noise in table:
+        # 1e-4 of the tensor's scale, plus what the ORACLE's own fp32 arithmetic is away from a float64 evaluation of the
+        # same step (sums over 2400 samples: 1e-5 of the scale for the instance codes; the phase networks, differences of
+        # saturated sigmoids: up to 1e-2)
+        assert err <= 1e-4 * scale + 3.0 * noise, (k, err, scale, noise)
+        if not k.startswith('phase_networks.'):
+            assert err <= 2e-4 * scale, (k, err, scale)
+
+
+def test_default_v1_at_its_real_hyper_parameters_in_lock_step():
+    """config/default-v1.yml as shipped (NemoV1, h 500, K 200, C 10, batch 128, lr_human 0.01, plateau schedulers with
+    factor 0.5; BASELINE configs[0]: 1 instance x 30 frames) on the 6890-vertex mesh: 30 update steps in lock step -- the
+    CPU oracle drives, before every step the HIP model takes over its parameters, Adam state, learning rates and
+    scheduler state; every loss term and per-joint loss of every step within 1e-4, every gradient within 1e-3 of its
+    scale (the V = 1 branch of engine.ldp and the single-view keypoint mean at real sizes)."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV1
+    from oracle.model import OracleNemo
+    V, T = 1, 30
+    args = syn.default_v1_args(out_dir='')
+    assert (args.h_dim, args.monotonic_network_n_nodes, args.instance_code_size, args.batch_size, args.lr_factor) == \
+        (500, 200, 10, 128, 0.5)
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    torch.manual_seed(0)
+    m = NemoV1(args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+    assert m.engine.ldp == 2 * 200 + 8 and len(m.schedulers) == 4
+    with torch.no_grad():
+        m.learned_motion.rot_out.weight.mul_(2e3)
+    o = OracleNemo(1, args, seqs, assets, vps, gmm, state={k: v.detach().cpu() for k, v in m.state_dict().items()})
+    gen = torch.Generator().manual_seed(6)
+    first_lr = o.optimizers[1].param_groups[0]['lr']
+    for s in range(30):
+        m.load_state_dict({k: v for k, v in o.state_dict().items()}, strict=False)
+        for mo, oo in zip(m.optimizers, o.optimizers):
+            sd = oo.state_dict()
+            if sd['state']:
+                mo.load_state_dict(sd)
+            mo.param_groups[0]['lr'] = oo.param_groups[0]['lr']
+        for ms, os_ in zip(m.schedulers, o.schedulers):
+            ms.load_state_dict({k: v for k, v in os_.state_dict().items() if k != 'optimizer'})
+        vi, fi = torch.randint(0, V, (128,), generator=gen), torch.randint(0, T, (128,), generator=gen)
+        ld_o, info_o = o.step(vi, fi)
+        ld_h, info_h = m.step(vi, fi)
+        assert ld_h.keys() == ld_o.keys()
+        for k in ld_o:
+            assert rel_err(ld_h[k], ld_o[k]) < 1e-4 or abs(float(ld_o[k])) < 1e-12, (s, k, ld_h[k], ld_o[k])
+        assert rel_err(info_h['loss_all'], info_o['loss_all']) < 1e-4, s
+        assert rel_err(info_h['j'], info_o['j']) < 1e-4, s
+        for k, err, scale, _ in _grad_table(m, o):
+            if not k.startswith('phase_networks.'):
+                assert err <= 1e-3 * scale, (s, k, err, scale)
+    for mo, oo in zip(m.optimizers, o.optimizers):
+        assert mo.param_groups[0]['lr'] == oo.param_groups[0]['lr']
+
+
 def test_more_than_one_mesh_chunk_vs_oracle():
     """N > 8192: the full-mesh term is processed in 8192-sample chunks (so that dVP^T stays bounded at any N);
     a 4 x 2058 full batch (N = 8232: one whole chunk + a ragged 40-sample one) on a small mesh against the oracle."""

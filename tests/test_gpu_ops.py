@@ -532,6 +532,18 @@ def test_v2v_fused_mesh_kernel(L, num_verts, N, plan, monkeypatch):
                                 ldn, dA.data_ptr(), ws.data_ptr(), ws.numel() * 4, H.st()) == 0
     assert rel_err(loss[0], l1.detach()) < 1e-5
     assert float(dVPt[NV3:].abs().sum()) == 0.0 and float(dVPt[:, N:].abs().sum()) == 0.0   # pads stay zero
+    # deferred combine (dA = NULL + nemo_v2v_combine, what the step runs beside the adjoint GEMM): bit-identical dA, and
+    # an in-launch combine afterwards still finds its tickets at zero
+    loss2, dVPt2, dA2 = Z(1), Z(3 * ctx.NVp, ldn), Z(N, 24, 12).fill_(-3.0)
+    assert L.nemo_v2v_fused(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss2.data_ptr(), dVPt2.data_ptr(),
+                            ldn, None, ws.data_ptr(), ws.numel() * 4, H.st()) == 0
+    assert L.nemo_v2v_combine(ctx.handle, N, dA2.data_ptr(), ws.data_ptr(), ws.numel() * 4, H.st()) == 0
+    assert torch.equal(dA2, dA) and torch.equal(dVPt2, dVPt) and torch.equal(loss2, loss)
+    dA3 = Z(N, 24, 12)
+    loss2.zero_()
+    assert L.nemo_v2v_fused(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss2.data_ptr(), dVPt2.data_ptr(),
+                            ldn, dA3.data_ptr(), ws.data_ptr(), ws.numel() * 4, H.st()) == 0
+    assert torch.equal(dA3, dA)
     assert L.nemo_gemm_f32(1, 1, N, 207, NV3, dVPt.data_ptr(), ldn, ctx.posedirs, ctx.ldP, dPF.data_ptr(), 208,
                            None, 0, None, 0, 0, 1.0, 2, 8, None, 0, H.st()) == 0
     assert L.nemo_fk_bwd(ctx.handle, N, dR2.data_ptr(), A.data_ptr(), dA.data_ptr(), None, dPF.data_ptr(), 208,
