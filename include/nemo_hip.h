@@ -62,6 +62,23 @@ int32_t nemo_gemm_bf16(int32_t transA, int32_t transB, int64_t M, int64_t N, int
                        const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
                        int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream);
 /* out[n] += sum_m X[m*ldx+n]   (bias gradients). */
+/* Up to NEMO_GEMM_GROUP_MAX independent products C_i (op)= alpha_i * opA(A_i) @ opB(B_i) (out_mode 0 store / 1 C +=; no
+ * bias / activation / mask) in ONE launch when they share a layout and their operands are 16-byte aligned -- the
+ * parameter gradients dW_l = dY_l^T X_l of the whole MotionNet backward (nemo/neural_motion_model.py:58-71,130-148 under
+ * autograd): four launches of 32 ... 256 tiles, each paying its own pipeline fill and output burst at one block per CU,
+ * become one of 592; the small problems are cut along K to fill the launch's last slots.  Anything else runs as
+ * consecutive nemo_gemm_f32 calls with the same results.  `ws` as for nemo_gemm_f32 (the problems share it).
+ * nemo_gemm_grouped_bf16: operands rounded to bf16 on their way into the matrix cores, as nemo_gemm_bf16. */
+#define NEMO_GEMM_GROUP_MAX 4
+typedef struct {
+    int32_t transA, transB; int64_t M, N, K;
+    const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc;
+    float alpha; int32_t out_mode;
+} nemo_gemm_problem;
+int32_t nemo_gemm_grouped_f32(int32_t n, const nemo_gemm_problem* problems /* HOST array */, void* ws, int64_t ws_bytes,
+                              void* stream);
+int32_t nemo_gemm_grouped_bf16(int32_t n, const nemo_gemm_problem* problems /* HOST array */, void* ws, int64_t ws_bytes,
+                               void* stream);
 int32_t nemo_colsum_f32(const float* X, int64_t M, int64_t N, int64_t ldx, float* out, void* stream);
 /* The same for up to NEMO_COLSUM_MAX matrices in ONE launch (all bias gradients of the MLP backward). */
 #define NEMO_COLSUM_MAX 8

@@ -19,6 +19,12 @@ class ColsumDesc(Structure):
     _fields_ = [('X', c_void_p), ('M', c_int64), ('N', c_int64), ('ldx', c_int64), ('out', c_void_p)]
 
 
+class GemmProblem(Structure):
+    _fields_ = [('transA', c_int32), ('transB', c_int32), ('M', c_int64), ('N', c_int64), ('K', c_int64),
+                ('A', c_void_p), ('lda', c_int64), ('B', c_void_p), ('ldb', c_int64), ('C', c_void_p), ('ldc', c_int64),
+                ('alpha', c_float), ('out_mode', c_int32)]
+
+
 class AdamSeg(Structure):
     _fields_ = [('offset', c_int64), ('numel', c_int64), ('lr', c_float), ('weight_decay', c_float),
                 ('step_size', c_float), ('bias_corr2_sqrt', c_float), ('adamw', c_int32), ('step', c_int32)]
@@ -35,6 +41,8 @@ SIGNATURES = {
                             f32, i32, i32, ptr, i64, ptr]),
     'nemo_gemm_bf16': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32,
                              f32, i32, i32, ptr, i64, ptr]),
+    'nemo_gemm_grouped_f32': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),
+    'nemo_gemm_grouped_bf16': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),
     'nemo_colsum_f32': (i32, [ptr, i64, i64, i64, ptr, ptr]),
     'nemo_colsum_multi': (i32, [i32, POINTER(ColsumDesc), ptr]),
     'nemo_phase_embed_fwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,

@@ -734,6 +734,102 @@ extern "C" int32_t nemo_gemm_bf16(int32_t transA, int32_t transB, int64_t M, int
                      out_mode, split_k, ws, ws_bytes, stream);
 }
 
+// Several independent products of ONE layout in one launch (glds::gemm_glds_grouped_kernel): the parameter gradients
+// dW_l = dY_l^T X_l of the whole MLP backward.  Anything the grouped kernel does not cover (mixed layouts, unaligned
+// operands, more than MAX_GROUP problems, tuning overrides) runs as consecutive single launches: same results.
+static int32_t gemm_grouped_impl(bool bf16, int32_t n, const nemo_gemm_problem* pr, void* ws, int64_t ws_bytes, void* stream) {
+    if (n < 0 || (n && !pr) || ws_bytes < 0 || (ws_bytes > 0 && !ws)) return NEMO_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        const nemo_gemm_problem& q = pr[i];
+        if (q.M < 0 || q.N < 0 || q.K < 0 || !q.C || (q.out_mode != 0 && q.out_mode != 1)) return NEMO_EINVAL;
+        if (q.M && q.N && q.K && (!q.A || !q.B)) return NEMO_EINVAL;
+    }
+    static const bool enabled = [] { const char* f = getenv("NEMO_GEMM_GROUPED"); return !(f && atoi(f) == 0); }();
+    const bool can_split = ws != nullptr && ws_bytes > COUNTER_BYTES && (((uintptr_t)ws) & 15) == 0;
+    bool ok = enabled && n >= 2 && n <= glds::MAX_GROUP && !getenv("NEMO_GEMM_TILE") && !getenv("NEMO_GEMM_SPLIT");
+    glds::GroupArgs ga;
+    long total_tiles = 0, small_tiles = 0;
+    for (int i = 0; ok && i < n; ++i) {
+        const nemo_gemm_problem& q = pr[i];
+        ok = q.M > 0 && q.N > 0 && q.K > 0 && q.transA == pr[0].transA && q.transB == pr[0].transB &&
+             aligned16(q.A, q.lda) && aligned16(q.B, q.ldb);
+        if (!ok) break;
+        GemmArgs& g = ga.p[i];
+        g = GemmArgs{};
+        ok = glds::extents(q.transA, q.transB, q.M, q.N, q.K, q.lda, q.ldb, &g.a_bytes, &g.b_bytes);
+        g.A = q.A; g.B = q.B; g.C = q.C; g.bias = nullptr; g.mask = nullptr;
+        g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.ldc = q.ldc; g.ldmask = 0;
+        g.act = 0; g.mask_mode = 0; g.out_mode = q.out_mode; g.alpha = q.alpha;
+        g.tiles_m = (int)((q.M + 63) / 64); g.tiles_n = (int)((q.N + 63) / 64); g.n_tiles = g.tiles_m * g.tiles_n;
+        g.xcd_order = 0;
+        total_tiles += g.n_tiles;
+        if (g.n_tiles <= 64) small_tiles += g.n_tiles;
+    }
+    if (!ok) {
+        for (int i = 0; i < n; ++i) {
+            const nemo_gemm_problem& q = pr[i];
+            const int32_t rc = gemm_impl(bf16, q.transA, q.transB, q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, nullptr, 0,
+                                         nullptr, 0, 0, q.alpha, q.out_mode, 0, ws, ws_bytes, stream);
+            if (rc) return rc;
+        }
+        return NEMO_OK;
+    }
+    // Balance: three blocks are resident per CU (768 slots).  The large problems keep whole tiles; if slots are left over in
+    // the launch's only round, the SMALL problems (<= 64 tiles: the head and first-layer gradients) are cut along K to fill
+    // them -- 512 + 48 + 32 tiles of the 8 x 300 step become 512 whole tiles + 80 tiles x 3 slices = 752 blocks.
+    int S = 1;
+    if (can_split && small_tiles > 0 && total_tiles < 768) {
+        S = 1 + (int)((768 - total_tiles) / small_tiles);
+        if (S > 4) S = 4;
+    }
+    long ticket0 = 0, slab_bytes = COUNTER_BYTES, blk = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs& g = ga.p[i];
+        int s_i = (g.n_tiles <= 64) ? S : 1;
+        while (s_i > 1 && g.K / s_i < 256) --s_i;                         // >= 8 K tiles per slice
+        long kc = ((g.K + s_i - 1) / s_i + 31) / 32 * 32;
+        g.k_chunk = kc;
+        g.split = (int)((g.K + kc - 1) / kc);
+        g.t0 = g.split > 1 ? 0 : g.n_tiles;
+        g.counters = reinterpret_cast<int*>(ws) + ticket0;
+        g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + slab_bytes);
+        if (g.split > 1) {
+            ticket0 += g.n_tiles;
+            slab_bytes += (long)g.n_tiles * g.split * 64 * 64 * 4;
+            if (ticket0 > COUNTER_BYTES / 4 || slab_bytes > ws_bytes) return NEMO_EINVAL;
+        }
+        ga.blk0[i] = (int)blk;
+        blk += g.split > 1 ? (long)g.n_tiles * g.split : g.n_tiles;
+    }
+    for (int i = n; i <= glds::MAX_GROUP; ++i) ga.blk0[i] = (int)blk;
+    for (int i = n; i < glds::MAX_GROUP; ++i) ga.p[i] = ga.p[0];
+    static const bool debug = getenv("NEMO_GEMM_DEBUG") != nullptr;
+    if (debug) fprintf(stderr, "nemo_gemm_grouped n=%d ta=%d tb=%d: %ld tiles, small-problem split %d -> %ld blocks\n", n,
+                       pr[0].transA, pr[0].transB, total_tiles, S, blk);
+    const bool akc = !pr[0].transA, bkc = pr[0].transB != 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+    if (bf16) {
+        if (akc && bkc) e = glds::launch_grouped<64, 64, 32, 32, 32, true, true, 3, true, true>(ga, s);
+        else if (akc) e = glds::launch_grouped<64, 64, 32, 32, 32, true, false, 3, true, true>(ga, s);
+        else if (bkc) e = glds::launch_grouped<64, 64, 32, 32, 32, false, true, 3, true, true>(ga, s);
+        else e = glds::launch_grouped<64, 64, 32, 32, 32, false, false, 3, true, true>(ga, s);
+    } else if (akc && bkc) e = glds::launch_grouped<64, 64, 32, 32, 32, true, true, 3, true>(ga, s);
+    else if (akc) e = glds::launch_grouped<64, 64, 32, 32, 32, true, false, 3, true>(ga, s);
+    else if (bkc) e = glds::launch_grouped<64, 64, 32, 32, 32, false, true, 3, true>(ga, s);
+    else e = glds::launch_grouped<64, 64, 32, 32, 32, false, false, 3, true>(ga, s);
+    if (e != hipSuccess) return (int32_t)e;
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_gemm_grouped_f32(int32_t n, const nemo_gemm_problem* problems, void* ws, int64_t ws_bytes, void* stream) {
+    return gemm_grouped_impl(false, n, problems, ws, ws_bytes, stream);
+}
+extern "C" int32_t nemo_gemm_grouped_bf16(int32_t n, const nemo_gemm_problem* problems, void* ws, int64_t ws_bytes, void* stream) {
+    return gemm_grouped_impl(true, n, problems, ws, ws_bytes, stream);
+}
+
 // Column sums of a row-major (M x N) matrix: out[n] (+)= sum_m X[m][n].  Bias gradients.
 namespace {
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long M, long N, long ldx,

@@ -177,7 +177,7 @@ struct Operand {
 // BF16: operands are rounded to bf16 on their way from LDS into the matrix cores (v_mfma_f32_32x32x16_bf16, fp32
 // accumulate; memory stays fp32 on both sides) -- BASELINE configs[2].
 template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>
-__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(Args g) {
+__device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, float* smem) {
     constexpr int TM = WM / T, TN = WN / T, WGN = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves");
     constexpr int KG = T == 32 ? 8 : 16, NQ = BK / KG, AR = T * T / 64;      // AR: accumulator registers
@@ -194,9 +194,6 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(Args g) {
     static_assert(!BF16 || T == 32, "bf16 path uses the 32x32x16 MFMA");
     constexpr int G = OA::PER_WAVE + OB::PER_WAVE;                           // pieces per wave and tile (UNIFORM)
     typedef float accv __attribute__((ext_vector_type(AR)));
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int bid = blockIdx.x;
     const bool whole = bid < g.t0 || g.xcd_order;
     const int n_tail = g.n_tiles - g.t0;
     int tile = whole ? bid : g.t0 + (bid - g.t0) % n_tail;
@@ -452,6 +449,47 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(Args g) {
                 else atomicAdd(c, v);
             }
         }
+}
+
+template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(Args g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_glds_body<BM, BN, WM, WN, T, AKC, BKC, NST, SPREAD, BF16>(g, (int)blockIdx.x, smem);
+}
+
+// Several independent problems of ONE layout in one launch (round 3: the parameter-gradient GEMMs of the whole MLP
+// backward, dW_l = dY_l^T X_l -- four launches of 32 ... 256 tiles each, every one paying its own ~8 us of pipeline fill,
+// output burst and launch latency at one block per CU, become one launch of 592 tiles).  Problem i owns blocks
+// [blk0[i], blk0[i + 1]); inside them the block id means what it means in a launch of that problem alone (whole tiles
+// / K slices / slabs and tickets at the problem's own scratch offsets).
+constexpr int MAX_GROUP = 4;
+struct GroupArgs {
+    Args p[MAX_GROUP];
+    int blk0[MAX_GROUP + 1];
+};
+template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>
+__global__ __launch_bounds__(256, 2) void gemm_glds_grouped_kernel(GroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_GROUP; ++q) i += bid >= ga.blk0[q] ? 1 : 0;       // (blk0 of unused problems = total)
+    gemm_glds_body<BM, BN, WM, WN, T, AKC, BKC, NST, SPREAD, BF16>(ga.p[i], bid - ga.blk0[i], smem);
+}
+
+template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>
+hipError_t launch_grouped(const GroupArgs& ga, hipStream_t s) {
+    constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(float);
+    static bool attr_set = false;
+    auto kern = &gemm_glds_grouped_kernel<BM, BN, WM, WN, T, AKC, BKC, NST, SPREAD, BF16>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(ga.blk0[MAX_GROUP]), dim3(256), lds, s, ga);
+    return hipSuccess;
 }
 
 template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>

@@ -293,6 +293,7 @@ class FitEngine:
         self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(3)]
         self.overlap_bwd = os.environ.get('NEMO_SERIAL_BWD', '0') == '0'
         self.defer_combine = self.overlap_bwd and os.environ.get('NEMO_DEFER_COMBINE', '1') != '0'
+        self.dw_group = int(os.environ.get('NEMO_DW_GROUP', '1'))
         self._colsums = []
         self._seg_host = self._seg_dev = self._seg_pending = None
         self.timers = None
@@ -445,6 +446,19 @@ class FitEngine:
         self.gemm(1, 0, fout, fin, rows, dy, lddy, x, ldx, gw, fin, out_mode=1, dense=True)
         if gb is not None:       # bias gradients are batched into one launch (flush_colsums)
             self._colsums.append((dy, rows, fout if nbias is None else nbias, lddy, gb))
+
+    def gemm_grouped(self, problems, dense=True):
+        """problems: list of (ta, tb, M, N, K, A, lda, B, ldb, C, ldc, out_mode) -- independent products of one layout in
+        ONE launch (nemo_gemm_grouped_f32: the parameter gradients of the whole MLP backward)."""
+        arr = (_lib.GemmProblem * len(problems))()
+        for i, (ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, om) in enumerate(problems):
+            q = arr[i]
+            q.transA, q.transB, q.M, q.N, q.K = ta, tb, M, N, K
+            q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.alpha, q.out_mode = A, lda, B, ldb, Cp, ldc, 1.0, om
+        cur = torch.cuda.current_stream()
+        ws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]
+        fn = self.lib.nemo_gemm_grouped_bf16 if (dense and self.bf16) else self.lib.nemo_gemm_grouped_f32
+        check(fn(len(problems), arr, ws.data_ptr(), ws.numel() * 4, _stream()), 'nemo_gemm_grouped')
 
     def flush_colsums(self):
         if not self._colsums:
@@ -747,6 +761,54 @@ class FitEngine:
 
         def dY_ready():
             return main.record_event() if small else None
+
+        # Round 3: ALL parameter-gradient GEMMs of the backward as ONE grouped launch (nemo_gemm_grouped_f32) on the side
+        # stream once the last dY of the dX chain exists, beside the layer-0 dX GEMM and the phase backward on the main
+        # stream: four launches of 32 - 256 tiles (each with its own pipeline fill / output burst at ~one block per CU) ->
+        # one of 592 tiles (NEMO_DW_GROUP=0: the per-layer launches; 2: the grouped launch on the main stream)
+        # Measured (same box, un-profiled): one-instance shard 0.493 ms grouped against 0.501 per layer; 8 x 300: 1.567 against
+        # 1.559 (there the per-layer launches on the 64 x 64 / 8-wave skinny configuration are ahead) -> small batches only.
+        grp = self.dw_group if (not bucketed and tuple(stages) == (0, 1, 2) and (small or self.dw_group == 2)) else 0
+        if grp:
+            dWs = []
+
+            def dWg(rows, x, ldx_, fin, dy, lddy, fout, gw, gb, nbias=None):
+                dWs.append((1, 0, fout, fin, rows, dy, lddy, x, ldx_, gw, fin, 1))
+                if gb is not None:
+                    self._colsums.append((dy, rows, fout if nbias is None else nbias, lddy, gb))
+            dWg(r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout, self.g(lm + 'rot_out.weight'),
+                self.g(lm + 'rot_out.bias'), nbias=nbias)
+            self.gemm(0, 0, r, h, nout, dptr(w['dHEAD']), HEAD_LD, self.p(lm + 'rot_out.weight'), h,
+                      dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1, dense=True)
+            dWg(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
+            self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
+                      mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx', dense=True)
+            dWg(r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+            self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
+                      mask=dptr(w['H1']), ldmask=h, mask_mode=1, dense=True)
+            dWg(r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h, self.g(lm + 'net.net.0.weight'),
+                self.g(lm + 'net.net.0.bias'))
+            ev = main.record_event()
+            self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
+                      dptr(w['dX']), self.ldx, dense=True)
+            check(L.nemo_phase_embed_bwd(
+                N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
+                self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), self.ldp,
+                self.p('phase_rbf.log_sigmas') if self.D > 0 else None, self.kernel_id, dptr(w['phase']),
+                dptr(w['dX']), self.ldx, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
+                self.g('phase_networks.0.scales'),
+                self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
+                self.g('learned_instance_code') if self.C > 0 else None, _stream()), 'nemo_phase_embed_bwd')
+            if grp == 2 or not overlap:
+                self.gemm_grouped(dWs)
+                self.flush_colsums()
+            else:
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self.gemm_grouped(dWs)
+                    self.flush_colsums()
+                main.wait_stream(side)
+            return
 
         def end_of_stage():
             """bucketed: this stage's parameter gradients (incl. the bias column sums) are complete on `main`."""

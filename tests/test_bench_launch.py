@@ -89,7 +89,7 @@ def _rccl_world1(mode, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('mode', ['single', 'split'])
+@pytest.mark.parametrize('mode', ['single', 'split', 'buckets'])
 def test_sharded_step_over_rccl_world_of_one(mode):
     """RCCL (backend 'nccl') on hardware: communicator creation, the all-reduce(s) of the sharded step on their
     streams, the watchdog thread next to HIP-graph capture and replay.  Numerically a 1-rank all-reduce is the
@@ -122,3 +122,38 @@ def test_sharded_step_over_rccl_world_of_one(mode):
             ld, _ = m.step(torch.randint(0, V, (B,), generator=g), torch.randint(0, T, (B,), generator=g))
         for k, v in ld.items():
             assert abs(got[it][k] - float(v)) <= 1e-4 * max(abs(float(v)), 1e-6), (it, k, got[it][k], float(v))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_as_the_driver_launches_them(tmp_path):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2 ...` -- the driver's own command
+    line for the scaling run -- on the one GPU of this box (gloo instead of RCCL, which refuses two ranks per device):
+    the whole N > 1 path of bench.py (world check, `--shard-mode auto` over all three layouts, the timed regions, the
+    per-rank compute / collective probe, the sharded minibatch leg with padded launches, the roofline leg) must
+    produce ONE JSON line with the contract's keys."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, NEMO_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), BENCH, '--gpus', '2', '--instances', '2', '--steps', '4', '--warmup', '1', '--repeat', '2',
+           '--minibatch-steps', '6']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1, r.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['ranks_seen'] == [0, 1] and out['steps'] == 4 and out['scaling'] == 'strong'
+    assert out['value'] > 0 and abs(out['value'] * out['ms_per_step'] / 1e3 - 1) < 0.01
+    assert set(out['shard_modes_ms']) == {'single', 'split', 'buckets'} and out['shard_mode'] in out['shard_modes_ms']
+    assert out['collectives_per_step'] == {'single': 1, 'split': 2, 'buckets': 3}[out['shard_mode']]
+    assert [p['rank'] for p in out['per_rank']] == [0, 1] and all(p['compute_ms'] > 0 and p['instances'] == 1 for p in out['per_rank'])
+    assert out['scaling_model']['predicted_ms_per_step_no_overlap'] >= out['scaling_model']['shard_step_ms']
+    assert len(out['repeat_ms_per_step']) == 2
+    assert out['minibatch512']['steps'] == 6 and out['minibatch512']['value'] > 0
+    assert out['roofline']['kernel'] == 'mesh_v2v_fused' and 0 < out['roofline']['frac'] < 1
+    assert out['config']['parallelism'] == 'instance-shard x2'

@@ -782,6 +782,50 @@ def test_gemm_skinny_paths(L, ta, tb, M, N, K, pad):
     assert int(H.gemm_ws()[:4096].view(torch.int32).abs().sum()) == 0        # tickets of the sliced launches back at zero
 
 
+@pytest.mark.parametrize('rows', [2401, 301, 37])
+@pytest.mark.parametrize('bf16', [False, True])
+def test_gemm_grouped_parameter_gradients(L, rows, bf16):
+    """nemo_gemm_grouped_f32 / _bf16: the four parameter-gradient products dW = dY^T X of the MotionNet backward (heads 147,
+    two hidden layers, first layer with its 108-float row stride) in ONE launch -- `C +=` on the two big ones and a plain
+    store on the others, the small problems cut along K at 2401 rows -- against float64; a repeat is bit-identical; the
+    tickets are back at zero; a group of mixed layouts falls back to single launches with the same results."""
+    from nemo_cvpr2023_amd._lib import GemmProblem, check
+    H = _ops()
+    g = torch.Generator().manual_seed(rows + bf16)
+    h, din, ldx = 1000, 105, 108
+    dHEAD, H3 = H.dev(torch.randn(rows, 148, generator=g)), H.dev(torch.randn(rows, h, generator=g))
+    dH, H2 = H.dev(torch.randn(rows, h, generator=g)), H.dev(torch.randn(rows, h, generator=g))
+    dHb, H1 = H.dev(torch.randn(rows, h, generator=g)), H.dev(torch.randn(rows, h, generator=g))
+    dHc, X = H.dev(torch.randn(rows, h, generator=g)), H.dev(torch.randn(rows, ldx, generator=g))
+    probs = [(147, h, dHEAD, 148, H3, h, 1), (h, h, dH, h, H2, h, 1), (h, h, dHb, h, H1, h, 0), (h, din, dHc, h, X, ldx, 1)]
+    fn = L.nemo_gemm_grouped_bf16 if bf16 else L.nemo_gemm_grouped_f32
+    tol = 1e-2 if bf16 else TOL
+    ws = H.gemm_ws()
+
+    def run(problems):
+        C0 = [H.dev(torch.randn(M, N, generator=torch.Generator().manual_seed(i))) for i, (M, N, *_) in enumerate(problems)]
+        Cs = [c.clone() for c in C0]
+        arr = (GemmProblem * len(problems))()
+        for i, (M, N, A, lda, B, ldb, om) in enumerate(problems):
+            q = arr[i]
+            q.transA, q.transB, q.M, q.N, q.K = 1, 0, M, N, rows
+            q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.alpha, q.out_mode = A.data_ptr(), lda, B.data_ptr(), ldb, Cs[i].data_ptr(), N, 1.0, om
+        check(fn(len(problems), arr, ws.data_ptr(), ws.numel() * 4, H.st()), 'grouped')
+        return C0, Cs
+    C0, Cs = run(probs)
+    for (M, N, A, lda, B, ldb, om), c0, c in zip(probs, C0, Cs):
+        ref = A[:, :M].double().T @ B[:, :N].double() + (c0.double() if om else 0)
+        assert rel_err(c, ref) < tol, (M, N, om)
+    _, Cs2 = run(probs)
+    assert all(torch.equal(a, b) for a, b in zip(Cs, Cs2))
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+    # two problems only; and a single one (falls back to nemo_gemm_f32)
+    for sub in (probs[:2], probs[1:2]):
+        C0, Cs = run(sub)
+        for (M, N, A, lda, B, ldb, om), c0, c in zip(sub, C0, Cs):
+            assert rel_err(c, A[:, :M].double().T @ B[:, :N].double() + (c0.double() if om else 0)) < tol
+
+
 def test_gemm_auto_plan_random_shapes(L):
     """split_k = 0 over random problems on both sides of every kernel-selection threshold (skinny 32x32 / 32x64 /
     64x64 / sliced, LDS-DMA tiles, first-generation kernel for unaligned rows): product, bias + ReLU, determinism."""
