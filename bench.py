@@ -305,7 +305,11 @@ def main():
     # (like a compile step); they are not part of the warm-up / timed protocol below
     shard_modes = None
     if sharded:
-        modes = ['single', 'split', 'buckets'] if opts.shard_mode == 'auto' else [opts.shard_mode]
+        # auto: one collective per step against the early loss all-reduce; the three-bucket layout only where a rank's step is
+        # long enough for it to matter (it costs two more launches per step and is host-bound below ~1 ms per step:
+        # profiles/r03_bench_lines.md) -- e.g. BASELINE configs[3], 256 x 1024 over 8 GPUs = 32 768 samples per rank
+        modes = (['single', 'split'] + (['buckets'] if V * T // max(world, 1) >= 4096 else [])) if opts.shard_mode == 'auto' \
+            else [opts.shard_mode]
         shard_modes = {}
         for mode in modes:
             model.set_shard_mode(mode)

@@ -149,7 +149,7 @@ def test_bench_two_ranks_as_the_driver_launches_them(tmp_path):
     out = json.loads(line[0])
     assert out['n_gpus'] == 2 and out['ranks_seen'] == [0, 1] and out['steps'] == 4 and out['scaling'] == 'strong'
     assert out['value'] > 0 and abs(out['value'] * out['ms_per_step'] / 1e3 - 1) < 0.01
-    assert set(out['shard_modes_ms']) == {'single', 'split', 'buckets'} and out['shard_mode'] in out['shard_modes_ms']
+    assert set(out['shard_modes_ms']) == {'single', 'split'} and out['shard_mode'] in out['shard_modes_ms']     # (300 samples per rank)
     assert out['collectives_per_step'] == {'single': 1, 'split': 2, 'buckets': 3}[out['shard_mode']]
     assert [p['rank'] for p in out['per_rank']] == [0, 1] and all(p['compute_ms'] > 0 and p['instances'] == 1 for p in out['per_rank'])
     assert out['scaling_model']['predicted_ms_per_step_no_overlap'] >= out['scaling_model']['shard_step_ms']

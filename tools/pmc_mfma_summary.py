@@ -21,7 +21,8 @@ def load(path):
 
 
 m = load(os.path.join(G, 'pmc_mfma', 'm_counter_collection.csv'))
-l = load(os.path.join(G, 'pmc_lds', 'l_counter_collection.csv'))
+lp = os.path.join(G, 'pmc_lds', 'l_counter_collection.csv')
+l = load(lp) if os.path.exists(lp) else {}          # (the LDS pass is optional)
 print('| kernel | blocks | launches | GPU cycles | MFMA pipe busy | executed GFLOP | LDS bank-conflict cycles / LDS active cycles |')
 print('|---|---:|---:|---:|---:|---:|---:|')
 rows = []
