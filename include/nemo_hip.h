@@ -62,6 +62,19 @@ int32_t nemo_gemm_bf16(int32_t transA, int32_t transB, int64_t M, int64_t N, int
                        const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
                        int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream);
 /* out[n] += sum_m X[m*ldx+n]   (bias gradients). */
+/* bf16 operands IN MEMORY (round 3): C (M x N, fp32) (op)= maskfn(act(alpha * A @ B^T + bias)) with A (M x K) and B (N x K)
+ * bf16 (uint16_t bit patterns), row-major, k-contiguous; K even, lda / ldb multiples of 8, 16-byte aligned bases.  Same
+ * epilogues and scratch as nemo_gemm_f32; additionally the result can be stored as bf16 (Cb, row stride ldcb) and as its
+ * bf16 TRANSPOSE (CbT (N x M), ldcbt % 4 == 0) -- the k-contiguous operands the following products of an MLP chain need
+ * (forward: next layer's A; dX: next dY; dW = dY^T X: both operands transposed).  The values entering the matrix cores are
+ * the ones nemo_gemm_bf16 rounds on the fly; half the bytes move.  nemo_cast_bf16: dst (bf16) = src (fp32, rows x cols),
+ * transposed when `transpose` != 0; the k-pad up to the next multiple of 8 (bounded by ldd) is zero-filled. */
+int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                          float* C, int64_t ldc, const float* bias, int32_t act, const float* mask, int64_t ldmask,
+                          int32_t mask_mode, float alpha, int32_t out_mode, uint16_t* Cb, int64_t ldcb, uint16_t* CbT,
+                          int64_t ldcbt, void* ws, int64_t ws_bytes, void* stream);
+int32_t nemo_cast_bf16(int64_t rows, int64_t cols, const float* src, int64_t lds, uint16_t* dst, int64_t ldd,
+                       int32_t transpose, void* stream);
 /* Up to NEMO_GEMM_GROUP_MAX independent products C_i (op)= alpha_i * opA(A_i) @ opB(B_i) (out_mode 0 store / 1 C +=; no
  * bias / activation / mask) in ONE launch when they share a layout and their operands are 16-byte aligned -- the
  * parameter gradients dW_l = dY_l^T X_l of the whole MotionNet backward (nemo/neural_motion_model.py:58-71,130-148 under

@@ -533,11 +533,15 @@ static int skinny_kind(bool akc, bool bkc, bool aligned, bool can_split, long M,
     return aligned && K >= 512 && t3264 >= 128 && t3264 <= 256 ? 1 : 0;
 }
 
-static int32_t gemm_impl(bool bf16, int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
+// bf16: 0 = fp32 arithmetic; 1 = fp32 operands in memory, rounded to bf16 on their way into the matrix cores; 2 = operands
+// ALREADY bf16 in memory (NT only: A (M x K) and B (N x K) k-contiguous; A / B / lda / ldb / K arrive in units of bf16
+// PAIRS, i.e. as the fp32-typed view of the same bytes), optional bf16 copies of the result (Cb, CbT)
+static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
                          const float* A, int64_t lda, const float* B, int64_t ldb,
                          float* C, int64_t ldc, const float* bias, int32_t act,
                          const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
-                         int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream) {
+                         int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream,
+                         unsigned short* Cb = nullptr, long ldcb = 0, unsigned short* CbT = nullptr, long ldcbt = 0) {
     if (M < 0 || N < 0 || K < 0 || !C) return NEMO_EINVAL;
     if (M == 0 || N == 0) return NEMO_OK;
     if (K > 0 && (!A || !B)) return NEMO_EINVAL;
@@ -683,6 +687,8 @@ static int32_t gemm_impl(bool bf16, int32_t transA, int32_t transB, int64_t M, i
     // requested issued between the MFMAs of the tile being multiplied.  Same tiles, slices, slabs and epilogue as the
     // register-staged kernel below, which keeps the unaligned operands, the 128x128 tile and very large operands.
     g.xcd_order = 0;
+    g.Cb = Cb; g.ldcb = ldcb; g.CbT = CbT; g.ldcbt = ldcbt;
+    if (bf16 == 2 && !(tile == 64 && glds_ok && !transA && transB)) return NEMO_EINVAL;
     if (tile == 64 && glds_ok) {
         g.a_bytes = a_bytes; g.b_bytes = b_bytes;
         static const bool xcd_ok = [] { const char* f = getenv("NEMO_GEMM_XCD"); return !(f && atoi(f) == 0); }();
@@ -692,7 +698,8 @@ static int32_t gemm_impl(bool bf16, int32_t transA, int32_t transB, int64_t M, i
             nblocks = 8L * ((g.tiles_m + 7) / 8) * g.tiles_n;
         }
         const bool akc = !transA, bkc = transB != 0;
-        if (bf16) {
+        if (bf16 == 2) e = glds::launch<64, 64, 32, 32, 32, true, true, 3, true, 2>(g, (int)nblocks, s);
+        else if (bf16) {
             if (akc && bkc) e = glds::launch<64, 64, 32, 32, 32, true, true, 3, true, true>(g, (int)nblocks, s);
             else if (akc) e = glds::launch<64, 64, 32, 32, 32, true, false, 3, true, true>(g, (int)nblocks, s);
             else if (bkc) e = glds::launch<64, 64, 32, 32, 32, false, true, 3, true, true>(g, (int)nblocks, s);
@@ -732,6 +739,69 @@ extern "C" int32_t nemo_gemm_bf16(int32_t transA, int32_t transB, int64_t M, int
                                   int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream) {
     return gemm_impl(true, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, mask, ldmask, mask_mode, alpha,
                      out_mode, split_k, ws, ws_bytes, stream);
+}
+
+// ---- bf16 operands IN MEMORY (round 3, BASELINE configs[2]) ----------------------------------------------------
+// nemo_gemm_bf16 rounds fp32 operands to bf16 between LDS and the matrix cores: the LDS-DMA stream of fp32 tiles bounds
+// it at ~190 TFLOP/s.  Here the operands are bf16 already (half the bytes through the DMA and LDS, no conversion
+// VALU work): one layout -- both operands k-contiguous, C = A B^T -- which every product of the MLP chain takes once
+// the caller keeps a bf16 copy and a TRANSPOSED bf16 copy of each activation / weight (the kernel's epilogue writes
+// both for its own result: Cb, CbT; nemo_cast_bf16 makes them for everything else).  Same values enter the MFMAs as in
+// nemo_gemm_bf16 (round-to-nearest-even of the same fp32 numbers), same fp32 accumulation.
+extern "C" int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, const uint16_t* B,
+                                     int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t act, const float* mask,
+                                     int64_t ldmask, int32_t mask_mode, float alpha, int32_t out_mode, uint16_t* Cb,
+                                     int64_t ldcb, uint16_t* CbT, int64_t ldcbt, void* ws, int64_t ws_bytes, void* stream) {
+    if (M < 0 || N < 0 || K < 0 || !C || (K & 1) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) return NEMO_EINVAL;
+    if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return NEMO_EINVAL;
+    if (Cb && ldcb < N) return NEMO_EINVAL;
+    if (CbT && (ldcbt < M || (ldcbt & 3) || (((uintptr_t)CbT) & 7))) return NEMO_EINVAL;
+    if (M == 0 || N == 0) return NEMO_OK;
+    if (K == 0) return NEMO_EINVAL;
+    return gemm_impl(2, 0, 1, M, N, K / 2, reinterpret_cast<const float*>(A), lda / 2, reinterpret_cast<const float*>(B),
+                     ldb / 2, C, ldc, bias, act, mask, ldmask, mask_mode, alpha, out_mode, 0, ws, ws_bytes, stream, Cb, ldcb,
+                     CbT, ldcbt);
+}
+
+namespace {
+// dst (bf16) = src (fp32), optionally transposed; 32 x 32 tiles through LDS so that both sides move whole lines.
+// Columns (transpose: rows) beyond the source up to `pad_to` are zero-filled: k-pads of a GEMM operand.
+__global__ __launch_bounds__(256) void cast_bf16_kernel(long rows, long cols, const float* __restrict__ src, long lds,
+                                                        unsigned short* __restrict__ dst, long ldd, int transpose, long pad_to) {
+    __shared__ float t[32][33];
+    const long r0 = (long)blockIdx.y * 32, c0 = (long)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const long r = r0 + i, c = c0 + tx;
+        t[i][tx] = (r < rows && c < cols) ? src[r * lds + c] : 0.f;
+    }
+    __syncthreads();
+    if (!transpose) {
+        for (int i = ty; i < 32; i += 8) {
+            const long r = r0 + i, c = c0 + tx;
+            if (r < rows && c < pad_to) dst[r * ldd + c] = __builtin_bit_cast(unsigned short, (__bf16)t[i][tx]);
+        }
+    } else {
+        for (int i = ty; i < 32; i += 8) {
+            const long c = c0 + i, r = r0 + tx;                  // dst row = source column
+            if (c < cols && r < pad_to) dst[c * ldd + r] = __builtin_bit_cast(unsigned short, (__bf16)t[tx][i]);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int32_t nemo_cast_bf16(int64_t rows, int64_t cols, const float* src, int64_t lds, uint16_t* dst, int64_t ldd,
+                                  int32_t transpose, void* stream) {
+    if (rows < 0 || cols < 0 || !src || !dst || lds < cols || ldd < (transpose ? rows : cols)) return NEMO_EINVAL;
+    if (rows == 0 || cols == 0) return NEMO_OK;
+    const long inner = transpose ? rows : cols;
+    long pad_to = (inner + 7) / 8 * 8;
+    if (pad_to > ldd) pad_to = ldd;
+    dim3 grid(nemo_cdiv(transpose ? cols : pad_to, 32), nemo_cdiv(transpose ? pad_to : rows, 32));
+    hipLaunchKernelGGL(cast_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (long)rows, (long)cols, src, (long)lds,
+                       dst, (long)ldd, (int)transpose, pad_to);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
 }
 
 // Several independent products of ONE layout in one launch (glds::gemm_glds_grouped_kernel): the parameter gradients

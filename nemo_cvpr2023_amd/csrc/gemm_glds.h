@@ -63,6 +63,12 @@ struct Args {
     float alpha;
     unsigned a_bytes, b_bytes;      // buffer extents (last valid byte + 1) of the two operands
     int xcd_order;                  // 1: whole-tile launch of 8 * ceil(tiles_m / 8) * tiles_n blocks in XCD-aware order
+    // optional bf16 copies of the RESULT (after bias / activation / mask), written by the epilogue: Cb[m][n] (row stride
+    // ldcb) and its transpose CbT[n][m] (row stride ldcbt) -- what the next GEMMs of a bf16-in-memory chain read as
+    // k-contiguous operands (round 3, BF16 == 2)
+    unsigned short* Cb = nullptr;
+    unsigned short* CbT = nullptr;
+    long ldcb = 0, ldcbt = 0;
 };
 
 constexpr int BK = 32;
@@ -157,6 +163,14 @@ struct Operand {
         return v;
     }
 
+    // bf16-in-memory tiles (BF16 == 2): a row of the tile is 64 bf16 = 128 B = the same eight 16-byte chunks; chunk
+    // 2 s + h IS the operand of k-step s (16 k) for lane half h -- one ds_read_b128, no conversion
+    static __device__ __forceinline__ bf16x8 fetch16(const float* tile, int row, int s, int h) {
+        static_assert(KC, "bf16-in-memory operands are k-contiguous");
+        const int c = 2 * s + h;
+        return *reinterpret_cast<const bf16x8*>(tile + row * BK + ((c ^ ((row >> 1) & 7)) << 2));
+    }
+
     // four operands (MFMA steps 0..3) of group q for `row`, k-slice h
     template <int KG>      // 8 (32x32x2) or 16 (16x16x4)
     static __device__ __forceinline__ void fetch(const float* tile, int row, int q, int h, float (&f)[4]) {
@@ -176,7 +190,7 @@ struct Operand {
 // the T x T MFMA (T = 32: v_mfma_f32_32x32x2_f32, T = 16: v_mfma_f32_16x16x4_f32).  NST LDS stages.
 // BF16: operands are rounded to bf16 on their way from LDS into the matrix cores (v_mfma_f32_32x32x16_bf16, fp32
 // accumulate; memory stays fp32 on both sides) -- BASELINE configs[2].
-template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>
+template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, int BF16 = 0>
 __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, float* smem) {
     constexpr int TM = WM / T, TN = WN / T, WGN = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves");
@@ -248,7 +262,32 @@ __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, flo
         const float* bs = st + OA::FLOATS;
         const unsigned nb = smem_byte + (unsigned)(((t_next < 0 ? 0 : t_next) % NST) * STAGE * 4);
         const long nk = kbeg + (long)(t_next < 0 ? 0 : t_next) * BK;
-        if constexpr (BF16) {
+        if constexpr (BF16 == 2) {
+            // operands already bf16 in memory: a K tile is 64 k = four MFMA k-steps of 16; the tile being requested goes
+            // out in four quarters behind them
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = OA::fetch16(as, wm * WM + i * 32 + lr, ks, lh);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = OB::fetch16(bs, wn * WN + j * 32 + lr, ks, lh);
+                if constexpr (SPREAD) {
+                    if (t_next >= 0) {
+#pragma unroll
+                        for (int p = (ks * G) / 4; p < ((ks + 1) * G) / 4; ++p) {
+                            if (p < OA::PER_WAVE) oa.dma_one(nb, m0, nk, wid, p);
+                            else ob.dma_one(nb + OA::FLOATS * 4, n0, nk, wid, p - OA::PER_WAVE);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        } else if constexpr (BF16) {
             // two MFMA k-steps of 16 per tile; the tile being requested goes out in two halves behind them
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -431,10 +470,23 @@ __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, flo
             const long n = n0 + wn * WN + j * T + lr;
             if (n >= g.N) continue;
             const float bv = add_bias ? g.bias[n] : 0.f;
+            unsigned short tq[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int r = 0; r < AR; ++r) {
                 const long m = m0 + wm * WM + i * T + (T == 32 ? (r & 3) + 8 * (r >> 2) + 4 * lh : 4 * lh + r);
-                if (m >= g.M) continue;
+                if (m >= g.M) {
+                    if constexpr (BF16 == 2) {
+                        // a ragged last group of four rows: its valid members go out one by one
+                        if (g.CbT && (r & 3) > 0 && m - (r & 3) < g.M) {
+                            for (int u = 0; u < (r & 3); ++u)
+                                if (m - (r & 3) + u < g.M) g.CbT[n * g.ldcbt + m - (r & 3) + u] = tq[u];
+                        }
+                        // odd M: column M of the transposed copy is the k-pad of the product that reads it (K is taken
+                        // in pairs) -- zero it here, the buffer may be shared with larger batches
+                        if (g.CbT && m == g.M && (g.M & 1) && m < g.ldcbt) g.CbT[n * g.ldcbt + m] = 0;
+                    }
+                    continue;
+                }
                 float v = g.alpha * acc[i][j][r] + bv;
                 if (g.act == 1) v = v > 0.f ? v : 0.f;
                 else if (g.act == 2) v = v > 0.f ? v : 0.01f * v;
@@ -445,13 +497,30 @@ __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, flo
                 }
                 float* c = g.C + m * g.ldc + n;
                 if (g.out_mode == 0) *c = v;
-                else if (g.out_mode == 1) *c += v;
+                else if (g.out_mode == 1) { v += *c; *c = v; }
                 else atomicAdd(c, v);
+                if constexpr (BF16 == 2) {
+                    const unsigned short bits = __builtin_bit_cast(unsigned short, (__bf16)v);
+                    if (g.Cb) g.Cb[m * g.ldcb + n] = bits;                 // 32 lanes x 2 B: 64-byte runs along n
+                    if (g.CbT) {
+                        // the lane's registers r = 4 q .. 4 q + 3 are four CONSECUTIVE rows m: one 8-byte store per group
+                        tq[r & 3] = bits;
+                        if ((r & 3) == 3) {
+                            unsigned short* dst = g.CbT + n * g.ldcbt + (m - 3);
+                            if (m < g.M) {                                  // (m - 3 .. m all valid: m ascends inside a group)
+                                uint2 pk;
+                                pk.x = (unsigned)tq[0] | ((unsigned)tq[1] << 16);
+                                pk.y = (unsigned)tq[2] | ((unsigned)tq[3] << 16);
+                                *reinterpret_cast<uint2*>(dst) = pk;
+                            }
+                        }
+                    }
+                }
             }
         }
 }
 
-template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>
+template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, int BF16 = 0>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(Args g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_glds_body<BM, BN, WM, WN, T, AKC, BKC, NST, SPREAD, BF16>(g, (int)blockIdx.x, smem);
@@ -467,7 +536,7 @@ struct GroupArgs {
     Args p[MAX_GROUP];
     int blk0[MAX_GROUP + 1];
 };
-template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>
+template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, int BF16 = 0>
 __global__ __launch_bounds__(256, 2) void gemm_glds_grouped_kernel(GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = (int)blockIdx.x;
@@ -477,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_grouped_kernel(GroupArgs ga)
     gemm_glds_body<BM, BN, WM, WN, T, AKC, BKC, NST, SPREAD, BF16>(ga.p[i], bid - ga.blk0[i], smem);
 }
 
-template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>
+template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, int BF16 = 0>
 hipError_t launch_grouped(const GroupArgs& ga, hipStream_t s) {
     constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(float);
     static bool attr_set = false;
@@ -492,7 +561,7 @@ hipError_t launch_grouped(const GroupArgs& ga, hipStream_t s) {
     return hipSuccess;
 }
 
-template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, bool BF16 = false>
+template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, int BF16 = 0>
 hipError_t launch(const Args& g, int blocks, hipStream_t s) {
     constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(float);
     static bool attr_set = false;

@@ -160,3 +160,48 @@ def test_c3_bf16_step_vs_fp32_oracle():
     for _ in range(4):
         last = m16.step(None, None, update=True, full_batch=True)[0]
     assert np.isfinite(float(last['total_loss'])) and float(last['total_loss']) < first
+
+
+@pytest.mark.parametrize('M,N,K', [(301, 1000, 1000), (2401, 147, 1000), (130, 70, 101), (12000, 512, 63), (77, 207, 2070)])
+def test_gemm_with_bf16_operands_in_memory(L, M, N, K):
+    """nemo_gemm_bf16mem (round 3): operands cast once (nemo_cast_bf16, plain and transposed), then C = A B^T with half the
+    bytes through the LDS-DMA.  Exactly the fp32-accumulated product of the bf16-ROUNDED operands (2e-5), i.e. what
+    nemo_gemm_bf16 computes; fused bias + ReLU, C += mode, and the two bf16 copies of the result the epilogue can write (the
+    result rounded to bf16, plain and transposed); ragged M / N / odd K (the cast's zero pad)."""
+    import hipops as H
+    from nemo_cvpr2023_amd._lib import check, dptr
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = torch.randn(M, K + 3, generator=g).to(DEV)[:, :K]
+    Bt = torch.randn(K, N + 1, generator=g).to(DEV)[:, :N]                # B given as (K x N): goes through the TRANSPOSING cast
+    bias = torch.randn(N, generator=g).to(DEV)
+    Kp = (K + 7) // 8 * 8
+    Ab = torch.full((M, Kp), 0x7fc0, dtype=torch.int16, device=DEV)       # NaN-poisoned: the cast must fill the k-pad with zeros
+    Bb = torch.full((N, Kp), 0x7fc0, dtype=torch.int16, device=DEV)
+    check(L.nemo_cast_bf16(M, K, dptr(A), A.stride(0), dptr(Ab), Kp, 0, H.st()), 'cast')
+    check(L.nemo_cast_bf16(K, N, dptr(Bt), Bt.stride(0), dptr(Bb), Kp, 1, H.st()), 'cast T')
+    rnd = lambda x: x.to(torch.bfloat16)
+    assert torch.equal(Ab[:, :K].view(torch.bfloat16), rnd(A)) and torch.equal(Bb[:, :K].view(torch.bfloat16), rnd(Bt.T))
+    assert int(Ab[:, K:].abs().sum()) == 0 and int(Bb[:, K:].abs().sum()) == 0
+    Keven = (K + 1) // 2 * 2
+    ws = H.gemm_ws()
+    C = torch.zeros(M, N, device=DEV)
+    Mp = (M + 7) // 8 * 8
+    Cb = torch.zeros(M, N, dtype=torch.int16, device=DEV)
+    CbT = torch.zeros(N, Mp, dtype=torch.int16, device=DEV)
+    check(L.nemo_gemm_bf16mem(M, N, Keven, dptr(Ab), Kp, dptr(Bb), Kp, dptr(C), N, dptr(bias), 1, None, 0, 0, 1.0, 0,
+                              dptr(Cb), N, dptr(CbT), Mp, dptr(ws), ws.numel() * 4, H.st()), 'gemm_bf16mem')
+    ref = torch.relu(rnd(A).double() @ rnd(Bt).double() + bias.double())
+    assert rel_err(C, ref) < 2e-5
+    assert torch.equal(Cb.view(torch.bfloat16), rnd(C)) and torch.equal(CbT[:, :M].view(torch.bfloat16), rnd(C).T.contiguous())
+    assert int(CbT[:, M:].abs().sum()) == 0
+    # the on-the-fly kernel on the fp32 operands computes the same thing (it needs 16-byte aligned rows to take its bf16 path)
+    if K % 4 == 0 and N % 4 == 0:
+        C1 = _gemm(L, L.nemo_gemm_bf16, A.contiguous(), Bt.contiguous(), 0, 0, bias=bias, act=1)
+        assert rel_err(C, C1) < 2e-5
+    # C += (parameter-gradient mode)
+    C0 = torch.randn(M, N, generator=g).to(DEV)
+    C2 = C0.clone()
+    check(L.nemo_gemm_bf16mem(M, N, Keven, dptr(Ab), Kp, dptr(Bb), Kp, dptr(C2), N, None, 0, None, 0, 0, 1.0, 1,
+                              None, 0, None, 0, dptr(ws), ws.numel() * 4, H.st()), 'gemm_bf16mem')
+    assert rel_err(C2, C0.double() + rnd(A).double() @ rnd(Bt).double()) < 2e-5
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
