@@ -67,7 +67,9 @@ int32_t nemo_gemm_bf16(int32_t transA, int32_t transB, int64_t M, int64_t N, int
  * epilogues and scratch as nemo_gemm_f32; additionally the result can be stored as bf16 (Cb, row stride ldcb) and as its
  * bf16 TRANSPOSE (CbT (N x M), ldcbt % 4 == 0) -- the k-contiguous operands the following products of an MLP chain need
  * (forward: next layer's A; dX: next dY; dW = dY^T X: both operands transposed).  The values entering the matrix cores are
- * the ones nemo_gemm_bf16 rounds on the fly; half the bytes move.  nemo_cast_bf16: dst (bf16) = src (fp32, rows x cols),
+ * the ones nemo_gemm_bf16 rounds on the fly; half the bytes move.  C may be NULL when Cb / CbT are given (out_mode 0: only the
+ * bf16 copies of the result are kept -- hidden activations).  mask_mode 17 / 18 = modes 1 / 2 with `mask` pointing at a
+ * BF16 matrix (ldmask in bf16 elements), e.g. the bf16 copy of the ReLU output.  nemo_cast_bf16: dst (bf16) = src (fp32, rows x cols),
  * transposed when `transpose` != 0; the k-pad up to the next multiple of 8 (bounded by ldd) is zero-filled. */
 int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
                           float* C, int64_t ldc, const float* bias, int32_t act, const float* mask, int64_t ldmask,
@@ -291,6 +293,11 @@ int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t
 /* The same with the pose blend (lbs.py:229-233, K = 207) on the bf16 matrix cores: blend shapes rounded to bf16 once
  * at nemo_ctx_create, pose features rounded when staged, fp32 accumulate; skinning, L1 and the adjoints in fp32.
  * BASELINE configs[2] ("bf16"); not covered by the 1e-4 parity gate (tests state the bf16 tolerance). */
+/* nemo_v2v_fused_bf16 with d vp written as bf16 and NOT transposed (round 3): dVPb has 16 * ceil(N / 16) rows (one per
+ * sample) of ldk >= 3 * NVp bf16 -- the k-contiguous A operand of the blend-shape adjoint through nemo_gemm_bf16mem. */
+int32_t nemo_v2v_fused_bf16mem(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
+                               float* loss_sum, uint16_t* dVPb, int64_t ldk, float* dA, void* ws, int64_t ws_bytes,
+                               void* stream);
 /* dA == NULL in nemo_v2v_fused(_bf16): DEFERRED combine -- the launch leaves the per-block partial dA images in `ws`
  * and nemo_v2v_combine (same ctx, N, ws; any stream ordered behind the fused launch) sums them into dA (N,24,12),
  * overwriting.  The step runs it beside the blend-shape adjoint GEMM: the last-arriver reduction inside the fused

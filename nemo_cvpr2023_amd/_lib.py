@@ -86,6 +86,7 @@ SIGNATURES = {
     'nemo_v2v_fused': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_fused_bf16': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_combine': (i32, [ptr, i64, ptr, ptr, i64, ptr]),
+    'nemo_v2v_fused_bf16mem': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_prep_fwd': (i32, [i64, ptr, ptr, ptr, ptr, ptr, ptr]),
     'nemo_v2v_prep_bwd': (i32, [i64, ptr, ptr, f32, ptr, ptr, ptr]),
     'nemo_kl_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, i64, ptr, ptr]),

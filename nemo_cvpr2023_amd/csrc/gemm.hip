@@ -541,13 +541,14 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
                          float* C, int64_t ldc, const float* bias, int32_t act,
                          const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
                          int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream,
-                         unsigned short* Cb = nullptr, long ldcb = 0, unsigned short* CbT = nullptr, long ldcbt = 0) {
-    if (M < 0 || N < 0 || K < 0 || !C) return NEMO_EINVAL;
+                         unsigned short* Cb = nullptr, long ldcb = 0, unsigned short* CbT = nullptr, long ldcbt = 0,
+                         const unsigned short* mask16 = nullptr, long ldmask16 = 0) {
+    if (M < 0 || N < 0 || K < 0 || (!C && !(bf16 == 2 && (Cb || CbT) && out_mode == 0))) return NEMO_EINVAL;
     if (M == 0 || N == 0) return NEMO_OK;
     if (K > 0 && (!A || !B)) return NEMO_EINVAL;
     if (act < 0 || act > 2 || mask_mode < 0 || mask_mode > 2 || out_mode < 0 || out_mode > 2)
         return NEMO_EINVAL;
-    if (mask_mode && !mask) return NEMO_EINVAL;
+    if (mask_mode && !mask && !mask16) return NEMO_EINVAL;
     if (split_k < 0 || ws_bytes < 0 || (ws_bytes > 0 && !ws)) return NEMO_EINVAL;
     // atomically accumulated slices are only linear: no activation / mask
     if (out_mode == 2 && (act || mask_mode)) return NEMO_EINVAL;
@@ -687,7 +688,7 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     // requested issued between the MFMAs of the tile being multiplied.  Same tiles, slices, slabs and epilogue as the
     // register-staged kernel below, which keeps the unaligned operands, the 128x128 tile and very large operands.
     g.xcd_order = 0;
-    g.Cb = Cb; g.ldcb = ldcb; g.CbT = CbT; g.ldcbt = ldcbt;
+    g.Cb = Cb; g.ldcb = ldcb; g.CbT = CbT; g.ldcbt = ldcbt; g.mask16 = mask16; g.ldmask16 = ldmask16;
     if (bf16 == 2 && !(tile == 64 && glds_ok && !transA && transB)) return NEMO_EINVAL;
     if (tile == 64 && glds_ok) {
         g.a_bytes = a_bytes; g.b_bytes = b_bytes;
@@ -752,15 +753,20 @@ extern "C" int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint
                                      int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t act, const float* mask,
                                      int64_t ldmask, int32_t mask_mode, float alpha, int32_t out_mode, uint16_t* Cb,
                                      int64_t ldcb, uint16_t* CbT, int64_t ldcbt, void* ws, int64_t ws_bytes, void* stream) {
-    if (M < 0 || N < 0 || K < 0 || !C || (K & 1) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) return NEMO_EINVAL;
+    if (M < 0 || N < 0 || K < 0 || (K & 1) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) return NEMO_EINVAL;
+    if (!C && !(Cb || CbT)) return NEMO_EINVAL;
     if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return NEMO_EINVAL;
     if (Cb && ldcb < N) return NEMO_EINVAL;
     if (CbT && (ldcbt < M || (ldcbt & 3) || (((uintptr_t)CbT) & 7))) return NEMO_EINVAL;
     if (M == 0 || N == 0) return NEMO_OK;
     if (K == 0) return NEMO_EINVAL;
+    // mask_mode 1 / 2 with a FLOAT mask; 17 / 18: the same tests on a BF16 mask (`mask` then points at uint16_t data and
+    // ldmask counts bf16 elements) -- e.g. the bf16 copy of a ReLU output, whose sign and zeros survive the rounding
+    const bool m16 = mask_mode >= 16;
     return gemm_impl(2, 0, 1, M, N, K / 2, reinterpret_cast<const float*>(A), lda / 2, reinterpret_cast<const float*>(B),
-                     ldb / 2, C, ldc, bias, act, mask, ldmask, mask_mode, alpha, out_mode, 0, ws, ws_bytes, stream, Cb, ldcb,
-                     CbT, ldcbt);
+                     ldb / 2, C, ldc, bias, act, m16 ? nullptr : mask, ldmask, m16 ? mask_mode - 16 : mask_mode, alpha, out_mode,
+                     0, ws, ws_bytes, stream, Cb, ldcb, CbT, ldcbt,
+                     m16 ? reinterpret_cast<const unsigned short*>(mask) : nullptr, ldmask);
 }
 
 namespace {

@@ -69,6 +69,10 @@ struct Args {
     unsigned short* Cb = nullptr;
     unsigned short* CbT = nullptr;
     long ldcb = 0, ldcbt = 0;
+    // BF16 == 2 only: the activation mask read from a bf16 copy (sign and zero survive the rounding) instead of `mask`;
+    // C may be NULL when only the bf16 copies of the result are wanted (hidden activations of a bf16-in-memory chain)
+    const unsigned short* mask16 = nullptr;
+    long ldmask16 = 0;
 };
 
 constexpr int BK = 32;
@@ -491,14 +495,20 @@ __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, flo
                 if (g.act == 1) v = v > 0.f ? v : 0.f;
                 else if (g.act == 2) v = v > 0.f ? v : 0.01f * v;
                 if (g.mask_mode) {
-                    const float mv = g.mask[m * g.ldmask + n];
+                    float mv;
+                    if (BF16 == 2 && g.mask16) {
+                        const unsigned short mb = g.mask16[m * g.ldmask16 + n];
+                        mv = (mb & 0x7fffu) != 0 && !(mb & 0x8000u) ? 1.f : 0.f;       // bf16 > 0
+                    } else mv = g.mask[m * g.ldmask + n];
                     if (g.mask_mode == 1) v = mv > 0.f ? v : 0.f;
                     else v = mv > 0.f ? v : 0.01f * v;
                 }
-                float* c = g.C + m * g.ldc + n;
-                if (g.out_mode == 0) *c = v;
-                else if (g.out_mode == 1) { v += *c; *c = v; }
-                else atomicAdd(c, v);
+                if (BF16 != 2 || g.C) {
+                    float* c = g.C + m * g.ldc + n;
+                    if (g.out_mode == 0) *c = v;
+                    else if (g.out_mode == 1) { v += *c; *c = v; }
+                    else atomicAdd(c, v);
+                }
                 if constexpr (BF16 == 2) {
                     const unsigned short bits = __builtin_bit_cast(unsigned short, (__bf16)v);
                     if (g.Cb) g.Cb[m * g.ldcb + n] = bits;                 // 32 lanes x 2 B: 64-byte runs along n

@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     const float* __restrict__ P, long ldP, const float* __restrict__ vs, const float* __restrict__ W,
     int G, int cpg, int RA, int CA, int nB, int vec_stage, float* __restrict__ loss_sum, float* __restrict__ dVPt, long ldn,
     float* __restrict__ dA, float* __restrict__ parts, int* __restrict__ tickets, float* __restrict__ loss_parts,
-    int* __restrict__ grid_ticket) {
+    int* __restrict__ grid_ticket, unsigned short* __restrict__ dVPb, long ldk) {
     // All constants are zero-padded by nemo_ctx_create (P: 224 rows x 3*NVp columns, W / v_shaped: NVp
     // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
     // predicate: padded vertices / samples produce v_rec == v_orig == 0, i.e. zero loss and gradient.
@@ -1336,12 +1336,30 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (BF16 && dVPb) {
+            // bf16-in-memory chain: d vp as bf16, NOT transposed -- row = sample, the lane's 4 vertices x 3 coordinates are
+            // 12 consecutive k (24 bytes, 8-byte aligned): the k-contiguous A operand of the adjoint product dPF = dVP P^T
+            unsigned short* dstb = dVPb + (s0 + l15) * ldk + (v0 + 4 * g) * 3;
+            unsigned short hb[12];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) hb[r * 3 + d] = __builtin_bit_cast(unsigned short, (__bf16)dvp[d][r]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                uint2 pk;
+                pk.x = (unsigned)hb[4 * q] | ((unsigned)hb[4 * q + 1] << 16);
+                pk.y = (unsigned)hb[4 * q + 2] | ((unsigned)hb[4 * q + 3] << 16);
+                reinterpret_cast<uint2*>(dstb)[q] = pk;
+            }
+        } else {
         // d vp (transposed store: row 3v+d, 16 consecutive samples per 64-byte segment)
         float* dst = dVPt + ((v0 + 4 * g) * 3) * ldn + s0 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int d = 0; d < 3; ++d) dst[(r * 3 + d) * ldn] = dvp[d][r];
+        }
     }
 
     // ---- cross-wave reduction of dA through LDS (the staged sample data is dead now)
@@ -1802,8 +1820,9 @@ extern "C" int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N) {
 
 static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const float* PF2, int64_t ldpf,
                               const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
-                              void* ws, int64_t ws_bytes, void* stream) {
-    if (!ctx || N < 0 || !PF2 || !A2 || !loss_sum || !dVPt || ldpf < 207 || ldn < ((N + 15) / 16) * 16)
+                              void* ws, int64_t ws_bytes, void* stream, unsigned short* dVPb = nullptr, int64_t ldk = 0) {
+    if (!ctx || N < 0 || !PF2 || !A2 || !loss_sum || ldpf < 207) return NEMO_EINVAL;
+    if (dVPb ? (!bf16 || ldk < ctx->ldP || (ldk & 3) || (((uintptr_t)dVPb) & 7)) : (!dVPt || ldn < ((N + 15) / 16) * 16))
         return NEMO_EINVAL;                                    // (dA == NULL: deferred combine, nemo_v2v_combine)
     if (N == 0) return NEMO_OK;
     const int lds_bytes = ((bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * MF_AS) * (int)sizeof(float);
@@ -1832,12 +1851,12 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const f
                            (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2,
                            reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp, ctx->d_v_shaped, ctx->d_W, pl.G,
                            pl.cpg, pl.RA, pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets, loss_parts,
-                           grid_ticket);
+                           grid_ticket, dVPb, (long)ldk);
     else
         hipLaunchKernelGGL(mesh_v2v_fused_kernel<false>, dim3((unsigned)blocks), dim3(256), lds_bytes,
                            (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, ctx->d_posedirs, ctx->ldP,
                            ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA, pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn,
-                           dA, parts, tickets, loss_parts, grid_ticket);
+                           dA, parts, tickets, loss_parts, grid_ticket, (unsigned short*)nullptr, 0L);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -1861,6 +1880,14 @@ extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* P
                                   const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
                                   void* ws, int64_t ws_bytes, void* stream) {
     return v2v_fused_impl(ctx, false, N, PF2, ldpf, A2, loss_sum, dVPt, ldn, dA, ws, ws_bytes, stream);
+}
+
+// bf16 variant whose d vp output is bf16 and NOT transposed: dVPb (16 * ceil(N / 16) rows x ldk >= 3 NVp, bf16) -- the
+// k-contiguous operand nemo_gemm_bf16mem takes for the blend-shape adjoint (half the bytes written here and read there)
+extern "C" int32_t nemo_v2v_fused_bf16mem(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
+                                          float* loss_sum, uint16_t* dVPb, int64_t ldk, float* dA, void* ws, int64_t ws_bytes,
+                                          void* stream) {
+    return v2v_fused_impl(ctx, true, N, PF2, ldpf, A2, loss_sum, nullptr, 0, dA, ws, ws_bytes, stream, dVPb, ldk);
 }
 
 extern "C" int32_t nemo_v2v_fused_bf16(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,

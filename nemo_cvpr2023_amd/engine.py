@@ -247,6 +247,11 @@ class FitEngine:
         if dt not in ('f32', 'bf16'):
             raise ValueError(f"args.gemm_dtype must be 'f32' or 'bf16', got {dt!r}")
         self.bf16 = dt == 'bf16'
+        # bf16 operands IN MEMORY (round 3): every dense product of the MotionNet / VPoser chain reads bf16 copies of its
+        # operands (written by the producing GEMM's epilogue, plain and transposed, or by nemo_cast_bf16) through
+        # nemo_gemm_bf16mem -- the same values enter the matrix cores as with the on-the-fly rounding of nemo_gemm_bf16,
+        # half the bytes move (NEMO_BF16_MEM=0: the on-the-fly path, A/B aid)
+        self.b16mem = self.bf16 and version >= 1 and os.environ.get('NEMO_BF16_MEM', '1') != '0'
         self.din = (self.D if self.D > 0 else 1) + self.C
         self.ldx = (self.din + 3) // 4 * 4          # row stride of the MLP input / its gradient (16-byte rows)
         self.cx, self.cy = float(img_d0 // 2), float(img_d1 // 2)       # :3104-3106 (sic)
@@ -260,6 +265,20 @@ class FitEngine:
         self._jm = jm
         self.NV = self.ctx.NV
         self.vp = fold_vposer(vposer_sd, self.device)
+        if self.b16mem:
+            r8 = lambda n: (n + 7) // 8 * 8
+            # blend shapes as a plain bf16 [207][3 NVp] matrix: the k-contiguous B operand of the adjoint product
+            self.Pb = torch.zeros(207, self.ctx.ldP, dtype=torch.int16, device=self.device)
+            self._cast(207, 3 * self.NV, self.ctx.posedirs, self.ctx.ldP, self.Pb, 0)
+            self.vpb = {}
+            for k in ('e2w', 'emw', 'd0w', 'd3w', 'd5w'):               # (out, in) -> bf16 [out][in padded]
+                wt = self.vp[k]
+                self.vpb[k] = torch.zeros(wt.shape[0], r8(wt.shape[1]), dtype=torch.int16, device=self.device)
+                self._cast(wt.shape[0], wt.shape[1], wt.data_ptr(), wt.stride(0), self.vpb[k], 0)
+            for k in ('emw', 'e2w'):                                      # transposes for the KL backward: [in][out padded]
+                wt = self.vp[k]
+                self.vpb[k + 'T'] = torch.zeros(wt.shape[1], r8(wt.shape[0]), dtype=torch.int16, device=self.device)
+                self._cast(wt.shape[0], wt.shape[1], wt.data_ptr(), wt.stride(0), self.vpb[k + 'T'], 1)
         self.gmm = gmm_constants(gmm, self.device)
         f32 = dict(dtype=torch.float32, device=self.device)
         self.targets = targets.to(**f32).contiguous()
@@ -357,7 +376,7 @@ class FitEngine:
             E1=Z(N, 512), MULV=Z(N, 64), D1=Z(N, 512), D2=Z(N, 512),
             D3=Z(N, 126), AAdec=Z(N, 63),
             R2=Z(2 * Nc, 24, 9), A2=Z(2 * Nc, 24, 12), Jp2=Z(2 * Nc, 24, 3), PF2=Z(2 * Nc, 208),
-            dVPt=Z(3 * self.ctx.NVp, (Nc + 15) // 16 * 16),
+            dVPt=Z(3 * self.ctx.NVp, (Nc + 15) // 16 * 16) if not self.b16mem else Z(16),
             dR2=Z(N, 24, 9),
             dR=Z(N, 24, 9), dA=Z(N, 24, 12), dMq=Z(N, max(nq * 72, 1)),
             dPF=Z(N, 208), dHEAD=Z(N + 1, HEAD_LD), dH=Z(N + 1, h), dH_b=Z(N + 1, h), dH_c=Z(N + 1, h),
@@ -368,6 +387,18 @@ class FitEngine:
             fi_static=torch.zeros(N + 1, dtype=torch.long, device=self.device), graphs={}, cap=N)
         w.update(views)
         w['zero_arena'] = arena
+        if self.b16mem:
+            # bf16 copies (plain: [row][feature], k-contiguous for the forward / dX products; T: [feature][row] for the
+            # parameter gradients) of every operand of the dense chain; zero-initialised: pad columns are never written
+            i16 = dict(dtype=torch.int16, device=self.device)
+            r8 = lambda n: (n + 7) // 8 * 8
+            rp, hp = r8(N + 1), r8(h)
+            Zb = lambda *sh: torch.zeros(*sh, **i16)
+            w.update(dVPb=Zb((Nc + 15) // 16 * 16, self.ctx.ldP), dHEADb=Zb(N + 1, 152), dHEADbT=Zb(147, rp),
+                     AAb=Zb(N, 64), E1b=Zb(N, 512), MULVb=Zb(N, 64), D1b=Zb(N, 512), D2b=Zb(N, 512), dMULVb=Zb(N, 64),
+                     dE_ab=Zb(N, 512))
+            for k in ('H1', 'H2', 'H3', 'dH', 'dH_b', 'dH_c'):
+                w[k + 'b'], w[k + 'bT'] = Zb(N + 1, hp), Zb(h, rp)
         if self.version == 0:            # hidden activations of the orient and translation networks (poses: H1..H3)
             w.update(O1=Z(N + 1, h), O2=Z(N + 1, h), O3=Z(N + 1, h), T1=Z(N + 1, h), T2=Z(N + 1, h))
         # scratch of nemo_v2v_fused (arrival tickets, zero at allocation and returned to zero by the kernel, +
@@ -447,6 +478,100 @@ class FitEngine:
         if gb is not None:       # bias gradients are batched into one launch (flush_colsums)
             self._colsums.append((dy, rows, fout if nbias is None else nbias, lddy, gb))
 
+    # ---- bf16-in-memory chain (self.b16mem) -----------------------------------------------------------------
+    def _cast(self, rows, cols, src_ptr, lds, dst, transpose):
+        check(self.lib.nemo_cast_bf16(rows, cols, src_ptr, lds, dst.data_ptr(), dst.stride(0), transpose, _stream()),
+              'nemo_cast_bf16')
+
+    def gemm16(self, M, N, K, Ab, Bb, Cp, ldc, bias=None, act=0, mask=None, ldmask=0, mask_mode=0, alpha=1.0, out_mode=0,
+               Cb=None, CbT=None, tag=None):
+        """C (M x N, fp32) (op)= epilogue(alpha * A B^T) with A (M x K), B (N x K) bf16 in memory (2-D int16 tensors whose
+        row stride is the ld; K is taken up to the next even number: the pad column is zero by construction)."""
+        ev = self._event_begin(tag, 2.0 * M * N * K)
+        cur = torch.cuda.current_stream()
+        ws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]
+        check(self.lib.nemo_gemm_bf16mem(M, N, (K + 1) // 2 * 2, Ab.data_ptr(), Ab.stride(0), Bb.data_ptr(), Bb.stride(0), Cp, ldc,
+                                         bias, act, mask, ldmask, mask_mode, alpha, out_mode,
+                                         dptr(Cb), Cb.stride(0) if Cb is not None else 0,
+                                         dptr(CbT), CbT.stride(0) if CbT is not None else 0,
+                                         ws.data_ptr(), ws.numel() * 4, _stream()), 'nemo_gemm_bf16mem')
+        self._event_end(ev)
+
+    def _weights_b16(self, transposed):
+        """bf16 copies of the four MotionNet weight matrices for this step (they change in Adam at the step's end): plain
+        [out][in] for the forward, transposed [in][out] for the activation gradients."""
+        lm, h = 'learned_motion.', self.h
+        if not hasattr(self, '_wb'):
+            i16 = dict(dtype=torch.int16, device=self.device)
+            r8 = lambda n: (n + 7) // 8 * 8
+            self._wb = {'0': torch.zeros(h, r8(self.din), **i16), '2': torch.zeros(h, r8(h), **i16), '4': torch.zeros(h, r8(h), **i16),
+                        'head': torch.zeros(147, r8(h), **i16), '0T': torch.zeros(self.din, r8(h), **i16),
+                        '2T': torch.zeros(h, r8(h), **i16), '4T': torch.zeros(h, r8(h), **i16), 'headT': torch.zeros(h, 152, **i16)}
+        shapes = (('2', lm + 'net.net.2.weight', h, h), ('4', lm + 'net.net.4.weight', h, h), ('head', lm + 'rot_out.weight', 147, h))
+        for key, name, fo, fi in shapes:
+            self._cast(fo, fi, self.p(name), fi, self._wb[key + ('T' if transposed else '')], 1 if transposed else 0)
+        return self._wb
+
+    def _forward_nets_b16(self, w, N, train):
+        """forward_pose's MLP on the bf16-in-memory chain: every layer reads the previous layer's bf16 copy and leaves its
+        own (plain for the next layer, transposed for its parameter gradient when `train`)."""
+        lm, h, r = 'learned_motion.', self.h, N + 1
+        wb = self._weights_b16(False)
+        T = lambda k: w[k] if train else None
+        # the first layer (K = 105 RBF features + code, rows of nn.Linear(105, h) not 16-byte aligned) stays where it was:
+        # fp32 arithmetic (its operands never qualified for the bf16 path; 2 % of the MLP's FLOPs)
+        self._linear(r, dptr(w['X']), self.ldx, self.din, self.p(lm + 'net.net.0.weight'),
+                     self.p(lm + 'net.net.0.bias'), h, dptr(w['H1']), h, act=1)
+        self._cast(r, h, dptr(w['H1']), h, w['H1b'], 0)
+        if train:
+            self._cast(r, h, dptr(w['H1']), h, w['H1bT'], 1)
+        # (hidden activations exist as bf16 copies only: the ReLU masks of the backward read them -- sign and zero survive
+        #  the rounding --, nothing else needs the fp32 values)
+        self.gemm16(r, h, h, w['H1b'], wb['2'], None, h, bias=self.p(lm + 'net.net.2.bias'), act=1,
+                    Cb=w['H2b'], CbT=T('H2bT'), tag='gemm_mlp_hidden_fwd')
+        self.gemm16(r, h, h, w['H2b'], wb['4'], None, h, bias=self.p(lm + 'net.net.4.bias'), act=1,
+                    Cb=w['H3b'], CbT=T('H3bT'))
+        self.gemm16(r, 147, h, w['H3b'], wb['head'], dptr(w['HEAD']), HEAD_LD, bias=self.p(lm + 'rot_out.bias'))
+
+    def _backward_mlp_b16(self, w, N, view_idx, frame_idx, raw_phase, nout, nbias):
+        """backward_mlp on the bf16-in-memory chain.  Every product is C = A B^T with k-contiguous bf16 operands:
+        dX_l = dY_l (W_l^T)^T reads dY_l's plain copy and the transposed weight copy; dW_l = dY_l^T X_l reads the two
+        TRANSPOSED activation copies (K = rows)."""
+        L, lm, h, r = self.lib, 'learned_motion.', self.h, N + 1
+        wb = self._weights_b16(True)
+        self._cast(r, nout, dptr(w['dHEAD']), HEAD_LD, w['dHEADb'], 0)
+        self._cast(r, nout, dptr(w['dHEAD']), HEAD_LD, w['dHEADbT'], 1)
+        cs = self._colsums
+        # heads
+        self.gemm16(nout, h, r, w['dHEADbT'], w['H3bT'], self.g(lm + 'rot_out.weight'), h, out_mode=1)
+        cs.append((dptr(w['dHEAD']), r, nbias, HEAD_LD, self.g(lm + 'rot_out.bias')))
+        self.gemm16(r, h, nout, w['dHEADb'], wb['headT'], dptr(w['dH']), h, mask=dptr(w['H3b']), ldmask=w['H3b'].stride(0),
+                    mask_mode=17, Cb=w['dHb'], CbT=w['dHbT'])
+        # layer 4
+        self.gemm16(h, h, r, w['dHbT'], w['H2bT'], self.g(lm + 'net.net.4.weight'), h, out_mode=1)
+        cs.append((dptr(w['dH']), r, h, h, self.g(lm + 'net.net.4.bias')))
+        self.gemm16(r, h, h, w['dHb'], wb['4T'], dptr(w['dH_b']), h, mask=dptr(w['H2b']), ldmask=w['H2b'].stride(0),
+                    mask_mode=17, Cb=w['dH_bb'], CbT=w['dH_bbT'], tag='gemm_mlp_hidden_dx')
+        # layer 2
+        self.gemm16(h, h, r, w['dH_bbT'], w['H1bT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1)
+        cs.append((dptr(w['dH_b']), r, h, h, self.g(lm + 'net.net.2.bias')))
+        self.gemm16(r, h, h, w['dH_bb'], wb['2T'], dptr(w['dH_c']), h, mask=dptr(w['H1b']), ldmask=w['H1b'].stride(0),
+                    mask_mode=17, Cb=None, CbT=None)
+        # layer 0: as before (see _forward_nets_b16)
+        self._linear_bwd_params(r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h, self.g(lm + 'net.net.0.weight'),
+                                self.g(lm + 'net.net.0.bias'))
+        self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din, dptr(w['dX']), self.ldx,
+                  dense=True)
+        self.flush_colsums()
+        check(L.nemo_phase_embed_bwd(
+            N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
+            self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), self.ldp,
+            self.p('phase_rbf.log_sigmas') if self.D > 0 else None, self.kernel_id, dptr(w['phase']),
+            dptr(w['dX']), self.ldx, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
+            self.g('phase_networks.0.scales'),
+            self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
+            self.g('learned_instance_code') if self.C > 0 else None, _stream()), 'nemo_phase_embed_bwd')
+
     def gemm_grouped(self, problems, dense=True):
         """problems: list of (ta, tb, M, N, K, A, lda, B, ldb, C, ldc, out_mode) -- independent products of one layout in
         ONE launch (nemo_gemm_grouped_f32: the parameter gradients of the whole MLP backward)."""
@@ -471,7 +596,7 @@ class FitEngine:
         self._colsums = []
 
     # ------------------------------------------------------------------ forward pieces
-    def forward_pose(self, w, N, view_idx, frame_idx, raw_phase=None, code_noise=None):
+    def forward_pose(self, w, N, view_idx, frame_idx, raw_phase=None, code_noise=None, train=True):
         """K1-K5: phase warp, RBF, MLP, rot6d->R->aa.  Fills X,H1..H3,ROT,TR,R,AA."""
         L, st = self.lib, _stream()
         sh0 = self.p('phase_networks.0.shifts')
@@ -486,6 +611,10 @@ class FitEngine:
         if self.version == 0:
             return self._forward_nets_v0(w, N)
         lm = 'learned_motion.'
+        if self.b16mem:
+            self._forward_nets_b16(w, N, train)
+            check(L.nemo_rot6d_fwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, dptr(w['R']), dptr(w['AA']), st), 'nemo_rot6d_fwd')
+            return
         self._linear(r, dptr(w['X']), self.ldx, self.din, self.p(lm + 'net.net.0.weight'),
                      self.p(lm + 'net.net.0.bias'), h, dptr(w['H1']), h, act=1)
         self._linear(r, dptr(w['H1']), h, h, self.p(lm + 'net.net.2.weight'), self.p(lm + 'net.net.2.bias'),
@@ -611,6 +740,17 @@ class FitEngine:
         exists: the KL term and its backward (vposer_kl / backward_vposer_kl) run from there on another stream."""
         L, st, vp = self.lib, _stream(), self.vp
         aa63 = w['AA'].data_ptr() + 4 * 3
+        if self.b16mem:
+            vb = self.vpb
+            self._cast(N, 63, aa63, 72, w['AAb'], 0)
+            self.gemm16(N, 512, 63, w['AAb'], vb['e2w'], dptr(w['E1']), 512, bias=dptr(vp['e2b']), act=2, Cb=w['E1b'])
+            self.gemm16(N, 64, 512, w['E1b'], vb['emw'], dptr(w['MULV']), 64, bias=dptr(vp['emb']), Cb=w['MULVb'])
+            enc_done = torch.cuda.current_stream().record_event()
+            self.gemm16(N, 512, 32, w['MULVb'], vb['d0w'], dptr(w['D1']), 512, bias=dptr(vp['d0b']), act=2, Cb=w['D1b'])
+            self.gemm16(N, 512, 512, w['D1b'], vb['d3w'], dptr(w['D2']), 512, bias=dptr(vp['d3b']), act=2, Cb=w['D2b'])
+            self.gemm16(N, 126, 512, w['D2b'], vb['d5w'], dptr(w['D3']), 126, bias=dptr(vp['d5b']))
+            check(L.nemo_rot6d_fwd(N, 21, dptr(w['D3']), 126, 0, None, dptr(w['AAdec']), st), 'nemo_rot6d_fwd')
+            return enc_done
         self._linear(N, aa63, 72, 63, dptr(vp['e2w_p']), dptr(vp['e2b']), 512, dptr(w['E1']), 512, act=2, ldw=64)
         self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
         enc_done = torch.cuda.current_stream().record_event()
@@ -643,7 +783,7 @@ class FitEngine:
         blended mesh goes to HBM); the blend-shape adjoint is one GEMM on the transposed dVP."""
         L, st, ctx = self.lib, _stream(), self.ctx
         Nc, NV3, ldP = w['Nc'], 3 * self.NV, self.ctx.ldP
-        ldn = w['dVPt'].shape[1]
+        ldn = w['dVPt'].shape[1] if w['dVPt'].dim() == 2 else 0          # (bf16-in-memory chain: dVPb instead)
         for c0 in range(0, N, Nc):
             n = min(Nc, N - c0)
             R = w['R'].data_ptr() + 4 * c0 * 216
@@ -661,9 +801,15 @@ class FitEngine:
             # (large batches only: at a one-instance shard the extra fork / join of the replayed graph costs more than the
             #  reduction's tail -- 0.509 against 0.503 ms, same box; 8 x 300: 1.557 against 1.564 ms)
             defer = self.defer_combine and need_grad and self.SMALL_BATCH_ROWS < N <= Nc and self.timers is None
-            check(fused(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
-                        self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPt']), ldn, None if defer else dptr(w['dA2']),
-                        ws.data_ptr(), ws.numel() * 4, st), 'nemo_v2v_fused')
+            if self.b16mem:
+                check(L.nemo_v2v_fused_bf16mem(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
+                                               self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPb']), w['dVPb'].stride(0),
+                                               None if defer else dptr(w['dA2']), ws.data_ptr(), ws.numel() * 4, st),
+                      'nemo_v2v_fused_bf16mem')
+            else:
+                check(fused(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
+                            self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPt']), ldn, None if defer else dptr(w['dA2']),
+                            ws.data_ptr(), ws.numel() * 4, st), 'nemo_v2v_fused')
             self._event_end(ev)
             mesh_done = torch.cuda.current_stream().record_event() if defer else None
             if after_loss is not None and c0 + Nc >= N:
@@ -671,8 +817,11 @@ class FitEngine:
             if need_grad:
                 if c0 > 0:
                     w['dPF2'].zero_()
-                self.gemm(1, 1, n, 207, NV3, dptr(w['dVPt']), ldn, ctx.posedirs, ldP, dptr(w['dPF2']), 208,
-                          out_mode=1, tag='gemm_pose_blend_bwd', dense=True)
+                if self.b16mem:
+                    self.gemm16(n, 207, NV3, w['dVPb'], self.Pb, dptr(w['dPF2']), 208, out_mode=1, tag='gemm_pose_blend_bwd')
+                else:
+                    self.gemm(1, 1, n, 207, NV3, dptr(w['dVPt']), ldn, ctx.posedirs, ldP, dptr(w['dPF2']), 208,
+                              out_mode=1, tag='gemm_pose_blend_bwd', dense=True)
                 if defer:           # (enqueued AFTER the GEMM: a replayed graph keeps the first successor on the queue)
                     side2 = self.side_stream2
                     side2.wait_event(mesh_done)
@@ -716,6 +865,13 @@ class FitEngine:
     def backward_vposer_kl(self, w, N, weight):
         """d(weight*KL)/d poses[:, :63] through the frozen encoder, accumulated into dAA[:, 3:66]."""
         vp = self.vp
+        if self.b16mem:
+            vb = self.vpb
+            self._cast(N, 64, dptr(w['dMULV']), 64, w['dMULVb'], 0)
+            self.gemm16(N, 512, 64, w['dMULVb'], vb['emwT'], dptr(w['dE_a']), 512, alpha=weight, mask=dptr(w['E1']), ldmask=512,
+                        mask_mode=2, Cb=w['dE_ab'])
+            self.gemm16(N, 63, 512, w['dE_ab'], vb['e2wT'], w['dAA'].data_ptr() + 4 * 3, 72, out_mode=1)
+            return
         self.gemm(0, 0, N, 512, 64, dptr(w['dMULV']), 64, dptr(vp['emw']), 512, dptr(w['dE_a']), 512,
                   alpha=weight, mask=dptr(w['E1']), ldmask=512, mask_mode=2, dense=True)
         self.gemm(0, 0, N, 63, 512, dptr(w['dE_a']), 512, dptr(vp['e2w_p']), 64,
@@ -738,6 +894,8 @@ class FitEngine:
         # exact 0 there), so its column sum is skipped unless the global trajectory is un-anchored.
         nout = 147 if has_trans_grad else 144
         nbias = 147 if (has_trans_grad and self.start_global_traj_anywhere) else 144
+        if self.b16mem and not bucketed and tuple(stages) == (0, 1, 2):
+            return self._backward_mlp_b16(w, N, view_idx, frame_idx, raw_phase, nout, nbias)
         # Schedule.  Large batches (each hidden-layer GEMM fills the machine; co-scheduling two of them measured no gain):
         # the activation-gradient chain (dX) and the parameter-gradient GEMMs (dW) alternate on the main stream up to
         # layer 2; then one fork: the (small) layer-0 dW GEMM and the batched bias column sums on the side stream, the

@@ -476,7 +476,7 @@ class MultiViewModel(nn.Module):
         N = vi.numel()
         w = e._ws(N)
         raw = None if phases is None else phases.to(self.device, torch.float32).reshape(-1).contiguous()
-        e.forward_pose(w, N, vi, fi, raw_phase=raw, code_noise=self._noise(N))
+        e.forward_pose(w, N, vi, fi, raw_phase=raw, code_noise=self._noise(N), train=False)
         j3d = torch.empty(N, e.ctx.n_out, 3, device=self.device)
         e.forward_joints(w, N, vi, fi, with_loss=False, add_trans=add_trans, j3d=j3d)
         trans = w['TR'][:N] - w['TR'][N:N + 1] if not e.start_global_traj_anywhere else w['TR'][:N].clone()
@@ -530,7 +530,7 @@ class MultiViewModel(nn.Module):
             return e.backward_mlp(w, N, vi, fi, None, stages=(int(part[1]),), bucketed=True)
         # loss scalars, view accumulators, dAA, dJp, dA2, dPF2, the gradient buffer (and the device Adam table's step)
         e.step_begin(w['zero_arena'], bool(update), adam_segs)
-        e.forward_pose(w, N, vi, fi, code_noise=self._noise(N))
+        e.forward_pose(w, N, vi, fi, code_noise=self._noise(N), train=bool(update))
         main = torch.cuda.current_stream()
         side, side2 = e.side_stream, e.side_stream2
         pose_done = main.record_event()
@@ -1083,7 +1083,7 @@ class MultiViewModel(nn.Module):
             cam_opt.zero_grad()
             e.scal.zero_()
             w['zero_arena'].zero_()
-            e.forward_pose(w, N, vi, fi)
+            e.forward_pose(w, N, vi, fi, train=False)
             Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=1)
             e.backward_kp(w, N, vi, fi, Mq, mean_mode=1, upstream=float(sh.mr), cams_only=True)
             cam_opt.step()

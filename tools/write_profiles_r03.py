@@ -32,7 +32,10 @@ def bench_row(name, f, cmd):
 for tag, title, cmd in (
         ('c2', 'headline C2 (8 x 300 full batch, fp32)', f'python3 bench.py --steps 20 --warmup 2 {X} {B}'),
         ('v1', 'one-instance shard (1 x 300: one rank of eight)', f'python3 bench.py --instances 1 --steps 20 --warmup 2 {X} {B}'),
-        ('v2', 'two-instance shard (2 x 300: one rank of four)', f'python3 bench.py --instances 2 --steps 20 --warmup 2 {X} {B}')):
+        ('v2', 'two-instance shard (2 x 300: one rank of four)', f'python3 bench.py --instances 2 --steps 20 --warmup 2 {X} {B}'),
+        ('c3b', 'C3 (40 x 300) bf16, operands bf16 in memory', f'python3 bench.py --instances 40 --dtype bf16 --steps 10 --warmup 2 {X} {B}')):
+    if not os.path.exists(os.path.join(G, f'trace_{tag}.log')):
+        continue
     d = line(f'trace_{tag}.log')
     r = d['roofline']
     open(os.path.join(P, f'r03_kernel_trace_{tag}.md'), 'w').write(
@@ -97,6 +100,7 @@ txt = (f"# Round 3 (commit {head}) -- bench.py lines of every BASELINE configura
        + bench_row('C2 sizes, bf16 dense contractions', 'bench_c2_bf16.json', 'python3 bench.py --dtype bf16 --steps 30 --warmup 5') + '\n'
        + bench_row('C3: 40 x 300, fp32', 'bench_c3_f32.json', 'python3 bench.py --instances 40 --steps 20 --warmup 3') + '\n'
        + bench_row('C3: 40 x 300, bf16 (BASELINE configs[2])', 'bench_c3_bf16.json', 'python3 bench.py --instances 40 --dtype bf16 --steps 20 --warmup 3') + '\n'
+       + (bench_row('C3 bf16 with NEMO_BF16_MEM=0 (round 2\'s on-the-fly rounding, same box)', 'bench_c3_bf16_onthefly.json', 'NEMO_BF16_MEM=0 python3 bench.py --instances 40 --dtype bf16 --steps 20 --warmup 3') + '\n' if os.path.exists(os.path.join(G, 'bench_c3_bf16_onthefly.json')) else '')
        + bench_row('C4: 256 x 1024 on ONE GPU (32 mesh chunks of 8192)', 'bench_c4.json',
                    'python3 bench.py --instances 256 --frames 1024 --steps 5 --warmup 2 --repeat 3 --minibatch-steps 20') + '\n'
        + bench_row('shard of 8 GPUs: 1 x 300', 'bench_shard_v1.json', 'python3 bench.py --instances 1 --steps 100') + '\n'
@@ -119,6 +123,9 @@ txt += ("\n`buckets` (three gradient buckets, three launches per step) loses on 
         "configs[3]: 256 x 1024 over 8 GPUs = 32 768 samples per rank); `--shard-mode auto` decides on the machine it runs on.\n\n"
         "## the full default line (what the driver records)\n```\n" + json.dumps(full) + "\n```\n"
         f"cpu_baseline: {json.dumps(full['cpu_baseline'])}\n")
+if os.path.exists(os.path.join(G, 'bf16mem_gemm.txt')):
+    txt += ('\n## nemo_gemm_bf16mem against nemo_gemm_bf16 / nemo_gemm_f32 at the C3 shapes (tools/bench_bf16mem.py; HIP events, 20 launches)\n```\n'
+            + '\n'.join(l for l in rd('bf16mem_gemm.txt').splitlines() if 'GFLOP' in l) + '\n```\n')
 open(os.path.join(P, 'r03_bench_lines.md'), 'w').write(txt)
 
 
