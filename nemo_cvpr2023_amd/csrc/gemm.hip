@@ -689,6 +689,22 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     // register-staged kernel below, which keeps the unaligned operands, the 128x128 tile and very large operands.
     g.xcd_order = 0;
     g.Cb = Cb; g.ldcb = ldcb; g.CbT = CbT; g.ldcbt = ldcbt; g.mask16 = mask16; g.ldmask16 = ldmask16;
+    // Tuning aid (NEMO_B16_TILE=128): bf16-in-memory products on 128 x 128 tiles -- twice the MFMA work per byte the LDS-DMA
+    // moves, but one block per CU (96 KiB of LDS stages).  Measured SLOWER than the 64 x 64 tile at every shape of the step
+    // (12 000 x 1000 x 1000: 98 us = 244 TFLOP/s against 71 us = 337; profiles/r03_experiments.md section 9): not used.
+    if (bf16 == 2 && glds_ok && !transA && transB) {
+        static const int b16_tile = [] { const char* f = getenv("NEMO_B16_TILE"); return f ? atoi(f) : 0; }();
+        const bool big = b16_tile == 128;
+        if (big && split_k == 0) {
+            g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (int)((N + 127) / 128); g.n_tiles = g.tiles_m * g.tiles_n;
+            g.split = 1; g.t0 = g.n_tiles; g.k_chunk = (K + 31) / 32 * 32;
+            g.a_bytes = a_bytes; g.b_bytes = b_bytes;
+            const hipError_t e128 = glds::launch<128, 128, 64, 64, 32, true, true, 3, true, 2>(g, g.n_tiles, (hipStream_t)stream);
+            if (e128 != hipSuccess) return (int32_t)e128;
+            NEMO_LAUNCH_CHECK();
+            return NEMO_OK;
+        }
+    }
     if (bf16 == 2 && !(tile == 64 && glds_ok && !transA && transB)) return NEMO_EINVAL;
     if (tile == 64 && glds_ok) {
         g.a_bytes = a_bytes; g.b_bytes = b_bytes;
