@@ -694,12 +694,15 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     // (12 000 x 1000 x 1000: 98 us = 244 TFLOP/s against 71 us = 337; profiles/r03_experiments.md section 9): not used.
     if (bf16 == 2 && glds_ok && !transA && transB) {
         static const int b16_tile = [] { const char* f = getenv("NEMO_B16_TILE"); return f ? atoi(f) : 0; }();
-        const bool big = b16_tile == 128;
+        const bool big = b16_tile == 128 || b16_tile == 12864;
         if (big && split_k == 0) {
-            g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (int)((N + 127) / 128); g.n_tiles = g.tiles_m * g.tiles_n;
+            const int bn = b16_tile == 128 ? 128 : 64;
+            g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (int)((N + bn - 1) / bn); g.n_tiles = g.tiles_m * g.tiles_n;
             g.split = 1; g.t0 = g.n_tiles; g.k_chunk = (K + 31) / 32 * 32;
             g.a_bytes = a_bytes; g.b_bytes = b_bytes;
-            const hipError_t e128 = glds::launch<128, 128, 64, 64, 32, true, true, 3, true, 2>(g, g.n_tiles, (hipStream_t)stream);
+            const hipError_t e128 = bn == 128
+                ? glds::launch<128, 128, 64, 64, 32, true, true, 3, true, 2>(g, g.n_tiles, (hipStream_t)stream)
+                : glds::launch<128, 64, 32, 64, 32, true, true, 3, true, 2>(g, g.n_tiles, (hipStream_t)stream);
             if (e128 != hipSuccess) return (int32_t)e128;
             NEMO_LAUNCH_CHECK();
             return NEMO_OK;
