@@ -62,7 +62,7 @@ mesh = kern['mesh_v2v_fused_kernel<false>']
 nsteps = mesh[0]                                        # one mesh launch per step
 for k, (n, f2, w) in kern.items():
     tot += n / float(nsteps) * (f2 + w)
-adj = [v for k, v in kern.items() if 'false, true, 3, true, false' in k][0]
+adj = [v for k, v in kern.items() if 'false, true, 3, true, false' in k or 'false, true, 3, true, 0>' in k][0]
 full = line('bench_c2_full.json')
 traffic = {'8x300x1xf32': {
     'source': 'profiles/r03_pmc_traffic.md (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, eager launches; '
@@ -87,7 +87,7 @@ open(os.path.join(P, 'r03_pmc_mfma.md'), 'w').write(
     f"Command (eager launches): `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 "
     f"--output-format csv -- python3 bench.py --steps 4 --warmup 1 {X} {B}`.\n"
     "MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs); executed GFLOP = MOPS_F32 x 512.\n"
-    "`glds::gemm_glds_kernel<64, 64, 32, 32, 32, AKC, BKC, 3, true, false>`: AKC / BKC = operand is k-contiguous in memory "
+    "`glds::gemm_glds_kernel<64, 64, 32, 32, 32, AKC, BKC, 3, true, 0>`: AKC / BKC = operand is k-contiguous in memory "
     "(true, true = NT: nn.Linear forward; true, false = NN: activation gradients; false, false = TN: parameter gradients; "
     "false, true = TT: blend-shape adjoint).\n\n" + mf)
 
