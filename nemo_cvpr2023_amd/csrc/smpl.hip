@@ -40,6 +40,13 @@ struct nemo_ctx {
     // blend shapes rounded to bf16 (RNE) in MFMA-operand order for nemo_v2v_fused_bf16: [k-step S = 0..6][lane group
     // g = 0..3][vertex][component][8 consecutive k = 32 S + 8 g ..], zero for k >= 207 and for pad vertices
     unsigned short* d_posedirs_bf16;
+    // skinning weights as TWO bf16 pieces (hi = bf16(w), lo = bf16(w - hi): 16 mantissa bits) for the split-precision
+    // skinning of the bf16 mesh kernel, in MFMA-operand order:
+    //   d_Wsk  [piece][vertex (NVp)][32]: forward A-operand rows (k = joint, zero for k >= 24)
+    //   d_Wadj [tile][joint tile 2][piece][lane 64][8]: adjoint A-operand of v_mfma_f32_16x16x32_bf16 -- lane (l15, g)
+    //          holds W[16 tile + 4 g + t][16 jt + l15] for t = 0..3 TWICE (k = 8 g + t and 8 g + 4 + t: the B-operand
+    //          carries the hi pieces of dT in the first four k and the lo pieces in the last four)
+    unsigned short *d_Wsk, *d_Wadj;
     // host copies needed to re-derive the shape-dependent constants
     std::vector<float> h_v_template, h_shapedirs, h_Jreg, h_W;
     std::vector<std::vector<std::pair<long, float>>> q_rows;   // sparse rows of the nq functionals
@@ -189,6 +196,25 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
         c->d_posedirs_bf16 = nullptr;
         HIPCHK(hipMalloc((void**)&c->d_posedirs_bf16, pb.size() * 2));
         HIPCHK(hipMemcpy(c->d_posedirs_bf16, pb.data(), pb.size() * 2, hipMemcpyHostToDevice));
+        auto unbf = [](unsigned short h) -> float { unsigned int u = (unsigned int)h << 16; float f; memcpy(&f, &u, 4); return f; };
+        const long ntl = c->NVp / 16;
+        std::vector<unsigned short> wsk((size_t)2 * c->NVp * 32, 0), wadj((size_t)ntl * 2 * 2 * 64 * 8, 0);
+        for (long v = 0; v < NV; ++v)
+            for (int j = 0; j < 24; ++j) {
+                const float w = lbs_weights[v * 24 + j];
+                const unsigned short hi = bf16(w), lo = bf16(w - unbf(hi));
+                wsk[((size_t)0 * c->NVp + v) * 32 + j] = hi;
+                wsk[((size_t)1 * c->NVp + v) * 32 + j] = lo;
+                const long t = v / 16; const int vv = (int)(v % 16), g = vv / 4, r = vv % 4, jt = j / 16, l15 = j % 16;
+                const size_t base = ((((size_t)t * 2 + jt) * 2) * 64 + (g * 16 + l15)) * 8;
+                wadj[base + r] = hi; wadj[base + 4 + r] = hi;
+                wadj[base + 64 * 8 + r] = lo; wadj[base + 64 * 8 + 4 + r] = lo;
+            }
+        c->d_Wsk = c->d_Wadj = nullptr;
+        HIPCHK(hipMalloc((void**)&c->d_Wsk, wsk.size() * 2));
+        HIPCHK(hipMemcpy(c->d_Wsk, wsk.data(), wsk.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&c->d_Wadj, wadj.size() * 2));
+        HIPCHK(hipMemcpy(c->d_Wadj, wadj.data(), wadj.size() * 2, hipMemcpyHostToDevice));
     }
     if (nq) {
         HIPCHK(hipMemcpy(c->d_C1, C1.data(), sizeof(float) * 207 * nq * 72, hipMemcpyHostToDevice));
@@ -206,6 +232,8 @@ extern "C" int32_t nemo_ctx_destroy(nemo_ctx* c) {
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->d_posedirs_bf16) (void)hipFree(c->d_posedirs_bf16);
+    if (c->d_Wsk) (void)hipFree(c->d_Wsk);
+    if (c->d_Wadj) (void)hipFree(c->d_Wadj);
     delete c;
     return NEMO_OK;
 }
@@ -1017,16 +1045,36 @@ __global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const
 typedef __bf16 mbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
 
-// BF16: the pose blend (K = 207, 57 % of the kernel's MFMAs) runs on v_mfma_f32_16x16x32_bf16 -- blend shapes rounded
-// to bf16 once in nemo_ctx_create, pose features rounded when they are staged, fp32 accumulate; skinning, L1, and both
-// adjoints stay fp32.  BASELINE configs[2].  P then points at nemo_ctx::d_posedirs_bf16 and ldP is NVp.
-template <bool BF16>
+// MODE 1 / 2 (bf16): the pose blend (K = 207, 57 % of the kernel's MFMAs) runs on v_mfma_f32_16x16x32_bf16 -- blend shapes
+// rounded to bf16 once in nemo_ctx_create, pose features rounded when they are staged, fp32 accumulate.  BASELINE
+// configs[2].  P then points at nemo_ctx::d_posedirs_bf16 and ldP is NVp.
+//   MODE 1 (round 2): skinning, L1 and both adjoints on the fp32 pipe.
+//   MODE 3 (default): the vertex->joint adjoint on the bf16 pipe in SPLIT precision (its operands are lane-local),
+//   skinning on the fp32 pipe.  MODE 2: skinning in split precision too -- measured SLOWER than MODE 1 (475 against
+//   358 us at 8 x 300): its 48 ds_read_b128 per tile form serial LDS round trips the register budget (255 VGPRs) leaves no
+//   room to pipeline (tools/mesh_phase_prof.py: 11.9 k cycles per tile for the 36 MFMAs of one body); kept as an A/B aid.
+//   Split precision: every fp32 operand is
+//   carried as two bf16 pieces (hi = bf16(x), lo = bf16(x - hi): 16 significant bits, ~4e-6 relative) and the product
+//   is the sum of the piece products with fp32 accumulation:
+//     T_e = W A_e        : hi*hi + hi*lo + lo*hi, K = 24 joints in one K = 32 instruction  (36 MFMAs per body, was 72)
+//     dA_e = W^T dT_e    : K = 16 vertices x 2 pieces fill one K = 32 instruction: [Whi | Whi] x [dThi ; dTlo] +
+//                          [Wlo | Wlo] x [dThi ; dTlo] = all four piece products         (48 MFMAs, was 96)
+//   at 16 cycles per instruction instead of 32: 2592 MFMA cycles per vertex tile against 8352 in MODE 1.  The error of
+//   the split (1e-5) is far below the bf16 blend's (4e-3 of the pose offsets), so MODE 2 meets MODE 1's tolerances.
+#ifndef MESH_PQD
+#define MESH_PQD 3
+#endif
+#define MF_AB 392       // MODE 2: transform row stride in bf16 elements (12 entries x 32 joints + 8: 784 B, the 16 sample
+                        // rows of a ds_read_b128 lane group land in 16 different 16-byte bank quads)
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     long N, long NV, const float* __restrict__ PF2, long ldpf, const float* __restrict__ A2,
     const float* __restrict__ P, long ldP, const float* __restrict__ vs, const float* __restrict__ W,
     int G, int cpg, int RA, int CA, int nB, int vec_stage, float* __restrict__ loss_sum, float* __restrict__ dVPt, long ldn,
     float* __restrict__ dA, float* __restrict__ parts, int* __restrict__ tickets, float* __restrict__ loss_parts,
-    int* __restrict__ grid_ticket, unsigned short* __restrict__ dVPb, long ldk) {
+    int* __restrict__ grid_ticket, unsigned short* __restrict__ dVPb, long ldk,
+    const unsigned short* __restrict__ Wsk, const unsigned short* __restrict__ Wadj) {
+    constexpr bool BF16 = MODE != 0, SPLIT = MODE == 2, ADJS = MODE >= 2;
     // All constants are zero-padded by nemo_ctx_create (P: 224 rows x 3*NVp columns, W / v_shaped: NVp
     // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
     // predicate: padded vertices / samples produce v_rec == v_orig == 0, i.e. zero loss and gradient.
@@ -1034,6 +1082,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     float* pfL = lds;                                   // [2][16][MF_PFS] floats  (BF16: [2][16][MF_PFB] bf16)
     __bf16* pfB = reinterpret_cast<__bf16*>(lds);
     float* AL = lds + (BF16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS);     // [2][16][MF_AS], entry (e*24 + j)
+    __bf16* ALb = reinterpret_cast<__bf16*>(AL);        // MODE 2: [body 2][piece 2][16][MF_AB] bf16, entry (e*32 + j)
     __shared__ float red[16];
     const long ntiles = (NV + 15) / 16;
     // Work = (sample group, chunk of 4 vertex tiles) units, G groups x cpg chunks.  Two classes of blocks, all
@@ -1124,9 +1173,21 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             const int set = idx / 1152, n = (idx / 72) % 16, q = idx % 72;
             const int j = q / 3, e = 4 * (q % 3);                   // a float4 never straddles a joint
             const bool live = s0 + n < N;
+            if constexpr (SPLIT) {
+                const float x[4] = {va[it].x, va[it].y, va[it].z, va[it].w};
+                __bf16* dh = ALb + ((set * 2 + 0) * 16 + n) * MF_AB + e * 32 + j;
+                __bf16* dl = ALb + ((set * 2 + 1) * 16 + n) * MF_AB + e * 32 + j;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xv = live ? x[i] : 0.f;
+                    const __bf16 h = (__bf16)xv;
+                    dh[32 * i] = h; dl[32 * i] = (__bf16)(xv - (float)h);
+                }
+            } else {
             float* d = AL + (set * 16 + n) * MF_AS + e * 24 + j;
             d[0] = live ? va[it].x : 0.f; d[24] = live ? va[it].y : 0.f;
             d[48] = live ? va[it].z : 0.f; d[72] = live ? va[it].w : 0.f;
+            }
         }
     } else {
         for (int idx = tid; idx < 2 * 16 * 224; idx += 256) {
@@ -1140,7 +1201,21 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             const int set = idx / (16 * 288), n = (idx / 288) % 16, je = idx % 288;
             const int j = je / 12, e = je % 12;
             const long s = s0 + n;
-            AL[(set * 16 + n) * MF_AS + e * 24 + j] = (s < N) ? A2[(set * N + s) * 288 + je] : 0.f;
+            const float xv = (s < N) ? A2[(set * N + s) * 288 + je] : 0.f;
+            if constexpr (SPLIT) {
+                const __bf16 h = (__bf16)xv;
+                ALb[((set * 2 + 0) * 16 + n) * MF_AB + e * 32 + j] = h;
+                ALb[((set * 2 + 1) * 16 + n) * MF_AB + e * 32 + j] = (__bf16)(xv - (float)h);
+            } else {
+                AL[(set * 16 + n) * MF_AS + e * 24 + j] = xv;
+            }
+        }
+    }
+    if constexpr (SPLIT) {
+        // joints 24..31 of every (body, piece, sample, entry) row: the zero tail of the K = 32 instruction
+        for (int idx = tid; idx < 2 * 2 * 16 * 12; idx += 256) {
+            const int row = idx / 12, e = idx % 12;
+            *reinterpret_cast<uint4*>(ALb + row * MF_AB + e * 32 + 24) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
     __syncthreads();
@@ -1156,6 +1231,8 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     const float* pf1 = pfL + (1 * 16 + l15) * MF_PFS + g;      // reconstruction
     const float* A0 = AL + (0 * 16 + l15) * MF_AS + g;
     const float* A1 = AL + (1 * 16 + l15) * MF_AS + g;
+    const __bf16* Ab0 = ALb + ((0 * 2 + 0) * 16 + l15) * MF_AB + 8 * g;   // MODE 2: hi piece; the lo piece is 16 rows on
+    const __bf16* Ab1 = ALb + ((1 * 2 + 0) * 16 + l15) * MF_AB + 8 * g;
 
     // Blend-shape A-operands, eight k-steps in flight, carried ACROSS vertex tiles: the end of a tile
     // requests the first eight k-steps of the wave's next tile, so a tile never starts with an empty
@@ -1171,12 +1248,13 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     const int kstride = BF16 ? 4 * (int)ldP * 48 : 4 * (int)ldP * 4;                    // bytes between consecutive k-steps
     constexpr int TILE_B = BF16 ? 16 * 48 : 192;                 // bytes between consecutive vertex tiles
     u32x3 pa[8];                                                 // fp32: eight k-steps (of 4) in flight
-    u32x4m pq[2][3];                                             // bf16: two k-steps (of 32) x 3 components in flight
+    constexpr int PQD = MODE == 3 ? MESH_PQD : 2;                      // bf16: PQD k-steps (of 32) x 3 components in flight
+    u32x4m pq[PQD][3];
     {
         const int tf = (int)min(t_beg + wid, ntiles - 1);        // (a wave without tiles loads a valid one)
         if (BF16) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < PQD; ++u)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     pq[u][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff + 16 * c, tf * TILE_B + u * kstride, 0);
@@ -1185,18 +1263,36 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             for (int u = 0; u < 8; ++u) pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, tf * 192 + u * kstride, 0);
         }
     }
+    /*prof:init*/
     for (long t = t_beg + wid; t < t_end; t += 4) {
+        /*prof:c0*/
         const long v0 = t * 16;
         // weights as A-operands: forward (rows = vertices, k = joints) and adjoint (rows = joints, k = vertices)
         float wf[6], wa[4][2];
-        const float* Wf = W + (v0 + l15) * 24 + g;
+        mbf16x8 wsk[2], wad[2][2];                               // split precision: [piece], [joint tile][piece]
+        if constexpr (SPLIT) {
+            const long NVp16 = ((NV + 15) / 16) * 16;
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) wf[kk] = Wf[4 * kk];
-        const float* Wa = W + (v0 + 4 * g) * 24 + l15;
+            for (int pc = 0; pc < 2; ++pc)
+                wsk[pc] = *reinterpret_cast<const mbf16x8*>(Wsk + ((long)pc * NVp16 + v0 + l15) * 32 + 8 * g);
+        } else {
+            const float* Wf = W + (v0 + l15) * 24 + g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            wa[r][0] = Wa[r * 24];
-            wa[r][1] = l15 < 8 ? Wa[r * 24 + 16] : 0.f;
+            for (int kk = 0; kk < 6; ++kk) wf[kk] = Wf[4 * kk];
+        }
+        if constexpr (ADJS) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc)
+                    wad[jt][pc] = *reinterpret_cast<const mbf16x8*>(Wadj + (((t * 2 + jt) * 2 + pc) * 64 + lane) * 8);
+        } else {
+            const float* Wa = W + (v0 + 4 * g) * 24 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wa[r][0] = Wa[r * 24];
+                wa[r][1] = l15 < 8 ? Wa[r * 24 + 16] : 0.f;
+            }
         }
         // ---- pose blend of both bodies: 52 k-steps x 3 components, A-operand P[p][3v+c] from L2
         f32x4 vp[2][3];
@@ -1220,11 +1316,11 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 const mbf16x8 b1 = *reinterpret_cast<const mbf16x8*>(pb1 + 32 * S);
                 mbf16x8 a[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) a[c] = __builtin_bit_cast(mbf16x8, pq[S & 1][c]);
-                if (S + 2 < 7) {
+                for (int c = 0; c < 3; ++c) a[c] = __builtin_bit_cast(mbf16x8, pq[S % PQD][c]);
+                if (S + PQD < 7) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        pq[S & 1][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff + 16 * c, pt + (S + 2) * kstride, 0);
+                        pq[S % PQD][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff + 16 * c, pt + (S + PQD) * kstride, 0);
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -1259,6 +1355,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             }
         }
         }
+        /*prof:c1*/
         // ---- reconstruction body, one output row c (4 transform entries) at a time
         float vrec[3][4];
 #pragma unroll
@@ -1268,16 +1365,32 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             for (int d = 0; d < 4; ++d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) T4[d][r] = 0.f;
+            if constexpr (SPLIT) {
+                mbf16x8 bh[4], bl[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    bh[d] = *reinterpret_cast<const mbf16x8*>(Ab1 + (4 * c + d) * 32);
+                    bl[d] = *reinterpret_cast<const mbf16x8*>(Ab1 + 16 * MF_AB + (4 * c + d) * 32);
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[0], bh[d], T4[d], 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[0], bl[d], T4[d], 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[1], bh[d], T4[d], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk)
 #pragma unroll
                 for (int d = 0; d < 4; ++d)       // 4 independent accumulators back to back
                     T4[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk], A1[(4 * c + d) * 24 + 4 * kk], T4[d], 0, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 vrec[c][r] = T4[0][r] * vp[1][0][r] + T4[1][r] * vp[1][1][r] + T4[2][r] * vp[1][2][r] + T4[3][r];
             __builtin_amdgcn_sched_barrier(0);
         }
+        /*prof:c2*/
         // ---- original body: row c of the transform -> vertex coordinate c -> sign -> its share of dvp and
         // the four dT entries (c, 0..3), which go straight into the vertex->joint MFMA as B-operands
         float dvp[3][4];
@@ -1287,16 +1400,33 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             for (int r = 0; r < 4; ++r) dvp[d][r] = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+            /*prof:q0*/
             f32x4 T4[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) T4[d][r] = 0.f;
+            if constexpr (SPLIT) {
+                mbf16x8 bh[4], bl[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    bh[d] = *reinterpret_cast<const mbf16x8*>(Ab0 + (4 * c + d) * 32);
+                    bl[d] = *reinterpret_cast<const mbf16x8*>(Ab0 + 16 * MF_AB + (4 * c + d) * 32);
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[0], bh[d], T4[d], 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[0], bl[d], T4[d], 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[1], bh[d], T4[d], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk)
 #pragma unroll
                 for (int d = 0; d < 4; ++d)       // 4 independent accumulators back to back
                     T4[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk], A0[(4 * c + d) * 24 + 4 * kk], T4[d], 0, 0, 0);
+            }
+            /*prof:q1*/
             float gs[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1307,13 +1437,14 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 #pragma unroll
                 for (int d2 = 0; d2 < 3; ++d2) dvp[d2][r] += T4[d2][r] * gs[r];
             }
+            /*prof:q2*/
             if (c == 2) {
                 // the wave's NEXT tile: first eight k-steps requested here, under the cover of the last 32
                 // adjoint MFMAs and the dvp store (their registers are dead during the skinning phases,
                 // where the pressure peaks -- a ring kept full across the whole tile spills)
                 if (BF16) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
+                    for (int u = 0; u < PQD; ++u)
 #pragma unroll
                         for (int c2 = 0; c2 < 3; ++c2)
                             pq[u][c2] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff + 16 * c2, ptn + u * kstride, 0);
@@ -1324,6 +1455,27 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (ADJS) {
+                // B-operand of entry e = (c, d): k = 8 g + t <-> the lane's own vertex row 4 g + t, hi pieces in t = 0..3,
+                // lo pieces in t = 4..7 -- formed from the accumulator-layout values without leaving the lane
+                mbf16x8 bq[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dT = d < 3 ? gs[r] * vp[0][d][r] : gs[r];
+                        const __bf16 h = (__bf16)dT;
+                        bq[d][r] = h; bq[d][4 + r] = (__bf16)(dT - (float)h);
+                    }
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int e = 4 * c + d;
+                        accdA[e][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wad[0][pc], bq[d], accdA[e][0], 0, 0, 0);
+                        accdA[e][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wad[1][pc], bq[d], accdA[e][1], 0, 0, 0);
+                    }
+            } else {
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 const int e = 4 * c + d;
@@ -1334,8 +1486,11 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                     accdA[e][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[r][1], dT, accdA[e][1], 0, 0, 0);
                 }
             }
+            }
             __builtin_amdgcn_sched_barrier(0);
+            /*prof:q2e*/
         }
+        /*prof:q3*/
         if (BF16 && dVPb) {
             // bf16-in-memory chain: d vp as bf16, NOT transposed -- row = sample, the lane's 4 vertices x 3 coordinates are
             // 12 consecutive k (24 bytes, 8-byte aligned): the k-contiguous A operand of the adjoint product dPF = dVP P^T
@@ -1360,6 +1515,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 #pragma unroll
             for (int d = 0; d < 3; ++d) dst[(r * 3 + d) * ldn] = dvp[d][r];
         }
+        /*prof:c3*/
     }
 
     // ---- cross-wave reduction of dA through LDS (the staged sample data is dead now)
@@ -1472,6 +1628,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                     if (j < 24) dA[(s0 + l15) * 288 + j * 12 + e] = accdA[e][t][r];
                 }
     }
+    /*prof:out*/
     }   // segment
     // L1 sum: every block publishes its partial (write-through), the LAST block to arrive adds all of them in block
     // order in float64 and accumulates the result into the loss slot -- one writer per launch, launches of a
@@ -1825,12 +1982,17 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const f
     if (dVPb ? (!bf16 || ldk < ctx->ldP || (ldk & 3) || (((uintptr_t)dVPb) & 7)) : (!dVPt || ldn < ((N + 15) / 16) * 16))
         return NEMO_EINVAL;                                    // (dA == NULL: deferred combine, nemo_v2v_combine)
     if (N == 0) return NEMO_OK;
-    const int lds_bytes = ((bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * MF_AS) * (int)sizeof(float);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[bf16]) {
-        HIPCHK(hipFuncSetAttribute(bf16 ? (const void*)mesh_v2v_fused_kernel<true> : (const void*)mesh_v2v_fused_kernel<false>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set[bf16] = true;
+    // bf16: split-precision vertex->joint adjoint on the bf16 pipe (MODE 3); NEMO_MESH_SPLIT=0 -> MODE 1, =2 -> MODE 2 (A/B aids)
+    static const int split_env = [] { const char* e = getenv("NEMO_MESH_SPLIT"); return e ? atoi(e) : 1; }();
+    const int mode = bf16 ? (split_env == 2 ? 2 : split_env ? 3 : 1) : 0;
+    const int lds_bytes = mode == 2 ? 2 * 16 * MF_PFB * 2 + 2 * 2 * 16 * MF_AB * 2
+                                    : ((bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * MF_AS) * (int)sizeof(float);
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[mode]) {
+        const void* fn = mode == 3 ? (const void*)mesh_v2v_fused_kernel<3> : mode == 2 ? (const void*)mesh_v2v_fused_kernel<2>
+                       : mode == 1 ? (const void*)mesh_v2v_fused_kernel<1> : (const void*)mesh_v2v_fused_kernel<0>;
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set[mode] = true;
     }
     const int vec_stage = (ldpf % 4 == 0) && (((uintptr_t)PF2 | (uintptr_t)A2) & 15) == 0 && ldpf >= 208;
     const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
@@ -1846,17 +2008,15 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const f
     float* loss_parts = reinterpret_cast<float*>(wsb + 16);
     int* tickets = reinterpret_cast<int*>(wsb + 16 + MESH_MAX_BLOCKS * 4);
     float* parts = reinterpret_cast<float*>(wsb + MESH_HEADER_BYTES);
-    if (bf16)
-        hipLaunchKernelGGL(mesh_v2v_fused_kernel<true>, dim3((unsigned)blocks), dim3(256), lds_bytes,
-                           (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2,
-                           reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp, ctx->d_v_shaped, ctx->d_W, pl.G,
-                           pl.cpg, pl.RA, pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets, loss_parts,
-                           grid_ticket, dVPb, (long)ldk);
-    else
-        hipLaunchKernelGGL(mesh_v2v_fused_kernel<false>, dim3((unsigned)blocks), dim3(256), lds_bytes,
-                           (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, ctx->d_posedirs, ctx->ldP,
-                           ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA, pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn,
-                           dA, parts, tickets, loss_parts, grid_ticket, (unsigned short*)nullptr, 0L);
+#define MESH_LAUNCH(M, PP, LDP) hipLaunchKernelGGL(mesh_v2v_fused_kernel<M>, dim3((unsigned)blocks), dim3(256), lds_bytes, \
+        (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, PP, LDP, ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA,  \
+        pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets, loss_parts, grid_ticket, dVPb, (long)ldk,    \
+        ctx->d_Wsk, ctx->d_Wadj)
+    if (mode == 3) MESH_LAUNCH(3, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
+    else if (mode == 2) MESH_LAUNCH(2, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
+    else if (mode == 1) MESH_LAUNCH(1, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
+    else MESH_LAUNCH(0, ctx->d_posedirs, ctx->ldP);
+#undef MESH_LAUNCH
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
