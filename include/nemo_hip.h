@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 7
+#define NEMO_ABI_VERSION 8
 int32_t nemo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -74,7 +74,12 @@ int32_t nemo_gemm_bf16(int32_t transA, int32_t transB, int64_t M, int64_t N, int
 int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
                           float* C, int64_t ldc, const float* bias, int32_t act, const float* mask, int64_t ldmask,
                           int32_t mask_mode, float alpha, int32_t out_mode, uint16_t* Cb, int64_t ldcb, uint16_t* CbT,
-                          int64_t ldcbt, void* ws, int64_t ws_bytes, void* stream);
+                          int64_t ldcbt, float* colsum, int64_t ldcs, void* ws, int64_t ws_bytes, void* stream);
+/* colsum != NULL (out_mode 0 / 1): the epilogue also leaves the column sums of the result per 32-row band in
+ * colsum[band * ldcs + n], band = 0 .. nemo_gemm_colsum_rows(M) - 1, ldcs >= N -- the bias gradient sum_m dY[m][n] of a
+ * layer (nemo/neural_motion_model.py:58-71 under autograd) is then nemo_colsum_multi over that short matrix, and dY need
+ * not exist in fp32.  Every element has one writer: deterministic. */
+int64_t nemo_gemm_colsum_rows(int64_t M);
 int32_t nemo_cast_bf16(int64_t rows, int64_t cols, const float* src, int64_t lds, uint16_t* dst, int64_t ldd,
                        int32_t transpose, void* stream);
 /* Up to NEMO_GEMM_GROUP_MAX independent products C_i (op)= alpha_i * opA(A_i) @ opB(B_i) (out_mode 0 store / 1 C +=; no

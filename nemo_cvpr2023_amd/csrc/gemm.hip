@@ -542,8 +542,9 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
                          const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
                          int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream,
                          unsigned short* Cb = nullptr, long ldcb = 0, unsigned short* CbT = nullptr, long ldcbt = 0,
-                         const unsigned short* mask16 = nullptr, long ldmask16 = 0) {
+                         const unsigned short* mask16 = nullptr, long ldmask16 = 0, float* colsum = nullptr, long ldcs = 0) {
     if (M < 0 || N < 0 || K < 0 || (!C && !(bf16 == 2 && (Cb || CbT) && out_mode == 0))) return NEMO_EINVAL;
+    if (colsum && (bf16 != 2 || out_mode == 2 || ldcs < N)) return NEMO_EINVAL;
     if (M == 0 || N == 0) return NEMO_OK;
     if (K > 0 && (!A || !B)) return NEMO_EINVAL;
     if (act < 0 || act > 2 || mask_mode < 0 || mask_mode > 2 || out_mode < 0 || out_mode > 2)
@@ -689,13 +690,14 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     // register-staged kernel below, which keeps the unaligned operands, the 128x128 tile and very large operands.
     g.xcd_order = 0;
     g.Cb = Cb; g.ldcb = ldcb; g.CbT = CbT; g.ldcbt = ldcbt; g.mask16 = mask16; g.ldmask16 = ldmask16;
+    g.colsum = colsum; g.ldcs = ldcs;
     // Tuning aid (NEMO_B16_TILE=128): bf16-in-memory products on 128 x 128 tiles -- twice the MFMA work per byte the LDS-DMA
     // moves, but one block per CU (96 KiB of LDS stages).  Measured SLOWER than the 64 x 64 tile at every shape of the step
     // (12 000 x 1000 x 1000: 98 us = 244 TFLOP/s against 71 us = 337; profiles/r03_experiments.md section 9): not used.
     if (bf16 == 2 && glds_ok && !transA && transB) {
         static const int b16_tile = [] { const char* f = getenv("NEMO_B16_TILE"); return f ? atoi(f) : 0; }();
         const bool big = b16_tile == 128 || b16_tile == 12864;
-        if (big && split_k == 0) {
+        if (big && split_k == 0 && !colsum) {
             const int bn = b16_tile == 128 ? 128 : 64;
             g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (int)((N + bn - 1) / bn); g.n_tiles = g.tiles_m * g.tiles_n;
             g.split = 1; g.t0 = g.n_tiles; g.k_chunk = (K + 31) / 32 * 32;
@@ -771,7 +773,8 @@ extern "C" int32_t nemo_gemm_bf16(int32_t transA, int32_t transB, int64_t M, int
 extern "C" int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, const uint16_t* B,
                                      int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t act, const float* mask,
                                      int64_t ldmask, int32_t mask_mode, float alpha, int32_t out_mode, uint16_t* Cb,
-                                     int64_t ldcb, uint16_t* CbT, int64_t ldcbt, void* ws, int64_t ws_bytes, void* stream) {
+                                     int64_t ldcb, uint16_t* CbT, int64_t ldcbt, float* colsum, int64_t ldcs, void* ws,
+                                     int64_t ws_bytes, void* stream) {
     if (M < 0 || N < 0 || K < 0 || (K & 1) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) return NEMO_EINVAL;
     if (!C && !(Cb || CbT)) return NEMO_EINVAL;
     if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return NEMO_EINVAL;
@@ -785,8 +788,11 @@ extern "C" int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint
     return gemm_impl(2, 0, 1, M, N, K / 2, reinterpret_cast<const float*>(A), lda / 2, reinterpret_cast<const float*>(B),
                      ldb / 2, C, ldc, bias, act, m16 ? nullptr : mask, ldmask, m16 ? mask_mode - 16 : mask_mode, alpha, out_mode,
                      0, ws, ws_bytes, stream, Cb, ldcb, CbT, ldcbt,
-                     m16 ? reinterpret_cast<const unsigned short*>(mask) : nullptr, ldmask);
+                     m16 ? reinterpret_cast<const unsigned short*>(mask) : nullptr, ldmask, colsum, ldcs);
 }
+
+// rows of the `colsum` scratch nemo_gemm_bf16mem fills for an M-row result: one per 32-row band of its 64 x 64 tiles
+extern "C" int64_t nemo_gemm_colsum_rows(int64_t M) { return M < 0 ? -1 : 2 * ((M + 63) / 64); }
 
 namespace {
 // dst (bf16) = src (fp32), optionally transposed; 32 x 32 tiles through LDS so that both sides move whole lines.

@@ -73,6 +73,12 @@ struct Args {
     // C may be NULL when only the bf16 copies of the result are wanted (hidden activations of a bf16-in-memory chain)
     const unsigned short* mask16 = nullptr;
     long ldmask16 = 0;
+    // BF16 == 2 only: column sums of the RESULT (after bias / activation / mask) per 32-row wave band -- row
+    // (tile_m * (BM / 32) + band) of colsum[.][ldcs] gets the band's sum of every column: the bias gradient of a layer is
+    // then a sum over 2 ceil(M / 64) short rows instead of a pass over the M x N result, which no longer has to exist in
+    // fp32 at all.  One writer per element, no atomics: deterministic.
+    float* colsum = nullptr;
+    long ldcs = 0;
 };
 
 constexpr int BK = 32;
@@ -475,6 +481,7 @@ __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, flo
             if (n >= g.N) continue;
             const float bv = add_bias ? g.bias[n] : 0.f;
             unsigned short tq[4] = {0, 0, 0, 0};
+            float csum = 0.f;
 #pragma unroll
             for (int r = 0; r < AR; ++r) {
                 const long m = m0 + wm * WM + i * T + (T == 32 ? (r & 3) + 8 * (r >> 2) + 4 * lh : 4 * lh + r);
@@ -510,6 +517,7 @@ __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, flo
                     else atomicAdd(c, v);
                 }
                 if constexpr (BF16 == 2) {
+                    csum += v;
                     const unsigned short bits = __builtin_bit_cast(unsigned short, (__bf16)v);
                     if (g.Cb) g.Cb[m * g.ldcb + n] = bits;                 // 32 lanes x 2 B: 64-byte runs along n
                     if (g.CbT) {
@@ -525,6 +533,12 @@ __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, flo
                             }
                         }
                     }
+                }
+            }
+            if constexpr (BF16 == 2 && T == 32) {
+                if (g.colsum) {
+                    csum += __shfl_xor(csum, 32, 64);              // lanes l and l + 32: the same column, the other rows
+                    if (lh == 0) g.colsum[((long)tm * (BM / 32) + wm * TM + i) * g.ldcs + n] = csum;
                 }
             }
         }

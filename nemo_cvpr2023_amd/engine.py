@@ -307,6 +307,7 @@ class FitEngine:
         self.ws = {}
         self.side_stream = torch.cuda.Stream(device=self.device)   # prior branches of the step (see _forward_backward)
         self.side_stream2 = torch.cuda.Stream(device=self.device)
+        self.pub_stream = torch.cuda.Stream(device=self.device)     # NEMO_PUBLISH=aside4 (A/B aid)
         self.comm_stream = torch.cuda.Stream(device=self.device)    # bucketed gradient all-reduces + their Adam (dist.py)
         # split-K scratch of nemo_gemm_f32 (arrival tickets + partial tiles), one per stream that launches GEMMs
         self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(3)]
@@ -399,6 +400,9 @@ class FitEngine:
                      dE_ab=Zb(N, 512))
             for k in ('H1', 'H2', 'H3', 'dH', 'dH_b', 'dH_c'):
                 w[k + 'b'], w[k + 'bT'] = Zb(N + 1, hp), Zb(h, rp)
+            # per-band column sums of the two hidden activation gradients (nemo_gemm_bf16mem(colsum)): their bias gradients
+            R = int(self.lib.nemo_gemm_colsum_rows(N + 1))
+            w['cs4'], w['cs2'] = Z(R, h), Z(R, h)
         if self.version == 0:            # hidden activations of the orient and translation networks (poses: H1..H3)
             w.update(O1=Z(N + 1, h), O2=Z(N + 1, h), O3=Z(N + 1, h), T1=Z(N + 1, h), T2=Z(N + 1, h))
         # scratch of nemo_v2v_fused (arrival tickets, zero at allocation and returned to zero by the kernel, +
@@ -438,6 +442,12 @@ class FitEngine:
         (profiles/r03_experiments.md) -- the kernel trace's late start of the third queue is a profiler artefact.
         NEMO_PRIOR_MODE: A/B override."""
         return int(os.environ.get('NEMO_PRIOR_MODE', '0'))
+
+    def late_join(self, N):
+        """Whether the prior branch joins the main chain BEHIND the fused mesh kernel (small batches) instead of in front of
+        it.  NEMO_LATE_JOIN: A/B override (0 | 1); default: measured, see profiles/r03_experiments.md section 12."""
+        v = os.environ.get('NEMO_LATE_JOIN')
+        return bool(int(v)) if v is not None else False
 
     def kernel_flops_by_pipe(self, tag, flops):
         """Split a tagged (bench-timed) kernel's algorithmic FLOPs by the matrix pipe they run on, so that bench.py can
@@ -484,7 +494,7 @@ class FitEngine:
               'nemo_cast_bf16')
 
     def gemm16(self, M, N, K, Ab, Bb, Cp, ldc, bias=None, act=0, mask=None, ldmask=0, mask_mode=0, alpha=1.0, out_mode=0,
-               Cb=None, CbT=None, tag=None):
+               Cb=None, CbT=None, colsum=None, tag=None):
         """C (M x N, fp32) (op)= epilogue(alpha * A B^T) with A (M x K), B (N x K) bf16 in memory (2-D int16 tensors whose
         row stride is the ld; K is taken up to the next even number: the pad column is zero by construction)."""
         ev = self._event_begin(tag, 2.0 * M * N * K)
@@ -494,6 +504,7 @@ class FitEngine:
                                          bias, act, mask, ldmask, mask_mode, alpha, out_mode,
                                          dptr(Cb), Cb.stride(0) if Cb is not None else 0,
                                          dptr(CbT), CbT.stride(0) if CbT is not None else 0,
+                                         dptr(colsum), colsum.stride(0) if colsum is not None else 0,
                                          ws.data_ptr(), ws.numel() * 4, _stream()), 'nemo_gemm_bf16mem')
         self._event_end(ev)
 
@@ -509,19 +520,28 @@ class FitEngine:
                         '2T': torch.zeros(h, r8(h), **i16), '4T': torch.zeros(h, r8(h), **i16), 'headT': torch.zeros(h, 152, **i16)}
         shapes = (('2', lm + 'net.net.2.weight', h, h), ('4', lm + 'net.net.4.weight', h, h), ('head', lm + 'rot_out.weight', 147, h))
         for key, name, fo, fi in shapes:
-            self._cast(fo, fi, self.p(name), fi, self._wb[key + ('T' if transposed else '')], 1 if transposed else 0)
+            for tr in ((0, 1) if transposed == 'both' else (1,) if transposed else (0,)):
+                self._cast(fo, fi, self.p(name), fi, self._wb[key + ('T' if tr else '')], tr)
         return self._wb
 
     def _forward_nets_b16(self, w, N, train):
         """forward_pose's MLP on the bf16-in-memory chain: every layer reads the previous layer's bf16 copy and leaves its
         own (plain for the next layer, transposed for its parameter gradient when `train`)."""
         lm, h, r = 'learned_motion.', self.h, N + 1
-        wb = self._weights_b16(False)
+        # the weights' bf16 copies (plain for this forward and, in a training step, the transposed ones of the backward: the
+        # weights only change in Adam) are made on the side stream, beside the first layer's fp32 product
+        main, side = torch.cuda.current_stream(), self.side_stream
+        side.wait_event(main.record_event())
+        with torch.cuda.stream(side):
+            wb = self._weights_b16('both' if train else False)
+            casts_done = side.record_event()
+        self._wbT_fresh = bool(train)
         T = lambda k: w[k] if train else None
         # the first layer (K = 105 RBF features + code, rows of nn.Linear(105, h) not 16-byte aligned) stays where it was:
         # fp32 arithmetic (its operands never qualified for the bf16 path; 2 % of the MLP's FLOPs)
         self._linear(r, dptr(w['X']), self.ldx, self.din, self.p(lm + 'net.net.0.weight'),
                      self.p(lm + 'net.net.0.bias'), h, dptr(w['H1']), h, act=1)
+        main.wait_event(casts_done)
         self._cast(r, h, dptr(w['H1']), h, w['H1b'], 0)
         if train:
             self._cast(r, h, dptr(w['H1']), h, w['H1bT'], 1)
@@ -538,23 +558,30 @@ class FitEngine:
         dX_l = dY_l (W_l^T)^T reads dY_l's plain copy and the transposed weight copy; dW_l = dY_l^T X_l reads the two
         TRANSPOSED activation copies (K = rows)."""
         L, lm, h, r = self.lib, 'learned_motion.', self.h, N + 1
-        wb = self._weights_b16(True)
+        if getattr(self, '_wbT_fresh', False):
+            wb = self._wb                     # cast in this step's forward (_forward_nets_b16)
+        else:
+            wb = self._weights_b16(True)
+        self._wbT_fresh = False
         self._cast(r, nout, dptr(w['dHEAD']), HEAD_LD, w['dHEADb'], 0)
         self._cast(r, nout, dptr(w['dHEAD']), HEAD_LD, w['dHEADbT'], 1)
         cs = self._colsums
         # heads
         self.gemm16(nout, h, r, w['dHEADbT'], w['H3bT'], self.g(lm + 'rot_out.weight'), h, out_mode=1)
         cs.append((dptr(w['dHEAD']), r, nbias, HEAD_LD, self.g(lm + 'rot_out.bias')))
-        self.gemm16(r, h, nout, w['dHEADb'], wb['headT'], dptr(w['dH']), h, mask=dptr(w['H3b']), ldmask=w['H3b'].stride(0),
-                    mask_mode=17, Cb=w['dHb'], CbT=w['dHbT'])
+        # The activation gradients of the two hidden layers exist as bf16 copies only; their bias gradients come from the
+        # per-band column sums the same launches leave (nemo_gemm_bf16mem(colsum)): 2 ceil(r / 64) rows instead of r
+        R = int(L.nemo_gemm_colsum_rows(r))
+        self.gemm16(r, h, nout, w['dHEADb'], wb['headT'], None, h, mask=dptr(w['H3b']), ldmask=w['H3b'].stride(0),
+                    mask_mode=17, Cb=w['dHb'], CbT=w['dHbT'], colsum=w['cs4'])
         # layer 4
         self.gemm16(h, h, r, w['dHbT'], w['H2bT'], self.g(lm + 'net.net.4.weight'), h, out_mode=1)
-        cs.append((dptr(w['dH']), r, h, h, self.g(lm + 'net.net.4.bias')))
-        self.gemm16(r, h, h, w['dHb'], wb['4T'], dptr(w['dH_b']), h, mask=dptr(w['H2b']), ldmask=w['H2b'].stride(0),
-                    mask_mode=17, Cb=w['dH_bb'], CbT=w['dH_bbT'], tag='gemm_mlp_hidden_dx')
+        cs.append((dptr(w['cs4']), R, h, h, self.g(lm + 'net.net.4.bias')))
+        self.gemm16(r, h, h, w['dHb'], wb['4T'], None, h, mask=dptr(w['H2b']), ldmask=w['H2b'].stride(0),
+                    mask_mode=17, Cb=w['dH_bb'], CbT=w['dH_bbT'], colsum=w['cs2'], tag='gemm_mlp_hidden_dx')
         # layer 2
         self.gemm16(h, h, r, w['dH_bbT'], w['H1bT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1)
-        cs.append((dptr(w['dH_b']), r, h, h, self.g(lm + 'net.net.2.bias')))
+        cs.append((dptr(w['cs2']), R, h, h, self.g(lm + 'net.net.2.bias')))
         self.gemm16(r, h, h, w['dH_bb'], wb['2T'], dptr(w['dH_c']), h, mask=dptr(w['H1b']), ldmask=w['H1b'].stride(0),
                     mask_mode=17, Cb=None, CbT=None)
         # layer 0: as before (see _forward_nets_b16)

@@ -601,8 +601,14 @@ class MultiViewModel(nn.Module):
                 side2.wait_event(kp_done)
                 e.finalize_kp(w, mean_mode=0)
             main.wait_stream(side)
-            main.wait_stream(side2)
+            # Small batches: the prior branch (GMM, 3-D term, KL and its backward, the key-point loss scalar) joins BEHIND the
+            # mesh kernel instead of in front of it -- nothing the mesh kernel reads comes from there, and below ~1024
+            # samples its blocks do not fill the machine anyway (NEMO_LATE_JOIN=0 | 1: A/B aid)
+            late_join = bool(use_vposer and e.late_join(N) and os.environ.get('NEMO_PUBLISH', 'aside') != 'main_early')
+            if not late_join:
+                main.wait_stream(side2)
         else:
+            late_join = False
             with torch.cuda.stream(side):
                 priors()
                 priors_done = side.record_event()
@@ -628,19 +634,31 @@ class MultiViewModel(nn.Module):
         # (NEMO_PUBLISH=main_early | main_late: A/B aid.)
         loss_final = []
         pub_mode = os.environ.get('NEMO_PUBLISH', 'aside')
-        pub_aside = bool(publish and update and part == 'all' and use_vposer and e.overlap_bwd and pub_mode == 'aside')
+        pub_aside = bool(publish and update and part == 'all' and use_vposer and e.overlap_bwd and pub_mode in ('aside', 'aside4'))
+        pub4 = pub_aside and pub_mode == 'aside4'      # (A/B aid: the hand-over on a stream of its own, enqueued FIRST)
         pub_early = bool(publish and use_vposer and pub_mode == 'main_early')
         if use_vposer:
             e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss), pre_done=True,
                           after_loss=(lambda: loss_final.append(main.record_event())) if pub_aside else
                           (e.publish_scalars if pub_early else None))
+        if pub4:
+            ps = e.pub_stream
+            ps.wait_event(loss_final[0])
+            if late_join:
+                ps.wait_stream(side2)
+            with torch.cuda.stream(ps):
+                e.publish_scalars()
+        if late_join:
+            main.wait_stream(side2)
         if publish and not pub_aside and not pub_early:
             e.publish_scalars()
         if not update or part == 'head':
             return
         self._backward_tail(w, N, vi, fi, update, use_vposer, sh, stages=(0,) if part == 'k0' else (0, 1, 2),
                             bucketed=part == 'k0')
-        if pub_aside:
+        if pub4:
+            main.wait_stream(e.pub_stream)
+        elif pub_aside:
             side2.wait_event(loss_final[0])
             with torch.cuda.stream(side2):
                 e.publish_scalars()

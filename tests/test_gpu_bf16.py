@@ -222,10 +222,23 @@ def test_gemm_with_bf16_operands_in_memory(L, M, N, K):
     Mp = (M + 7) // 8 * 8
     Cb = torch.zeros(M, N, dtype=torch.int16, device=DEV)
     CbT = torch.zeros(N, Mp, dtype=torch.int16, device=DEV)
+    R = int(L.nemo_gemm_colsum_rows(M))
+    assert R == 2 * ((M + 63) // 64)
+    cs = torch.full((R, N + 3), float('nan'), device=DEV)           # per-band column sums of the result (bias gradients)
     check(L.nemo_gemm_bf16mem(M, N, Keven, dptr(Ab), Kp, dptr(Bb), Kp, dptr(C), N, dptr(bias), 1, None, 0, 0, 1.0, 0,
-                              dptr(Cb), N, dptr(CbT), Mp, dptr(ws), ws.numel() * 4, H.st()), 'gemm_bf16mem')
+                              dptr(Cb), N, dptr(CbT), Mp, dptr(cs), N + 3, dptr(ws), ws.numel() * 4, H.st()), 'gemm_bf16mem')
     ref = torch.relu(rnd(A).double() @ rnd(Bt).double() + bias.double())
     assert rel_err(C, ref) < 2e-5
+    assert bool(torch.isfinite(cs[:, :N]).all()) and bool(torch.isnan(cs[:, N:]).all())
+    assert rel_err(cs[:, :N].double().sum(0), C.double().sum(0)) < 1e-5
+    band = torch.zeros(R * 32, N, dtype=torch.float64, device=DEV)
+    band[:M] = C.double()
+    assert rel_err(cs[:, :N], band.reshape(R, 32, N).sum(1)) < 1e-5          # band b = rows [32 b, 32 b + 32)
+    # without C: only the bf16 copies and the column sums are produced
+    Cb2, cs2 = torch.zeros_like(Cb), torch.zeros_like(cs)
+    check(L.nemo_gemm_bf16mem(M, N, Keven, dptr(Ab), Kp, dptr(Bb), Kp, None, 0, dptr(bias), 1, None, 0, 0, 1.0, 0,
+                              dptr(Cb2), N, None, 0, dptr(cs2), N + 3, dptr(ws), ws.numel() * 4, H.st()), 'gemm_bf16mem')
+    assert torch.equal(Cb2, Cb) and torch.equal(cs2[:, :N], cs[:, :N])
     assert torch.equal(Cb.view(torch.bfloat16), rnd(C)) and torch.equal(CbT[:, :M].view(torch.bfloat16), rnd(C).T.contiguous())
     assert int(CbT[:, M:].abs().sum()) == 0
     # the on-the-fly kernel on the fp32 operands computes the same thing (it needs 16-byte aligned rows to take its bf16 path)
@@ -236,6 +249,6 @@ def test_gemm_with_bf16_operands_in_memory(L, M, N, K):
     C0 = torch.randn(M, N, generator=g).to(DEV)
     C2 = C0.clone()
     check(L.nemo_gemm_bf16mem(M, N, Keven, dptr(Ab), Kp, dptr(Bb), Kp, dptr(C2), N, None, 0, None, 0, 0, 1.0, 1,
-                              None, 0, None, 0, dptr(ws), ws.numel() * 4, H.st()), 'gemm_bf16mem')
+                              None, 0, None, 0, None, 0, dptr(ws), ws.numel() * 4, H.st()), 'gemm_bf16mem')
     assert rel_err(C2, C0.double() + rnd(A).double() @ rnd(Bt).double()) < 2e-5
     assert int(ws[:4096].view(torch.int32).abs().sum()) == 0

@@ -30,10 +30,10 @@ for M, N, K in ((12000, 1000, 1000), (2401, 1000, 1000), (12000, 512, 512), (120
     Cb, CbT = torch.zeros(M, N, dtype=torch.int16, device='cuda'), torch.zeros(N, (M + 7) // 8 * 8, dtype=torch.int16, device='cuda')
     check(L.nemo_cast_bf16(M, K, dptr(A), K, dptr(Ab), K, 0, H.st()), 'c')
     check(L.nemo_cast_bf16(N, K, dptr(B), K, dptr(Bb), K, 0, H.st()), 'c')
-    f32 = lambda: L.nemo_gemm_f32(0, 1, M, N, K, dptr(A), K, dptr(B), K, dptr(C), N, None, 1, None, 0, 0, 1.0, 0, 0, dptr(ws), ws.numel() * 4, H.st())
-    b16 = lambda: L.nemo_gemm_bf16(0, 1, M, N, K, dptr(A), K, dptr(B), K, dptr(C), N, None, 1, None, 0, 0, 1.0, 0, 0, dptr(ws), ws.numel() * 4, H.st())
-    mem = lambda: L.nemo_gemm_bf16mem(M, N, K, dptr(Ab), K, dptr(Bb), K, dptr(C), N, None, 1, None, 0, 0, 1.0, 0, None, 0, None, 0, dptr(ws), ws.numel() * 4, H.st())
-    mem2 = lambda: L.nemo_gemm_bf16mem(M, N, K, dptr(Ab), K, dptr(Bb), K, dptr(C), N, None, 1, None, 0, 0, 1.0, 0, dptr(Cb), N, dptr(CbT), CbT.stride(0), dptr(ws), ws.numel() * 4, H.st())
+    f32 = lambda: L.nemo_gemm_f32(0, 1, M, N, K, dptr(A), K, dptr(B), K, dptr(C), N, None, 1, None, 0, 0, 1.0, 0, 0, None, 0, dptr(ws), ws.numel() * 4, H.st())
+    b16 = lambda: L.nemo_gemm_bf16(0, 1, M, N, K, dptr(A), K, dptr(B), K, dptr(C), N, None, 1, None, 0, 0, 1.0, 0, 0, None, 0, dptr(ws), ws.numel() * 4, H.st())
+    mem = lambda: L.nemo_gemm_bf16mem(M, N, K, dptr(Ab), K, dptr(Bb), K, dptr(C), N, None, 1, None, 0, 0, 1.0, 0, None, 0, None, 0, None, 0, dptr(ws), ws.numel() * 4, H.st())
+    mem2 = lambda: L.nemo_gemm_bf16mem(M, N, K, dptr(Ab), K, dptr(Bb), K, dptr(C), N, None, 1, None, 0, 0, 1.0, 0, dptr(Cb), N, dptr(CbT), CbT.stride(0), None, 0, dptr(ws), ws.numel() * 4, H.st())
     cast = lambda: L.nemo_cast_bf16(M, K, dptr(A), K, dptr(Ab), K, 0, H.st())
     castT = lambda: L.nemo_cast_bf16(M, N, dptr(C), N, dptr(CbT), CbT.stride(0), 1, H.st())
     gf = 2e-9 * M * N * K
