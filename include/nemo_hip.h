@@ -80,6 +80,14 @@ int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint16_t* A, in
  * layer (nemo/neural_motion_model.py:58-71 under autograd) is then nemo_colsum_multi over that short matrix, and dY need
  * not exist in fp32.  Every element has one writer: deterministic. */
 int64_t nemo_gemm_colsum_rows(int64_t M);
+/* nemo_gemm_f32 (fp32 operands, fp32 arithmetic, out_mode 0, no mask) whose result is stored as bf16 (Cb, ldcb >= N) and /
+ * or as its bf16 transpose (CbT (N x M), ldcbt >= M, ldcbt % 4 == 0, 8-byte aligned) instead of / beside C (may be NULL):
+ * the first MotionNet layer (nn.Linear(105, h), nemo/neural_motion_model.py:58-71) of the bf16-in-memory chain, whose
+ * rows of 105 floats keep it on the fp32 path -- its output feeds bf16 products only. */
+int32_t nemo_gemm_f32_b16out(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda,
+                             const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t act,
+                             uint16_t* Cb, int64_t ldcb, uint16_t* CbT, int64_t ldcbt, void* ws, int64_t ws_bytes,
+                             void* stream);
 int32_t nemo_cast_bf16(int64_t rows, int64_t cols, const float* src, int64_t lds, uint16_t* dst, int64_t ldd,
                        int32_t transpose, void* stream);
 /* Up to NEMO_GEMM_GROUP_MAX independent products C_i (op)= alpha_i * opA(A_i) @ opB(B_i) (out_mode 0 store / 1 C +=; no

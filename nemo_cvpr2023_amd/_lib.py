@@ -44,6 +44,8 @@ SIGNATURES = {
     'nemo_gemm_bf16mem': (i32, [i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32, f32, i32, ptr, i64, ptr,
                                 i64, ptr, i64, ptr, i64, ptr]),
     'nemo_gemm_colsum_rows': (i64, [i64]),
+    'nemo_gemm_f32_b16out': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, ptr, i64, ptr, i64,
+                                   ptr]),
     'nemo_cast_bf16': (i32, [i64, i64, ptr, i64, ptr, i64, i32, ptr]),
     'nemo_gemm_grouped_f32': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),
     'nemo_gemm_grouped_bf16': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),

@@ -327,10 +327,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
             const long n = n0 + wn * WN + j * 32 + l31;
             if (n >= g.N) continue;
             const float bv = add_bias ? g.bias[n] : 0.f;
+            unsigned short tq[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m >= g.M) continue;
+                if (m >= g.M) {
+                    if (g.CbT) {
+                        // a ragged last group of four rows: its valid members go out one by one
+                        if ((r & 3) > 0 && m - (r & 3) < g.M)
+                            for (int u = 0; u < (r & 3); ++u)
+                                if (m - (r & 3) + u < g.M) g.CbT[n * g.ldcbt + m - (r & 3) + u] = tq[u];
+                        // (odd M: column M of the transposed bf16 copy is the k-pad of the product that reads it)
+                        if (m == g.M && (g.M & 1) && m < g.ldcbt) g.CbT[n * g.ldcbt + m] = 0;
+                    }
+                    continue;
+                }
                 float v = g.alpha * acc[i][j][r] + bv;
                 if (g.act == 1) v = v > 0.f ? v : 0.f;
                 else if (g.act == 2) v = v > 0.f ? v : 0.01f * v;
@@ -339,10 +350,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
                     if (g.mask_mode == 1) v = mv > 0.f ? v : 0.f;
                     else v = mv > 0.f ? v : 0.01f * v;
                 }
-                float* c = g.C + m * g.ldc + n;
-                if (g.out_mode == 0) *c = v;
-                else if (g.out_mode == 1) *c += v;
-                else atomicAdd(c, v);
+                if (g.C) {
+                    float* c = g.C + m * g.ldc + n;
+                    if (g.out_mode == 0) *c = v;
+                    else if (g.out_mode == 1) *c += v;
+                    else atomicAdd(c, v);
+                }
+                // nemo_gemm_f32_b16out: the result as bf16 and as its bf16 transpose (fp32 arithmetic; the first layer of a
+                // bf16-in-memory chain, whose own operands stay fp32)
+                if (g.Cb || g.CbT) {
+                    const unsigned short bits = __builtin_bit_cast(unsigned short, (__bf16)v);
+                    if (g.Cb) g.Cb[m * g.ldcb + n] = bits;
+                    if (g.CbT) {
+                        // the lane's registers r = 4 q .. 4 q + 3 are four CONSECUTIVE rows m: one 8-byte store per group
+                        tq[r & 3] = bits;
+                        if ((r & 3) == 3) {
+                            uint2 pk;
+                            pk.x = (unsigned)tq[0] | ((unsigned)tq[1] << 16);
+                            pk.y = (unsigned)tq[2] | ((unsigned)tq[3] << 16);
+                            *reinterpret_cast<uint2*>(g.CbT + n * g.ldcbt + (m - 3)) = pk;
+                        }
+                    }
+                }
             }
         }
 }
@@ -543,7 +572,11 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
                          int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream,
                          unsigned short* Cb = nullptr, long ldcb = 0, unsigned short* CbT = nullptr, long ldcbt = 0,
                          const unsigned short* mask16 = nullptr, long ldmask16 = 0, float* colsum = nullptr, long ldcs = 0) {
-    if (M < 0 || N < 0 || K < 0 || (!C && !(bf16 == 2 && (Cb || CbT) && out_mode == 0))) return NEMO_EINVAL;
+    // bf16 == 0 with Cb / CbT (nemo_gemm_f32_b16out): fp32 product whose result is (also) stored as bf16 -- register-staged
+    // kernel only (its epilogue writes the copies; the operands of that call are the unaligned ones anyway)
+    const bool b16out = bf16 == 0 && (Cb || CbT);
+    if (M < 0 || N < 0 || K < 0 || (!C && !((bf16 == 2 || b16out) && (Cb || CbT) && out_mode == 0))) return NEMO_EINVAL;
+    if (b16out && (out_mode != 0 || (Cb && ldcb < N) || (CbT && (ldcbt < M || (ldcbt & 3) || (((uintptr_t)CbT) & 7))))) return NEMO_EINVAL;
     if (colsum && (bf16 != 2 || out_mode == 2 || ldcs < N)) return NEMO_EINVAL;
     if (M == 0 || N == 0) return NEMO_OK;
     if (K > 0 && (!A || !B)) return NEMO_EINVAL;
@@ -569,7 +602,7 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     //  four ds_read_b32 per operand group instead of one ds_read_b128 and runs at ~half the rate there)
     static const bool use_glds = [] { const char* f = getenv("NEMO_GEMM_GLDS"); return !(f && atoi(f) == 0); }();
     unsigned a_bytes = 0, b_bytes = 0;
-    const bool glds_ok = vec && use_glds && force_tile != 128 &&
+    const bool glds_ok = vec && use_glds && force_tile != 128 && !b16out &&
                          glds::extents(transA, transB, M, N, K, lda, ldb, &a_bytes, &b_bytes);
     Plan pl = plan_gemm(M, N, K, can_split, ws_bytes, out_mode == 2, split_k,
                         vec && !transA && transB && !(bf16 && glds_ok), vec, glds_ok);
@@ -617,7 +650,7 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     // and ~2x on the small layers (profiles/r02_gemm_skinny.md).  Very long K (the blend-shape adjoint) stays with the
     // LDS-staged kernel: a wave's K slice would be thousands of steps.
     static const bool use_skinny = [] { const char* f = getenv("NEMO_GEMM_SKINNY"); return !(f && atoi(f) == 0); }();
-    const int sk_kind = use_skinny && !bf16 && split_k == 0 && force_tile == 0 && K >= 1
+    const int sk_kind = use_skinny && !bf16 && !b16out && split_k == 0 && force_tile == 0 && K >= 1
                             ? skinny_kind(!transA, transB != 0, (va || transA) && (vb || !transB),
                                           can_split && out_mode != 2 && ws_bytes >= COUNTER_BYTES + (8L << 20), M, N, K) : -1;
     if (sk_kind >= 0 && (glds_ok || glds::extents(transA, transB, M, N, K, lda, ldb, &a_bytes, &b_bytes))) {
@@ -789,6 +822,18 @@ extern "C" int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint
                      ldb / 2, C, ldc, bias, act, m16 ? nullptr : mask, ldmask, m16 ? mask_mode - 16 : mask_mode, alpha, out_mode,
                      0, ws, ws_bytes, stream, Cb, ldcb, CbT, ldcbt,
                      m16 ? reinterpret_cast<const unsigned short*>(mask) : nullptr, ldmask, colsum, ldcs);
+}
+
+// nemo_gemm_f32 whose result is stored as bf16 (Cb) and / or as its bf16 transpose (CbT) instead of / beside C: fp32
+// operands and arithmetic -- the first layer of the bf16-in-memory MLP chain (K = 105: fp32 by design), which then needs no
+// cast launches behind it.  out_mode 0 only; C may be NULL.
+extern "C" int32_t nemo_gemm_f32_b16out(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K, const float* A,
+                                        int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                                        int32_t act, uint16_t* Cb, int64_t ldcb, uint16_t* CbT, int64_t ldcbt, void* ws,
+                                        int64_t ws_bytes, void* stream) {
+    if (!Cb && !CbT) return NEMO_EINVAL;
+    return gemm_impl(0, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, nullptr, 0, 0, 1.f, 0, 0, ws, ws_bytes,
+                     stream, Cb, ldcb, CbT, ldcbt);
 }
 
 // rows of the `colsum` scratch nemo_gemm_bf16mem fills for an M-row result: one per 32-row band of its 64 x 64 tiles

@@ -402,7 +402,7 @@ class FitEngine:
                 w[k + 'b'], w[k + 'bT'] = Zb(N + 1, hp), Zb(h, rp)
             # per-band column sums of the two hidden activation gradients (nemo_gemm_bf16mem(colsum)): their bias gradients
             R = int(self.lib.nemo_gemm_colsum_rows(N + 1))
-            w['cs4'], w['cs2'] = Z(R, h), Z(R, h)
+            w['cs4'], w['cs2'], w['cs0'] = Z(R, h), Z(R, h), Z(R, h)
         if self.version == 0:            # hidden activations of the orient and translation networks (poses: H1..H3)
             w.update(O1=Z(N + 1, h), O2=Z(N + 1, h), O3=Z(N + 1, h), T1=Z(N + 1, h), T2=Z(N + 1, h))
         # scratch of nemo_v2v_fused (arrival tickets, zero at allocation and returned to zero by the kernel, +
@@ -539,12 +539,14 @@ class FitEngine:
         T = lambda k: w[k] if train else None
         # the first layer (K = 105 RBF features + code, rows of nn.Linear(105, h) not 16-byte aligned) stays where it was:
         # fp32 arithmetic (its operands never qualified for the bf16 path; 2 % of the MLP's FLOPs)
-        self._linear(r, dptr(w['X']), self.ldx, self.din, self.p(lm + 'net.net.0.weight'),
-                     self.p(lm + 'net.net.0.bias'), h, dptr(w['H1']), h, act=1)
+        # ... and leaves its output as bf16 straight from the epilogue (nemo_gemm_f32_b16out): H1 is only ever read as the
+        # bf16 operand of the next layer, of the layer-2 parameter gradient and as a ReLU mask
+        ws = self.gemm_ws[1 if main == self.side_stream else (2 if main == self.side_stream2 else 0)]
+        check(self.lib.nemo_gemm_f32_b16out(0, 1, r, h, self.din, dptr(w['X']), self.ldx, self.p(lm + 'net.net.0.weight'),
+                                            self.din, None, 0, self.p(lm + 'net.net.0.bias'), 1, w['H1b'].data_ptr(),
+                                            w['H1b'].stride(0), dptr(T('H1bT')), w['H1bT'].stride(0), ws.data_ptr(),
+                                            ws.numel() * 4, _stream()), 'nemo_gemm_f32_b16out')
         main.wait_event(casts_done)
-        self._cast(r, h, dptr(w['H1']), h, w['H1b'], 0)
-        if train:
-            self._cast(r, h, dptr(w['H1']), h, w['H1bT'], 1)
         # (hidden activations exist as bf16 copies only: the ReLU masks of the backward read them -- sign and zero survive
         #  the rounding --, nothing else needs the fp32 values)
         self.gemm16(r, h, h, w['H1b'], wb['2'], None, h, bias=self.p(lm + 'net.net.2.bias'), act=1,
@@ -583,10 +585,10 @@ class FitEngine:
         self.gemm16(h, h, r, w['dH_bbT'], w['H1bT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1)
         cs.append((dptr(w['cs2']), R, h, h, self.g(lm + 'net.net.2.bias')))
         self.gemm16(r, h, h, w['dH_bb'], wb['2T'], dptr(w['dH_c']), h, mask=dptr(w['H1b']), ldmask=w['H1b'].stride(0),
-                    mask_mode=17, Cb=None, CbT=None)
+                    mask_mode=17, Cb=None, CbT=None, colsum=w['cs0'])
         # layer 0: as before (see _forward_nets_b16)
-        self._linear_bwd_params(r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h, self.g(lm + 'net.net.0.weight'),
-                                self.g(lm + 'net.net.0.bias'))
+        self._linear_bwd_params(r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h, self.g(lm + 'net.net.0.weight'), None)
+        cs.append((dptr(w['cs0']), R, h, h, self.g(lm + 'net.net.0.bias')))
         self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din, dptr(w['dX']), self.ldx,
                   dense=True)
         self.flush_colsums()

@@ -252,3 +252,30 @@ def test_gemm_with_bf16_operands_in_memory(L, M, N, K):
                               None, 0, None, 0, None, 0, dptr(ws), ws.numel() * 4, H.st()), 'gemm_bf16mem')
     assert rel_err(C2, C0.double() + rnd(A).double() @ rnd(Bt).double()) < 2e-5
     assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize('M,N,K', [(301, 1000, 105), (2401, 1000, 105), (130, 70, 33), (77, 200, 64)])
+def test_fp32_product_with_bf16_output_copies(L, M, N, K):
+    """nemo_gemm_f32_b16out: the first MotionNet layer of the bf16-in-memory chain -- fp32 operands (rows of 105 floats),
+    fp32 arithmetic, the result stored as bf16 and as its bf16 transpose straight from the epilogue (and in fp32 when asked)."""
+    import hipops as H
+    from nemo_cvpr2023_amd._lib import check, dptr
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B, bias = torch.randn(M, K, generator=g).to(DEV), torch.randn(N, K, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    ws = H.gemm_ws()
+    Mp, Np = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    for with_c in (True, False):
+        C = torch.zeros(M, N, device=DEV)
+        Cb = torch.zeros(M, Np, dtype=torch.int16, device=DEV)
+        CbT = torch.zeros(N, Mp, dtype=torch.int16, device=DEV)
+        check(L.nemo_gemm_f32_b16out(0, 1, M, N, K, dptr(A), K, dptr(B), K, dptr(C) if with_c else None, N, dptr(bias), 1,
+                                     dptr(Cb), Np, dptr(CbT), Mp, dptr(ws), ws.numel() * 4, H.st()), 'gemm_f32_b16out')
+        ref = torch.relu(A.double() @ B.double().T + bias.double())
+        if with_c:
+            assert rel_err(C, ref) < 2e-5
+            assert torch.equal(Cb[:, :N].view(torch.bfloat16), C.to(torch.bfloat16))
+        assert rel_err(Cb[:, :N].view(torch.bfloat16).double(), ref) < 5e-3
+        assert torch.equal(CbT[:, :M].view(torch.bfloat16), Cb[:, :N].view(torch.bfloat16).T.contiguous())
+        assert int(CbT[:, M:].abs().sum()) == 0 and int(Cb[:, N:].abs().sum()) == 0
+    assert L.nemo_gemm_f32_b16out(0, 1, M, N, K, dptr(A), K, dptr(B), K, None, 0, None, 0, None, 0, None, 0, dptr(ws),
+                                  ws.numel() * 4, H.st()) != 0                   # neither copy asked for
