@@ -431,15 +431,15 @@ def main():
             traffic = json.load(open(TRAFFIC_FILE)).get(f'{V}x{T}x{world}x{opts.dtype}', {})
         ktr = traffic.get('kernels', {}).get(tag)
         # the whole step, same pricing: which parts of step_flops() the bf16 build moves to the bf16 pipe
-        mesh_blend = parts['mesh'] * (2 * 3 * 207) / (2 * 3 * 207 + 2 * 288 + 288)
-        on_bf16 = (mesh_blend + parts['blend_adjoint'] + parts['mlp'] + parts['vposer']) if opts.dtype == 'bf16' else 0.0
+        mesh_b16 = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh']).get('bf16', 0.0)
+        on_bf16 = (mesh_b16 + parts['blend_adjoint'] + parts['mlp'] + parts['vposer']) if opts.dtype == 'bf16' else 0.0
         step_peak = f_step / (on_bf16 / MFMA_PEAK_TFLOPS['bf16'] + (f_step - on_bf16) / MFMA_PEAK_TFLOPS['f32'])
         roof = {'kernel': tag, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(kpeak, 1),
                 'unit': 'TFLOP/s', 'frac': round(achieved / kpeak, 4),
                 'pipes': {d: round(f / 1e9, 2) for d, f in pipes.items()},
                 'peak_note': 'fp32 MFMA peak' if len(pipes) == 1 and 'f32' in pipes else
                              'harmonic mix of the bf16 (2500) and fp32 (157.3) MFMA peaks over this kernel\'s GFLOP per pipe '
-                             '(`pipes`); the fp32 skinning / adjoint part bounds it',
+                             '(`pipes`); the fp32 skinning part bounds it',
                 'traffic': ktr, 'traffic_source': traffic.get('source') if ktr else None,
                 'launches': n, 'mean_launch_ms': round(mean_ms, 4), 'flops_per_launch': flops,
                 'timed_in': f'{n_inst} instrumented (un-captured) steps after the timed region',

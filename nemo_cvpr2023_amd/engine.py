@@ -452,13 +452,17 @@ class FitEngine:
     def kernel_flops_by_pipe(self, tag, flops):
         """Split a tagged (bench-timed) kernel's algorithmic FLOPs by the matrix pipe they run on, so that bench.py can
         price each part against its own peak.  fp32 build: everything on the fp32 MFMA pipe.  gemm_dtype='bf16': the
-        tagged GEMMs run on the bf16 pipe; of the fused mesh kernel only the two pose blends do (2 x 3 x 207 of its
-        2 x 3 x 207 + 2 x 288 + 288 multiply-adds per vertex and sample) -- skinning, L1 and both adjoints stay fp32."""
+        tagged GEMMs run on the bf16 pipe; of the fused mesh kernel the two pose blends and the vertex->joint adjoint do
+        (2 x 3 x 207 + 288 of its 2 x 3 x 207 + 2 x 288 + 288 multiply-adds per vertex and sample) -- skinning and L1 stay
+        fp32."""
         if not self.bf16:
             return {'f32': flops}
         if tag == 'mesh_v2v_fused':
-            blend = flops * (2 * 3 * 207) / (2 * 3 * 207 + 2 * 288 + 288)
-            return {'bf16': blend, 'f32': flops - blend}
+            # (csrc/smpl.hip MODE 3, the default: the vertex->joint adjoint -- 288 of the multiply-adds -- runs on the bf16
+            #  pipe too, as four bf16 piece products per algorithmic product; NEMO_MESH_SPLIT=0: blend only)
+            on16 = 2 * 3 * 207 + (288 if os.environ.get('NEMO_MESH_SPLIT', '1') != '0' else 0)
+            b16 = flops * on16 / (2 * 3 * 207 + 2 * 288 + 288)
+            return {'bf16': b16, 'f32': flops - b16}
         return {'bf16': flops}
 
     # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
