@@ -100,6 +100,7 @@ txt = (f"# Round 3 (commit {head}) -- bench.py lines of every BASELINE configura
        + bench_row('C2 sizes, bf16 dense contractions', 'bench_c2_bf16.json', 'python3 bench.py --dtype bf16 --steps 30 --warmup 5') + '\n'
        + bench_row('C3: 40 x 300, fp32', 'bench_c3_f32.json', 'python3 bench.py --instances 40 --steps 20 --warmup 3') + '\n'
        + bench_row('C3: 40 x 300, bf16 (BASELINE configs[2])', 'bench_c3_bf16.json', 'python3 bench.py --instances 40 --dtype bf16 --steps 20 --warmup 3') + '\n'
+       + (bench_row('C3 bf16 with NEMO_MESH_SPLIT=0 (mesh kernel\'s vertex->joint adjoint on the fp32 pipe, same box)', 'bench_c3_bf16_nosplit.json', 'NEMO_MESH_SPLIT=0 python3 bench.py --instances 40 --dtype bf16 --steps 20 --warmup 3') + '\n' if os.path.exists(os.path.join(G, 'bench_c3_bf16_nosplit.json')) else '')
        + (bench_row('C3 bf16 with NEMO_BF16_MEM=0 (round 2\'s on-the-fly rounding, same box)', 'bench_c3_bf16_onthefly.json', 'NEMO_BF16_MEM=0 python3 bench.py --instances 40 --dtype bf16 --steps 20 --warmup 3') + '\n' if os.path.exists(os.path.join(G, 'bench_c3_bf16_onthefly.json')) else '')
        + bench_row('C4: 256 x 1024 on ONE GPU (32 mesh chunks of 8192)', 'bench_c4.json',
                    'python3 bench.py --instances 256 --frames 1024 --steps 5 --warmup 2 --repeat 3 --minibatch-steps 20') + '\n'
