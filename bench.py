@@ -305,11 +305,12 @@ def main():
     # (like a compile step); they are not part of the warm-up / timed protocol below
     shard_modes = None
     if sharded:
-        # auto: one collective per step against the early loss all-reduce; the three-bucket layout only where a rank's step is
-        # long enough for it to matter (it costs two more launches per step and is host-bound below ~1 ms per step:
-        # profiles/r03_bench_lines.md) -- e.g. BASELINE configs[3], 256 x 1024 over 8 GPUs = 32 768 samples per rank
-        modes = (['single', 'split'] + (['buckets'] if V * T // max(world, 1) >= 4096 else [])) if opts.shard_mode == 'auto' \
-            else [opts.shard_mode]
+        # auto: one collective per step against the early loss all-reduce against three gradient buckets behind the backward.
+        # With RCCL every mode is ONE captured launch per step (collectives inside the graph); where they are not capturable
+        # (gloo) the three-bucket layout costs two more launches per step and is only tried for long per-rank steps
+        in_graph = getattr(model, 'capturable', False) and os.environ.get('NEMO_GRAPH_COMM', '1') != '0'
+        modes = (['single', 'split'] + (['buckets'] if in_graph or V * T // max(world, 1) >= 4096 else [])) \
+            if opts.shard_mode == 'auto' else [opts.shard_mode]
         shard_modes = {}
         for mode in modes:
             model.set_shard_mode(mode)
@@ -513,6 +514,7 @@ def main():
             out.update(shard_info)
         print(json.dumps(out))
     if sharded:
+        model.close()                  # captured graphs hold RCCL launches: released before the communicator
         dist.destroy_process_group()
 
 

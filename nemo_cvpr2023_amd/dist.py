@@ -141,9 +141,27 @@ class ShardedNemo:
         self._span = (a, b)
         self.args, self.optimizers = args, self.model.optimizers
         # measurement aid (bench.py): False = every collective is skipped, the step is what ONE rank computes
+        import atexit, weakref
+        ref = weakref.ref(self)
+        atexit.register(lambda: ref() is not None and ref().close())      # (before torch tears the communicator down)
         self.collectives = True
+        # RCCL all-reduces can be captured into the step's HIP graph (one launch per sharded step); gloo's cannot
+        self.capturable = dist.get_backend(group) == 'nccl'
         self.shard_mode = 'single'
         self.set_shard_mode('split' if os.environ.get('NEMO_SHARD_SPLIT', '0') == '1' else 'single')
+
+    def close(self):
+        """Release every captured HIP graph of the model.  Sharded steps capture their RCCL all-reduces into the step's
+        graph; those graphs must go BEFORE ``dist.destroy_process_group()`` tears the communicator down."""
+        try:
+            if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize()
+            for w in self.model.engine.ws.values():
+                w['graphs'].clear()
+        except Exception:                  # (interpreter shutdown: best effort)
+            pass
+        # (deliberately no __del__: a finaliser that synchronises the device can fire from the garbage collector in the
+        #  middle of another model's graph capture and invalidate it)
 
     def set_shard_mode(self, mode):
         """'single': one all-reduce per step (gradient + loss scalars).  'split': + an early 32-byte all-reduce
@@ -167,7 +185,8 @@ class ShardedNemo:
     def _info(self, d, pad=0):
         return ShardInfo(kr=d['kr'], mr=d['mr'], vr=d['vr'], n_global=d['n_global'], comm=self._comm,
                          comm_small=self._comm_small if self.shard_mode == 'split' else None,
-                         comm_bucket=self._comm_small if self.shard_mode == 'buckets' else None, pad=pad)
+                         comm_bucket=self._comm_small if self.shard_mode == 'buckets' else None, pad=pad,
+                         capturable=self.capturable)
 
     def _sharder(self):
         """Draw the GLOBAL (view, frame) batch from the CPU RNG (identical on every rank) and keep

@@ -1154,8 +1154,10 @@ class FitEngine:
                                        self._seg_dev.data_ptr() if n_seg else None, n_seg, 0.9, 0.999, _stream()),
               'nemo_step_begin')
 
-    def adam_from_table(self, n, max_numel):
-        check(self.lib.nemo_adam_step_dev(n, self._seg_dev.data_ptr(), max_numel, self.params.data_ptr(),
+    def adam_from_table(self, n, max_numel, start=0):
+        """Fused Adam over segments [start, start + n) of the device-resident table."""
+        check(self.lib.nemo_adam_step_dev(n, self._seg_dev.data_ptr() + start * ctypes.sizeof(AdamSeg), max_numel,
+                                          self.params.data_ptr(),
                                           self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                           self.exp_avg_sq.data_ptr(), 0.9, 0.999, 1e-8, _stream()),
               'nemo_adam_step_dev')

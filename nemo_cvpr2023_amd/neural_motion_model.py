@@ -19,6 +19,7 @@ Deliberate deviations from the reference (documented in DESIGN.md):
 """
 from __future__ import annotations
 
+import gc
 import os
 import warnings
 from collections import OrderedDict, defaultdict
@@ -63,8 +64,11 @@ class ShardInfo:
     V_local / V_global the instance-code regulariser.  ``comm(engine)`` all-reduces the shared
     gradients together with the loss scalars.  The single-process default is the identity."""
 
-    def __init__(self, kr=1.0, mr=1.0, vr=1.0, n_global=None, comm=None, comm_small=None, comm_bucket=None, pad=0):
+    def __init__(self, kr=1.0, mr=1.0, vr=1.0, n_global=None, comm=None, comm_small=None, comm_bucket=None, pad=0,
+                 capturable=False):
         self.kr, self.mr, self.vr, self.n_global, self.comm = kr, mr, vr, n_global, comm
+        # the collectives may be captured into a HIP graph (RCCL; not gloo, whose device collectives go through the host)
+        self.capturable = bool(capturable)
         self.comm_small = comm_small          # all-reduce of a small device tensor (the loss scalars)
         # all-reduce of ONE gradient bucket (a contiguous slice of the flat gradient buffer): when set, update steps
         # reduce the shared gradient in three buckets, each as soon as the backward has completed it (dist.py 'buckets')
@@ -250,6 +254,7 @@ class MultiViewModel(nn.Module):
         # capture each (batch size, mode) variant of the step as a HIP graph after one eager run
         self.use_graphs = os.environ.get('NEMO_GRAPHS', '1') != '0'
         self.GRAPH_AFTER = 1             # eager runs of a (batch size, mode) variant before it is captured
+        self.graph_comm = os.environ.get('NEMO_GRAPH_COMM', '1') != '0'    # sharded steps: collectives inside the graph
         self.launch_stats = {'replayed': 0, 'other': 0}     # launches that replayed an existing graph / ran eagerly or captured
         self._build_parameters()
         self._init_parameters()
@@ -715,14 +720,64 @@ class MultiViewModel(nn.Module):
             vi = torch.nn.functional.pad(vi, (0, N - Nv))         # (view 0, frame 0): valid memory, masked out
             fi = torch.nn.functional.pad(fi, (0, N - Nv))
             sh = ShardInfo(kr=sh.kr, mr=N / float(sh.n_global), vr=sh.vr, n_global=sh.n_global, comm=sh.comm,
-                           comm_small=sh.comm_small, comm_bucket=sh.comm_bucket, pad=sh.pad)
+                           comm_small=sh.comm_small, comm_bucket=sh.comm_bucket, pad=sh.pad, capturable=sh.capturable)
         w = e._ws(max(N, 1))
         e.scal = w['scal']               # (a replayed graph wrote this workspace's slots)
         e.sync_betas()                   # host-side state a captured graph cannot re-read (checkpoint load, eval)
         has_inst = bool(self.VERSION >= 3 and getattr(a, 'weight_instance_loss', 0) and e.C > 0)
 
-        def body(vi_, fi_, adam_table, part='all'):
+        def body(vi_, fi_, adam_table, part='all', run_adam=True):
             """Everything of the step (or of one half of it) that runs on the device without host interaction."""
+            if part == 'bucketc':
+                # 'buckets' mode as ONE launch: the three gradient buckets are all-reduced on the communication stream as
+                # soon as the backward has completed them, each with its share of the fused Adam (device table, segments
+                # grouped by bucket) right behind its collective; the main stream goes on with the backward meanwhile
+                main, cs = torch.cuda.current_stream(), e.comm_stream
+                bk = e.layout.buckets()
+                slot = e.view('_comm_scalars', e.grads)
+                for i, kpart in enumerate(('k0', 'k1', 'k2')):
+                    body(vi_, fi_, adam_table if i == 0 else None, kpart, run_adam=False)
+                    cs.wait_event(main.record_event())
+                    with torch.cuda.stream(cs):
+                        if i == 2:
+                            torch.mul(e.scal, self._shard_weights(sh), out=slot)
+                        sh.comm_bucket(e.grads[bk[i][0]:bk[i][1]])
+                        if i == 2:
+                            e.publish_scalars(slot)
+                        st_, n_, mx_ = bgroups[i]
+                        if n_:
+                            e.adam_from_table(n_, mx_, st_)
+                st_, n_, mx_ = bgroups[3]                      # this rank's private parameters, on the main stream
+                if n_:
+                    e.adam_from_table(n_, mx_, st_)
+                main.wait_stream(cs)
+                return
+            if part in ('allc', 'splitc'):
+                # Sharded update step with its collectives INSIDE the launch (one captured graph per step: RCCL all-reduces
+                # are capturable, tools/debug/graph_capture_rccl.py): body -> weighted loss scalars -> all-reduce(s) ->
+                # hand-over to the host -> Adam.  'splitc': the 32-byte all-reduce of the loss scalars and their hand-over
+                # fork to the side stream after the first half, as in ShardedNemo's 'split' mode.
+                main = torch.cuda.current_stream()
+                if part == 'splitc':
+                    body(vi_, fi_, adam_table, 'head', run_adam=False)
+                    self._reduce_scalars_on_side_stream(sh)
+                    if N > 0:
+                        body(vi_, fi_, None, 'tail', run_adam=False)
+                    sh.comm(e, update)
+                else:
+                    body(vi_, fi_, adam_table, 'all', run_adam=False)
+                    slot = e.view('_comm_scalars', e.grads)
+                    torch.mul(e.scal, self._shard_weights(sh), out=slot)
+                    sh.comm(e, update)
+                    e.publish_scalars(slot)
+                if adam_table is not None:
+                    e.adam_from_table(*adam_table)
+                else:
+                    e.adam(segs)
+                if part == 'splitc':
+                    main.wait_stream(e.side_stream)
+                return
+
             def inst_term():                                                              # :3864-3867
                 n_code = e.V * e.C
                 check(e.lib.nemo_sqmean_fwd_bwd(n_code, e.p('learned_instance_code'), e.scal.data_ptr() + 4 * S_INST,
@@ -740,7 +795,7 @@ class MultiViewModel(nn.Module):
                     e.grads.zero_()
                 if has_inst:
                     inst_term()
-            if adam_table is not None:
+            if adam_table is not None and run_adam:
                 e.adam_from_table(*adam_table)
 
         # single-GPU steps hand the losses to the host as soon as they are final (engine.publish_scalars)
@@ -760,9 +815,29 @@ class MultiViewModel(nn.Module):
             segs = []
             for o in self.optimizers:
                 segs += o.segments(None)
-        # the fused Adam runs inside the captured graph unless a gradient all-reduce must come first
-        in_graph_adam = update and sh.comm is None
-        if early or split or (bucketed and e.early_readback):
+        # Sharded update steps as ONE launch: collectives, hand-over and Adam inside the captured graph (NEMO_GRAPH_COMM=0:
+        # the round-2 structure -- graph, then eager all-reduce / hand-over / Adam)
+        cap_ok = bool(self.graph_comm and sh.capturable and graphable and update and sh.comm is not None
+                      and e.early_readback and self.VERSION >= 1)
+        comm_in_graph = cap_ok and not bucketed
+        bucket_in_graph = cap_ok and bucketed
+        bgroups = None
+        if bucket_in_graph:
+            # the device Adam table grouped by bucket: [bucket 0 | bucket 1 | bucket 2 | private], (start, count, max numel)
+            bk = e.layout.buckets()
+            lo_, hi_ = bk[2][0], bk[0][1]
+            groups = [clip_segments(segs, *bk[i]) for i in range(3)]
+            groups.append(clip_segments(segs, 0, lo_) + clip_segments(segs, hi_, e.layout.total))
+            bgroups, at = [], 0
+            for g_ in groups:
+                bgroups.append((at, len(g_), max([s_['numel'] for s_ in g_], default=0)))
+                at += len(g_)
+            segs = [s_ for g_ in groups for s_ in g_]
+            if len(segs) > _lib.ADAM_MAX_SEG:
+                bucket_in_graph, bgroups = False, None
+        # the fused Adam runs inside the captured graph unless a gradient all-reduce must come first (and stays outside)
+        in_graph_adam = update and (sh.comm is None or comm_in_graph or bucket_in_graph)
+        if early or split or comm_in_graph or (bucketed and e.early_readback):
             e.arm_scalars()
 
         def run(part):
@@ -777,7 +852,7 @@ class MultiViewModel(nn.Module):
                    e.detach_articulation, e.start_global_traj_anywhere, has_inst, self._weights_key(),
                    tuple((s_['offset'], s_['numel']) for s_ in segs) if in_graph_adam else None)
             cap = w['cap']
-            if part in ('all', 'head', 'k0'):          # the first launch of a step stages its inputs
+            if part in ('all', 'head', 'k0', 'allc', 'splitc', 'bucketc'):          # the first launch of a step stages its inputs
                 src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N)
                 if w.get('_static_src') != src or vi is not w.get('_static_vi'):   # (full batch: cached, unchanged)
                     if vi.device.type == 'cpu' and fi.device.type == 'cpu':
@@ -832,6 +907,11 @@ class MultiViewModel(nn.Module):
                 if not isinstance(entry, torch.cuda.CUDAGraph):   # capture the ~70-launch step as one HIP graph
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
+                    # The cyclic garbage collector stays off while the capture is open (torch.cuda.graph collects once
+                    # BEFORE it begins): a finaliser that touches the device -- a stale graph, a communicator kept alive by
+                    # one -- firing between two captured launches aborts the process.
+                    gc_on = gc.isenabled()
+                    gc.disable()
                     try:
                         with torch.cuda.graph(g):
                             body(svi, sfi, table, part)
@@ -845,14 +925,23 @@ class MultiViewModel(nn.Module):
                         body(svi, sfi, table, part)
                     else:
                         w['graphs'][key] = entry = g
+                    finally:
+                        if gc_on:
+                            gc.enable()
                 if entry != 'eager':
                     entry.replay()
 
         need_adam = update and not (graphable and in_graph_adam)
         e.nvalid = w['vi_static'][w['cap']:].data_ptr() if padded else None
         try:
-            if bucketed:
+            if bucket_in_graph:
+                run('bucketc')
+                s = e.wait_scalars()
+            elif bucketed:
                 s = self._bucketed_update(sh, segs, run, N, has_inst)
+            elif comm_in_graph:
+                run('splitc' if split else 'allc')
+                s = e.wait_scalars()
             elif split:
                 run('head')
                 self._reduce_scalars_on_side_stream(sh)         # weights -> small all-reduce -> publish

@@ -85,6 +85,8 @@ def _rccl_world1(mode, q):
         out.append({k: float(v) for k, v in ld.items()})
     graphs = [v for w in m.model.engine.ws.values() for v in w['graphs'].values()]
     q['res'] = (out, sum(isinstance(x, torch.cuda.CUDAGraph) for x in graphs))
+    del graphs
+    m.close()
     dist.destroy_process_group()
 
 
