@@ -110,18 +110,23 @@ txt = (f"# Round 3 (commit {head}) -- bench.py lines of every BASELINE configura
        + "\n(all but the first with `--no-cpu-baseline --no-torch-gpu-baseline`.  `--dtype bf16`: each part of a kernel is priced against the "
          "pipe it runs on -- the quoted peak is the harmonic mix of the bf16 (2500) and fp32 (157.3) MFMA peaks over the kernel's own GFLOP per "
          "pipe; the fused mesh kernel keeps its skinning / L1 / adjoints on the fp32 pipe, which bounds it.)\n\n"
-         "## the sharded code path in a process group of ONE rank (`NEMO_BENCH_SHARD_OF_ONE=1`: ShardedNemo, RCCL communicator of world size 1, "
-         "the collectives on their streams, Adam behind them) -- what the sharded launch structure costs by itself\n\n"
-         "| instances | it/s | ms/step | modes timed by `--shard-mode auto` (ms/step) | kept | compute_ms (collectives skipped) | collective_ms (9 MB all-reduce alone, world of one) |\n"
-         "|---:|---:|---:|---|---|---:|---:|\n")
+         "## the sharded code path in a process group of ONE rank (`NEMO_BENCH_SHARD_OF_ONE=1`: ShardedNemo, RCCL communicator of world size 1) "
+         "-- what the sharded launch structure costs by itself.  Since the last third of round 3 a sharded step is ONE captured launch: the "
+         "RCCL all-reduce(s), the loss hand-over and the fused Adam sit inside the step's HIP graph; `NEMO_GRAPH_COMM=0` = the earlier "
+         "structure (graph, then eager all-reduce / hand-over / Adam), same box\n\n"
+         "| instances | structure | it/s | ms/step | modes timed by `--shard-mode auto` (ms/step) | kept | compute_ms (collectives skipped) | collective_ms (9 MB all-reduce alone, world of one) |\n"
+         "|---:|---|---:|---:|---|---|---:|---:|\n")
 for v in (1, 2, 4):
-    d = line(f'bench_group1_v{v}.json')
-    pr = d['per_rank'][0]
-    txt += (f"| {v} | {d['value']} | {d['ms_per_step']} | {json.dumps(d['shard_modes_ms'])} | {d['shard_mode']} | {pr['compute_ms']} | "
-            f"{pr['collective_ms']} |\n")
-txt += ("\n`buckets` (three gradient buckets, three launches per step) loses on one GPU at these sizes: the step becomes HOST-bound (three graph "
-        "replays + three collectives + four Adam launches per 0.5 ms step).  It is meant for steps of milliseconds per rank (BASELINE "
-        "configs[3]: 256 x 1024 over 8 GPUs = 32 768 samples per rank); `--shard-mode auto` decides on the machine it runs on.\n\n"
+    for fn, lab in ((f'bench_group1_v{v}.json', 'collectives in the graph'), (f'bench_group1_eager_v{v}.json', 'NEMO_GRAPH_COMM=0')):
+        if not os.path.exists(os.path.join(G, fn)):
+            continue
+        d = line(fn)
+        pr = d['per_rank'][0]
+        txt += (f"| {v} | {lab} | {d['value']} | {d['ms_per_step']} | {json.dumps(d['shard_modes_ms'])} | {d['shard_mode']} | {pr['compute_ms']} | "
+                f"{pr['collective_ms']} |\n")
+txt += ("\n`buckets` (three gradient buckets reduced behind the backward) loses on one GPU at these sizes even as one launch: its backward "
+        "runs the parameter gradients on the critical chain (a bucket must be complete before its collective) and a world of one gains "
+        "nothing from the overlap; `--shard-mode auto` times all three on the machine it runs on and keeps the fastest.\n\n"
         "## the full default line (what the driver records)\n```\n" + json.dumps(full) + "\n```\n"
         f"cpu_baseline: {json.dumps(full['cpu_baseline'])}\n")
 if os.path.exists(os.path.join(G, 'bf16mem_gemm.txt')):
