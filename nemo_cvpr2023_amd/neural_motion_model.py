@@ -913,7 +913,9 @@ class MultiViewModel(nn.Module):
                     gc_on = gc.isenabled()
                     gc.disable()
                     try:
-                        with torch.cuda.graph(g):
+                        # (sharded: the process group's watchdog thread polls events of earlier collectives -- legal next
+                        #  to a capture in 'thread_local' mode, an invalidated capture in the default 'global' mode)
+                        with torch.cuda.graph(g, capture_error_mode='thread_local' if sh.comm is not None else 'global'):
                             body(svi, sfi, table, part)
                     except RuntimeError as ex:
                         # e.g. a capture invalidated by another thread of the process (a collective's
