@@ -420,7 +420,7 @@ def main():
     if best is not None:
         _, tag, mean_ms, flops, n = best
         # Price every part of the kernel against the pipe it runs on: with --dtype bf16 only the pose blend of the fused
-        # mesh kernel is bf16 work, its skinning / L1 / adjoints stay on the fp32 pipe.  The peak quoted is the rate at
+        # mesh kernel is bf16 work, its skinning / L1 stay on the fp32 pipe (the vertex->joint adjoint: bf16 pipe, split precision).  The peak quoted is the rate at
         # which the kernel's own mix of work would run with both pipes at their peaks (harmonic mix; = the fp32 peak
         # for the fp32 build).
         f_step, parts = step_flops(V * T // world if world > 1 else V * T)

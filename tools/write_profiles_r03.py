@@ -109,7 +109,7 @@ txt = (f"# Round 3 (commit {head}) -- bench.py lines of every BASELINE configura
        + bench_row('shard of 2 GPUs: 4 x 300', 'bench_shard_v4.json', 'python3 bench.py --instances 4 --steps 100') + '\n'
        + "\n(all but the first with `--no-cpu-baseline --no-torch-gpu-baseline`.  `--dtype bf16`: each part of a kernel is priced against the "
          "pipe it runs on -- the quoted peak is the harmonic mix of the bf16 (2500) and fp32 (157.3) MFMA peaks over the kernel's own GFLOP per "
-         "pipe; the fused mesh kernel keeps its skinning / L1 / adjoints on the fp32 pipe, which bounds it.)\n\n"
+         "pipe; the fused mesh kernel keeps its skinning / L1 on the fp32 pipe, which bounds it.)\n\n"
          "## the sharded code path in a process group of ONE rank (`NEMO_BENCH_SHARD_OF_ONE=1`: ShardedNemo, RCCL communicator of world size 1) "
          "-- what the sharded launch structure costs by itself.  Since the last third of round 3 a sharded step is ONE captured launch: the "
          "RCCL all-reduce(s), the loss hand-over and the fused Adam sit inside the step's HIP graph; `NEMO_GRAPH_COMM=0` = the earlier "
