@@ -308,8 +308,9 @@ def main():
         # auto: one collective per step against the early loss all-reduce against three gradient buckets behind the backward.
         # With RCCL every mode is ONE captured launch per step (collectives inside the graph); where they are not capturable
         # (gloo) the three-bucket layout costs two more launches per step and is only tried for long per-rank steps
-        in_graph = getattr(model, 'capturable', False) and os.environ.get('NEMO_GRAPH_COMM', '1') != '0'
-        modes = (['single', 'split'] + (['buckets'] if in_graph or V * T // max(world, 1) >= 4096 else [])) \
+        # -- and in any case only for long per-rank steps: in a group of one it needs > 150 us of hidden collective per step to
+        # catch up with `split` (0.67 against 0.52 ms at one instance), more than the whole 9 MB all-reduce takes
+        modes = (['single', 'split'] + (['buckets'] if V * T // max(world, 1) >= 4096 else [])) \
             if opts.shard_mode == 'auto' else [opts.shard_mode]
         shard_modes = {}
         for mode in modes:
