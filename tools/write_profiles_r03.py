@@ -33,7 +33,10 @@ for tag, title, cmd in (
         ('c2', 'headline C2 (8 x 300 full batch, fp32)', f'python3 bench.py --steps 20 --warmup 2 {X} {B}'),
         ('v1', 'one-instance shard (1 x 300: one rank of eight)', f'python3 bench.py --instances 1 --steps 20 --warmup 2 {X} {B}'),
         ('v2', 'two-instance shard (2 x 300: one rank of four)', f'python3 bench.py --instances 2 --steps 20 --warmup 2 {X} {B}'),
-        ('c3b', 'C3 (40 x 300) bf16, operands bf16 in memory', f'python3 bench.py --instances 40 --dtype bf16 --steps 10 --warmup 2 {X} {B}')):
+        ('c3b', 'C3 (40 x 300) bf16, operands bf16 in memory', f'python3 bench.py --instances 40 --dtype bf16 --steps 10 --warmup 2 {X} {B}'),
+        ('g1', 'the SHARDED step (1 x 300) in an RCCL process group of one rank, `split` mode: weighting of the loss scalars, the all-reduces '
+               '(a world of one reduces in place: no kernel), the hand-over and the fused Adam inside the step\'s one graph',
+         f'NEMO_BENCH_SHARD_OF_ONE=1 python3 bench.py --instances 1 --shard-mode split --steps 20 --warmup 2 {X} {B}')):
     if not os.path.exists(os.path.join(G, f'trace_{tag}.log')):
         continue
     d = line(f'trace_{tag}.log')
