@@ -393,6 +393,15 @@ int32_t nemo_adam_step_dev(int32_t n_seg, const nemo_adam_seg* segs_dev, int64_t
  * re-uploads the table when a learning rate, the segment list or the step counts change under it. */
 int32_t nemo_step_begin(void* z0, int64_t bytes0, void* z1, int64_t bytes1, nemo_adam_seg* segs_dev, int32_t n_seg,
                         double beta1, double beta2, void* stream);
+/* nemo_phase_embed_fwd and nemo_step_begin (same arguments, same results) in ONE launch -- the first node of an
+ * update step's graph: the zero-fills touch nothing the phase kernel reads or writes, so they run in further blocks of the
+ * same grid and the step's critical chain is one dependent launch shorter. */
+int32_t nemo_phase_embed_fwd_begin(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
+                                   const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
+                                   const float* shifts, const float* scales, int64_t ldp, const float* log_sigmas,
+                                   const float* codes, const float* code_noise, int32_t kernel_id, float* X, int64_t ldx,
+                                   float* phase_out, float* den_out, void* z0, int64_t bytes0, void* z1, int64_t bytes1,
+                                   nemo_adam_seg* segs_dev, int32_t n_seg, double beta1, double beta2, void* stream);
 
 /* Instance-code regulariser of NemoV3 / V4 (nemo/neural_motion_model.py:3864-3867):
  * scalar_out += mean(x[0..n)^2);  grad (may be NULL) += gscale * x. */

@@ -100,6 +100,8 @@ SIGNATURES = {
     'nemo_adam_step_dev': (i32, [i32, ptr, i64, ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),
     'nemo_sqmean_fwd_bwd': (i32, [i64, ptr, ptr, ptr, f32, ptr]),
     'nemo_step_begin': (i32, [ptr, i64, ptr, i64, ptr, i32, c_double, c_double, ptr]),
+    'nemo_phase_embed_fwd_begin': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
+                                         i32, ptr, i64, ptr, ptr, ptr, i64, ptr, i64, ptr, i32, c_double, c_double, ptr]),
     'nemo_scale_neg_rowsum': (i32, [i64, i64, ptr, i64, ptr, ptr]),
 }
 

@@ -56,14 +56,29 @@ __device__ __forceinline__ float lin01(long i, long n) {
 // One wave per sample.  Lanes stride over the K nodes of the owning phase network (the three passes
 // x, 0, 1 of monotonic_network.py:23-39 share one sweep), wave-reduce, then stride over the D RBF
 // centres / C code entries of the MLP input row.
-__global__ __launch_bounds__(256) void phase_embed_fwd_kernel(
-    long N, long V, long T, int K, int D, int C, const int64_t* __restrict__ view_idx,
-    const int64_t* __restrict__ frame_idx, const float* __restrict__ raw_phase,
-    const float* __restrict__ shifts, const float* __restrict__ scales, long ldp,
-    const float* __restrict__ log_sigmas, const float* __restrict__ codes,
-    const float* __restrict__ code_noise, int kid, float* __restrict__ X, long ldx,
-    float* __restrict__ phase_out, float* __restrict__ den_out) {
-    const long s = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+struct PhaseFwdArgs {
+    long N, V, T;
+    int K, D, C;
+    const int64_t* view_idx; const int64_t* frame_idx; const float* raw_phase;
+    const float* shifts; const float* scales; long ldp;
+    const float* log_sigmas; const float* codes; const float* code_noise;
+    int kid; float* X; long ldx; float* phase_out; float* den_out;
+};
+__device__ __forceinline__ void phase_embed_fwd_body(const PhaseFwdArgs& a, long bid) {
+    const long N = a.N, T = a.T, ldp = a.ldp, ldx = a.ldx;
+    const int K = a.K, D = a.D, C = a.C, kid = a.kid;
+    const int64_t* __restrict__ view_idx = a.view_idx;
+    const int64_t* __restrict__ frame_idx = a.frame_idx;
+    const float* __restrict__ raw_phase = a.raw_phase;
+    const float* __restrict__ shifts = a.shifts;
+    const float* __restrict__ scales = a.scales;
+    const float* __restrict__ log_sigmas = a.log_sigmas;
+    const float* __restrict__ codes = a.codes;
+    const float* __restrict__ code_noise = a.code_noise;
+    float* __restrict__ X = a.X;
+    float* __restrict__ phase_out = a.phase_out;
+    float* __restrict__ den_out = a.den_out;
+    const long s = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (s > N) return;                      // wave-uniform
     float ph = 0.f;
@@ -102,6 +117,32 @@ __global__ __launch_bounds__(256) void phase_embed_fwd_kernel(
             if (code_noise) cv += code_noise[s * C + c];
         }
         xr[off + c] = cv;
+    }
+}
+__global__ __launch_bounds__(256) void phase_embed_fwd_kernel(PhaseFwdArgs a) { phase_embed_fwd_body(a, (long)blockIdx.x); }
+
+// The FIRST launch of a step: phase / RBF / code forward in blocks [0, nb_phase), and in the blocks behind them what
+// nemo_step_begin does (zero-fill of the gradient buffer and of the workspace's accumulator arena -- nothing the phase blocks
+// touch --, the per-update bookkeeping of the device-resident Adam table): one graph node less on the step's critical chain.
+struct StepBeginArgs {
+    float4* z0; long n0; float4* z1; long n1; float* t0; int r0; float* t1; int r1;
+    nemo_adam_seg* segs; int n_seg; double b1, b2;
+};
+__global__ __launch_bounds__(256) void phase_embed_begin_kernel(PhaseFwdArgs a, StepBeginArgs b, int nb_phase) {
+    if ((int)blockIdx.x < nb_phase) { phase_embed_fwd_body(a, (long)blockIdx.x); return; }
+    const long nbz = (long)gridDim.x - nb_phase, bz = (long)blockIdx.x - nb_phase;
+    const long stride = nbz * blockDim.x, i0 = bz * blockDim.x + threadIdx.x;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long i = i0; i < b.n0; i += stride) b.z0[i] = z;
+    for (long i = i0; i < b.n1; i += stride) b.z1[i] = z;
+    if (i0 < b.r0) b.t0[i0] = 0.f;
+    if (i0 < b.r1) b.t1[i0] = 0.f;
+    if (b.segs && bz == 0 && (int)threadIdx.x < b.n_seg) {
+        nemo_adam_seg sg = b.segs[threadIdx.x];
+        sg.step += 1;
+        sg.step_size = (float)((double)sg.lr / (1.0 - pow(b.b1, (double)sg.step)));
+        sg.bias_corr2_sqrt = (float)sqrt(1.0 - pow(b.b2, (double)sg.step));
+        b.segs[threadIdx.x] = sg;
     }
 }
 
@@ -321,20 +362,59 @@ __global__ __launch_bounds__(1024) void neg_rowsum_kernel(long N, int cols, cons
 
 #define GRID1D(n) dim3(nemo_cdiv((n), 256)), dim3(256), 0, (hipStream_t)stream
 
+static int32_t phase_fwd_args(PhaseFwdArgs* a, int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
+                              const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase, const float* shifts,
+                              const float* scales, int64_t ldp, const float* log_sigmas, const float* codes,
+                              const float* code_noise, int32_t kernel_id, float* X, int64_t ldx, float* phase_out,
+                              float* den_out) {
+    if (N < 0 || V <= 0 || K <= 0 || D < 0 || C < 0 || !X || !shifts || !scales) return NEMO_EINVAL;
+    if (N > 0 && (!view_idx || (!frame_idx && !raw_phase))) return NEMO_EINVAL;
+    if ((D > 0 && !log_sigmas) || (C > 0 && !codes) || kernel_id < 0 || kernel_id > 10) return NEMO_EINVAL;
+    if (ldx < (D > 0 ? D : 1) + C || ldp < K) return NEMO_EINVAL;
+    *a = PhaseFwdArgs{(long)N, (long)V, (long)T, (int)K, (int)D, (int)C, view_idx, frame_idx, raw_phase, shifts, scales,
+                      (long)ldp, log_sigmas, codes, code_noise, (int)kernel_id, X, (long)ldx, phase_out, den_out};
+    return NEMO_OK;
+}
+
 extern "C" int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
                                         const int64_t* view_idx, const int64_t* frame_idx,
                                         const float* raw_phase, const float* shifts, const float* scales,
                                         int64_t ldp, const float* log_sigmas, const float* codes,
                                         const float* code_noise, int32_t kernel_id, float* X, int64_t ldx,
                                         float* phase_out, float* den_out, void* stream) {
-    if (N < 0 || V <= 0 || K <= 0 || D < 0 || C < 0 || !X || !shifts || !scales) return NEMO_EINVAL;
-    if (N > 0 && (!view_idx || (!frame_idx && !raw_phase))) return NEMO_EINVAL;
-    if ((D > 0 && !log_sigmas) || (C > 0 && !codes) || kernel_id < 0 || kernel_id > 10) return NEMO_EINVAL;
-    if (ldx < (D > 0 ? D : 1) + C || ldp < K) return NEMO_EINVAL;
-    hipLaunchKernelGGL(phase_embed_fwd_kernel, dim3(nemo_cdiv(N + 1, 4)), dim3(256), 0, (hipStream_t)stream,
-                       (long)N, (long)V, (long)T, (int)K, (int)D, (int)C, view_idx, frame_idx, raw_phase,
-                       shifts, scales, (long)ldp, log_sigmas, codes, code_noise, (int)kernel_id, X, (long)ldx,
-                       phase_out, den_out);
+    PhaseFwdArgs a;
+    const int32_t rc = phase_fwd_args(&a, N, V, T, K, D, C, view_idx, frame_idx, raw_phase, shifts, scales, ldp, log_sigmas,
+                                      codes, code_noise, kernel_id, X, ldx, phase_out, den_out);
+    if (rc) return rc;
+    hipLaunchKernelGGL(phase_embed_fwd_kernel, dim3(nemo_cdiv(N + 1, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+// nemo_phase_embed_fwd + nemo_step_begin (same arguments, same results) as ONE launch: the first node of a step's graph.
+extern "C" int32_t nemo_phase_embed_fwd_begin(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
+                                              const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
+                                              const float* shifts, const float* scales, int64_t ldp,
+                                              const float* log_sigmas, const float* codes, const float* code_noise,
+                                              int32_t kernel_id, float* X, int64_t ldx, float* phase_out, float* den_out,
+                                              void* z0, int64_t bytes0, void* z1, int64_t bytes1, nemo_adam_seg* segs_dev,
+                                              int32_t n_seg, double beta1, double beta2, void* stream) {
+    PhaseFwdArgs a;
+    const int32_t rc = phase_fwd_args(&a, N, V, T, K, D, C, view_idx, frame_idx, raw_phase, shifts, scales, ldp, log_sigmas,
+                                      codes, code_noise, kernel_id, X, ldx, phase_out, den_out);
+    if (rc) return rc;
+    if (bytes0 < 0 || bytes1 < 0 || (bytes0 && !z0) || (bytes1 && !z1) || ((bytes0 | bytes1) & 3) ||
+        (((uintptr_t)z0 | (uintptr_t)z1) & 15) || n_seg < 0 || n_seg > NEMO_ADAM_MAX_SEG)
+        return NEMO_EINVAL;
+    if (!segs_dev) n_seg = 0;
+    const long n0 = bytes0 / 16, n1 = bytes1 / 16;
+    int bz = nemo_cdiv((n0 > n1 ? n0 : n1), 256 * 4);
+    if (bz < 1) bz = 1;
+    if (bz > 1024) bz = 1024;
+    const int nbp = (int)nemo_cdiv(N + 1, 4);
+    StepBeginArgs b{(float4*)z0, n0, (float4*)z1, n1, (float*)z0 + 4 * n0, (int)((bytes0 & 15) / 4), (float*)z1 + 4 * n1,
+                    (int)((bytes1 & 15) / 4), n_seg ? segs_dev : nullptr, (int)n_seg, beta1, beta2};
+    hipLaunchKernelGGL(phase_embed_begin_kernel, dim3(nbp + bz), dim3(256), 0, (hipStream_t)stream, a, b, nbp);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -629,17 +629,26 @@ class FitEngine:
         self._colsums = []
 
     # ------------------------------------------------------------------ forward pieces
-    def forward_pose(self, w, N, view_idx, frame_idx, raw_phase=None, code_noise=None, train=True):
-        """K1-K5: phase warp, RBF, MLP, rot6d->R->aa.  Fills X,H1..H3,ROT,TR,R,AA."""
+    def forward_pose(self, w, N, view_idx, frame_idx, raw_phase=None, code_noise=None, train=True, begin=None):
+        """K1-K5: phase warp, RBF, MLP, rot6d->R->aa.  Fills X,H1..H3,ROT,TR,R,AA.
+        ``begin`` = (arena, zero_grads, n_seg): what ``step_begin`` would be called with -- done by further blocks of the
+        phase kernel's launch instead of a launch of its own (nemo_phase_embed_fwd_begin)."""
         L, st = self.lib, _stream()
         sh0 = self.p('phase_networks.0.shifts')
         sc0 = self.p('phase_networks.0.scales')
-        check(L.nemo_phase_embed_fwd(
-            N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
-            sh0, sc0, self.ldp, self.p('phase_rbf.log_sigmas') if self.D > 0 else None,
-            self.p('learned_instance_code') if self.C > 0 else None, dptr(code_noise), self.kernel_id,
-            dptr(w['X']), self.ldx, dptr(w['phase']), dptr(w['phase_ws']), st),
-              'nemo_phase_embed_fwd')
+        pargs = (N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
+                 sh0, sc0, self.ldp, self.p('phase_rbf.log_sigmas') if self.D > 0 else None,
+                 self.p('learned_instance_code') if self.C > 0 else None, dptr(code_noise), self.kernel_id,
+                 dptr(w['X']), self.ldx, dptr(w['phase']), dptr(w['phase_ws']))
+        if begin is not None:
+            arena, zero_grads, n_seg = begin
+            check(L.nemo_phase_embed_fwd_begin(*pargs, arena.data_ptr(), arena.numel() * 4,
+                                               self.grads.data_ptr() if zero_grads else None,
+                                               self.grads.numel() * 4 if zero_grads else 0,
+                                               self._seg_dev.data_ptr() if n_seg else None, n_seg, 0.9, 0.999, st),
+                  'nemo_phase_embed_fwd_begin')
+        else:
+            check(L.nemo_phase_embed_fwd(*pargs, st), 'nemo_phase_embed_fwd')
         h, r = self.h, N + 1
         if self.version == 0:
             return self._forward_nets_v0(w, N)

@@ -534,8 +534,12 @@ class MultiViewModel(nn.Module):
         if part in ('k1', 'k2'):             # bucketed sharded step: the later stages of the MLP backward (see step())
             return e.backward_mlp(w, N, vi, fi, None, stages=(int(part[1]),), bucketed=True)
         # loss scalars, view accumulators, dAA, dJp, dA2, dPF2, the gradient buffer (and the device Adam table's step)
-        e.step_begin(w['zero_arena'], bool(update), adam_segs)
-        e.forward_pose(w, N, vi, fi, code_noise=self._noise(N), train=bool(update))
+        if os.environ.get('NEMO_FUSED_BEGIN', '1') != '0':        # zero-fills + Adam-table bookkeeping inside the first launch
+            e.forward_pose(w, N, vi, fi, code_noise=self._noise(N), train=bool(update),
+                           begin=(w['zero_arena'], bool(update), adam_segs))
+        else:
+            e.step_begin(w['zero_arena'], bool(update), adam_segs)
+            e.forward_pose(w, N, vi, fi, code_noise=self._noise(N), train=bool(update))
         main = torch.cuda.current_stream()
         side, side2 = e.side_stream, e.side_stream2
         pose_done = main.record_event()

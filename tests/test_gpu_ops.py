@@ -302,6 +302,26 @@ def test_phase_embed_vs_oracle(L, kern):
                                   Xd.data_ptr(), D + C, phd.data_ptr(), den.data_ptr(), H.st()) == 0
     assert rel_err(phd, ph.detach().squeeze(1)) < 1e-5
     assert rel_err(Xd, Xo.detach()) < 1e-5
+    # the same launch with the step's zero-fills and Adam-table bookkeeping in further blocks (nemo_phase_embed_fwd_begin)
+    from nemo_cvpr2023_amd._lib import AdamSeg
+    import ctypes
+    Xd2, phd2, den2 = torch.full_like(Xd, 7.0), torch.zeros_like(phd), torch.zeros_like(den)
+    z0, z1 = torch.ones(1003, device='cuda'), torch.ones(77, device='cuda')           # (sizes not multiples of 16 bytes)
+    seg_host = (AdamSeg * 2)()
+    for i, (lr, st_) in enumerate(((1e-3, 4), (5e-2, 0))):
+        seg_host[i].offset, seg_host[i].numel, seg_host[i].lr, seg_host[i].step = 0, 8, lr, st_
+    seg_dev = torch.frombuffer(bytearray(bytes(seg_host)), dtype=torch.uint8).cuda()
+    assert L.nemo_phase_embed_fwd_begin(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
+                                        pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), dco.data_ptr(), None, kid,
+                                        Xd2.data_ptr(), D + C, phd2.data_ptr(), den2.data_ptr(), z0.data_ptr(), 1003 * 4,
+                                        z1.data_ptr(), 77 * 4, seg_dev.data_ptr(), 2, 0.9, 0.999, H.st()) == 0
+    assert torch.equal(Xd2, Xd) and torch.equal(phd2, phd) and torch.equal(den2, den)
+    assert float(z0.abs().sum()) == 0.0 and float(z1.abs().sum()) == 0.0
+    back = (AdamSeg * 2).from_buffer_copy(bytes(seg_dev.cpu().numpy().tobytes()))
+    for i, (lr, st_) in enumerate(((1e-3, 4), (5e-2, 0))):
+        assert back[i].step == st_ + 1
+        assert abs(back[i].step_size - lr / (1 - 0.9 ** (st_ + 1))) <= 1e-6 * back[i].step_size
+        assert abs(back[i].bias_corr2_sqrt - (1 - 0.999 ** (st_ + 1)) ** 0.5) <= 1e-6
     for ws in (den, None):          # with the forward pass's denominators, and re-evaluating them
         gpn = torch.zeros_like(pn)
         gls, gco = torch.zeros(D, device='cuda'), torch.zeros(V, C, device='cuda')
