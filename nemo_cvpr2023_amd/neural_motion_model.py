@@ -928,6 +928,11 @@ class MultiViewModel(nn.Module):
                         warnings.warn(f'HIP graph capture failed ({ex}); this step variant runs un-captured')
                         torch.cuda.synchronize()
                         w['graphs'][key] = entry = 'eager'
+                        if part in ('allc', 'splitc', 'bucketc'):
+                            # a collective that would not capture: from the next step on this model goes back to a graph of
+                            # the step followed by eager collectives / hand-over / Adam (the same collectives in the same
+                            # order, so ranks that did capture stay in step with this one)
+                            self.graph_comm = False
                         body(svi, sfi, table, part)
                     else:
                         w['graphs'][key] = entry = g
