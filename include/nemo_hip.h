@@ -327,6 +327,11 @@ int32_t nemo_v2v_fused_bf16(const nemo_ctx* ctx, int64_t N, const float* PF2, in
  * L1 term and its gradient are then exactly zero for them. */
 int32_t nemo_v2v_prep_fwd(int64_t N, const float* R, const float* aa, const float* aa_dec, float* R2,
                           const int64_t* n_valid, void* stream);
+/* The same from the VPoser decoder's 6-D output dec6d (N,21,6; row stride lddec >= 126): the conversion 6-D -> rotation
+ * matrix -> axis-angle (vposer_model.py:100-113, what nemo_rot6d_fwd(N, 21, ..., aa) computes) happens in the same launch and
+ * aa_dec_out (N,63) receives the axis-angle form -- one launch less on the chain the mesh kernel waits for. */
+int32_t nemo_v2v_prep_fwd_dec(int64_t N, const float* R, const float* aa, const float* dec6d, int64_t lddec,
+                              float* aa_dec_out, float* R2, const int64_t* n_valid, void* stream);
 /* dR2 (N,24,9) -> d_aa (N,72) += scale * J^T dR2[:,1:],  dR (N,24,9)[:,0] += scale * dR2[:,0]. */
 int32_t nemo_v2v_prep_bwd(int64_t N, const float* aa, const float* dR2, float scale, float* d_aa,
                           float* dR, void* stream);

@@ -91,6 +91,7 @@ SIGNATURES = {
     'nemo_v2v_combine': (i32, [ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_fused_bf16mem': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_prep_fwd': (i32, [i64, ptr, ptr, ptr, ptr, ptr, ptr]),
+    'nemo_v2v_prep_fwd_dec': (i32, [i64, ptr, ptr, ptr, i64, ptr, ptr, ptr, ptr]),
     'nemo_v2v_prep_bwd': (i32, [i64, ptr, ptr, f32, ptr, ptr, ptr]),
     'nemo_kl_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, i64, ptr, ptr]),
     'nemo_publish_scalars': (i32, [ptr, i32, ptr, ptr, ptr]),

@@ -233,11 +233,17 @@ __global__ __launch_bounds__(256) void rodrigues_bwd_kernel(long M, const float*
 
 // rows<N : joint 0 = R[s][0];  joints 1..23 = Rodrigues(aa[s][3j .. 3j+2])
 // rows>=N: joint 0 = R[s][0];  joints 1..21 = Rodrigues(aa_dec[s][3(j-1)..]); 22,23 from aa
+// dec6d != NULL (nemo_v2v_prep_fwd_dec): the decoder's 6-D output (N, 21, 6; row stride lddec) instead of its axis-angle
+// form -- the thread of (second body, joint 1..21) does the conversion 6-D -> R -> axis-angle itself (what a
+// nemo_rot6d_fwd launch in front of this one did) and stores the axis-angle in aa_dec_out: one launch less on the chain
+// the mesh kernel waits for.
 __global__ __launch_bounds__(256) void v2v_prep_fwd_kernel(long N, const float* __restrict__ R,
                                                            const float* __restrict__ aa,
                                                            const float* __restrict__ aa_dec,
                                                            float* __restrict__ R2,
-                                                           const int64_t* __restrict__ n_valid) {
+                                                           const int64_t* __restrict__ n_valid,
+                                                           const float* __restrict__ dec6d = nullptr, long lddec = 0,
+                                                           float* __restrict__ aa_dec_out = nullptr) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * N * 24) return;
     const long row = i / 24;
@@ -250,6 +256,18 @@ __global__ __launch_bounds__(256) void v2v_prep_fwd_kernel(long N, const float* 
     if (j == 0) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) Rm[k] = R[s * 216 + k];
+    } else if (dec6d && row >= N && j <= 21) {
+        float x[6], Rd[9], t[3];
+        const float* src6 = dec6d + s * lddec + (j - 1) * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x[k] = src6[k];
+        rot6d_fwd(x, Rd);
+        rotmat_to_aa_fwd(Rd, 0, t);
+        aa_dec_out[s * 63 + (j - 1) * 3 + 0] = t[0];
+        aa_dec_out[s * 63 + (j - 1) * 3 + 1] = t[1];
+        aa_dec_out[s * 63 + (j - 1) * 3 + 2] = t[2];
+        if (!dec) { t[0] = aa[s * 72 + j * 3]; t[1] = aa[s * 72 + j * 3 + 1]; t[2] = aa[s * 72 + j * 3 + 2]; }
+        rodrigues_fwd(t, Rm);
     } else {
         const float* src = (row >= N && j <= 21 && dec) ? aa_dec + s * 63 + (j - 1) * 3 : aa + s * 72 + j * 3;
         const float t[3] = {src[0], src[1], src[2]};
@@ -640,6 +658,16 @@ extern "C" int32_t nemo_v2v_prep_fwd(int64_t N, const float* R, const float* aa,
     if (N < 0 || !R || !aa || !aa_dec || !R2) return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
     hipLaunchKernelGGL(v2v_prep_fwd_kernel, GRID1D(2 * N * 24), (long)N, R, aa, aa_dec, R2, n_valid);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_v2v_prep_fwd_dec(int64_t N, const float* R, const float* aa, const float* dec6d, int64_t lddec,
+                                         float* aa_dec_out, float* R2, const int64_t* n_valid, void* stream) {
+    if (N < 0 || !R || !aa || !dec6d || lddec < 126 || !aa_dec_out || !R2) return NEMO_EINVAL;
+    if (N == 0) return NEMO_OK;
+    hipLaunchKernelGGL(v2v_prep_fwd_kernel, GRID1D(2 * N * 24), (long)N, R, aa, (const float*)nullptr, R2, n_valid, dec6d,
+                       (long)lddec, aa_dec_out);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -777,7 +777,7 @@ class FitEngine:
             ctx.set_betas(self.betas.detach().cpu().numpy())
             ctx._betas_version = self.betas._version
 
-    def forward_vposer(self, w, N):
+    def forward_vposer(self, w, N, dec_aa=True):
         """K9: encode(mean) -> decode -> axis-angle.  Returns the event recorded once the encoder output (mu | logvar)
         exists: the KL term and its backward (vposer_kl / backward_vposer_kl) run from there on another stream."""
         L, st, vp = self.lib, _stream(), self.vp
@@ -791,7 +791,7 @@ class FitEngine:
             self.gemm16(N, 512, 32, w['MULVb'], vb['d0w'], dptr(w['D1']), 512, bias=dptr(vp['d0b']), act=2, Cb=w['D1b'])
             self.gemm16(N, 512, 512, w['D1b'], vb['d3w'], dptr(w['D2']), 512, bias=dptr(vp['d3b']), act=2, Cb=w['D2b'])
             self.gemm16(N, 126, 512, w['D2b'], vb['d5w'], dptr(w['D3']), 126, bias=dptr(vp['d5b']))
-            check(L.nemo_rot6d_fwd(N, 21, dptr(w['D3']), 126, 0, None, dptr(w['AAdec']), st), 'nemo_rot6d_fwd')
+            self._dec_aa(w, N, 0 if dec_aa else min(w['Nc'], N))
             return enc_done
         self._linear(N, aa63, 72, 63, dptr(vp['e2w_p']), dptr(vp['e2b']), 512, dptr(w['E1']), 512, act=2, ldw=64)
         self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
@@ -801,21 +801,32 @@ class FitEngine:
         self._linear(N, dptr(w['D1']), 512, 512, dptr(vp['d3w']), dptr(vp['d3b']), 512, dptr(w['D2']), 512,
                      act=2)
         self._linear(N, dptr(w['D2']), 512, 512, dptr(vp['d5w']), dptr(vp['d5b']), 126, dptr(w['D3']), 126)
-        check(L.nemo_rot6d_fwd(N, 21, dptr(w['D3']), 126, 0, None, dptr(w['AAdec']), st), 'nemo_rot6d_fwd')
+        self._dec_aa(w, N, 0 if dec_aa else min(w['Nc'], N))
         return enc_done
+
+    def _dec_aa(self, w, N, first):
+        """Axis-angle form of the decoder output for samples [first, N) (vposer_model.py:100-113).  first > 0: the first
+        `first` samples are converted inside nemo_v2v_prep_fwd_dec (forward_v2v_pre(fused_dec=True))."""
+        if first < N:
+            check(self.lib.nemo_rot6d_fwd(N - first, 21, w['D3'].data_ptr() + 4 * first * 126, 126, 0, None,
+                                          w['AAdec'].data_ptr() + 4 * first * 63, _stream()), 'nemo_rot6d_fwd')
 
     def vposer_kl(self, w, N):
         """K12: KL( N(mu, softplus(logvar)) || N(0, 1) ) and its gradient w.r.t. (mu | logvar)."""
         check(self.lib.nemo_kl_fwd_bwd(N, 32, dptr(w['MULV']), 64, self.scal.data_ptr() + 4 * S_KL,
                                        dptr(w['dMULV']), 64, self.nvalid, _stream()), 'nemo_kl_fwd_bwd')
 
-    def forward_v2v_pre(self, w, N):
+    def forward_v2v_pre(self, w, N, fused_dec=False):
         """The part of forward_v2v's first chunk that only needs the poses: both bodies' rotations (v2v_prep) and their
         FK.  The step runs it at the end of the VPoser stream, off the main chain (``forward_v2v(pre_done=True)``)."""
         L, st, ctx = self.lib, _stream(), self.ctx
         n = min(w['Nc'], N)
-        check(L.nemo_v2v_prep_fwd(n, dptr(w['R']), dptr(w['AA']), dptr(w['AAdec']), dptr(w['R2']), self.nvalid, st),
-              'nemo_v2v_prep_fwd')
+        if fused_dec:        # (the decoder's 6-D output -> axis-angle inside the same launch: forward_vposer(dec_aa=False))
+            check(L.nemo_v2v_prep_fwd_dec(n, dptr(w['R']), dptr(w['AA']), dptr(w['D3']), 126, dptr(w['AAdec']), dptr(w['R2']),
+                                          self.nvalid, st), 'nemo_v2v_prep_fwd_dec')
+        else:
+            check(L.nemo_v2v_prep_fwd(n, dptr(w['R']), dptr(w['AA']), dptr(w['AAdec']), dptr(w['R2']), self.nvalid, st),
+                  'nemo_v2v_prep_fwd')
         check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']), dptr(w['PF2']), 208, st),
               'nemo_fk_fwd')
 

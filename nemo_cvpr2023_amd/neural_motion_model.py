@@ -600,8 +600,9 @@ class MultiViewModel(nn.Module):
             side2.wait_event(pose_done)
             with torch.cuda.stream(side):
                 if use_vposer:
-                    enc_done = e.forward_vposer(w, N)                             # always evaluated, :3569
-                    e.forward_v2v_pre(w, N)          # rotations + FK of both mesh bodies: only the poses are needed
+                    fd = os.environ.get('NEMO_FUSED_DEC', '1') != '0'
+                    enc_done = e.forward_vposer(w, N, dec_aa=not fd)              # always evaluated, :3569
+                    e.forward_v2v_pre(w, N, fused_dec=fd)   # rotations + FK of both mesh bodies: only the poses are needed
             with torch.cuda.stream(side2):
                 priors()
                 if use_vposer:
@@ -622,8 +623,9 @@ class MultiViewModel(nn.Module):
                 priors()
                 priors_done = side.record_event()
                 if use_vposer:
-                    enc_done = e.forward_vposer(w, N)
-                    e.forward_v2v_pre(w, N)
+                    fd = os.environ.get('NEMO_FUSED_DEC', '1') != '0'
+                    enc_done = e.forward_vposer(w, N, dec_aa=not fd)
+                    e.forward_v2v_pre(w, N, fused_dec=fd)
             if use_vposer:
                 main.wait_event(enc_done)
                 main.wait_event(priors_done)             # (`+=` into dAA: after the prior terms)

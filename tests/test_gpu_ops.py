@@ -594,6 +594,22 @@ def test_v2v_prep(L):
                                dRm.data_ptr(), H.st()) == 0
     assert rel_err(daa, 0.5 * aao.grad) < 1e-4
     assert rel_err(dRm[:, 0], 0.5 * ct[:, 0]) < TOL and float(dRm[:, 1:].abs().max()) == 0.0
+    # the decoder's 6-D output converted inside the same launch (nemo_v2v_prep_fwd_dec) == nemo_rot6d_fwd + nemo_v2v_prep_fwd,
+    # with and without padding rows
+    d6 = H.dev(torch.randn(N, 130, generator=gen))                          # (row stride 130 >= 126)
+    aad2 = torch.zeros(N, 63, device='cuda')
+    assert L.nemo_rot6d_fwd(N, 21, d6.data_ptr(), 130, 0, None, aad2.data_ptr(), H.st()) == 0
+    for nv in (None, torch.tensor([3], device='cuda')):
+        Ra, Rb = torch.zeros(2 * N, 24, 9, device='cuda'), torch.zeros(2 * N, 24, 9, device='cuda')
+        aad3 = torch.zeros(N, 63, device='cuda')
+        nvp = nv.data_ptr() if nv is not None else None
+        assert L.nemo_v2v_prep_fwd(N, H.dev(R).data_ptr(), H.dev(aa).data_ptr(), aad2.data_ptr(), Ra.data_ptr(), nvp,
+                                   H.st()) == 0
+        assert L.nemo_v2v_prep_fwd_dec(N, H.dev(R).data_ptr(), H.dev(aa).data_ptr(), d6.data_ptr(), 130, aad3.data_ptr(),
+                                       Rb.data_ptr(), nvp, H.st()) == 0
+        assert rel_err(aad3, aad2) < 1e-6 and rel_err(Rb, Ra) < 1e-6
+        if nv is not None:
+            assert torch.equal(Rb[N + 3:], Rb[3:N])                        # padding rows: the first body twice
 
 
 # ------------------------------------------------------------------------------------------ priors
