@@ -145,6 +145,16 @@ int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t
                              const float* dX, int64_t ldx, float* ws,
                              float* d_shifts, float* d_scales, float* d_log_sigmas, float* d_codes,
                              void* stream);
+/* nemo_phase_embed_bwd and nemo_colsum_multi(n_cs, descs) (same arguments, same results) in ONE launch: the batched bias
+ * column sums of the MLP backward (nemo/neural_motion_model.py:58-71 under autograd) need only the activation gradients the
+ * dX chain has produced by the time the phase backward starts, so they run in further blocks of its grid instead of as a
+ * launch of their own behind the last parameter-gradient GEMM. */
+int32_t nemo_phase_embed_bwd_colsum(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
+                                    const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
+                                    const float* shifts, const float* scales, int64_t ldp, const float* log_sigmas,
+                                    int32_t kernel_id, const float* phase, const float* dX, int64_t ldx, float* ws,
+                                    float* d_shifts, float* d_scales, float* d_log_sigmas, float* d_codes, int32_t n_cs,
+                                    const nemo_colsum_desc* descs /* HOST array */, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * rot6d -> rotation matrix -> axis-angle, per (row, joint).

@@ -444,7 +444,8 @@ extern "C" int32_t nemo_phase_embed_fwd_begin(int64_t N, int64_t V, int64_t T, i
 // (view, node, group).  Blocks [nAB, ...): stage C (independent of A and B: column sums of dX).
 namespace {
 constexpr int PH_SPB = 32;
-__global__ __launch_bounds__(256) void phase_bwd_fused_kernel(
+__device__ __forceinline__ void phase_bwd_fused_body(
+    const int bid,
     long N, long V, long T, int K, int D, int C, const int64_t* __restrict__ view_idx,
     const int64_t* __restrict__ frame_idx, const float* __restrict__ raw_phase, const float* __restrict__ shifts,
     const float* __restrict__ scales, long ldp, const float* __restrict__ log_sigmas, int kid,
@@ -454,10 +455,10 @@ __global__ __launch_bounds__(256) void phase_bwd_fused_kernel(
     __shared__ float red[16];
     __shared__ float cx[PH_SPB], cy[PH_SPB], cz[PH_SPB], co[PH_SPB];
     __shared__ long cv[PH_SPB];
-    if ((int)blockIdx.x >= nAB) {
+    if (bid >= nAB) {
         // ---- stage C: one block per reduced column.  b < D: d log_sigma_d over all N + 1 rows; otherwise (c, v):
         // d code[v][c] over the samples of view v
-        const int b = (int)blockIdx.x - nAB;
+        const int b = bid - nAB;
         float acc = 0.f;
         if (b < D) {
             if (!d_log_sigmas) return;
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void phase_bwd_fused_kernel(
     // den = o - z + 1e-6 only (a per-view constant: the forward kernel hands it over in den_ws; without it the two sums
     // are re-evaluated here).  (Round 2 walked a wave's eight samples one after the other, each behind its own chain of
     // dependent global loads and three K-long sigmoid sums: 35 us whatever N was.)
-    const long s0 = (long)blockIdx.x * spb;
+    const long s0 = (long)bid * spb;
     const int ns = (int)min((long)spb, N - s0);
     {
         const int i = threadIdx.x >> 3, l = threadIdx.x & 7;
@@ -563,17 +564,51 @@ __global__ __launch_bounds__(256) void phase_bwd_fused_kernel(
         }
     }
 }
+struct PhaseBwdArgs {
+    long N, V, T; int K, D, C; const int64_t* view_idx; const int64_t* frame_idx; const float* raw_phase;
+    const float* shifts; const float* scales; long ldp; const float* log_sigmas; int kid; const float* phase;
+    const float* den_ws; const float* dX; long ldx; float* d_shifts; float* d_scales; float* d_log_sigmas; float* d_codes;
+    int nAB, spb;
+};
+#define PHASE_BWD_CALL(a, bid) phase_bwd_fused_body(bid, a.N, a.V, a.T, a.K, a.D, a.C, a.view_idx, a.frame_idx, a.raw_phase, \
+    a.shifts, a.scales, a.ldp, a.log_sigmas, a.kid, a.phase, a.den_ws, a.dX, a.ldx, a.d_shifts, a.d_scales, a.d_log_sigmas, \
+    a.d_codes, a.nAB, a.spb)
+__global__ __launch_bounds__(256) void phase_bwd_fused_kernel(PhaseBwdArgs a) { PHASE_BWD_CALL(a, (int)blockIdx.x); }
+
+// The phase backward with the step's batched bias column sums (nemo_colsum_multi: out[n] += sum_m X[m][n] for up to
+// NEMO_COLSUM_MAX matrices) in further blocks of the same grid: both only need the activation gradients the dX chain has
+// produced, and as a launch of its own the column-sum pass sat behind the last parameter-gradient GEMM on the side stream, at
+// the very end of the backward.
+struct ColsumBatchP { nemo_colsum_desc d[NEMO_COLSUM_MAX]; int n; int gx, gy; long rows_per_block; };
+__global__ __launch_bounds__(256) void phase_bwd_colsum_kernel(PhaseBwdArgs a, int n_phase, ColsumBatchP cb) {
+    if ((int)blockIdx.x < n_phase) { PHASE_BWD_CALL(a, (int)blockIdx.x); return; }
+    const int lin = (int)blockIdx.x - n_phase;
+    const int bx = lin % cb.gx, by = (lin / cb.gx) % cb.gy, bz = lin / (cb.gx * cb.gy);
+    const nemo_colsum_desc d = cb.d[bz];
+    const long n = (long)bx * 64 + (threadIdx.x & 63);
+    const long mbeg = (long)by * cb.rows_per_block;
+    if (mbeg >= d.M || (long)bx * 64 >= d.N) return;                 // block-uniform
+    const long mend = min((long)d.M, mbeg + cb.rows_per_block);
+    float sacc = 0.f;
+    if (n < d.N)
+        for (long m = mbeg + (threadIdx.x >> 6); m < mend; m += 4) sacc += d.X[m * d.ldx + n];
+    __shared__ float redc[4][64];
+    redc[threadIdx.x >> 6][threadIdx.x & 63] = sacc;
+    __syncthreads();
+    if (threadIdx.x < 64 && n < d.N)
+        atomicAdd(d.out + n, redc[0][threadIdx.x] + redc[1][threadIdx.x] + redc[2][threadIdx.x] + redc[3][threadIdx.x]);
+}
 }  // namespace
 
-extern "C" int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
-                                        const int64_t* view_idx, const int64_t* frame_idx,
-                                        const float* raw_phase, const float* shifts, const float* scales,
-                                        int64_t ldp, const float* log_sigmas, int32_t kernel_id,
-                                        const float* phase, const float* dX, int64_t ldx, float* ws,
-                                        float* d_shifts, float* d_scales, float* d_log_sigmas,
-                                        float* d_codes, void* stream) {
+static int32_t phase_bwd_launch(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
+                                const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
+                                const float* shifts, const float* scales, int64_t ldp, const float* log_sigmas,
+                                int32_t kernel_id, const float* phase, const float* dX, int64_t ldx, float* ws,
+                                float* d_shifts, float* d_scales, float* d_log_sigmas, float* d_codes, int32_t n_cs,
+                                const nemo_colsum_desc* descs, void* stream) {
     if (N < 0 || V <= 0 || K <= 0 || D < 0 || C < 0 || !dX || !shifts || !scales || !phase) return NEMO_EINVAL;
     if ((d_shifts == nullptr) != (d_scales == nullptr)) return NEMO_EINVAL;
+    if (n_cs < 0 || n_cs > NEMO_COLSUM_MAX || (n_cs && !descs)) return NEMO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     // samples per stage-A/B block: short node loops for small batches (a one-instance shard: 38 blocks of 8 samples
     // instead of 10 blocks whose threads walk 32 samples each), fewer atomics for large ones
@@ -582,13 +617,53 @@ extern "C" int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t
     // blocks [nAB, nAB + D) reduce log_sigma columns; if d_log_sigmas is NULL they are still launched (as no-ops) so
     // that the block -> column map stays fixed
     const long nC = (d_log_sigmas || d_codes) ? D + (d_codes ? V * C : 0) : 0;
-    if (nAB + nC == 0) return NEMO_OK;
-    hipLaunchKernelGGL(phase_bwd_fused_kernel, dim3((unsigned)(nAB + nC)), dim3(256), 0, st, (long)N, (long)V, (long)T,
-                       (int)K, (int)D, (int)C, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp, log_sigmas,
-                       (int)kernel_id, phase, (const float*)ws, dX, (long)ldx, d_shifts, d_scales, d_log_sigmas, d_codes,
-                       (int)nAB, spb);
+    PhaseBwdArgs a{(long)N, (long)V, (long)T, (int)K, (int)D, (int)C, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp,
+                   log_sigmas, (int)kernel_id, phase, (const float*)ws, dX, (long)ldx, d_shifts, d_scales, d_log_sigmas, d_codes,
+                   (int)nAB, spb};
+    ColsumBatchP cb;
+    cb.n = 0; cb.gx = cb.gy = 0; cb.rows_per_block = 128;
+    long maxM = 0, maxN = 0;
+    for (int i = 0; i < n_cs; ++i) {
+        if (descs[i].M < 0 || descs[i].N < 0 || !descs[i].X || !descs[i].out) return NEMO_EINVAL;
+        cb.d[i] = descs[i];
+        if (descs[i].M > maxM) maxM = descs[i].M;
+        if (descs[i].N > maxN) maxN = descs[i].N;
+    }
+    long ncs = 0;
+    if (n_cs && maxM > 0 && maxN > 0) {
+        cb.n = n_cs; cb.gx = (int)nemo_cdiv(maxN, 64); cb.gy = (int)nemo_cdiv(maxM, cb.rows_per_block);
+        ncs = (long)cb.gx * cb.gy * n_cs;
+    }
+    if (nAB + nC + ncs == 0) return NEMO_OK;
+    if (ncs == 0)
+        hipLaunchKernelGGL(phase_bwd_fused_kernel, dim3((unsigned)(nAB + nC)), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(phase_bwd_colsum_kernel, dim3((unsigned)(nAB + nC + ncs)), dim3(256), 0, st, a, (int)(nAB + nC), cb);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
+}
+
+extern "C" int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
+                                        const int64_t* view_idx, const int64_t* frame_idx,
+                                        const float* raw_phase, const float* shifts, const float* scales,
+                                        int64_t ldp, const float* log_sigmas, int32_t kernel_id,
+                                        const float* phase, const float* dX, int64_t ldx, float* ws,
+                                        float* d_shifts, float* d_scales, float* d_log_sigmas,
+                                        float* d_codes, void* stream) {
+    return phase_bwd_launch(N, V, T, K, D, C, view_idx, frame_idx, raw_phase, shifts, scales, ldp, log_sigmas, kernel_id, phase,
+                            dX, ldx, ws, d_shifts, d_scales, d_log_sigmas, d_codes, 0, nullptr, stream);
+}
+
+// nemo_phase_embed_bwd + nemo_colsum_multi(n_cs, descs) in ONE launch (further blocks of the same grid).
+extern "C" int32_t nemo_phase_embed_bwd_colsum(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
+                                               const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
+                                               const float* shifts, const float* scales, int64_t ldp,
+                                               const float* log_sigmas, int32_t kernel_id, const float* phase,
+                                               const float* dX, int64_t ldx, float* ws, float* d_shifts, float* d_scales,
+                                               float* d_log_sigmas, float* d_codes, int32_t n_cs,
+                                               const nemo_colsum_desc* descs, void* stream) {
+    return phase_bwd_launch(N, V, T, K, D, C, view_idx, frame_idx, raw_phase, shifts, scales, ldp, log_sigmas, kernel_id, phase,
+                            dX, ldx, ws, d_shifts, d_scales, d_log_sigmas, d_codes, n_cs, descs, stream);
 }
 
 extern "C" int32_t nemo_rot6d_fwd(int64_t rows, int64_t J, const float* rot6d, int64_t ld6, int32_t zero_nan,

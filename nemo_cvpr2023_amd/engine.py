@@ -307,6 +307,7 @@ class FitEngine:
         self.ws = {}
         self.side_stream = torch.cuda.Stream(device=self.device)   # prior branches of the step (see _forward_backward)
         self.side_stream2 = torch.cuda.Stream(device=self.device)
+        self.cs_in_phase = os.environ.get('NEMO_COLSUM_IN_PHASE', '1') != '0'
         self.pub_stream = torch.cuda.Stream(device=self.device)     # NEMO_PUBLISH=aside4 (A/B aid)
         self.comm_stream = torch.cuda.Stream(device=self.device)    # bucketed gradient all-reduces + their Adam (dist.py)
         # split-K scratch of nemo_gemm_f32 (arrival tickets + partial tiles), one per stream that launches GEMMs
@@ -595,15 +596,9 @@ class FitEngine:
         cs.append((dptr(w['cs0']), R, h, h, self.g(lm + 'net.net.0.bias')))
         self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din, dptr(w['dX']), self.ldx,
                   dense=True)
-        self.flush_colsums()
-        check(L.nemo_phase_embed_bwd(
-            N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
-            self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), self.ldp,
-            self.p('phase_rbf.log_sigmas') if self.D > 0 else None, self.kernel_id, dptr(w['phase']),
-            dptr(w['dX']), self.ldx, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
-            self.g('phase_networks.0.scales'),
-            self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
-            self.g('learned_instance_code') if self.C > 0 else None, _stream()), 'nemo_phase_embed_bwd')
+        if not self.cs_in_phase:
+            self.flush_colsums()
+        self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=self.cs_in_phase)
 
     def gemm_grouped(self, problems, dense=True):
         """problems: list of (ta, tb, M, N, K, A, lda, B, ldb, C, ldc, out_mode) -- independent products of one layout in
@@ -617,6 +612,26 @@ class FitEngine:
         ws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]
         fn = self.lib.nemo_gemm_grouped_bf16 if (dense and self.bf16) else self.lib.nemo_gemm_grouped_f32
         check(fn(len(problems), arr, ws.data_ptr(), ws.numel() * 4, _stream()), 'nemo_gemm_grouped')
+
+    def phase_bwd(self, w, N, view_idx, frame_idx, raw_phase, with_colsums=False):
+        """Phase / RBF / code backward; ``with_colsums``: the pending bias column sums (self._colsums) ride in further blocks
+        of the same launch (nemo_phase_embed_bwd_colsum) instead of a launch of their own."""
+        args = (N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
+                self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), self.ldp,
+                self.p('phase_rbf.log_sigmas') if self.D > 0 else None, self.kernel_id, dptr(w['phase']),
+                dptr(w['dX']), self.ldx, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
+                self.g('phase_networks.0.scales'),
+                self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
+                self.g('learned_instance_code') if self.C > 0 else None)
+        if with_colsums and self._colsums:
+            n = len(self._colsums)
+            arr = (ColsumDesc * n)()
+            for i, (x, m, nn, ld, out) in enumerate(self._colsums):
+                arr[i].X, arr[i].M, arr[i].N, arr[i].ldx, arr[i].out = x, m, nn, ld, out
+            self._colsums = []
+            check(self.lib.nemo_phase_embed_bwd_colsum(*args, n, arr, _stream()), 'nemo_phase_embed_bwd_colsum')
+        else:
+            check(self.lib.nemo_phase_embed_bwd(*args, _stream()), 'nemo_phase_embed_bwd')
 
     def flush_colsums(self):
         if not self._colsums:
@@ -957,6 +972,7 @@ class FitEngine:
         # the chain dX_head -> dX4 -> dX2 -> dX0 -> phase backward runs uninterrupted on the main stream.
         # (NEMO_SERIAL_BWD=1: everything on the main stream, for A/B timing.)
         main, side = torch.cuda.current_stream(), self.side_stream
+        cs_in = self.cs_in_phase and not bucketed      # bias column sums inside the phase backward's launch
         overlap = self.overlap_bwd
         small = overlap and r <= self.SMALL_BATCH_ROWS
 
@@ -1002,14 +1018,7 @@ class FitEngine:
             ev = main.record_event()
             self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
                       dptr(w['dX']), self.ldx, dense=True)
-            check(L.nemo_phase_embed_bwd(
-                N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
-                self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), self.ldp,
-                self.p('phase_rbf.log_sigmas') if self.D > 0 else None, self.kernel_id, dptr(w['phase']),
-                dptr(w['dX']), self.ldx, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
-                self.g('phase_networks.0.scales'),
-                self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
-                self.g('learned_instance_code') if self.C > 0 else None, _stream()), 'nemo_phase_embed_bwd')
+            self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=cs_in)
             if grp == 2 or not overlap:
                 self.gemm_grouped(dWs)
                 self.flush_colsums()
@@ -1063,14 +1072,7 @@ class FitEngine:
             return
 
         def phase_bwd():
-            check(L.nemo_phase_embed_bwd(
-                N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
-                self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), self.ldp,
-                self.p('phase_rbf.log_sigmas') if self.D > 0 else None, self.kernel_id, dptr(w['phase']),
-                dptr(w['dX']), self.ldx, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
-                self.g('phase_networks.0.scales'),
-                self.g('phase_rbf.log_sigmas') if self.D > 0 else None,
-                self.g('learned_instance_code') if self.C > 0 else None, _stream()), 'nemo_phase_embed_bwd')
+            self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=cs_in)
 
         def dX0():
             self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
@@ -1083,6 +1085,9 @@ class FitEngine:
             # the three phase / RBF / code kernels that consume it
             ev = main.record_event()
             dX0()
+            if cs_in:             # (the layer-0 bias column sum rides in the phase launch with the others)
+                self._colsums.append((w0[4], w0[0], w0[6], w0[5], w0[8]))
+                w0 = w0[:8] + (None,)
             phase_bwd()
             side.wait_event(ev)
             with torch.cuda.stream(side):
@@ -1092,7 +1097,8 @@ class FitEngine:
         else:
             self._linear_bwd_params(*w0)
             dX0()
-            self.flush_colsums()
+            if not cs_in:
+                self.flush_colsums()
             phase_bwd()
 
     def finish_trans_grad(self, w, N):

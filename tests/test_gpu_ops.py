@@ -336,6 +336,21 @@ def test_phase_embed_vs_oracle(L, kern):
         assert rel_err(gpn[:, 0], sho.grad) < 1e-4
         assert rel_err(gpn[:, 1], sco.grad) < 1e-4
         assert float(gpn[1].abs().max()) == 0.0
+    # the same backward with two batched bias column sums in further blocks of the launch (nemo_phase_embed_bwd_colsum)
+    from nemo_cvpr2023_amd._lib import ColsumDesc
+    Y1, Y2 = torch.randn(301, 70, generator=gen).cuda(), torch.randn(150, 200, generator=gen).cuda()
+    o1, o2 = torch.ones(70, device='cuda'), torch.zeros(130, device='cuda')
+    arr = (ColsumDesc * 2)()
+    arr[0].X, arr[0].M, arr[0].N, arr[0].ldx, arr[0].out = Y1.data_ptr(), 301, 70, 70, o1.data_ptr()
+    arr[1].X, arr[1].M, arr[1].N, arr[1].ldx, arr[1].out = Y2.data_ptr(), 150, 130, 200, o2.data_ptr()
+    gpn2 = torch.zeros_like(pn)
+    gls2, gco2 = torch.zeros(D, device='cuda'), torch.zeros(V, C, device='cuda')
+    assert L.nemo_phase_embed_bwd_colsum(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
+                                         pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), kid, phd.data_ptr(),
+                                         H.dev(ct).data_ptr(), D + C, den.data_ptr(), gpn2.data_ptr(), gpn2.data_ptr() + 4 * K,
+                                         gls2.data_ptr(), gco2.data_ptr(), 2, arr, H.st()) == 0
+    assert rel_err(gpn2.reshape(V, 2, K), gpn) < 1e-5 and rel_err(gls2, gls) < 1e-5 and rel_err(gco2, gco) < 1e-5
+    assert rel_err(o1, 1.0 + Y1.double().sum(0)) < 1e-5 and rel_err(o2, Y2[:, :130].double().sum(0)) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------ SMPL pieces
