@@ -114,6 +114,11 @@ def fold_vposer(sd: dict, device):
         'd5w': g('decoder_net.5.weight'), 'd5b': g('decoder_net.5.bias'),
     }
     out['e2w_p'] = torch.cat([out['e2w'], torch.zeros(out['e2w'].shape[0], 1, dtype=out['e2w'].dtype)], 1)   # ld 64: 16-byte rows
+    # decode(q_z.mean) (:3569, vposer_model.py:100-113): the first decoder layer reads the mean head's output with nothing in
+    # between, so it is ONE affine map of the encoder's hidden activation (512 -> 512, rank 32) -- the decoder chain then
+    # starts beside the (mu | logvar) product instead of behind it
+    out['d0mw'] = out['d0w'] @ out['emw'][:32]
+    out['d0mb'] = out['d0w'] @ out['emb'][:32] + out['d0b']
     return {k: v.float().contiguous().to(device) for k, v in out.items()}
 
 
@@ -271,7 +276,7 @@ class FitEngine:
             self.Pb = torch.zeros(207, self.ctx.ldP, dtype=torch.int16, device=self.device)
             self._cast(207, 3 * self.NV, self.ctx.posedirs, self.ctx.ldP, self.Pb, 0)
             self.vpb = {}
-            for k in ('e2w', 'emw', 'd0w', 'd3w', 'd5w'):               # (out, in) -> bf16 [out][in padded]
+            for k in ('e2w', 'emw', 'd0w', 'd0mw', 'd3w', 'd5w'):       # (out, in) -> bf16 [out][in padded]
                 wt = self.vp[k]
                 self.vpb[k] = torch.zeros(wt.shape[0], r8(wt.shape[1]), dtype=torch.int16, device=self.device)
                 self._cast(wt.shape[0], wt.shape[1], wt.data_ptr(), wt.stride(0), self.vpb[k], 0)
@@ -792,27 +797,48 @@ class FitEngine:
             ctx.set_betas(self.betas.detach().cpu().numpy())
             ctx._betas_version = self.betas._version
 
-    def forward_vposer(self, w, N, dec_aa=True):
+    def vposer_mulv(self, w, N):
+        """The encoder's (mu | logvar) product alone (forward_vposer(compose=True) leaves it to the caller's KL stream)."""
+        vp = self.vp
+        if self.b16mem:
+            self.gemm16(N, 64, 512, w['E1b'], self.vpb['emw'], dptr(w['MULV']), 64, bias=dptr(vp['emb']), Cb=w['MULVb'])
+        else:
+            self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
+
+    def forward_vposer(self, w, N, dec_aa=True, compose=False):
         """K9: encode(mean) -> decode -> axis-angle.  Returns the event recorded once the encoder output (mu | logvar)
-        exists: the KL term and its backward (vposer_kl / backward_vposer_kl) run from there on another stream."""
+        exists: the KL term and its backward (vposer_kl / backward_vposer_kl) run from there on another stream.
+        ``compose``: the decoder starts from the encoder's hidden activation through the composed first layer (fold_vposer:
+        d0mw) and the (mu | logvar) product is NOT launched here -- only the KL term reads it, so the caller runs it on the
+        KL stream (vposer_mulv) behind the event this call then returns (hidden activation ready): the product leaves the
+        chain the mesh kernel waits for."""
         L, st, vp = self.lib, _stream(), self.vp
         aa63 = w['AA'].data_ptr() + 4 * 3
+        cur = torch.cuda.current_stream()
         if self.b16mem:
             vb = self.vpb
             self._cast(N, 63, aa63, 72, w['AAb'], 0)
             self.gemm16(N, 512, 63, w['AAb'], vb['e2w'], dptr(w['E1']), 512, bias=dptr(vp['e2b']), act=2, Cb=w['E1b'])
-            self.gemm16(N, 64, 512, w['E1b'], vb['emw'], dptr(w['MULV']), 64, bias=dptr(vp['emb']), Cb=w['MULVb'])
-            enc_done = torch.cuda.current_stream().record_event()
-            self.gemm16(N, 512, 32, w['MULVb'], vb['d0w'], dptr(w['D1']), 512, bias=dptr(vp['d0b']), act=2, Cb=w['D1b'])
+            if compose:
+                enc_done = cur.record_event()
+                self.gemm16(N, 512, 512, w['E1b'], vb['d0mw'], dptr(w['D1']), 512, bias=dptr(vp['d0mb']), act=2, Cb=w['D1b'])
+            else:
+                self.gemm16(N, 64, 512, w['E1b'], vb['emw'], dptr(w['MULV']), 64, bias=dptr(vp['emb']), Cb=w['MULVb'])
+                enc_done = cur.record_event()
+                self.gemm16(N, 512, 32, w['MULVb'], vb['d0w'], dptr(w['D1']), 512, bias=dptr(vp['d0b']), act=2, Cb=w['D1b'])
             self.gemm16(N, 512, 512, w['D1b'], vb['d3w'], dptr(w['D2']), 512, bias=dptr(vp['d3b']), act=2, Cb=w['D2b'])
             self.gemm16(N, 126, 512, w['D2b'], vb['d5w'], dptr(w['D3']), 126, bias=dptr(vp['d5b']))
             self._dec_aa(w, N, 0 if dec_aa else min(w['Nc'], N))
             return enc_done
         self._linear(N, aa63, 72, 63, dptr(vp['e2w_p']), dptr(vp['e2b']), 512, dptr(w['E1']), 512, act=2, ldw=64)
-        self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
-        enc_done = torch.cuda.current_stream().record_event()
-        self._linear(N, dptr(w['MULV']), 64, 32, dptr(vp['d0w']), dptr(vp['d0b']), 512, dptr(w['D1']), 512,
-                     act=2)
+        if compose:
+            enc_done = cur.record_event()
+            self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['d0mw']), dptr(vp['d0mb']), 512, dptr(w['D1']), 512, act=2)
+        else:
+            self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
+            enc_done = cur.record_event()
+            self._linear(N, dptr(w['MULV']), 64, 32, dptr(vp['d0w']), dptr(vp['d0b']), 512, dptr(w['D1']), 512,
+                         act=2)
         self._linear(N, dptr(w['D1']), 512, 512, dptr(vp['d3w']), dptr(vp['d3b']), 512, dptr(w['D2']), 512,
                      act=2)
         self._linear(N, dptr(w['D2']), 512, 512, dptr(vp['d5w']), dptr(vp['d5b']), 126, dptr(w['D3']), 126)

@@ -601,12 +601,17 @@ class MultiViewModel(nn.Module):
             with torch.cuda.stream(side):
                 if use_vposer:
                     fd = os.environ.get('NEMO_FUSED_DEC', '1') != '0'
-                    enc_done = e.forward_vposer(w, N, dec_aa=not fd)              # always evaluated, :3569
+                    # the (mu | logvar) product runs on side2 in front of the KL term, the decoder starts from the encoder's
+                    # hidden activation (NEMO_VP_COMPOSE=0: product on the decoder's chain, as before)
+                    vc = os.environ.get('NEMO_VP_COMPOSE', '1') != '0'
+                    enc_done = e.forward_vposer(w, N, dec_aa=not fd, compose=vc)          # always evaluated, :3569
                     e.forward_v2v_pre(w, N, fused_dec=fd)   # rotations + FK of both mesh bodies: only the poses are needed
             with torch.cuda.stream(side2):
                 priors()
                 if use_vposer:
                     side2.wait_event(enc_done)
+                    if vc:
+                        e.vposer_mulv(w, N)
                     kl_terms()
                 side2.wait_event(kp_done)
                 e.finalize_kp(w, mean_mode=0)
