@@ -32,7 +32,6 @@ python3 bench.py --instances 256 --frames 1024 --steps 5 --warmup 2 --repeat 3 -
 for v in 1 2 4; do python3 bench.py --instances $v --steps 100 --warmup 5 $B > $O/bench_shard_v$v.json 2>/dev/null; done
 for v in 1 2 4; do NEMO_BENCH_SHARD_OF_ONE=1 python3 bench.py --instances $v --steps 100 --warmup 5 $B 2>/dev/null | grep '^{' > $O/bench_group1_v$v.json; done
 # 5. un-profiled contribution of single kernels to the step (NEMO_ABLATE) at the shard sizes and the headline size
-bash tools/ablate.sh 2 nemo_v2v_fused nemo_gemm_f32@600x207x20670 nemo_gemm_f32@601x1000x1000 nemo_gemm_f32@1000x1000x601 nemo_colsum_multi nemo_phase_embed_bwd nemo_adam_step_dev nemo_kp_bwd_ex nemo_gmm_fwd_bwd nemo_fk_bwd nemo_pose_bwd_fused nemo_step_begin > $O/ablate_v2.txt 2>&1
-bash tools/ablate.sh 4 nemo_v2v_fused nemo_gemm_f32@1200x207x20670 nemo_gemm_f32@1201x1000x1000 nemo_gemm_f32@1000x1000x1201 nemo_colsum_multi nemo_phase_embed_bwd nemo_adam_step_dev nemo_kp_bwd_ex nemo_gmm_fwd_bwd nemo_fk_bwd nemo_pose_bwd_fused nemo_step_begin > $O/ablate_v4.txt 2>&1
+bash tools/ablate_r03_final.sh > /dev/null 2>&1
 find $O -name "*.db" -size +30M -delete
 du -sh $O; tail -c 300 $O/bench_c2_full.json

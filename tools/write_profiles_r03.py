@@ -154,8 +154,8 @@ sb = (f"# Round 3 (commit {head}) -- where the time of a SHARD-sized step goes, 
       "fork / join of the graph.\n\n"
       "Shard sizes of the 8 x 300 problem: 1 instance = one rank of 8 GPUs (N = 300), 2 = one rank of 4 (N = 600), 4 = one rank of 2 "
       "(N = 1200), 8 = the single-GPU step (N = 2400).\n\n")
-names = {'r3_ablate1.log': 'N = 300 (1 instance)', 'r3_ablate2.log': 'N = 300, the remaining GEMM shapes', 'ablate_v2.txt': 'N = 600 (2 instances)',
-         'ablate_v4.txt': 'N = 1200 (4 instances)', 'r3_ablate8.log': 'N = 2400 (8 instances: the headline step)'}
+names = {'ablate_v1.txt': 'N = 300 (1 instance)', 'ablate_v1b.txt': 'N = 300, the remaining GEMM shapes', 'ablate_v2.txt': 'N = 600 (2 instances)',
+         'ablate_v4.txt': 'N = 1200 (4 instances)', 'ablate_v8.txt': 'N = 2400 (8 instances: the headline step)'}
 for fn, title in names.items():
     try:
         sb += f"## {title}\n```\n" + '\n'.join(ab(fn)) + "\n```\n\n"
