@@ -114,6 +114,16 @@ def test_vposer_folding_matches_unfolded():
     mean, scale = ops.VPoserOracle(sd).encode(x)
     assert float((ml[:, :32] - mean).abs().max()) < 1e-5
     assert float((torch.nn.functional.softplus(ml[:, 32:]) - scale).abs().max()) < 1e-5
+    # decode(q_z.mean): the decoder's first Linear composed with the mean head (d0mw, d0mb) == the two maps one after the
+    # other, and the whole decoder from there equals the oracle's decode(mean)
+    d1 = torch.nn.functional.leaky_relu(lin(ml[:, :32], f['d0w'], f['d0b']))
+    d1c = torch.nn.functional.leaky_relu(lin(h, f['d0mw'], f['d0mb']))
+    assert float((d1c - d1).abs().max()) < 1e-5 * float(d1.abs().max())
+    d3 = lin(torch.nn.functional.leaky_relu(lin(d1c, f['d3w'], f['d3b'])), f['d5w'], f['d5b'])
+    _, Rdec = ops.VPoserOracle(sd).decode(mean)
+    ref6 = Rdec.reshape(7, 21, 3, 3)
+    got = ops.rot6d_to_rotmat(d3.reshape(-1, 6)).reshape(7, 21, 3, 3)
+    assert float((got - ref6).abs().max()) < 1e-5
 
 
 def test_real_asset_loaders_round_trip(tmp_path):
