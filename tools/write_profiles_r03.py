@@ -129,7 +129,7 @@ for v in (1, 2, 4):
                 f"{pr['collective_ms']} |\n")
 txt += ("\n`buckets` (three gradient buckets reduced behind the backward) loses on one GPU at these sizes even as one launch: its backward "
         "runs the parameter gradients on the critical chain (a bucket must be complete before its collective) and a world of one gains "
-        "nothing from the overlap (these lines were taken with all three modes in `auto`; `--shard-mode auto` times `buckets` only for per-rank steps of >= 4096 samples).\n\n"
+        "nothing from the overlap -- 0.66 - 0.67 ms at one instance against 0.51 - 0.52 for `split` when all three were timed (`r03_experiments.md` section 16); `--shard-mode auto` times `buckets` only for per-rank steps of >= 4096 samples, so it is not in the lines above.\n\n"
         "## the full default line (what the driver records)\n```\n" + json.dumps(full) + "\n```\n"
         f"cpu_baseline: {json.dumps(full['cpu_baseline'])}\n")
 if os.path.exists(os.path.join(G, 'bf16mem_gemm.txt')):
