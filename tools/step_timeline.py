@@ -10,7 +10,7 @@ which = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 c = sqlite3.connect(db).cursor()
 rows = list(c.execute('select name,start,end,queue_id from kernels order by start'))
 short = lambda n: re.sub(r'\(anonymous namespace\)::|void ', '', n).split('(')[0][:58]
-idx = [i for i, r in enumerate(rows) if 'phase_embed_fwd' in r[0]]
+idx = [i for i, r in enumerate(rows) if 'phase_embed_fwd' in r[0] or 'phase_embed_begin' in r[0]]
 for s in (which - 1, which, which + 1):
     seg = rows[idx[s]:idx[s + 1]]
     iv = sorted((r[1], r[2]) for r in seg)
