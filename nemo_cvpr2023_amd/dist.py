@@ -186,7 +186,7 @@ class ShardedNemo:
         return ShardInfo(kr=d['kr'], mr=d['mr'], vr=d['vr'], n_global=d['n_global'], comm=self._comm,
                          comm_small=self._comm_small if self.shard_mode == 'split' else None,
                          comm_bucket=self._comm_small if self.shard_mode == 'buckets' else None, pad=pad,
-                         capturable=self.capturable)
+                         capturable=self.capturable, live=self.collectives)
 
     def _sharder(self):
         """Draw the GLOBAL (view, frame) batch from the CPU RNG (identical on every rank) and keep

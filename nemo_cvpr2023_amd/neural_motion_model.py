@@ -65,8 +65,11 @@ class ShardInfo:
     gradients together with the loss scalars.  The single-process default is the identity."""
 
     def __init__(self, kr=1.0, mr=1.0, vr=1.0, n_global=None, comm=None, comm_small=None, comm_bucket=None, pad=0,
-                 capturable=False):
+                 capturable=False, live=True):
         self.kr, self.mr, self.vr, self.n_global, self.comm = kr, mr, vr, n_global, comm
+        # False: `comm` / `comm_small` / `comm_bucket` skip their collectives (bench.py's compute-only pass) -- part of the
+        # graph key: a step captured with its collectives inside must not be replayed for the other setting
+        self.live = bool(live)
         # the collectives may be captured into a HIP graph (RCCL; not gloo, whose device collectives go through the host)
         self.capturable = bool(capturable)
         self.comm_small = comm_small          # all-reduce of a small device tensor (the loss scalars)
@@ -731,7 +734,8 @@ class MultiViewModel(nn.Module):
             vi = torch.nn.functional.pad(vi, (0, N - Nv))         # (view 0, frame 0): valid memory, masked out
             fi = torch.nn.functional.pad(fi, (0, N - Nv))
             sh = ShardInfo(kr=sh.kr, mr=N / float(sh.n_global), vr=sh.vr, n_global=sh.n_global, comm=sh.comm,
-                           comm_small=sh.comm_small, comm_bucket=sh.comm_bucket, pad=sh.pad, capturable=sh.capturable)
+                           comm_small=sh.comm_small, comm_bucket=sh.comm_bucket, pad=sh.pad, capturable=sh.capturable,
+                           live=sh.live)
         w = e._ws(max(N, 1))
         e.scal = w['scal']               # (a replayed graph wrote this workspace's slots)
         e.sync_betas()                   # host-side state a captured graph cannot re-read (checkpoint load, eval)
@@ -859,7 +863,7 @@ class MultiViewModel(nn.Module):
                 return
             # everything the captured launches bake in besides device-resident inputs: the mode, the shard
             # normalisers, the engine switches of the public NemoV2 setters, the loss weights and loss type
-            key = (N, bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, part, early, padded,
+            key = (N, bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, sh.live, part, early, padded,
                    e.detach_articulation, e.start_global_traj_anywhere, has_inst, self._weights_key(),
                    tuple((s_['offset'], s_['numel']) for s_ in segs) if in_graph_adam else None)
             cap = w['cap']
