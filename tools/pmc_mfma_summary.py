@@ -23,8 +23,10 @@ def load(path):
 m = load(os.path.join(G, 'pmc_mfma', 'm_counter_collection.csv'))
 lp = os.path.join(G, 'pmc_lds', 'l_counter_collection.csv')
 l = load(lp) if os.path.exists(lp) else {}          # (the LDS pass is optional)
-print('| kernel | blocks | launches | GPU cycles | MFMA pipe busy | executed GFLOP | LDS bank-conflict cycles / LDS active cycles |')
-print('|---|---:|---:|---:|---:|---:|---:|')
+has16 = any('SQ_INSTS_VALU_MFMA_MOPS_BF16' in v for v in m.values())
+print('| kernel | blocks | launches | GPU cycles | MFMA pipe busy | executed GFLOP (fp32 MFMA)' + (' | executed GFLOP (bf16 MFMA)' if has16 else '')
+      + ' | LDS bank-conflict cycles / LDS active cycles |')
+print('|---|---:|---:|---:|---:|---:|---:|' + ('---:|' if has16 else ''))
 rows = []
 for k, v in m.items():
     if not v.get('SQ_VALU_MFMA_BUSY_CYCLES'):
@@ -34,6 +36,7 @@ for k, v in m.items():
     lv = l.get(k, {})
     conf = lv.get('SQ_LDS_BANK_CONFLICT', 0.0) / max(lv.get('SQ_LDS_IDX_ACTIVE', 0.0), 1.0)
     rows.append((cyc * v['_n'], f"| `{k[0]}` | {k[1]} | {v['_n']} | {cyc:,.0f} | {busy:.1f} % | "
-                 f"{v.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) * 512 / 1e9:.2f} | {conf:.3f} |"))
+                 f"{v.get('SQ_INSTS_VALU_MFMA_MOPS_F32', 0) * 512 / 1e9:.2f} | "
+                 + (f"{v.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0) * 512 / 1e9:.2f} | " if has16 else '') + f"{conf:.3f} |"))
 for _, line in sorted(rows, reverse=True):
     print(line)
