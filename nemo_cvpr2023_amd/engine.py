@@ -565,45 +565,57 @@ class FitEngine:
                     Cb=w['H3b'], CbT=T('H3bT'))
         self.gemm16(r, 147, h, w['H3b'], wb['head'], dptr(w['HEAD']), HEAD_LD, bias=self.p(lm + 'rot_out.bias'))
 
-    def _backward_mlp_b16(self, w, N, view_idx, frame_idx, raw_phase, nout, nbias):
+    def _backward_mlp_b16(self, w, N, view_idx, frame_idx, raw_phase, nout, nbias, stages=(0, 1, 2), bucketed=False):
         """backward_mlp on the bf16-in-memory chain.  Every product is C = A B^T with k-contiguous bf16 operands:
         dX_l = dY_l (W_l^T)^T reads dY_l's plain copy and the transposed weight copy; dW_l = dY_l^T X_l reads the two
-        TRANSPOSED activation copies (K = rows)."""
+        TRANSPOSED activation copies (K = rows).  ``stages`` / ``bucketed`` as in backward_mlp: a bucketed (sharded) step
+        runs the three stages as separate calls and wants each stage's bias column sums flushed at its end."""
         L, lm, h, r = self.lib, 'learned_motion.', self.h, N + 1
-        if getattr(self, '_wbT_fresh', False):
-            wb = self._wb                     # cast in this step's forward (_forward_nets_b16)
-        else:
-            wb = self._weights_b16(True)
+        if 0 in stages and not getattr(self, '_wbT_fresh', False):
+            self._weights_b16(True)           # (no training forward ran in front of this backward: warm-up after an eval pass)
         self._wbT_fresh = False
-        self._cast(r, nout, dptr(w['dHEAD']), HEAD_LD, w['dHEADb'], 0)
-        self._cast(r, nout, dptr(w['dHEAD']), HEAD_LD, w['dHEADbT'], 1)
+        wb = self._wb                         # transposed copies cast in this step's forward (_forward_nets_b16) or just above
         cs = self._colsums
-        # heads
-        self.gemm16(nout, h, r, w['dHEADbT'], w['H3bT'], self.g(lm + 'rot_out.weight'), h, out_mode=1)
-        cs.append((dptr(w['dHEAD']), r, nbias, HEAD_LD, self.g(lm + 'rot_out.bias')))
         # The activation gradients of the two hidden layers exist as bf16 copies only; their bias gradients come from the
         # per-band column sums the same launches leave (nemo_gemm_bf16mem(colsum)): 2 ceil(r / 64) rows instead of r
         R = int(L.nemo_gemm_colsum_rows(r))
-        self.gemm16(r, h, nout, w['dHEADb'], wb['headT'], None, h, mask=dptr(w['H3b']), ldmask=w['H3b'].stride(0),
-                    mask_mode=17, Cb=w['dHb'], CbT=w['dHbT'], colsum=w['cs4'])
-        # layer 4
-        self.gemm16(h, h, r, w['dHbT'], w['H2bT'], self.g(lm + 'net.net.4.weight'), h, out_mode=1)
-        cs.append((dptr(w['cs4']), R, h, h, self.g(lm + 'net.net.4.bias')))
-        self.gemm16(r, h, h, w['dHb'], wb['4T'], None, h, mask=dptr(w['H2b']), ldmask=w['H2b'].stride(0),
-                    mask_mode=17, Cb=w['dH_bb'], CbT=w['dH_bbT'], colsum=w['cs2'], tag='gemm_mlp_hidden_dx')
-        # layer 2
-        self.gemm16(h, h, r, w['dH_bbT'], w['H1bT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1)
-        cs.append((dptr(w['cs2']), R, h, h, self.g(lm + 'net.net.2.bias')))
-        self.gemm16(r, h, h, w['dH_bb'], wb['2T'], dptr(w['dH_c']), h, mask=dptr(w['H1b']), ldmask=w['H1b'].stride(0),
-                    mask_mode=17, Cb=None, CbT=None, colsum=w['cs0'])
+
+        def end_of_stage():
+            if bucketed:
+                self.flush_colsums()
+
+        if 0 in stages:
+            self._cast(r, nout, dptr(w['dHEAD']), HEAD_LD, w['dHEADb'], 0)
+            self._cast(r, nout, dptr(w['dHEAD']), HEAD_LD, w['dHEADbT'], 1)
+            # heads
+            self.gemm16(nout, h, r, w['dHEADbT'], w['H3bT'], self.g(lm + 'rot_out.weight'), h, out_mode=1)
+            cs.append((dptr(w['dHEAD']), r, nbias, HEAD_LD, self.g(lm + 'rot_out.bias')))
+            self.gemm16(r, h, nout, w['dHEADb'], wb['headT'], None, h, mask=dptr(w['H3b']), ldmask=w['H3b'].stride(0),
+                        mask_mode=17, Cb=w['dHb'], CbT=w['dHbT'], colsum=w['cs4'])
+            # layer 4
+            self.gemm16(h, h, r, w['dHbT'], w['H2bT'], self.g(lm + 'net.net.4.weight'), h, out_mode=1)
+            cs.append((dptr(w['cs4']), R, h, h, self.g(lm + 'net.net.4.bias')))
+            self.gemm16(r, h, h, w['dHb'], wb['4T'], None, h, mask=dptr(w['H2b']), ldmask=w['H2b'].stride(0),
+                        mask_mode=17, Cb=w['dH_bb'], CbT=w['dH_bbT'], colsum=w['cs2'], tag='gemm_mlp_hidden_dx')
+            end_of_stage()
+        if 1 in stages:
+            # layer 2
+            self.gemm16(h, h, r, w['dH_bbT'], w['H1bT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1)
+            cs.append((dptr(w['cs2']), R, h, h, self.g(lm + 'net.net.2.bias')))
+            self.gemm16(r, h, h, w['dH_bb'], wb['2T'], dptr(w['dH_c']), h, mask=dptr(w['H1b']), ldmask=w['H1b'].stride(0),
+                        mask_mode=17, Cb=None, CbT=None, colsum=w['cs0'])
+            end_of_stage()
+        if 2 not in stages:
+            return
         # layer 0: as before (see _forward_nets_b16)
         self._linear_bwd_params(r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h, self.g(lm + 'net.net.0.weight'), None)
         cs.append((dptr(w['cs0']), R, h, h, self.g(lm + 'net.net.0.bias')))
         self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din, dptr(w['dX']), self.ldx,
                   dense=True)
-        if not self.cs_in_phase:
+        cs_in = self.cs_in_phase and not bucketed
+        if not cs_in:
             self.flush_colsums()
-        self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=self.cs_in_phase)
+        self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=cs_in)
 
     def gemm_grouped(self, problems, dense=True):
         """problems: list of (ta, tb, M, N, K, A, lda, B, ldb, C, ldc, out_mode) -- independent products of one layout in
@@ -988,8 +1000,8 @@ class FitEngine:
         # exact 0 there), so its column sum is skipped unless the global trajectory is un-anchored.
         nout = 147 if has_trans_grad else 144
         nbias = 147 if (has_trans_grad and self.start_global_traj_anywhere) else 144
-        if self.b16mem and not bucketed and tuple(stages) == (0, 1, 2):
-            return self._backward_mlp_b16(w, N, view_idx, frame_idx, raw_phase, nout, nbias)
+        if self.b16mem:
+            return self._backward_mlp_b16(w, N, view_idx, frame_idx, raw_phase, nout, nbias, tuple(stages), bucketed)
         # Schedule.  Large batches (each hidden-layer GEMM fills the machine; co-scheduling two of them measured no gain):
         # the activation-gradient chain (dX) and the parameter-gradient GEMMs (dW) alternate on the main stream up to
         # layer 2; then one fork: the (small) layer-0 dW GEMM and the batched bias column sums on the side stream, the

@@ -357,6 +357,103 @@ def test_sharded_gradients_and_parameters_equal_single_process(mode):
         assert float(np.abs(got[k] - v).max()) <= 2.05 * lr + 1e-6 * float(np.abs(v).max()), k
 
 
+def _bf16_worker(rank, world, port, q, mode, anchored):
+    """bf16 operands in memory (args.gemm_dtype = 'bf16') x sharded launch structures: ADVICE r03 (high) -- the bucketed
+    backward used to read fp32 activations the bf16 chain never writes (every MotionNet gradient silently zero)."""
+    try:
+        from nemo_cvpr2023_amd.dist import ShardedNemo
+        dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+        args = _args(3)
+        args.gemm_dtype = 'bf16'
+        seqs = syn.SyntheticSequences(V, T, seed=1234)
+        m = ShardedNemo(3, args, seqs, 'cuda:0', rank=rank, world=world, seed=0,
+                        smpl_assets=syn.make_smpl_assets(NV, seed=1), vposer_state=syn.make_vposer_state(),
+                        gmm=syn.make_gmm())
+        assert m.model.engine.b16mem
+        m.model.start_global_traj_anywhere = not anchored
+        m.set_shard_mode(mode)
+        with torch.no_grad():
+            m.model.learned_motion.rot_out.weight.mul_(2e3)
+        e = m.model.engine
+        shared = [n for n in e.layout.groups['motion']]
+        rec = []
+        for it in range(4):             # the same full-batch variant four times: eager, then captured and replayed
+            before = {k: v.numpy().copy() for k, v in m.gather_state_dict().items()}
+            ld, _ = m.step(None, None, full_batch=True)
+            torch.cuda.synchronize()
+            grads = {n: e.view(n, e.grads).detach().cpu().numpy().copy() for n in shared}
+            rec.append((before, grads, {k: float(v) for k, v in ld.items()}))
+        for vi, fi in _draws(2):        # padded minibatch launches
+            before = {k: v.numpy().copy() for k, v in m.gather_state_dict().items()}
+            ld, _ = m.step(vi, fi)
+            torch.cuda.synchronize()
+            grads = {n: e.view(n, e.grads).detach().cpu().numpy().copy() for n in shared}
+            rec.append((before, grads, {k: float(v) for k, v in ld.items()}))
+        q.put((rank, rec))
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as exc:
+        q.put((rank, repr(exc)))
+        raise
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('anchored', [False, True])
+@pytest.mark.parametrize('mode', ['single', 'split', 'buckets'])
+def test_sharded_bf16_gradients_equal_the_unsharded_bf16_model(mode, anchored):
+    """Every shared (all-reduced) gradient of the bf16-in-memory chain under every sharded launch structure -- one launch,
+    two halves ('split': the transposed weight copies are cast in the first half and consumed in the second), three
+    bucket stages -- against the single-process bf16 model stepping from the same gathered state: non-zero, and equal
+    to it up to the summation order of a rank's GEMMs (same bf16-rounded operands on both sides): 2e-2 of a tensor's scale
+    with the trajectory un-anchored.  Anchored (the default, trans - trans_0, :3755-3766) every rank carries its own
+    "phase 0" row whose head gradient is -sum of ITS samples' translation gradients; the bf16 chain rounds that row to
+    bf16 per rank, and bf16(a) + bf16(b) differs from the single process's bf16(a + b) by 2^-9 of the PARTIAL sums, which
+    largely cancel -- a rounding property of the sharded bf16 formulation, not of a launch structure (the same numbers in
+    all three modes, with and without graphs): there the gate is the bf16 one of tests/test_gpu_bf16.py (cosine > 0.99,
+    entries within 0.15 of the tensor's scale)."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV3
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, world, port, q, mode, anchored)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    assert all(len(r) == 2 and not isinstance(r[1], str) for r in res), res
+    res = sorted(res, key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    args = _args(3)
+    args.gemm_dtype = 'bf16'
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    m = NemoV3(args, seqs, 'cuda:0', smpl_assets=syn.make_smpl_assets(NV, seed=1), vposer_state=syn.make_vposer_state(),
+               gmm=syn.make_gmm())
+    named = dict(m.named_parameters())
+    m.start_global_traj_anywhere = not anchored
+    steps = [(None, None)] * 4 + _draws(2)
+    for s_, (vi, fi) in enumerate(steps):
+        before = res[0][1][s_][0]
+        m.load_state_dict({k: torch.tensor(v) for k, v in before.items()}, strict=False)
+        ld, _ = m.step(vi, fi, full_batch=vi is None)
+        for r in range(world):
+            got_l = res[r][1][s_][2]
+            for k in ('kp_loss', 'vp_recon_loss', 'vp_kl_loss', 'gmm_loss', 'total_loss'):
+                assert abs(got_l[k] - float(ld[k])) <= 2e-3 * max(abs(float(ld[k])), 1e-6), (s_, r, k, got_l[k], float(ld[k]))
+            for k, gv in res[r][1][s_][1].items():
+                want = named[k].grad.detach().cpu().numpy()
+                scale = float(np.abs(want).max())
+                if k.endswith('weight') and 'net.net' in k:
+                    assert float(np.abs(gv).max()) > 0 and scale > 0, (s_, r, k)      # (the bug: exact zeros)
+                err = float(np.abs(gv - want).max())
+                if anchored:
+                    cos = float((gv * want).sum() / max(np.linalg.norm(gv) * np.linalg.norm(want), 1e-30))
+                    assert err <= 0.15 * scale + 1e-12 and (cos > 0.99 or scale == 0), (s_, r, k, err, scale, cos)
+                else:
+                    assert err <= 2e-2 * scale + 1e-12, (s_, r, k, err, scale)
+
+
 B60 = 80
 
 
