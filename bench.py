@@ -3,14 +3,6 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-With N > 1 and no launcher environment (``WORLD_SIZE`` unset) this process starts N ranks itself --
-``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` as a CHILD
-process, before anything here touches the GPU -- and exits with the children's code.  Launched by
-``torch.distributed.run`` directly (the driver's way) the ranks run as they are.  Either way every rank checks
-that the world it sees is the world it was asked for (backend ``nccl`` = RCCL, ``world_size == --gpus``, one
-distinct device per rank) and rank 0 prints ``ranks_seen``; fewer visible GPUs than ``--gpus`` is an error
-(exit code 3), never a silent single-GPU number.
-
 Workload (config.workload): the Baseball-Pitch fit of BASELINE.json configs[1] -- 8 instances x 300
 frames, full batch N = 2400 (instance x frame) samples per step, NemoV2 with the published-run
 hyper-parameters (h_dim 1000, RBF 100, instance code 5, mse_robust, w_vp 10, w_vp_z 1, w_gmm 1; every
@@ -18,28 +10,45 @@ loss term evaluated as the reference does), 6890-vertex SMPL, fp32, synthetic SM
 random OpenPose targets (no dataset / licensed model files on the box).  One "step" = one
 ``model.step(update=True)``: forward, backward, Adam on all four optimisers, loss read-back.
 
-N > 1: strong scaling -- the same 8 x 300 problem sharded by instance over the ranks
-(nemo_cvpr2023_amd/dist.py).  The library default is ONE RCCL all-reduce per step (shared MLP gradient + loss
-scalars in one buffer); ``--shard-mode auto`` (the bench default for N > 1) times that against the two-collective
-variant (loss scalars reduced early on a side stream, see dist.py) for a few steps on the actual machine, takes
-the faster one on all ranks and reports both timings and ``collectives_per_step``.
-
 Output (rank 0, ONE JSON line): metric/value/... per the driver contract plus
-  roofline     -- the dominant kernel, timed live with HIP events on its launch stream (in a short
-                  instrumented pass of the same steps: the timed region replays a captured HIP graph);
-                  achieved = algorithmic FLOPs per launch / mean launch time vs the MFMA peak of the dtype;
-                  `step` = the whole step's algorithmic FLOPs / step time; `hbm` = counter bytes per step
-                  (profiles/) / step time vs 8 TB/s
-  cpu_baseline -- the CPU oracle ("port" of the reference PyTorch path) timed on this box's host cores:
-                  SURVEY 8(d) protocol, 3 warm-up + 10 timed steps at C2 full batch (N = 2400), C2 minibatch
-                  (N = 512) and C1 (1 x 30, default-v1), each in a child process with a wall-clock bound
+  roofline      -- the dominant kernel, timed live with HIP events on its launch stream (in a short
+                   instrumented pass of the same steps: the timed region replays a captured HIP graph);
+                   achieved = algorithmic FLOPs per launch / mean launch time vs the MFMA peak of the dtype;
+                   `step` = the whole step's algorithmic FLOPs / step time; `hbm` = counter bytes per step
+                   (profiles/) / step time vs 8 TB/s
+  cpu_baseline  -- the CPU oracle ("port" of the reference PyTorch path) timed on this box's host cores:
+                   SURVEY 8(d) protocol, 3 warm-up + 10 timed steps at C2 full batch (N = 2400), C2 minibatch
+                   (N = 512) and C1 (1 x 30, default-v1), each in a child process with a wall-clock bound
+  minibatch512  -- random minibatches of 512 (the published run's mode)
+  published_fit -- wall clock of the published schedule (300 warm-up + 1000 camera + 2000 minibatch-512 steps,
+                   run_scripts_examples/nemomocap-example.sh:10,17,30-33) through fit.run_fit, it/s per phase
+  c3_bf16, c4   -- BASELINE configs[2] (40 x 300, bf16 operands) and configs[3] (256 x 1024), each with its own
+                   roofline block; at N > 1 `c4` is the leg that has the work to scale
+  scaling_model -- N = 1: what one rank of 2 / 4 / 8 computes per step (measured here) -> predicted speed-ups;
+                   N > 1: per-rank compute and collective times of this run
+
+N > 1: strong scaling -- the same 8 x 300 problem sharded by instance over the ranks (nemo_cvpr2023_amd/dist.py),
+one process per GPU over RCCL.  The library default is ONE all-reduce per step (shared MLP gradient + loss scalars),
+captured INSIDE the step's HIP graph; ``--shard-mode auto`` times the alternatives on the machine and keeps the fastest.
+
+**A first multi-GPU run must not fail silently.**  Every rank process of an N > 1 run is a SUPERVISOR that never touches
+the GPU: it starts the measuring worker as a child process (fresh interpreter, never a re-exec) under a wall-clock bound
+and a no-progress watchdog, and the supervisors agree through the launcher's TCP store: if ANY rank's worker exits
+non-zero, hangs or aborts (a failed RCCL-in-graph capture is the known risk), all workers are stopped and restarted with
+``NEMO_GRAPH_COMM=0`` (graph, then eager collectives), then with ``NEMO_GRAPHS=0`` (no graphs at all).  Rank 0 prints the
+surviving attempt's line with ``"fallback"`` / ``"graph_comm"`` / ``"attempts"`` filled in.  With no launcher environment
+(``WORLD_SIZE`` unset) ``--gpus N`` starts the N supervisors itself through ``torch.distributed.run``.
+Fewer visible GPUs than ``--gpus`` is an error (exit code 3), never a silent single-GPU number.
 """
 import argparse
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -51,6 +60,9 @@ V0, T0 = 8, 300
 MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}
 HBM_PEAK_GBS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'traffic.json')
+# what a supervisor tries, in order (environment of the worker processes)
+ATTEMPTS = [('none', {}), ('NEMO_GRAPH_COMM=0', {'NEMO_GRAPH_COMM': '0'}),
+            ('NEMO_GRAPHS=0', {'NEMO_GRAPH_COMM': '0', 'NEMO_GRAPHS': '0'})]
 
 
 def step_flops(n, nv=6890, h=1000, din=105):
@@ -76,7 +88,7 @@ def _free_port():
     return p
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
@@ -99,15 +111,24 @@ def parse():
                          'default --steps: one region alone is at the mercy of a single scheduling hiccup)')
     ap.add_argument('--minibatch-steps', type=int, default=60,
                     help='extra, separately reported leg: random minibatches of 512 samples (the published run\'s mode); 0 = skip')
+    ap.add_argument('--no-extra-legs', action='store_true',
+                    help='skip the legs beyond the headline: published_fit, c3_bf16, c4, the scaling model')
+    ap.add_argument('--attempt-timeout', type=float, default=1500.0,
+                    help='N > 1: wall-clock bound of one attempt of the rank workers before the supervisors fall back')
+    ap.add_argument('--watchdog', type=float, default=420.0,
+                    help='N > 1: a worker that makes no progress for this many seconds exits non-zero instead of hanging')
     ap.add_argument('--spawn-selftest', action='store_true',
                     help='test aid: the N ranks only rendezvous (gloo, no GPU) and report ranks_seen')
+    ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)      # a supervisor's child: the measuring process
+    ap.add_argument('--attempt', default='main0', help=argparse.SUPPRESS)         # rendezvous prefix of this attempt
+    ap.add_argument('--phase', choices=['main', 'legs'], default='main', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-child', default='', help=argparse.SUPPRESS)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 # ----------------------------------------------------------------------------------------------- launcher
 def spawn_ranks(opts):
-    """Parent of an N-rank run.  Touches no GPU: ``device_count()`` does not initialise HIP on this image."""
+    """Parent of a self-launched N-rank run.  Touches no GPU: ``device_count()`` does not initialise HIP on this image."""
     if not opts.spawn_selftest:
         import torch
         have = torch.cuda.device_count()
@@ -122,7 +143,139 @@ def spawn_ranks(opts):
         env['NEMO_DIST_BACKEND'] = 'gloo'
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={opts.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    try:
+        return subprocess.run(cmd, env=env, timeout=len(ATTEMPTS) * opts.attempt_timeout + 300).returncode
+    except subprocess.TimeoutExpired:
+        sys.stderr.write('bench.py: the rank supervisors did not finish inside their own bounds\n')
+        return 4
+
+
+def _kill_tree(proc):
+    """Stop a worker and whatever it started (it runs in its own session / process group)."""
+    if proc.poll() is not None:
+        return
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            break
+        try:
+            proc.wait(timeout=10)
+            break
+        except subprocess.TimeoutExpired:
+            continue
+
+
+def rank_supervisor(opts):
+    """One per rank of an N > 1 run.  Never touches the GPU, never initialises a process group: it runs the measuring
+    worker as a child and agrees with the other ranks' supervisors through the launcher's TCP store on whether an
+    attempt succeeded everywhere.  Two phases: `main` (the headline line; falls back through ATTEMPTS) and `legs` (the
+    C4 leg, in the launch structure that survived; its failure costs the `c4` key, never the headline).  Returns the
+    process exit code; rank 0 prints the JSON line."""
+    import torch.distributed as dist
+    from datetime import timedelta
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    try:
+        store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), world_size=None, is_master=False,
+                              timeout=timedelta(seconds=60))
+        store = dist.PrefixStore('nemo_bench_supervisor', store)
+    except Exception as ex:           # no launcher store to agree through: run unsupervised (one attempt, as before round 4)
+        sys.stderr.write(f'bench.py[rank {rank}]: no launcher store ({ex!r}); running without the fallback supervisor\n')
+        return worker_main(opts)
+    me = os.path.abspath(__file__)
+    argv = [a for a in sys.argv[1:] if a != '--worker']
+
+    def run(tag, extra_env, phase):
+        """One attempt of one phase on every rank.  -> (status, parsed JSON line of rank 0's worker or None)."""
+        env = dict(os.environ, **extra_env)
+        env['NEMO_BENCH_ATTEMPT'] = tag
+        out = tempfile.NamedTemporaryFile('w+', prefix=f'nemo_bench_r{rank}_{tag}_', suffix='.out', delete=False)
+        proc = subprocess.Popen([sys.executable, me, '--worker', '--attempt', tag, '--phase', phase] + argv, env=env,
+                                stdout=out, start_new_session=True)
+        t0, status = time.monotonic(), None
+        fail_key, done_key = f'fail_{tag}', f'done_{tag}'
+        while status is None:
+            rc = proc.poll()
+            if rc is not None:
+                status = 'ok' if rc == 0 else f'rank {rank}: worker exit code {rc}'
+            elif time.monotonic() - t0 > opts.attempt_timeout:
+                status = f'rank {rank}: worker exceeded {opts.attempt_timeout:.0f} s'
+            elif store.check([fail_key]):
+                status = 'peer: ' + store.get(fail_key).decode()
+            else:
+                time.sleep(0.25)
+        if status == 'ok':
+            store.add(done_key, 1)
+            # ... everywhere?  (a peer may still fail, e.g. while tearing its communicator down)
+            while True:
+                if store.check([fail_key]):
+                    status = 'peer: ' + store.get(fail_key).decode()
+                    break
+                if store.add(done_key, 0) >= world:
+                    break
+                if time.monotonic() - t0 > opts.attempt_timeout + 120:
+                    status = f'rank {rank}: peers did not finish attempt {tag}'
+                    store.set(fail_key, status)
+                    break
+                time.sleep(0.25)
+        elif not status.startswith('peer'):
+            store.set(fail_key, status)
+        _kill_tree(proc)
+        line = None
+        if status == 'ok' and rank == 0:
+            out.seek(0)
+            lines = [l for l in out.read().splitlines() if l.startswith('{')]
+            line = json.loads(lines[-1]) if lines else None
+            if line is None:
+                status = 'rank 0: worker printed no JSON line'
+        out.close()
+        os.unlink(out.name)
+        if status != 'ok':
+            sys.stderr.write(f'bench.py[rank {rank}]: attempt {tag} failed -- {status}\n')
+        return status, line
+
+    log = []
+    for k, (label, extra) in enumerate(ATTEMPTS):
+        status, line = run(f'main{k}', extra, 'main')
+        log.append({'attempt': k, 'env': label, 'status': status})
+        if status != 'ok':
+            continue
+        legs = None
+        if not opts.no_extra_legs and not opts.spawn_selftest:
+            st2, legs = run(f'legs{k}', extra, 'legs')
+            if st2 != 'ok':
+                legs = {'c4': {'error': st2}}
+        if rank == 0:
+            line.update(fallback=label, graph_comm=(k == 0), attempts=log)
+            line.update(legs or {})
+            print(json.dumps(line), flush=True)
+        return 0
+    if rank == 0:
+        print(json.dumps({'metric': 'NeMo fit iters/sec (instances x frames/step), Baseball-Pitch', 'value': None,
+                          'unit': 'iters/s', 'n_gpus': world, 'error': 'every launch structure failed', 'attempts': log}),
+              flush=True)
+    return 6
+
+
+class Watchdog:
+    """A worker of an N > 1 run exits non-zero when it makes no progress for `seconds` (a hung collective or capture
+    would otherwise sit there until the supervisor's bound): `beat()` at every phase boundary."""
+
+    def __init__(self, seconds):
+        self.seconds, self.last, self.what = float(seconds), time.monotonic(), 'start'
+        if seconds > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def beat(self, what=''):
+        self.last, self.what = time.monotonic(), what
+
+    def _run(self):
+        while True:
+            time.sleep(2.0)
+            if time.monotonic() - self.last > self.seconds:
+                sys.stderr.write(f'bench.py watchdog: no progress for {self.seconds:.0f} s after "{self.what}"; exiting 17\n')
+                sys.stderr.flush()
+                os._exit(17)
 
 
 def check_world(opts, dist, torch, rank, world, local_rank):
@@ -140,6 +293,15 @@ def check_world(opts, dist, torch, rank, world, local_rank):
     if want == 'nccl' and len({d for _, _, d in seen}) != world:
         raise SystemExit(f'bench.py: {world} ranks share devices {[d for _, _, d in seen]}')
     return ranks
+
+
+def init_group(dist, backend, rank, world, attempt):
+    """Process group of attempt k: rendezvous keys under a prefix of their own (an earlier, failed attempt has left its
+    keys in the launcher's store)."""
+    from datetime import timedelta
+    base = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), world_size=None, is_master=False,
+                         timeout=timedelta(seconds=120))
+    dist.init_process_group(backend, store=dist.PrefixStore(f'nemo_bench_attempt{attempt}', base), rank=rank, world_size=world)
 
 
 # ----------------------------------------------------------------------------------------------- CPU leg
@@ -213,163 +375,415 @@ def cpu_baseline(opts):
             'cpu_count': ncpu, **({'error': full['error']} if 'error' in full else {})}
 
 
-# ----------------------------------------------------------------------------------------------- main
-def main():
-    opts = parse()
-    if opts.cpu_child:
-        return cpu_child(opts.cpu_child)
-    if opts.gpus < 1:
-        raise SystemExit('--gpus must be >= 1')
-    if 'WORLD_SIZE' not in os.environ and opts.gpus > 1:
-        sys.exit(spawn_ranks(opts))
+# ----------------------------------------------------------------------------------------------- measuring pieces
+class Ctx:
+    """What the legs of one worker share."""
+    pass
+
+
+def build_model(cx, V, T, dtype, batch_size=512):
+    """(model, engine) for a V x T synthetic fit on this worker's device -- ShardedNemo over the ranks when sharded."""
+    import torch
+    from nemo_cvpr2023_amd import synthetic as syn
+    args = syn.published_args(batch_size=batch_size, out_dir='')
+    args.gemm_dtype = dtype
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets = dict(smpl_assets=syn.make_smpl_assets(6890, seed=1), vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
+    torch.manual_seed(0)
+    if cx.sharded:
+        from nemo_cvpr2023_amd.dist import ShardedNemo
+        model = ShardedNemo(2, args, seqs, cx.device, rank=cx.rank, world=cx.world, seed=0, **assets)
+        return model, model.model.engine, args
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    model = NemoV2(args, seqs, cx.device, **assets)
+    return model, model.engine, args
+
+
+def release(cx, model):
+    import gc
+    import torch
+    if cx.sharded:
+        model.close()                  # captured graphs hold RCCL launches: released before the communicator
+    del model
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def timed(cx, fn, n):
+    """EXACTLY n calls bracketed by barrier + synchronize on both sides; max over ranks."""
+    import torch
+    cx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    cx.barrier()
+    dt = time.perf_counter() - t0
+    if cx.world > 1:
+        tmax = torch.tensor([dt], device=cx.device, dtype=torch.float64)
+        cx.dist.all_reduce(tmax, op=cx.dist.ReduceOp.MAX)
+        dt = float(tmax)
+    return dt, out
+
+
+def snapshot(model):
+    """Parameters, Adam moments and step counters of a model (restored around probes that take real update steps)."""
+    mm = model.model if hasattr(model, 'model') else model
+    e = mm.engine
+    return (e.params.clone(), e.exp_avg.clone(), e.exp_avg_sq.clone(), [dict(o.steps) for o in mm.optimizers],
+            [float(o.param_groups[0]['lr']) for o in mm.optimizers])
+
+
+def restore(model, snap):
+    mm = model.model if hasattr(model, 'model') else model
+    e = mm.engine
+    e.params.copy_(snap[0]); e.exp_avg.copy_(snap[1]); e.exp_avg_sq.copy_(snap[2])
+    for o, st, lr in zip(mm.optimizers, snap[3], snap[4]):
+        o.steps.update(st)
+        o.param_groups[0]['lr'] = lr
+    e.adam_table_invalidate()
+
+
+def choose_shard_mode(cx, model, step, V, T, want):
+    """--shard-mode auto: every candidate runs the SAME 4 + 10 update steps from the SAME state (snapshot / restore), so
+    their last total_loss must agree -- a candidate with broken numerics cannot win on time alone."""
+    modes = (['single', 'split'] + (['buckets'] if V * T // max(cx.world, 1) >= 4096 else [])) if want == 'auto' else [want]
+    snap = snapshot(model)
+    ms, last = {}, {}
+    for mode in modes:
+        restore(model, snap)
+        model.set_shard_mode(mode)
+        for _ in range(4):
+            step()
+        dt, out = timed(cx, step, 10)
+        ms[mode], last[mode] = round(1e3 * dt / 10, 4), float(out[0]['total_loss'])
+        cx.wd.beat(f'shard mode {mode}')
+    ref = last[modes[0]]
+    agree = {m_: abs(v - ref) <= 2e-3 * max(abs(ref), 1e-9) for m_, v in last.items()}
+    ok = [m_ for m_ in modes if agree[m_]]
+    best = min(ok, key=ms.get)       # max-over-ranks timings, identical losses on every rank: the same choice everywhere
+    restore(model, snap)
+    model.set_shard_mode(best)
+    return best, ms, {m_: {'total_loss_after_14_steps': last[m_], 'agrees_with_' + modes[0]: agree[m_]} for m_ in modes}
+
+
+def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype):
+    """The dominant tagged kernel of `timers` against the peak of its own mix of matrix pipes, + the whole step."""
+    best = None
+    for tag, evs in timers.items():
+        ms = [a.elapsed_time(b) for a, b, _ in evs]
+        tot = sum(ms)
+        if best is None or tot > best[0]:       # mean launch time and mean FLOPs per launch (chunked batches differ)
+            best = (tot, tag, sum(ms) / len(ms), sum(e_[2] for e_ in evs) / len(evs), len(ms))
+    if best is None:
+        return None
+    _, tag, mean_ms, flops, n = best
+    # Price every part of the kernel against the pipe it runs on: with bf16 the pose blends and the vertex->joint adjoint
+    # of the fused mesh kernel are bf16 work, its skinning / L1 stay on the fp32 pipe.  The peak quoted is the rate at
+    # which the kernel's own mix of work would run with both pipes at their peaks (harmonic mix; = the fp32 peak for
+    # the fp32 build).
+    f_step, parts = step_flops(V * T // cx.world if cx.world > 1 else V * T)
+    pipes = engine.kernel_flops_by_pipe(tag, flops)
+    kpeak = flops / sum(f / MFMA_PEAK_TFLOPS[d] for d, f in pipes.items())
+    achieved = flops / (mean_ms * 1e-3) / 1e12
+    traffic = {}
+    if os.path.exists(TRAFFIC_FILE):
+        traffic = json.load(open(TRAFFIC_FILE)).get(f'{V}x{T}x{cx.world}x{dtype}', {})
+    ktr = traffic.get('kernels', {}).get(tag)
+    mesh_b16 = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh']).get('bf16', 0.0)
+    on_bf16 = (mesh_b16 + parts['blend_adjoint'] + parts['mlp'] + parts['vposer']) if dtype == 'bf16' else 0.0
+    step_peak = f_step / (on_bf16 / MFMA_PEAK_TFLOPS['bf16'] + (f_step - on_bf16) / MFMA_PEAK_TFLOPS['f32'])
+    roof = {'kernel': tag, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(kpeak, 1),
+            'unit': 'TFLOP/s', 'frac': round(achieved / kpeak, 4),
+            'pipes': {d: round(f / 1e9, 2) for d, f in pipes.items()},
+            'peak_note': 'fp32 MFMA peak' if len(pipes) == 1 and 'f32' in pipes else
+                         'harmonic mix of the bf16 (2500) and fp32 (157.3) MFMA peaks over this kernel\'s GFLOP per pipe '
+                         '(`pipes`); the fp32 skinning part bounds it',
+            'traffic': ktr, 'traffic_source': traffic.get('source') if ktr else None,
+            'launches': n, 'mean_launch_ms': round(mean_ms, 4), 'flops_per_launch': flops,
+            'timed_in': f'{n_inst} instrumented (un-captured) steps after the timed region',
+            'per_kernel_ms_per_step': {t: round(sum(a.elapsed_time(b) for a, b, _ in e_) / n_inst, 4)
+                                       for t, e_ in timers.items()},
+            # the whole step against both roofs: algorithmic FLOPs of one rank's step / step time against the peak of
+            # its own mix of pipes (fp32 build: the fp32 MFMA peak), and counter-measured HBM-side bytes per step
+            # (separate --pmc passes, profiles/) / step time
+            'step': {'flops': f_step, 'achieved': round(f_step / (ms_per_step * 1e-3) / 1e12, 2),
+                     'peak': round(step_peak, 1), 'unit': 'TFLOP/s',
+                     'frac': round(f_step / (ms_per_step * 1e-3) / 1e12 / step_peak, 4),
+                     'gflop_on_bf16_pipe': round(on_bf16 / 1e9, 2),
+                     'flops_parts': {k: round(v / 1e9, 2) for k, v in parts.items()}},
+            'hbm': None}
+    if traffic.get('step_bytes'):
+        gbs = traffic['step_bytes'] / (ms_per_step * 1e-3) / 1e9
+        roof['hbm'] = {'bytes_per_step': traffic['step_bytes'], 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS,
+                       'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'source': traffic.get('source')}
+    roof['hbm_frac'] = roof['hbm']['frac'] if roof['hbm'] else None
+    return roof
+
+
+def instrumented(cx, engine, step, n_inst):
+    """The production step replays a captured HIP graph (events cannot be recorded inside one), so the same steps are run
+    once more, un-captured, with HIP events around the tagged kernels on their launch streams.  Not part of `value`."""
+    engine.timers = {}
+    for _ in range(n_inst):
+        step()
+    cx.barrier()
+    timers, engine.timers = engine.timers, None
+    return timers
+
+
+def leg(cx, name, V, T, dtype, steps, warm, shard_mode='single'):
+    """A further BASELINE configuration as an extra key of the line: full-batch update steps of a V x T fit, timed like
+    the headline (barrier + synchronize, max over ranks), with its own roofline block."""
+    import torch
+    try:
+        model, engine, _ = build_model(cx, V, T, dtype)
+        if cx.sharded:
+            model.set_shard_mode(shard_mode)
+
+        def step():
+            return model.step(None, None, update=True, full_batch=True)
+        for _ in range(2):               # set-up: workspace + graph capture
+            step()
+        for _ in range(warm):
+            step()
+        dt, out = timed(cx, step, steps)
+        ms = 1e3 * dt / steps
+        timers = instrumented(cx, engine, step, 2)
+        res = {'value': round(steps / dt, 3), 'unit': 'iters/s', 'ms_per_step': round(ms, 3), 'steps': steps, 'warmup': warm,
+               'dtype': dtype, 'samples_per_s': round(V * T * steps / dt, 1),
+               'workload': f'{V} instances x {T} frames full batch (N={V * T}), published hyper-parameters, all loss terms',
+               'final_total_loss': float(out[0]['total_loss']),
+               'roofline': roofline_block(cx, engine, timers, 2, ms, V, T, dtype)}
+        if cx.sharded:
+            res['shard_mode'] = model.shard_mode
+            res.update(shard_probe(cx, model, step, steps))
+        release(cx, model)
+        cx.wd.beat(f'leg {name}')
+        return res
+    except Exception as ex:          # a leg must never take the headline down
+        import traceback
+        traceback.print_exc()
+        if cx.world > 1:
+            raise                    # (ranks must stay in step: let the supervisor fall back)
+        return {'error': repr(ex)[:300]}
+
+
+def shard_probe(cx, model, step, steps):
+    """What one rank computes per step without any collective, and what the collective costs alone -- so that a multi-GPU
+    number can be read as  step = compute + (un-hidden part of the) collective.  The compute-only steps would let the
+    replicas drift apart (Adam on un-reduced gradients): the model's state is restored afterwards."""
+    import torch
+    dist = cx.dist
+    n_probe = max(5, min(50, steps))
+    snap = snapshot(model)
+    try:
+        model.collectives = False                             # the sharded code path with the collectives skipped
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_probe):
+            step()
+        torch.cuda.synchronize()
+        compute_ms = 1e3 * (time.perf_counter() - t0) / n_probe
+    finally:
+        model.collectives = True
+        restore(model, snap)
+    a_, b_ = model._span
+    buf = torch.zeros(b_ - a_, device=cx.device)
+    for _ in range(5):
+        dist.all_reduce(buf)
+    cx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    coll_ms = 1e3 * (time.perf_counter() - t0) / 20
+    per_rank = [None] * cx.world
+    dist.all_gather_object(per_rank, {'rank': cx.rank, 'compute_ms': round(compute_ms, 4), 'collective_ms': round(coll_ms, 4),
+                                      'instances': model.plan.v_local, 'device': torch.cuda.current_device()})
+    worst = max(p_['compute_ms'] for p_ in per_rank)
+    coll = max(p_['collective_ms'] for p_ in per_rank)
+    return {'per_rank': per_rank, 'allreduce_bytes': int((b_ - a_) * 4),
+            'scaling_model': {'shard_step_ms': worst, 'allreduce_ms': coll,
+                              'predicted_ms_per_step_no_overlap': round(worst + coll, 4),
+                              'note': 'compute_ms = this rank\'s step with every collective stubbed out; collective_ms = '
+                                      'the all-reduce of the shared-gradient slice alone (back-to-back, synchronised); '
+                                      'the measured ms_per_step lies between max(compute) and compute + collective'}}
+
+
+def scaling_model_single_gpu(cx, headline_ms, c4_ms):
+    """N = 1: what ONE rank of a 2 / 4 / 8-GPU run computes per step, measured here (the k-instance problem on this
+    GPU), and the speed-up that predicts once a 9 MB gradient all-reduce over xGMI is added un-hidden.  The headline
+    (8 x 300: a 1.5 ms step) is latency-bound -- one rank's share is a third of the step, not an eighth --, C4
+    (256 x 1024) is where the work to scale is."""
+    out = {'assumed_allreduce_ms': [0.1, 0.3],
+           'note': 'per_rank_compute_ms[W] = measured step time of one rank\'s share (V / W instances) on this GPU; '
+                   'predicted_speedup[W] = single-GPU step / (per-rank compute + an un-hidden 9 MB all-reduce at the two assumed '
+                   'costs); xGMI all-reduce times are NOT measured here (one GPU)'}
+    for name, V, T, base_ms, steps in (('headline_8x300', V0, T0, headline_ms, 30), ('c4_256x1024', 256, 1024, c4_ms, 3)):
+        if base_ms is None:
+            continue
+        per_rank, pred = {}, {}
+        for W in (2, 4, 8):
+            try:
+                model, engine, _ = build_model(cx, V // W, T, 'f32')
+
+                def step():
+                    return model.step(None, None, update=True, full_batch=True)
+                for _ in range(3):
+                    step()
+                dt, _ = timed(cx, step, steps)
+                per_rank[W] = round(1e3 * dt / steps, 4)
+                pred[W] = [round(base_ms / (per_rank[W] + a_), 2) for a_ in out['assumed_allreduce_ms']]
+                release(cx, model)
+            except Exception as ex:
+                per_rank[W] = {'error': repr(ex)[:200]}
+            cx.wd.beat(f'scaling model {name} W={W}')
+        out[name] = {'single_gpu_ms_per_step': round(base_ms, 4), 'per_rank_compute_ms': per_rank, 'predicted_speedup': pred}
+    return out
+
+
+def published_fit(cx):
+    """The published schedule end to end (nemomocap-example.sh:10,17,30-33): eval at init, 300 warm-up iterations, 1000
+    camera-fit iterations, 2000 minibatch-512 steps with the script's evaluation cadence -- through fit.run_fit."""
+    import torch
+    from nemo_cvpr2023_amd import fit
+    try:
+        model, engine, args = build_model(cx, V0, T0, 'f32')
+        args.warmup_step, args.opt_cam_step, args.n_steps = 300, 1000, 2000
+        torch.manual_seed(0)
+        # set-up outside the clock (like the capture steps of the headline): workspaces + graphs of the three phases
+        model.warmup(3); model.opt_cam(3)
+        for _ in range(3):
+            model.step(*model.draw_batch())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = fit.run_fit(model, args, out_dir=None, evaluate=None)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ph = res['phase_seconds']
+        out = {'wall_seconds': round(wall, 3), 'schedule': {'warmup': 300, 'opt_cam': 1000, 'steps': 2000, 'batch': 512},
+               'phases': {k: {'seconds': round(v, 4), 'iters': n, 'iters_per_s': round(n / v, 1), 'ms_per_iter': round(1e3 * v / n, 4)}
+                          for (k, v), n in zip(ph.items(), (300, 1000, 2000))},
+               'final_total_loss': res['losses']['total_loss'][-1], 'final_warmup_loss': res['warmup_losses'][-1],
+               'final_cam_loss': res['cam_losses'][-1],
+               'note': 'fit.run_fit on 8 x 300 synthetic sequences: host-drawn batches (CPU RNG, the script\'s order), evaluation '
+                       'steps at step 0 and every 500th, no checkpoints / metrics written; warm-up and camera fit run as '
+                       'captured iterations whose losses are read once per phase'}
+        release(cx, model)
+        cx.wd.beat('published_fit')
+        return out
+    except Exception as ex:
+        import traceback
+        traceback.print_exc()
+        return {'error': repr(ex)[:300]}
+
+
+# ----------------------------------------------------------------------------------------------- the measuring process
+def worker_main(opts):
     V, T = opts.instances, opts.frames
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != opts.gpus:
         raise SystemExit(f'bench.py: --gpus {opts.gpus} but WORLD_SIZE={world}')
+    attempt = opts.attempt
 
     import torch
     import torch.distributed as dist
+    cx = Ctx()
+    cx.wd = Watchdog(opts.watchdog if world > 1 else 0)
 
     if opts.spawn_selftest:                                   # rendezvous only (CPU test of the launcher)
-        dist.init_process_group('gloo')
+        fault = os.environ.get('NEMO_TEST_FAIL_CAPTURE', '')
+        if opts.worker:
+            init_group(dist, 'gloo', rank, world, attempt)
+        else:
+            dist.init_process_group('gloo')
         ranks = check_world(opts, dist, torch, rank, world, local_rank)
+        if fault and attempt == 'main0' and rank == 1:        # fault injection: this rank's first capture dies / hangs
+            if fault == 'hang':
+                time.sleep(3600)
+            os._exit(23)
+        dist.barrier()
         if rank == 0:
-            print(json.dumps({'selftest': True, 'n_gpus': world, 'ranks_seen': ranks}))
+            print(json.dumps({'selftest': True, 'n_gpus': world, 'ranks_seen': ranks}), flush=True)
         dist.destroy_process_group()
-        return
+        return 0
 
-    from nemo_cvpr2023_amd import synthetic as syn
+    from nemo_cvpr2023_amd import synthetic as syn            # noqa: F401  (import errors before any rendezvous)
     have = torch.cuda.device_count()
     backend = os.environ.get('NEMO_DIST_BACKEND', 'nccl')
     if have < (world if backend == 'nccl' else 1):
         raise SystemExit(f'bench.py: {world} ranks but {have} GPU(s) visible')
-    device = f'cuda:{local_rank % have}'
-    torch.cuda.set_device(device)
+    cx.device = f'cuda:{local_rank % have}'
+    torch.cuda.set_device(cx.device)
+    cx.rank, cx.world, cx.dist = rank, world, dist
     ranks_seen = [0]
-    # diagnostic: NEMO_BENCH_SHARD_OF_ONE=1 runs the SHARDED code path (ShardedNemo, the all-reduce, Adam after it, both
-    # shard modes) in a process group of one rank -- what the sharded host / launch structure costs by itself on one GPU
-    sharded = world > 1
+    # diagnostic: NEMO_BENCH_SHARD_OF_ONE=1 runs the SHARDED code path (ShardedNemo, the all-reduce, Adam after it, every
+    # shard mode) in a process group of one rank -- what the sharded host / launch structure costs by itself on one GPU
+    cx.sharded = world > 1
     if world == 1 and os.environ.get('NEMO_BENCH_SHARD_OF_ONE') == '1':
-        sharded = True
+        cx.sharded = True
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', str(_free_port()))
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group(backend, rank=0, world_size=1)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         # RCCL on ROCm.  (NEMO_DIST_BACKEND=gloo: test aid for boxes where several ranks must share one GPU,
         # which RCCL refuses.)
-        dist.init_process_group(backend)
+        if opts.worker:
+            init_group(dist, backend, rank, world, attempt)
+        else:
+            dist.init_process_group(backend)
         ranks_seen = check_world(opts, dist, torch, rank, world, local_rank)
-
-    args = syn.published_args(batch_size=512, out_dir='')
-    args.gemm_dtype = opts.dtype
-    seqs = syn.SyntheticSequences(V, T, seed=1234)
-    assets = dict(smpl_assets=syn.make_smpl_assets(6890, seed=1), vposer_state=syn.make_vposer_state(),
-                  gmm=syn.make_gmm())
-    torch.manual_seed(0)
-    if sharded:
-        from nemo_cvpr2023_amd.dist import ShardedNemo
-        model = ShardedNemo(2, args, seqs, device, rank=rank, world=world, seed=0, **assets)
-        engine = model.model.engine
-    else:
-        from nemo_cvpr2023_amd.neural_motion_model import NemoV2
-        model = NemoV2(args, seqs, device, **assets)
-        engine = model.engine
-
-    def step():
-        return model.step(None, None, update=True, full_batch=True)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    cx.barrier = barrier
 
-    def timed(n):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            out = step()
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax)
-        return dt, out
+    if opts.phase == 'legs':         # (a supervisor's second child: the C4 leg alone, as {'c4': {...}})
+        res = {'c4': leg(cx, 'c4', 256, 1024, 'f32', 3, 2)}
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        dist.destroy_process_group()
+        return 0
+
+    model, engine, args = build_model(cx, V, T, opts.dtype)
+    cx.wd.beat('model built')
+
+    def step():
+        return model.step(None, None, update=True, full_batch=True)
 
     # set-up: the first calls of a (batch size, mode) variant allocate its workspace and capture its HIP graph
     # (like a compile step); they are not part of the warm-up / timed protocol below
-    shard_modes = None
-    if sharded:
+    shard_modes = mode_check = None
+    if cx.sharded:
         # auto: one collective per step against the early loss all-reduce against three gradient buckets behind the backward.
-        # With RCCL every mode is ONE captured launch per step (collectives inside the graph); where they are not capturable
-        # (gloo) the three-bucket layout costs two more launches per step and is only tried for long per-rank steps
-        # -- and in any case only for long per-rank steps: in a group of one it needs > 150 us of hidden collective per step to
-        # catch up with `split` (0.67 against 0.52 ms at one instance), more than the whole 9 MB all-reduce takes
-        modes = (['single', 'split'] + (['buckets'] if V * T // max(world, 1) >= 4096 else [])) \
-            if opts.shard_mode == 'auto' else [opts.shard_mode]
-        shard_modes = {}
-        for mode in modes:
-            model.set_shard_mode(mode)
-            for _ in range(4):
-                step()
-            shard_modes[mode] = round(1e3 * timed(10)[0] / 10, 4)
-        best = min(shard_modes, key=shard_modes.get)       # max-over-ranks timings: the same choice on every rank
-        model.set_shard_mode(best)
+        # With RCCL every mode is ONE captured launch per step (collectives inside the graph); the three-bucket layout is
+        # only tried for long per-rank steps: in a group of one it needs > 150 us of hidden collective per step to catch up
+        # with `split` (0.67 against 0.52 ms at one instance), more than the whole 9 MB all-reduce takes
+        for _ in range(2):
+            step()
+        cx.wd.beat('first sharded steps')
+        _, shard_modes, mode_check = choose_shard_mode(cx, model, step, V, T, opts.shard_mode)
     for _ in range(3):
         step()
     for _ in range(opts.warmup):
         step()
+    cx.wd.beat('warm-up')
     # EXACTLY --steps steps per timed region (barrier + synchronize on both sides, max over ranks); --repeat regions, the
     # median one is reported (all of them are listed in `repeat_ms_per_step`)
-    regions = []
-    for _ in range(max(1, opts.repeat)):
-        regions.append(timed(opts.steps))
+    regions = [timed(cx, step, opts.steps) for _ in range(max(1, opts.repeat))]
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     elapsed, (ld, _) = regions[order[len(order) // 2]]
     repeat_ms = [round(1e3 * r[0] / opts.steps, 4) for r in regions]
-
-    # ---- sharded runs: what one rank computes per step without any collective, and what the collective costs alone -- so
-    # that a multi-GPU number can be read as  step = compute + (un-hidden part of the) collective
-    shard_info = None
-    if sharded:
-        n_probe = max(10, min(50, opts.steps))
-        try:
-            model.collectives = False                             # the sharded code path with the collectives skipped
-            for _ in range(3):
-                step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n_probe):
-                step()
-            torch.cuda.synchronize()
-            compute_ms = 1e3 * (time.perf_counter() - t0) / n_probe
-        finally:
-            model.collectives = True
-        a_, b_ = model._span
-        buf = torch.zeros(b_ - a_, device=device)
-        for _ in range(5):
-            dist.all_reduce(buf)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            dist.all_reduce(buf)
-        torch.cuda.synchronize()
-        coll_ms = 1e3 * (time.perf_counter() - t0) / 20
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, {'rank': rank, 'compute_ms': round(compute_ms, 4), 'collective_ms': round(coll_ms, 4),
-                                          'instances': model.plan.v_local, 'device': torch.cuda.current_device()})
-        worst = max(p_['compute_ms'] for p_ in per_rank)
-        shard_info = {'per_rank': per_rank, 'allreduce_bytes': int((b_ - a_) * 4),
-                      'scaling_model': {'shard_step_ms': worst, 'allreduce_ms': max(p_['collective_ms'] for p_ in per_rank),
-                                        'predicted_ms_per_step_no_overlap': round(worst + max(p_['collective_ms'] for p_ in per_rank), 4),
-                                        'note': 'compute_ms = this rank\'s step with every collective stubbed out; collective_ms = '
-                                                'the all-reduce of the shared-gradient slice alone (back-to-back, synchronised); '
-                                                'the measured ms_per_step lies between max(compute) and compute + collective'}}
+    ms_per_step = 1e3 * elapsed / opts.steps
+    iters_per_s = opts.steps / elapsed
+    cx.wd.beat('timed regions')
 
     # ---- the published run's mode: random minibatches of 512 samples drawn like the script does (CPU RNG, views then frames)
     mini = None
@@ -377,90 +791,41 @@ def main():
         gen = torch.Generator().manual_seed(1234)
         draws = [(torch.randint(0, V, (512,), generator=gen), torch.randint(0, T, (512,), generator=gen))
                  for _ in range(opts.minibatch_steps + 12)]
-        mm = model.model if sharded else model
+        mm = model.model if cx.sharded else model
         for vi_, fi_ in draws[:12]:                     # set-up: workspaces + graph captures of the launch sizes
             model.step(vi_, fi_)
         stats0 = dict(mm.launch_stats)
-        barrier()
-        t0 = time.perf_counter()
-        for vi_, fi_ in draws[12:]:
-            model.step(vi_, fi_)
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax)
+        it = iter(draws[12:])
+        dt, _ = timed(cx, lambda: model.step(*next(it)), opts.minibatch_steps)
         rep = mm.launch_stats['replayed'] - stats0['replayed']
         oth = mm.launch_stats['other'] - stats0['other']
         mini = {'value': round(opts.minibatch_steps / dt, 2), 'unit': 'iters/s', 'ms_per_step': round(1e3 * dt / opts.minibatch_steps, 4),
                 'batch': 512, 'steps': opts.minibatch_steps, 'graph_replay_fraction': round(rep / max(rep + oth, 1), 3),
                 'note': 'random (view, frame) minibatches of 512 out of %d x %d, drawn on the host like '
                         'scripts/learned_multi_view_recon_nn.py:291-296; rank 0\'s launches' % (V, T)}
-    # Roofline leg: the production step replays a captured HIP graph (events cannot be recorded inside
-    # one), so the same steps are run once more, un-captured, with HIP events around the tagged kernels
-    # on their launch streams.  These instrumented steps are not part of `value`.
-    engine.timers = {}
-    n_inst = max(3, min(10, opts.steps))
-    for _ in range(n_inst):
-        step()
-    barrier()
-    timers, engine.timers = engine.timers, None
-    ms_per_step = 1e3 * elapsed / opts.steps
-    iters_per_s = opts.steps / elapsed
-    peak = MFMA_PEAK_TFLOPS[opts.dtype]
+        cx.wd.beat('minibatch leg')
 
-    # dominant tagged kernel (largest total time in the timed region)
-    roof = None
-    best = None
-    for tag, evs in timers.items():
-        ms = [a.elapsed_time(b) for a, b, _ in evs]
-        tot = sum(ms)
-        if best is None or tot > best[0]:       # mean launch time and mean FLOPs per launch (chunked batches differ)
-            best = (tot, tag, sum(ms) / len(ms), sum(e[2] for e in evs) / len(evs), len(ms))
-    if best is not None:
-        _, tag, mean_ms, flops, n = best
-        # Price every part of the kernel against the pipe it runs on: with --dtype bf16 only the pose blend of the fused
-        # mesh kernel is bf16 work, its skinning / L1 stay on the fp32 pipe (the vertex->joint adjoint: bf16 pipe, split precision).  The peak quoted is the rate at
-        # which the kernel's own mix of work would run with both pipes at their peaks (harmonic mix; = the fp32 peak
-        # for the fp32 build).
-        f_step, parts = step_flops(V * T // world if world > 1 else V * T)
-        pipes = engine.kernel_flops_by_pipe(tag, flops)
-        kpeak = flops / sum(f / MFMA_PEAK_TFLOPS[d] for d, f in pipes.items())
-        achieved = flops / (mean_ms * 1e-3) / 1e12
-        traffic = {}
-        if os.path.exists(TRAFFIC_FILE):
-            traffic = json.load(open(TRAFFIC_FILE)).get(f'{V}x{T}x{world}x{opts.dtype}', {})
-        ktr = traffic.get('kernels', {}).get(tag)
-        # the whole step, same pricing: which parts of step_flops() the bf16 build moves to the bf16 pipe
-        mesh_b16 = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh']).get('bf16', 0.0)
-        on_bf16 = (mesh_b16 + parts['blend_adjoint'] + parts['mlp'] + parts['vposer']) if opts.dtype == 'bf16' else 0.0
-        step_peak = f_step / (on_bf16 / MFMA_PEAK_TFLOPS['bf16'] + (f_step - on_bf16) / MFMA_PEAK_TFLOPS['f32'])
-        roof = {'kernel': tag, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(kpeak, 1),
-                'unit': 'TFLOP/s', 'frac': round(achieved / kpeak, 4),
-                'pipes': {d: round(f / 1e9, 2) for d, f in pipes.items()},
-                'peak_note': 'fp32 MFMA peak' if len(pipes) == 1 and 'f32' in pipes else
-                             'harmonic mix of the bf16 (2500) and fp32 (157.3) MFMA peaks over this kernel\'s GFLOP per pipe '
-                             '(`pipes`); the fp32 skinning part bounds it',
-                'traffic': ktr, 'traffic_source': traffic.get('source') if ktr else None,
-                'launches': n, 'mean_launch_ms': round(mean_ms, 4), 'flops_per_launch': flops,
-                'timed_in': f'{n_inst} instrumented (un-captured) steps after the timed region',
-                'per_kernel_ms_per_step': {t: round(sum(a.elapsed_time(b) for a, b, _ in e) / n_inst, 4)
-                                           for t, e in timers.items()},
-                # the whole step against both roofs: algorithmic FLOPs of one rank's step / step time against the peak of
-                # its own mix of pipes (fp32 build: the fp32 MFMA peak), and counter-measured HBM-side bytes per step
-                # (separate --pmc passes, profiles/) / step time
-                'step': {'flops': f_step, 'achieved': round(f_step / (ms_per_step * 1e-3) / 1e12, 2),
-                         'peak': round(step_peak, 1), 'unit': 'TFLOP/s',
-                         'frac': round(f_step / (ms_per_step * 1e-3) / 1e12 / step_peak, 4),
-                         'gflop_on_bf16_pipe': round(on_bf16 / 1e9, 2),
-                         'flops_parts': {k: round(v / 1e9, 2) for k, v in parts.items()}},
-                'hbm': None}
-        if traffic.get('step_bytes'):
-            gbs = traffic['step_bytes'] / (ms_per_step * 1e-3) / 1e9
-            roof['hbm'] = {'bytes_per_step': traffic['step_bytes'], 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS,
-                           'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'source': traffic.get('source')}
-        roof['hbm_frac'] = roof['hbm']['frac'] if roof['hbm'] else None
+    n_inst = max(3, min(10, opts.steps))
+    timers = instrumented(cx, engine, step, n_inst)
+    roof = roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, opts.dtype)
+    cx.wd.beat('roofline leg')
+
+    # ---- sharded runs: per-rank compute / collective (LAST on this model: the probe takes un-reduced update steps)
+    shard_info = shard_probe(cx, model, step, opts.steps) if cx.sharded else None
+    shard_mode = model.shard_mode if cx.sharded else None
+    release(cx, model)
+    cx.wd.beat('headline done')
+
+    # ---- the other BASELINE configurations and the end-to-end schedule, as extra keys of the same line
+    extra = {}
+    if not opts.no_extra_legs and (V, T, opts.dtype) == (V0, T0, 'f32'):
+        if world == 1 and not cx.sharded:
+            extra['published_fit'] = published_fit(cx)
+            extra['c3_bf16'] = leg(cx, 'c3_bf16', 40, 300, 'bf16', 10, 3)
+        if world == 1:               # (N > 1: the supervisor runs this leg as a run of its own, see rank_supervisor)
+            extra['c4'] = leg(cx, 'c4', 256, 1024, 'f32', 3, 2, shard_mode=shard_mode or 'single')
+        if world == 1 and not cx.sharded:
+            extra['scaling_model'] = scaling_model_single_gpu(cx, ms_per_step, extra['c4'].get('ms_per_step'))
 
     cpu = None
     if rank == 0 and world == 1 and not opts.no_cpu_baseline:
@@ -500,24 +865,48 @@ def main():
                                    'NemoV2 published hyper-parameters, all loss terms, 6890-vertex SMPL',
                        'instances': V, 'frames': T, 'samples_per_step': V * T, 'h_dim': args.h_dim,
                        'parallelism': f'instance-shard x{world}' if world > 1 else
-                       ('sharded code path in a process group of ONE rank (diagnostic)' if sharded else 'single GPU')},
+                       ('sharded code path in a process group of ONE rank (diagnostic)' if cx.sharded else 'single GPU')},
             'ranks_seen': ranks_seen,
             'repeat': len(repeat_ms), 'repeat_ms_per_step': repeat_ms,
             'minibatch512': mini,
             'final_total_loss': float(ld['total_loss']),
             'roofline': roof, 'cpu_baseline': cpu, 'torch_gpu_baseline': tgpu,
         }
-        if sharded:
+        out.update(extra)
+        if cx.sharded:
             out['backend'] = dist.get_backend()
             out['shard_modes_ms'] = shard_modes
-            out['shard_mode'] = model.shard_mode
-            out['collectives_per_step'] = {'single': 1, 'split': 2, 'buckets': 3}[model.shard_mode]
+            out['shard_mode_check'] = mode_check
+            out['shard_mode'] = shard_mode
+            out['collectives_per_step'] = {'single': 1, 'split': 2, 'buckets': 3}[shard_mode]
+            out['graph_comm'] = os.environ.get('NEMO_GRAPH_COMM', '1') != '0' and os.environ.get('NEMO_GRAPHS', '1') != '0'
             out.update(shard_info)
-        print(json.dumps(out))
-    if sharded:
-        model.close()                  # captured graphs hold RCCL launches: released before the communicator
+            if world > 1:
+                out['scaling_note'] = ('the headline (8 x 300, a 1.5 ms single-GPU step) is latency-bound: one rank\'s share of an 8-way '
+                                       'split still takes ~0.48 ms before any wire time (profiles/r03_shard_budget.md), i.e. <= ~3x; '
+                                       'the `c4` key (256 x 1024) is the configuration with the work to scale')
+        print(json.dumps(out), flush=True)
+    if cx.sharded:
         dist.destroy_process_group()
+    return 0
+
+
+def main():
+    opts = parse()
+    if opts.cpu_child:
+        return cpu_child(opts.cpu_child)
+    if opts.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if opts.worker:
+        return worker_main(opts)
+    if opts.gpus > 1:
+        if 'WORLD_SIZE' not in os.environ:
+            return spawn_ranks(opts)
+        if int(os.environ['WORLD_SIZE']) != opts.gpus:
+            raise SystemExit(f'bench.py: --gpus {opts.gpus} but WORLD_SIZE={os.environ["WORLD_SIZE"]}')
+        return rank_supervisor(opts)
+    return worker_main(opts)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

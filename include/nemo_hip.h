@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 8
+#define NEMO_ABI_VERSION 9
 int32_t nemo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -398,6 +398,26 @@ int32_t nemo_adam_step(int32_t n_seg, const nemo_adam_seg* segs /* HOST */, floa
 int32_t nemo_adam_step_dev(int32_t n_seg, const nemo_adam_seg* segs_dev, int64_t max_numel, float* params,
                            const float* grads, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
                            float eps, void* stream);
+
+/* nemo_adam_step_dev that does NOTHING when *skip_if_nonzero != 0 (device scalar; NULL = unconditional): the update of
+ * a captured warm-up step behind the device-side "nan gradient found" check of nemo/neural_motion_model.py:3497-3500 --
+ * the reference stops BEFORE opt.step(), so the parameters must not receive the poisoned update. */
+int32_t nemo_adam_step_dev_if(int32_t n_seg, const nemo_adam_seg* segs_dev, int64_t max_numel, float* params,
+                              const float* grads, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
+                              float eps, const float* skip_if_nonzero, void* stream);
+/* *count_out += number of NaN entries of x[0..n): `torch.isnan(param.grad).any()` over every parameter (:3497-3500) as
+ * one pass inside the captured step instead of a 9 MB scan plus a blocking read-back per warm-up iteration. */
+int32_t nemo_nan_count(const float* x, int64_t n, float* count_out, void* stream);
+
+/* Fit phases whose iterations the host does not have to see one by one (warmup :3455-3509, opt_cam :2869-2906: their
+ * losses are only returned as a list at the end): the phase's batches are drawn up front in the reference's RNG order
+ * and live in device memory as (steps, B) index tables, a device counter selects the row.
+ * nemo_seq_gather: view_out[0..B) = all_view[*counter][0..B), frame_out likewise (the step's kernels then read the
+ *                  usual index buffers: the captured graph of an iteration is the same for every iteration);
+ * nemo_seq_log:    log[*counter][0..n) = src[0..n), then *counter += 1 (one block; the last launch of an iteration). */
+int32_t nemo_seq_gather(const int64_t* all_view, const int64_t* all_frame, int64_t B, const int32_t* counter,
+                        int64_t* view_out, int64_t* frame_out, void* stream);
+int32_t nemo_seq_log(const float* src, int32_t n, float* log, int64_t ld, int32_t* counter, void* stream);
 
 /* First launch of a step (replaces two memsets and the per-step host-to-device copy of the Adam table of the
  * graph-replayed step, `zero_grad()` x k + the bias corrections of :3586-3592): zero-fills the byte ranges

@@ -32,7 +32,7 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 8        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 9        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -101,6 +101,10 @@ SIGNATURES = {
     'nemo_pose3d_fwd_bwd': (i32, [i64, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, f32, ptr, i64, ptr, ptr]),
     'nemo_adam_step': (i32, [i32, POINTER(AdamSeg), ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),
     'nemo_adam_step_dev': (i32, [i32, ptr, i64, ptr, ptr, ptr, ptr, f32, f32, f32, ptr]),
+    'nemo_adam_step_dev_if': (i32, [i32, ptr, i64, ptr, ptr, ptr, ptr, f32, f32, f32, ptr, ptr]),
+    'nemo_nan_count': (i32, [ptr, i64, ptr, ptr]),
+    'nemo_seq_gather': (i32, [ptr, ptr, i64, ptr, ptr, ptr, ptr]),
+    'nemo_seq_log': (i32, [ptr, i32, ptr, i64, ptr, ptr]),
     'nemo_sqmean_fwd_bwd': (i32, [i64, ptr, ptr, ptr, f32, ptr]),
     'nemo_step_begin': (i32, [ptr, i64, ptr, i64, ptr, i32, c_double, c_double, ptr]),
     'nemo_phase_embed_fwd_begin': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
@@ -137,31 +141,9 @@ def load():
     return lib
 
 
-class Ablated:
-    """Measurement aid (NEMO_ABLATE=name1,name2,...): a view of the library in which the named entry points do nothing
-    and return 0.  The step then computes garbage -- the only meaningful output is its TIME: the difference to the full
-    step is what the kernel contributes to the un-profiled critical path (kernel traces over-state cross-queue
-    latencies inside replayed graphs).  `nemo_gemm_f32@<M>x<N>x<K>` ablates one GEMM shape."""
-
-    def __init__(self, lib, names):
-        self._lib, self._names = lib, set(names)
-
-    def __getattr__(self, name):
-        fn = getattr(self._lib, name)
-        if name in self._names:
-            return lambda *a, **k: 0
-        shapes = {n.split('@')[1] for n in self._names if n.startswith(name + '@')}
-        if shapes:
-            def gated(*a, **k):
-                return 0 if f'{a[2]}x{a[3]}x{a[4]}' in shapes else fn(*a, **k)
-            return gated
-        return fn
-
-
 def load_for_engine():
-    lib = load()
-    names = [n for n in os.environ.get('NEMO_ABLATE', '').split(',') if n]
-    return Ablated(lib, names) if names else lib
+    """The library as FitEngine sees it (a seam for measurement tools: tools/ablate.py wraps it)."""
+    return load()
 
 
 def check(rc: int, what: str):

@@ -590,8 +590,7 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     if (split_k > 1 && out_mode != 2 && !can_split) return NEMO_EINVAL;
 
     int force_tile = 0;
-    if (const char* f = getenv("NEMO_GEMM_TILE")) force_tile = atoi(f);          // tuning aids (tools/bench_gemm.py)
-    if (const char* f = getenv("NEMO_GEMM_SPLIT")) { if (split_k == 0 && atoi(f) > 0) split_k = atoi(f); }
+    if (const char* f = getenv("NEMO_GEMM_TILE")) force_tile = atoi(f);          // test / tuning aid (tests/test_gpu_ops.py, tools/bench_gemm.py)
     // K-chunk starts are multiples of 32, so operand alignment only depends on the base and the ld; each
     // operand independently takes the dwordx4 or the dword staging path (64x64 tiles; the 128x128 tile
     // needs both aligned).  Dword staging serves the few operands whose rows are not 16-byte aligned,
@@ -600,9 +599,8 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     const bool vec = va && vb;
     // (128x128 tiles pay off only with both operands k-contiguous: the k-major LDS image is fetched with
     //  four ds_read_b32 per operand group instead of one ds_read_b128 and runs at ~half the rate there)
-    static const bool use_glds = [] { const char* f = getenv("NEMO_GEMM_GLDS"); return !(f && atoi(f) == 0); }();
     unsigned a_bytes = 0, b_bytes = 0;
-    const bool glds_ok = vec && use_glds && force_tile != 128 && !b16out &&
+    const bool glds_ok = vec && force_tile != 128 && !b16out &&
                          glds::extents(transA, transB, M, N, K, lda, ldb, &a_bytes, &b_bytes);
     Plan pl = plan_gemm(M, N, K, can_split, ws_bytes, out_mode == 2, split_k,
                         vec && !transA && transB && !(bf16 && glds_ok), vec, glds_ok);
@@ -611,7 +609,6 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
         pl.t0 = 0;
         if (split_k > 0) pl.split = split_k;
     }
-    if (const char* f = getenv("NEMO_GEMM_T0")) { if (atol(f) >= 0 && pl.tile == 64 && can_split && out_mode != 2) pl.t0 = atol(f); }   // tuning aid
     // The blend-shape adjoint at large batch (dPF = dVP P^T: M = samples, N = 207, K = 3 NV = 20670, both operands
     // "transposed"): a 64 x 208 tile on v_mfma_f32_16x16x4_f32 (13 accumulators per wave) reads the (K x M) operand ONCE
     // instead of once per 64-column tile.  At M = 2400 that ties with the 64x64 plan (the narrow MFMA needs twice the LDS
@@ -649,8 +646,7 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     // mini-batches of a few hundred samples): the intra-block K split of gemm_skinny.h, 19 -> 13 us for 300 x 1000 x 1000
     // and ~2x on the small layers (profiles/r02_gemm_skinny.md).  Very long K (the blend-shape adjoint) stays with the
     // LDS-staged kernel: a wave's K slice would be thousands of steps.
-    static const bool use_skinny = [] { const char* f = getenv("NEMO_GEMM_SKINNY"); return !(f && atoi(f) == 0); }();
-    const int sk_kind = use_skinny && !bf16 && !b16out && split_k == 0 && force_tile == 0 && K >= 1
+    const int sk_kind = !bf16 && !b16out && split_k == 0 && force_tile == 0 && K >= 1
                             ? skinny_kind(!transA, transB != 0, (va || transA) && (vb || !transB),
                                           can_split && out_mode != 2 && ws_bytes >= COUNTER_BYTES + (8L << 20), M, N, K) : -1;
     if (sk_kind >= 0 && (glds_ok || glds::extents(transA, transB, M, N, K, lda, ldb, &a_bytes, &b_bytes))) {
@@ -724,31 +720,13 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     g.xcd_order = 0;
     g.Cb = Cb; g.ldcb = ldcb; g.CbT = CbT; g.ldcbt = ldcbt; g.mask16 = mask16; g.ldmask16 = ldmask16;
     g.colsum = colsum; g.ldcs = ldcs;
-    // Tuning aid (NEMO_B16_TILE=128): bf16-in-memory products on 128 x 128 tiles -- twice the MFMA work per byte the LDS-DMA
-    // moves, but one block per CU (96 KiB of LDS stages).  Measured SLOWER than the 64 x 64 tile at every shape of the step
-    // (12 000 x 1000 x 1000: 98 us = 244 TFLOP/s against 71 us = 337; profiles/r03_experiments.md section 9): not used.
-    if (bf16 == 2 && glds_ok && !transA && transB) {
-        static const int b16_tile = [] { const char* f = getenv("NEMO_B16_TILE"); return f ? atoi(f) : 0; }();
-        const bool big = b16_tile == 128 || b16_tile == 12864;
-        if (big && split_k == 0 && !colsum) {
-            const int bn = b16_tile == 128 ? 128 : 64;
-            g.tiles_m = (int)((M + 127) / 128); g.tiles_n = (int)((N + bn - 1) / bn); g.n_tiles = g.tiles_m * g.tiles_n;
-            g.split = 1; g.t0 = g.n_tiles; g.k_chunk = (K + 31) / 32 * 32;
-            g.a_bytes = a_bytes; g.b_bytes = b_bytes;
-            const hipError_t e128 = bn == 128
-                ? glds::launch<128, 128, 64, 64, 32, true, true, 3, true, 2>(g, g.n_tiles, (hipStream_t)stream)
-                : glds::launch<128, 64, 32, 64, 32, true, true, 3, true, 2>(g, g.n_tiles, (hipStream_t)stream);
-            if (e128 != hipSuccess) return (int32_t)e128;
-            NEMO_LAUNCH_CHECK();
-            return NEMO_OK;
-        }
-    }
+    // (bf16-in-memory products on 128 x 128 / 128 x 64 tiles were measured SLOWER than the 64 x 64 tile at every shape of the
+    //  step -- 12 000 x 1000 x 1000: 98 us = 244 TFLOP/s against 71 us = 337; profiles/r03_experiments.md section 9)
     if (bf16 == 2 && !(tile == 64 && glds_ok && !transA && transB)) return NEMO_EINVAL;
     if (tile == 64 && glds_ok) {
         g.a_bytes = a_bytes; g.b_bytes = b_bytes;
-        static const bool xcd_ok = [] { const char* f = getenv("NEMO_GEMM_XCD"); return !(f && atoi(f) == 0); }();
         long nblocks = blocks;
-        if (nz == 1 && g.n_tiles >= 2048 && xcd_ok) {          // XCD-aware tile order for the large whole-tile launches
+        if (nz == 1 && g.n_tiles >= 2048) {          // XCD-aware tile order for the large whole-tile launches
             g.xcd_order = 1;
             nblocks = 8L * ((g.tiles_m + 7) / 8) * g.tiles_n;
         }
@@ -890,9 +868,8 @@ static int32_t gemm_grouped_impl(bool bf16, int32_t n, const nemo_gemm_problem* 
         if (q.M < 0 || q.N < 0 || q.K < 0 || !q.C || (q.out_mode != 0 && q.out_mode != 1)) return NEMO_EINVAL;
         if (q.M && q.N && q.K && (!q.A || !q.B)) return NEMO_EINVAL;
     }
-    static const bool enabled = [] { const char* f = getenv("NEMO_GEMM_GROUPED"); return !(f && atoi(f) == 0); }();
     const bool can_split = ws != nullptr && ws_bytes > COUNTER_BYTES && (((uintptr_t)ws) & 15) == 0;
-    bool ok = enabled && n >= 2 && n <= glds::MAX_GROUP && !getenv("NEMO_GEMM_TILE") && !getenv("NEMO_GEMM_SPLIT");
+    bool ok = n >= 2 && n <= glds::MAX_GROUP && !getenv("NEMO_GEMM_TILE");
     glds::GroupArgs ga;
     long total_tiles = 0, small_tiles = 0;
     for (int i = 0; ok && i < n; ++i) {

@@ -303,7 +303,8 @@ template <bool SEGS_DEV>
 __global__ __launch_bounds__(256) void adam_kernel(AdamSegs segs, const nemo_adam_seg* __restrict__ segs_dev,
                                                    float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, float b1,
-                                                   float b2, float eps) {
+                                                   float b2, float eps, const float* __restrict__ skip_if_nonzero) {
+    if (skip_if_nonzero && *skip_if_nonzero != 0.f) return;        // (nemo_adam_step_dev_if: NaN gradients were counted)
     const nemo_adam_seg sg = SEGS_DEV ? segs_dev[blockIdx.y] : segs.s[blockIdx.y];
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < sg.numel; i += (long)gridDim.x * blockDim.x) {
         const long k = sg.offset + i;
@@ -451,14 +452,14 @@ extern "C" int32_t nemo_adam_step(int32_t n_seg, const nemo_adam_seg* segs, floa
     if (bx < 1) bx = 1;
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(adam_kernel<false>, dim3(bx, n_seg), dim3(256), 0, (hipStream_t)stream, a, nullptr,
-                       params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps);
+                       params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, (const float*)nullptr);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
 
-extern "C" int32_t nemo_adam_step_dev(int32_t n_seg, const nemo_adam_seg* segs_dev, int64_t max_numel,
-                                      float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                                      float beta1, float beta2, float eps, void* stream) {
+extern "C" int32_t nemo_adam_step_dev_if(int32_t n_seg, const nemo_adam_seg* segs_dev, int64_t max_numel,
+                                         float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                         float beta1, float beta2, float eps, const float* skip_if_nonzero, void* stream) {
     if (n_seg < 0 || n_seg > NEMO_ADAM_MAX_SEG || !segs_dev || !params || !grads || !exp_avg || !exp_avg_sq ||
         max_numel < 0)
         return NEMO_EINVAL;
@@ -469,7 +470,70 @@ extern "C" int32_t nemo_adam_step_dev(int32_t n_seg, const nemo_adam_seg* segs_d
     if (bx < 1) bx = 1;
     if (bx > 2048) bx = 2048;
     hipLaunchKernelGGL(adam_kernel<true>, dim3(bx, n_seg), dim3(256), 0, (hipStream_t)stream, a, segs_dev,
-                       params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps);
+                       params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, skip_if_nonzero);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_adam_step_dev(int32_t n_seg, const nemo_adam_seg* segs_dev, int64_t max_numel,
+                                      float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                      float beta1, float beta2, float eps, void* stream) {
+    return nemo_adam_step_dev_if(n_seg, segs_dev, max_numel, params, grads, exp_avg, exp_avg_sq, beta1, beta2, eps, nullptr,
+                                 stream);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void nan_count_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float c = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) c += x[i] != x[i] ? 1.f : 0.f;
+    const float t = block_sum(c, red);
+    if (threadIdx.x == 0 && t != 0.f) atomicAdd(out, t);
+}
+
+__global__ __launch_bounds__(256) void seq_gather_kernel(const long* __restrict__ all_v, const long* __restrict__ all_f, long B,
+                                                         const int* __restrict__ counter, long* __restrict__ vo,
+                                                         long* __restrict__ fo) {
+    const long row = (long)*counter * B;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (long)gridDim.x * blockDim.x) {
+        vo[i] = all_v[row + i];
+        fo[i] = all_f[row + i];
+    }
+}
+
+__global__ void seq_log_kernel(const float* __restrict__ src, int n, float* __restrict__ log, long ld, int* __restrict__ counter) {
+    const int c = *counter;
+    if ((int)threadIdx.x < n) log[(long)c * ld + threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) *counter = c + 1;
+}
+}  // namespace
+
+extern "C" int32_t nemo_nan_count(const float* x, int64_t n, float* count_out, void* stream) {
+    if (n < 0 || (n && !x) || !count_out) return NEMO_EINVAL;
+    if (n == 0) return NEMO_OK;
+    int blocks = nemo_cdiv(n, 256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(nan_count_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)n, count_out);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_seq_gather(const int64_t* all_view, const int64_t* all_frame, int64_t B, const int32_t* counter,
+                                   int64_t* view_out, int64_t* frame_out, void* stream) {
+    if (B < 0 || !all_view || !all_frame || !counter || !view_out || !frame_out) return NEMO_EINVAL;
+    if (B == 0) return NEMO_OK;
+    int blocks = nemo_cdiv(B, 256);
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(seq_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const long*)all_view,
+                       (const long*)all_frame, (long)B, (const int*)counter, (long*)view_out, (long*)frame_out);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_seq_log(const float* src, int32_t n, float* log, int64_t ld, int32_t* counter, void* stream) {
+    if (!src || !log || !counter || n < 1 || n > 64 || ld < n) return NEMO_EINVAL;
+    hipLaunchKernelGGL(seq_log_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, (int)n, log, (long)ld, (int*)counter);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -1892,12 +1892,8 @@ extern "C" int32_t nemo_v2v_skin_l1(const nemo_ctx* ctx, int64_t N, const float*
     if (!ctx || N < 0 || !VP || !A || !loss_sum || !dVP || !dA || ldvp < ctx->NV * 3 || lddvp < ctx->NV * 3)
         return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
-    static int S = -1;
-    if (S < 0) { const char* e = getenv("NEMO_V2V_S"); S = e ? atoi(e) : 4; }
-#define V2V_LAUNCH(SS) hipLaunchKernelGGL(v2v_skin_l1_kernel<SS>, dim3(nemo_cdiv(N, SS)), dim3(256), 0, \
-        (hipStream_t)stream, (long)N, ctx->NV, VP, (long)ldvp, A, ctx->d_Wt, loss_sum, dVP, (long)lddvp, dA)
-    if (S == 1) V2V_LAUNCH(1); else if (S == 2) V2V_LAUNCH(2); else V2V_LAUNCH(4);
-#undef V2V_LAUNCH
+    hipLaunchKernelGGL(v2v_skin_l1_kernel<4>, dim3(nemo_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, (long)N, ctx->NV, VP,
+                       (long)ldvp, A, ctx->d_Wt, loss_sum, dVP, (long)lddvp, dA);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -1982,15 +1978,14 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const f
     if (dVPb ? (!bf16 || ldk < ctx->ldP || (ldk & 3) || (((uintptr_t)dVPb) & 7)) : (!dVPt || ldn < ((N + 15) / 16) * 16))
         return NEMO_EINVAL;                                    // (dA == NULL: deferred combine, nemo_v2v_combine)
     if (N == 0) return NEMO_OK;
-    // bf16: split-precision vertex->joint adjoint on the bf16 pipe (MODE 3); NEMO_MESH_SPLIT=0 -> MODE 1, =2 -> MODE 2 (A/B aids)
-    static const int split_env = [] { const char* e = getenv("NEMO_MESH_SPLIT"); return e ? atoi(e) : 1; }();
-    const int mode = bf16 ? (split_env == 2 ? 2 : split_env ? 3 : 1) : 0;
-    const int lds_bytes = mode == 2 ? 2 * 16 * MF_PFB * 2 + 2 * 2 * 16 * MF_AB * 2
-                                    : ((bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * MF_AS) * (int)sizeof(float);
+    // bf16: bf16 blend + split-precision vertex->joint adjoint on the bf16 pipe (kernel MODE 3).  MODE 1 (bf16 blend only:
+    // 3.55 against 3.25 ms per C3 step) and MODE 2 (split-precision skinning as well: slower, 475 against ~300 us per
+    // launch) were measured in round 3 (profiles/r03_experiments.md sections 10, 13) and are no longer instantiated.
+    const int mode = bf16 ? 3 : 0;
+    const int lds_bytes = ((bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * MF_AS) * (int)sizeof(float);
     static bool attr_set[4] = {false, false, false, false};
     if (!attr_set[mode]) {
-        const void* fn = mode == 3 ? (const void*)mesh_v2v_fused_kernel<3> : mode == 2 ? (const void*)mesh_v2v_fused_kernel<2>
-                       : mode == 1 ? (const void*)mesh_v2v_fused_kernel<1> : (const void*)mesh_v2v_fused_kernel<0>;
+        const void* fn = mode == 3 ? (const void*)mesh_v2v_fused_kernel<3> : (const void*)mesh_v2v_fused_kernel<0>;
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set[mode] = true;
     }
@@ -2013,8 +2008,6 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const f
         pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets, loss_parts, grid_ticket, dVPb, (long)ldk,    \
         ctx->d_Wsk, ctx->d_Wadj)
     if (mode == 3) MESH_LAUNCH(3, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
-    else if (mode == 2) MESH_LAUNCH(2, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
-    else if (mode == 1) MESH_LAUNCH(1, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
     else MESH_LAUNCH(0, ctx->d_posedirs, ctx->ldP);
 #undef MESH_LAUNCH
     NEMO_LAUNCH_CHECK();

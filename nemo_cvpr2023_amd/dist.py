@@ -32,7 +32,7 @@ LAUNCHED at the next multiple of ``pad`` (default 32) samples with masked paddin
 nemo_kp_fwd: valid indices, no loss, not counted, exactly-zero gradients) and the per-sample means are taken with
 ``mr = N_launch / N_global``: two or three graphs serve a whole run at any world size.
 
-Opt-in ``shard_mode='split'`` (``ShardedNemo.set_shard_mode`` / ``NEMO_SHARD_SPLIT=1``): a second, 32-byte
+Opt-in ``shard_mode='split'`` (``ShardedNemo.set_shard_mode``): a second, 32-byte
 all-reduce of the loss scalars is issued on a side stream as soon as they are final (a third of a step before
 the gradient is), so the host holds the global losses early and prepares the next launch under the rest of the
 backward.  Which of the two is faster depends on the machine's small-message all-reduce latency against the host's
@@ -132,7 +132,7 @@ class ShardedNemo:
         local = SequenceSubset(multi_view_seqs, self.plan.lo, self.plan.hi)
         self.model = NEMO_VERSIONS[version](args, local, device, **assets)
         # a rank's share of a random minibatch changes size from step to step: launched at multiples of `pad` samples
-        self.pad = int(os.environ.get('NEMO_SHARD_PAD', '32'))
+        self.pad = 32
         self.model.load_state_dict({k: v for k, v in slice_state(state, self.plan.lo, self.plan.hi).items()},
                                    strict=False)
         torch.manual_seed(seed + 1)       # re-synchronise the index stream across ranks
@@ -148,7 +148,7 @@ class ShardedNemo:
         # RCCL all-reduces can be captured into the step's HIP graph (one launch per sharded step); gloo's cannot
         self.capturable = dist.get_backend(group) == 'nccl'
         self.shard_mode = 'single'
-        self.set_shard_mode('split' if os.environ.get('NEMO_SHARD_SPLIT', '0') == '1' else 'single')
+        self.set_shard_mode('single')
 
     def close(self):
         """Release every captured HIP graph of the model.  Sharded steps capture their RCCL all-reduces into the step's
@@ -186,7 +186,7 @@ class ShardedNemo:
         return ShardInfo(kr=d['kr'], mr=d['mr'], vr=d['vr'], n_global=d['n_global'], comm=self._comm,
                          comm_small=self._comm_small if self.shard_mode == 'split' else None,
                          comm_bucket=self._comm_small if self.shard_mode == 'buckets' else None, pad=pad,
-                         capturable=self.capturable, live=self.collectives)
+                         capturable=self.capturable, live=self.collectives, comm_log=self._comm_small)
 
     def _sharder(self):
         """Draw the GLOBAL (view, frame) batch from the CPU RNG (identical on every rank) and keep

@@ -254,9 +254,9 @@ class FitEngine:
         self.bf16 = dt == 'bf16'
         # bf16 operands IN MEMORY (round 3): every dense product of the MotionNet / VPoser chain reads bf16 copies of its
         # operands (written by the producing GEMM's epilogue, plain and transposed, or by nemo_cast_bf16) through
-        # nemo_gemm_bf16mem -- the same values enter the matrix cores as with the on-the-fly rounding of nemo_gemm_bf16,
-        # half the bytes move (NEMO_BF16_MEM=0: the on-the-fly path, A/B aid)
-        self.b16mem = self.bf16 and version >= 1 and os.environ.get('NEMO_BF16_MEM', '1') != '0'
+        # nemo_gemm_bf16mem -- the same values enter the matrix cores as with the on-the-fly rounding of nemo_gemm_bf16
+        # (which NemoV0's three networks keep), half the bytes move
+        self.b16mem = self.bf16 and version >= 1
         self.din = (self.D if self.D > 0 else 1) + self.C
         self.ldx = (self.din + 3) // 4 * 4          # row stride of the MLP input / its gradient (16-byte rows)
         self.cx, self.cy = float(img_d0 // 2), float(img_d1 // 2)       # :3104-3106 (sic)
@@ -312,14 +312,9 @@ class FitEngine:
         self.ws = {}
         self.side_stream = torch.cuda.Stream(device=self.device)   # prior branches of the step (see _forward_backward)
         self.side_stream2 = torch.cuda.Stream(device=self.device)
-        self.cs_in_phase = os.environ.get('NEMO_COLSUM_IN_PHASE', '1') != '0'
-        self.pub_stream = torch.cuda.Stream(device=self.device)     # NEMO_PUBLISH=aside4 (A/B aid)
         self.comm_stream = torch.cuda.Stream(device=self.device)    # bucketed gradient all-reduces + their Adam (dist.py)
         # split-K scratch of nemo_gemm_f32 (arrival tickets + partial tiles), one per stream that launches GEMMs
         self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(3)]
-        self.overlap_bwd = os.environ.get('NEMO_SERIAL_BWD', '0') == '0'
-        self.defer_combine = self.overlap_bwd and os.environ.get('NEMO_DEFER_COMBINE', '1') != '0'
-        self.dw_group = int(os.environ.get('NEMO_DW_GROUP', '1'))
         self._colsums = []
         self._seg_host = self._seg_dev = self._seg_pending = None
         self.timers = None
@@ -441,20 +436,6 @@ class FitEngine:
                  split_k, ws.data_ptr(), ws.numel() * 4, _stream()), 'nemo_gemm')
         self._event_end(ev)
 
-    def prior_mode(self, N):
-        """How the step lays the prior terms out over the HIP streams (MultiViewModel._forward_backward): 0 = a third
-        stream for GMM / 3-D / KL (the default at every size), 1 = two streams (GMM / 3-D open the VPoser stream, KL closes
-        the main chain).  Measured at a one-instance shard, same box, un-profiled: 0.508 ms with 1 against 0.495 with 0
-        (profiles/r03_experiments.md) -- the kernel trace's late start of the third queue is a profiler artefact.
-        NEMO_PRIOR_MODE: A/B override."""
-        return int(os.environ.get('NEMO_PRIOR_MODE', '0'))
-
-    def late_join(self, N):
-        """Whether the prior branch joins the main chain BEHIND the fused mesh kernel (small batches) instead of in front of
-        it.  NEMO_LATE_JOIN: A/B override (0 | 1); default: measured, see profiles/r03_experiments.md section 12."""
-        v = os.environ.get('NEMO_LATE_JOIN')
-        return bool(int(v)) if v is not None else False
-
     def kernel_flops_by_pipe(self, tag, flops):
         """Split a tagged (bench-timed) kernel's algorithmic FLOPs by the matrix pipe they run on, so that bench.py can
         price each part against its own peak.  fp32 build: everything on the fp32 MFMA pipe.  gemm_dtype='bf16': the
@@ -464,9 +445,9 @@ class FitEngine:
         if not self.bf16:
             return {'f32': flops}
         if tag == 'mesh_v2v_fused':
-            # (csrc/smpl.hip MODE 3, the default: the vertex->joint adjoint -- 288 of the multiply-adds -- runs on the bf16
-            #  pipe too, as four bf16 piece products per algorithmic product; NEMO_MESH_SPLIT=0: blend only)
-            on16 = 2 * 3 * 207 + (288 if os.environ.get('NEMO_MESH_SPLIT', '1') != '0' else 0)
+            # (csrc/smpl.hip MODE 3: the vertex->joint adjoint -- 288 of the multiply-adds -- runs on the bf16 pipe too, as
+            #  four bf16 piece products per algorithmic product)
+            on16 = 2 * 3 * 207 + 288
             b16 = flops * on16 / (2 * 3 * 207 + 2 * 288 + 288)
             return {'bf16': b16, 'f32': flops - b16}
         return {'bf16': flops}
@@ -612,10 +593,9 @@ class FitEngine:
         cs.append((dptr(w['cs0']), R, h, h, self.g(lm + 'net.net.0.bias')))
         self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din, dptr(w['dX']), self.ldx,
                   dense=True)
-        cs_in = self.cs_in_phase and not bucketed
-        if not cs_in:
+        if bucketed:
             self.flush_colsums()
-        self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=cs_in)
+        self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=not bucketed)
 
     def gemm_grouped(self, problems, dense=True):
         """problems: list of (ta, tb, M, N, K, A, lda, B, ldb, C, ldc, out_mode) -- independent products of one layout in
@@ -769,6 +749,13 @@ class FitEngine:
                        j3d=None, p2d=None, finalize=True):
         """K6-K8: FK, mesh-functional joints, projection, 2-D loss accumulators.  ``finalize=False``: the caller runs
         ``finalize_kp`` itself (off the main chain: ``backward_kp(norm_from_acc=True)`` does not need its output)."""
+        Mq = self.joint_functionals(w, N, ctx)
+        self.project_and_loss(w, N, view_idx, frame_idx, Mq, mean_mode, with_loss, add_trans, ctx, j3d, p2d, finalize)
+        return Mq
+
+    def joint_functionals(self, w, N, ctx=None):
+        """K6: FK of the N bodies and the pre-contracted mesh functionals Mq = PF C1 + c0 (nothing here depends on the
+        cameras: a camera fit evaluates it once)."""
         L, st = self.lib, _stream()
         ctx = ctx or self.ctx
         self.sync_betas(ctx)
@@ -779,6 +766,14 @@ class FitEngine:
         if ctx.nq:
             self.gemm(0, 0, N, nq72, 207, dptr(w['PF']), 208, ctx.C1, nq72, dptr(Mq), max(nq72, 1),
                       bias=ctx.c0)
+        return Mq
+
+    def project_and_loss(self, w, N, view_idx, frame_idx, Mq, mean_mode=0, with_loss=True, add_trans=True, ctx=None,
+                         j3d=None, p2d=None, finalize=True):
+        """K7 + K8: output joints, camera projection, 2-D loss accumulators (+ the loss scalar when ``finalize``)."""
+        L, st = self.lib, _stream()
+        ctx = ctx or self.ctx
+        nq72 = ctx.nq * 72
         lt = LOSS_TYPES[self.args.loss]
         check(L.nemo_kp_fwd(
             ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), max(nq72, 1),
@@ -791,7 +786,6 @@ class FitEngine:
             'nemo_kp_fwd')
         if with_loss and finalize:
             self.finalize_kp(w, mean_mode, ctx)
-        return Mq
 
     def finalize_kp(self, w, mean_mode=0, ctx=None):
         """Per-view accumulators -> the keypoint loss scalar (+ the normaliser, for callers of nemo_kp_bwd that pass it)."""
@@ -906,7 +900,7 @@ class FitEngine:
             # second side stream, beside the blend-shape adjoint GEMM (only the FK adjoint behind that GEMM needs dA)
             # (large batches only: at a one-instance shard the extra fork / join of the replayed graph costs more than the
             #  reduction's tail -- 0.509 against 0.503 ms, same box; 8 x 300: 1.557 against 1.564 ms)
-            defer = self.defer_combine and need_grad and self.SMALL_BATCH_ROWS < N <= Nc and self.timers is None
+            defer = need_grad and self.SMALL_BATCH_ROWS < N <= Nc and self.timers is None
             if self.b16mem:
                 check(L.nemo_v2v_fused_bf16mem(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
                                                self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPb']), w['dVPb'].stride(0),
@@ -1008,11 +1002,9 @@ class FitEngine:
         # layer-0 dX GEMM and the three phase / RBF / code backward kernels that consume it on the main stream.  Small batches (one rank's share at 8 GPUs: a GEMM is ~80 tiles, a third of the CUs): the dW
         # GEMMs are off the dependency chain, so they ALL go to the side stream, each as soon as its dY exists, and
         # the chain dX_head -> dX4 -> dX2 -> dX0 -> phase backward runs uninterrupted on the main stream.
-        # (NEMO_SERIAL_BWD=1: everything on the main stream, for A/B timing.)
         main, side = torch.cuda.current_stream(), self.side_stream
-        cs_in = self.cs_in_phase and not bucketed      # bias column sums inside the phase backward's launch
-        overlap = self.overlap_bwd
-        small = overlap and r <= self.SMALL_BATCH_ROWS
+        cs_in = not bucketed      # bias column sums inside the phase backward's launch
+        small = r <= self.SMALL_BATCH_ROWS
 
         # (Enqueue order in small mode: the chain's next GEMM BEFORE the parameter-gradient GEMM that branches off -- a
         #  replayed graph keeps a node's first successor on its hardware queue and pays a 15 - 30 us cross-queue barrier
@@ -1030,11 +1022,10 @@ class FitEngine:
         # Round 3: ALL parameter-gradient GEMMs of the backward as ONE grouped launch (nemo_gemm_grouped_f32) on the side
         # stream once the last dY of the dX chain exists, beside the layer-0 dX GEMM and the phase backward on the main
         # stream: four launches of 32 - 256 tiles (each with its own pipeline fill / output burst at ~one block per CU) ->
-        # one of 592 tiles (NEMO_DW_GROUP=0: the per-layer launches; 2: the grouped launch on the main stream)
-        # Measured (same box, un-profiled): one-instance shard 0.493 ms grouped against 0.501 per layer; 8 x 300: 1.567 against
-        # 1.559 (there the per-layer launches on the 64 x 64 / 8-wave skinny configuration are ahead) -> small batches only.
-        grp = self.dw_group if (not bucketed and tuple(stages) == (0, 1, 2) and (small or self.dw_group == 2)) else 0
-        if grp:
+        # one of 592 tiles.  Measured (same box, un-profiled): one-instance shard 0.493 ms grouped against 0.501 per layer;
+        # 8 x 300: 1.567 against 1.559 (there the per-layer launches on the 64 x 64 / 8-wave skinny configuration are ahead)
+        # -> small batches only.
+        if not bucketed and tuple(stages) == (0, 1, 2) and small:
             dWs = []
 
             def dWg(rows, x, ldx_, fin, dy, lddy, fout, gw, gb, nbias=None):
@@ -1057,15 +1048,11 @@ class FitEngine:
             self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
                       dptr(w['dX']), self.ldx, dense=True)
             self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=cs_in)
-            if grp == 2 or not overlap:
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
                 self.gemm_grouped(dWs)
                 self.flush_colsums()
-            else:
-                side.wait_event(ev)
-                with torch.cuda.stream(side):
-                    self.gemm_grouped(dWs)
-                    self.flush_colsums()
-                main.wait_stream(side)
+            main.wait_stream(side)
             return
 
         def end_of_stage():
@@ -1117,27 +1104,20 @@ class FitEngine:
                       dptr(w['dX']), self.ldx, dense=True)
         w0 = (r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h,
               self.g(lm + 'net.net.0.weight'), self.g(lm + 'net.net.0.bias'))
-        if small or overlap:
-            # ONE more fork, one join: the side stream takes the layer-0 parameter gradient and the batched bias column
-            # sums (every dY exists from here on), the main stream -- enqueued first, see above -- the layer-0 dX GEMM and
-            # the three phase / RBF / code kernels that consume it
-            ev = main.record_event()
-            dX0()
-            if cs_in:             # (the layer-0 bias column sum rides in the phase launch with the others)
-                self._colsums.append((w0[4], w0[0], w0[6], w0[5], w0[8]))
-                w0 = w0[:8] + (None,)
-            phase_bwd()
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                self._linear_bwd_params(*w0)
-                self.flush_colsums()
-            main.wait_stream(side)
-        else:
+        # ONE more fork, one join: the side stream takes the layer-0 parameter gradient and the batched bias column
+        # sums (every dY exists from here on), the main stream -- enqueued first, see above -- the layer-0 dX GEMM and
+        # the three phase / RBF / code kernels that consume it
+        ev = main.record_event()
+        dX0()
+        if cs_in:             # (the layer-0 bias column sum rides in the phase launch with the others)
+            self._colsums.append((w0[4], w0[0], w0[6], w0[5], w0[8]))
+            w0 = w0[:8] + (None,)
+        phase_bwd()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
             self._linear_bwd_params(*w0)
-            dX0()
-            if not cs_in:
-                self.flush_colsums()
-            phase_bwd()
+            self.flush_colsums()
+        main.wait_stream(side)
 
     def finish_trans_grad(self, w, N):
         """d trans_0 = - sum_s d trans_s  (row N of dTR), :3764-3766."""
@@ -1209,22 +1189,57 @@ class FitEngine:
         """The device table may have been advanced by a launch the host did not see complete: upload it next time."""
         self._seg_shadow = None
 
-    def step_begin(self, arena, zero_grads, n_seg=0):
-        """First launch of a step: zero the workspace's accumulator arena (+ the flat gradient buffer) and, for a
-        captured update step, advance the device Adam table -- one kernel instead of two memsets and a copy."""
-        check(self.lib.nemo_step_begin(arena.data_ptr(), arena.numel() * 4,
-                                       self.grads.data_ptr() if zero_grads else None,
-                                       self.grads.numel() * 4 if zero_grads else 0,
+    def step_begin(self, arena, grads=None, n_seg=0):
+        """First launch of an iteration whose first kernel is not the phase kernel (camera fit): zero the workspace's
+        accumulator arena and `grads` (a slice of the flat gradient buffer, or None) and advance the device Adam table --
+        one kernel instead of two memsets and a copy."""
+        check(self.lib.nemo_step_begin(arena.data_ptr(), arena.numel() * 4, dptr(grads),
+                                       grads.numel() * 4 if grads is not None else 0,
                                        self._seg_dev.data_ptr() if n_seg else None, n_seg, 0.9, 0.999, _stream()),
               'nemo_step_begin')
 
-    def adam_from_table(self, n, max_numel, start=0):
-        """Fused Adam over segments [start, start + n) of the device-resident table."""
-        check(self.lib.nemo_adam_step_dev(n, self._seg_dev.data_ptr() + start * ctypes.sizeof(AdamSeg), max_numel,
-                                          self.params.data_ptr(),
-                                          self.grads.data_ptr(), self.exp_avg.data_ptr(),
-                                          self.exp_avg_sq.data_ptr(), 0.9, 0.999, 1e-8, _stream()),
-              'nemo_adam_step_dev')
+    def adam_from_table(self, n, max_numel, start=0, exp_avg=None, exp_avg_sq=None, guard=None):
+        """Fused Adam over segments [start, start + n) of the device-resident table; ``guard``: a device scalar -- no
+        update when it is non-zero (warm-up: NaN gradients were counted)."""
+        m = self.exp_avg if exp_avg is None else exp_avg
+        v = self.exp_avg_sq if exp_avg_sq is None else exp_avg_sq
+        check(self.lib.nemo_adam_step_dev_if(n, self._seg_dev.data_ptr() + start * ctypes.sizeof(AdamSeg), max_numel,
+                                             self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                             0.9, 0.999, 1e-8, dptr(guard), _stream()), 'nemo_adam_step_dev_if')
+
+    def sequence(self, steps, B, view_idx=None, frame_idx=None):
+        """Device-side state of a fit phase the host does not watch iteration by iteration (warm-up, camera fit): the
+        phase's (steps, B) index tables (drawn up front), a (steps, 8) loss log, the iteration counter that selects the
+        rows (nemo_seq_gather / nemo_seq_log) and a sticky NaN-gradient count.  The buffers are PERSISTENT per batch size
+        (captured graphs of an iteration hold their addresses); they only grow, and `gen` -- part of the graph keys --
+        changes when they do."""
+        if not hasattr(self, '_seq'):
+            self._seq, self._seq_gen = {}, 0
+        seq = self._seq.get(B)
+        if seq is None or seq['cap'] < steps:
+            dev, cap = self.device, max(steps, 1024)
+            self._seq_gen += 1
+            seq = self._seq[B] = {'cap': cap, 'gen': self._seq_gen, 'log': torch.zeros(cap, 8, dtype=torch.float32, device=dev),
+                                  'counter': torch.zeros(1, dtype=torch.int32, device=dev),
+                                  'nan': torch.zeros(1, dtype=torch.float32, device=dev)}
+            if B:
+                seq['vi'] = torch.zeros(cap, B, dtype=torch.long, device=dev)
+                seq['fi'] = torch.zeros(cap, B, dtype=torch.long, device=dev)
+        seq['counter'].zero_()
+        seq['nan'].zero_()
+        if B:
+            seq['vi'][:steps].copy_(view_idx.to(torch.long).contiguous().pin_memory(), non_blocking=True)
+            seq['fi'][:steps].copy_(frame_idx.to(torch.long).contiguous().pin_memory(), non_blocking=True)
+        return seq
+
+    def scratch_moments(self):
+        """Zeroed Adam moment buffers of a throw-away optimiser (opt_cam builds a fresh Adam on the cameras, :2870):
+        persistent storage, because the captured iteration holds their addresses."""
+        if not hasattr(self, '_tmp_m'):
+            self._tmp_m, self._tmp_v = torch.zeros_like(self.exp_avg), torch.zeros_like(self.exp_avg_sq)
+        self._tmp_m.zero_()
+        self._tmp_v.zero_()
+        return self._tmp_m, self._tmp_v
 
     def read_scalars(self):
         self._scal_host.copy_(self.scal, non_blocking=True)

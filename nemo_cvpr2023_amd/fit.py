@@ -65,8 +65,15 @@ def run_fit(model, args, out_dir=None, eval_every=500, log=None, evaluate=None):
     res['init'] = dict(ld)
     dump('_init.pt', ld, info)
     # 2. / 3.
+    def clock():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return time.perf_counter()
+    t_a = clock()
     res['warmup_losses'] = [float(x) for x in model.warmup(args.warmup_step)]
+    t_b = clock()
     res['cam_losses'] = [float(x) for x in model.opt_cam(args.opt_cam_step)]
+    t_c = clock()
     # 4.
     losses, lrs = defaultdict(list), defaultdict(list)
     t0 = time.perf_counter()
@@ -89,7 +96,8 @@ def run_fit(model, args, out_dir=None, eval_every=500, log=None, evaluate=None):
             lrs[name].append(float(opt.param_groups[0]['lr']))
         if log is not None:
             log(step_idx, ld)
-    res['seconds'] = time.perf_counter() - t0
+    res['seconds'] = clock() - t0
+    res['phase_seconds'] = {'warmup': t_b - t_a, 'opt_cam': t_c - t_b, 'steps': res['seconds']}
     res['losses'], res['learning_rates'] = dict(losses), dict(lrs)
     # 5.
     res['metrics'] = evaluate(model, out_dir) if evaluate is not None else None

@@ -35,6 +35,18 @@ from .engine import (FOCAL_LENGTH, HEAD_LD, LOSS_TYPES, S_3D, S_GMM, S_KL, S_KP,
 
 S_INST = 5
 S_SMOOTH = 6
+S_NAN = 7          # warm-up: number of NaN gradient entries (:3497-3500)
+
+
+class _Batch:
+    """The samples of one step as the kernels see them: indices (host- or device-resident), N = launch size, Nv = real
+    samples (N > Nv: masked padding rows), shard normalisers."""
+    __slots__ = ('vi', 'fi', 'N', 'Nv', 'padded', 'sh', 'is_full', 'noise', 'host_idx')
+
+
+class _Plan:
+    """How one step is launched (MultiViewModel._plan_step)."""
+    __slots__ = ('mode', 'update', 'early', 'graphable', 'segs', 'bgroups', 'in_graph_adam', 'has_inst')
 
 
 class _LazyInfo(dict):
@@ -65,8 +77,9 @@ class ShardInfo:
     gradients together with the loss scalars.  The single-process default is the identity."""
 
     def __init__(self, kr=1.0, mr=1.0, vr=1.0, n_global=None, comm=None, comm_small=None, comm_bucket=None, pad=0,
-                 capturable=False, live=True):
+                 capturable=False, live=True, comm_log=None):
         self.kr, self.mr, self.vr, self.n_global, self.comm = kr, mr, vr, n_global, comm
+        self.comm_log = comm_log              # all-reduce of a device vector (the loss log of a camera fit, once per phase)
         # False: `comm` / `comm_small` / `comm_bucket` skip their collectives (bench.py's compute-only pass) -- part of the
         # graph key: a step captured with its collectives inside must not be replayed for the other setting
         self.live = bool(live)
@@ -79,6 +92,22 @@ class ShardInfo:
         # > 0: a minibatch share of n samples is LAUNCHED as ceil(n / pad) * pad samples (masked padding rows, see
         # include/nemo_hip.h nemo_kp_fwd), so that a handful of captured graphs serve every share size
         self.pad = int(pad)
+
+
+def _inject_capture_fault(sharded, comm_inside):
+    """Fault injection for the tests of bench.py's multi-GPU fallback (NEMO_TEST_FAIL_CAPTURE = raise | exit | hang): the first
+    capture of a sharded step on rank 1 of a supervisor's first attempt raises, kills the process or hangs."""
+    fault = os.environ.get('NEMO_TEST_FAIL_CAPTURE')
+    if not fault or not sharded:
+        return
+    if fault == 'raise' and comm_inside:
+        raise RuntimeError('NEMO_TEST_FAIL_CAPTURE=raise')
+    if os.environ.get('NEMO_BENCH_ATTEMPT') == 'main0' and os.environ.get('RANK') == '1':
+        if fault == 'exit':
+            os._exit(23)
+        if fault == 'hang':
+            import time
+            time.sleep(3600)
 
 
 def clip_segments(segs, lo, hi):
@@ -257,7 +286,9 @@ class MultiViewModel(nn.Module):
         # capture each (batch size, mode) variant of the step as a HIP graph after one eager run
         self.use_graphs = os.environ.get('NEMO_GRAPHS', '1') != '0'
         self.GRAPH_AFTER = 1             # eager runs of a (batch size, mode) variant before it is captured
-        self.graph_comm = os.environ.get('NEMO_GRAPH_COMM', '1') != '0'    # sharded steps: collectives inside the graph
+        # sharded steps: collectives inside the graph (NEMO_GRAPH_COMM=0: the graph-then-eager-collectives structure --
+        # what bench.py's multi-GPU launcher falls back to when a capture with RCCL inside fails on the machine)
+        self.graph_comm = os.environ.get('NEMO_GRAPH_COMM', '1') != '0'
         self.launch_stats = {'replayed': 0, 'other': 0}     # launches that replayed an existing graph / ran eagerly or captured
         self._build_parameters()
         self._init_parameters()
@@ -521,11 +552,15 @@ class MultiViewModel(nn.Module):
     def _forward_backward(self, w, N, vi, fi, update, use_vposer=True, detach_pose=False, sh=None,
                           smooth_ok=False, extra_losses=None, publish=False, part='all', adam_segs=0, use_gmm=None):
         """Forward of :3511-3584 (+V3 extras) and, when ``update``, the whole backward down to the
-        parameter gradients.  After the pose MLP the step forks into two independent branches that
-        run CONCURRENTLY on two HIP streams (most of their kernels are too small to fill 256 CUs):
-          main stream: FK -> pre-contracted joints -> projection -> 2-D loss -> its backward (dR, dTR, dcams)
-          side stream: VPoser encode/decode, KL (+ its backward), GMM, 3-D pose loss
-        joins, runs the full-mesh v2v term alone, then the rot6d / MLP backward."""
+        parameter gradients.  After the pose MLP the step forks into three branches that run CONCURRENTLY on three HIP
+        streams (most of their kernels are too small to fill 256 CUs):
+          main : FK -> pre-contracted joints -> projection -> 2-D loss -> its backward (dR, dTR, dcams)
+          side : VPoser encode -> decode -> rotations + FK of both mesh bodies (the mesh term waits for it)
+          side2: everything that accumulates into dAA -- GMM prior, 3-D pose term, then, once the encoder output exists,
+                 KL and its backward through the frozen encoder (one stream for all of them: their `+=` into dAA are plain
+                 read-modify-writes) -- and the key-point loss scalar
+        joins, runs the full-mesh v2v term alone, then the rot6d / MLP backward.  (Schedules measured and dropped --
+        priors on the VPoser stream, late joins, the loss hand-over on the main chain: profiles/r0{2,3}_experiments.md.)"""
         e, a = self.engine, self.args
         sh = sh or ShardInfo()
         use_gmm = use_vposer if use_gmm is None else use_gmm
@@ -536,13 +571,10 @@ class MultiViewModel(nn.Module):
             return self._backward_tail(w, N, vi, fi, update, use_vposer, sh)
         if part in ('k1', 'k2'):             # bucketed sharded step: the later stages of the MLP backward (see step())
             return e.backward_mlp(w, N, vi, fi, None, stages=(int(part[1]),), bucketed=True)
-        # loss scalars, view accumulators, dAA, dJp, dA2, dPF2, the gradient buffer (and the device Adam table's step)
-        if os.environ.get('NEMO_FUSED_BEGIN', '1') != '0':        # zero-fills + Adam-table bookkeeping inside the first launch
-            e.forward_pose(w, N, vi, fi, code_noise=self._noise(N), train=bool(update),
-                           begin=(w['zero_arena'], bool(update), adam_segs))
-        else:
-            e.step_begin(w['zero_arena'], bool(update), adam_segs)
-            e.forward_pose(w, N, vi, fi, code_noise=self._noise(N), train=bool(update))
+        # first launch: phase / RBF / code forward; its further blocks zero the loss scalars, view accumulators, dAA, dJp,
+        # dA2, dPF2 and the gradient buffer and advance the device Adam table (nemo_phase_embed_fwd_begin)
+        e.forward_pose(w, N, vi, fi, code_noise=self._noise(N), train=bool(update),
+                       begin=(w['zero_arena'], bool(update), adam_segs))
         main = torch.cuda.current_stream()
         side, side2 = e.side_stream, e.side_stream2
         pose_done = main.record_event()
@@ -564,19 +596,16 @@ class MultiViewModel(nn.Module):
         if update:
             e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose,
                           dj3d_extra=dj, norm_from_acc=True)
-        # side : VPoser encode -> decode -> axis-angle (the mesh term waits for it)
-        # side2: everything that accumulates into dAA -- GMM prior, 3-D pose term (they only need the pose), then, once
-        #        the encoder output exists, KL and its backward through the frozen encoder.  One stream for all of
-        #        them: their `+=` into dAA are plain read-modify-writes.
-        # (Variants measured and dropped, profiles/r02_experiments.md section 5: priors enqueued before the VPoser chain,
-        #  KL + its backward appended to the VPoser chain or to the main chain -- equal or slower un-profiled.)
-        # Small batches (one rank's share at 8 GPUs; `e.prior_mode(N)` = 1): TWO queues instead of three -- a replayed
-        # graph starts the third hardware queue ~70 us after its dependency is met (profiles/r02_kernel_trace_v1.md), which
-        # made the prior branch the last arriver in front of the mesh kernel.  The GMM prior and the 3-D term open the
-        # VPoser stream (they need the pose only), KL and its backward close the main chain behind the keypoint backward.
-        mode = e.prior_mode(N)
-
-        def priors():
+        side.wait_event(pose_done)
+        side2.wait_event(pose_done)
+        enc_done = None
+        with torch.cuda.stream(side):
+            if use_vposer:
+                # the decoder starts from the encoder's hidden activation (composed first layer); the (mu | logvar) product
+                # runs on side2 in front of the KL term; 6-D -> axis-angle of the decoder output inside v2v_prep
+                enc_done = e.forward_vposer(w, N, dec_aa=False, compose=True)          # always evaluated, :3569
+                e.forward_v2v_pre(w, N, fused_dec=True)   # rotations + FK of both mesh bodies: only the poses are needed
+        with torch.cuda.stream(side2):
             st = _stream()
             if use_gmm:
                 g = e.gmm
@@ -591,55 +620,16 @@ class MultiViewModel(nn.Module):
                                                 dptr(vi), dptr(fi), e.T, e.scal.data_ptr() + 4 * S_3D,
                                                 float(a.weight_3d_loss) * sh.mr, daa69 if update else None,
                                                 72, e.nvalid, st), 'nemo_pose3d_fwd_bwd')
-
-        def kl_terms():
-            e.vposer_kl(w, N)
-            if update and a.weight_vp_z_loss:
-                e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
-
-        side.wait_event(pose_done)
-        enc_done = None
-        if mode == 0:
-            side2.wait_event(pose_done)
-            with torch.cuda.stream(side):
-                if use_vposer:
-                    fd = os.environ.get('NEMO_FUSED_DEC', '1') != '0'
-                    # the (mu | logvar) product runs on side2 in front of the KL term, the decoder starts from the encoder's
-                    # hidden activation (NEMO_VP_COMPOSE=0: product on the decoder's chain, as before)
-                    vc = os.environ.get('NEMO_VP_COMPOSE', '1') != '0'
-                    enc_done = e.forward_vposer(w, N, dec_aa=not fd, compose=vc)          # always evaluated, :3569
-                    e.forward_v2v_pre(w, N, fused_dec=fd)   # rotations + FK of both mesh bodies: only the poses are needed
-            with torch.cuda.stream(side2):
-                priors()
-                if use_vposer:
-                    side2.wait_event(enc_done)
-                    if vc:
-                        e.vposer_mulv(w, N)
-                    kl_terms()
-                side2.wait_event(kp_done)
-                e.finalize_kp(w, mean_mode=0)
-            main.wait_stream(side)
-            # Small batches: the prior branch (GMM, 3-D term, KL and its backward, the key-point loss scalar) joins BEHIND the
-            # mesh kernel instead of in front of it -- nothing the mesh kernel reads comes from there, and below ~1024
-            # samples its blocks do not fill the machine anyway (NEMO_LATE_JOIN=0 | 1: A/B aid)
-            late_join = bool(use_vposer and e.late_join(N) and os.environ.get('NEMO_PUBLISH', 'aside') != 'main_early')
-            if not late_join:
-                main.wait_stream(side2)
-        else:
-            late_join = False
-            with torch.cuda.stream(side):
-                priors()
-                priors_done = side.record_event()
-                if use_vposer:
-                    fd = os.environ.get('NEMO_FUSED_DEC', '1') != '0'
-                    enc_done = e.forward_vposer(w, N, dec_aa=not fd)
-                    e.forward_v2v_pre(w, N, fused_dec=fd)
             if use_vposer:
-                main.wait_event(enc_done)
-                main.wait_event(priors_done)             # (`+=` into dAA: after the prior terms)
-                kl_terms()
+                side2.wait_event(enc_done)
+                e.vposer_mulv(w, N)
+                e.vposer_kl(w, N)
+                if update and a.weight_vp_z_loss:
+                    e.backward_vposer_kl(w, N, float(a.weight_vp_z_loss) * sh.mr)
+            side2.wait_event(kp_done)
             e.finalize_kp(w, mean_mode=0)
-            main.wait_stream(side)
+        main.wait_stream(side)
+        main.wait_stream(side2)
         # the fused mesh kernel is sized to fill the machine in exactly one resident wave of blocks:
         # it runs alone (anything co-scheduled pushes part of its grid into a second wave, +60 %)
         if extra_losses is not None:
@@ -650,34 +640,18 @@ class MultiViewModel(nn.Module):
         # enqueued LAST (a replayed graph keeps the first-enqueued successor on the queue, see above), joined before Adam.
         # Measured (same box, three runs each): 0.494 ms at one instance / 1.557 ms at C2 against 0.512 / 1.576 with the
         # hand-over on the main stream, before or after the adjoint -- its system-scope release stalls the queue it is on.
-        # (NEMO_PUBLISH=main_early | main_late: A/B aid.)
         loss_final = []
-        pub_mode = os.environ.get('NEMO_PUBLISH', 'aside')
-        pub_aside = bool(publish and update and part == 'all' and use_vposer and e.overlap_bwd and pub_mode in ('aside', 'aside4'))
-        pub4 = pub_aside and pub_mode == 'aside4'      # (A/B aid: the hand-over on a stream of its own, enqueued FIRST)
-        pub_early = bool(publish and use_vposer and pub_mode == 'main_early')
+        pub_aside = bool(publish and update and part == 'all' and use_vposer)
         if use_vposer:
             e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss), pre_done=True,
-                          after_loss=(lambda: loss_final.append(main.record_event())) if pub_aside else
-                          (e.publish_scalars if pub_early else None))
-        if pub4:
-            ps = e.pub_stream
-            ps.wait_event(loss_final[0])
-            if late_join:
-                ps.wait_stream(side2)
-            with torch.cuda.stream(ps):
-                e.publish_scalars()
-        if late_join:
-            main.wait_stream(side2)
-        if publish and not pub_aside and not pub_early:
+                          after_loss=(lambda: loss_final.append(main.record_event())) if pub_aside else None)
+        if publish and not pub_aside:
             e.publish_scalars()
         if not update or part == 'head':
             return
         self._backward_tail(w, N, vi, fi, update, use_vposer, sh, stages=(0,) if part == 'k0' else (0, 1, 2),
                             bucketed=part == 'k0')
-        if pub4:
-            main.wait_stream(e.pub_stream)
-        elif pub_aside:
+        if pub_aside:
             side2.wait_event(loss_final[0])
             with torch.cuda.stream(side2):
                 e.publish_scalars()
@@ -698,291 +672,328 @@ class MultiViewModel(nn.Module):
             e.finish_trans_grad(w, N)
         e.backward_mlp(w, N, vi, fi, None, stages=stages, bucketed=bucketed)
 
+    # ---- launch machinery shared by step / warmup / opt_cam ----------------------------------------------------------
+    def _captured(self, w, key, fn, sharded=False, comm_inside=False):
+        """Run ``fn()`` -- a closure that only ENQUEUES device work on the current stream(s), no host read-back -- as a
+        replayed HIP graph: the first sight of ``key`` in workspace ``w`` runs eagerly (sets kernel attributes, sizes
+        pools; a shape that shows up once -- a rank's share of a random minibatch -- is not worth a capture), the second
+        is captured, every later one replayed.  ``comm_inside``: fn contains RCCL collectives; if their capture fails this
+        model goes back to the graph-then-eager-collectives structure from the next step on (``self.graph_comm``)."""
+        entry = w['graphs'].get(key)
+        self.launch_stats['replayed' if isinstance(entry, torch.cuda.CUDAGraph) else 'other'] += 1
+        if entry == 'eager':
+            return fn()
+        if not isinstance(entry, torch.cuda.CUDAGraph) and (entry or 0) < self.GRAPH_AFTER:
+            w['graphs'][key] = (entry or 0) + 1
+            return fn()
+        if not isinstance(entry, torch.cuda.CUDAGraph):           # capture the launches of `fn` as one HIP graph
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            # The cyclic garbage collector stays off while the capture is open (torch.cuda.graph collects once
+            # BEFORE it begins): a finaliser that touches the device -- a stale graph, a communicator kept alive by
+            # one -- firing between two captured launches aborts the process.
+            gc_on = gc.isenabled()
+            gc.disable()
+            try:
+                _inject_capture_fault(sharded, comm_inside)
+                # (sharded: the process group's watchdog thread polls events of earlier collectives -- legal next
+                #  to a capture in 'thread_local' mode, an invalidated capture in the default 'global' mode)
+                with torch.cuda.graph(g, capture_error_mode='thread_local' if sharded else 'global'):
+                    fn()
+            except RuntimeError as ex:
+                # e.g. a capture invalidated by another thread of the process (a collective's
+                # watchdog): nothing of fn has run; keep launching this variant kernel by
+                # kernel -- same HIP kernels, only the launch overhead comes back
+                warnings.warn(f'HIP graph capture failed ({ex}); this step variant runs un-captured')
+                torch.cuda.synchronize()
+                w['graphs'][key] = 'eager'
+                if comm_inside:
+                    # a collective that would not capture: from the next step on this model goes back to a graph of
+                    # the step followed by eager collectives / hand-over / Adam (the same collectives in the same
+                    # order, so ranks that did capture stay in step with this one)
+                    self.graph_comm = False
+                return fn()
+            else:
+                w['graphs'][key] = entry = g
+            finally:
+                if gc_on:
+                    gc.enable()
+        entry.replay()
+
+    def _stage_indices(self, w, vi, fi, N, n_valid=None):
+        """Step inputs of a captured launch live in the workspace's device-resident index buffers.  Host-resident indices
+        go through pinned staging: a pageable H2D copy would block the host until the previous step -- still running,
+        the losses are handed over mid-step -- has drained.  The staging buffer is free: the previous copy out of it was
+        enqueued before the launch whose losses we already hold.  ``n_valid``: the number of real samples of a padded
+        launch, stored behind the view indices (one copy)."""
+        cap = w['cap']
+        src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N)
+        if w.get('_static_src') != src or vi is not w.get('_static_vi'):   # (full batch: cached, unchanged)
+            if vi.device.type == 'cpu' and fi.device.type == 'cpu':
+                if '_idx_pin' not in w:
+                    w['_idx_pin'] = torch.zeros(2, cap + 1, dtype=w['vi_static'].dtype).pin_memory()
+                pin = w['_idx_pin']
+                pin[0, :N].copy_(vi)
+                pin[1, :N].copy_(fi)
+                if n_valid is not None:
+                    pin[0, cap] = n_valid
+                    w['vi_static'].copy_(pin[0], non_blocking=True)
+                else:
+                    w['vi_static'][:N].copy_(pin[0, :N], non_blocking=True)
+                w['fi_static'][:N].copy_(pin[1, :N], non_blocking=True)
+            else:
+                w['vi_static'][:N].copy_(vi)
+                w['fi_static'][:N].copy_(fi)
+                if n_valid is not None:
+                    w['vi_static'][cap:].fill_(n_valid)
+            w['_static_src'], w['_static_vi'] = src, vi
+        return w['vi_static'][:N], w['fi_static'][:N]      # (the workspace may be larger than this batch)
+
+    def _prepare_batch(self, view_idx, frame_idx, full_batch, sh):
+        """-> _Batch: the samples of one step as the kernels will see them (indices, launch size, shard normalisers)."""
+        e, a = self.engine, self.args
+        b = _Batch()
+        b.is_full = not (a.batch_size > -1 and not full_batch)
+        b.noise = bool(self.VERSION >= 3 and self.training and getattr(a, 'code_noise', 0) > 0)
+        b.host_idx = False
+        if not b.is_full:
+            vi, fi = torch.as_tensor(view_idx), torch.as_tensor(frame_idx)
+            # Host-resident indices (what fit.run_fit / draw_batch produce) stay on the host when the step replays a graph
+            # (_stage_indices); device-resident ones (the reference script moves them first, scripts:291-296) are used as
+            # they are
+            b.host_idx = (vi.numel() > 0 and vi.device.type == 'cpu' and fi.device.type == 'cpu'
+                          and vi.dtype == torch.long and fi.dtype == torch.long)
+            if not (b.host_idx and self.use_graphs and e.timers is None and not b.noise):
+                vi, fi = self._idx(vi), self._idx(fi)
+        else:
+            vi, fi = self.full_indices()
+        b.Nv = b.N = vi.numel()              # Nv: real samples; N: samples the kernels are launched with
+        # Padded launch (a rank's share of a sharded random minibatch, scripts:291-296 / nemomocap-example.sh:17): the
+        # share size changes every step, a captured graph is per launch size -- so the share is rounded up to a multiple
+        # of sh.pad with masked rows (valid indices, no loss, no count, zero gradient: include/nemo_hip.h) and the
+        # per-sample means are taken over the launch size with mr = N_launch / N_global.
+        b.padded = bool(sh.pad and not b.is_full and b.Nv > 0 and sh.n_global)
+        if b.padded:
+            b.N = -(-b.Nv // sh.pad) * sh.pad
+            assert b.N <= 8192, 'padded launches are single-chunk (minibatch shares)'
+            vi = torch.nn.functional.pad(vi, (0, b.N - b.Nv))         # (view 0, frame 0): valid memory, masked out
+            fi = torch.nn.functional.pad(fi, (0, b.N - b.Nv))
+            sh = ShardInfo(kr=sh.kr, mr=b.N / float(sh.n_global), vr=sh.vr, n_global=sh.n_global, comm=sh.comm,
+                           comm_small=sh.comm_small, comm_bucket=sh.comm_bucket, pad=sh.pad, capturable=sh.capturable,
+                           live=sh.live)
+        b.vi, b.fi, b.sh = vi, fi, sh
+        return b
+
+    def _plan_step(self, b, update):
+        """-> _Plan: HOW this step is launched.  One place decides the launch structure; `_graph_key` is the one place
+        that says what a captured launch bakes in.
+
+        mode 'plain'   : one launch (graph) of the whole step [+ Adam]; single GPU, or a sharded step whose collectives
+                         cannot be captured (gloo): then graph -> eager all-reduce -> hand-over -> Adam;
+             'split'   : two launches ('head' / 'tail'), the 32-byte loss all-reduce + hand-over on the side stream between;
+             'buckets' : three launches (k0 / k1 / k2), a gradient bucket reduced + Adam-stepped behind each;
+             'allc' / 'splitc' / 'bucketc': the same three structures as ONE captured launch with the RCCL collectives,
+                         the hand-over and Adam inside the graph (sharded, nccl backend, self.graph_comm)."""
+        e, a, sh = self.engine, self.args, b.sh
+        pl = _Plan()
+        pl.update = bool(update)
+        pl.has_inst = bool(self.VERSION >= 3 and getattr(a, 'weight_instance_loss', 0) and e.C > 0)
+        # single-GPU steps hand the losses to the host as soon as they are final (engine.publish_scalars)
+        pl.early = bool(e.early_readback and sh.comm is None and b.N > 0)
+        bucketed = bool(update and sh.comm is not None and sh.comm_bucket is not None and self.VERSION >= 1)
+        split = bool(update and sh.comm is not None and sh.comm_small is not None and e.early_readback and not bucketed)
+        pl.graphable = bool(self.use_graphs and b.N > 0 and e.timers is None and not b.noise)
+        pl.segs = None
+        if update:
+            pl.segs = []
+            for o in self.optimizers:
+                pl.segs += o.segments(None)
+        cap_ok = bool(self.graph_comm and sh.capturable and pl.graphable and update and sh.comm is not None
+                      and e.early_readback and self.VERSION >= 1)
+        pl.bgroups = None
+        pl.mode = 'plain'
+        if bucketed:
+            pl.mode = 'buckets'
+            if cap_ok:
+                # the device Adam table grouped by bucket: [bucket 0 | bucket 1 | bucket 2 | private], (start, count, max numel)
+                bk = e.layout.buckets()
+                lo_, hi_ = bk[2][0], bk[0][1]
+                groups = [clip_segments(pl.segs, *bk[i]) for i in range(3)]
+                groups.append(clip_segments(pl.segs, 0, lo_) + clip_segments(pl.segs, hi_, e.layout.total))
+                if sum(len(g_) for g_ in groups) <= _lib.ADAM_MAX_SEG:
+                    pl.bgroups, at = [], 0
+                    for g_ in groups:
+                        pl.bgroups.append((at, len(g_), max([s_['numel'] for s_ in g_], default=0)))
+                        at += len(g_)
+                    pl.segs = [s_ for g_ in groups for s_ in g_]
+                    pl.mode = 'bucketc'
+        elif cap_ok:
+            pl.mode = 'splitc' if split else 'allc'
+        elif split:
+            pl.mode = 'split'
+        # the fused Adam runs inside the captured graph unless a gradient all-reduce must come first (and stays outside)
+        pl.in_graph_adam = bool(update and (sh.comm is None or pl.mode in ('allc', 'splitc', 'bucketc')))
+        return pl
+
+    def _graph_key(self, b, pl, part):
+        """Everything a captured launch bakes in besides device-resident inputs: the launch size and mode, the shard
+        normalisers, the engine switches of the public NemoV2 setters, the loss weights and loss type, and the geometry
+        of the in-graph Adam."""
+        e, sh = self.engine, b.sh
+        return ('step', b.N, pl.update, b.is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, sh.live, part, pl.early,
+                b.padded, e.detach_articulation, e.start_global_traj_anywhere, pl.has_inst, self._weights_key(),
+                tuple((s_['offset'], s_['numel']) for s_ in pl.segs) if pl.in_graph_adam else None)
+
+    def _inst_term(self, sh, update):                                                 # :3864-3867
+        e, a = self.engine, self.args
+        n_code = e.V * e.C
+        check(e.lib.nemo_sqmean_fwd_bwd(n_code, e.p('learned_instance_code'), e.scal.data_ptr() + 4 * S_INST,
+                                        e.g('learned_instance_code') if update else None,
+                                        2.0 * float(a.weight_instance_loss) * sh.vr / n_code, _stream()),
+              'nemo_sqmean_fwd_bwd')
+
+    def _body(self, w, b, pl, vi_, fi_, adam_table, part='all', run_adam=True):
+        """Everything of the step (or of one part of it) that runs on the device without host interaction."""
+        e, sh, update = self.engine, b.sh, pl.update
+        if part == 'bucketc':
+            # 'buckets' mode as ONE launch: the three gradient buckets are all-reduced on the communication stream as
+            # soon as the backward has completed them, each with its share of the fused Adam (device table, segments
+            # grouped by bucket) right behind its collective; the main stream goes on with the backward meanwhile
+            main, cs = torch.cuda.current_stream(), e.comm_stream
+            bk = e.layout.buckets()
+            slot = e.view('_comm_scalars', e.grads)
+            for i, kpart in enumerate(('k0', 'k1', 'k2')):
+                self._body(w, b, pl, vi_, fi_, adam_table if i == 0 else None, kpart, run_adam=False)
+                cs.wait_event(main.record_event())
+                with torch.cuda.stream(cs):
+                    if i == 2:
+                        torch.mul(e.scal, self._shard_weights(sh), out=slot)
+                    sh.comm_bucket(e.grads[bk[i][0]:bk[i][1]])
+                    if i == 2:
+                        e.publish_scalars(slot)
+                    st_, n_, mx_ = pl.bgroups[i]
+                    if n_:
+                        e.adam_from_table(n_, mx_, st_)
+            st_, n_, mx_ = pl.bgroups[3]                      # this rank's private parameters, on the main stream
+            if n_:
+                e.adam_from_table(n_, mx_, st_)
+            main.wait_stream(cs)
+            return
+        if part in ('allc', 'splitc'):
+            # Sharded update step with its collectives INSIDE the launch (one captured graph per step: RCCL all-reduces
+            # are capturable, tools/debug/graph_capture_rccl.py): body -> weighted loss scalars -> all-reduce(s) ->
+            # hand-over to the host -> Adam.  'splitc': the 32-byte all-reduce of the loss scalars and their hand-over
+            # fork to the side stream after the first half, as in ShardedNemo's 'split' mode.
+            main = torch.cuda.current_stream()
+            if part == 'splitc':
+                self._body(w, b, pl, vi_, fi_, adam_table, 'head', run_adam=False)
+                self._reduce_scalars_on_side_stream(sh)
+                if b.N > 0:
+                    self._body(w, b, pl, vi_, fi_, None, 'tail', run_adam=False)
+                sh.comm(e, update)
+            else:
+                self._body(w, b, pl, vi_, fi_, adam_table, 'all', run_adam=False)
+                slot = e.view('_comm_scalars', e.grads)
+                torch.mul(e.scal, self._shard_weights(sh), out=slot)
+                sh.comm(e, update)
+                e.publish_scalars(slot)
+            if adam_table is not None:
+                e.adam_from_table(*adam_table)
+            else:
+                e.adam(pl.segs)
+            if part == 'splitc':
+                main.wait_stream(e.side_stream)
+            return
+        if b.N > 0:
+            self._forward_backward(w, b.N, vi_, fi_, update, sh=sh, smooth_ok=b.is_full,
+                                   extra_losses=(lambda: self._inst_term(sh, update)) if pl.has_inst else None,
+                                   publish=pl.early, part=part,
+                                   adam_segs=adam_table[0] if adam_table is not None else 0,
+                                   use_vposer=self.VERSION >= 1, use_gmm=True)
+        elif part != 'tail':        # a shard may own none of a minibatch's samples
+            e.scal.zero_()
+            if update:
+                e.grads.zero_()
+            if pl.has_inst:
+                self._inst_term(sh, update)
+        if adam_table is not None and run_adam:
+            e.adam_from_table(*adam_table)
+
+    def _run_part(self, w, b, pl, part):
+        """One launch of `part` of the step: a replayed HIP graph once the variant has been seen often enough."""
+        e = self.engine
+        if not pl.graphable and not b.padded:
+            return self._body(w, b, pl, b.vi, b.fi, None, part)
+        if part in ('all', 'head', 'k0', 'allc', 'splitc', 'bucketc'):          # the first launch of a step stages its inputs
+            self._stage_indices(w, b.vi, b.fi, b.N, b.Nv if b.padded else None)
+        svi, sfi = w['vi_static'][:b.N], w['fi_static'][:b.N]
+        if not pl.graphable:
+            self._body(w, b, pl, svi, sfi, None, part)
+            b.vi, b.fi = svi, sfi
+            return
+        table = e.adam_table_sync(pl.segs) if (pl.in_graph_adam and part != 'head') else None
+        try:
+            self._captured(w, self._graph_key(b, pl, part), lambda: self._body(w, b, pl, svi, sfi, table, part),
+                           sharded=b.sh.comm is not None, comm_inside=part in ('allc', 'splitc', 'bucketc'))
+        except BaseException:
+            if table is not None:
+                e.adam_table_invalidate()     # step_begin may or may not have advanced the device table
+            raise
+        if table is not None:
+            e.adam_table_commit()
+        if part != 'head':
+            b.vi, b.fi = svi, sfi
+
     def step(self, view_idx, frame_idx, update=True, full_batch=False, _shard=None):
         """:3511-3598 (V1/V2), :3796-3909 (V3/V4)."""
         e, a = self.engine, self.args
-        sh = _shard or ShardInfo()
         if self.VERSION == 0 and a.weight_vp_loss:
             # the reference multiplies weight_vp_loss with the (v2v, kl) TUPLE vposer_loss returns (:3330-3332)
             raise TypeError("NemoV0 cannot run with weight_vp_loss != 0 (can't multiply sequence by non-int in the reference)")
         if self.VERSION >= 3 and update:
             self.training = True
-        is_full = not (a.batch_size > -1 and not full_batch)
-        noise = self.VERSION >= 3 and self.training and getattr(a, 'code_noise', 0) > 0
-        if not is_full:
-            vi, fi = torch.as_tensor(view_idx), torch.as_tensor(frame_idx)
-            # Host-resident indices (what the script draws, scripts/learned_multi_view_recon_nn.py:291-296) stay on
-            # the host when the step replays a graph: they reach the device through the workspace's pinned staging
-            # buffer below.  A plain ``.to(device)`` of pageable memory would park the host until the previous step
-            # -- still running, see `early` -- has drained.
-            stage = (self.use_graphs and e.timers is None and not noise and vi.numel() > 0
-                     and vi.device.type == 'cpu' and fi.device.type == 'cpu'
-                     and vi.dtype == torch.long and fi.dtype == torch.long)
-            if not stage:
-                vi, fi = self._idx(vi), self._idx(fi)
-        else:
-            vi, fi = self.full_indices()
-        Nv = N = vi.numel()              # Nv: real samples; N: samples the kernels are launched with
-        # Padded launch (a rank's share of a sharded random minibatch, scripts:291-296 / nemomocap-example.sh:17): the
-        # share size changes every step, a captured graph is per launch size -- so the share is rounded up to a multiple
-        # of sh.pad with masked rows (valid indices, no loss, no count, zero gradient: include/nemo_hip.h) and the
-        # per-sample means are taken over the launch size with mr = N_launch / N_global.
-        padded = bool(sh.pad and not is_full and Nv > 0 and sh.n_global)
-        if padded:
-            N = -(-Nv // sh.pad) * sh.pad
-            assert N <= 8192, 'padded launches are single-chunk (minibatch shares)'
-            vi = torch.nn.functional.pad(vi, (0, N - Nv))         # (view 0, frame 0): valid memory, masked out
-            fi = torch.nn.functional.pad(fi, (0, N - Nv))
-            sh = ShardInfo(kr=sh.kr, mr=N / float(sh.n_global), vr=sh.vr, n_global=sh.n_global, comm=sh.comm,
-                           comm_small=sh.comm_small, comm_bucket=sh.comm_bucket, pad=sh.pad, capturable=sh.capturable,
-                           live=sh.live)
+        b = self._prepare_batch(view_idx, frame_idx, full_batch, _shard or ShardInfo())
+        sh, N = b.sh, b.N
         w = e._ws(max(N, 1))
         e.scal = w['scal']               # (a replayed graph wrote this workspace's slots)
         e.sync_betas()                   # host-side state a captured graph cannot re-read (checkpoint load, eval)
-        has_inst = bool(self.VERSION >= 3 and getattr(a, 'weight_instance_loss', 0) and e.C > 0)
-
-        def body(vi_, fi_, adam_table, part='all', run_adam=True):
-            """Everything of the step (or of one half of it) that runs on the device without host interaction."""
-            if part == 'bucketc':
-                # 'buckets' mode as ONE launch: the three gradient buckets are all-reduced on the communication stream as
-                # soon as the backward has completed them, each with its share of the fused Adam (device table, segments
-                # grouped by bucket) right behind its collective; the main stream goes on with the backward meanwhile
-                main, cs = torch.cuda.current_stream(), e.comm_stream
-                bk = e.layout.buckets()
-                slot = e.view('_comm_scalars', e.grads)
-                for i, kpart in enumerate(('k0', 'k1', 'k2')):
-                    body(vi_, fi_, adam_table if i == 0 else None, kpart, run_adam=False)
-                    cs.wait_event(main.record_event())
-                    with torch.cuda.stream(cs):
-                        if i == 2:
-                            torch.mul(e.scal, self._shard_weights(sh), out=slot)
-                        sh.comm_bucket(e.grads[bk[i][0]:bk[i][1]])
-                        if i == 2:
-                            e.publish_scalars(slot)
-                        st_, n_, mx_ = bgroups[i]
-                        if n_:
-                            e.adam_from_table(n_, mx_, st_)
-                st_, n_, mx_ = bgroups[3]                      # this rank's private parameters, on the main stream
-                if n_:
-                    e.adam_from_table(n_, mx_, st_)
-                main.wait_stream(cs)
-                return
-            if part in ('allc', 'splitc'):
-                # Sharded update step with its collectives INSIDE the launch (one captured graph per step: RCCL all-reduces
-                # are capturable, tools/debug/graph_capture_rccl.py): body -> weighted loss scalars -> all-reduce(s) ->
-                # hand-over to the host -> Adam.  'splitc': the 32-byte all-reduce of the loss scalars and their hand-over
-                # fork to the side stream after the first half, as in ShardedNemo's 'split' mode.
-                main = torch.cuda.current_stream()
-                if part == 'splitc':
-                    body(vi_, fi_, adam_table, 'head', run_adam=False)
-                    self._reduce_scalars_on_side_stream(sh)
-                    if N > 0:
-                        body(vi_, fi_, None, 'tail', run_adam=False)
-                    sh.comm(e, update)
-                else:
-                    body(vi_, fi_, adam_table, 'all', run_adam=False)
-                    slot = e.view('_comm_scalars', e.grads)
-                    torch.mul(e.scal, self._shard_weights(sh), out=slot)
-                    sh.comm(e, update)
-                    e.publish_scalars(slot)
-                if adam_table is not None:
-                    e.adam_from_table(*adam_table)
-                else:
-                    e.adam(segs)
-                if part == 'splitc':
-                    main.wait_stream(e.side_stream)
-                return
-
-            def inst_term():                                                              # :3864-3867
-                n_code = e.V * e.C
-                check(e.lib.nemo_sqmean_fwd_bwd(n_code, e.p('learned_instance_code'), e.scal.data_ptr() + 4 * S_INST,
-                                                e.g('learned_instance_code') if update else None,
-                                                2.0 * float(a.weight_instance_loss) * sh.vr / n_code, _stream()),
-                      'nemo_sqmean_fwd_bwd')
-            if N > 0:
-                self._forward_backward(w, N, vi_, fi_, update, sh=sh, smooth_ok=is_full,
-                                       extra_losses=inst_term if has_inst else None, publish=early, part=part,
-                                       adam_segs=adam_table[0] if adam_table is not None else 0,
-                                       use_vposer=self.VERSION >= 1, use_gmm=True)
-            elif part != 'tail':        # a shard may own none of a minibatch's samples
-                e.scal.zero_()
-                if update:
-                    e.grads.zero_()
-                if has_inst:
-                    inst_term()
-            if adam_table is not None and run_adam:
-                e.adam_from_table(*adam_table)
-
-        # single-GPU steps hand the losses to the host as soon as they are final (engine.publish_scalars)
-        early = e.early_readback and sh.comm is None and N > 0
-        # Sharded update steps: by default ONE collective per step -- the loss scalars ride in the last 8 floats of
-        # the shared-gradient all-reduce (_reduce_and_read).  Opt-in (ShardedNemo.set_shard_mode('split'), which
-        # hands a `comm_small` to the step): two halves -- the loss scalars are final after the first, so their
-        # (tiny) all-reduce and the hand-over to the host go to the side stream while the main stream continues
-        # with the rest of the backward, the gradient all-reduce and Adam; the host then has the global losses
-        # before the step ends and prepares the next launch meanwhile.  (Every rank takes the same route whatever
-        # its share of the batch, so the collectives line up.)
-        bucketed = bool(update and sh.comm is not None and sh.comm_bucket is not None and self.VERSION >= 1)
-        split = bool(update and sh.comm is not None and sh.comm_small is not None and e.early_readback and not bucketed)
-        graphable = self.use_graphs and N > 0 and e.timers is None and not noise
-        segs = None
-        if update:
-            segs = []
-            for o in self.optimizers:
-                segs += o.segments(None)
-        # Sharded update steps as ONE launch: collectives, hand-over and Adam inside the captured graph (NEMO_GRAPH_COMM=0:
-        # the round-2 structure -- graph, then eager all-reduce / hand-over / Adam)
-        cap_ok = bool(self.graph_comm and sh.capturable and graphable and update and sh.comm is not None
-                      and e.early_readback and self.VERSION >= 1)
-        comm_in_graph = cap_ok and not bucketed
-        bucket_in_graph = cap_ok and bucketed
-        bgroups = None
-        if bucket_in_graph:
-            # the device Adam table grouped by bucket: [bucket 0 | bucket 1 | bucket 2 | private], (start, count, max numel)
-            bk = e.layout.buckets()
-            lo_, hi_ = bk[2][0], bk[0][1]
-            groups = [clip_segments(segs, *bk[i]) for i in range(3)]
-            groups.append(clip_segments(segs, 0, lo_) + clip_segments(segs, hi_, e.layout.total))
-            bgroups, at = [], 0
-            for g_ in groups:
-                bgroups.append((at, len(g_), max([s_['numel'] for s_ in g_], default=0)))
-                at += len(g_)
-            segs = [s_ for g_ in groups for s_ in g_]
-            if len(segs) > _lib.ADAM_MAX_SEG:
-                bucket_in_graph, bgroups = False, None
-        # the fused Adam runs inside the captured graph unless a gradient all-reduce must come first (and stays outside)
-        in_graph_adam = update and (sh.comm is None or comm_in_graph or bucket_in_graph)
-        if early or split or comm_in_graph or (bucketed and e.early_readback):
+        pl = self._plan_step(b, update)
+        if pl.early or pl.mode in ('split', 'allc', 'splitc', 'bucketc') or (pl.mode == 'buckets' and e.early_readback):
             e.arm_scalars()
-
-        def run(part):
-            """One launch of `part` of the body: a replayed HIP graph once the variant has been seen often enough."""
-            nonlocal vi, fi
-            if not graphable and not padded:
-                body(vi, fi, None, part)
-                return
-            # everything the captured launches bake in besides device-resident inputs: the mode, the shard
-            # normalisers, the engine switches of the public NemoV2 setters, the loss weights and loss type
-            key = (N, bool(update), is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, sh.live, part, early, padded,
-                   e.detach_articulation, e.start_global_traj_anywhere, has_inst, self._weights_key(),
-                   tuple((s_['offset'], s_['numel']) for s_ in segs) if in_graph_adam else None)
-            cap = w['cap']
-            if part in ('all', 'head', 'k0', 'allc', 'splitc', 'bucketc'):          # the first launch of a step stages its inputs
-                src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N)
-                if w.get('_static_src') != src or vi is not w.get('_static_vi'):   # (full batch: cached, unchanged)
-                    if vi.device.type == 'cpu' and fi.device.type == 'cpu':
-                        # through pinned staging: a pageable H2D copy would block the host until the previous
-                        # step (still running, see `early`) has drained.  The staging buffer is free: the
-                        # previous copy out of it was enqueued before the launch whose losses we already hold.
-                        if '_idx_pin' not in w:
-                            w['_idx_pin'] = torch.zeros(2, cap + 1, dtype=w['vi_static'].dtype).pin_memory()
-                        pin = w['_idx_pin']
-                        pin[0, :N].copy_(vi)
-                        pin[1, :N].copy_(fi)
-                        if padded:                       # + the number of real samples, behind the view indices
-                            pin[0, cap] = Nv
-                            w['vi_static'].copy_(pin[0], non_blocking=True)
-                        else:
-                            w['vi_static'][:N].copy_(pin[0, :N], non_blocking=True)
-                        w['fi_static'][:N].copy_(pin[1, :N], non_blocking=True)
-                    else:
-                        w['vi_static'][:N].copy_(vi)
-                        w['fi_static'][:N].copy_(fi)
-                        if padded:
-                            w['vi_static'][cap:].fill_(Nv)
-                    w['_static_src'], w['_static_vi'] = src, vi
-            svi, sfi = w['vi_static'][:N], w['fi_static'][:N]      # (the workspace may be larger than this batch)
-            if not graphable:
-                body(svi, sfi, None, part)
-                vi, fi = svi, sfi
-                return
-            table = e.adam_table_sync(segs) if (in_graph_adam and part != 'head') else None
-            try:
-                launch(key, svi, sfi, table, part)
-            except BaseException:
-                if table is not None:
-                    e.adam_table_invalidate()     # step_begin may or may not have advanced the device table
-                raise
-            if table is not None:
-                e.adam_table_commit()
-            if part != 'head':
-                vi, fi = svi, sfi
-
-        def launch(key, svi, sfi, table, part):
-            entry = w['graphs'].get(key)
-            self.launch_stats['replayed' if isinstance(entry, torch.cuda.CUDAGraph) else 'other'] += 1
-            if entry == 'eager':
-                body(svi, sfi, table, part)
-            elif not isinstance(entry, torch.cuda.CUDAGraph) and (entry or 0) < self.GRAPH_AFTER:
-                # first sights: eager (sets kernel attributes, sizes pools; a shape that shows up once or
-                # twice -- a rank's share of a random minibatch -- is not worth a capture)
-                w['graphs'][key] = (entry or 0) + 1
-                body(svi, sfi, table, part)
-            else:
-                if not isinstance(entry, torch.cuda.CUDAGraph):   # capture the ~70-launch step as one HIP graph
-                    torch.cuda.synchronize()
-                    g = torch.cuda.CUDAGraph()
-                    # The cyclic garbage collector stays off while the capture is open (torch.cuda.graph collects once
-                    # BEFORE it begins): a finaliser that touches the device -- a stale graph, a communicator kept alive by
-                    # one -- firing between two captured launches aborts the process.
-                    gc_on = gc.isenabled()
-                    gc.disable()
-                    try:
-                        # (sharded: the process group's watchdog thread polls events of earlier collectives -- legal next
-                        #  to a capture in 'thread_local' mode, an invalidated capture in the default 'global' mode)
-                        with torch.cuda.graph(g, capture_error_mode='thread_local' if sh.comm is not None else 'global'):
-                            body(svi, sfi, table, part)
-                    except RuntimeError as ex:
-                        # e.g. a capture invalidated by another thread of the process (a collective's
-                        # watchdog): nothing of the body has run; keep launching this variant kernel by
-                        # kernel -- same HIP kernels, only the launch overhead comes back
-                        warnings.warn(f'HIP graph capture failed ({ex}); this step variant runs un-captured')
-                        torch.cuda.synchronize()
-                        w['graphs'][key] = entry = 'eager'
-                        if part in ('allc', 'splitc', 'bucketc'):
-                            # a collective that would not capture: from the next step on this model goes back to a graph of
-                            # the step followed by eager collectives / hand-over / Adam (the same collectives in the same
-                            # order, so ranks that did capture stay in step with this one)
-                            self.graph_comm = False
-                        body(svi, sfi, table, part)
-                    else:
-                        w['graphs'][key] = entry = g
-                    finally:
-                        if gc_on:
-                            gc.enable()
-                if entry != 'eager':
-                    entry.replay()
-
-        need_adam = update and not (graphable and in_graph_adam)
-        e.nvalid = w['vi_static'][w['cap']:].data_ptr() if padded else None
+        need_adam = update and not (pl.graphable and pl.in_graph_adam)
+        e.nvalid = w['vi_static'][w['cap']:].data_ptr() if b.padded else None
         try:
-            if bucket_in_graph:
-                run('bucketc')
+            if pl.mode in ('allc', 'splitc', 'bucketc'):       # one captured launch, collectives inside
+                self._run_part(w, b, pl, pl.mode)
                 s = e.wait_scalars()
-            elif bucketed:
-                s = self._bucketed_update(sh, segs, run, N, has_inst)
-            elif comm_in_graph:
-                run('splitc' if split else 'allc')
-                s = e.wait_scalars()
-            elif split:
-                run('head')
+            elif pl.mode == 'buckets':
+                s = self._bucketed_update(w, b, pl)
+            elif pl.mode == 'split':
+                # Two halves -- the loss scalars are final after the first, so their (tiny) all-reduce and the hand-over
+                # to the host go to the side stream while the main stream continues with the rest of the backward, the
+                # gradient all-reduce and Adam; the host then has the global losses before the step ends and prepares
+                # the next launch meanwhile.  (Every rank takes the same route whatever its share of the batch, so the
+                # collectives line up.)
+                self._run_part(w, b, pl, 'head')
                 self._reduce_scalars_on_side_stream(sh)         # weights -> small all-reduce -> publish
                 if N > 0:
-                    run('tail')
+                    self._run_part(w, b, pl, 'tail')
                 sh.comm(e, update)                              # shared-gradient all-reduce (main stream)
-                e.adam(segs)
+                e.adam(pl.segs)
                 s = e.wait_scalars()
             else:
-                run('all')
-                if early:    # the losses arrive while the backward / Adam launches above are still running
+                self._run_part(w, b, pl, 'all')
+                if pl.early:    # the losses arrive while the backward / Adam launches above are still running
                     if need_adam:
-                        e.adam(segs)
+                        e.adam(pl.segs)
                     s = e.wait_scalars()
-                else:
-                    s = self._reduce_and_read(sh, update, then=(lambda: e.adam(segs)) if need_adam else None)
+                else:           # sharded default: ONE collective -- the loss scalars ride in the last 8 floats of the
+                    #             shared-gradient all-reduce (_reduce_and_read)
+                    s = self._reduce_and_read(sh, update, then=(lambda: e.adam(pl.segs)) if need_adam else None)
         finally:
             e.nvalid = None
-        if padded:
+        vi, fi, Nv = b.vi, b.fi, b.Nv
+        if b.padded:
             if sh.comm is None:          # (with a collective the scalars come back weighted: _shard_weights)
                 s = np.array(s, dtype=np.float32)
                 s[[S_KL, S_GMM, S_3D]] *= np.float32(N / Nv)          # kernel means are over the launch size
@@ -999,8 +1010,8 @@ class MultiViewModel(nn.Module):
             loss = f32(loss + f32(a.weight_vp_z_loss) * kl)
         loss_dict = {'kp_loss': np.asarray(kp)}
         if self.VERSION >= 3:
-            inst = f32(s[S_INST]) if has_inst else 0
-            if has_inst:
+            inst = f32(s[S_INST]) if pl.has_inst else 0
+            if pl.has_inst:
                 loss = f32(loss + f32(a.weight_instance_loss) * inst)
             if getattr(a, 'weight_3d_loss', 0):
                 loss = f32(loss + f32(a.weight_3d_loss) * l3d)
@@ -1009,7 +1020,7 @@ class MultiViewModel(nn.Module):
         if a.weight_gmm_loss:
             loss = f32(loss + f32(a.weight_gmm_loss) * gmm)
         w_s = float(getattr(a, 'weight_smooth', 0) or 0)
-        if w_s and is_full:                  # optional term, an extra key only when it is switched on
+        if w_s and b.is_full:                  # optional term, an extra key only when it is switched on
             loss = f32(loss + f32(w_s) * f32(s[S_SMOOTH]))
             loss_dict['smooth_loss'] = np.asarray(f32(s[S_SMOOTH]))
         if self.VERSION == 0:             # :3325-3340: kp_loss, gmm_loss, total_loss
@@ -1017,15 +1028,16 @@ class MultiViewModel(nn.Module):
         else:
             loss_dict.update(gmm_loss=np.asarray(gmm), vp_recon_loss=np.asarray(v2v), vp_kl_loss=np.asarray(kl),
                              total_loss=np.asarray(loss))
-        # Non-scalar outputs.  Evaluation steps (update=False; what the script dumps with joblib)
-        # get private copies as in the reference; on training steps the script discards info_dict
-        # (`loss_dict, _ = model.step(...)`), so the tensors are materialised only if accessed --
-        # access them before the next step() call.
+        # Non-scalar outputs.  Evaluation steps (update=False; what the script dumps with joblib) and training steps whose
+        # indices the caller handed over as DEVICE tensors (the unchanged reference script, scripts:291-300) get private
+        # copies as in the reference.  Training steps driven with host-side draws (fit.run_fit, draw_batch) discard
+        # info_dict (`loss_dict, _ = model.step(...)`): there the tensors are materialised only if accessed -- before
+        # the next step() call, which reuses the buffers.
         info_dict = _LazyInfo({'view_idx': vi, 'frame_idx': fi})
         if N > 0:
             makers = dict(loss_all=lambda: self._loss_all(w, N), points2d_gt=lambda: e.targets[vi, fi],
                           points2d=lambda: w['p2d'][:N].clone(), j=lambda: w['j3d'][:N].clone())
-            if update:
+            if update and (b.host_idx or b.is_full):
                 info_dict.lazy.update(makers)
             else:
                 info_dict.update({k: f() for k, f in makers.items()})
@@ -1035,14 +1047,14 @@ class MultiViewModel(nn.Module):
         self.training = False
         return loss_dict, info_dict
 
-    def _bucketed_update(self, sh, segs, run, N, has_inst):
+    def _bucketed_update(self, w, b, pl):
         """Sharded update step with the shared gradient reduced in THREE buckets, each as soon as the backward has
         completed it (engine.ParamLayout.buckets: heads + layer 4, layer 2, layer 0 + RBF widths + the loss scalars),
         on the engine's communication stream, with the fused Adam of a bucket right behind its collective there.  The
         step is three launches (captured graphs k0 / k1 / k2, cut where a bucket completes); the main stream only joins
         the communication stream at the end of the step.  Every rank issues the same three collectives whatever its
         share of the batch (a rank without samples reduces zeros)."""
-        e = self.engine
+        e, sh, segs, N = self.engine, b.sh, pl.segs, b.N
         main, cs = torch.cuda.current_stream(), e.comm_stream
         bk = e.layout.buckets()
         lo, hi = bk[2][0], bk[0][1]
@@ -1060,22 +1072,18 @@ class MultiViewModel(nn.Module):
                 e.adam(clip_segments(segs, *bk[i]))
 
         if N > 0:
-            run('k0')
+            self._run_part(w, b, pl, 'k0')
         else:                    # a shard may own none of a minibatch's samples
             e.scal.zero_()
             e.grads.zero_()
-            if has_inst:
-                n_code = e.V * e.C
-                check(e.lib.nemo_sqmean_fwd_bwd(n_code, e.p('learned_instance_code'), e.scal.data_ptr() + 4 * S_INST,
-                                                e.g('learned_instance_code'),
-                                                2.0 * float(self.args.weight_instance_loss) * sh.vr / n_code, _stream()),
-                      'nemo_sqmean_fwd_bwd')
+            if pl.has_inst:
+                self._inst_term(sh, True)
         reduce(0)
         if N > 0:
-            run('k1')
+            self._run_part(w, b, pl, 'k1')
         reduce(1)
         if N > 0:
-            run('k2')
+            self._run_part(w, b, pl, 'k2')
         reduce(2, last=True)
         # this rank's private parameters (cameras, phase networks, instance codes) on the main stream meanwhile
         e.adam(clip_segments(segs, 0, lo) + clip_segments(segs, hi, e.layout.total))
@@ -1092,7 +1100,8 @@ class MultiViewModel(nn.Module):
                 float(getattr(a, 'weight_smooth', 0) or 0))
 
     def _shard_weights(self, sh):
-        """Per-rank weights that turn the local loss scalars into this rank's share of the global ones."""
+        """Per-rank weights that turn the local loss scalars into this rank's share of the global ones (slot 7: the
+        NaN-gradient count of a warm-up step -- summed over the ranks as it is)."""
         key = (sh.kr, sh.mr, sh.vr)
         if not hasattr(self, '_shard_w'):
             self._shard_w = {}
@@ -1100,7 +1109,7 @@ class MultiViewModel(nn.Module):
         if wv is None:                       # (cached: a host-to-device upload per step otherwise)
             if len(self._shard_w) > 256:
                 self._shard_w.clear()
-            wv = self._shard_w[key] = torch.tensor([sh.kr, 1.0, sh.mr, sh.mr, sh.mr, sh.vr, 1.0, 0.0],
+            wv = self._shard_w[key] = torch.tensor([sh.kr, 1.0, sh.mr, sh.mr, sh.mr, sh.vr, 1.0, 1.0],
                                                    device=self.device)
         return wv
 
@@ -1152,8 +1161,35 @@ class MultiViewModel(nn.Module):
         B = self.args.batch_size
         return (torch.randint(0, self.num_views, size=(B,)), torch.randint(0, self.num_frames, size=(B,)))
 
+    # ------------------------------------------------------------------ warm-up (:3455-3509)
+    def _warmup_device_work(self, w, N, vi, fi, sh, begin, nan_out=None):
+        """One warm-up iteration up to (not including) the update: MLP forward, masked robust 3-D pose loss against the
+        HMR / VIBE track, backward to every motion / phase parameter, NaN-gradient count (+= into ``nan_out``, default:
+        slot 7 of the step's scalars)."""
+        e = self.engine
+        st = _stream()
+        e.scal = w['scal']
+        e.forward_pose(w, N, vi, fi, begin=begin)
+        check(e.lib.nemo_pose3d_fwd_bwd(N, 69, w['AA'].data_ptr() + 12, 72, dptr(e.hmr_theta), dptr(e.hmr_mask),
+                                        dptr(vi), dptr(fi), e.T, e.scal.data_ptr() + 4 * S_3D, float(sh.mr),
+                                        w['dAA'].data_ptr() + 12, 72, None, st), 'nemo_pose3d_fwd_bwd')
+        # rot6d backward of the axis-angle gradient; row N (the phase-0 row: a workspace shared with larger batches keeps
+        # their row there) cleared in the same launch
+        check(e.lib.nemo_pose_bwd_fused(N, dptr(w['ROT']), HEAD_LD, 1, None, dptr(w['dAA']), dptr(w['dROT']), HEAD_LD,
+                                        None, None, 0.0, None, HEAD_LD, 1, st), 'nemo_pose_bwd_fused')
+        e.backward_mlp(w, N, vi, fi, None, has_trans_grad=False)
+        check(e.lib.nemo_nan_count(e.grads.data_ptr(), e.grads.numel(),
+                                   e.scal.data_ptr() + 4 * S_NAN if nan_out is None else dptr(nan_out), _stream()), 'nemo_nan_count')
+
     def warmup(self, warmup_steps=1000, _sharder=None):
-        """:3455-3509: fit the MLP pose output to the HMR/VIBE 3-D pose (motion + phase optimisers)."""
+        """:3455-3509: fit the MLP pose output to the HMR/VIBE 3-D pose (motion + phase optimisers).
+
+        Single process: the iterations never need the host -- their batches are drawn up front in the reference's RNG
+        order (views, then frames, per iteration) and live on the device, an iteration is ONE replayed HIP graph (index
+        gather by a device counter, zero-fills + Adam-table bookkeeping in the phase kernel's launch, forward, backward,
+        NaN-gradient count, loss into a device log, Adam skipped once a NaN has been counted), and the losses and the
+        NaN flag are read once at the end.  A NaN gradient raises FloatingPointError as before -- at the end of the
+        phase, with the parameters as they were before the first poisoned update."""
         if warmup_steps == 0:
             return []
         e, a = self.engine, self.args
@@ -1166,8 +1202,10 @@ class MultiViewModel(nn.Module):
         lm = 'learned_motion.'
         active = set(e.layout.groups['motion'] + e.layout.groups['phase']) - {
             lm + 'linear_out.weight', lm + 'linear_out.bias'}            # their .grad is None in the reference
+        opts = [self.opt_motion, self.opt_phase]
+        if _sharder is None and self.use_graphs and e.timers is None and a.batch_size > 0:
+            return self._warmup_captured(warmup_steps, active, opts)
         losses = []
-        st = _stream()
         for _ in range(warmup_steps):
             if _sharder is not None:          # sharded: GLOBAL draw, routed to this rank's samples
                 vi, fi, sh = _sharder()
@@ -1176,48 +1214,115 @@ class MultiViewModel(nn.Module):
             vi, fi = self._idx(vi), self._idx(fi)
             N = vi.numel()
             w = e._ws(max(N, 1))
-            e.scal.zero_()
-            e.grads.zero_()
+            e.scal = w['scal']
             if N > 0:
-                w['zero_arena'].zero_()
-                e.forward_pose(w, N, vi, fi)
-                check(e.lib.nemo_pose3d_fwd_bwd(N, 69, w['AA'].data_ptr() + 12, 72, dptr(e.hmr_theta),
-                                                dptr(e.hmr_mask), dptr(vi), dptr(fi), e.T,
-                                                e.scal.data_ptr() + 4 * S_3D, float(sh.mr),
-                                                w['dAA'].data_ptr() + 12, 72, None, st), 'nemo_pose3d_fwd_bwd')
-                check(e.lib.nemo_rot6d_bwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, None, dptr(w['dAA']),
-                                           dptr(w['dROT']), HEAD_LD, st), 'nemo_rot6d_bwd')
-                w['dHEAD'][N].zero_()     # the phase-0 row: a workspace shared with larger batches keeps their row here
-                e.backward_mlp(w, N, vi, fi, None, has_trans_grad=False)
+                self._warmup_device_work(w, N, vi, fi, sh, begin=(w['zero_arena'], True, 0))
+            else:
+                e.scal.zero_()
+                e.grads.zero_()
             s = self._reduce_and_read(sh, True)
-            if bool(torch.isnan(e.grads).any()):
+            if s[S_NAN] != 0:
                 raise FloatingPointError('nan gradient found during warmup')        # :3497-3500
-            self._adam_all([self.opt_motion, self.opt_phase], active)
+            self._adam_all(opts, active)
             losses.append(float(s[S_3D]))
         return losses
 
+    def _warmup_captured(self, steps, active, opts):
+        e, a = self.engine, self.args
+        B = a.batch_size
+        draws = [self.draw_batch() for _ in range(steps)]              # the reference's RNG order
+        seq = e.sequence(steps, B, torch.stack([d[0] for d in draws]), torch.stack([d[1] for d in draws]))
+        w = e._ws(B)
+        sh = ShardInfo()
+
+        def body(table):
+            check(e.lib.nemo_seq_gather(dptr(seq['vi']), dptr(seq['fi']), B, dptr(seq['counter']), dptr(w['vi_static']),
+                                        dptr(w['fi_static']), _stream()), 'nemo_seq_gather')
+            vi, fi = w['vi_static'][:B], w['fi_static'][:B]
+            # (the count is sticky across iterations: once a NaN gradient has been seen no further update is applied)
+            self._warmup_device_work(w, B, vi, fi, sh, begin=(w['zero_arena'], True, table[0]), nan_out=seq['nan'])
+            check(e.lib.nemo_seq_log(e.scal.data_ptr(), 8, dptr(seq['log']), 8, dptr(seq['counter']), _stream()), 'nemo_seq_log')
+            e.adam_from_table(*table, guard=seq['nan'])
+
+        w['_static_src'] = None          # (the gather overwrites the staged indices of a step that used this workspace)
+        for _ in range(steps):
+            segs = []
+            for o in opts:
+                segs += o.segments(active)
+            table = e.adam_table_sync(segs)
+            key = ('warmup', B, seq['gen'], tuple((s_['offset'], s_['numel']) for s_ in segs))
+            try:
+                self._captured(w, key, lambda: body(table))
+            except BaseException:
+                e.adam_table_invalidate()
+                raise
+            e.adam_table_commit()
+        torch.cuda.current_stream().synchronize()
+        log = seq['log'][:steps].cpu().numpy()
+        if float(seq['nan'].cpu()) != 0:
+            raise FloatingPointError('nan gradient found during warmup')        # :3497-3500
+        return [float(x) for x in log[:, S_3D]]
+
+    # ------------------------------------------------------------------ camera fit (:2869-2906)
     def opt_cam(self, cam_opt_steps=2000, _shard=None):
-        """:2869-2906: a fresh Adam on the cameras only, first frame of every view."""
+        """:2869-2906: a fresh Adam on the cameras only, first frame of every view.
+
+        Nothing but the cameras changes between the iterations, and the 3-D side of the objective -- phase / MLP forward,
+        FK, the pre-contracted mesh functionals -- does not depend on them: it is evaluated ONCE (the reference recomputes
+        the identical values every iteration).  An iteration is then projection + 2-D loss, its camera gradient and the
+        fused Adam: one replayed HIP graph that logs its loss on the device; the host reads the log at the end (sharded:
+        the per-rank logs are summed with one collective instead of one per iteration)."""
         e, a = self.engine, self.args
         sh = _shard or ShardInfo()
-        m, v = torch.zeros_like(e.exp_avg), torch.zeros_like(e.exp_avg_sq)
+        if cam_opt_steps == 0:
+            return []
+        m, v = e.scratch_moments()
         cam_opt = FusedAdam(e, ['learned_cameras'], [self.learned_cameras], a.lr_camera, exp_avg=m,
                             exp_avg_sq=v)
-        vi = torch.arange(self.num_views, device=self.device)
-        fi = torch.zeros(self.num_views, dtype=torch.long, device=self.device)
         N = self.num_views
         w = e._ws(N)
-        log = []
+        if '_cam_idx' not in w:           # (persistent: the captured iteration holds their addresses)
+            w['_cam_idx'] = (torch.arange(N, device=self.device), torch.zeros(N, dtype=torch.long, device=self.device))
+        vi, fi = w['_cam_idx']
+        e.scal = w['scal']
+        seq = e.sequence(cam_opt_steps, 0)
+        a0, b0 = e.layout.span(['learned_cameras'])
+        cam_grads = e.grads[a0:b0]
+        # loop-invariant part: pose, FK, mesh functionals of the V first frames
+        e.forward_pose(w, N, vi, fi, train=False)
+        Mq = e.joint_functionals(w, N)
+        lt_weight = float(sh.mr)
+
+        def body(table):
+            e.scal = w['scal']
+            e.step_begin(w['zero_arena'], cam_grads, table[0] if table is not None else 0)
+            e.project_and_loss(w, N, vi, fi, Mq, mean_mode=1)
+            e.backward_kp(w, N, vi, fi, Mq, mean_mode=1, upstream=lt_weight, cams_only=True)
+            check(e.lib.nemo_seq_log(e.scal.data_ptr(), 8, dptr(seq['log']), 8, dptr(seq['counter']), _stream()), 'nemo_seq_log')
+            if table is not None:
+                e.adam_from_table(*table, exp_avg=m, exp_avg_sq=v)
+
+        graphable = self.use_graphs and e.timers is None
         for _ in range(cam_opt_steps):
-            cam_opt.zero_grad()
-            e.scal.zero_()
-            w['zero_arena'].zero_()
-            e.forward_pose(w, N, vi, fi, train=False)
-            Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=1)
-            e.backward_kp(w, N, vi, fi, Mq, mean_mode=1, upstream=float(sh.mr), cams_only=True)
-            cam_opt.step()
-            log.append(np.asarray(self._reduce_and_read(ShardInfo(kr=sh.mr, comm=sh.comm), False)[S_KP]))
-        return log
+            segs = cam_opt.segments(None)
+            if graphable:
+                table = e.adam_table_sync(segs)
+                try:
+                    self._captured(w, ('opt_cam', N, seq['gen'], lt_weight, a.loss), lambda: body(table))
+                except BaseException:
+                    e.adam_table_invalidate()
+                    raise
+                e.adam_table_commit()
+            else:
+                body(None)
+                e.adam(segs, m, v)
+        torch.cuda.current_stream().synchronize()
+        log = seq['log'][:cam_opt_steps, S_KP].clone()
+        if sh.comm is not None:              # this rank's views' share of the per-view mean -> the global loss
+            log.mul_(float(sh.mr))
+            if sh.comm_log is not None:
+                sh.comm_log(log)
+        return [np.asarray(x) for x in log.cpu().numpy()]
 
 
 class NemoV0(MultiViewModel):
@@ -1263,7 +1368,9 @@ class NemoV4(NemoV3):
     VERSION = 4
 
     def opt_cam(self, cam_opt_steps=2000, _sharder=None):
-        """:4060-4151: random batches, body pose detached, every optimiser steps."""
+        """:4060-4151: random batches, body pose detached, every optimiser steps.  Single process: one replayed HIP graph
+        per iteration (the 2-D / 3-D part of the step without the VPoser and mesh terms, Adam inside), no read-back --
+        the reference returns no losses from this phase."""
         e, a = self.engine, self.args
         if a.batch_size <= -1 and cam_opt_steps:
             raise NotImplementedError()
@@ -1272,9 +1379,30 @@ class NemoV4(NemoV3):
                 vi, fi, sh = _sharder()
             else:
                 (vi, fi), sh = self.draw_batch(), ShardInfo()
-            vi, fi = self._idx(vi), self._idx(fi)
-            N = vi.numel()
+            b = self._prepare_batch(vi, fi, False, sh)
+            N = b.N
             w = e._ws(max(N, 1))
+            e.scal = w['scal']
+            if N > 0 and sh.comm is None and self.use_graphs and e.timers is None and not b.noise:
+                svi, sfi = self._stage_indices(w, b.vi, b.fi, N)
+                segs = []
+                for o in self.optimizers:
+                    segs += o.segments(None)
+                table = e.adam_table_sync(segs)
+
+                def body():
+                    self._forward_backward(w, N, svi, sfi, True, use_vposer=False, detach_pose=True, sh=sh, adam_segs=table[0])
+                    e.adam_from_table(*table)
+                key = ('cam4', N, e.detach_articulation, e.start_global_traj_anywhere, self._weights_key(),
+                       tuple((s_['offset'], s_['numel']) for s_ in segs))
+                try:
+                    self._captured(w, key, body)
+                except BaseException:
+                    e.adam_table_invalidate()
+                    raise
+                e.adam_table_commit()
+                continue
+            vi, fi = self._idx(b.vi), self._idx(b.fi)
             if N > 0:
                 self._forward_backward(w, N, vi, fi, True, use_vposer=False, detach_pose=True, sh=sh)
             else:

@@ -30,7 +30,24 @@ def test_bench_self_launch_reaches_n_ranks_under_gloo():
     line = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(line) == 1, r.stdout                       # rank 0 alone prints
     out = json.loads(line[0])
-    assert out == {'selftest': True, 'n_gpus': 2, 'ranks_seen': [0, 1]}
+    assert {k: out[k] for k in ('selftest', 'n_gpus', 'ranks_seen')} == {'selftest': True, 'n_gpus': 2, 'ranks_seen': [0, 1]}
+    assert out['fallback'] == 'none' and out['graph_comm'] is True and [a['status'] for a in out['attempts']] == ['ok']
+
+
+@pytest.mark.parametrize('fault', ['exit', 'hang'])
+def test_bench_falls_back_when_a_rank_dies_or_hangs_in_its_first_capture(fault):
+    """rank 1's worker exits non-zero (or hangs) in its first attempt -- the rank supervisors stop every
+    worker, agree through the launcher's store and start FRESH workers with NEMO_GRAPH_COMM=0; the parent still prints
+    exactly one valid line, which says what happened."""
+    r = _run('--gpus', '2', '--spawn-selftest', '--attempt-timeout', '8', env={'NEMO_TEST_FAIL_CAPTURE': fault}, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out['selftest'] and out['ranks_seen'] == [0, 1]
+    assert out['fallback'] == 'NEMO_GRAPH_COMM=0' and out['graph_comm'] is False
+    assert [a['status'] == 'ok' for a in out['attempts']] == [False, True]
+    assert ('exit code 23' in out['attempts'][0]['status']) if fault == 'exit' else ('exceeded' in out['attempts'][0]['status'])
 
 
 def test_bench_refuses_more_gpus_than_visible():
@@ -143,7 +160,7 @@ def test_bench_two_ranks_as_the_driver_launches_them(tmp_path):
         env.pop(k, None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), BENCH, '--gpus', '2', '--instances', '2', '--steps', '4', '--warmup', '1', '--repeat', '2',
-           '--minibatch-steps', '6']
+           '--minibatch-steps', '6', '--no-extra-legs']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')]
@@ -159,3 +176,31 @@ def test_bench_two_ranks_as_the_driver_launches_them(tmp_path):
     assert out['minibatch512']['steps'] == 6 and out['minibatch512']['value'] > 0
     assert out['roofline']['kernel'] == 'mesh_v2v_fused' and 0 < out['roofline']['frac'] < 1
     assert out['config']['parallelism'] == 'instance-shard x2'
+    assert out['fallback'] == 'none' and [a['status'] for a in out['attempts']] == ['ok']
+    assert all(c['agrees_with_single'] for c in out['shard_mode_check'].values())
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_fall_back_when_a_capture_kills_a_rank():
+    """The driver's launch form with rank 1's worker dying inside its first sharded graph capture (fault injection in
+    MultiViewModel._captured): the supervisors restart both workers with NEMO_GRAPH_COMM=0 and the line says so."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, NEMO_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4',
+               NEMO_TEST_FAIL_CAPTURE='exit')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), BENCH, '--gpus', '2', '--instances', '2', '--steps', '3', '--warmup', '1', '--repeat', '1',
+           '--minibatch-steps', '0', '--no-extra-legs', '--shard-mode', 'single']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1, r.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0
+    assert out['fallback'] == 'NEMO_GRAPH_COMM=0' and out['graph_comm'] is False
+    assert 'exit code 23' in out['attempts'][0]['status'] and out['attempts'][1]['status'] == 'ok'

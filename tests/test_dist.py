@@ -480,8 +480,8 @@ def _replay_worker(rank, world, port, q, mode):
             shares.append(int(m.plan.route(vi, fi)[0].numel()))
             losses.append({k: float(v) for k, v in m.step(vi, fi)[0].items()})
         sd = {k: v.numpy() for k, v in m.gather_state_dict().items()}
-        sizes = sorted({k[0] for w in m.model.engine.ws.values() for k, g in w['graphs'].items()
-                        if isinstance(g, torch.cuda.CUDAGraph)})
+        sizes = sorted({k[1] for w in m.model.engine.ws.values() for k, g in w['graphs'].items()
+                        if isinstance(g, torch.cuda.CUDAGraph) and k[0] == 'step'})
         q.put((rank, losses, sd, shares, dict(m.model.launch_stats), sizes))
         dist.barrier()
         dist.destroy_process_group()

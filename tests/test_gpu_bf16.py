@@ -45,8 +45,6 @@ def _gemm(L, fn, A, B, ta, tb, **kw):
 @pytest.mark.parametrize('ta,tb', [(0, 1), (0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize('M,N,K', [(301, 1000, 1000), (2401, 147, 1000), (130, 70, 100), (300, 207, 2070)])
 def test_gemm_bf16_is_the_fp32_kernel_on_rounded_operands(L, ta, tb, M, N, K):
-    if os.environ.get('NEMO_GEMM_GLDS', '1') == '0':
-        pytest.skip('NEMO_GEMM_GLDS=0 (A/B aid) takes every GEMM to the first-generation fp32 kernel, which has no bf16 path')
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K + ta + 2 * tb)
     pad = lambda n: (n + 3) // 4 * 4
     A = torch.randn((K, pad(M)) if ta else (M, pad(K)), generator=g).to(DEV)[:, :(M if ta else K)]
@@ -106,11 +104,9 @@ def test_v2v_fused_bf16_blend_vs_fp32_kernel(L, num_verts, N):
 @pytest.mark.parametrize('num_verts,N', [(700, 40), (6890, 50)])
 def test_v2v_fused_bf16_split_precision_skinning(L, num_verts, N):
     """With ZERO pose features the blend contributes nothing (vp == v_shaped in both kernels), so whatever separates the
-    bf16 kernel from the fp32 one is its vertex->joint adjoint (and, with NEMO_MESH_SPLIT=2, its skinning) -- which runs on
+    bf16 kernel from the fp32 one is its vertex->joint adjoint -- which runs on
     the bf16 pipe in split precision (two bf16 pieces per fp32 operand, csrc/smpl.hip MODE 3 / 2): 16 significant bits,
     i.e. two orders below bf16."""
-    if os.environ.get('NEMO_MESH_SPLIT', '1') == '0':
-        pytest.skip('NEMO_MESH_SPLIT=0 (A/B aid): everything but the blend stays on the fp32 pipe, bit-identical to the fp32 kernel')
     import hipops as H
     from test_gpu_ops import _ctx, _rand_rot
     assets, ctx, idx = _ctx(num_verts, 2)
@@ -150,8 +146,6 @@ def test_c3_bf16_step_vs_fp32_oracle():
     """BASELINE configs[2] at its real size: 40 instances x 300 frames, h = 1000, 6890 vertices, every loss term,
     gemm_dtype = 'bf16'.  Rows of ~300 samples against the fp32 oracle (bf16 tolerance), the full-batch losses against
     the fp32 HIP path from the same state, MLP gradients, and three descending update steps."""
-    if os.environ.get('NEMO_GEMM_GLDS', '1') == '0':
-        pytest.skip('NEMO_GEMM_GLDS=0 (A/B aid): the first-generation GEMM kernel has no bf16 path')
     from nemo_cvpr2023_amd.neural_motion_model import NemoV2
     from oracle.model import OracleNemo
     V, T = 40, 300

@@ -157,8 +157,8 @@ def test_captured_graphs_survive_other_batch_sizes():
     # batch sizes share workspaces by capacity (multiples of 64 below 2048); graphs are per batch size inside them
     assert e._ws(24) is e._ws(57) and e._ws(200) is e._ws(240) and e._ws(24) is not e._ws(200)
     graphs = e._ws(24)['graphs']
-    assert {k[0] for k in graphs} == {24, 57}
-    assert all(isinstance(g, torch.cuda.CUDAGraph) for k, g in graphs.items() if k[0] in (24, 57))
+    assert {k[1] for k in graphs} == {24, 57}
+    assert all(isinstance(g, torch.cuda.CUDAGraph) for k, g in graphs.items() if k[1] in (24, 57))
     assert e._ws(24)['mesh_ws'].data_ptr() != e._ws(200)['mesh_ws'].data_ptr()             # scratch owned per workspace
     named = dict(m.named_parameters())
     for k in ('learned_motion.net.net.2.weight', 'learned_motion.rot_out.weight'):

@@ -539,7 +539,7 @@ def test_padded_launch_equals_the_unpadded_step(version):
             assert float((named_a[k].grad - named_b[k].grad).abs().max()) <= 2e-5 * sc + 1e-12, (it, n, k)
         _copy_model_state(b, a)           # (keep the two in lock step: Adam amplifies rounding-level differences)
     keys = [k for w in b.engine.ws.values() for k, g in w['graphs'].items() if isinstance(g, torch.cuda.CUDAGraph)]
-    assert sorted(k[0] for k in keys) == [32, 64], keys      # launch sizes 32 (19, 27, 23, 32, 5 samples) and 64 (40, 45)
+    assert sorted(k[1] for k in keys) == [32, 64], keys      # launch sizes 32 (19, 27, 23, 32, 5 samples) and 64 (40, 45)
     assert b.launch_stats['replayed'] >= 5
 
 
@@ -777,6 +777,84 @@ def test_loss_curve_parity_real_size():
         assert rel[k][:80].max() < 3e-4, (k, float(rel[k][:80].max()))
         assert rel[k].max() < 3e-2 and rel[k].mean() < 5e-3, (k, float(rel[k].max()), float(rel[k].mean()))
     assert np.mean(co['total_loss'][-10:]) < np.mean(co['total_loss'][:10])
+
+
+def test_200_steps_of_the_published_configuration_in_lock_step():
+    """SURVEY 8(d)'s "200 steps", GATED: the published configuration at its real sizes (NemoV2,
+    h = 1000, RBF 100, 6890 vertices, every loss term, minibatches of 512 out of 8 x 300 in the script's order) runs 200
+    update steps on the HIP path; before every 10th step -- and before each of the first five -- the CPU oracle takes
+    over the HIP model's parameters and Adam state and both take THAT step: every loss term of every compared step must
+    agree to 1e-4 (25 oracle steps instead of 200: the suite's CPU budget), i.e. the step function is held to the
+    reference along the whole trajectory the HIP fit actually takes, and the fit descends."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    from oracle.model import OracleNemo
+    V, T, B, steps = 8, 300, 512, 200
+    args = syn.published_args(batch_size=B, out_dir='')
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    torch.manual_seed(0)
+    m = NemoV2(args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+    o = OracleNemo(2, args, seqs, assets, vps, gmm, state={k: v.cpu() for k, v in m.state_dict().items()})
+    gen = torch.Generator().manual_seed(2)
+    keys = ('kp_loss', 'gmm_loss', 'vp_recon_loss', 'vp_kl_loss', 'total_loss')
+    worst, compared, curve = 0.0, 0, []
+    for s in range(steps):
+        vi = torch.randint(0, V, (B,), generator=gen)
+        fi = torch.randint(0, T, (B,), generator=gen)
+        check = s < 5 or s % 10 == 9
+        if check:
+            o.load_state({k: v.cpu() for k, v in m.state_dict().items()})
+            for oo, mo in zip(o.optimizers, m.optimizers):
+                sd = mo.state_dict()
+                if sd['state']:
+                    oo.load_state_dict(sd)
+        ld_h = m.step(vi, fi)[0]
+        curve.append(float(ld_h['total_loss']))
+        if check:
+            ld_o = o.step(vi, fi)[0]
+            compared += 1
+            for k in keys:
+                err = abs(float(ld_h[k]) - float(ld_o[k])) / max(abs(float(ld_o[k])), 1e-6)
+                worst = max(worst, err)
+                assert err <= 1e-4, (s, k, float(ld_h[k]), float(ld_o[k]))
+    assert compared == 25
+    assert np.mean(curve[-10:]) < np.mean(curve[:10])
+
+
+def test_bf16_loss_curve_stays_with_the_fp32_curve_over_100_steps():
+    """the bf16 build (operands bf16 in memory, fp32 accumulation, fp32 master weights) against the
+    fp32 build over 100 FREE-RUNNING update steps at the published sizes (minibatches of 512 out of 8 x 300, same draws,
+    same initial state): the bf16 fit must descend like the fp32 one -- every loss term within 2 % of the fp32 curve at
+    every step, the mean total loss of the last ten steps within 1 %."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    V, T, B, steps = 8, 300, 512, 100
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    models = []
+    for dt in ('f32', 'bf16'):
+        args = syn.published_args(batch_size=B, out_dir='')
+        args.gemm_dtype = dt
+        torch.manual_seed(0)
+        models.append(NemoV2(args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm))
+    models[1].load_state_dict({k: v.clone() for k, v in models[0].state_dict().items()}, strict=False)
+    assert models[1].engine.b16mem and not models[0].engine.bf16
+    gen = torch.Generator().manual_seed(2)
+    keys = ('kp_loss', 'gmm_loss', 'vp_recon_loss', 'vp_kl_loss', 'total_loss')
+    cur = [{k: [] for k in keys} for _ in models]
+    for _ in range(steps):
+        vi = torch.randint(0, V, (B,), generator=gen)
+        fi = torch.randint(0, T, (B,), generator=gen)
+        for m_, c_ in zip(models, cur):
+            ld = m_.step(vi, fi)[0]
+            for k in keys:
+                c_[k].append(float(ld[k]))
+    for k in keys:
+        a, b = np.asarray(cur[0][k]), np.asarray(cur[1][k])
+        rel = np.abs(a - b) / np.maximum(np.abs(a), 1e-6)
+        assert rel.max() < 2e-2, (k, float(rel.max()), int(rel.argmax()))
+    f32_end, b16_end = np.mean(cur[0]['total_loss'][-10:]), np.mean(cur[1]['total_loss'][-10:])
+    assert abs(b16_end - f32_end) <= 1e-2 * abs(f32_end), (f32_end, b16_end)
+    assert b16_end < np.mean(cur[1]['total_loss'][:10])
 
 
 def test_optional_temporal_smoothness_term():
