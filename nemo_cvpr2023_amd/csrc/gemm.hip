@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "gemm_glds.h"
+#include "gemm_adj.h"
 #include "gemm_skinny.h"
 #include "../../include/nemo_hip.h"
 
@@ -609,22 +610,24 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
         pl.t0 = 0;
         if (split_k > 0) pl.split = split_k;
     }
-    // The blend-shape adjoint at large batch (dPF = dVP P^T: M = samples, N = 207, K = 3 NV = 20670, both operands
-    // "transposed"): a 64 x 208 tile on v_mfma_f32_16x16x4_f32 (13 accumulators per wave) reads the (K x M) operand ONCE
-    // instead of once per 64-column tile.  At M = 2400 that ties with the 64x64 plan (the narrow MFMA needs twice the LDS
-    // operand reads per FLOP), from M ~ 3000 on the saved memory traffic wins: 563 vs 678 us at M = 8192, 307 vs 344 us at
-    // M = 3808 (profiles/r02_experiments.md).  K slices so that ~512 blocks are resident (two per CU).
-    if (glds_ok && !bf16 && transA && transB && N > 128 && N <= 208 && M >= 3072 && K >= 2048 && split_k == 0 &&
-        out_mode != 2 && force_tile == 0 && can_split) {
+    // The blend-shape adjoint (dPF = dVP P^T: M = samples, N = 207, K = 3 NV = 20 670, both operands "transposed") above
+    // ~1000 samples: ONE 64 x 208 column tile per workgroup with mixed MFMA shapes (gemm_adj.h: columns [0, 192) on
+    // v_mfma_f32_32x32x2_f32, the 16-column remainder on 16x16x4) -- dVP^T is streamed once instead of once per 64-column
+    // tile and 0.5 % instead of 24 % of the MFMAs multiply padding.  tools/gemm_glds_dev adj <M> (us per launch, best K
+    // split each): M = 1200: 102 against 130 (64 x 64 plan) / 128 (skinny 32 x 224); 2400: 172 against 227; 3808: 270
+    // against 305 (round 2's all-16x16x4 wide tile) / 351; 8192: 526 against 570 / 688.  K slices so that ~512 workgroups
+    // (two per CU) are resident.  Below ~1000 samples the skinny configurations keep the shape (profiles/r04_experiments.md).
+    if (glds_ok && !bf16 && transA && transB && N > 128 && N <= 208 && M > 1000 && K >= 2048 && split_k == 0 &&
+        out_mode != 2 && force_tile == 0 && can_split && !bias && !act && !mask_mode) {
         const long tiles_m = (M + 63) / 64;
-        int S = (int)((512 + tiles_m - 1) / tiles_m);
+        int S = (int)(512 / tiles_m);
         if (S < 1) S = 1;
         while (S > 1 && ((K + 31) / 32 / S < 8 || COUNTER_BYTES + tiles_m * S * 64L * 208 * 4 > ws_bytes)) --S;
         if (tiles_m <= COUNTER_BYTES / 4) {
             GemmArgs g;
-            g.A = A; g.B = B; g.C = C; g.bias = bias; g.mask = mask;
-            g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldmask = ldmask;
-            g.act = act; g.mask_mode = mask_mode; g.out_mode = out_mode; g.alpha = alpha;
+            g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.mask = nullptr;
+            g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldmask = 0;
+            g.act = 0; g.mask_mode = 0; g.out_mode = out_mode; g.alpha = alpha;
             g.counters = reinterpret_cast<int*>(ws);
             g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
             long kc = (K + S - 1) / S;
@@ -635,8 +638,8 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
             g.a_bytes = a_bytes; g.b_bytes = b_bytes; g.xcd_order = 0;
             static const bool debug_wide = getenv("NEMO_GEMM_DEBUG") != nullptr;
             if (debug_wide)
-                fprintf(stderr, "nemo_gemm_f32 ta=1 tb=1 M=%ld N=%ld K=%ld -> glds 64x208/16 split %d\n", (long)M, (long)N, (long)K, g.split);
-            hipError_t e = glds::launch<64, 208, 16, 208, 16, false, true, 2>(g, g.n_tiles * g.split, (hipStream_t)stream);
+                fprintf(stderr, "nemo_gemm_f32 ta=1 tb=1 M=%ld N=%ld K=%ld -> 64x208 mixed-shape tile, %d K slices\n", (long)M, (long)N, (long)K, g.split);
+            hipError_t e = glds::launch_adj(g, (hipStream_t)stream);
             if (e != hipSuccess) return (int32_t)e;
             NEMO_LAUNCH_CHECK();
             return NEMO_OK;

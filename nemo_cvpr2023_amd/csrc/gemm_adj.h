@@ -1,0 +1,226 @@
+// The blend-shape adjoint  dPF (M x 207) (+)= dVP^T P^T  (human_body_prior/body_model/lbs.py:229-233 backward; K = 3 NV =
+// 20 670) on ONE 64 x 208 column tile per workgroup with MIXED MFMA shapes (round 4).
+//
+// The 64 x 64 plan of gemm_glds.h covers 207 columns with four 64-wide tiles: 24 % of its MFMAs multiply padding and the
+// (K x M) operand dVP^T is streamed once per column tile (4.6 x its size in fetch traffic).  Round 2's single 64 x 208
+// tile on v_mfma_f32_16x16x4_f32 read dVP^T once but paid the narrow instruction's doubled LDS operand reads on EVERY
+// column and tied.  Here columns [0, 192) run on v_mfma_f32_32x32x2_f32 (wave w: rows [32 (w & 1), +32) x three 32-column
+// blocks starting at 96 (w >> 1)) and only the 16-column remainder [192, 208) on v_mfma_f32_16x16x4_f32 (wave w: rows
+// [16 w, +16)): 48 + 8 MFMAs per wave and K tile = 3328 pipe cycles for 851 968 FLOP -- the pipe's full rate -- with
+// 1.3 % row padding and 0.5 % column padding instead of 24 %.
+//
+// Operand tiles through LDS-DMA exactly as in gemm_glds.h (same Operand class, same images and k permutation): A = dVP^T
+// is image M (row-contiguous, 64 rows: 8 pieces per K tile), B = the blend shapes image K (k-contiguous, 208 rows: 26
+// pieces -- row 207 reads zeros through the buffer descriptor).  dVP^T is read exactly once, straight from HBM (the mesh
+// kernel has just written its 198 MB), the blend shapes 38 times from L2 / the Infinity Cache: the A ring is THREE K tiles
+// deep (8 KiB each), the B ring two (26 KiB each) -- 76 KiB, two workgroups per CU.  Per iteration the pieces of B (t + 1)
+// and then of A (t + 2) leave one at a time between the first MFMAs of tile t (an LDS-DMA issue holds the wave's
+// instruction stream ~100 cycles); the wait at the top of an iteration leaves the two youngest pieces -- A's -- in flight.
+// K is cut into slices across workgroups (write-through slabs + ticket, combined by the last arriver in slice order:
+// deterministic), as in gemm_glds.h.
+#pragma once
+#include "gemm_glds.h"
+
+namespace glds {
+
+constexpr int ADJ_BM = 64, ADJ_BN = 208;
+constexpr int ADJ_A_FLOATS = ADJ_BM * BK, ADJ_B_FLOATS = ADJ_BN * BK, ADJ_NA = 3, ADJ_NB = 2;
+constexpr int ADJ_LDS_BYTES = (ADJ_NA * ADJ_A_FLOATS + ADJ_NB * ADJ_B_FLOATS) * 4;
+
+__global__ __launch_bounds__(256, 2) void gemm_adj_kernel(Args g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using OA = Operand<ADJ_BM, false>;
+    using OB = Operand<ADJ_BN, true>;
+    constexpr int GA = OA::PER_WAVE, GB = OB::NI / 4 + 1;        // 2 pieces of A per wave and K tile, 6 or 7 of B
+    const int bid = (int)blockIdx.x;
+    const int tile = bid % g.tiles_m, slice = bid / g.tiles_m, split = g.split;
+    const long m0 = (long)tile * ADJ_BM;
+    const long kbeg = (long)slice * g.k_chunk;
+    const long kend = min(g.K, kbeg + g.k_chunk);
+    const long klen = kend > kbeg ? kend - kbeg : 0;
+    const int nt = (int)((klen + BK - 1) / BK);
+    const bool tail = (klen % BK) != 0;                          // (B is image K: masked fill of a partial last tile)
+    const int nfull = tail ? nt - 1 : nt;
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 31, lh = lane >> 5, lr16 = lane & 15, lh16 = lane >> 4;
+    const int row32 = 32 * (wid & 1) + lr, col32 = 96 * (wid >> 1) + lr;        // (+ 32 j)
+    const int row16 = 16 * wid + lr16, col16 = 192 + lr16;
+
+    f32x16 acc[3];
+    f32x4 acc16 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const unsigned smem_byte = (unsigned)reinterpret_cast<unsigned long long>(smem);
+    OA oa; OB ob;
+    oa.init(g.A, g.a_bytes, g.lda, lane, wid);
+    ob.init(g.B, g.b_bytes, g.ldb, lane, wid);
+
+    float* const sa = smem;                                       // A ring, then B ring
+    float* const sb = smem + ADJ_NA * ADJ_A_FLOATS;
+    const unsigned sa_byte = smem_byte, sb_byte = smem_byte + ADJ_NA * ADJ_A_FLOATS * 4;
+    const bool b_extra = wid < OB::NI % 4;                        // this wave issues a 7th piece of B
+
+    // MFMAs of K tile t (A slot t % 3, B slot t % 2); meanwhile request B of tile tb and then A of tile ta (< 0: none)
+    auto compute = [&](const float* as, const float* bs, int tb, int ta) {
+        const unsigned nbb = sb_byte + (unsigned)(((tb < 0 ? 0 : tb) % ADJ_NB) * ADJ_B_FLOATS * 4);
+        const unsigned nab = sa_byte + (unsigned)(((ta < 0 ? 0 : ta) % ADJ_NA) * ADJ_A_FLOATS * 4);
+        const long nkb = kbeg + (long)(tb < 0 ? 0 : tb) * BK, nka = kbeg + (long)(ta < 0 ? 0 : ta) * BK;
+        float fa[2][4], fb[2][3][4];
+        OA::template fetch<8>(as, row32, 0, lh, fa[0]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) OB::template fetch<8>(bs, col32 + 32 * j, 0, lh, fb[0][j]);
+        int piece = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q + 1 < 4) {
+                OA::template fetch<8>(as, row32, q + 1, lh, fa[(q + 1) & 1]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) OB::template fetch<8>(bs, col32 + 32 * j, q + 1, lh, fb[(q + 1) & 1][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);         // the next group's operand reads stay AHEAD of this group's MFMAs
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][s], fb[q & 1][j][s], acc[j], 0, 0, 0);
+                // one LDS-DMA piece behind every step of the first groups: B's 6 - 7 first, A's 2 last
+                if (piece < GB) {
+                    if (tb >= 0 && (piece < GB - 1 || b_extra)) ob.dma_one(nbb, 0, nkb, wid, piece);
+                } else if (piece < GB + GA) {
+                    if (ta >= 0) oa.dma_one(nab, m0, nka, wid, piece - GB);
+                }
+                ++piece;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q == 1 || q == 3) {                    // the 16-column remainder: k group (q >> 1) of the narrow shape
+                float ga[4], gb[4];
+                OA::template fetch<16>(as, row16, q >> 1, lh16, ga);
+                OB::template fetch<16>(bs, col16, q >> 1, lh16, gb);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc16 = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s], gb[s], acc16, 0, 0, 0);
+            }
+        }
+    };
+
+    if (nfull > 0) {
+        oa.dma(sa_byte, m0, kbeg, wid);
+        ob.dma(sb_byte, 0, kbeg, wid);
+        if (nfull > 1) oa.dma(sa_byte + ADJ_A_FLOATS * 4, m0, kbeg + BK, wid);
+    }
+    for (int t = 0; t < nfull; ++t) {
+        // tile t has landed (this wave's pieces): everything but the two youngest pieces, which are A (t + 1)'s
+        if (t + 1 < nfull) wait_vmcnt<GA>(); else wait_vmcnt<0>();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // ... everybody's, and everybody is done reading tile t - 1
+        asm volatile("" ::: "memory");
+        compute(sa + (t % ADJ_NA) * ADJ_A_FLOATS, sb + (t % ADJ_NB) * ADJ_B_FLOATS, t + 1 < nfull ? t + 1 : -1,
+                t + 2 < nfull ? t + 2 : -1);
+    }
+    if (tail) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const long k0 = kbeg + (long)nfull * BK;
+        oa.dma(sa_byte, m0, k0, wid);                                     // image M: k rows beyond K read zeros
+        ob.fill_tail(sb, g.B, 0, k0, g.N, kend);                           // image K: masked through registers
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        compute(sa, sb, -1, -1);
+    }
+
+    // ---- split-K: publish the partial tile (13 float4 per thread), the last arriver sums all slices in slice order
+    if (split > 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // (smem is reused for the hand-off flag below)
+        float4* slab = reinterpret_cast<float4*>(g.slabs) + ((size_t)tile * split + slice) * (size_t)(ADJ_BM * ADJ_BN / 4);
+        auto put = [&](int idx, f32x4 vv) {
+            float4* dst = slab + idx * 256 + threadIdx.x;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
+        };
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                put(j * 4 + r4, f32x4{acc[j][4 * r4], acc[j][4 * r4 + 1], acc[j][4 * r4 + 2], acc[j][4 * r4 + 3]});
+        put(12, acc16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0)
+            *flag = __hip_atomic_fetch_add(g.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != split - 1) return;
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(g.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const float4* base = reinterpret_cast<const float4*>(g.slabs) + (size_t)tile * split * (size_t)(ADJ_BM * ADJ_BN / 4);
+        float4 sum[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) sum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sl = 0; sl < split; ++sl) {           // slice-major: 13 independent loads in flight, fixed order
+            const float4* p = base + (size_t)sl * (ADJ_BM * ADJ_BN / 4) + threadIdx.x;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) {
+                const float4 v = p[i * 256];
+                sum[i].x += v.x; sum[i].y += v.y; sum[i].z += v.z; sum[i].w += v.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 v = sum[j * 4 + r4];
+                acc[j][4 * r4] = v.x; acc[j][4 * r4 + 1] = v.y; acc[j][4 * r4 + 2] = v.z; acc[j][4 * r4 + 3] = v.w;
+            }
+        acc16 = f32x4{sum[12].x, sum[12].y, sum[12].z, sum[12].w};
+    }
+
+    // ---- epilogue: C = alpha * acc (out_mode 0) or C += alpha * acc (1)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const long n = col32 + 32 * j;
+        if (n >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = m0 + 32 * (wid & 1) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= g.M) continue;
+            float* c = g.C + m * g.ldc + n;
+            const float v = g.alpha * acc[j][r];
+            *c = g.out_mode == 1 ? *c + v : v;
+        }
+    }
+    if (col16 < g.N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = m0 + 16 * wid + 4 * lh16 + r;
+            if (m >= g.M) continue;
+            float* c = g.C + m * g.ldc + col16;
+            const float v = g.alpha * acc16[r];
+            *c = g.out_mode == 1 ? *c + v : v;
+        }
+    }
+}
+
+// g: TT problem (A = (K x M) row-contiguous, B = (N x K) k-contiguous), 128 < N <= 208; tiles_m = ceil(M / 64), split /
+// k_chunk (multiple of 32) / counters / slabs (64 x 208 floats per (tile, slice)) set by the caller
+inline hipError_t launch_adj(const Args& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_adj_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, ADJ_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_adj_kernel, dim3(g.tiles_m * g.split), dim3(256), ADJ_LDS_BYTES, s, g);
+    return hipSuccess;
+}
+
+}  // namespace glds

@@ -121,6 +121,31 @@ def test_gemm_split_k_in_launch_combine(L, monkeypatch, tile, ta, tb, M, N, K, s
     assert int(H.gemm_ws()[:4096].view(torch.int32).abs().sum()) == 0
 
 
+@pytest.mark.parametrize('M,N,K', [(2400, 207, 20670), (1201, 207, 2100), (1100, 200, 4099), (8192, 207, 2048), (1003, 129, 2222)])
+def test_blend_shape_adjoint_on_the_mixed_shape_tile(L, M, N, K):
+    """csrc/gemm_adj.h (round 4): the TT product dPF (+)= dVP^T P^T above ~1000 samples on one 64 x 208 column tile per
+    workgroup -- columns [0, 192) on v_mfma_f32_32x32x2_f32, the remainder on 16x16x4 -- with K slices combined in the
+    launch: overwrite and accumulate modes against float64, NaN-poisoned row pads, bit-identical run to run, tickets
+    returned to zero."""
+    H = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    lda, ldb = (M + 15) // 16 * 16 + 16, (K + 3) // 4 * 4 + 4
+    Af, Bf = torch.randn(K, lda, generator=g), torch.randn(N, ldb, generator=g)
+    Af[:, M:] = float('nan')
+    Bf[:, K:] = float('nan')
+    ref = Af[:, :M].T.double() @ Bf[:, :K].T.double()
+    dA, dB = H.dev(Af)[:, :M], H.dev(Bf)[:, :K]
+    C1 = H.gemm(dA, dB, 1, 1, split_k=0)
+    assert rel_err(C1, ref) < TOL
+    assert torch.equal(C1, H.gemm(dA, dB, 1, 1, split_k=0))
+    C0 = torch.randn(M, 208, generator=g)
+    C = H.dev(C0).clone()
+    H.gemm(dA, dB, 1, 1, alpha=0.5, out_mode=1, split_k=0, C=C[:, :N])
+    assert rel_err(C[:, :N], C0[:, :N].double() + 0.5 * ref) < TOL
+    assert torch.equal(C[:, N:].cpu(), C0[:, N:])                  # columns beyond N untouched
+    assert int(H.gemm_ws()[:4096].view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize('M,N,K', [(2400, 1000, 1000), (300, 1000, 1000), (1000, 1000, 300), (2400, 148, 1000),
                                    (207, 2400, 20670), (600, 512, 512), (300, 64, 512)])
 def test_gemm_auto_plan(L, M, N, K):

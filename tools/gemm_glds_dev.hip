@@ -8,7 +8,9 @@
 #include <cmath>
 #include <vector>
 #include <string>
+#include <algorithm>
 #include "../nemo_cvpr2023_amd/csrc/gemm_glds.h"
+#include "../nemo_cvpr2023_amd/csrc/gemm_adj.h"
 
 using glds::Args;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -207,8 +209,121 @@ void calib() {
         }
 }
 
+// ---- adj: the blend-shape adjoint (TT, N = 207, K = 20 670) on the mixed-shape 64 x 208 tile of csrc/gemm_adj.h against
+// a float64 host product (small, ragged, NaN-poisoned pads) and, timed, against the 64 x 64 plan and round 2's 64 x 208 / 16.
+static hipError_t run_adj(long M, long N, long K, const float* A, long lda, const float* B, long ldb, float* C, long ldc, int out_mode,
+                          int split, float* ws, hipStream_t s) {
+    Args g{};
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.out_mode = out_mode; g.alpha = 1.f;
+    g.counters = reinterpret_cast<int*>(ws); g.slabs = ws + 4096;
+    if (!glds::extents(1, 1, M, N, K, lda, ldb, &g.a_bytes, &g.b_bytes)) return hipErrorInvalidValue;
+    long kc = (K + split - 1) / split; kc = (kc + 31) / 32 * 32; if (kc == 0) kc = 32;
+    g.k_chunk = kc; g.split = (int)((K + kc - 1) / kc);
+    g.tiles_m = (int)((M + 63) / 64); g.tiles_n = 1; g.n_tiles = g.tiles_m;
+    return glds::launch_adj(g, s);
+}
+
+int adj(long Mt) {
+    float* ws; CK(hipMalloc(&ws, 256 << 20)); CK(hipMemset(ws, 0, 256 << 20));
+    int bad = 0;
+    for (auto p : {Prob{1, 1, 301, 207, 2100}, Prob{1, 1, 77, 207, 515}, Prob{1, 1, 64, 200, 96}, Prob{1, 1, 130, 129, 1000}}) {
+        const long lda = (p.M + 3) / 4 * 4 + 4, ldb = (p.K + 3) / 4 * 4 + 8, ldc = 208;
+        std::vector<float> hA(p.K * lda), hB(p.N * ldb), hC(p.M * ldc);
+        for (auto& x : hA) x = frand();
+        for (auto& x : hB) x = frand();
+        for (long r = 0; r < p.K; ++r) for (long c = p.M; c < lda; ++c) hA[r * lda + c] = NAN;
+        for (long r = 0; r < p.N; ++r) for (long c = p.K; c < ldb; ++c) hB[r * ldb + c] = NAN;
+        std::vector<double> ref(p.M * p.N);
+        for (long m = 0; m < p.M; ++m) for (long n = 0; n < p.N; ++n) {
+            double acc = 0;
+            for (long k = 0; k < p.K; ++k) acc += (double)hA[k * lda + m] * hB[n * ldb + k];
+            ref[m * p.N + n] = acc;
+        }
+        float *dA, *dB, *dC;
+        CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, hC.size() * 4));
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+        for (int split : {1, 3, 7})
+            for (int om : {0, 1}) {
+                if (split > 1 && p.K < 32 * split) continue;
+                for (auto& x : hC) x = om ? 1.f : NAN;
+                CK(hipMemcpy(dC, hC.data(), hC.size() * 4, hipMemcpyHostToDevice));
+                if (run_adj(p.M, p.N, p.K, dA, lda, dB, ldb, dC, ldc, om, split, ws, 0) != hipSuccess) { printf("launch failed\n"); ++bad; continue; }
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+                double err = 0, scale = 0;
+                for (long m = 0; m < p.M; ++m) for (long n = 0; n < p.N; ++n) {
+                    const double d = fabs((double)hC[m * ldc + n] - (om ? 1.0 : 0.0) - ref[m * p.N + n]);
+                    if (!(d <= err)) err = d;
+                    scale = fmax(scale, fabs(ref[m * p.N + n]));
+                }
+                bool pad_ok = true;        // columns beyond N are never written
+                for (long m = 0; m < p.M && pad_ok; ++m) for (long n = p.N; n < ldc; ++n) { const float v = hC[m * ldc + n]; if (om ? v != 1.f : v == v) pad_ok = false; }
+                const bool ok = err <= 2e-5 * scale + 1e-6 && pad_ok;
+                if (!ok) ++bad;
+                printf("adj 64x208 mixed M=%4ld N=%3ld K=%5ld split=%d out_mode=%d  max err %.3g (scale %.3g) pads %s %s\n", p.M, p.N, p.K, split, om,
+                       err, scale, pad_ok ? "untouched" : "WRITTEN", ok ? "ok" : "FAIL");
+            }
+        int tk; CK(hipMemcpy(&tk, ws, 4, hipMemcpyDeviceToHost));
+        CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
+    }
+    {   // timing at the step's shape
+        const long M = Mt, N = 207, K = 20670, lda = (M + 15) / 16 * 16, ldb = 20672, ldc = 208;
+        float *dA, *dB, *dC, *dC2;
+        CK(hipMalloc(&dA, (size_t)(K + 2) * lda * 4)); CK(hipMalloc(&dB, (size_t)N * ldb * 4)); CK(hipMalloc(&dC, M * ldc * 4)); CK(hipMalloc(&dC2, M * ldc * 4));
+        std::vector<float> hA((size_t)(K + 2) * lda), hB((size_t)N * ldb);
+        for (auto& x : hA) x = frand();
+        for (auto& x : hB) x = frand();
+        CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        auto time_it = [&](auto go) {
+            go(); go(); CK(hipDeviceSynchronize());
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0));
+                for (int r = 0; r < 10; ++r) go();
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                best = fminf(best, ms * 100.f);
+            }
+            return best;
+        };
+        printf("blend-shape adjoint M=%ld N=%ld K=%ld (%.2f GFLOP, %.1f us at 157.3 TF)\n", M, N, K, 2e-9 * M * N * K, 2e-6 * M * N * K / 157.3);
+        std::string line = "   64x64 spread:";
+        for (int split : {4, 6, 8, 13}) { char b[48]; snprintf(b, sizeof b, " s%d=%.1f", split, time_it([&] { CK(run(S64, 1, 1, M, N, K, dA, lda, dB, ldb, dC, ldc, nullptr, 0, 0, split, 0, ws, 0)); })); line += b; }
+        printf("%s\n", line.c_str());
+        line = "   64x208/16:";
+        for (int split : {8, 13, 16}) { char b[48]; snprintf(b, sizeof b, " s%d=%.1f", split, time_it([&] { CK(run(C64x208, 1, 1, M, N, K, dA, lda, dB, ldb, dC, ldc, nullptr, 0, 0, split, 0, ws, 0)); })); line += b; }
+        printf("%s\n", line.c_str());
+        line = "   64x208 mixed:";
+        for (int split : {6, 8, 10, 13, 16, 20}) { char b[48]; snprintf(b, sizeof b, " s%d=%.1f", split, time_it([&] { CK(run_adj(M, N, K, dA, lda, dB, ldb, dC2, ldc, 0, split, ws, 0)); })); line += b; }
+        printf("%s\n", line.c_str());
+        {   // the same with A cold (as in the step, where the mesh kernel has just written 198 MB and other kernels ran in between):
+            // a 512 MB memset between the launches evicts L2 and the Infinity Cache; its own time is subtracted
+            float* junk; CK(hipMalloc(&junk, 512u << 20));
+            const float t_flush = time_it([&] { CK(hipMemsetAsync(junk, 1, 512u << 20, 0)); });
+            const float t64 = time_it([&] { CK(hipMemsetAsync(junk, 1, 512u << 20, 0)); CK(run(S64, 1, 1, M, N, K, dA, lda, dB, ldb, dC, ldc, nullptr, 0, 0, 8, 0, ws, 0)); });
+            const float tmx = time_it([&] { CK(hipMemsetAsync(junk, 1, 512u << 20, 0)); CK(run_adj(M, N, K, dA, lda, dB, ldb, dC2, ldc, 0, 13, ws, 0)); });
+            printf("   operands evicted between launches (512 MB memset, %.1f us, subtracted): 64x64 s8 %.1f, mixed s13 %.1f\n", t_flush, t64 - t_flush, tmx - t_flush);
+            CK(hipFree(junk));
+        }
+        // same product from both kernels
+        CK(run(S64, 1, 1, M, N, K, dA, lda, dB, ldb, dC, ldc, nullptr, 0, 0, 6, 0, ws, 0));
+        CK(run_adj(M, N, K, dA, lda, dB, ldb, dC2, ldc, 0, 13, ws, 0)); CK(hipDeviceSynchronize());
+        std::vector<float> h1(M * ldc), h2(M * ldc);
+        CK(hipMemcpy(h1.data(), dC, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), dC2, h2.size() * 4, hipMemcpyDeviceToHost));
+        double err = 0, scale = 0;
+        for (long m = 0; m < M; ++m) for (long n = 0; n < N; ++n) { err = fmax(err, fabs((double)h1[m * ldc + n] - h2[m * ldc + n])); scale = fmax(scale, fabs((double)h1[m * ldc + n])); }
+        const bool ok = err <= 2e-5 * scale;
+        if (!ok) ++bad;
+        printf("   mixed tile vs 64x64 plan at the real shape: max |d| %.3g (scale %.3g) %s\n", err, scale, ok ? "ok" : "FAIL");
+    }
+    printf(bad ? "ADJ CHECK FAILED (%d)\n" : "ADJ CHECK OK\n", bad);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "check";
+    if (mode == "adj") return adj(argc > 2 ? atol(argv[2]) : 2400);
     if (mode == "check") return check();
     if (mode == "calib") { calib(); return 0; }
     timeit(argc > 2 ? atol(argv[2]) : 2400);
