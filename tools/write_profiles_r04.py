@@ -55,7 +55,10 @@ if os.path.exists(os.path.join(G, 'trace_phases.log')):
         "configuration, 8 x 300 synthetic sequences.  Warm-up and camera fit run as captured iterations (DESIGN.md 5a): the kernels below "
         "with 1320 / 1020 calls are theirs (`seq_gather_kernel`, `seq_log_kernel`, `nan_count_kernel`, `step_begin_kernel`; the camera fit has no "
         "GEMM and no FK in its loop).\n\nWall clock of the same (profiled) run:\n```\n"
-        + '\n'.join(l for l in rd('trace_phases.log').splitlines() if 'ms' in l or ':' in l and 'amdgpu' not in l) + "\n```\n\n" + rd('summary_phases.md'))
+        + '\n'.join(l for l in rd('trace_phases.log').splitlines() if l.startswith(('warmup', 'opt_cam', 'minibatch')) or 'ms/step' in l)
+        + "\n```\n(un-profiled: 0.259 / 0.033 / 0.645 ms -- the profiler's per-dispatch cost is large against 5 - 20 us kernels.)\n\n"
+        "Per-kernel totals over the WHOLE run (the `calls/step` and `us/step` columns are totals divided by 35, the script's divisor: read "
+        "them as relative weights; `avg us/launch` is exact):\n\n" + rd('summary_phases.md'))
 
 # ---- traffic
 pmc = rd('pmc_traffic.md')
