@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 9
+#define NEMO_ABI_VERSION 10
 int32_t nemo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -264,6 +264,19 @@ int32_t nemo_kp_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const 
                     int32_t loss_type, int32_t mean_mode, const float* view_acc, const float* norm,
                     float upstream, float* dA, float* dJp, float* dMq, float* dTR, int64_t lddt,
                     float* d_cams, void* stream);
+/* nemo_kp_fwd + nemo_kp_bwd in ONE launch (round 4).  The backward needs one thing from a COMPLETED forward: the per-view
+ * normaliser of :3551-3558 -- and that depends on the batch's indices alone: view_count[v] = number of (unpadded) samples of
+ * view v in the batch (device int64[V]; the caller knows it from the indices it drew: a constant for a full batch).  With
+ * it the launch evaluates projection and loss once, writes the forward's outputs (j3d, p2d, loss_all: each may be NULL;
+ * view_acc (V,2) += [sum(loss*conf), #samples], from which nemo_kp_finalize makes the loss scalar) and the backward's
+ * (as nemo_kp_bwd).  Same results as the two launches; view_count must equal what the forward would have counted. */
+int32_t nemo_kp_fwd_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A, const float* Jp,
+                        const float* Mq, int64_t ldq, const float* TR, int64_t ldt, int32_t add_trans,
+                        const int64_t* view_idx, const int64_t* frame_idx, const float* cams, const float* targets,
+                        const float* gt_size, float focal, float cx, float cy, int32_t loss_type, int32_t mean_mode,
+                        const int64_t* view_count, float upstream, float* j3d, float* p2d, float* loss_all, float* view_acc,
+                        float* dA, float* dJp, float* dMq, float* dTR, int64_t lddt, float* d_cams,
+                        const int64_t* n_valid, void* stream);
 /* nemo_kp_bwd with an additional gradient dj3d_extra (N, n_out, 3) w.r.t. the 3-D output joints (world space,
  * translation included) added before the pull-back through FK / the mesh functionals; cameras do not see it. */
 int32_t nemo_kp_bwd_ex(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A, const float* Jp,

@@ -32,7 +32,7 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 9        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 10        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -83,6 +83,8 @@ SIGNATURES = {
                           f32, f32, f32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i64, ptr, ptr]),
     'nemo_kp_bwd_ex': (i32, [ptr, i64, i64, i64, ptr, ptr, ptr, i64, ptr, i64, i32, ptr, ptr, ptr, ptr, ptr,
                              f32, f32, f32, i32, i32, ptr, ptr, f32, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, ptr]),
+    'nemo_kp_fwd_bwd': (i32, [ptr, i64, i64, i64, ptr, ptr, ptr, i64, ptr, i64, i32, ptr, ptr, ptr, ptr, ptr,
+                              f32, f32, f32, i32, i32, ptr, f32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr]),
     'nemo_smooth_fwd_bwd': (i32, [i64, i64, i64, ptr, f32, ptr, ptr, ptr]),
     'nemo_project': (i32, [i64, i64, i64, ptr, ptr, ptr, f32, f32, f32, ptr, ptr]),
     'nemo_skin_vertices': (i32, [ptr, i64, ptr, i64, ptr, ptr, i64, ptr, ptr]),

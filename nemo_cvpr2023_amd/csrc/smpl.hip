@@ -678,13 +678,21 @@ __global__ void kp_finalize_kernel(long V, int n_out, int W, int mean_mode, cons
     else { *scalar_out += cnt > 0.f ? sum / (cnt * (float)(n_out * W)) : 0.f; norm[0] = cnt; }
 }
 
-template <int LANES>
+// FUSED (nemo_kp_fwd_bwd): the forward of kp_fwd_kernel and this backward in ONE launch.  The only thing the backward needs
+// from a completed forward is the per-view normaliser, and that is a function of the INDICES alone (view_cnt[v] = samples of
+// view v in the batch) -- the caller passes it, the launch writes the forward's outputs (j3d, p2d, loss_all, view_acc) on the
+// way and needs no predecessor launch: one dependent node and one pass over the joints less on the step's main chain.
+template <int LANES, bool FUSED = false>
 __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const float* __restrict__ view_acc,
                                                      const float* __restrict__ norm, float upstream,
                                                      float* __restrict__ dA, float* __restrict__ dJp,
                                                      float* __restrict__ dMq, float* __restrict__ dTR,
                                                      long lddt, float* __restrict__ d_cams, int nq,
-                                                     const float* __restrict__ dj3d_extra) {
+                                                     const float* __restrict__ dj3d_extra,
+                                                     const int64_t* __restrict__ view_cnt = nullptr,
+                                                     float* __restrict__ j3d = nullptr, float* __restrict__ p2d = nullptr,
+                                                     float* __restrict__ loss_all = nullptr,
+                                                     float* __restrict__ view_acc_out = nullptr) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long s = t / LANES;
     const int o = (int)(t % LANES);
@@ -695,13 +703,13 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
     // norm == NULL: the normaliser nemo_kp_finalize would write (number of views present / total confidence count) is
     // derived here from the per-view accumulators, so that kp_finalize is off the dependency chain of the step
     float nrm;
-    if (norm) {
+    if (!FUSED && norm) {
         nrm = norm[0];
     } else {
         __shared__ float nred[4];
         float part = 0.f;
         for (long vv = threadIdx.x; vv < a.V; vv += 256) {
-            const float c = view_acc[vv * 2 + 1];
+            const float c = FUSED ? (float)view_cnt[vv] : view_acc[vv * 2 + 1];
             part += a.mean_mode == 0 ? (c > 0.f ? 1.f : 0.f) : c;
         }
 #pragma unroll
@@ -716,14 +724,16 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
     float dpos[3] = {0.f, 0.f, 0.f};
     float dcam[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int kind = 0;
+    float wsum = 0.f;                // FUSED: this lane's contribution to the view's loss accumulator
     if (active) kind = kc.out_kind[o];
-    if (active && !pad) {
+    if (active && (!pad || FUSED)) {
         float pos[3];
         kp_joint(a, kc, s, o, Al[threadIdx.x / LANES], pos);
         if (a.add_trans) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) pos[c] += a.TR[s * a.ldt + c] - a.TR[a.N * a.ldt + c];
         }
+        if (FUSED && j3d) { j3d[(s * kc.n_out + o) * 3] = pos[0]; j3d[(s * kc.n_out + o) * 3 + 1] = pos[1]; j3d[(s * kc.n_out + o) * 3 + 2] = pos[2]; }
         const float* cam = a.cams + v * 9;
         float Rc[9];
         rot6d_fwd(cam + 3, Rc);
@@ -732,16 +742,27 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
         const float pz = Rc[6] * pos[0] + Rc[7] * pos[1] + Rc[8] * pos[2] + cam[2];
         const float nx = px / pz, ny = py / pz, nz = pz / pz;
         const float u = a.focal * nx + a.cx * nz, w = a.focal * ny + a.cy * nz;
+        if (FUSED && p2d) { p2d[(s * kc.n_out + o) * 2] = u; p2d[(s * kc.n_out + o) * 2 + 1] = w; }
         const long f = a.frame_idx[s];
         const float* g = a.targets + ((v * a.T + f) * kc.n_out + o) * 3;
         const float size = a.gt_size ? a.gt_size[v * a.T + f] : 1.f;
         float l[2], du, dv;
         kp_loss_eval(a.loss_type, u, w, g[0], g[1], g[2], size, l, &du, &dv);
         const int W = loss_width(a.loss_type);
+        if (FUSED) {
+            if (pad) { l[0] = 0.f; l[1] = 0.f; du = 0.f; dv = 0.f; }
+            if (loss_all) {
+                loss_all[(s * kc.n_out + o) * W] = l[0];
+                if (W == 2) loss_all[(s * kc.n_out + o) * W + 1] = l[1];
+            }
+            wsum = (l[0] + (W == 2 ? l[1] : 0.f)) * (a.mean_mode == 0 ? g[2] : 1.f);
+        }
         // d total / d loss_all element
+        const float cnt_v = FUSED ? (float)view_cnt[v] : view_acc[v * 2 + 1];
         float coef;
-        if (a.mean_mode == 0) coef = upstream * g[2] / (nrm * view_acc[v * 2 + 1] * (float)(kc.n_out * W));
+        if (a.mean_mode == 0) coef = upstream * g[2] / (nrm * cnt_v * (float)(kc.n_out * W));
         else coef = upstream / (nrm * (float)(kc.n_out * W));
+        if (FUSED && pad) coef = 0.f;
         du *= coef; dv *= coef;
         // u = f*px/pz + cx*(pz/pz)
         const float dpx = du * a.focal / pz, dpy = dv * a.focal / pz;
@@ -756,6 +777,28 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
         if (dj3d_extra) {       // gradient of a world-space term on the output joints (temporal smoothness)
             const float* x = dj3d_extra + (s * kc.n_out + o) * 3;
             dpos[0] += x[0]; dpos[1] += x[1]; dpos[2] += x[2];
+        }
+    }
+    if (FUSED && view_acc_out) {
+        // the forward's per-view accumulators [sum(loss * conf), #samples]: one atomic per (block, view), as in kp_fwd_kernel
+        constexpr int SPBf = 256 / LANES;
+        __shared__ float fsum[SPBf];
+        __shared__ long fview[SPBf];
+        if (LANES == 32) wsum = group32_sum(wsum);
+        const int slf = threadIdx.x / LANES;
+        if (o == 0) { fsum[slf] = wsum; fview[slf] = (live && !pad) ? v : -1; }
+        __syncthreads();
+        if (threadIdx.x < SPBf && fview[threadIdx.x] >= 0) {
+            const long mv = fview[threadIdx.x];
+            bool first = true;
+            for (int k = 0; k < (int)threadIdx.x; ++k) first = first && fview[k] != mv;
+            if (first) {
+                float tot = 0.f, cnt = 0.f;
+                for (int k = threadIdx.x; k < SPBf; ++k)
+                    if (fview[k] == mv) { tot += fsum[k]; cnt += 1.f; }
+                atomicAdd(view_acc_out + mv * 2, tot);
+                atomicAdd(view_acc_out + mv * 2 + 1, cnt);
+            }
         }
     }
     // camera gradient: reduce over the sample's joints (shuffles), then over the block's samples of the
@@ -1851,6 +1894,29 @@ extern "C" int32_t nemo_kp_bwd_ex(const nemo_ctx* ctx, int64_t N, int64_t V, int
     return kp_bwd_impl(ctx, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams, targets,
                        gt_size, focal, cx, cy, loss_type, mean_mode, view_acc, norm, upstream, dA, dJp, dMq, dTR,
                        lddt, d_cams, dj3d_extra, n_valid, stream);
+}
+
+extern "C" int32_t nemo_kp_fwd_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T, const float* A, const float* Jp,
+                                   const float* Mq, int64_t ldq, const float* TR, int64_t ldt, int32_t add_trans,
+                                   const int64_t* view_idx, const int64_t* frame_idx, const float* cams, const float* targets,
+                                   const float* gt_size, float focal, float cx, float cy, int32_t loss_type, int32_t mean_mode,
+                                   const int64_t* view_count, float upstream, float* j3d, float* p2d, float* loss_all,
+                                   float* view_acc, float* dA, float* dJp, float* dMq, float* dTR, int64_t lddt,
+                                   float* d_cams, const int64_t* n_valid, void* stream) {
+    KpArgs a;
+    const int rc = kp_args(ctx, a, N, V, T, A, Jp, Mq, ldq, TR, ldt, add_trans, view_idx, frame_idx, cams,
+                           targets, gt_size, focal, cx, cy, loss_type, mean_mode);
+    if (rc) return rc;
+    a.n_valid = n_valid;
+    if (!targets || !view_count || !view_acc) return NEMO_EINVAL;
+    if (dA && (!dJp || (ctx->nq > 0 && !dMq))) return NEMO_EINVAL;
+    if (N == 0) return NEMO_OK;
+    if (ctx->n_out > 32) return NEMO_EINVAL;
+    hipLaunchKernelGGL((kp_bwd_kernel<32, true>), dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       ctx->kc, (const float*)nullptr, (const float*)nullptr, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams,
+                       (int)ctx->nq, (const float*)nullptr, view_count, j3d, p2d, loss_all, view_acc);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
 }
 
 extern "C" int32_t nemo_smooth_fwd_bwd(int64_t V, int64_t T, int64_t J, const float* j3d, float weight,

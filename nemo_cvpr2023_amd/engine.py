@@ -323,6 +323,9 @@ class FitEngine:
         # device scalar 'number of real samples' of a PADDED step (include/nemo_hip.h, nemo_kp_fwd), else None; set by
         # MultiViewModel.step around its launches only
         self.nvalid = None
+        # device int64[V]: samples per view of the batch being launched (known from the indices: MultiViewModel._stage_indices),
+        # or None -- then the key-point objective runs as two launches (nemo_kp_fwd, nemo_kp_bwd_ex)
+        self.view_cnt = None
 
     # ------------------------------------------------------------------ parameter views
     def view(self, name, buf=None):
@@ -383,9 +386,9 @@ class FitEngine:
             dR=Z(N, 24, 9), dA=Z(N, 24, 12), dMq=Z(N, max(nq * 72, 1)),
             dPF=Z(N, 208), dHEAD=Z(N + 1, HEAD_LD), dH=Z(N + 1, h), dH_b=Z(N + 1, h), dH_c=Z(N + 1, h),
             dX=Z(N + 1, self.ldx), dMULV=Z(N, 64), dE_a=Z(N, 512), Nc=Nc,
-            # device-resident step inputs of a captured graph: the indices and (last element of vi_static) the number of
-            # real samples of a padded step
-            vi_static=torch.zeros(N + 1, dtype=torch.long, device=self.device),
+            # device-resident step inputs of a captured graph: the indices, the number of real samples of a padded step
+            # (element N of vi_static) and, behind it, the V per-view sample counts of the batch (nemo_kp_fwd_bwd)
+            vi_static=torch.zeros(N + 1 + self.V, dtype=torch.long, device=self.device),
             fi_static=torch.zeros(N + 1, dtype=torch.long, device=self.device), graphs={}, cap=N)
         w.update(views)
         w['zero_arena'] = arena
@@ -934,19 +937,31 @@ class FitEngine:
 
     # ------------------------------------------------------------------ backward pieces
     def backward_kp(self, w, N, view_idx, frame_idx, Mq, mean_mode, upstream, cams_only=False,
-                    detach_pose=False, dj3d_extra=None, norm_from_acc=False):
+                    detach_pose=False, dj3d_extra=None, norm_from_acc=False, fused_counts=None):
+        """Backward of the key-point objective down to dR (and the camera gradient).  ``fused_counts`` (device int64[V],
+        samples per view of this batch): the forward of project_and_loss runs in the same launch (nemo_kp_fwd_bwd) -- the
+        caller then skips project_and_loss and only finalises the loss scalar."""
         L, st, ctx = self.lib, _stream(), self.ctx
         nq72 = max(ctx.nq * 72, 1)
         lt = LOSS_TYPES[self.args.loss]
         add_trans = 0 if self.start_global_traj_anywhere else 1
-        check(L.nemo_kp_bwd_ex(
-            ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), nq72, dptr(w['TR']),
-            HEAD_LD, add_trans, dptr(view_idx), dptr(frame_idx), self.p('learned_cameras'), dptr(self.targets),
-            dptr(self.gt_size), FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode, dptr(w['view_acc']),
-            None if norm_from_acc else dptr(w['norm']), upstream, None if cams_only else dptr(w['dA']),
-            None if cams_only else dptr(w['dJp']), None if cams_only else dptr(w['dMq']),
-            None if cams_only else dptr(w['dTR']), HEAD_LD, self.g('learned_cameras'), dptr(dj3d_extra), self.nvalid, st),
-            'nemo_kp_bwd_ex')
+        if fused_counts is not None:
+            assert dj3d_extra is None and not cams_only
+            check(L.nemo_kp_fwd_bwd(
+                ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), nq72, dptr(w['TR']), HEAD_LD, add_trans,
+                dptr(view_idx), dptr(frame_idx), self.p('learned_cameras'), dptr(self.targets), dptr(self.gt_size),
+                FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode, fused_counts, upstream, dptr(w['j3d']), dptr(w['p2d']),
+                dptr(w['loss_all']), dptr(w['view_acc']), dptr(w['dA']), dptr(w['dJp']), dptr(w['dMq']), dptr(w['dTR']),
+                HEAD_LD, self.g('learned_cameras'), self.nvalid, st), 'nemo_kp_fwd_bwd')
+        else:
+            check(L.nemo_kp_bwd_ex(
+                ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), nq72, dptr(w['TR']),
+                HEAD_LD, add_trans, dptr(view_idx), dptr(frame_idx), self.p('learned_cameras'), dptr(self.targets),
+                dptr(self.gt_size), FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode, dptr(w['view_acc']),
+                None if norm_from_acc else dptr(w['norm']), upstream, None if cams_only else dptr(w['dA']),
+                None if cams_only else dptr(w['dJp']), None if cams_only else dptr(w['dMq']),
+                None if cams_only else dptr(w['dTR']), HEAD_LD, self.g('learned_cameras'), dptr(dj3d_extra), self.nvalid, st),
+                'nemo_kp_bwd_ex')
         if cams_only:
             return
         if self.detach_articulation:

@@ -582,20 +582,29 @@ class MultiViewModel(nn.Module):
         # The main-stream branch (the longest of the three) is ENQUEUED FIRST: a replayed HIP graph keeps a node's first
         # successor on the hardware queue of the node and starts the others on further queues behind a cross-queue
         # barrier that costs 15 - 30 us (profiles/r02_kernel_trace_v1.md) -- that delay has to land on the short branches.
-        Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0, finalize=False)
-        kp_done = main.record_event()        # (view accumulators complete: the loss scalar is finalised on side2, below)
-        # optional temporal smoothness of the output joints (not part of the published step; only defined on
-        # complete (view, frame) sequences, i.e. full-batch steps -- see DESIGN.md section 8, row f-4)
-        dj = None
         w_s = float(getattr(a, 'weight_smooth', 0) or 0)
-        if w_s and N == e.V * e.T and smooth_ok:
-            check(e.lib.nemo_smooth_fwd_bwd(e.V, e.T, e.ctx.n_out, dptr(w['j3d']), w_s,
-                                            e.scal.data_ptr() + 4 * S_SMOOTH, dptr(w['dj3d']) if update else None,
-                                            _stream()), 'nemo_smooth_fwd_bwd')
-            dj = w['dj3d'] if update else None
-        if update:
+        smooth = bool(w_s and N == e.V * e.T and smooth_ok)
+        if update and e.view_cnt is not None and not smooth:
+            # projection, 2-D loss and their backward in ONE launch: the per-view normaliser only needs the per-view sample
+            # counts, which the host knows from the indices it staged (nemo_kp_fwd_bwd)
+            Mq = e.joint_functionals(w, N)
             e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose,
-                          dj3d_extra=dj, norm_from_acc=True)
+                          fused_counts=e.view_cnt)
+            kp_done = main.record_event()
+        else:
+            Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0, finalize=False)
+            kp_done = main.record_event()        # (view accumulators complete: the loss scalar is finalised on side2, below)
+            # optional temporal smoothness of the output joints (not part of the published step; only defined on
+            # complete (view, frame) sequences, i.e. full-batch steps -- see DESIGN.md section 8, row f-4)
+            dj = None
+            if smooth:
+                check(e.lib.nemo_smooth_fwd_bwd(e.V, e.T, e.ctx.n_out, dptr(w['j3d']), w_s,
+                                                e.scal.data_ptr() + 4 * S_SMOOTH, dptr(w['dj3d']) if update else None,
+                                                _stream()), 'nemo_smooth_fwd_bwd')
+                dj = w['dj3d'] if update else None
+            if update:
+                e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose,
+                              dj3d_extra=dj, norm_from_acc=True)
         side.wait_event(pose_done)
         side2.wait_event(pose_done)
         enc_done = None
@@ -641,16 +650,29 @@ class MultiViewModel(nn.Module):
         # Measured (same box, three runs each): 0.494 ms at one instance / 1.557 ms at C2 against 0.512 / 1.576 with the
         # hand-over on the main stream, before or after the adjoint -- its system-scope release stalls the queue it is on.
         loss_final = []
+        pub_side = False
         pub_aside = bool(publish and update and part == 'all' and use_vposer)
         if use_vposer:
             e.forward_v2v(w, N, need_grad=bool(update and a.weight_vp_loss), pre_done=True,
                           after_loss=(lambda: loss_final.append(main.record_event())) if pub_aside else None)
         if publish and not pub_aside:
             e.publish_scalars()
+        if pub_aside and N + 1 <= e.SMALL_BATCH_ROWS:
+            # Small batches (minibatch steps, a rank's share): the hand-over goes onto the VPoser stream, which is idle by
+            # now, enqueued right here.  Enqueued last on side2 (below) it shares a hardware queue with the grouped
+            # parameter-gradient launch of the small-batch backward and reaches the host only at the END of the step
+            # (profiles/r04_kernel_trace_phases.md) -- the host then prepares the next minibatch on an idle GPU: 0.625 ->
+            # 0.596 ms per minibatch-512 step, 0.633 -> 0.620 at two instances; no difference at 8 x 300.
+            side.wait_event(loss_final[0])
+            with torch.cuda.stream(side):
+                e.publish_scalars()
+            pub_aside, pub_side = False, True
         if not update or part == 'head':
             return
         self._backward_tail(w, N, vi, fi, update, use_vposer, sh, stages=(0,) if part == 'k0' else (0, 1, 2),
                             bucketed=part == 'k0')
+        if pub_side:
+            main.wait_stream(side)            # (every forked stream rejoins the launch's stream)
         if pub_aside:
             side2.wait_event(loss_final[0])
             with torch.cuda.stream(side2):
@@ -720,33 +742,39 @@ class MultiViewModel(nn.Module):
                     gc.enable()
         entry.replay()
 
-    def _stage_indices(self, w, vi, fi, N, n_valid=None):
+    def _stage_indices(self, w, vi, fi, N, n_valid=None, full=False):
         """Step inputs of a captured launch live in the workspace's device-resident index buffers.  Host-resident indices
         go through pinned staging: a pageable H2D copy would block the host until the previous step -- still running,
         the losses are handed over mid-step -- has drained.  The staging buffer is free: the previous copy out of it was
         enqueued before the launch whose losses we already hold.  ``n_valid``: the number of real samples of a padded
-        launch, stored behind the view indices (one copy)."""
-        cap = w['cap']
-        src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N)
+        launch, stored behind the view indices; behind that the V per-view sample counts of the batch (what
+        nemo_kp_fwd_bwd normalises with) whenever the host can know them -- host-resident indices, or a full batch
+        (``full``: T samples per view); all of it travels in ONE copy.  Sets ``engine.view_cnt`` accordingly."""
+        e = self.engine
+        cap, V = w['cap'], e.V
+        src = (vi.data_ptr(), fi.data_ptr(), vi._version, fi._version, N, n_valid)
         if w.get('_static_src') != src or vi is not w.get('_static_vi'):   # (full batch: cached, unchanged)
             if vi.device.type == 'cpu' and fi.device.type == 'cpu':
                 if '_idx_pin' not in w:
-                    w['_idx_pin'] = torch.zeros(2, cap + 1, dtype=w['vi_static'].dtype).pin_memory()
+                    w['_idx_pin'] = torch.zeros(2, cap + 1 + V, dtype=w['vi_static'].dtype).pin_memory()
                 pin = w['_idx_pin']
                 pin[0, :N].copy_(vi)
                 pin[1, :N].copy_(fi)
-                if n_valid is not None:
-                    pin[0, cap] = n_valid
-                    w['vi_static'].copy_(pin[0], non_blocking=True)
-                else:
-                    w['vi_static'][:N].copy_(pin[0, :N], non_blocking=True)
+                pin[0, cap] = N if n_valid is None else n_valid
+                pin[0, cap + 1:] = torch.bincount(vi[:N if n_valid is None else n_valid], minlength=V)
+                w['vi_static'].copy_(pin[0], non_blocking=True)
                 w['fi_static'][:N].copy_(pin[1, :N], non_blocking=True)
+                w['_cnt_ok'] = True
             else:
                 w['vi_static'][:N].copy_(vi)
                 w['fi_static'][:N].copy_(fi)
                 if n_valid is not None:
-                    w['vi_static'][cap:].fill_(n_valid)
+                    w['vi_static'][cap:cap + 1].fill_(n_valid)
+                w['_cnt_ok'] = bool(full)
+                if full:
+                    w['vi_static'][cap + 1:].fill_(e.T)
             w['_static_src'], w['_static_vi'] = src, vi
+        e.view_cnt = w['vi_static'][cap + 1:].data_ptr() if w.get('_cnt_ok') else None
         return w['vi_static'][:N], w['fi_static'][:N]      # (the workspace may be larger than this batch)
 
     def _prepare_batch(self, view_idx, frame_idx, full_batch, sh):
@@ -841,7 +869,7 @@ class MultiViewModel(nn.Module):
         of the in-graph Adam."""
         e, sh = self.engine, b.sh
         return ('step', b.N, pl.update, b.is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, sh.live, part, pl.early,
-                b.padded, e.detach_articulation, e.start_global_traj_anywhere, pl.has_inst, self._weights_key(),
+                b.padded, e.view_cnt is not None, e.detach_articulation, e.start_global_traj_anywhere, pl.has_inst, self._weights_key(),
                 tuple((s_['offset'], s_['numel']) for s_ in pl.segs) if pl.in_graph_adam else None)
 
     def _inst_term(self, sh, update):                                                 # :3864-3867
@@ -925,7 +953,7 @@ class MultiViewModel(nn.Module):
         if not pl.graphable and not b.padded:
             return self._body(w, b, pl, b.vi, b.fi, None, part)
         if part in ('all', 'head', 'k0', 'allc', 'splitc', 'bucketc'):          # the first launch of a step stages its inputs
-            self._stage_indices(w, b.vi, b.fi, b.N, b.Nv if b.padded else None)
+            self._stage_indices(w, b.vi, b.fi, b.N, b.Nv if b.padded else None, full=b.is_full)
         svi, sfi = w['vi_static'][:b.N], w['fi_static'][:b.N]
         if not pl.graphable:
             self._body(w, b, pl, svi, sfi, None, part)
@@ -991,7 +1019,7 @@ class MultiViewModel(nn.Module):
                     #             shared-gradient all-reduce (_reduce_and_read)
                     s = self._reduce_and_read(sh, update, then=(lambda: e.adam(pl.segs)) if need_adam else None)
         finally:
-            e.nvalid = None
+            e.nvalid = e.view_cnt = None
         vi, fi, Nv = b.vi, b.fi, b.Nv
         if b.padded:
             if sh.comm is None:          # (with a collective the scalars come back weighted: _shard_weights)
@@ -1394,12 +1422,14 @@ class NemoV4(NemoV3):
                     self._forward_backward(w, N, svi, sfi, True, use_vposer=False, detach_pose=True, sh=sh, adam_segs=table[0])
                     e.adam_from_table(*table)
                 key = ('cam4', N, e.detach_articulation, e.start_global_traj_anywhere, self._weights_key(),
-                       tuple((s_['offset'], s_['numel']) for s_ in segs))
+                       e.view_cnt is not None, tuple((s_['offset'], s_['numel']) for s_ in segs))
                 try:
                     self._captured(w, key, body)
                 except BaseException:
                     e.adam_table_invalidate()
                     raise
+                finally:
+                    e.view_cnt = None
                 e.adam_table_commit()
                 continue
             vi, fi = self._idx(b.vi), self._idx(b.fi)

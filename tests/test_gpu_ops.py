@@ -462,6 +462,33 @@ def test_keypoint_path_forward_backward(L, num_verts, version):
                          dTR2.data_ptr(), 3, dc2.data_ptr(), H.st()) == 0
     assert torch.equal(dA2, dA) and torch.equal(dMq2, dMq) and torch.equal(dTR2[:N], dTRg[:N])
     assert rel_err(dJp2, dJp) < 1e-6 and rel_err(dc2, dcg) < 1e-6          # (atomic accumulations: order may differ)
+    # nemo_kp_fwd_bwd (round 4): forward and backward in ONE launch, normalised with the per-view sample counts the caller knows
+    # from the indices -- every output of both launches, bit for bit where no atomics are involved
+    cnt = H.dev(torch.bincount(vi, minlength=V), torch.long)
+    j3, p3, la3, va3 = Z(N, 25, 3), Z(N, 25, 2), Z(N, 25, 2), Z(V, 2)
+    dA3, dJp3, dMq3, dTR3, dc3 = Z(N, 24, 12), Z(N, 24, 3), Z(N, nq72), Z(N + 1, 3), Z(V, 9)
+    assert L.nemo_kp_fwd_bwd(*args, cnt.data_ptr(), 1.0, j3.data_ptr(), p3.data_ptr(), la3.data_ptr(), va3.data_ptr(),
+                             dA3.data_ptr(), dJp3.data_ptr(), dMq3.data_ptr(), dTR3.data_ptr(), 3, dc3.data_ptr(), None,
+                             H.st()) == 0
+    assert torch.equal(j3, j3d) and torch.equal(p3, p2d) and torch.equal(la3, lall)
+    assert torch.equal(va3[:, 1], vacc[:, 1]) and rel_err(va3[:, 0], vacc[:, 0]) < 1e-6
+    assert torch.equal(dA3, dA) and torch.equal(dMq3, dMq) and torch.equal(dTR3[:N], dTRg[:N])
+    assert rel_err(dJp3, dJp) < 1e-6 and rel_err(dc3, dcg) < 1e-6
+    # ... and with padding rows (n_valid): no loss, not counted, exactly-zero gradient rows -- as the two launches do it
+    nv = H.dev(torch.tensor([N - 4]), torch.long)
+    cntp = H.dev(torch.bincount(vi[:N - 4], minlength=V), torch.long)
+    va4, dA4, dJp4, dMq4, dTR4, dc4 = Z(V, 2), Z(N, 24, 12), Z(N, 24, 3), Z(N, nq72), Z(N + 1, 3), Z(V, 9)
+    vaP, dAP, dJpP, dMqP, dTRP, dcP = Z(V, 2), Z(N, 24, 12), Z(N, 24, 3), Z(N, nq72), Z(N + 1, 3), Z(V, 9)
+    assert L.nemo_kp_fwd(*args, j3d.data_ptr(), p2d.data_ptr(), lall.data_ptr(), vaP.data_ptr(), nv.data_ptr(), H.st()) == 0
+    assert L.nemo_kp_bwd_ex(*args, vaP.data_ptr(), None, 1.0, dAP.data_ptr(), dJpP.data_ptr(), dMqP.data_ptr(),
+                            dTRP.data_ptr(), 3, dcP.data_ptr(), None, nv.data_ptr(), H.st()) == 0
+    assert L.nemo_kp_fwd_bwd(*args, cntp.data_ptr(), 1.0, j3.data_ptr(), p3.data_ptr(), la3.data_ptr(), va4.data_ptr(),
+                             dA4.data_ptr(), dJp4.data_ptr(), dMq4.data_ptr(), dTR4.data_ptr(), 3, dc4.data_ptr(),
+                             nv.data_ptr(), H.st()) == 0
+    assert torch.equal(la3, lall) and torch.equal(va4[:, 1], vaP[:, 1]) and rel_err(va4[:, 0], vaP[:, 0]) < 1e-6
+    assert torch.equal(dA4, dAP) and torch.equal(dMq4, dMqP) and torch.equal(dTR4[:N], dTRP[:N])
+    assert float(dA4[N - 4:].abs().max()) == 0.0 and float(dMq4[N - 4:].abs().max()) == 0.0
+    assert rel_err(dJp4, dJpP) < 1e-6 and rel_err(dc4, dcP) < 1e-6
 
 
 @pytest.mark.parametrize('loss_type,lid', [('mse', 1), ('rmse', 2), ('rmse_robust', 3),
