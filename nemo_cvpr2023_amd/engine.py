@@ -341,6 +341,7 @@ class FitEngine:
 
     # ------------------------------------------------------------------ workspaces
     SMALL_BATCH_ROWS = 1024  # backward_mlp: below this many rows the dW GEMMs run beside the dX chain
+    GROUPED_DW_ROWS = 400    # ... and up to this many as ONE grouped launch behind it (a one-instance shard)
     MAX_WORKSPACES = 24      # distinct batch sizes kept alive (a rank of a sharded minibatch run sees many)
 
     @staticmethod
@@ -1039,8 +1040,10 @@ class FitEngine:
         # stream: four launches of 32 - 256 tiles (each with its own pipeline fill / output burst at ~one block per CU) ->
         # one of 592 tiles.  Measured (same box, un-profiled): one-instance shard 0.493 ms grouped against 0.501 per layer;
         # 8 x 300: 1.567 against 1.559 (there the per-layer launches on the 64 x 64 / 8-wave skinny configuration are ahead)
-        # -> small batches only.
-        if not bucketed and tuple(stages) == (0, 1, 2) and small:
+        # -> small batches only.  Round 4, random minibatches of 512 (the published run's mode): the per-layer launches, each on
+        # the side stream as soon as its dY exists, are ahead again (0.575 against 0.590 ms per step; level at 600 rows, the
+        # grouped launch 0.478 against 0.481 at 300) -> grouped up to GROUPED_DW_ROWS rows.
+        if not bucketed and tuple(stages) == (0, 1, 2) and r <= self.GROUPED_DW_ROWS:
             dWs = []
 
             def dWg(rows, x, ldx_, fin, dy, lddy, fout, gw, gb, nbias=None):
