@@ -610,20 +610,23 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
         pl.t0 = 0;
         if (split_k > 0) pl.split = split_k;
     }
-    // The blend-shape adjoint (dPF = dVP P^T: M = samples, N = 207, K = 3 NV = 20 670, both operands "transposed") above
-    // ~1000 samples: ONE 64 x 208 column tile per workgroup with mixed MFMA shapes (gemm_adj.h: columns [0, 192) on
+    // The blend-shape adjoint (dPF = dVP P^T: M = samples, N = 207, K = 3 NV = 20 670, both operands "transposed") from 256
+    // samples on: ONE 64 x 208 column tile per workgroup with mixed MFMA shapes (gemm_adj.h: columns [0, 192) on
     // v_mfma_f32_32x32x2_f32, the 16-column remainder on 16x16x4) -- dVP^T is streamed once instead of once per 64-column
     // tile and 0.5 % instead of 24 % of the MFMAs multiply padding.  tools/gemm_glds_dev adj <M> (us per launch, best K
-    // split each): M = 1200: 102 against 130 (64 x 64 plan) / 128 (skinny 32 x 224); 2400: 172 against 227; 3808: 270
-    // against 305 (round 2's all-16x16x4 wide tile) / 351; 8192: 526 against 570 / 688.  K slices so that ~512 workgroups
-    // (two per CU) are resident.  Below ~1000 samples the skinny configurations keep the shape (profiles/r04_experiments.md).
-    if (glds_ok && !bf16 && transA && transB && N > 128 && N <= 208 && M > 1000 && K >= 2048 && split_k == 0 &&
+    // split each): M = 300: 49 against 58 (skinny 32 x 32 x 16 slices); 512: 56 against 72 (skinny 32 x 224); 600: 66 against 72;
+    // 1200: 101 against 130 (64 x 64 plan) / 128; 2400: 172 against 227; 3808: 270 against 305 (round 2's all-16x16x4 wide
+    // tile) / 351; 8192: 526 against 570 / 688.  K slices so that one workgroup per CU (up to 8 row tiles) or two (beyond) are
+    // resident -- a count that overshoots the 256 / 512 slots by a few workgroups costs a whole extra round -- and every slice
+    // keeps >= 8 K tiles; beyond 16 slices they are summed in two levels (gemm_adj.h).
+    if (glds_ok && !bf16 && transA && transB && N > 128 && N <= 208 && M >= 256 && K >= 2048 && split_k == 0 &&
         out_mode != 2 && force_tile == 0 && can_split && !bias && !act && !mask_mode) {
         const long tiles_m = (M + 63) / 64;
-        int S = (int)(512 / tiles_m);
+        int S = (int)((tiles_m <= 8 ? 256 : 512) / tiles_m);
         if (S < 1) S = 1;
-        while (S > 1 && ((K + 31) / 32 / S < 8 || COUNTER_BYTES + tiles_m * S * 64L * 208 * 4 > ws_bytes)) --S;
-        if (tiles_m <= COUNTER_BYTES / 4) {
+        while (S > 1 && ((K + 31) / 32 / S < 8 || COUNTER_BYTES + glds::adj_slab_floats(tiles_m, S) * 4 > ws_bytes ||
+                         glds::adj_counter_ints(tiles_m, S) > COUNTER_BYTES / 4)) --S;
+        if (glds::adj_counter_ints(tiles_m, S) <= COUNTER_BYTES / 4) {
             GemmArgs g;
             g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.mask = nullptr;
             g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldmask = 0;

@@ -134,53 +134,92 @@ __global__ __launch_bounds__(256, 2) void gemm_adj_kernel(Args g) {
         compute(sa, sb, -1, -1);
     }
 
-    // ---- split-K: publish the partial tile (13 float4 per thread), the last arriver sums all slices in slice order
+    // ---- split-K: publish the partial tile (13 float4 per thread); the slices of a tile are summed in a fixed order
+    // (deterministic) by last arrivers -- in ONE level up to 16 slices, in TWO levels beyond (groups of 8 slices: a group's
+    // last arriver sums its 8 slabs into a group slab, the last group's arriver sums the group slabs): a small batch needs
+    // 40 - 64 K slices to fill the machine, and one workgroup reading 64 slabs of 52 KiB back to back was a 30+ us tail
     if (split > 1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                  // (smem is reused for the hand-off flag below)
-        float4* slab = reinterpret_cast<float4*>(g.slabs) + ((size_t)tile * split + slice) * (size_t)(ADJ_BM * ADJ_BN / 4);
-        auto put = [&](int idx, f32x4 vv) {
+        constexpr size_t TILE4 = (size_t)(ADJ_BM * ADJ_BN / 4);
+        const int gs = split <= 16 ? split : 8;                     // slices per group
+        const int ngroups = (split + gs - 1) / gs;
+        const int grp = slice / gs, gsz = min(gs, split - grp * gs);
+        float4* const slabs4 = reinterpret_cast<float4*>(g.slabs);
+        float4* const gslabs4 = slabs4 + (size_t)g.tiles_m * split * TILE4;           // group slabs behind the slice slabs
+        int* const cnt2 = g.counters + tile;                                           // groups of this tile that are complete
+        int* const cnt1 = g.counters + g.tiles_m + tile * ngroups + grp;               // slices of this group that have arrived
+        int* flag = reinterpret_cast<int*>(smem);
+        auto put = [&](float4* slab, int idx, f32x4 vv) {
             float4* dst = slab + idx * 256 + threadIdx.x;
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
         };
+        auto put_all = [&](float4* slab) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4)
-                put(j * 4 + r4, f32x4{acc[j][4 * r4], acc[j][4 * r4 + 1], acc[j][4 * r4 + 2], acc[j][4 * r4 + 3]});
-        put(12, acc16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem);
-        if (threadIdx.x == 0)
-            *flag = __hip_atomic_fetch_add(g.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*flag != split - 1) return;
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(g.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        const float4* base = reinterpret_cast<const float4*>(g.slabs) + (size_t)tile * split * (size_t)(ADJ_BM * ADJ_BN / 4);
-        float4 sum[13];
+                for (int r4 = 0; r4 < 4; ++r4)
+                    put(slab, j * 4 + r4, f32x4{acc[j][4 * r4], acc[j][4 * r4 + 1], acc[j][4 * r4 + 2], acc[j][4 * r4 + 3]});
+            put(slab, 12, acc16);
+        };
+        // sum `n` consecutive slabs starting at `base` into acc / acc16, in order, two slabs' loads in flight
+        auto sum_slabs = [&](const float4* base, int n) {
+            float4 sum[13];
 #pragma unroll
-        for (int i = 0; i < 13; ++i) sum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sl = 0; sl < split; ++sl) {           // slice-major: 13 independent loads in flight, fixed order
-            const float4* p = base + (size_t)sl * (ADJ_BM * ADJ_BN / 4) + threadIdx.x;
+            for (int i = 0; i < 13; ++i) sum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int sl = 0;
+            for (; sl + 1 < n; sl += 2) {
+                const float4* p0 = base + (size_t)sl * TILE4 + threadIdx.x;
+                const float4* p1 = p0 + TILE4;
+                float4 v0[13], v1[13];
 #pragma unroll
-            for (int i = 0; i < 13; ++i) {
-                const float4 v = p[i * 256];
-                sum[i].x += v.x; sum[i].y += v.y; sum[i].z += v.z; sum[i].w += v.w;
+                for (int i = 0; i < 13; ++i) { v0[i] = p0[i * 256]; v1[i] = p1[i * 256]; }
+#pragma unroll
+                for (int i = 0; i < 13; ++i) {
+                    sum[i].x += v0[i].x; sum[i].y += v0[i].y; sum[i].z += v0[i].z; sum[i].w += v0[i].w;
+                    sum[i].x += v1[i].x; sum[i].y += v1[i].y; sum[i].z += v1[i].z; sum[i].w += v1[i].w;
+                }
             }
-        }
+            if (sl < n) {
+                const float4* p0 = base + (size_t)sl * TILE4 + threadIdx.x;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const float4 v = sum[j * 4 + r4];
-                acc[j][4 * r4] = v.x; acc[j][4 * r4 + 1] = v.y; acc[j][4 * r4 + 2] = v.z; acc[j][4 * r4 + 3] = v.w;
+                for (int i = 0; i < 13; ++i) {
+                    const float4 v = p0[i * 256];
+                    sum[i].x += v.x; sum[i].y += v.y; sum[i].z += v.z; sum[i].w += v.w;
+                }
             }
-        acc16 = f32x4{sum[12].x, sum[12].y, sum[12].z, sum[12].w};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 v = sum[j * 4 + r4];
+                    acc[j][4 * r4] = v.x; acc[j][4 * r4 + 1] = v.y; acc[j][4 * r4 + 2] = v.z; acc[j][4 * r4 + 3] = v.w;
+                }
+            acc16 = f32x4{sum[12].x, sum[12].y, sum[12].z, sum[12].w};
+        };
+        // arrive on `cnt` (after this workgroup's write-through stores have left); true in the last of `n` arrivers, which
+        // then sees everybody's slabs and has returned the counter to zero
+        auto last_of = [&](int* cnt, int n) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool last = *flag == n - 1;
+            if (last && threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            return last;
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // (smem is reused for the hand-off flag)
+        put_all(slabs4 + ((size_t)tile * split + slice) * TILE4);
+        if (!last_of(cnt1, gsz)) return;
+        sum_slabs(slabs4 + ((size_t)tile * split + (size_t)grp * gs) * TILE4, gsz);
+        if (ngroups > 1) {
+            put_all(gslabs4 + ((size_t)tile * ngroups + grp) * TILE4);
+            if (!last_of(cnt2, ngroups)) return;
+            sum_slabs(gslabs4 + (size_t)tile * ngroups * TILE4, ngroups);
+        }
     }
 
     // ---- epilogue: C = alpha * acc (out_mode 0) or C += alpha * acc (1)
@@ -210,7 +249,14 @@ __global__ __launch_bounds__(256, 2) void gemm_adj_kernel(Args g) {
 }
 
 // g: TT problem (A = (K x M) row-contiguous, B = (N x K) k-contiguous), 128 < N <= 208; tiles_m = ceil(M / 64), split /
-// k_chunk (multiple of 32) / counters / slabs (64 x 208 floats per (tile, slice)) set by the caller
+// k_chunk (multiple of 32) set by the caller; counters: adj_counter_ints(tiles_m, split) ints, zero between launches; slabs:
+// adj_slab_floats(tiles_m, split) floats
+inline long adj_groups(int split) { return split <= 16 ? 1 : (split + 7) / 8; }
+inline long adj_counter_ints(long tiles_m, int split) { return tiles_m * (1 + adj_groups(split)); }
+inline long adj_slab_floats(long tiles_m, int split) {
+    return tiles_m * (split + (adj_groups(split) > 1 ? adj_groups(split) : 0)) * (long)(ADJ_BM * ADJ_BN);
+}
+
 inline hipError_t launch_adj(const Args& g, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {

@@ -121,9 +121,10 @@ def test_gemm_split_k_in_launch_combine(L, monkeypatch, tile, ta, tb, M, N, K, s
     assert int(H.gemm_ws()[:4096].view(torch.int32).abs().sum()) == 0
 
 
-@pytest.mark.parametrize('M,N,K', [(2400, 207, 20670), (1201, 207, 2100), (1100, 200, 4099), (8192, 207, 2048), (1003, 129, 2222)])
+@pytest.mark.parametrize('M,N,K', [(2400, 207, 20670), (1201, 207, 2100), (1100, 200, 4099), (8192, 207, 2048), (1003, 129, 2222),
+                                   (300, 207, 20670), (512, 207, 20670), (257, 207, 5000)])
 def test_blend_shape_adjoint_on_the_mixed_shape_tile(L, M, N, K):
-    """csrc/gemm_adj.h (round 4): the TT product dPF (+)= dVP^T P^T above ~1000 samples on one 64 x 208 column tile per
+    """csrc/gemm_adj.h (round 4): the TT product dPF (+)= dVP^T P^T from 256 samples on, on one 64 x 208 column tile per
     workgroup -- columns [0, 192) on v_mfma_f32_32x32x2_f32, the remainder on 16x16x4 -- with K slices combined in the
     launch: overwrite and accumulate modes against float64, NaN-poisoned row pads, bit-identical run to run, tickets
     returned to zero."""

@@ -242,7 +242,7 @@ int adj(long Mt) {
         float *dA, *dB, *dC;
         CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dC, hC.size() * 4));
         CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
-        for (int split : {1, 3, 7})
+        for (int split : {1, 3, 7, 19, 33})
             for (int om : {0, 1}) {
                 if (split > 1 && p.K < 32 * split) continue;
                 for (auto& x : hC) x = om ? 1.f : NAN;
@@ -295,7 +295,9 @@ int adj(long Mt) {
         for (int split : {8, 13, 16}) { char b[48]; snprintf(b, sizeof b, " s%d=%.1f", split, time_it([&] { CK(run(C64x208, 1, 1, M, N, K, dA, lda, dB, ldb, dC, ldc, nullptr, 0, 0, split, 0, ws, 0)); })); line += b; }
         printf("%s\n", line.c_str());
         line = "   64x208 mixed:";
-        for (int split : {6, 8, 10, 13, 16, 20}) { char b[48]; snprintf(b, sizeof b, " s%d=%.1f", split, time_it([&] { CK(run_adj(M, N, K, dA, lda, dB, ldb, dC2, ldc, 0, split, ws, 0)); })); line += b; }
+        for (int split : {6, 8, 10, 13, 16, 20, 26, 32, 40, 51, 64, 80}) {
+            if ((long)((M + 63) / 64) * split > 1100) continue;
+            char b[48]; snprintf(b, sizeof b, " s%d=%.1f", split, time_it([&] { CK(run_adj(M, N, K, dA, lda, dB, ldb, dC2, ldc, 0, split, ws, 0)); })); line += b; }
         printf("%s\n", line.c_str());
         {   // the same with A cold (as in the step, where the mesh kernel has just written 198 MB and other kernels ran in between):
             // a 512 MB memset between the launches evicts L2 and the Infinity Cache; its own time is subtracted
