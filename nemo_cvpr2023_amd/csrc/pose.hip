@@ -590,8 +590,18 @@ __global__ __launch_bounds__(256) void phase_bwd_colsum_kernel(PhaseBwdArgs a, i
     if (mbeg >= d.M || (long)bx * 64 >= d.N) return;                 // block-uniform
     const long mend = min((long)d.M, mbeg + cb.rows_per_block);
     float sacc = 0.f;
-    if (n < d.N)
-        for (long m = mbeg + (threadIdx.x >> 6); m < mend; m += 4) sacc += d.X[m * d.ldx + n];
+    if (n < d.N) {
+        // four independent accumulators: the loads of a wave's rows are in flight together (one dependent chain of 32 loads
+        // per thread made this part a 30 us tail of the small-batch backward)
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long m = mbeg + (threadIdx.x >> 6);
+        for (; m + 12 < mend; m += 16) {
+            sacc += d.X[m * d.ldx + n]; s1 += d.X[(m + 4) * d.ldx + n];
+            s2 += d.X[(m + 8) * d.ldx + n]; s3 += d.X[(m + 12) * d.ldx + n];
+        }
+        for (; m < mend; m += 4) sacc += d.X[m * d.ldx + n];
+        sacc += s1 + s2 + s3;
+    }
     __shared__ float redc[4][64];
     redc[threadIdx.x >> 6][threadIdx.x & 63] = sacc;
     __syncthreads();
@@ -621,7 +631,7 @@ static int32_t phase_bwd_launch(int64_t N, int64_t V, int64_t T, int64_t K, int6
                    log_sigmas, (int)kernel_id, phase, (const float*)ws, dX, (long)ldx, d_shifts, d_scales, d_log_sigmas, d_codes,
                    (int)nAB, spb};
     ColsumBatchP cb;
-    cb.n = 0; cb.gx = cb.gy = 0; cb.rows_per_block = 128;
+    cb.n = 0; cb.gx = cb.gy = 0; cb.rows_per_block = 64;
     long maxM = 0, maxN = 0;
     for (int i = 0; i < n_cs; ++i) {
         if (descs[i].M < 0 || descs[i].N < 0 || !descs[i].X || !descs[i].out) return NEMO_EINVAL;
