@@ -903,7 +903,8 @@ class FitEngine:
             # single-chunk batches: the per-group sum of the blocks' partial dA images runs as a launch of its own on the
             # second side stream, beside the blend-shape adjoint GEMM (only the FK adjoint behind that GEMM needs dA)
             # (large batches only: at a one-instance shard the extra fork / join of the replayed graph costs more than the
-            #  reduction's tail -- 0.509 against 0.503 ms, same box; 8 x 300: 1.557 against 1.564 ms)
+            #  reduction's tail -- 0.509 against 0.503 ms, same box; 8 x 300: 1.557 against 1.564 ms; round 4: minibatch-512 steps
+            #  0.572 against 0.579 ms deferred, two instances 0.602 against 0.618)
             defer = need_grad and self.SMALL_BATCH_ROWS < N <= Nc and self.timers is None
             if self.b16mem:
                 check(L.nemo_v2v_fused_bf16mem(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),

@@ -501,6 +501,25 @@ def test_smaller_batch_after_a_larger_one_in_a_shared_workspace(mode):
         assert rel_err(named[k].grad, p.grad) < 2e-3, k
 
 
+@pytest.mark.parametrize('graphs', [True, False])
+def test_warmup_raises_on_nan_gradients_and_keeps_the_parameters(graphs):
+    """:3497-3500 ("nan gradient found" -> ipdb) on the captured warm-up: the NaN-gradient count is a device scalar, the
+    update is skipped from the first poisoned iteration on, and the phase ends with FloatingPointError -- the parameters are
+    the ones before that iteration (here: three clean iterations, then a NaN in the 3-D pose targets)."""
+    m, _ = _tiny_v2()
+    m.use_graphs = graphs
+    torch.manual_seed(3)
+    clean = m.warmup(3)
+    assert len(clean) == 3 and all(np.isfinite(clean))
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m.engine.hmr_theta[:] = float('nan')
+    with pytest.raises(FloatingPointError):
+        m.warmup(4)
+    for k, v in m.state_dict().items():
+        assert torch.isfinite(v).all(), k
+        assert torch.equal(v, before[k]), k
+
+
 @pytest.mark.parametrize('version', [2, 3])
 def test_padded_launch_equals_the_unpadded_step(version):
     """A minibatch launched with masked padding rows (what a rank of a sharded run does with its share of a random
