@@ -808,76 +808,56 @@ class FitEngine:
             ctx._betas_version = self.betas._version
 
     def vposer_mulv(self, w, N):
-        """The encoder's (mu | logvar) product alone (forward_vposer(compose=True) leaves it to the caller's KL stream)."""
+        """The encoder's (mu | logvar) product: only the KL term reads it, so it runs on the KL stream (the decoder starts
+        from the encoder's hidden activation, forward_vposer)."""
         vp = self.vp
         if self.b16mem:
             self.gemm16(N, 64, 512, w['E1b'], self.vpb['emw'], dptr(w['MULV']), 64, bias=dptr(vp['emb']), Cb=w['MULVb'])
         else:
             self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
 
-    def forward_vposer(self, w, N, dec_aa=True, compose=False):
-        """K9: encode(mean) -> decode -> axis-angle.  Returns the event recorded once the encoder output (mu | logvar)
-        exists: the KL term and its backward (vposer_kl / backward_vposer_kl) run from there on another stream.
-        ``compose``: the decoder starts from the encoder's hidden activation through the composed first layer (fold_vposer:
-        d0mw) and the (mu | logvar) product is NOT launched here -- only the KL term reads it, so the caller runs it on the
-        KL stream (vposer_mulv) behind the event this call then returns (hidden activation ready): the product leaves the
-        chain the mesh kernel waits for."""
-        L, st, vp = self.lib, _stream(), self.vp
+    def forward_vposer(self, w, N):
+        """K9: encode -> decode(mean) (vposer_model.py:100-113, :3569).  The decoder's first layer is composed with the mean head
+        (fold_vposer: d0mw), so the decoder chain starts from the encoder's hidden activation E1 and the (mu | logvar)
+        product leaves the chain the mesh kernel waits for (vposer_mulv, on the KL stream).  Returns the event recorded once
+        E1 exists.  The decoder's 6-D output D3 becomes axis-angle inside forward_v2v_pre's launch for the first mesh chunk
+        and here (nemo_rot6d_fwd) for the samples behind it."""
+        st, vp = _stream(), self.vp
         aa63 = w['AA'].data_ptr() + 4 * 3
         cur = torch.cuda.current_stream()
         if self.b16mem:
             vb = self.vpb
             self._cast(N, 63, aa63, 72, w['AAb'], 0)
             self.gemm16(N, 512, 63, w['AAb'], vb['e2w'], dptr(w['E1']), 512, bias=dptr(vp['e2b']), act=2, Cb=w['E1b'])
-            if compose:
-                enc_done = cur.record_event()
-                self.gemm16(N, 512, 512, w['E1b'], vb['d0mw'], dptr(w['D1']), 512, bias=dptr(vp['d0mb']), act=2, Cb=w['D1b'])
-            else:
-                self.gemm16(N, 64, 512, w['E1b'], vb['emw'], dptr(w['MULV']), 64, bias=dptr(vp['emb']), Cb=w['MULVb'])
-                enc_done = cur.record_event()
-                self.gemm16(N, 512, 32, w['MULVb'], vb['d0w'], dptr(w['D1']), 512, bias=dptr(vp['d0b']), act=2, Cb=w['D1b'])
+            enc_done = cur.record_event()
+            self.gemm16(N, 512, 512, w['E1b'], vb['d0mw'], dptr(w['D1']), 512, bias=dptr(vp['d0mb']), act=2, Cb=w['D1b'])
             self.gemm16(N, 512, 512, w['D1b'], vb['d3w'], dptr(w['D2']), 512, bias=dptr(vp['d3b']), act=2, Cb=w['D2b'])
             self.gemm16(N, 126, 512, w['D2b'], vb['d5w'], dptr(w['D3']), 126, bias=dptr(vp['d5b']))
-            self._dec_aa(w, N, 0 if dec_aa else min(w['Nc'], N))
-            return enc_done
-        self._linear(N, aa63, 72, 63, dptr(vp['e2w_p']), dptr(vp['e2b']), 512, dptr(w['E1']), 512, act=2, ldw=64)
-        if compose:
+        else:
+            self._linear(N, aa63, 72, 63, dptr(vp['e2w_p']), dptr(vp['e2b']), 512, dptr(w['E1']), 512, act=2, ldw=64)
             enc_done = cur.record_event()
             self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['d0mw']), dptr(vp['d0mb']), 512, dptr(w['D1']), 512, act=2)
-        else:
-            self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
-            enc_done = cur.record_event()
-            self._linear(N, dptr(w['MULV']), 64, 32, dptr(vp['d0w']), dptr(vp['d0b']), 512, dptr(w['D1']), 512,
-                         act=2)
-        self._linear(N, dptr(w['D1']), 512, 512, dptr(vp['d3w']), dptr(vp['d3b']), 512, dptr(w['D2']), 512,
-                     act=2)
-        self._linear(N, dptr(w['D2']), 512, 512, dptr(vp['d5w']), dptr(vp['d5b']), 126, dptr(w['D3']), 126)
-        self._dec_aa(w, N, 0 if dec_aa else min(w['Nc'], N))
-        return enc_done
-
-    def _dec_aa(self, w, N, first):
-        """Axis-angle form of the decoder output for samples [first, N) (vposer_model.py:100-113).  first > 0: the first
-        `first` samples are converted inside nemo_v2v_prep_fwd_dec (forward_v2v_pre(fused_dec=True))."""
+            self._linear(N, dptr(w['D1']), 512, 512, dptr(vp['d3w']), dptr(vp['d3b']), 512, dptr(w['D2']), 512, act=2)
+            self._linear(N, dptr(w['D2']), 512, 512, dptr(vp['d5w']), dptr(vp['d5b']), 126, dptr(w['D3']), 126)
+        first = min(w['Nc'], N)
         if first < N:
             check(self.lib.nemo_rot6d_fwd(N - first, 21, w['D3'].data_ptr() + 4 * first * 126, 126, 0, None,
-                                          w['AAdec'].data_ptr() + 4 * first * 63, _stream()), 'nemo_rot6d_fwd')
+                                          w['AAdec'].data_ptr() + 4 * first * 63, st), 'nemo_rot6d_fwd')
+        return enc_done
 
     def vposer_kl(self, w, N):
         """K12: KL( N(mu, softplus(logvar)) || N(0, 1) ) and its gradient w.r.t. (mu | logvar)."""
         check(self.lib.nemo_kl_fwd_bwd(N, 32, dptr(w['MULV']), 64, self.scal.data_ptr() + 4 * S_KL,
                                        dptr(w['dMULV']), 64, self.nvalid, _stream()), 'nemo_kl_fwd_bwd')
 
-    def forward_v2v_pre(self, w, N, fused_dec=False):
-        """The part of forward_v2v's first chunk that only needs the poses: both bodies' rotations (v2v_prep) and their
-        FK.  The step runs it at the end of the VPoser stream, off the main chain (``forward_v2v(pre_done=True)``)."""
+    def forward_v2v_pre(self, w, N):
+        """The part of forward_v2v's first chunk that only needs the poses: both bodies' rotations -- incl. the decoder output's
+        6-D -> axis-angle conversion (nemo_v2v_prep_fwd_dec) -- and their FK.  The step runs it at the end of the VPoser
+        stream, off the main chain (``forward_v2v(pre_done=True)``)."""
         L, st, ctx = self.lib, _stream(), self.ctx
         n = min(w['Nc'], N)
-        if fused_dec:        # (the decoder's 6-D output -> axis-angle inside the same launch: forward_vposer(dec_aa=False))
-            check(L.nemo_v2v_prep_fwd_dec(n, dptr(w['R']), dptr(w['AA']), dptr(w['D3']), 126, dptr(w['AAdec']), dptr(w['R2']),
-                                          self.nvalid, st), 'nemo_v2v_prep_fwd_dec')
-        else:
-            check(L.nemo_v2v_prep_fwd(n, dptr(w['R']), dptr(w['AA']), dptr(w['AAdec']), dptr(w['R2']), self.nvalid, st),
-                  'nemo_v2v_prep_fwd')
+        check(L.nemo_v2v_prep_fwd_dec(n, dptr(w['R']), dptr(w['AA']), dptr(w['D3']), 126, dptr(w['AAdec']), dptr(w['R2']),
+                                      self.nvalid, st), 'nemo_v2v_prep_fwd_dec')
         check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']), dptr(w['PF2']), 208, st),
               'nemo_fk_fwd')
 

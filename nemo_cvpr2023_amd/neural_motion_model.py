@@ -612,8 +612,8 @@ class MultiViewModel(nn.Module):
             if use_vposer:
                 # the decoder starts from the encoder's hidden activation (composed first layer); the (mu | logvar) product
                 # runs on side2 in front of the KL term; 6-D -> axis-angle of the decoder output inside v2v_prep
-                enc_done = e.forward_vposer(w, N, dec_aa=False, compose=True)          # always evaluated, :3569
-                e.forward_v2v_pre(w, N, fused_dec=True)   # rotations + FK of both mesh bodies: only the poses are needed
+                enc_done = e.forward_vposer(w, N)          # always evaluated, :3569
+                e.forward_v2v_pre(w, N)   # rotations + FK of both mesh bodies: only the poses are needed
         with torch.cuda.stream(side2):
             st = _stream()
             if use_gmm:

@@ -558,7 +558,8 @@ def test_padded_launch_equals_the_unpadded_step(version):
             assert float((named_a[k].grad - named_b[k].grad).abs().max()) <= 2e-5 * sc + 1e-12, (it, n, k)
         _copy_model_state(b, a)           # (keep the two in lock step: Adam amplifies rounding-level differences)
     keys = [k for w in b.engine.ws.values() for k, g in w['graphs'].items() if isinstance(g, torch.cuda.CUDAGraph)]
-    assert sorted(k[1] for k in keys) == [32, 64], keys      # launch sizes 32 (19, 27, 23, 32, 5 samples) and 64 (40, 45)
+    if os.environ.get('NEMO_GRAPHS', '1') != '0':
+        assert sorted(k[1] for k in keys) == [32, 64], keys      # launch sizes 32 (19, 27, 23, 32, 5 samples) and 64 (40, 45)
     assert b.launch_stats['replayed'] >= 5
 
 
