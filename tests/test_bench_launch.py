@@ -174,7 +174,7 @@ def test_bench_two_ranks_as_the_driver_launches_them(tmp_path):
     assert out['scaling_model']['predicted_ms_per_step_no_overlap'] >= out['scaling_model']['shard_step_ms']
     assert len(out['repeat_ms_per_step']) == 2
     assert out['minibatch512']['steps'] == 6 and out['minibatch512']['value'] > 0
-    assert out['roofline']['kernel'] == 'mesh_v2v_fused' and 0 < out['roofline']['frac'] < 1
+    assert out['roofline']['kernel'] in ('mesh_v2v_fused', 'gemm_pose_blend_bwd') and 0 < out['roofline']['frac'] < 1
     assert out['config']['parallelism'] == 'instance-shard x2'
     assert out['fallback'] == 'none' and [a['status'] for a in out['attempts']] == ['ok']
     assert all(c['agrees_with_single'] for c in out['shard_mode_check'].values())
@@ -185,6 +185,8 @@ def test_bench_two_ranks_fall_back_when_a_capture_kills_a_rank():
     """The driver's launch form with rank 1's worker dying inside its first sharded graph capture (fault injection in
     MultiViewModel._captured): the supervisors restart both workers with NEMO_GRAPH_COMM=0 and the line says so."""
     import socket
+    if os.environ.get('NEMO_GRAPHS', '1') == '0':
+        pytest.skip('NEMO_GRAPHS=0: nothing is captured, so nothing dies in a capture')
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]

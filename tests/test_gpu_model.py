@@ -560,7 +560,7 @@ def test_padded_launch_equals_the_unpadded_step(version):
     keys = [k for w in b.engine.ws.values() for k, g in w['graphs'].items() if isinstance(g, torch.cuda.CUDAGraph)]
     if os.environ.get('NEMO_GRAPHS', '1') != '0':
         assert sorted(k[1] for k in keys) == [32, 64], keys      # launch sizes 32 (19, 27, 23, 32, 5 samples) and 64 (40, 45)
-    assert b.launch_stats['replayed'] >= 5
+    assert b.launch_stats['replayed'] >= (5 if os.environ.get('NEMO_GRAPHS', '1') != '0' else 0)
 
 
 def test_full_batch_properties_at_benchmark_size(tmp_path):
