@@ -501,6 +501,26 @@ def test_smaller_batch_after_a_larger_one_in_a_shared_workspace(mode):
         assert rel_err(named[k].grad, p.grad) < 2e-3, k
 
 
+def test_info_dict_of_a_training_step_is_private_when_the_caller_passed_device_indices():
+    """with device-resident indices (what the unchanged reference script hands over, scripts:291-300) the
+    tensors of a training step's info_dict are private copies, as in the reference -- they survive the next step; with
+    host-drawn indices they are materialised on first access (and equal the eager ones when read in time)."""
+    m, _ = _tiny_v2()
+    gen = torch.Generator().manual_seed(4)
+    draw = lambda: (torch.randint(0, 3, (9,), generator=gen), torch.randint(0, 10, (9,), generator=gen))
+    for _ in range(3):                      # (eager, captured, replayed)
+        vi, fi = draw()
+        _, info = m.step(vi.to(DEV), fi.to(DEV))
+        assert not getattr(info, 'lazy', None), info.lazy
+        kept = {k: info[k].clone() for k in ('loss_all', 'points2d', 'j', 'points2d_gt')}
+        vi2, fi2 = draw()
+        _, info2 = m.step(vi2, fi2)             # host indices: lazy
+        assert set(info2.lazy) == {'loss_all', 'points2d', 'j', 'points2d_gt'}
+        for k, v in kept.items():
+            assert torch.equal(info[k], v), k   # the earlier step's tensors were not overwritten
+        assert info2['j'].shape == kept['j'].shape and not torch.equal(info2['j'], kept['j'])
+
+
 @pytest.mark.parametrize('graphs', [True, False])
 def test_warmup_raises_on_nan_gradients_and_keeps_the_parameters(graphs):
     """:3497-3500 ("nan gradient found" -> ipdb) on the captured warm-up: the NaN-gradient count is a device scalar, the
