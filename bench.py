@@ -115,7 +115,7 @@ def parse(argv=None):
                     help='skip the legs beyond the headline: published_fit, c3_bf16, c4, the scaling model')
     ap.add_argument('--attempt-timeout', type=float, default=1500.0,
                     help='N > 1: wall-clock bound of one attempt of the rank workers before the supervisors fall back')
-    ap.add_argument('--watchdog', type=float, default=420.0,
+    ap.add_argument('--watchdog', type=float, default=300.0,
                     help='N > 1: a worker that makes no progress for this many seconds exits non-zero instead of hanging')
     ap.add_argument('--spawn-selftest', action='store_true',
                     help='test aid: the N ranks only rendezvous (gloo, no GPU) and report ranks_seen')
@@ -262,18 +262,20 @@ class Watchdog:
     would otherwise sit there until the supervisor's bound): `beat()` at every phase boundary."""
 
     def __init__(self, seconds):
-        self.seconds, self.last, self.what = float(seconds), time.monotonic(), 'start'
+        self.seconds, self.last, self.what, self.limit = float(seconds), time.monotonic(), 'start', float(seconds)
         if seconds > 0:
             threading.Thread(target=self._run, daemon=True).start()
 
-    def beat(self, what=''):
+    def beat(self, what='', next_within=None):
+        """A phase boundary has been reached; the NEXT one is due within `next_within` seconds (default: the global bound)."""
         self.last, self.what = time.monotonic(), what
+        self.limit = self.seconds if next_within is None else min(self.seconds, float(next_within))
 
     def _run(self):
         while True:
             time.sleep(2.0)
-            if time.monotonic() - self.last > self.seconds:
-                sys.stderr.write(f'bench.py watchdog: no progress for {self.seconds:.0f} s after "{self.what}"; exiting 17\n')
+            if time.monotonic() - self.last > self.limit:
+                sys.stderr.write(f'bench.py watchdog: no progress for {self.limit:.0f} s after "{self.what}"; exiting 17\n')
                 sys.stderr.flush()
                 os._exit(17)
 
@@ -753,7 +755,9 @@ def worker_main(opts):
         return 0
 
     model, engine, args = build_model(cx, V, T, opts.dtype)
-    cx.wd.beat('model built')
+    # (the first sharded steps hold the one thing no box available to this build has ever run: an RCCL collective between
+    #  two GPUs, captured into a HIP graph -- if they hang, give up on this attempt after two minutes, not seven)
+    cx.wd.beat('model built', next_within=120 if cx.sharded else None)
 
     def step():
         return model.step(None, None, update=True, full_batch=True)
