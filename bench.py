@@ -65,12 +65,19 @@ ATTEMPTS = [('none', {}), ('NEMO_GRAPH_COMM=0', {'NEMO_GRAPH_COMM': '0'}),
             ('NEMO_GRAPHS=0', {'NEMO_GRAPH_COMM': '0', 'NEMO_GRAPHS': '0'})]
 
 
-def step_flops(n, nv=6890, h=1000, din=105):
+# Non-zero skinning weights per vertex of the synthetic SMPL-shaped model.  4 = the structure of the published SMPL model
+# file (at most four joints influence a vertex), which the fused mesh kernel skins sparsely; 24 = a dense weight matrix (the
+# `dense_skinning_weights` leg, and every round-1..3 record).  Both are the same operator (lbs.py:236-241) on different data.
+SKIN_NNZ = 4
+
+
+def step_flops(n, nv=6890, h=1000, din=105, skin_nnz=None):
     """Algorithmic FLOPs of one published-configuration update step as THIS engine formulates it (DESIGN.md
     section 4): fused mesh term (2 pose blends, 2 skinnings, vertex->joint adjoint), blend-shape adjoint, MLP
     forward + activation-gradient + parameter-gradient GEMMs, VPoser encode/decode + KL backward, the
     pre-contracted joint GEMM and its adjoint, GMM prior.  Returns (total, per-part dict)."""
-    mesh = 2.0 * n * nv * (2 * 3 * 207 + 2 * 288 + 288)
+    nnz = SKIN_NNZ if skin_nnz is None else skin_nnz
+    mesh = 2.0 * n * nv * (2 * 3 * 207 + 2 * 12 * (nnz if nnz <= 4 else 24) + 288)
     adj = 2.0 * n * 207 * 3 * nv
     mlp = 3 * 2.0 * (n + 1) * (din * h + 2 * h * h + h * 147)
     vposer = 2.0 * n * (63 * 512 + 512 * 64 + 32 * 512 + 512 * 512 + 512 * 126) + 2.0 * n * (64 * 512 + 512 * 63)
@@ -122,6 +129,8 @@ def parse(argv=None):
     ap.add_argument('--worker', action='store_true', help=argparse.SUPPRESS)      # a supervisor's child: the measuring process
     ap.add_argument('--attempt', default='main0', help=argparse.SUPPRESS)         # rendezvous prefix of this attempt
     ap.add_argument('--phase', choices=['main', 'legs'], default='main', help=argparse.SUPPRESS)
+    ap.add_argument('--skin-nnz', type=int, default=SKIN_NNZ,
+                    help='non-zero skinning weights per vertex of the synthetic body model (4 = as the published SMPL model; 24 = dense)')
     ap.add_argument('--cpu-child', default='', help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -308,9 +317,9 @@ def init_group(dist, backend, rank, world, attempt):
 
 # ----------------------------------------------------------------------------------------------- CPU leg
 def cpu_child(spec):
-    """``--cpu-child name,V,T,B,threads,warmup,steps``: time the CPU oracle (child process, no GPU)."""
-    name, V, T, B, threads, warm, steps, *dev = spec.split(',')
-    V, T, B, threads, warm, steps = int(V), int(T), int(B), int(threads), int(warm), int(steps)
+    """``--cpu-child name,V,T,B,threads,warmup,steps,skin_nnz[,device]``: time the CPU oracle (child process, no GPU)."""
+    name, V, T, B, threads, warm, steps, nnz, *dev = spec.split(',')
+    V, T, B, threads, warm, steps, nnz = int(V), int(T), int(B), int(threads), int(warm), int(steps), int(nnz)
     dev = dev[0] if dev else 'cpu'            # 'cuda': the same unfused step through PyTorch-ROCm (torch_gpu_baseline)
     import torch
     from nemo_cvpr2023_amd import synthetic as syn
@@ -323,7 +332,7 @@ def cpu_child(spec):
         version, args, nv = 2, syn.published_args(batch_size=B if B > 0 else 512, out_dir=''), 6890
     seqs = syn.SyntheticSequences(V, T, seed=1234)
     torch.manual_seed(0)
-    o = OracleNemo(version, args, seqs, syn.make_smpl_assets(nv, seed=1), syn.make_vposer_state(), syn.make_gmm())
+    o = OracleNemo(version, args, seqs, syn.make_smpl_assets(nv, seed=1, skin_nnz=nnz), syn.make_vposer_state(), syn.make_gmm())
     gen = torch.Generator().manual_seed(2)
     sync = (lambda: None) if dev == 'cpu' else torch.cuda.synchronize
     if dev != 'cpu':
@@ -356,7 +365,7 @@ def cpu_baseline(opts):
     thr = min(ncpu, 16)
 
     def run(name, V, T, B, threads, warm, steps, timeout):
-        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-child', f'{name},{V},{T},{B},{threads},{warm},{steps}']
+        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-child', f'{name},{V},{T},{B},{threads},{warm},{steps},{SKIN_NNZ}']
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
@@ -383,14 +392,15 @@ class Ctx:
     pass
 
 
-def build_model(cx, V, T, dtype, batch_size=512):
+def build_model(cx, V, T, dtype, batch_size=512, skin_nnz=None):
     """(model, engine) for a V x T synthetic fit on this worker's device -- ShardedNemo over the ranks when sharded."""
     import torch
     from nemo_cvpr2023_amd import synthetic as syn
     args = syn.published_args(batch_size=batch_size, out_dir='')
     args.gemm_dtype = dtype
     seqs = syn.SyntheticSequences(V, T, seed=1234)
-    assets = dict(smpl_assets=syn.make_smpl_assets(6890, seed=1), vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
+    assets = dict(smpl_assets=syn.make_smpl_assets(6890, seed=1, skin_nnz=SKIN_NNZ if skin_nnz is None else skin_nnz),
+                  vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
     torch.manual_seed(0)
     if cx.sharded:
         from nemo_cvpr2023_amd.dist import ShardedNemo
@@ -468,7 +478,7 @@ def choose_shard_mode(cx, model, step, V, T, want):
     return best, ms, {m_: {'total_loss_after_14_steps': last[m_], 'agrees_with_' + modes[0]: agree[m_]} for m_ in modes}
 
 
-def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype):
+def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nnz=None):
     """The dominant tagged kernel of `timers` against the peak of its own mix of matrix pipes, + the whole step."""
     best = None
     for tag, evs in timers.items():
@@ -483,7 +493,7 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype):
     # of the fused mesh kernel are bf16 work, its skinning / L1 stay on the fp32 pipe.  The peak quoted is the rate at
     # which the kernel's own mix of work would run with both pipes at their peaks (harmonic mix; = the fp32 peak for
     # the fp32 build).
-    f_step, parts = step_flops(V * T // cx.world if cx.world > 1 else V * T)
+    f_step, parts = step_flops(V * T // cx.world if cx.world > 1 else V * T, skin_nnz=skin_nnz)
     pipes = engine.kernel_flops_by_pipe(tag, flops)
     kpeak = flops / sum(f / MFMA_PEAK_TFLOPS[d] for d, f in pipes.items())
     achieved = flops / (mean_ms * 1e-3) / 1e12
@@ -533,12 +543,12 @@ def instrumented(cx, engine, step, n_inst):
     return timers
 
 
-def leg(cx, name, V, T, dtype, steps, warm, shard_mode='single'):
+def leg(cx, name, V, T, dtype, steps, warm, shard_mode='single', skin_nnz=None):
     """A further BASELINE configuration as an extra key of the line: full-batch update steps of a V x T fit, timed like
     the headline (barrier + synchronize, max over ranks), with its own roofline block."""
     import torch
     try:
-        model, engine, _ = build_model(cx, V, T, dtype)
+        model, engine, _ = build_model(cx, V, T, dtype, skin_nnz=skin_nnz)
         if cx.sharded:
             model.set_shard_mode(shard_mode)
 
@@ -555,7 +565,8 @@ def leg(cx, name, V, T, dtype, steps, warm, shard_mode='single'):
                'dtype': dtype, 'samples_per_s': round(V * T * steps / dt, 1),
                'workload': f'{V} instances x {T} frames full batch (N={V * T}), published hyper-parameters, all loss terms',
                'final_total_loss': float(out[0]['total_loss']),
-               'roofline': roofline_block(cx, engine, timers, 2, ms, V, T, dtype)}
+               'skinning': 'sparse' if engine.ctx.skin_sparse else 'dense', 'skin_nnz': engine.ctx.skin_nnz,
+               'roofline': roofline_block(cx, engine, timers, 2, ms, V, T, dtype, skin_nnz=skin_nnz)}
         if cx.sharded:
             res['shard_mode'] = model.shard_mode
             res.update(shard_probe(cx, model, step, steps))
@@ -830,6 +841,11 @@ def worker_main(opts):
             extra['c4'] = leg(cx, 'c4', 256, 1024, 'f32', 3, 2, shard_mode=shard_mode or 'single')
         if world == 1 and not cx.sharded:
             extra['scaling_model'] = scaling_model_single_gpu(cx, ms_per_step, extra['c4'].get('ms_per_step'))
+            if SKIN_NNZ <= 4:
+                # the headline workload with a DENSE skinning-weight matrix (24 non-zero weights per vertex: the synthetic
+                # model of rounds 1-3; the mesh kernel then runs the 24-joint product on the MFMA pipe) -- continuity
+                # with the earlier records, and what a body model without SMPL's sparsity would cost
+                extra['dense_skinning_weights'] = leg(cx, 'dense_skinning_weights', V0, T0, 'f32', 20, 3, skin_nnz=24)
 
     cpu = None
     if rank == 0 and world == 1 and not opts.no_cpu_baseline:
@@ -842,7 +858,7 @@ def worker_main(opts):
         # in a child process: the stock kernels fault on this GPU from ~24 x 300 samples on (32-bit indexing of the
         # (N, 6890, 24, ...) skinning intermediates), and a baseline must never take the bench line down
         n_t = 5
-        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-child', f'c2,{V},{T},-1,0,2,{n_t},cuda']
+        cmd = [sys.executable, os.path.abspath(__file__), '--cpu-child', f'c2,{V},{T},-1,0,2,{n_t},{SKIN_NNZ},cuda']
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             gval = json.loads(r.stdout.strip().splitlines()[-1])['value']
@@ -866,8 +882,10 @@ def worker_main(opts):
             'scaling': 'strong', 'vs_baseline': None, 'dtype': opts.dtype, 'data': 'synthetic',
             'samples_per_s': round(iters_per_s * V * T, 1),
             'config': {'workload': f'Baseball-Pitch-shaped fit, {V} instances x {T} frames full batch (N={V * T}), '
-                                   'NemoV2 published hyper-parameters, all loss terms, 6890-vertex SMPL',
-                       'instances': V, 'frames': T, 'samples_per_step': V * T, 'h_dim': args.h_dim,
+                                   'NemoV2 published hyper-parameters, all loss terms, 6890-vertex SMPL-shaped model with '
+                                   + (f'{SKIN_NNZ} non-zero skinning weights per vertex (the published SMPL model\'s sparsity)'
+                                      if SKIN_NNZ <= 4 else 'a dense skinning-weight matrix'),
+                       'instances': V, 'frames': T, 'samples_per_step': V * T, 'h_dim': args.h_dim, 'skin_nnz': SKIN_NNZ,
                        'parallelism': f'instance-shard x{world}' if world > 1 else
                        ('sharded code path in a process group of ONE rank (diagnostic)' if cx.sharded else 'single GPU')},
             'ranks_seen': ranks_seen,
@@ -896,7 +914,9 @@ def worker_main(opts):
 
 
 def main():
+    global SKIN_NNZ
     opts = parse()
+    SKIN_NNZ = opts.skin_nnz
     if opts.cpu_child:
         return cpu_child(opts.cpu_child)
     if opts.gpus < 1:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 10
+#define NEMO_ABI_VERSION 11
 int32_t nemo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -206,6 +206,14 @@ int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_template, con
 int32_t nemo_ctx_set_betas(nemo_ctx* ctx, const float* betas);
 int32_t nemo_ctx_destroy(nemo_ctx* ctx);
 int64_t nemo_ctx_num_verts(const nemo_ctx* ctx);
+/* Sparse skinning (round 4).  lbs.py:236-241 forms T = W A as a dense (V x 24) x (24 x 16) product; the published SMPL
+ * model has at most four non-zero weights per vertex.  nemo_ctx_skin_nnz: the largest number of non-zero lbs_weights any
+ * vertex has.  When it is <= 4, nemo_v2v_fused(_bf16 / _bf16mem) skins with the non-zero weights only (same sums without the
+ * zero terms); nemo_ctx_set_skin_sparse(ctx, 0) selects the dense product again (EINVAL for enable != 0 when
+ * skin_nnz > 4), nemo_ctx_skin_sparse reports the current choice.  Change it only while no launch is in flight. */
+int32_t nemo_ctx_skin_nnz(const nemo_ctx* ctx);
+int32_t nemo_ctx_skin_sparse(const nemo_ctx* ctx);
+int32_t nemo_ctx_set_skin_sparse(nemo_ctx* ctx, int32_t enable);
 int64_t nemo_ctx_nq(const nemo_ctx* ctx);            /* # non-kinematic output joints            */
 const float* nemo_ctx_C1(const nemo_ctx* ctx);       /* device (207, nq*72) pre-contracted basis   */
 const float* nemo_ctx_c0(const nemo_ctx* ctx);       /* device (nq*72) shape-dependent offset      */

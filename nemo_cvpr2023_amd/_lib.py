@@ -32,7 +32,7 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 10        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 11        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -68,6 +68,9 @@ SIGNATURES = {
     'nemo_ctx_set_betas': (i32, [ptr, ptr]),
     'nemo_ctx_destroy': (i32, [ptr]),
     'nemo_ctx_num_verts': (i64, [ptr]),
+    'nemo_ctx_skin_nnz': (i32, [ptr]),
+    'nemo_ctx_skin_sparse': (i32, [ptr]),
+    'nemo_ctx_set_skin_sparse': (i32, [ptr, i32]),
     'nemo_ctx_nq': (i64, [ptr]),
     'nemo_ctx_C1': (ptr, [ptr]),
     'nemo_ctx_c0': (ptr, [ptr]),

@@ -47,6 +47,14 @@ struct nemo_ctx {
     //          holds W[16 tile + 4 g + t][16 jt + l15] for t = 0..3 TWICE (k = 8 g + t and 8 g + 4 + t: the B-operand
     //          carries the hi pieces of dT in the first four k and the lo pieces in the last four)
     unsigned short *d_Wsk, *d_Wadj;
+    // SPARSE skinning weights (the published SMPL model has at most four non-zero weights per vertex; the dense 24-column
+    // product of lbs.py:236-241 then multiplies 20 zeros per vertex): per vertex (NVp of them, zero rows for the pad) the
+    // <= 4 non-zero weights in ascending joint order, and their joints as four bytes holding 3 * joint (the offset of the
+    // joint's 3 x 4 transform in float4 units).  skin_nnz = the largest number of non-zero weights any vertex has;
+    // the mesh kernel takes its sparse-skinning form when skin_nnz <= 4 and skin_sparse is set (the default then).
+    float* d_Wsp_w;
+    unsigned int* d_Wsp_j;
+    int skin_nnz, skin_sparse;
     // host copies needed to re-derive the shape-dependent constants
     std::vector<float> h_v_template, h_shapedirs, h_Jreg, h_W;
     std::vector<std::vector<std::pair<long, float>>> q_rows;   // sparse rows of the nq functionals
@@ -216,6 +224,28 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
         HIPCHK(hipMalloc((void**)&c->d_Wadj, wadj.size() * 2));
         HIPCHK(hipMemcpy(c->d_Wadj, wadj.data(), wadj.size() * 2, hipMemcpyHostToDevice));
     }
+    {
+        int nnz_max = 0;
+        std::vector<float> sw((size_t)c->NVp * 4, 0.f);
+        std::vector<unsigned int> sj((size_t)c->NVp, 0u);
+        for (long v = 0; v < NV; ++v) {
+            int n = 0;
+            for (int j = 0; j < 24; ++j) {
+                const float w = lbs_weights[v * 24 + j];
+                if (w == 0.f) continue;
+                if (n < 4) { sw[v * 4 + n] = w; sj[v] |= (unsigned)(3 * j) << (8 * n); }
+                ++n;
+            }
+            if (n > nnz_max) nnz_max = n;
+        }
+        c->skin_nnz = nnz_max;
+        c->skin_sparse = nnz_max <= 4;
+        c->d_Wsp_w = nullptr; c->d_Wsp_j = nullptr;
+        HIPCHK(hipMalloc((void**)&c->d_Wsp_w, sw.size() * 4));
+        HIPCHK(hipMemcpy(c->d_Wsp_w, sw.data(), sw.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&c->d_Wsp_j, sj.size() * 4));
+        HIPCHK(hipMemcpy(c->d_Wsp_j, sj.data(), sj.size() * 4, hipMemcpyHostToDevice));
+    }
     if (nq) {
         HIPCHK(hipMemcpy(c->d_C1, C1.data(), sizeof(float) * 207 * nq * 72, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(c->d_w0, w0.data(), sizeof(float) * nq * 24, hipMemcpyHostToDevice));
@@ -234,10 +264,19 @@ extern "C" int32_t nemo_ctx_destroy(nemo_ctx* c) {
     if (c->d_posedirs_bf16) (void)hipFree(c->d_posedirs_bf16);
     if (c->d_Wsk) (void)hipFree(c->d_Wsk);
     if (c->d_Wadj) (void)hipFree(c->d_Wadj);
+    if (c->d_Wsp_w) (void)hipFree(c->d_Wsp_w);
+    if (c->d_Wsp_j) (void)hipFree(c->d_Wsp_j);
     delete c;
     return NEMO_OK;
 }
 extern "C" int64_t nemo_ctx_num_verts(const nemo_ctx* c) { return c ? c->NV : -1; }
+extern "C" int32_t nemo_ctx_skin_nnz(const nemo_ctx* c) { return c ? c->skin_nnz : -1; }
+extern "C" int32_t nemo_ctx_skin_sparse(const nemo_ctx* c) { return c ? c->skin_sparse : -1; }
+extern "C" int32_t nemo_ctx_set_skin_sparse(nemo_ctx* c, int32_t enable) {
+    if (!c || (enable && c->skin_nnz > 4)) return NEMO_EINVAL;
+    c->skin_sparse = enable ? 1 : 0;
+    return NEMO_OK;
+}
 extern "C" int64_t nemo_ctx_nq(const nemo_ctx* c) { return c ? c->nq : -1; }
 extern "C" const float* nemo_ctx_C1(const nemo_ctx* c) { return c ? c->d_C1 : nullptr; }
 extern "C" const float* nemo_ctx_c0(const nemo_ctx* c) { return c ? c->d_c0 : nullptr; }
@@ -1107,26 +1146,72 @@ typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
 #ifndef MESH_PQD
 #define MESH_PQD 3
 #endif
+#define MF_ASP 288      // SPARSE: transforms in LDS as [body][joint][row c][sample 16][4 entries d] -- (joint, row) segments of 256
+                        // bytes, sample-major: a ds_read_b128 whose lanes read 16 bytes at 16 * (lane & 15) of ANY four
+                        // segments (one per 16-lane quarter: the quarters' vertices have different joints) is the access
+                        // the LDS serves at full rate (4 cycles).  A row-per-sample layout (lane stride 1168 B) measured
+                        // 66 LDS cycles per ds_read_b128 -- one lane per cycle, LDS 100 % busy, SQ_LDS_BANK_CONFLICT ~ 0.
+#define MF_TAIL 32      // block-reduction scratch + flags at the end of the dynamic LDS block (floats)
 #define MF_AB 392       // MODE 2: transform row stride in bf16 elements (12 entries x 32 joints + 8: 784 B, the 16 sample
                         // rows of a ds_read_b128 lane group land in 16 different 16-byte bank quads)
-template <int MODE>
+// Sparse skinning of one output row (4 transform entries) for a lane's 4 vertices x 1 sample: T4[d][r] = sum_q w[r][q] *
+// A[joint(r, q)][4 c + d].  Ab = the lane's sample column of row c of joint 0 in LDS (layout: MF_ASP); sj = 3 * joint per
+// byte, i.e. the joint's segment index.  4 RB float4 reads are issued BEFORE their FMAs.
+template <int RB>      // RB = vertices (of the lane's 4) per batch: 4 RB reads in flight
+__device__ __forceinline__ void sparse_rows(const float* Ab, const float4 (&sw)[4], const unsigned int (&sj)[4], f32x4 (&T4)[4]) {
+#pragma unroll
+    for (int h = 0; h < 4 / RB; ++h) {
+        float4 a[RB][4];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                a[rr][q] = *reinterpret_cast<const float4*>(Ab + 64 * ((sj[RB * h + rr] >> (8 * q)) & 0xffu));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int r = RB * h + rr;
+            const float wq[4] = {sw[r].x, sw[r].y, sw[r].z, sw[r].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                T4[0][r] = fmaf(wq[q], a[rr][q].x, T4[0][r]); T4[1][r] = fmaf(wq[q], a[rr][q].y, T4[1][r]);
+                T4[2][r] = fmaf(wq[q], a[rr][q].z, T4[2][r]); T4[3][r] = fmaf(wq[q], a[rr][q].w, T4[3][r]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// SPARSE (round 4): skinning with the <= 4 non-zero weights of a vertex (nemo_ctx::d_Wsp_*) on the VALU -- per (vertex,
+// sample) 4 x 12 FMAs against float4 rows of the joints' transforms in LDS -- instead of the dense 24-joint MFMA product:
+// 144 of the tile's 552 fp32 MFMAs (26 % of its matrix-pipe cycles) are gone, and the VALU work (384 FMAs + 96
+// ds_read_b128 per lane and tile) runs under the other resident wave's MFMAs.  Same sums without the zero terms.
+template <int MODE, bool SPARSE = false>
 __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     long N, long NV, const float* __restrict__ PF2, long ldpf, const float* __restrict__ A2,
     const float* __restrict__ P, long ldP, const float* __restrict__ vs, const float* __restrict__ W,
     int G, int cpg, int RA, int CA, int nB, int vec_stage, float* __restrict__ loss_sum, float* __restrict__ dVPt, long ldn,
     float* __restrict__ dA, float* __restrict__ parts, int* __restrict__ tickets, float* __restrict__ loss_parts,
     int* __restrict__ grid_ticket, unsigned short* __restrict__ dVPb, long ldk,
-    const unsigned short* __restrict__ Wsk, const unsigned short* __restrict__ Wadj) {
+    const unsigned short* __restrict__ Wsk, const unsigned short* __restrict__ Wadj,
+    const float* __restrict__ Wsp_w, const unsigned int* __restrict__ Wsp_j) {
     constexpr bool BF16 = MODE != 0, SPLIT = MODE == 2, ADJS = MODE >= 2;
+    static_assert(!(SPARSE && SPLIT), "sparse skinning replaces the split-precision skinning");
     // All constants are zero-padded by nemo_ctx_create (P: 224 rows x 3*NVp columns, W / v_shaped: NVp
     // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
     // predicate: padded vertices / samples produce v_rec == v_orig == 0, i.e. zero loss and gradient.
-    extern __shared__ float lds[];
+    // The ONLY LDS object of the kernel: dynamic LDS starts where the static objects end, whatever alignment it declares,
+    // and the three small ones this kernel used to have (72 bytes) left every ds_read_b128 below 8-byte aligned --
+    // 64 LDS cycles per instruction instead of 4 (SQ_LDS_UNALIGNED_STALL = 90 % of the LDS-active cycles).  They live
+    // in the last 32 floats of the dynamic block now (MF_TAIL).
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     float* pfL = lds;                                   // [2][16][MF_PFS] floats  (BF16: [2][16][MF_PFB] bf16)
     __bf16* pfB = reinterpret_cast<__bf16*>(lds);
     float* AL = lds + (BF16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS);     // [2][16][MF_AS], entry (e*24 + j)
     __bf16* ALb = reinterpret_cast<__bf16*>(AL);        // MODE 2: [body 2][piece 2][16][MF_AB] bf16, entry (e*32 + j)
-    __shared__ float red[16];
+    float* red = AL + 2 * 16 * (SPARSE ? MF_ASP : MF_AS);                  // MF_TAIL: 16 floats + the two flags
+    int& ticket_old = *reinterpret_cast<int*>(red + 16);
+    int& grid_last = *reinterpret_cast<int*>(red + 17);
     const long ntiles = (NV + 15) / 16;
     // Work = (sample group, chunk of 4 vertex tiles) units, G groups x cpg chunks.  Two classes of blocks, all
     // co-resident (<= 512 = 2 per CU), planned on the host (mesh_plan) so that every block gets the same
@@ -1216,7 +1301,11 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             const int set = idx / 1152, n = (idx / 72) % 16, q = idx % 72;
             const int j = q / 3, e = 4 * (q % 3);                   // a float4 never straddles a joint
             const bool live = s0 + n < N;
-            if constexpr (SPLIT) {
+            if constexpr (SPARSE) {
+                float4 v = va[it];
+                if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(AL + ((set * 72 + q) * 16 + n) * 4) = v;
+            } else if constexpr (SPLIT) {
                 const float x[4] = {va[it].x, va[it].y, va[it].z, va[it].w};
                 __bf16* dh = ALb + ((set * 2 + 0) * 16 + n) * MF_AB + e * 32 + j;
                 __bf16* dl = ALb + ((set * 2 + 1) * 16 + n) * MF_AB + e * 32 + j;
@@ -1245,7 +1334,9 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             const int j = je / 12, e = je % 12;
             const long s = s0 + n;
             const float xv = (s < N) ? A2[(set * N + s) * 288 + je] : 0.f;
-            if constexpr (SPLIT) {
+            if constexpr (SPARSE) {
+                AL[((set * 72 + je / 4) * 16 + n) * 4 + je % 4] = xv;
+            } else if constexpr (SPLIT) {
                 const __bf16 h = (__bf16)xv;
                 ALb[((set * 2 + 0) * 16 + n) * MF_AB + e * 32 + j] = h;
                 ALb[((set * 2 + 1) * 16 + n) * MF_AB + e * 32 + j] = (__bf16)(xv - (float)h);
@@ -1272,8 +1363,8 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             for (int r = 0; r < 4; ++r) accdA[e][t][r] = 0.f;
     const float* pf0 = pfL + (0 * 16 + l15) * MF_PFS + g;      // orig body, this lane's sample column
     const float* pf1 = pfL + (1 * 16 + l15) * MF_PFS + g;      // reconstruction
-    const float* A0 = AL + (0 * 16 + l15) * MF_AS + g;
-    const float* A1 = AL + (1 * 16 + l15) * MF_AS + g;
+    const float* A0 = SPARSE ? AL + 4 * l15 : AL + (0 * 16 + l15) * MF_AS + g;
+    const float* A1 = SPARSE ? AL + 72 * 64 + 4 * l15 : AL + (1 * 16 + l15) * MF_AS + g;
     const __bf16* Ab0 = ALb + ((0 * 2 + 0) * 16 + l15) * MF_AB + 8 * g;   // MODE 2: hi piece; the lo piece is 16 rows on
     const __bf16* Ab1 = ALb + ((1 * 2 + 0) * 16 + l15) * MF_AB + 8 * g;
 
@@ -1313,7 +1404,10 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         // weights as A-operands: forward (rows = vertices, k = joints) and adjoint (rows = joints, k = vertices)
         float wf[6], wa[4][2];
         mbf16x8 wsk[2], wad[2][2];                               // split precision: [piece], [joint tile][piece]
-        if constexpr (SPLIT) {
+        float4 sw[4];                                            // sparse: this lane's 4 vertices x <= 4 (weight, joint)
+        unsigned int sj[4];
+        if constexpr (SPARSE) {
+        } else if constexpr (SPLIT) {
             const long NVp16 = ((NV + 15) / 16) * 16;
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc)
@@ -1323,6 +1417,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk) wf[kk] = Wf[4 * kk];
         }
+        auto load_adjoint_weights = [&]() {
         if constexpr (ADJS) {
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
@@ -1337,6 +1432,11 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 wa[r][1] = l15 < 8 ? Wa[r * 24 + 16] : 0.f;
             }
         }
+        };
+        // (sparse bf16: requested after the reconstruction body -- first used a skinning row + the sign pass later -- so that
+        //  their 16 registers are not live across the blend and the first skinning phase: 18 spilled registers otherwise.
+        //  The fp32 form keeps them at the top of the tile: moved, hipcc spills 270.)
+        if constexpr (!(SPARSE && ADJS)) load_adjoint_weights();
         // ---- pose blend of both bodies: 52 k-steps x 3 components, A-operand P[p][3v+c] from L2
         f32x4 vp[2][3];
         const float* vsl = vs + (v0 + 4 * g) * 3;
@@ -1399,6 +1499,15 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         }
         }
         /*prof:c1*/
+        if constexpr (SPARSE) {
+            // (loaded HERE, after the blend: 20 registers the blend loop's operand ring needs; requesting them four
+            //  k-steps before the end of the blend instead measured the same, 501 against 494 - 502 us)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sw[r] = *reinterpret_cast<const float4*>(Wsp_w + (v0 + 4 * g + r) * 4);
+                sj[r] = Wsp_j[v0 + 4 * g + r];
+            }
+        }
         // ---- reconstruction body, one output row c (4 transform entries) at a time
         float vrec[3][4];
 #pragma unroll
@@ -1408,7 +1517,9 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             for (int d = 0; d < 4; ++d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) T4[d][r] = 0.f;
-            if constexpr (SPLIT) {
+            if constexpr (SPARSE) {
+                sparse_rows<2>(A1 + 64 * c, sw, sj, T4);
+            } else if constexpr (SPLIT) {
                 mbf16x8 bh[4], bl[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
@@ -1434,6 +1545,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
         /*prof:c2*/
+        if constexpr (SPARSE && ADJS) load_adjoint_weights();
         // ---- original body: row c of the transform -> vertex coordinate c -> sign -> its share of dvp and
         // the four dT entries (c, 0..3), which go straight into the vertex->joint MFMA as B-operands
         float dvp[3][4];
@@ -1449,7 +1561,9 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             for (int d = 0; d < 4; ++d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) T4[d][r] = 0.f;
-            if constexpr (SPLIT) {
+            if constexpr (SPARSE) {
+                sparse_rows<1>(A0 + 64 * c, sw, sj, T4);
+            } else if constexpr (SPLIT) {
                 mbf16x8 bh[4], bl[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
@@ -1599,7 +1713,6 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     // same-address fp32 atomics this used to cost (44 us at N = 2400, 95 us at N = 300).  All four waves of
     // the last arriver share the summation (wave w takes ranges w, w+4, ...: with 26 ranges per group at a
     // one-instance shard a single wave spent ~35 us on 26 dependent memory round trips).
-    __shared__ int ticket_old;
     // dA == NULL: DEFERRED combine -- every block leaves its partial image in the scratch and is done; nemo_v2v_combine
     // (a launch of its own, which the caller can run beside the blend-shape adjoint GEMM: nothing before the FK adjoint
     // needs dA) sums them.  Otherwise the group's last-arriving block does, below.
@@ -1678,7 +1791,6 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     // chunked batch are stream-ordered: the reported loss is bit-reproducible run to run and does not lose digits
     // at N = 262 144 (16 k fp32 atomics onto a 1e9 running sum used to cost 1e-4 relative).
     const float tot = block_sum(lsum, red);
-    __shared__ int grid_last;
     if (threadIdx.x == 0) {
         __hip_atomic_store(loss_parts + blockIdx.x, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2048,12 +2160,14 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const f
     // 3.55 against 3.25 ms per C3 step) and MODE 2 (split-precision skinning as well: slower, 475 against ~300 us per
     // launch) were measured in round 3 (profiles/r03_experiments.md sections 10, 13) and are no longer instantiated.
     const int mode = bf16 ? 3 : 0;
-    const int lds_bytes = ((bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * MF_AS) * (int)sizeof(float);
-    static bool attr_set[4] = {false, false, false, false};
-    if (!attr_set[mode]) {
-        const void* fn = mode == 3 ? (const void*)mesh_v2v_fused_kernel<3> : (const void*)mesh_v2v_fused_kernel<0>;
+    const bool sparse = ctx->skin_sparse != 0;
+    const int lds_bytes = ((bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * (sparse ? MF_ASP : MF_AS) + MF_TAIL) * (int)sizeof(float);
+    static bool attr_set[4][2] = {{false, false}, {false, false}, {false, false}, {false, false}};
+    if (!attr_set[mode][sparse]) {
+        const void* fn = mode == 3 ? (sparse ? (const void*)mesh_v2v_fused_kernel<3, true> : (const void*)mesh_v2v_fused_kernel<3, false>)
+                                   : (sparse ? (const void*)mesh_v2v_fused_kernel<0, true> : (const void*)mesh_v2v_fused_kernel<0, false>);
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set[mode] = true;
+        attr_set[mode][sparse] = true;
     }
     const int vec_stage = (ldpf % 4 == 0) && (((uintptr_t)PF2 | (uintptr_t)A2) & 15) == 0 && ldpf >= 208;
     const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
@@ -2069,12 +2183,14 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const f
     float* loss_parts = reinterpret_cast<float*>(wsb + 16);
     int* tickets = reinterpret_cast<int*>(wsb + 16 + MESH_MAX_BLOCKS * 4);
     float* parts = reinterpret_cast<float*>(wsb + MESH_HEADER_BYTES);
-#define MESH_LAUNCH(M, PP, LDP) hipLaunchKernelGGL(mesh_v2v_fused_kernel<M>, dim3((unsigned)blocks), dim3(256), lds_bytes, \
+#define MESH_LAUNCH(M, SP, PP, LDP) hipLaunchKernelGGL((mesh_v2v_fused_kernel<M, SP>), dim3((unsigned)blocks), dim3(256), lds_bytes, \
         (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, PP, LDP, ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA,  \
         pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets, loss_parts, grid_ticket, dVPb, (long)ldk,    \
-        ctx->d_Wsk, ctx->d_Wadj)
-    if (mode == 3) MESH_LAUNCH(3, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
-    else MESH_LAUNCH(0, ctx->d_posedirs, ctx->ldP);
+        ctx->d_Wsk, ctx->d_Wadj, ctx->d_Wsp_w, ctx->d_Wsp_j)
+    if (mode == 3 && sparse) MESH_LAUNCH(3, true, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
+    else if (mode == 3) MESH_LAUNCH(3, false, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
+    else if (sparse) MESH_LAUNCH(0, true, ctx->d_posedirs, ctx->ldP);
+    else MESH_LAUNCH(0, false, ctx->d_posedirs, ctx->ldP);
 #undef MESH_LAUNCH
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;

@@ -70,6 +70,18 @@ class SmplContext:
         self.NVp = self.ldP // 3
         self.v_shaped = self.lib.nemo_ctx_v_shaped(h)
         self._betas = np.zeros(10, dtype=np.float32)
+        # the largest number of non-zero skinning weights of any vertex (4 for the published SMPL model): at <= 4 the
+        # fused mesh kernel skins with the non-zero weights only
+        self.skin_nnz = int(self.lib.nemo_ctx_skin_nnz(h))
+
+    @property
+    def skin_sparse(self):
+        return bool(self.lib.nemo_ctx_skin_sparse(self.handle))
+
+    def set_skin_sparse(self, enable):
+        """Dense 24-joint skinning product (False) or the non-zero weights only (True; needs skin_nnz <= 4)."""
+        torch.cuda.synchronize()
+        check(self.lib.nemo_ctx_set_skin_sparse(self.handle, int(bool(enable))), 'nemo_ctx_set_skin_sparse')
 
     def set_betas(self, betas):
         b = np.ascontiguousarray(np.asarray(betas, dtype=np.float32).reshape(-1)[:10])
@@ -452,9 +464,16 @@ class FitEngine:
             # (csrc/smpl.hip MODE 3: the vertex->joint adjoint -- 288 of the multiply-adds -- runs on the bf16 pipe too, as
             #  four bf16 piece products per algorithmic product)
             on16 = 2 * 3 * 207 + 288
-            b16 = flops * on16 / (2 * 3 * 207 + 2 * 288 + 288)
+            b16 = flops * on16 / self.mesh_macs()
             return {'bf16': b16, 'f32': flops - b16}
         return {'bf16': flops}
+
+    def mesh_macs(self):
+        """Multiply-adds of the fused mesh kernel per (vertex, sample): two pose blends (3 x 207 each), two skinnings and
+        the vertex->joint adjoint (24 x 12).  A skinning is 24 x 12 as the dense product of lbs.py:236-241, or
+        skin_nnz x 12 on the VALU when the model's weights are sparse (<= 4 non-zero per vertex: csrc/smpl.hip SPARSE)."""
+        skin = 12 * (4 if self.ctx.skin_sparse else 24)
+        return 2 * 3 * 207 + 2 * skin + 288
 
     # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
     # recorded on the stream the kernels are launched on (torch's current stream).
@@ -877,7 +896,7 @@ class FitEngine:
                 check(L.nemo_v2v_prep_fwd(n, R, AA, AAd, dptr(w['R2']), self.nvalid if c0 == 0 else None, st), 'nemo_v2v_prep_fwd')
                 check(L.nemo_fk_fwd(ctx.handle, 2 * n, dptr(w['R2']), dptr(w['A2']), dptr(w['Jp2']),
                                     dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
-            ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * (2 * 3 * 207 + 2 * 288 + 288))
+            ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * self.mesh_macs())
             ws = w['mesh_ws']
             fused = L.nemo_v2v_fused_bf16 if self.bf16 else L.nemo_v2v_fused
             # single-chunk batches: the per-group sum of the blocks' partial dA images runs as a launch of its own on the

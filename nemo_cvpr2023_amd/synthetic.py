@@ -41,8 +41,13 @@ def _row_normalised(gen, rows, cols, power):
     return (w / w.sum(1, keepdim=True)).float()
 
 
-def make_smpl_assets(num_verts: int = 6890, seed: int = 1) -> dict:
-    """SMPL-shaped random model.  Keys mirror the buffers smplx.SMPL registers."""
+def make_smpl_assets(num_verts: int = 6890, seed: int = 1, skin_nnz: int = 24) -> dict:
+    """SMPL-shaped random model.  Keys mirror the buffers smplx.SMPL registers.
+
+    ``skin_nnz``: non-zero skinning weights per vertex.  24 (every joint; what the committed golden fixtures were
+    generated with) or fewer: the published SMPL model file has at most FOUR non-zero ``weights`` per vertex (Loper et
+    al. 2015, sec. 3: the blend weights are kept sparse for compatibility with rendering engines), which is what
+    ``skin_nnz=4`` reproduces -- each vertex keeps its ``skin_nnz`` largest random weights, renormalised."""
     g = torch.Generator().manual_seed(seed)
     nv = num_verts
     a = {}
@@ -52,6 +57,11 @@ def make_smpl_assets(num_verts: int = 6890, seed: int = 1) -> dict:
     a['J_regressor'] = _row_normalised(g, 24, nv, 8)
     a['J_regressor_extra'] = _row_normalised(g, NUM_EXTRA_ROWS, nv, 8)
     a['lbs_weights'] = _row_normalised(g, nv, 24, 6)
+    if skin_nnz < 24:
+        w = a['lbs_weights'].double()
+        keep = torch.zeros_like(w).scatter_(1, w.topk(int(skin_nnz), dim=1).indices, 1.0)
+        w = w * keep
+        a['lbs_weights'] = (w / w.sum(1, keepdim=True)).float()
     a['parents'] = torch.tensor(SMPL_PARENTS, dtype=torch.long)
     a['extra_vids'] = torch.randint(0, nv, (NUM_SELECTOR_VERTS,), generator=g)
     a['joint_map'] = torch.tensor(JOINT_MAP_49, dtype=torch.long)

@@ -142,15 +142,17 @@ def test_unknown_gemm_dtype_is_rejected():
                vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
 
 
-def test_c3_bf16_step_vs_fp32_oracle():
+@pytest.mark.parametrize('skin_nnz', [4, 24])
+def test_c3_bf16_step_vs_fp32_oracle(skin_nnz):
     """BASELINE configs[2] at its real size: 40 instances x 300 frames, h = 1000, 6890 vertices, every loss term,
-    gemm_dtype = 'bf16'.  Rows of ~300 samples against the fp32 oracle (bf16 tolerance), the full-batch losses against
+    gemm_dtype = 'bf16'; the body model with SMPL's 4 non-zero skinning weights per vertex (sparse-skinning mesh kernel) and
+    with a dense weight matrix.  Rows of ~300 samples against the fp32 oracle (bf16 tolerance), the full-batch losses against
     the fp32 HIP path from the same state, MLP gradients, and three descending update steps."""
     from nemo_cvpr2023_amd.neural_motion_model import NemoV2
     from oracle.model import OracleNemo
     V, T = 40, 300
     seqs = syn.SyntheticSequences(V, T, seed=1234)
-    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1, skin_nnz=skin_nnz), syn.make_vposer_state(), syn.make_gmm()
     models = {}
     for dt in ('f32', 'bf16'):
         args = syn.published_args(batch_size=512, out_dir='')

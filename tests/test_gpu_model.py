@@ -241,9 +241,11 @@ def test_published_config_step_vs_oracle(tmp_path):
         assert rel_err(ld_h[k], ld_o[k]) < 1e-4, k
 
 
-@pytest.mark.parametrize('version', [2, 3, 4])
-def test_benchmark_config_full_batch_step_vs_oracle(version):
-    """THE benchmark workload (8 x 300 full batch, N = 2400, h = 1000, RBF 100, 6890 vertices, every loss term) --
+@pytest.mark.parametrize('version,skin_nnz', [(2, 4), (2, 24), (3, 24), (4, 4)])
+def test_benchmark_config_full_batch_step_vs_oracle(version, skin_nnz):
+    """THE benchmark workload (8 x 300 full batch, N = 2400, h = 1000, RBF 100, 6890 vertices, every loss term; the body
+    model with the published SMPL model's 4 non-zero skinning weights per vertex -- the sparse-skinning mesh kernel -- and
+    with a dense weight matrix) --
     and the same sizes for NemoV3 / NemoV4 with their extra terms on: one update step and one evaluation step
     against the CPU oracle from the same state.  At this size the mesh kernel runs its 3-range + left-over-block
     grid (150 sample groups) and the hidden-layer GEMMs their whole-tiles + split-tail schedule."""
@@ -254,9 +256,10 @@ def test_benchmark_config_full_batch_step_vs_oracle(version):
     if version >= 3:
         args.weight_instance_loss, args.weight_3d_loss = 0.1, 0.5
     seqs = syn.SyntheticSequences(V, T, seed=1234)
-    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1, skin_nnz=skin_nnz), syn.make_vposer_state(), syn.make_gmm()
     torch.manual_seed(0)
     m = NEMO_VERSIONS[version](args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+    assert m.engine.ctx.skin_sparse == (skin_nnz <= 4)
     with torch.no_grad():                      # leave the near-identity regime so that every term is exercised
         m.learned_motion.rot_out.weight.mul_(2e3)
     o = OracleNemo(version, args, seqs, assets, vps, gmm,

@@ -8,7 +8,7 @@ def rep(a,b):
     assert a in s, a[:50]
     s=s.replace(a,b,1)
 RC='__builtin_readcyclecounter()'
-rep("template <int MODE>\n__global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(","__device__ unsigned long long mesh_prof[8 * 1024];\ntemplate <int MODE>\n__global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(")
+rep("template <int MODE, bool SPARSE = false>\n__global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(","__device__ unsigned long long mesh_prof[8 * 1024];\ntemplate <int MODE, bool SPARSE = false>\n__global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(")
 rep("/*prof:init*/","unsigned long long pr_blend = 0, pr_rec = 0, pr_orig = 0, pr_tiles = 0, pr_sk = 0, pr_va = 0, pr_ad = 0, pr_st = 0;")
 rep("/*prof:c0*/","unsigned long long c0 = "+RC+";")
 rep("/*prof:c1*/","unsigned long long c1 = "+RC+";")
