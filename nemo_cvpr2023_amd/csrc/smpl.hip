@@ -1156,7 +1156,9 @@ typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
                         // rows of a ds_read_b128 lane group land in 16 different 16-byte bank quads)
 // Sparse skinning of one output row (4 transform entries) for a lane's 4 vertices x 1 sample: T4[d][r] = sum_q w[r][q] *
 // A[joint(r, q)][4 c + d].  Ab = the lane's sample column of row c of joint 0 in LDS (layout: MF_ASP); sj = 3 * joint per
-// byte, i.e. the joint's segment index.  4 RB float4 reads are issued BEFORE their FMAs.
+// byte, i.e. the joint's segment index.  4 RB float4 reads are issued BEFORE their FMAs.  (Scalar v_fmac_f32 on purpose:
+// the same sums as v_pk_fma_f32 pairs measured 555 against 494 us per launch at 8 x 300 -- packed fp32 VALU beside
+// MFMAs is the slower form on this chip, see the Makefile.)
 template <int RB>      // RB = vertices (of the lane's 4) per batch: 4 RB reads in flight
 __device__ __forceinline__ void sparse_rows(const float* Ab, const float4 (&sw)[4], const unsigned int (&sj)[4], f32x4 (&T4)[4]) {
 #pragma unroll
