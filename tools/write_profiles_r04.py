@@ -67,7 +67,7 @@ tot, kern = 0.0, {}
 for l in rows:
     c = [x.strip() for x in l.strip().strip('|').split('|')]
     kern[c[0].strip('`')] = (int(c[1]), float(c[3]), float(c[4]))
-mesh = [v for k, v in kern.items() if k.startswith('mesh_v2v_fused_kernel<0>')][0]
+mesh = [v for k, v in kern.items() if k.startswith('mesh_v2v_fused_kernel<0')][0]
 nsteps = mesh[0]                                        # one mesh launch per step
 for k, (n, f2, w) in kern.items():
     tot += n / float(nsteps) * (f2 + w)
