@@ -392,12 +392,14 @@ class Ctx:
     pass
 
 
-def build_model(cx, V, T, dtype, batch_size=512, skin_nnz=None):
+def build_model(cx, V, T, dtype, batch_size=512, skin_nnz=None, weight_smooth=0.0):
     """(model, engine) for a V x T synthetic fit on this worker's device -- ShardedNemo over the ranks when sharded."""
     import torch
     from nemo_cvpr2023_amd import synthetic as syn
     args = syn.published_args(batch_size=batch_size, out_dir='')
     args.gemm_dtype = dtype
+    if weight_smooth:
+        args.weight_smooth = weight_smooth      # BASELINE configs[4]: the temporal-smoothness term in the loop
     seqs = syn.SyntheticSequences(V, T, seed=1234)
     assets = dict(smpl_assets=syn.make_smpl_assets(6890, seed=1, skin_nnz=SKIN_NNZ if skin_nnz is None else skin_nnz),
                   vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
@@ -543,12 +545,12 @@ def instrumented(cx, engine, step, n_inst):
     return timers
 
 
-def leg(cx, name, V, T, dtype, steps, warm, shard_mode='single', skin_nnz=None):
+def leg(cx, name, V, T, dtype, steps, warm, shard_mode='single', skin_nnz=None, weight_smooth=0.0):
     """A further BASELINE configuration as an extra key of the line: full-batch update steps of a V x T fit, timed like
     the headline (barrier + synchronize, max over ranks), with its own roofline block."""
     import torch
     try:
-        model, engine, _ = build_model(cx, V, T, dtype, skin_nnz=skin_nnz)
+        model, engine, _ = build_model(cx, V, T, dtype, skin_nnz=skin_nnz, weight_smooth=weight_smooth)
         if cx.sharded:
             model.set_shard_mode(shard_mode)
 
@@ -563,8 +565,10 @@ def leg(cx, name, V, T, dtype, steps, warm, shard_mode='single', skin_nnz=None):
         timers = instrumented(cx, engine, step, 2)
         res = {'value': round(steps / dt, 3), 'unit': 'iters/s', 'ms_per_step': round(ms, 3), 'steps': steps, 'warmup': warm,
                'dtype': dtype, 'samples_per_s': round(V * T * steps / dt, 1),
-               'workload': f'{V} instances x {T} frames full batch (N={V * T}), published hyper-parameters, all loss terms',
+               'workload': f'{V} instances x {T} frames full batch (N={V * T}), published hyper-parameters, all loss terms'
+                           + (f' + temporal smoothness of the output joints (weight {weight_smooth:g})' if weight_smooth else ''),
                'final_total_loss': float(out[0]['total_loss']),
+               **({'final_smooth_loss': float(out[0]['smooth_loss'])} if weight_smooth else {}),
                'skinning': 'sparse' if engine.ctx.skin_sparse else 'dense', 'skin_nnz': engine.ctx.skin_nnz,
                'roofline': roofline_block(cx, engine, timers, 2, ms, V, T, dtype, skin_nnz=skin_nnz)}
         if cx.sharded:
@@ -841,6 +845,8 @@ def worker_main(opts):
             extra['c4'] = leg(cx, 'c4', 256, 1024, 'f32', 3, 2, shard_mode=shard_mode or 'single')
         if world == 1 and not cx.sharded:
             extra['scaling_model'] = scaling_model_single_gpu(cx, ms_per_step, extra['c4'].get('ms_per_step'))
+            # BASELINE configs[4] on one GPU: the headline sizes with the temporal-smoothness term in the loop as well
+            extra['c5_smooth'] = leg(cx, 'c5_smooth', V0, T0, 'f32', 20, 3, weight_smooth=1e5)
             if SKIN_NNZ <= 4:
                 # the headline workload with a DENSE skinning-weight matrix (24 non-zero weights per vertex: the synthetic
                 # model of rounds 1-3; the mesh kernel then runs the 24-joint product on the MFMA pipe) -- continuity
