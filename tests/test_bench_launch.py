@@ -69,8 +69,10 @@ def test_bench_rejects_world_size_mismatch():
 def test_step_flops_accounting():
     sys.path.insert(0, ROOT)
     import bench
-    tot, parts = bench.step_flops(2400)
+    tot, parts = bench.step_flops(2400, skin_nnz=24)
     assert abs(parts['mesh'] - 69.649632e9) < 1e6           # the roofline kernel's algorithmic work
+    sparse = bench.step_flops(2400, skin_nnz=4)[1]['mesh']   # 4 non-zero skinning weights per vertex: 2 x 48 of the 2 x 288
+    assert abs(sparse - 2.0 * 2400 * 6890 * (2 * 3 * 207 + 2 * 48 + 288)) < 1e6 and bench.SKIN_NNZ == 4
     assert abs(parts['blend_adjoint'] - 20.54e9) < 0.01e9
     assert 120e9 < tot < 135e9
 
