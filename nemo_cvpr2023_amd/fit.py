@@ -143,7 +143,7 @@ def main(argv=None):
     else:
         seqs = syn.SyntheticSequences(V, T, seed=1234, with_eval=True)
         model = NEMO_VERSIONS[o.model_version](
-            args, seqs, 'cuda:0', smpl_assets=syn.make_smpl_assets(o.num_verts, seed=1),
+            args, seqs, 'cuda:0', smpl_assets=syn.make_smpl_assets(o.num_verts, seed=1, skin_nnz=4),   # (SMPL's skinning sparsity)
             vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
     evaluate = None
     if not o.no_eval:
