@@ -7,7 +7,7 @@ import torch
 
 from conftest import load_golden, rel_err
 from nemo_cvpr2023_amd import synthetic as syn
-from test_oracle_golden import CASES, replay
+from test_oracle_golden import CASES, SKIN_NNZ, replay
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -26,7 +26,7 @@ def build_hip_case(name, num_verts=128, tmp_path=None):
     args = base(**o)
     seqs = syn.SyntheticSequences(V, Tn, seed=1234)
     torch.manual_seed(0)
-    m = NEMO_VERSIONS[version](args, seqs, DEV, smpl_assets=syn.make_smpl_assets(num_verts, seed=1),
+    m = NEMO_VERSIONS[version](args, seqs, DEV, smpl_assets=syn.make_smpl_assets(num_verts, seed=1, skin_nnz=SKIN_NNZ.get(name, 24)),
                                vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
     state = {k[len('init__'):].replace('__', '.'): torch.tensor(v) for k, v in g.items()
              if k.startswith('init__')}
@@ -99,9 +99,13 @@ def test_v1_small_every_recorded_step_from_the_reference_state(tmp_path):
         assert abs(lr / float(g[f'final__opt{i}__lr']) - 1) < 1e-6
 
 
-def test_reference_trajectory_full_mesh(tmp_path):
-    m, g = build_hip_case('v2_6890', num_verts=6890, tmp_path=tmp_path)
-    replay(m, g, 'v2_6890', tol=1e-4, state_tol=2e-2, robust_state=True)
+@pytest.mark.parametrize('name', ['v2_6890', 'v2_6890_sparse4'])
+def test_reference_trajectory_full_mesh(name, tmp_path):
+    """The real reference's recorded steps over the 6890-vertex mesh -- with dense skinning weights and with SMPL's four
+    non-zero weights per vertex, which the HIP mesh kernel skins sparsely."""
+    m, g = build_hip_case(name, num_verts=6890, tmp_path=tmp_path)
+    assert m.engine.ctx.skin_sparse == name.endswith('sparse4')
+    replay(m, g, name, tol=1e-4, state_tol=2e-2, robust_state=True)
 
 
 def _float64_twin(o):

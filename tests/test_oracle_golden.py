@@ -144,7 +144,12 @@ CASES = {
     'v2_loss_rmse_robust': (2, {'loss': 'rmse_robust', 'weight_vp_loss': 0, 'weight_vp_z_loss': 0}, 0),
     'v2_loss_mse_robust_resized': (2, {'loss': 'mse_robust_resized', 'weight_vp_loss': 0,
                                        'weight_vp_z_loss': 0}, 0),
+    # the real reference over a body model with SMPL's skinning sparsity (4 non-zero weights per vertex): what the HIP mesh
+    # kernel skins sparsely (tools/gen_golden.py::run_sparse_cases)
+    'v2_sparse4': (2, {}, 2),
 }
+# non-zero skinning weights per vertex of the synthetic body model a case was recorded with (default: all 24)
+SKIN_NNZ = {'v2_sparse4': 4, 'v2_6890_sparse4': 4}
 
 
 def build_case(name, cls=OracleNemo, num_verts=128, **kw):
@@ -160,8 +165,8 @@ def build_case(name, cls=OracleNemo, num_verts=128, **kw):
     args = base(**o)
     seqs = syn.SyntheticSequences(V, Tn, seed=1234)
     state = {k[len('init__'):].replace('__', '.'): v for k, v in g.items() if k.startswith('init__')}
-    model = cls(version, args, seqs, syn.make_smpl_assets(num_verts, seed=1), syn.make_vposer_state(),
-                syn.make_gmm(), state=state, **kw)
+    model = cls(version, args, seqs, syn.make_smpl_assets(num_verts, seed=1, skin_nnz=SKIN_NNZ.get(name, 24)),
+                syn.make_vposer_state(), syn.make_gmm(), state=state, **kw)
     return model, g, (V, Tn, B)
 
 
@@ -212,7 +217,7 @@ def replay(model, g, name, n_cam_default=None, tol=2e-5, check_state=True, state
             assert rel_err(cl, g['cam_losses']) < 1e-4
         assert rel_err(model.state_dict()['learned_cameras'], g['aftercam__learned_cameras']) < 1e-4
     n_steps = g['batches_view'].shape[0]
-    n_full = 1 if name in ('v2_small', 'v0_small') else 0
+    n_full = 1 if name in ('v2_small', 'v0_small', 'v2_sparse4') else 0
     for s in range(n_steps):
         draw()
         vi, fi = torch.as_tensor(g['batches_view'][s]), torch.as_tensor(g['batches_frame'][s])
@@ -277,12 +282,13 @@ def test_step0_gradients():
             assert rel_err(got, v) < 2e-4 or np.abs(v).max() < 1e-12, name
 
 
-def test_full_mesh_6890_step():
-    model, g, _ = build_case('v2_6890', num_verts=6890)
+@pytest.mark.parametrize('name', ['v2_6890', 'v2_6890_sparse4'])
+def test_full_mesh_6890_step(name):
+    model, g, _ = build_case(name, num_verts=6890)
     # Adam divides by sqrt(v)+eps: entries whose gradient is a near-cancelling 20670-term sum
     # of magnitude ~eps amplify summation-order noise, so post-update weights are compared
     # loosely; the loss trajectory (the parity gate) is compared at 2e-5.
-    replay(model, g, 'v2_6890', state_tol=2e-2)
+    replay(model, g, name, state_tol=2e-2)
 
 
 # ------------------------------------------------------------------------------------------ next rows (8f)

@@ -583,7 +583,7 @@ def run_loader_case(name='loader_mocap'):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-6890', action='store_true')
-    ap.add_argument('--only', default='', help='comma list of: script, eval, loader, ckpt (skip everything else)')
+    ap.add_argument('--only', default='', help='comma list of: script, eval, loader, ckpt, sparse (skip everything else)')
     opts = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     scratch = tempfile.mkdtemp(prefix='nemo_golden_')
@@ -606,6 +606,8 @@ def main():
         run_loader_case()
     if not only or 'ckpt' in only:
         run_checkpoint_case(nmm, scratch)
+    if 'sparse' in only:
+        run_sparse_cases(nmm)
     if 'v0' in only:
         run_model_case(nmm, 'v0_small', 0, {'lr_factor': 1}, V=2, T=5, B=6, n_steps=5, n_warm=0, n_cam=2,
                        full_batch_steps=1)
@@ -645,6 +647,17 @@ def main():
         assets_full = syn.make_smpl_assets(6890, seed=1)
         install_synthetic_models(nmm, assets_full)
         run_model_case(nmm, 'v2_6890', 2, {}, V=2, T=4, B=6, n_steps=2, n_warm=0, n_cam=0)
+    run_sparse_cases(nmm, skip_6890=opts.skip_6890)
+
+
+def run_sparse_cases(nmm, skip_6890=False):
+    """The same reference classes over a body model with the published SMPL model's skinning sparsity (4 non-zero weights
+    per vertex, synthetic.make_smpl_assets(skin_nnz=4)): what the HIP mesh kernel skins sparsely (round 4)."""
+    install_synthetic_models(nmm, syn.make_smpl_assets(128, seed=1, skin_nnz=4))
+    run_model_case(nmm, 'v2_sparse4', 2, {}, V=2, T=5, B=6, n_steps=3, n_warm=2, n_cam=2, full_batch_steps=1)
+    if not skip_6890:
+        install_synthetic_models(nmm, syn.make_smpl_assets(6890, seed=1, skin_nnz=4))
+        run_model_case(nmm, 'v2_6890_sparse4', 2, {}, V=2, T=4, B=6, n_steps=2, n_warm=0, n_cam=0)
 
 
 if __name__ == '__main__':
