@@ -10,7 +10,7 @@ if len(sys.argv) > 2:
     args.gemm_dtype = sys.argv[2]
 seqs = syn.SyntheticSequences(V, 300, seed=1234)
 nnz = int(os.environ.get('SKIN_NNZ', '24'))
-m = NemoV2(args, seqs, 'cuda:0', smpl_assets=syn.make_smpl_assets(6890, seed=1, skin_nnz=nnz), vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
+m = NemoV2(args, seqs, 'cuda:0', smpl_assets=syn.make_smpl_assets(int(os.environ.get('NUM_VERTS', '6890')), seed=1, skin_nnz=nnz), vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
 if os.environ.get('SKIN_DENSE'): m.engine.ctx.set_skin_sparse(False)
 for _ in range(6): m.step(None, None, update=True, full_batch=True)
 torch.cuda.synchronize()
