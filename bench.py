@@ -500,7 +500,7 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
     kpeak = flops / sum(f / MFMA_PEAK_TFLOPS[d] for d, f in pipes.items())
     achieved = flops / (mean_ms * 1e-3) / 1e12
     traffic = {}
-    if os.path.exists(TRAFFIC_FILE):
+    if os.path.exists(TRAFFIC_FILE) and skin_nnz in (None, SKIN_NNZ):      # (counters were collected on the default body model)
         traffic = json.load(open(TRAFFIC_FILE)).get(f'{V}x{T}x{cx.world}x{dtype}', {})
     ktr = traffic.get('kernels', {}).get(tag)
     mesh_b16 = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh']).get('bf16', 0.0)
