@@ -542,7 +542,11 @@ static int skinny_kind(bool akc, bool bkc, bool aligned, bool can_split, long M,
     if (!akc && !bkc) {                     // parameter gradients dW = dY^T X
         // (at small K these run beside the input-gradient chain on a second stream: the 64 x 64 configuration's 128 KiB
         //  reduction buffer would keep the other stream's blocks off the CU)
-        if (t64 >= 200 && t64 <= 256 && K >= 1024) return 2;
+        // (tools/debug/dw_bigk.py, 1000 x 1000, us per launch: K = 2401: 61 against 65 for the LDS-staged kernel's K split;
+        //  12 001: 256 / 264; 32 768: 759 / 734; 65 536: 1443 / 1399; 131 072: 2671 / 2634; 262 145 (C4): 5364 / 4924 -- every
+        //  workgroup streams its own two 64-column strips of the operands, 16 x their size in all, and at C4 that is
+        //  33 GB per launch at 6.5 TB/s: HBM-bound; the K-split plan's workgroups of one slice share theirs in L2)
+        if (t64 >= 200 && t64 <= 256 && K >= 1024 && K < 32768) return 2;
         // (the 1000 x 1000 gradients of a two-instance shard, K = 600: 0.642 -> 0.635 ms per step on the 32 x 32
         //  configuration; at K = 300 the LDS-DMA kernel is 3 us ahead)
         use = (t64 <= 192 || (t64 <= 256 && K >= 512)) && K <= 4096;
