@@ -78,6 +78,32 @@ traffic = {'8x300x1xf32': {
               'FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE; the largest kernels of a step)',
     'step_bytes': int(tot * 2 ** 20),
     'kernels': {'mesh_v2v_fused': int((mesh[1] + mesh[2]) * 2 ** 20), 'gemm_pose_blend_bwd': int((adj[1] + adj[2]) * 2 ** 20)}}}
+# the C3 bf16 and C4 legs (tools/profile_r04_traffic_legs.sh), when collected
+legs_txt = ''
+for tag, key, title, cmd in (
+        ('c3b', '40x300x1xbf16', 'C3 (40 x 300) bf16', '--instances 40 --dtype bf16 --steps 3 --warmup 1'),
+        ('c4', '256x1024x1xf32', 'C4 (256 x 1024) fp32', '--instances 256 --frames 1024 --steps 2 --warmup 1')):
+    f = os.path.join(G, f'pmc_traffic_{tag}.md')
+    if not os.path.exists(f):
+        continue
+    lk = {}
+    for l in open(f).read().splitlines():
+        if l.startswith('| `'):
+            c = [x.strip() for x in l.strip().strip('|').split('|')]
+            lk[c[0].strip('`')] = (int(c[1]), float(c[3]), float(c[4]))
+    nst = [v[0] for k, v in lk.items() if k.startswith('adam_kernel')][0]          # one Adam launch per step
+    ltot = sum(n / float(nst) * (f2 + wv) for n, f2, wv in lk.values())
+    lmesh = [v for k, v in lk.items() if k.startswith('mesh_v2v_fused_kernel')][0]
+    traffic[key] = {'source': 'profiles/r04_pmc_traffic_legs.md (tools/profile_r04_traffic_legs.sh: separate FETCH_SIZE / WRITE_SIZE '
+                              'passes of the leg, eager launches; FETCH_SIZE x2 + WRITE_SIZE)',
+                    'step_bytes': int(ltot * 2 ** 20), 'kernels': {'mesh_v2v_fused': int((lmesh[1] + lmesh[2]) * 2 ** 20)}}
+    legs_txt += (f"## {title}: `bench.py {cmd} --repeat 1 --minibatch-steps 0 {B}` under `NEMO_GRAPHS=0`, {nst} steps\n\n"
+                 f"Sum over the kernels of one step: **{ltot:.0f} MiB** (x2-corrected fetch + write; memory-side requests of the L2s: "
+                 "Infinity-Cache hits are counted, so re-reads of an operand that lives in the 256 MB cache show up here without "
+                 f"reaching HBM).\n\n" + open(f).read() + '\n')
+if legs_txt:
+    open(os.path.join(P, 'r04_pmc_traffic_legs.md'), 'w').write(
+        f"# Round 4 (commit {head}) -- HBM-side traffic per kernel of the C3 bf16 and C4 legs (separate --pmc passes)\n\n" + legs_txt)
 json.dump(traffic, open(os.path.join(P, 'traffic.json'), 'w'), indent=1)
 open(os.path.join(P, 'r04_pmc_traffic.md'), 'w').write(
     f"# Round 4 (commit {head}) -- HBM-side traffic per kernel, separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)\n\n"
