@@ -652,6 +652,38 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
             return NEMO_OK;
         }
     }
+    // The same tile for the bf16-in-memory chain: dPF (+)= dVP P^T with both operands bf16 and k-contiguous (gemm_adj.h B16).
+    // K counts bf16 pairs here.
+    if (glds_ok && bf16 == 2 && !transA && transB && N > 128 && N <= 208 && M >= 256 && K >= 1024 && split_k == 0 && C &&
+        out_mode != 2 && force_tile == 0 && can_split && !bias && !act && !mask_mode && !mask16 && !Cb && !CbT && !colsum) {
+        const long tiles_m = (M + 63) / 64;
+        int S = (int)((tiles_m <= 8 ? 256 : 512) / tiles_m);
+        if (S < 1) S = 1;
+        while (S > 1 && ((K + 31) / 32 / S < 8 || COUNTER_BYTES + glds::adj_slab_floats(tiles_m, S) * 4 > ws_bytes ||
+                         glds::adj_counter_ints(tiles_m, S) > COUNTER_BYTES / 4)) --S;
+        if (glds::adj_counter_ints(tiles_m, S) <= COUNTER_BYTES / 4 &&
+            COUNTER_BYTES + glds::adj_slab_floats(tiles_m, S) * 4 <= ws_bytes) {
+            GemmArgs g;
+            g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.mask = nullptr;
+            g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldmask = 0;
+            g.act = 0; g.mask_mode = 0; g.out_mode = out_mode; g.alpha = alpha;
+            g.counters = reinterpret_cast<int*>(ws);
+            g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
+            long kc = (K + S - 1) / S;
+            kc = ((kc + 31) / 32) * 32;
+            g.k_chunk = kc;
+            g.split = (int)((K + kc - 1) / kc);
+            g.tiles_m = (int)tiles_m; g.tiles_n = 1; g.n_tiles = (int)tiles_m; g.t0 = 0;
+            g.a_bytes = a_bytes; g.b_bytes = b_bytes; g.xcd_order = 0;
+            static const bool debug_b16 = getenv("NEMO_GEMM_DEBUG") != nullptr;
+            if (debug_b16)
+                fprintf(stderr, "nemo_gemm_bf16mem M=%ld N=%ld K=%ld (bf16 pairs) -> 64x208 mixed-shape tile, %d K slices\n", (long)M, (long)N, (long)K, g.split);
+            hipError_t e = glds::launch_adj(g, (hipStream_t)stream, true);
+            if (e != hipSuccess) return (int32_t)e;
+            NEMO_LAUNCH_CHECK();
+            return NEMO_OK;
+        }
+    }
     // Skinny problems -- the 64 x 64 grid could not fill the chip without cutting K across blocks (one-instance shards,
     // mini-batches of a few hundred samples): the intra-block K split of gemm_skinny.h, 19 -> 13 us for 300 x 1000 x 1000
     // and ~2x on the small layers (profiles/r02_gemm_skinny.md).  Very long K (the blend-shape adjoint) stays with the

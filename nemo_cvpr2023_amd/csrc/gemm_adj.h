@@ -27,9 +27,16 @@ constexpr int ADJ_BM = 64, ADJ_BN = 208;
 constexpr int ADJ_A_FLOATS = ADJ_BM * BK, ADJ_B_FLOATS = ADJ_BN * BK, ADJ_NA = 3, ADJ_NB = 2;
 constexpr int ADJ_LDS_BYTES = (ADJ_NA * ADJ_A_FLOATS + ADJ_NB * ADJ_B_FLOATS) * 4;
 
-__global__ __launch_bounds__(256, 2) void gemm_adj_kernel(Args g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    using OA = Operand<ADJ_BM, false>;
+// B16 (round 4, last third): the same tile for the bf16-in-memory chain (BASELINE configs[2]) -- dPF (+)= dVP P^T with dVP
+// (samples x K) and P (207 x K) bf16 IN MEMORY, both k-contiguous (nemo_gemm_bf16mem's layout; A / B / lda / ldb / K arrive as
+// the fp32-typed view of the same bytes, i.e. in units of bf16 pairs).  A K tile is 64 bf16 = the same 128-byte rows: A is
+// image K too (8 pieces per tile), columns [0, 192) on v_mfma_f32_32x32x16_bf16 (4 k-steps x 3 per wave and K tile), the
+// 16-column remainder on v_mfma_f32_16x16x32_bf16 (2 per wave and K tile).  The 64 x 64 plan read the 339 MB of d vp four
+// times (once per column tile: 1.36 GB per 8192-sample launch at 5.4 TB/s -- bandwidth-bound) and spent 24 % of its MFMAs on
+// padding.
+template <bool B16>
+__device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
+    using OA = Operand<ADJ_BM, B16>;
     using OB = Operand<ADJ_BN, true>;
     constexpr int GA = OA::PER_WAVE, GB = OB::NI / 4 + 1;        // 2 pieces of A per wave and K tile, 6 or 7 of B
     const int bid = (int)blockIdx.x;
@@ -70,6 +77,41 @@ __global__ __launch_bounds__(256, 2) void gemm_adj_kernel(Args g) {
         const unsigned nbb = sb_byte + (unsigned)(((tb < 0 ? 0 : tb) % ADJ_NB) * ADJ_B_FLOATS * 4);
         const unsigned nab = sa_byte + (unsigned)(((ta < 0 ? 0 : ta) % ADJ_NA) * ADJ_A_FLOATS * 4);
         const long nkb = kbeg + (long)(tb < 0 ? 0 : tb) * BK, nka = kbeg + (long)(ta < 0 ? 0 : ta) * BK;
+        if constexpr (B16) {
+            int piece = 0;
+            auto issue_one = [&]() {
+                if (piece < GB) {
+                    if (tb >= 0 && (piece < GB - 1 || b_extra)) ob.dma_one(nbb, 0, nkb, wid, piece);
+                } else if (piece < GB + GA) {
+                    if (ta >= 0) oa.dma_one(nab, m0, nka, wid, piece - GB);
+                }
+                ++piece;
+            };
+            // the 16 x 16 x 32 operands: lane (row / column lane & 15, k group lane >> 4) holds 8 consecutive k = chunk 4 s2 + kq
+            auto chunk16 = [](const float* tile, int row, int c) {
+                return *reinterpret_cast<const bf16x8*>(tile + row * BK + ((c ^ ((row >> 1) & 7)) << 2));
+            };
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 fa = OA::fetch16(as, row32, ks, lh);
+                bf16x8 fb[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) fb[j] = OB::fetch16(bs, col32 + 32 * j, ks, lh);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
+                    issue_one();                       // one LDS-DMA piece behind every MFMA: B's 6 - 7 first, A's 2 last
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ks & 1) {
+                    const int s2 = ks >> 1;
+                    const bf16x8 ga = chunk16(as, row16, 4 * s2 + lh16), gb = chunk16(bs, col16, 4 * s2 + lh16);
+                    acc16 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, gb, acc16, 0, 0, 0);
+                }
+            }
+            return;
+        }
         float fa[2][4], fb[2][3][4];
         OA::template fetch<8>(as, row32, 0, lh, fa[0]);
 #pragma unroll
@@ -126,7 +168,8 @@ __global__ __launch_bounds__(256, 2) void gemm_adj_kernel(Args g) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const long k0 = kbeg + (long)nfull * BK;
-        oa.dma(sa_byte, m0, k0, wid);                                     // image M: k rows beyond K read zeros
+        if constexpr (B16) oa.fill_tail(sa, g.A, m0, k0, g.M, kend);       // image K: masked through registers
+        else oa.dma(sa_byte, m0, k0, wid);                                 // image M: k rows beyond K read zeros
         ob.fill_tail(sb, g.B, 0, k0, g.N, kend);                           // image K: masked through registers
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -257,15 +300,25 @@ inline long adj_slab_floats(long tiles_m, int split) {
     return tiles_m * (split + (adj_groups(split) > 1 ? adj_groups(split) : 0)) * (long)(ADJ_BM * ADJ_BN);
 }
 
-inline hipError_t launch_adj(const Args& g, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_adj_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, ADJ_LDS_BYTES);
+__global__ __launch_bounds__(256, 2) void gemm_adj_kernel(Args g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_adj_body<false>(g, smem);
+}
+__global__ __launch_bounds__(256, 2) void gemm_adj_b16_kernel(Args g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_adj_body<true>(g, smem);
+}
+
+inline hipError_t launch_adj(const Args& g, hipStream_t s, bool b16 = false) {
+    static bool attr_set[2] = {false, false};
+    const void* fn = b16 ? reinterpret_cast<const void*>(&gemm_adj_b16_kernel) : reinterpret_cast<const void*>(&gemm_adj_kernel);
+    if (!attr_set[b16]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ADJ_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[b16] = true;
     }
-    hipLaunchKernelGGL(gemm_adj_kernel, dim3(g.tiles_m * g.split), dim3(256), ADJ_LDS_BYTES, s, g);
+    if (b16) hipLaunchKernelGGL(gemm_adj_b16_kernel, dim3(g.tiles_m * g.split), dim3(256), ADJ_LDS_BYTES, s, g);
+    else hipLaunchKernelGGL(gemm_adj_kernel, dim3(g.tiles_m * g.split), dim3(256), ADJ_LDS_BYTES, s, g);
     return hipSuccess;
 }
 

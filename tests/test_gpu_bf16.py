@@ -250,6 +250,42 @@ def test_gemm_with_bf16_operands_in_memory(L, M, N, K):
     assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
 
 
+@pytest.mark.parametrize('M,N,K', [(2400, 207, 20670), (8192, 207, 20670), (3808, 207, 20670), (300, 207, 20670), (257, 200, 4098),
+                                   (1000, 130, 2050)])
+def test_blend_shape_adjoint_with_bf16_operands_on_the_mixed_shape_tile(L, M, N, K):
+    """csrc/gemm_adj.h B16 (round 4): the blend-shape adjoint of the bf16-in-memory chain -- dPF (+)= dVP P^T, both operands bf16
+    and k-contiguous, 128 < N <= 208 -- on ONE 64 x 208 column tile per workgroup (32x32x16 bf16 MFMAs for columns [0, 192),
+    16x16x32 for the remainder) with K slices combined in the launch: the fp32-accumulated product of the bf16 operands
+    (2e-5), NaN-poisoned k-pads and row pads that must never be read, accumulate mode, run-to-run bit equality, tickets back
+    at zero."""
+    import hipops as H
+    from nemo_cvpr2023_amd._lib import check, dptr
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    Kp = (K + 7) // 8 * 8 + 8
+    A = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    B = torch.randn(N, K, generator=g).to(DEV).to(torch.bfloat16)
+    Ab = torch.full((M + 5, Kp), 0x7fc0, dtype=torch.int16, device=DEV)      # NaN beyond K and beyond M
+    Bb = torch.full((N + 3, Kp), 0x7fc0, dtype=torch.int16, device=DEV)
+    Ab[:M, :K] = A.view(torch.int16)
+    Bb[:N, :K] = B.view(torch.int16)
+    ref = A.double() @ B.double().T
+    ws = H.gemm_ws()
+
+    def run(C, alpha, mode):
+        check(L.nemo_gemm_bf16mem(M, N, K, dptr(Ab), Kp, dptr(Bb), Kp, dptr(C), 208, None, 0, None, 0, 0, alpha, mode,
+                                  None, 0, None, 0, None, 0, dptr(ws), ws.numel() * 4, H.st()), 'gemm_bf16mem')
+        torch.cuda.synchronize()
+        return C
+    C0 = torch.randn(M, 208, generator=g).to(DEV)
+    C1 = run(C0.clone(), 1.0, 0)
+    assert rel_err(C1[:, :N], ref) < 2e-5
+    assert torch.equal(C1[:, N:], C0[:, N:])                           # columns beyond N untouched
+    assert torch.equal(C1, run(C0.clone(), 1.0, 0))
+    C2 = run(C0.clone(), 0.5, 1)
+    assert rel_err(C2[:, :N], C0[:, :N].double() + 0.5 * ref) < 2e-5
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize('M,N,K', [(301, 1000, 105), (2401, 1000, 105), (130, 70, 33), (77, 200, 64)])
 def test_fp32_product_with_bf16_output_copies(L, M, N, K):
     """nemo_gemm_f32_b16out: the first MotionNet layer of the bf16-in-memory chain -- fp32 operands (rows of 105 floats),
