@@ -8,13 +8,6 @@ st = torch.cuda.current_stream().cuda_stream
 ws = torch.zeros(16 << 20, device='cuda')
 K, Kp = 20670, 20688
 big = torch.empty(512 << 20, device='cuda', dtype=torch.uint8)
-ctx = None
-if os.environ.get('WITH_IMAGE'):
-    from nemo_cvpr2023_amd import synthetic as syn
-    from nemo_cvpr2023_amd.engine import SmplContext
-    assets = syn.make_smpl_assets(6890, seed=1, skin_nnz=4)
-    jm = [int(x) for x in assets['joint_map']]
-    ctx = SmplContext(assets, [jm[i] for i in [38] + list(range(1, 25))], 'cuda:0')
 for M in [int(a) for a in sys.argv[1:]] or [8192]:
     A = torch.randn(M, Kp, device='cuda').to(torch.bfloat16); B = torch.randn(207, Kp, device='cuda').to(torch.bfloat16)
     C = torch.zeros(M, 208, device='cuda')
@@ -28,17 +21,5 @@ for M in [int(a) for a in sys.argv[1:]] or [8192]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3)
-    if ctx is not None:
-        C2 = torch.zeros(M, 208, device='cuda')
-        f2 = lambda: L.nemo_blend_adjoint_bf16(M, K, A.data_ptr(), Kp, ctx.posedirs_adj16, ctx.posedirs_adj16_bytes, C2.data_ptr(), 208, 1.0, 0, ws.data_ptr(), ws.numel() * 4, st)
-        for _ in range(3): assert f2() == 0
-        torch.cuda.synchronize()
-        t2 = []
-        for _ in range(8):
-            big.zero_()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); f2(); e1.record(); torch.cuda.synchronize()
-            t2.append(e0.elapsed_time(e1) * 1e3)
-        print(f'M={M:6d}: image form {sorted(t2)[len(t2) // 2]:7.1f} us per launch (its blend shapes: the synthetic body model)')
     ref = A[:, :K].double() @ B[:, :K].double().T
     print(f'M={M:6d}: {sorted(ts)[len(ts) // 2]:7.1f} us per launch (cold operands) = {2e-6 * M * 207 * K / sorted(ts)[len(ts) // 2]:6.1f} TFLOP/s, err {float((C[:, :207].double() - ref).norm() / ref.norm()):.1e}')
