@@ -28,7 +28,7 @@ def _build(V, T, version=2, **over):
     from nemo_cvpr2023_amd.neural_motion_model import NEMO_VERSIONS
     args = syn.published_args(batch_size=512, out_dir='', **over)
     seqs = syn.SyntheticSequences(V, T, seed=1234)
-    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1), syn.make_vposer_state(), syn.make_gmm()
+    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1, skin_nnz=4), syn.make_vposer_state(), syn.make_gmm()
     torch.manual_seed(0)
     m = NEMO_VERSIONS[version](args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
     with torch.no_grad():                      # leave the near-identity regime so that every term is exercised
