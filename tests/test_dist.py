@@ -556,7 +556,7 @@ def _c5_worker(rank, world, port, q):
     args.weight_smooth = 1e5
     seqs = syn.SyntheticSequences(8, 300, seed=1234)
     m = ShardedNemo(2, args, seqs, 'cuda:0', rank=rank, world=world, seed=0,
-                    smpl_assets=syn.make_smpl_assets(6890, seed=1), vposer_state=syn.make_vposer_state(),
+                    smpl_assets=syn.make_smpl_assets(6890, seed=1, skin_nnz=4), vposer_state=syn.make_vposer_state(),
                     gmm=syn.make_gmm())
     with torch.no_grad():
         m.model.learned_motion.rot_out.weight.mul_(2e3)
@@ -589,7 +589,7 @@ def test_sharded_c5_real_size_equals_single_process():
     seqs = syn.SyntheticSequences(8, 300, seed=1234)
     torch.manual_seed(0)
     state = make_init_state(args, 2, 8, seqs.IMG_D0)
-    m = NemoV2(args, seqs, 'cuda:0', smpl_assets=syn.make_smpl_assets(6890, seed=1),
+    m = NemoV2(args, seqs, 'cuda:0', smpl_assets=syn.make_smpl_assets(6890, seed=1, skin_nnz=4),
                vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
     m.load_state_dict(state, strict=False)
     with torch.no_grad():
