@@ -352,6 +352,7 @@ class FitEngine:
         return self.view(name, self.grads).data_ptr()
 
     # ------------------------------------------------------------------ workspaces
+    B16_DW_ASIDE_ROWS = 10000       # bf16 chain: parameter-gradient products on the side stream up to this many rows
     SMALL_BATCH_ROWS = 1024  # backward_mlp: below this many rows the dW GEMMs run beside the dX chain
     GROUPED_DW_ROWS = 400    # ... and up to this many as ONE grouped launch behind it (a one-instance shard)
     MAX_WORKSPACES = 24      # distinct batch sizes kept alive (a rank of a sharded minibatch run sees many)
@@ -588,37 +589,73 @@ class FitEngine:
             if bucketed:
                 self.flush_colsums()
 
+        # The parameter-gradient products are off the dX chain.  Un-bucketed (single GPU) they go to the side stream, each as
+        # soon as its dY exists, ENQUEUED BEHIND the chain's next product (a replayed graph keeps a node's first successor on its
+        # queue): the bf16 products are bound by LDS-DMA issue and latency, not by the matrix pipe (11 % of its peak), so two of
+        # them side by side overlap -- unlike the fp32 ones (backward_mlp), where co-scheduling measured level.  Same box, ms per
+        # bf16 step beside / in line: 1200 rows 0.600 / 0.659, 2400: 0.792 / 0.866, 4800: 1.298 / 1.364, 7200: 1.726 / 1.849,
+        # 8100: 1.831 / 1.926, 9600: 2.257 / 2.292, 12 000 (C3): 2.68 / 2.63 -> beside up to B16_DW_ASIDE_ROWS.
+        main, side = torch.cuda.current_stream(), self.side_stream
+        aside = (not bucketed) and r <= self.B16_DW_ASIDE_ROWS
+        pend = []
+
+        def ready():
+            return main.record_event() if aside else None
+
+        def dW(ev, fn):
+            if not aside:
+                return fn()
+            pend.append((ev, fn))
+
+        def flush_dW():
+            for ev, fn in pend:
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    fn()
+            del pend[:]
+
         if 0 in stages:
             self._cast(r, nout, dptr(w['dHEAD']), HEAD_LD, w['dHEADb'], 0)
             self._cast(r, nout, dptr(w['dHEAD']), HEAD_LD, w['dHEADbT'], 1)
             # heads
-            self.gemm16(nout, h, r, w['dHEADbT'], w['H3bT'], self.g(lm + 'rot_out.weight'), h, out_mode=1)
+            ev = ready()
+            dW(ev, lambda: self.gemm16(nout, h, r, w['dHEADbT'], w['H3bT'], self.g(lm + 'rot_out.weight'), h, out_mode=1))
             cs.append((dptr(w['dHEAD']), r, nbias, HEAD_LD, self.g(lm + 'rot_out.bias')))
             self.gemm16(r, h, nout, w['dHEADb'], wb['headT'], None, h, mask=dptr(w['H3b']), ldmask=w['H3b'].stride(0),
                         mask_mode=17, Cb=w['dHb'], CbT=w['dHbT'], colsum=w['cs4'])
+            flush_dW()
             # layer 4
-            self.gemm16(h, h, r, w['dHbT'], w['H2bT'], self.g(lm + 'net.net.4.weight'), h, out_mode=1)
+            ev = ready()
+            dW(ev, lambda: self.gemm16(h, h, r, w['dHbT'], w['H2bT'], self.g(lm + 'net.net.4.weight'), h, out_mode=1))
             cs.append((dptr(w['cs4']), R, h, h, self.g(lm + 'net.net.4.bias')))
             self.gemm16(r, h, h, w['dHb'], wb['4T'], None, h, mask=dptr(w['H2b']), ldmask=w['H2b'].stride(0),
                         mask_mode=17, Cb=w['dH_bb'], CbT=w['dH_bbT'], colsum=w['cs2'], tag='gemm_mlp_hidden_dx')
+            flush_dW()
             end_of_stage()
         if 1 in stages:
             # layer 2
-            self.gemm16(h, h, r, w['dH_bbT'], w['H1bT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1)
+            ev = ready()
+            dW(ev, lambda: self.gemm16(h, h, r, w['dH_bbT'], w['H1bT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1))
             cs.append((dptr(w['cs2']), R, h, h, self.g(lm + 'net.net.2.bias')))
             self.gemm16(r, h, h, w['dH_bb'], wb['2T'], dptr(w['dH_c']), h, mask=dptr(w['H1b']), ldmask=w['H1b'].stride(0),
                         mask_mode=17, Cb=None, CbT=None, colsum=w['cs0'])
+            flush_dW()
             end_of_stage()
         if 2 not in stages:
             return
         # layer 0: as before (see _forward_nets_b16)
-        self._linear_bwd_params(r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h, self.g(lm + 'net.net.0.weight'), None)
+        ev = ready()
+        dW(ev, lambda: self._linear_bwd_params(r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h,
+                                               self.g(lm + 'net.net.0.weight'), None))
         cs.append((dptr(w['cs0']), R, h, h, self.g(lm + 'net.net.0.bias')))
         self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din, dptr(w['dX']), self.ldx,
                   dense=True)
         if bucketed:
             self.flush_colsums()
         self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=not bucketed)
+        flush_dW()
+        if aside:
+            main.wait_stream(side)
 
     def gemm_grouped(self, problems, dense=True):
         """problems: list of (ta, tb, M, N, K, A, lda, B, ldb, C, ldc, out_mode) -- independent products of one layout in
