@@ -352,6 +352,7 @@ class FitEngine:
         return self.view(name, self.grads).data_ptr()
 
     # ------------------------------------------------------------------ workspaces
+    DW_ASIDE_ROWS = 65536           # fp32 chain: hidden-layer parameter-gradient products on the side stream up to this many rows
     B16_DW_ASIDE_ROWS = 10000       # bf16 chain: parameter-gradient products on the side stream up to this many rows
     SMALL_BATCH_ROWS = 1024  # backward_mlp: below this many rows the dW GEMMs run beside the dX chain
     GROUPED_DW_ROWS = 400    # ... and up to this many as ONE grouped launch behind it (a one-instance shard)
@@ -592,7 +593,7 @@ class FitEngine:
         # The parameter-gradient products are off the dX chain.  Un-bucketed (single GPU) they go to the side stream, each as
         # soon as its dY exists, ENQUEUED BEHIND the chain's next product (a replayed graph keeps a node's first successor on its
         # queue): the bf16 products are bound by LDS-DMA issue and latency, not by the matrix pipe (11 % of its peak), so two of
-        # them side by side overlap -- unlike the fp32 ones (backward_mlp), where co-scheduling measured level.  Same box, ms per
+        # them side by side overlap well (the fp32 ones do too, less: backward_mlp).  Same box, ms per
         # bf16 step beside / in line: 1200 rows 0.600 / 0.659, 2400: 0.792 / 0.866, 4800: 1.298 / 1.364, 7200: 1.726 / 1.849,
         # 8100: 1.831 / 1.926, 9600: 2.257 / 2.292, 12 000 (C3): 2.68 / 2.63 -> beside up to B16_DW_ASIDE_ROWS.
         main, side = torch.cuda.current_stream(), self.side_stream
@@ -1049,28 +1050,34 @@ class FitEngine:
         nbias = 147 if (has_trans_grad and self.start_global_traj_anywhere) else 144
         if self.b16mem:
             return self._backward_mlp_b16(w, N, view_idx, frame_idx, raw_phase, nout, nbias, tuple(stages), bucketed)
-        # Schedule.  Large batches (each hidden-layer GEMM fills the machine; co-scheduling two of them measured no gain):
-        # the activation-gradient chain (dX) and the parameter-gradient GEMMs (dW) alternate on the main stream up to
-        # layer 2; then one fork: the (small) layer-0 dW GEMM and the batched bias column sums on the side stream, the
-        # layer-0 dX GEMM and the three phase / RBF / code backward kernels that consume it on the main stream.  Small batches (one rank's share at 8 GPUs: a GEMM is ~80 tiles, a third of the CUs): the dW
-        # GEMMs are off the dependency chain, so they ALL go to the side stream, each as soon as its dY exists, and
-        # the chain dX_head -> dX4 -> dX2 -> dX0 -> phase backward runs uninterrupted on the main stream.
+        # Schedule.  The parameter-gradient GEMMs (dW) are off the dependency chain: up to DW_ASIDE_ROWS rows they ALL go to
+        # the side stream, each as soon as its dY exists, and the chain dX_head -> dX4 -> dX2 -> dX0 -> phase backward runs
+        # uninterrupted on the main stream.  Beyond that (C4: every hidden-layer GEMM is thousands of tiles) only the heads'
+        # dW goes beside the chain; dX and the hidden dW alternate on the main stream up to layer 2, then one fork: the (small)
+        # layer-0 dW GEMM and the batched bias column sums on the side stream, the layer-0 dX GEMM and the three phase / RBF /
+        # code backward kernels that consume it on the main stream.
         main, side = torch.cuda.current_stream(), self.side_stream
         cs_in = not bucketed      # bias column sums inside the phase backward's launch
         small = r <= self.SMALL_BATCH_ROWS
+        # Round 4: the parameter-gradient products go beside the dX chain at (nearly) every size of an un-bucketed step -- same
+        # box, ms per step, all of them beside / only the heads' beside / none (the round-2 schedule for > 1024 rows): 2400 rows
+        # 1.386 / 1.380 / 1.405, 12 000: 5.581 / 5.607 / 5.718, 19 200: 8.766 / 8.864 / -, 38 400: 16.98 / 17.07 / -, 262 144 (C4):
+        # 116.5 / 114.1 / 114.2.  Round 2 measured "no gain" for the 1000 x 1000 ones on the kernels of that round.
+        aside = small or (not bucketed and r <= self.DW_ASIDE_ROWS)
 
         # (Enqueue order in small mode: the chain's next GEMM BEFORE the parameter-gradient GEMM that branches off -- a
         #  replayed graph keeps a node's first successor on its hardware queue and pays a 15 - 30 us cross-queue barrier
         #  for the others; that must not be the chain.)
         def dW(ready, *a, **k):
-            if not small:
+            if ready is None:
                 return self._linear_bwd_params(*a, **k)
             side.wait_event(ready)
             with torch.cuda.stream(side):
                 self._linear_bwd_params(*a, **k)
 
-        def dY_ready():
-            return main.record_event() if small else None
+        def dY_ready(heads=False):
+            # (the two small products of the output heads go beside the chain at every size of an un-bucketed step)
+            return main.record_event() if (aside or (heads and not bucketed)) else None
 
         # Round 3: ALL parameter-gradient GEMMs of the backward as ONE grouped launch (nemo_gemm_grouped_f32) on the side
         # stream once the last dY of the dX chain exists, beside the layer-0 dX GEMM and the phase backward on the main
@@ -1122,31 +1129,32 @@ class FitEngine:
                 self.flush_colsums()
 
         if 0 in stages:
-            ev = dY_ready()
-            if not small:
-                dW(None, r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
-                   self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
+            ev = dY_ready(heads=True)
+            a_ = (r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout, self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'))
+            if ev is None:
+                dW(None, *a_, nbias=nbias)
             self.gemm(0, 0, r, h, nout, dptr(w['dHEAD']), HEAD_LD, self.p(lm + 'rot_out.weight'), h,
                       dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1, dense=True)
-            if small:
-                dW(ev, r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout,
-                   self.g(lm + 'rot_out.weight'), self.g(lm + 'rot_out.bias'), nbias=nbias)
+            if ev is not None:
+                dW(ev, *a_, nbias=nbias)
             ev = dY_ready()
-            if not small:
-                dW(None, r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
+            a_ = (r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
+            if ev is None:
+                dW(None, *a_)
             self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
                       mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx', dense=True)
-            if small:
-                dW(ev, r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
+            if ev is not None:
+                dW(ev, *a_)
             end_of_stage()
         if 1 in stages:
             ev = dY_ready()
-            if not small:
-                dW(None, r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+            a_ = (r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+            if ev is None:
+                dW(None, *a_)
             self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
                       mask=dptr(w['H1']), ldmask=h, mask_mode=1, dense=True)
-            if small:
-                dW(ev, r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+            if ev is not None:
+                dW(ev, *a_)
             end_of_stage()
         if 2 not in stages:
             return
