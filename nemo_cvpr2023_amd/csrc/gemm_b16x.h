@@ -39,6 +39,7 @@ namespace b16x {
 using glds::bf16x8;
 using glds::f32x16;
 using glds::i32x4;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct Args {
     const unsigned short* A; const unsigned short* B;       // bf16 bit patterns
@@ -56,27 +57,28 @@ struct Args {
     unsigned a_bytes, b_bytes, mask_bytes;                  // buffer extents
 };
 
-constexpr int BK = 64;                                      // bf16 per K tile: a tile row is 128 B = 8 chunks of 16 B
+constexpr int BK = 32;                                      // bf16 per ring stage: a stage row is 64 B = 4 chunks of 16 B
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NST>
 struct Geo {
     static constexpr int NW = WGM * WGN;
     static_assert(NW == 8, "8 waves");
     static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile in 32 x 32 accumulators");
-    static constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW, G = PA + PB;       // DMA pieces per wave and K tile
-    static_assert(BM % 64 == 0 && BN % 64 == 0, "whole pieces per wave");
-    static constexpr int STAGE = (BM + BN) * 128;                                 // bytes
+    static constexpr int NPA = BM / 16, NPB = BN / 16;                            // 1-KiB DMA pieces (16 rows x 64 B) per stage
+    static constexpr int GW = (NPA + NPB + NW - 1) / NW;                          // pieces per wave and stage (waves whose last
+                                                                                  // piece does not exist issue a dummy: same counts)
+    static constexpr int STAGE = (BM + BN) * 64;                                  // bytes
+    static constexpr int RING = NST * STAGE;
     // epilogue scratch per wave: the larger of the [m][n] image (row stride WN * 2 + 16 B) and the [n][m] image
     // (row stride WM * 2 + 16 B)
     static constexpr int SROW = WN * 2 + 16, TROW = WM * 2 + 16;
     static constexpr int EPI = (WM * SROW > WN * TROW ? WM * SROW : WN * TROW);
-    static constexpr int LDS = (2 * STAGE > NW * EPI ? 2 * STAGE : NW * EPI);
+    static constexpr int LDS = (RING + 1024 > NW * EPI ? RING + 1024 : NW * EPI);  // (+ 1 KiB: where dummy pieces land)
 };
 
 // keep the first `nvalid` (<= 8, may be <= 0) bf16 of an operand fragment
 __device__ __forceinline__ bf16x8 keep_first(bf16x8 v, int nvalid) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 u = __builtin_bit_cast(u32x4, v);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -87,11 +89,14 @@ __device__ __forceinline__ bf16x8 keep_first(bf16x8 v, int nvalid) {
 }
 
 __device__ __forceinline__ unsigned short bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return (unsigned)bf16_bits(lo) | ((unsigned)bf16_bits(hi) << 16); }
 
-template <int BM, int BN, int WGM, int WGN>
+constexpr int OOB = (int)0x80000000u;      // a buffer offset beyond every descriptor of this kernel (extents < 2^31)
+
+template <int BM, int BN, int WGM, int WGN, int NST>
 __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
-    using Q = Geo<BM, BN, WGM, WGN>;
-    constexpr int WM = Q::WM, WN = Q::WN, TM = Q::TM, TN = Q::TN, PA = Q::PA, G = Q::G;
+    using Q = Geo<BM, BN, WGM, WGN, NST>;
+    constexpr int WM = Q::WM, WN = Q::WN, TM = Q::TM, TN = Q::TN, GW = Q::GW, NPA = Q::NPA, NPB = Q::NPB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];          // the ONLY LDS object of the kernel
 
     // ---- block -> (K slice, row tile, column tile).  Block b runs on XCD b % 8 (observed; speed only): give every XCD a
@@ -104,11 +109,12 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
     const long m0 = (long)tm * BM, n0 = (long)tn * BN;
     const long kbeg = (long)slice * g.k_chunk;
     const long kend = g.split > 1 ? min(g.K, kbeg + g.k_chunk) : g.K;
-    const long klen = kend > kbeg ? kend - kbeg : 0;
-    const int nt = (int)((klen + BK - 1) / BK);
+    const int klen = (int)(kend > kbeg ? kend - kbeg : 0);
+    const int nt = (klen + BK - 1) / BK;                    // >= 1: every slice is non-empty by construction
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __builtin_assume(wid >= 0 && wid < 8);
     const int wm = wid / WGN, wn = wid % WGN;
     const int l31 = lane & 31, lh = lane >> 5;
 
@@ -120,86 +126,127 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- LDS-DMA addressing.  Piece u of an operand tile = rows 8 u .. 8 u + 7; this wave issues pieces wid, wid + 8, ...
-    // ((u & 1) == (wid & 1): the piece-dependent swizzle term is a per-wave constant, one lane offset serves them all).
+    // ---- LDS-DMA addressing.  Stage image: [row][4 chunks of 16 B], chunk c of row r at slot c ^ ((r >> 2) & 3): the 16
+    // lanes a ds_read_b128 services together (rows {0-3, 12-15, 20-27} + 4 a of one chunk index) then touch 16 distinct
+    // 16-byte bank quads.  A piece = 16 rows; a piece's lane (row dr = lane >> 2, slot lane & 3) fetches source chunk
+    // (lane & 3) ^ ((dr >> 2) & 3) -- the swizzle does not depend on the piece.  Wave w issues pieces w, w + 8, ... of the
+    // NPA + NPB pieces of a stage (A's first).
     const unsigned smem_byte = (unsigned)reinterpret_cast<unsigned long long>(smem);
     auto rsrc = [](const void* p, unsigned bytes) {
         const unsigned long long b = reinterpret_cast<unsigned long long>(p);
         return i32x4{(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xffffu), (int)bytes, 0x00020000};
     };
     const i32x4 rsA = rsrc(g.A, g.a_bytes), rsB = rsrc(g.B, g.b_bytes);
-    const int dr = lane >> 3;
-    const int dchunk = (lane & 7) ^ ((dr >> 1) | (4 * (wid & 1)));
+    const int dr = lane >> 2;
+    const int dchunk = (lane & 3) ^ ((dr >> 2) & 3);
     const int voffA = (int)((dr * g.lda + 8 * dchunk) * 2), voffB = (int)((dr * g.ldb + 8 * dchunk) * 2);
-    const unsigned rowA = (unsigned)(((m0 + 8 * wid) * g.lda + kbeg) * 2), rowB = (unsigned)(((n0 + 8 * wid) * g.ldb + kbeg) * 2);
-    const unsigned stepA = (unsigned)(64 * g.lda * 2), stepB = (unsigned)(64 * g.ldb * 2);
-    // piece p (0 .. G - 1) of this wave for K tile t into stage (t & 1)
-    auto dma = [&](int p, int t) {
-        const unsigned st = smem_byte + (unsigned)((t & 1) * Q::STAGE);
-        if (p < PA) glds::dma_piece(rsA, st + (unsigned)((wid + 8 * p) * 1024), voffA, rowA + (unsigned)p * stepA + (unsigned)t * (BK * 2));
-        else glds::dma_piece(rsB, st + (unsigned)(BM * 128 + (wid + 8 * (p - PA)) * 1024), voffB,
-                             rowB + (unsigned)(p - PA) * stepB + (unsigned)t * (BK * 2));
-    };
-
-    // ---- operand fetch: row (in the wave's 32-row block) l31, chunk 2 s + lh of k-step s; (row >> 1) & 7 == (l31 >> 1) & 7
-    // because every 32-row block starts at a multiple of 32
-    const int sw = (l31 >> 1) & 7;
-    const unsigned fa0 = (unsigned)((wm * WM + l31) * 128), fb0 = (unsigned)(BM * 128 + (wn * WN + l31) * 128);
-    auto compute = [&](int t, auto tailc, auto issuec) {
-        constexpr bool TAIL = decltype(tailc)::value, ISSUE = decltype(issuec)::value;
-        const unsigned char* st = smem + (t & 1) * Q::STAGE;
-        const int krem = (int)(klen - (long)t * BK);            // (TAIL: < 64)
+    const unsigned baseA = (unsigned)((m0 * g.lda + kbeg) * 2), baseB = (unsigned)((n0 * g.ldb + kbeg) * 2);
+    const unsigned rowsA = (unsigned)(16 * g.lda * 2), rowsB = (unsigned)(16 * g.ldb * 2);
+    // the p-th piece (0 .. GW - 1) of this wave: which operand, where in a stage, from where -- selected once, branch-free
+    // (q = wid + 8 p).  Pieces that do not exist (q >= NPA + NPB) and tiles beyond the slice are requested out of bounds
+    // (nothing is fetched; zeros land in the 1 KiB behind the ring resp. in a stage nobody reads any more): every wave has the
+    // same number of DMAs in flight per tile, which is what the counted vmcnt below relies on.
+    i32x4 prs[GW];
+    unsigned plds[GW], psrc[GW];
+    int pvoff[GW];
+    bool pdummy[GW];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 fa[TM], fb[TN];
-            const unsigned co = (unsigned)(((2 * s + lh) ^ sw) << 4);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(st + fa0 + i * 32 * 128 + co);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(st + fb0 + j * 32 * 128 + co);
-            if constexpr (TAIL) {
-                const int nv = krem - (16 * s + 8 * lh);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = keep_first(fa[i], nv);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = keep_first(fb[j], nv);
-            }
-            if constexpr (ISSUE) {
-                // two pieces of tile t + 1 per k-step, front-loaded: the last piece has at least a quarter of the tile's
-                // MFMAs plus the barrier to land
-#pragma unroll
-                for (int p = 2 * s; p < 2 * s + 2; ++p)
-                    if (p < G) dma(p, t + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    // ---- K loop (nt >= 1: every slice is non-empty by construction).  Tile t lives in stage t & 1.  Iteration t: this
-    // wave's pieces of tile t have landed (vmcnt), barrier (everyone's have; everyone is done reading tile t - 1), tile t + 1
-    // is requested into the stage tile t - 1 occupied while tile t is multiplied.
-    // The loop body exists ONCE (tile t + 1 requested, no masking); the last tile runs behind the loop through the masking
-    // variant whether it is partial or not (a few dozen VALU operations once per block) -- with several variants selected
-    // inside the loop hipcc copies all accumulators between two register sets on every iteration.
-#pragma unroll
-    for (int p = 0; p < G; ++p) dma(p, 0);
-    for (int t = 0; t < nt - 1; ++t) {
-        glds::wait_vmcnt<0>();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        compute(t, std::false_type{}, std::true_type{});
+    for (int p = 0; p < GW; ++p) {
+        const int q = wid + 8 * p;
+        const bool isA = q < NPA;
+        pdummy[p] = q >= NPA + NPB;
+        prs[p] = isA ? rsA : rsB;
+        plds[p] = pdummy[p] ? (unsigned)Q::RING : (isA ? (unsigned)(q * 1024) : (unsigned)(BM * 64 + (q - NPA) * 1024));
+        psrc[p] = isA ? baseA + (unsigned)q * rowsA : baseB + (unsigned)(q - NPA) * rowsB;
+        pvoff[p] = pdummy[p] ? OOB : (isA ? voffA : voffB);
     }
-    glds::wait_vmcnt<0>();
+    // piece p of K tile t into ring stage `stage`
+    auto dma = [&](int p, int t, int stage) {
+        const unsigned st = pdummy[p] ? 0u : (unsigned)(stage * Q::STAGE);
+        glds::dma_piece(prs[p], smem_byte + st + plds[p], t < nt ? pvoff[p] : OOB, psrc[p] + (unsigned)t * (BK * 2));
+    };
+
+    // ---- operand fetch.  k-step s (0 / 1) of a stage, lane half lh: chunk 2 s + lh of row l31 of each 32-row block;
+    // (row >> 2) & 3 == (l31 >> 2) & 3 because every 32-row block starts at a multiple of 32.
+    struct Frag { bf16x8 a[TM], b[TN]; };
+    const int sw = (l31 >> 2) & 3;
+    const unsigned fa0 = (unsigned)((wm * WM + l31) * 64), fb0 = (unsigned)(BM * 64 + (wn * WN + l31) * 64);
+    auto fetch = [&](Frag& f, int stage, int s) {
+        const unsigned char* st = smem + stage * Q::STAGE;
+        const unsigned co = (unsigned)(((2 * s + lh) ^ sw) << 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(st + fa0 + i * 32 * 64 + co);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(st + fb0 + j * 32 * 64 + co);
+    };
+    auto mask_tail = [&](Frag& f, int t, int s) {           // elements at or beyond the end of K
+        const int nv = klen - t * BK - (16 * s + 8 * lh);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.a[i] = keep_first(f.a[i], nv);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) f.b[j] = keep_first(f.b[j], nv);
+    };
+    // the MFMAs of one k-step.  `after_first()` runs behind the FIRST of them: the next fragment reads are issued there, so
+    // that the wait hipcc puts in front of this k-step's first MFMA finds nothing younger outstanding (its scoreboard is
+    // conservative next to the inline-asm DMAs: a wait for these operands placed behind younger reads becomes lgkmcnt(0)
+    // and would stall on those).  `issue_t` >= 0: this wave's pieces of that tile leave one at a time behind the MFMAs
+    // that follow.
+    auto mma = [&](const Frag& f, auto&& after_first, int issue_t, int stage) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+                if (i == 0 && j == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    after_first();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (issue_t >= 0 && i * TN + j >= 1 && i * TN + j - 1 < GW) {
+                    dma(i * TN + j - 1, issue_t, stage);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+    };
+    static_assert(GW < TM * TN, "one piece behind each of GW MFMAs");
+
+    // ---- K loop over a ring of NST stages (tile t in stage t % NST), software-pipelined by one k-step ACROSS the barrier:
+    //   iteration t:  MFMAs of F = (t, k-step 0), G = fragments (t, k-step 1) read behind the first of them;
+    //                 tile t + 1 has landed (counted vmcnt: NST - 2 younger tiles stay in flight), G has arrived (lgkmcnt),
+    //                 s_barrier: tile t + 1 is visible to every wave, nobody reads stage t % NST any more;
+    //                 MFMAs of G, F = fragments (t + 1, k-step 0) read behind the first of them, tile t + NST requested
+    //                 into stage t % NST piece by piece behind the next ones.
+    // After every barrier a wave has MFMAs whose operands are already in registers while its next reads are in flight.
+    // The loop body exists once; the last tile runs behind it through the masking variant whether it is partial or not
+    // (with several variants selected inside the loop hipcc copies all accumulators between two register sets per iteration).
+#pragma unroll
+    for (int t = 0; t < NST; ++t)
+#pragma unroll
+        for (int p = 0; p < GW; ++p) dma(p, t, t);
+    glds::wait_vmcnt<(NST - 1) * GW>();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    compute(nt - 1, std::true_type{}, std::false_type{});
+    Frag F, G;
+    fetch(F, 0, 0);
+    int cur = 0;                                            // stage of tile t
+    for (int t = 0; t < nt - 1; ++t) {
+        mma(F, [&] { fetch(G, cur, 1); }, -1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * GW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int nxt = cur + 1 == NST ? 0 : cur + 1;
+        mma(G, [&] { fetch(F, nxt, 0); }, t + NST, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    fetch(G, cur, 1);
+    mask_tail(F, nt - 1, 0);
+    mask_tail(G, nt - 1, 1);
+    mma(F, [] {}, -1, 0);
+    mma(G, [] {}, -1, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (dummy pieces of the tiles behind the slice)
 
     // ---- split-K: publish the partial tile write-through, take a ticket; the last arriver sums all slices in slice order
     // (deterministic) and runs the epilogue.  Slab layout = the register image: float4 #(i, j, r4) of thread t.
@@ -217,7 +264,7 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
                     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
                 }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();                                    // (also: every wave is done reading the stages)
+        __syncthreads();                                    // (also: every wave is done reading the ring)
         int* flag = reinterpret_cast<int*>(smem);
         if (threadIdx.x == 0)
             *flag = __hip_atomic_fetch_add(g.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -251,100 +298,170 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();                                        // the stages become the epilogue's wave-private scratch
+    __syncthreads();                                        // the ring becomes the epilogue's wave-private scratch
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Everything
+    // per element is branch-free; what depends on the call (mask, edge tiles, which outputs) is decided once per pass.
     unsigned char* const ws = smem + wid * Q::EPI;
     const long mw = m0 + wm * WM, nw0 = n0 + wn * WN;       // first row / column of this wave's tile
     constexpr int SROW = Q::SROW, TROW = Q::TROW;
+    const bool edge = mw + WM > g.M || nw0 + WN > g.N;      // (wave-uniform)
+    const int mrem = (int)min((long)WM, g.M - mw) - 4 * lh; // rows ml = c + 4 lh of the wave's tile are valid while c < mrem
+    auto rowc = [](int i, int r) { return i * 32 + (r & 3) + 8 * (r >> 2); };
+    // one row limit for every pass (interior tiles: no row is beyond it), re-materialised per pass: shared between the
+    // passes, hipcc keeps ~50 compare masks alive in scalar registers and spills them
+    const int mlim_ = edge ? mrem : (1 << 20);
+    auto row_limit = [&]() { int v = mlim_; asm volatile("" : "+v"(v)); return v; };
 
     if (g.mask_mode) {
-        // the wave's WM x WN mask tile as whole 128-byte row segments (16 B per lane, OOB rows read as zero = masked out,
-        // they are never stored) -> LDS image [m][n]
+        // the wave's WM x WN mask tile as whole 128-byte row segments (16 B per lane; OOB rows read as zero = masked out,
+        // they are never stored) -> LDS image [m][n]; four loads in flight
         const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g.mask16), 0, (int)g.mask_bytes, 0x00020000);
-        constexpr int CH = WN / 8;                          // 16-byte chunks per row
-        constexpr int NP = WM * CH / 64;
-        i32x4 mv[NP];
+        constexpr int CH = WN / 8, NP = WM * CH / 64;
+        static_assert(NP % 4 == 0, "mask tile in batches of four loads");
+        const int row0 = lane / CH, ch = lane % CH;         // (64 / CH rows per load)
+        const int moff = (int)(((mw + row0) * g.ldmask16 + nw0 + 8 * ch) * 2);
+        const int mstep = (int)((64 / CH) * g.ldmask16 * 2);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int idx = p * 64 + lane, row = idx / CH, ch = idx % CH;
-            const long off = ((mw + row) * g.ldmask16 + nw0 + 8 * ch) * 2;
-            mv[p] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsM, (int)off, 0, 0));
-        }
+        for (int p0 = 0; p0 < NP; p0 += 4) {
+            i32x4 mv[4];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int idx = p * 64 + lane, row = idx / CH, ch = idx % CH;
-            *reinterpret_cast<i32x4*>(ws + row * SROW + ch * 16) = mv[p];
+            for (int u = 0; u < 4; ++u)
+                mv[u] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsM, moff, (p0 + u) * mstep, 0));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<i32x4*>(ws + (row0 + (p0 + u) * (64 / CH)) * SROW + ch * 16) = mv[u];
         }
+        asm volatile("" ::: "memory");              // (the image is written and read through different types: no reordering across)
     }
 
-    // final values in place of the accumulators (acc[i][j][r] := v)
+    // final values in place of the accumulators
+    const float slope = g.act == 1 ? 0.f : (g.act == 2 ? 0.01f : 1.f);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const long n = nw0 + j * 32 + l31;
         const float bv = (g.bias != nullptr && n < g.N) ? g.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float csum = 0.f;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;        // row inside the wave's tile
-                float v = g.alpha * acc[i][j][r] + bv;
-                if (g.act == 1) v = v > 0.f ? v : 0.f;
-                else if (g.act == 2) v = v > 0.f ? v : 0.01f * v;
-                if (g.mask_mode) {
-                    const unsigned short mb = *reinterpret_cast<const unsigned short*>(ws + ml * SROW + (j * 32 + l31) * 2);
-                    v = ((mb & 0x7fffu) != 0 && !(mb & 0x8000u)) ? v : 0.f;     // bf16 > 0
-                }
-                if (mw + ml >= g.M || n >= g.N) v = 0.f;                        // pads of the bf16 copies stay zero
-                acc[i][j][r] = v;
-                csum += v;
+                const float v = g.alpha * acc[i][j][r] + bv;
+                acc[i][j][r] = v > 0.f ? v : v * slope;
             }
-            if (g.colsum) {
+    }
+    if (g.mask_mode) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const short mb = *reinterpret_cast<const short*>(ws + (rowc(i, r) + 4 * lh) * SROW + (j * 32 + l31) * 2);
+                    acc[i][j][r] = mb > 0 ? acc[i][j][r] : 0.f;                // bf16 > 0  <=>  its bits, as int16, > 0
+                }
+        asm volatile("" ::: "memory");              // (the image is written and read through different types: no reordering across)
+    }
+    if (edge) {                                             // pads of the bf16 copies stay zero; column sums skip them
+        const int mlim = row_limit();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int lim = nw0 + j * 32 + l31 >= g.N ? -1 : mlim;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = rowc(i, r) >= lim ? 0.f : acc[i][j][r];
+        }
+    }
+
+    if (g.colsum) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const long n = nw0 + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float csum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) csum += acc[i][j][r];
                 csum += __shfl_xor(csum, 32, 64);          // lanes l and l + 32: the same column, the other rows of the band
                 const long band = (mw + i * 32) / 32;
                 if (lh == 0 && n < g.N && band < 2 * ((g.M + 63) / 64)) g.colsum[band * g.ldcs + n] = csum;
             }
-            if (g.C) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < g.M && n < g.N) {
-                        float* c = g.C + m * g.ldc + n;
-                        if (g.out_mode == 0) *c = acc[i][j][r];
-                        else *c += acc[i][j][r];
-                    }
-                }
-            }
         }
+    }
+
+    if (g.C) {
+        // through a buffer descriptor: a lane's 32-bit offset, rows / columns beyond the matrix pointed out of bounds
+        const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)(((g.M - 1) * g.ldc + g.N) * 4), 0x00020000);
+        const int ldc4 = (int)(g.ldc * 4);
+        // a lane's four consecutive rows (r & 3) go through the scalar offset (4 values), the row group (i, r >> 2) through the
+        // lane offset (one add each): few scalar registers (one scalar offset per element used to spill ~100 of them)
+        const int so1 = ldc4, so2 = 2 * ldc4, so3 = 3 * ldc4;
+        auto store_c = [&](auto addc) {
+            const int mlim = row_limit();
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const long n = nw0 + j * 32 + l31;
+                const int off0 = n < g.N ? (int)(((mw + 4 * lh) * g.ldc + n) * 4) : OOB;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int base = n < g.N ? off0 + (i * 32 + 8 * q) * ldc4 : OOB;
+                        int off[4];
+                        float v[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            off[c] = i * 32 + 8 * q + c >= mlim ? OOB : base;
+                            v[c] = acc[i][j][4 * q + c];
+                        }
+                        if constexpr (decltype(addc)::value) {
+                            float old[4];
+                            old[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, off[0], 0, 0));
+                            old[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, off[1], so1, 0));
+                            old[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, off[2], so2, 0));
+                            old[3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsC, off[3], so3, 0));
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] += old[c];
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[0]), rsC, off[0], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[1]), rsC, off[1], so1, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[2]), rsC, off[2], so2, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[3]), rsC, off[3], so3, 0);
+                    }
+            }
+        };
+        if (g.out_mode) store_c(std::true_type{}); else store_c(std::false_type{});
     }
 
     if (g.Cb) {
         // [m][n] image: element writes, then whole 128-byte row segments out, 16 B per lane
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the mask reads above are done: same region)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    *reinterpret_cast<unsigned short*>(ws + ml * SROW + (j * 32 + l31) * 2) = bf16_bits(acc[i][j][r]);
-                }
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<unsigned short*>(ws + (rowc(i, r) + 4 * lh) * SROW + (j * 32 + l31) * 2) = bf16_bits(acc[i][j][r]);
+        asm volatile("" ::: "memory");              // (the image is written and read through different types: no reordering across)
+        // (plain global stores under a lane predicate, NOT buffer stores with a scalar offset: hipcc's hazard recognizer
+        //  assumes a >64-bit MUBUF store with a REGISTER soffset has read its data registers at once and re-used the first of
+        //  them in the next VALU instruction -- on gfx950 the store then wrote that scratch value; tools/gemm_b16x_dev check)
         constexpr int CH = WN / 8, NP = WM * CH / 64;
+        const int row0 = lane / CH, ch = lane % CH;
+        const int mvalid = row_limit() + 4 * lh;            // valid rows m of the wave's tile
+        const bool nok = nw0 + 8 * ch < g.N;                // (n + 8 <= ldcb: host-checked)
+        unsigned short* dst = g.Cb + (mw + row0) * g.ldcb + nw0 + 8 * ch;
+        const long ostep = (64 / CH) * g.ldcb;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int idx = p * 64 + lane, row = idx / CH, ch = idx % CH;
-            const i32x4 v = *reinterpret_cast<const i32x4*>(ws + row * SROW + ch * 16);
-            const long m = mw + row, n = nw0 + 8 * ch;
-            if (m < g.M && n < g.N) *reinterpret_cast<i32x4*>(g.Cb + m * g.ldcb + n) = v;     // (n + 8 <= ldcb: host-checked)
+            const i32x4 v = *reinterpret_cast<const i32x4*>(ws + (row0 + p * (64 / CH)) * SROW + ch * 16);
+            if (nok && row0 + p * (64 / CH) < mvalid) *reinterpret_cast<i32x4*>(dst + p * ostep) = v;
         }
+        asm volatile("" ::: "memory");              // (the image is written and read through different types: no reordering across)
     }
 
     if (g.CbT) {
         // [n][m] image: a lane's registers r = 4 q .. 4 q + 3 are four CONSECUTIVE rows m -> one 8-byte write; then whole
         // 2 WM-byte row segments out, 16 B per lane
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -352,27 +469,29 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     uint2 pk;
-                    pk.x = (unsigned)bf16_bits(acc[i][j][4 * q]) | ((unsigned)bf16_bits(acc[i][j][4 * q + 1]) << 16);
-                    pk.y = (unsigned)bf16_bits(acc[i][j][4 * q + 2]) | ((unsigned)bf16_bits(acc[i][j][4 * q + 3]) << 16);
+                    pk.x = pack_bf16(acc[i][j][4 * q], acc[i][j][4 * q + 1]);
+                    pk.y = pack_bf16(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                     *reinterpret_cast<uint2*>(ws + (j * 32 + l31) * TROW + (i * 32 + 8 * q + 4 * lh) * 2) = pk;
                 }
+        asm volatile("" ::: "memory");              // (the image is written and read through different types: no reordering across)
         constexpr int CH = WM / 8, NP = (WN * CH + 63) / 64;
+        const int mvalid = row_limit() + 4 * lh;            // valid rows m of the wave's tile
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int idx = p * 64 + lane, row = idx / CH, ch = idx % CH;
             if (WN * CH % 64 != 0 && row >= WN) break;
             const i32x4 v = *reinterpret_cast<const i32x4*>(ws + row * TROW + ch * 16);
-            const long n = nw0 + row, m = mw + 8 * ch;
-            if (n < g.N && m < g.M) *reinterpret_cast<i32x4*>(g.CbT + n * g.ldcbt + m) = v;   // (m + 8 <= ldcbt: host-checked)
+            if (nw0 + row < g.N && 8 * ch < mvalid)         // (m + 8 <= ldcbt: host-checked)
+                *reinterpret_cast<i32x4*>(g.CbT + (nw0 + row) * g.ldcbt + mw + 8 * ch) = v;
         }
     }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NST>
 hipError_t launch(const Args& g, hipStream_t s) {
-    using Q = Geo<BM, BN, WGM, WGN>;
+    using Q = Geo<BM, BN, WGM, WGN, NST>;
     static bool attr_set = false;
-    auto kern = &gemm_b16x_kernel<BM, BN, WGM, WGN>;
+    auto kern = &gemm_b16x_kernel<BM, BN, WGM, WGN, NST>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Q::LDS);
         if (e != hipSuccess) return e;
@@ -383,12 +502,16 @@ hipError_t launch(const Args& g, hipStream_t s) {
     return hipSuccess;
 }
 
-// tile configurations: 0 = 192 x 256, 1 = 256 x 256, 2 = 128 x 256 (all 2 x 4 waves)
+// tile configurations: 0 = 192 x 256, 1 = 256 x 256, 2 = 128 x 256 (all 2 x 4 waves); ring depth: 5 stages where they fit
+#ifndef B16X_NST
+#define B16X_NST 5
+#endif
+constexpr int NST_DEFAULT = B16X_NST;
 inline int tile_bm(int cfg) { return cfg == 0 ? 192 : cfg == 1 ? 256 : 128; }
 inline hipError_t launch_cfg(int cfg, const Args& g, hipStream_t s) {
-    if (cfg == 0) return launch<192, 256, 2, 4>(g, s);
-    if (cfg == 1) return launch<256, 256, 2, 4>(g, s);
-    return launch<128, 256, 2, 4>(g, s);
+    if (cfg == 0) return launch<192, 256, 2, 4, NST_DEFAULT>(g, s);
+    if (cfg == 1) return launch<256, 256, 2, 4, 4>(g, s);
+    return launch<128, 256, 2, 4, NST_DEFAULT>(g, s);
 }
 
 // Fills tiles / slices / extents; false when the problem does not fit the kernel's addressing (32-bit buffer offsets).
@@ -398,20 +521,24 @@ inline bool plan(Args& g, int cfg, int split) {
     g.tiles_n = (int)((g.N + BN - 1) / BN);
     if (split < 1) split = 1;
     long kc = (g.K + split - 1) / split;
-    kc = (kc + BK - 1) / BK * BK;
+    kc = (kc + 63) / 64 * 64;
     g.k_chunk = kc;
     g.split = (int)((g.K + kc - 1) / kc);
     auto up8 = [](long x) { return (x + 7) / 8 * 8; };
     const long a_el = (g.M - 1) * g.lda + (up8(g.K) < g.lda ? up8(g.K) : g.lda);
     const long b_el = (g.N - 1) * g.ldb + (up8(g.K) < g.ldb ? up8(g.K) : g.ldb);
     const long a_max = (g.M + 512) * g.lda + g.K + 128, b_max = (g.N + 512) * g.ldb + g.K + 128;
-    if (a_max * 2 >= (1L << 32) || b_max * 2 >= (1L << 32) || g.K < 1) return false;
+    // every offset the kernel forms stays below 2^31 (OOB = 2^31 is then beyond every extent, with or without the scalar part)
+    if (a_max * 2 >= (1L << 31) || b_max * 2 >= (1L << 31) || g.K < 1) return false;
+    if (g.C && (g.M + 512) * g.ldc * 4 >= (1L << 31)) return false;
+    if (g.Cb && (g.M + 512) * g.ldcb * 2 >= (1L << 31)) return false;
+    if (g.CbT && (g.N + 512) * g.ldcbt * 2 >= (1L << 31)) return false;
     g.a_bytes = (unsigned)(a_el * 2);
     g.b_bytes = (unsigned)(b_el * 2);
     g.mask_bytes = 0;
     if (g.mask_mode) {
         const long m_el = (g.M - 1) * g.ldmask16 + (up8(g.N) < g.ldmask16 ? up8(g.N) : g.ldmask16);
-        if ((g.M + 512) * g.ldmask16 * 2 >= (1L << 32)) return false;
+        if ((g.M + 512) * g.ldmask16 * 2 >= (1L << 31)) return false;
         g.mask_bytes = (unsigned)(m_el * 2);
     }
     return true;

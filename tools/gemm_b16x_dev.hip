@@ -90,6 +90,7 @@ static int check() {
                 CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hCb.data(), dCb, hCb.size() * 2, hipMemcpyDeviceToHost));
                 CK(hipMemcpy(hCbT.data(), dCbT, hCbT.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hcs.data(), dcs, hcs.size() * 4, hipMemcpyDeviceToHost));
                 double errc = 0, errb = 0, errt = 0, errs = 0, scale = 0;
+                long nbadcb = 0;
                 bool pads = true;
                 std::vector<double> cs(csrows * p.N, 0.0);
                 for (long m = 0; m < p.M; ++m) for (long n = 0; n < p.N; ++n) {
@@ -99,7 +100,8 @@ static int check() {
                     scale = fmax(scale, fabs(v));
                     cs[(m / 32) * p.N + n] += v;
                     if (f.c) { const double d = fabs((double)hC[m * ldc + n] - (f.out_mode ? 1.0 : 0.0) - v); if (!(d <= errc)) errc = d; }
-                    if (f.cb) { const double d = fabs((double)b2f(hCb[m * ldcb + n]) - v) / (fabs(v) + 1e-2); if (!(d <= errb)) errb = d; }
+                    if (f.cb) { const double d = fabs((double)b2f(hCb[m * ldcb + n]) - v) / (fabs(v) + 1e-2); if (!(d <= errb)) errb = d;
+                                if (d > 0.1 && nbadcb++ < 12) printf("    Cb[%ld][%ld] = %g (bits %04x), want %g\n", m, n, b2f(hCb[m * ldcb + n]), hCb[m * ldcb + n], v); }
                     if (f.cbt) { const double d = fabs((double)b2f(hCbT[n * ldcbt + m]) - v) / (fabs(v) + 1e-2); if (!(d <= errt)) errt = d; }
                 }
                 if (f.colsum) for (long b = 0; b < csrows; ++b) for (long n = 0; n < p.N; ++n) { const double d = fabs(hcs[b * p.N + n] - cs[b * p.N + n]); if (!(d <= errs)) errs = d; }
@@ -111,6 +113,7 @@ static int check() {
                 for (int t = 0; t < g.tiles_m * g.tiles_n; ++t) { int x; CK(hipMemcpy(&x, reinterpret_cast<int*>(ws) + t, 4, hipMemcpyDeviceToHost)); tk |= x; }
                 const bool ok = errc <= 2e-5 * scale + 1e-6 && errb <= 4.5e-3 && errt <= 4.5e-3 && errs <= 1e-4 * scale * 32 + 1e-5 && pads && tk == 0;
                 if (!ok) ++bad;
+                if (nbadcb) printf("    %ld wrong Cb elements\n", nbadcb);
                 printf("cfg %d (%dx256) M=%4ld N=%4ld K=%4ld %-20s errC %.2g errCb %.2g errCbT %.2g errcs %.2g (scale %.3g) pads %s tickets %d %s\n", cfg,
                        b16x::tile_bm(cfg), p.M, p.N, p.K, f.name, errc, errb, errt, errs, scale, pads ? "ok" : "BAD", tk, ok ? "ok" : "FAIL");
             }
@@ -229,10 +232,34 @@ static void trprobe() {
         printf("lane %2d: %4u %4u %4u %4u%s", l, h[2 * l] & 0xffff, h[2 * l] >> 16, h[2 * l + 1] & 0xffff, h[2 * l + 1] >> 16, (l & 3) == 3 ? "\n" : "   ");
 }
 
+// ---- does the scalar offset of a raw buffer access take part in the bounds check?  (the kernels point rows beyond an
+// operand out of bounds through it)
+__global__ void oobprobe_kernel(const unsigned* buf, unsigned bytes, unsigned* out) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(buf), 0, (int)bytes, 0x00020000);
+    out[threadIdx.x] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * (int)threadIdx.x, 0, 0);                    // in bounds
+    out[64 + threadIdx.x] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * (int)threadIdx.x, (int)bytes, 0);      // soffset = extent
+    out[128 + threadIdx.x] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * (int)threadIdx.x + (int)bytes, 0, 0);  // voffset beyond
+    out[192 + threadIdx.x] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * (int)threadIdx.x, (int)bytes - 128, 0);// straddles the end
+}
+static void oobprobe() {
+    unsigned *d, *o; CK(hipMalloc(&d, 4096)); CK(hipMalloc(&o, 256 * 4));
+    std::vector<unsigned> h(1024); for (int i = 0; i < 1024; ++i) h[i] = 1000 + i;
+    CK(hipMemcpy(d, h.data(), 4096, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(oobprobe_kernel, dim3(1), dim3(64), 0, 0, d, 1024u, o);
+    CK(hipDeviceSynchronize());
+    unsigned r[256]; CK(hipMemcpy(r, o, sizeof r, hipMemcpyDeviceToHost));
+    printf("raw buffer, extent 1024 B of a 4096 B allocation holding 1000 + i:\n");
+    printf("  in bounds             lanes 0,1,63: %u %u %u\n", r[0], r[1], r[63]);
+    printf("  soffset = extent      lanes 0,1,63: %u %u %u   (0 = the scalar offset is bounds-checked)\n", r[64], r[65], r[127]);
+    printf("  voffset beyond        lanes 0,1,63: %u %u %u\n", r[128], r[129], r[191]);
+    printf("  soffset = extent-128  lanes 0,31,32,63: %u %u %u %u   (lanes >= 32 are beyond)\n", r[192], r[223], r[224], r[255]);
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "check";
     if (mode == "check") return check();
     if (mode == "trprobe") { trprobe(); return 0; }
+    if (mode == "oobprobe") { oobprobe(); return 0; }
     timeit(argc > 2 ? atol(argv[2]) : 12001);
     return 0;
 }
