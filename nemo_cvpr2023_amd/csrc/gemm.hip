@@ -28,6 +28,7 @@
 #include "gemm_glds.h"
 #include "gemm_adj.h"
 #include "gemm_skinny.h"
+#include "gemm_b16x.h"
 #include "../../include/nemo_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -838,6 +839,46 @@ extern "C" int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint
     // mask_mode 1 / 2 with a FLOAT mask; 17 / 18: the same tests on a BF16 mask (`mask` then points at uint16_t data and
     // ldmask counts bf16 elements) -- e.g. the bf16 copy of a ReLU output, whose sign and zeros survive the rounding
     const bool m16 = mask_mode >= 16;
+    // Round 5: the large products of the chain go to the large-tile kernel (gemm_b16x.h: 8 MFMA waves on a 192 x 256 /
+    // 128 x 256 tile + 4 loader waves).  tools/gemm_b16x_dev time, us per launch against the 64 x 64 kernel below
+    // (12 001 x 1000 x 1000): forward with both bf16 copies 40.7 / 84.7, dX with mask, copies and column sums 45.8 / 110.7,
+    // head dX (K = 152) 24.4 / 66.5; from 4801 rows on the 128 x 256 tile (26.0 / 34.4, dX 30.1 / 49.3), level at 2401 rows.
+    // The parameter gradients (K = samples) only from 24 576 samples on (65 537: 235 / 363; 12 001: 63 / 67, 8193: 55 / 46):
+    // every workgroup streams its own K slice there and a CU pulls ~40 GB/s.
+    static const bool no_b16x = getenv("NEMO_B16X") != nullptr && atoi(getenv("NEMO_B16X")) == 0;
+    const bool wide = M >= 3072 && N >= 512 && K >= 64;
+    const bool deep = K >= 24576 && M >= 512 && N >= 512 && M * N <= 2048L * 2048 && !Cb && !CbT && !colsum;
+    if (!no_b16x && (wide || deep) && (mask_mode == 0 || (mask_mode == 17 && mask)) && out_mode != 2 &&
+        (!Cb || ((ldcb & 7) == 0 && ldcb >= (N + 7) / 8 * 8 && (((uintptr_t)Cb) & 15) == 0)) &&
+        (!CbT || ((ldcbt & 7) == 0 && ldcbt >= (M + 7) / 8 * 8 && (((uintptr_t)CbT) & 15) == 0)) &&
+        (mask_mode == 0 || ((ldmask & 7) == 0 && ldmask >= N && (((uintptr_t)mask) & 15) == 0)) && (!colsum || ldcs >= N) &&
+        !getenv("NEMO_GEMM_TILE")) {
+        b16x::Args g{};
+        g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.C = C; g.ldc = ldc; g.out_mode = out_mode;
+        g.bias = bias; g.act = act; g.alpha = alpha;
+        g.mask16 = mask_mode ? reinterpret_cast<const unsigned short*>(mask) : nullptr; g.ldmask16 = ldmask; g.mask_mode = mask_mode ? 1 : 0;
+        g.Cb = Cb; g.ldcb = ldcb; g.CbT = CbT; g.ldcbt = ldcbt; g.colsum = colsum; g.ldcs = ldcs;
+        g.counters = reinterpret_cast<int*>(ws);
+        g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
+        const long t128 = ((M + 127) / 128) * ((N + 255) / 256), t192 = ((M + 191) / 192) * ((N + 255) / 256);
+        int cfg = 3, split = 1;                             // 192 x 256 + loader waves
+        if (wide && t128 <= 256) cfg = 5;                   // 128 x 256 + loader waves while its grid is one round of the chip
+        if (!wide) {                                        // K slices: ~one workgroup per CU, >= 2048 k each
+            split = (int)(256 / t192);
+            while (split > 1 && (K / split < 2048 || COUNTER_BYTES + t192 * split * 192L * 256 * 4 > ws_bytes)) --split;
+            if (!ws || (((uintptr_t)ws) & 15) || t192 > COUNTER_BYTES / 4) split = 1;
+        }
+        if (b16x::plan(g, cfg, split)) {
+            static const bool debug_x = getenv("NEMO_GEMM_DEBUG") != nullptr;
+            if (debug_x)
+                fprintf(stderr, "nemo_gemm_bf16mem M=%ld N=%ld K=%ld -> b16x %dx256 + 4 loader waves, %d K slices\n", (long)M, (long)N, (long)K,
+                        b16x::tile_bm(cfg), g.split);
+            const hipError_t e = b16x::launch_cfg(cfg, g, (hipStream_t)stream);
+            if (e != hipSuccess) return (int32_t)e;
+            NEMO_LAUNCH_CHECK();
+            return NEMO_OK;
+        }
+    }
     return gemm_impl(2, 0, 1, M, N, K / 2, reinterpret_cast<const float*>(A), lda / 2, reinterpret_cast<const float*>(B),
                      ldb / 2, C, ldc, bias, act, m16 ? nullptr : mask, ldmask, m16 ? mask_mode - 16 : mask_mode, alpha, out_mode,
                      0, ws, ws_bytes, stream, Cb, ldcb, CbT, ldcbt,

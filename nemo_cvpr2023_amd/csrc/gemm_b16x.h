@@ -59,15 +59,21 @@ struct Args {
 
 constexpr int BK = 32;                                      // bf16 per ring stage: a stage row is 64 B = 4 chunks of 16 B
 
-template <int BM, int BN, int WGM, int WGN, int NST>
+// LW: loader waves (0: the eight MFMA waves request their operand tiles themselves; 4: four more waves -- one per SIMD --
+// issue every LDS-DMA piece and the MFMA waves never stall on a DMA issue, ~100 - 180 cycles each beside MFMAs and LDS
+// reads: with eight pieces per wave and 64 k that was as long as the MFMAs themselves)
+template <int BM, int BN, int WGM, int WGN, int NST, int LW = 0>
 struct Geo {
     static constexpr int NW = WGM * WGN;
-    static_assert(NW == 8, "8 waves");
+    static_assert(NW == 8, "8 MFMA waves");
+    static_assert(LW == 0 || LW == 4, "loader waves: none or one per SIMD");
+    static constexpr int THREADS = 64 * (NW + LW);
     static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile in 32 x 32 accumulators");
     static constexpr int NPA = BM / 16, NPB = BN / 16;                            // 1-KiB DMA pieces (16 rows x 64 B) per stage
-    static constexpr int GW = (NPA + NPB + NW - 1) / NW;                          // pieces per wave and stage (waves whose last
-                                                                                  // piece does not exist issue a dummy: same counts)
+    static constexpr int NI = LW ? LW : NW;                                       // waves that issue DMAs
+    static constexpr int GW = (NPA + NPB + NI - 1) / NI;                          // pieces per issuing wave and stage (waves whose
+                                                                                  // last piece does not exist issue a dummy: same counts)
     static constexpr int STAGE = (BM + BN) * 64;                                  // bytes
     static constexpr int RING = NST * STAGE;
     // epilogue scratch per wave: the larger of the [m][n] image (row stride WN * 2 + 16 B) and the [n][m] image
@@ -93,10 +99,10 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return (unsi
 
 constexpr int OOB = (int)0x80000000u;      // a buffer offset beyond every descriptor of this kernel (extents < 2^31)
 
-template <int BM, int BN, int WGM, int WGN, int NST>
-__global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
-    using Q = Geo<BM, BN, WGM, WGN, NST>;
-    constexpr int WM = Q::WM, WN = Q::WN, TM = Q::TM, TN = Q::TN, GW = Q::GW, NPA = Q::NPA, NPB = Q::NPB;
+template <int BM, int BN, int WGM, int WGN, int NST, int LW>
+__global__ __launch_bounds__(64 * (8 + LW)) void gemm_b16x_kernel(Args g) {
+    using Q = Geo<BM, BN, WGM, WGN, NST, LW>;
+    constexpr int WM = Q::WM, WN = Q::WN, TM = Q::TM, TN = Q::TN, GW = Q::GW, NPA = Q::NPA, NPB = Q::NPB, NI = Q::NI;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];          // the ONLY LDS object of the kernel
 
     // ---- block -> (K slice, row tile, column tile).  Block b runs on XCD b % 8 (observed; speed only): give every XCD a
@@ -114,7 +120,9 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __builtin_assume(wid >= 0 && wid < 8);
+    __builtin_assume(wid >= 0 && wid < 8 + LW);
+    const bool loader = LW > 0 && wid >= 8;                 // (wave-uniform)
+    const int iw = LW > 0 ? wid - 8 : wid;                  // index among the issuing waves (loaders: 0 .. LW - 1)
     const int wm = wid / WGN, wn = wid % WGN;
     const int l31 = lane & 31, lh = lane >> 5;
 
@@ -129,8 +137,8 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
     // ---- LDS-DMA addressing.  Stage image: [row][4 chunks of 16 B], chunk c of row r at slot c ^ ((r >> 2) & 3): the 16
     // lanes a ds_read_b128 services together (rows {0-3, 12-15, 20-27} + 4 a of one chunk index) then touch 16 distinct
     // 16-byte bank quads.  A piece = 16 rows; a piece's lane (row dr = lane >> 2, slot lane & 3) fetches source chunk
-    // (lane & 3) ^ ((dr >> 2) & 3) -- the swizzle does not depend on the piece.  Wave w issues pieces w, w + 8, ... of the
-    // NPA + NPB pieces of a stage (A's first).
+    // (lane & 3) ^ ((dr >> 2) & 3) -- the swizzle does not depend on the piece.  Issuing wave w of NI issues pieces w, w + NI,
+    // ... of the NPA + NPB pieces of a stage (A's first).
     const unsigned smem_byte = (unsigned)reinterpret_cast<unsigned long long>(smem);
     auto rsrc = [](const void* p, unsigned bytes) {
         const unsigned long long b = reinterpret_cast<unsigned long long>(p);
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
     const unsigned baseA = (unsigned)((m0 * g.lda + kbeg) * 2), baseB = (unsigned)((n0 * g.ldb + kbeg) * 2);
     const unsigned rowsA = (unsigned)(16 * g.lda * 2), rowsB = (unsigned)(16 * g.ldb * 2);
     // the p-th piece (0 .. GW - 1) of this wave: which operand, where in a stage, from where -- selected once, branch-free
-    // (q = wid + 8 p).  Pieces that do not exist (q >= NPA + NPB) and tiles beyond the slice are requested out of bounds
+    // (q = iw + NI p).  Pieces that do not exist (q >= NPA + NPB) and tiles beyond the slice are requested out of bounds
     // (nothing is fetched; zeros land in the 1 KiB behind the ring resp. in a stage nobody reads any more): every wave has the
     // same number of DMAs in flight per tile, which is what the counted vmcnt below relies on.
     i32x4 prs[GW];
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
     bool pdummy[GW];
 #pragma unroll
     for (int p = 0; p < GW; ++p) {
-        const int q = wid + 8 * p;
+        const int q = iw + NI * p;
         const bool isA = q < NPA;
         pdummy[p] = q >= NPA + NPB;
         prs[p] = isA ? rsA : rsB;
@@ -202,13 +210,13 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
                     after_first();
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (issue_t >= 0 && i * TN + j >= 1 && i * TN + j - 1 < GW) {
+                if (LW == 0 && issue_t >= 0 && i * TN + j >= 1 && i * TN + j - 1 < GW) {
                     dma(i * TN + j - 1, issue_t, stage);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
     };
-    static_assert(GW < TM * TN, "one piece behind each of GW MFMAs");
+    static_assert(LW > 0 || GW < TM * TN, "one piece behind each of GW MFMAs");
 
     // ---- K loop over a ring of NST stages (tile t in stage t % NST), software-pipelined by one k-step ACROSS the barrier:
     //   iteration t:  MFMAs of F = (t, k-step 0), G = fragments (t, k-step 1) read behind the first of them;
@@ -219,40 +227,66 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
     // After every barrier a wave has MFMAs whose operands are already in registers while its next reads are in flight.
     // The loop body exists once; the last tile runs behind it through the masking variant whether it is partial or not
     // (with several variants selected inside the loop hipcc copies all accumulators between two register sets per iteration).
-#pragma unroll
-    for (int t = 0; t < NST; ++t)
-#pragma unroll
-        for (int p = 0; p < GW; ++p) dma(p, t, t);
-    glds::wait_vmcnt<(NST - 1) * GW>();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    // With loader waves (LW > 0) the same schedule is split by role: a loader's iteration is { tile t + 1 has landed (its
+    // pieces: counted vmcnt); s_barrier; request tile t + NST into stage t % NST }, an MFMA wave's is the one above without
+    // the waits for and the requests of DMAs; both pass the same barriers.
     Frag F, G;
-    fetch(F, 0, 0);
-    int cur = 0;                                            // stage of tile t
-    for (int t = 0; t < nt - 1; ++t) {
-        mma(F, [&] { fetch(G, cur, 1); }, -1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * GW) : "memory");
+    if (loader) {
+#pragma unroll
+        for (int t = 0; t < NST; ++t)
+#pragma unroll
+            for (int p = 0; p < GW; ++p) dma(p, t, t);
+        glds::wait_vmcnt<(NST - 1) * GW>();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int t = 0; t < nt - 1; ++t) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * GW) : "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int p = 0; p < GW; ++p) dma(p, t + NST, cur);
+            cur = cur + 1 == NST ? 0 : cur + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (pieces of the tiles behind the slice: zeros into dead stages)
+    } else {
+        if (LW == 0) {
+#pragma unroll
+            for (int t = 0; t < NST; ++t)
+#pragma unroll
+                for (int p = 0; p < GW; ++p) dma(p, t, t);
+            glds::wait_vmcnt<(NST - 1) * GW>();
+        }
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int nxt = cur + 1 == NST ? 0 : cur + 1;
-        mma(G, [&] { fetch(F, nxt, 0); }, t + NST, cur);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
+        fetch(F, 0, 0);
+        int cur = 0;                                        // stage of tile t
+        for (int t = 0; t < nt - 1; ++t) {
+            mma(F, [&] { fetch(G, cur, 1); }, -1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (LW == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * GW) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int nxt = cur + 1 == NST ? 0 : cur + 1;
+            mma(G, [&] { fetch(F, nxt, 0); }, t + NST, cur);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+        fetch(G, cur, 1);
+        mask_tail(F, nt - 1, 0);
+        mask_tail(G, nt - 1, 1);
+        mma(F, [] {}, -1, 0);
+        mma(G, [] {}, -1, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (dummy pieces of the tiles behind the slice)
     }
-    fetch(G, cur, 1);
-    mask_tail(F, nt - 1, 0);
-    mask_tail(G, nt - 1, 1);
-    mma(F, [] {}, -1, 0);
-    mma(G, [] {}, -1, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (dummy pieces of the tiles behind the slice)
 
     // ---- split-K: publish the partial tile write-through, take a ticket; the last arriver sums all slices in slice order
     // (deterministic) and runs the epilogue.  Slab layout = the register image: float4 #(i, j, r4) of thread t.
     constexpr int NV4 = TM * TN * 4;
     if (g.split > 1) {
         float4* slab = reinterpret_cast<float4*>(g.slabs) + ((size_t)tile * g.split + slice) * (size_t)(BM * BN / 4);
+        if (!loader)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -277,6 +311,7 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
         }
         __syncthreads();
         const float4* base = reinterpret_cast<const float4*>(g.slabs) + (size_t)tile * g.split * (size_t)(BM * BN / 4);
+        if (!loader)
 #pragma unroll
         for (int c = 0; c < NV4; ++c) {
             float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -299,6 +334,7 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                                        // the ring becomes the epilogue's wave-private scratch
+    if (loader) return;
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Everything
     // per element is branch-free; what depends on the call (mask, edge tiles, which outputs) is decided once per pass.
@@ -487,35 +523,40 @@ __global__ __launch_bounds__(512) void gemm_b16x_kernel(Args g) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST>
+template <int BM, int BN, int WGM, int WGN, int NST, int LW>
 hipError_t launch(const Args& g, hipStream_t s) {
-    using Q = Geo<BM, BN, WGM, WGN, NST>;
+    using Q = Geo<BM, BN, WGM, WGN, NST, LW>;
     static bool attr_set = false;
-    auto kern = &gemm_b16x_kernel<BM, BN, WGM, WGN, NST>;
+    auto kern = &gemm_b16x_kernel<BM, BN, WGM, WGN, NST, LW>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Q::LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const long blocks = (long)g.tiles_m * g.tiles_n * (g.split > 1 ? g.split : 1);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), Q::LDS, s, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q::THREADS), Q::LDS, s, g);
     return hipSuccess;
 }
 
-// tile configurations: 0 = 192 x 256, 1 = 256 x 256, 2 = 128 x 256 (all 2 x 4 waves); ring depth: 5 stages where they fit
+// tile configurations: 0 = 192 x 256, 1 = 256 x 256, 2 = 128 x 256 (all 2 x 4 MFMA waves), + 3: the same with four loader
+// waves (192 x 256 and 128 x 256: their register budgets allow three waves per SIMD); ring depth: 5 stages where they fit
 #ifndef B16X_NST
 #define B16X_NST 5
 #endif
 constexpr int NST_DEFAULT = B16X_NST;
-inline int tile_bm(int cfg) { return cfg == 0 ? 192 : cfg == 1 ? 256 : 128; }
+inline int tile_bm(int cfg) { return cfg % 3 == 0 ? 192 : cfg % 3 == 1 ? 256 : 128; }
 inline hipError_t launch_cfg(int cfg, const Args& g, hipStream_t s) {
-    if (cfg == 0) return launch<192, 256, 2, 4, NST_DEFAULT>(g, s);
-    if (cfg == 1) return launch<256, 256, 2, 4, 4>(g, s);
-    return launch<128, 256, 2, 4, NST_DEFAULT>(g, s);
+    if (cfg == 0) return launch<192, 256, 2, 4, NST_DEFAULT, 0>(g, s);
+    if (cfg == 1) return launch<256, 256, 2, 4, 4, 0>(g, s);
+    if (cfg == 2) return launch<128, 256, 2, 4, NST_DEFAULT, 0>(g, s);
+    if (cfg == 3) return launch<192, 256, 2, 4, NST_DEFAULT, 4>(g, s);
+    if (cfg == 5) return launch<128, 256, 2, 4, NST_DEFAULT, 4>(g, s);
+    return hipErrorInvalidValue;
 }
 
 // Fills tiles / slices / extents; false when the problem does not fit the kernel's addressing (32-bit buffer offsets).
 inline bool plan(Args& g, int cfg, int split) {
+    if (cfg == 4) return false;
     const int BM = tile_bm(cfg), BN = 256;
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (int)((g.N + BN - 1) / BN);

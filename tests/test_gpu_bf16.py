@@ -250,6 +250,107 @@ def test_gemm_with_bf16_operands_in_memory(L, M, N, K):
     assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
 
 
+@pytest.mark.parametrize('M,N,K', [(12001, 1000, 1000), (4801, 1000, 152), (3100, 520, 203), (8193, 1000, 1000), (3072, 512, 64)])
+def test_large_tile_bf16_product(L, M, N, K):
+    """The large-tile kernel of round 5 (csrc/gemm_b16x.h: 8 MFMA waves on a 192 x 256 / 128 x 256 tile + 4 loader waves; what
+    nemo_gemm_bf16mem runs from 3072 rows on) against the fp32-accumulated product of the same bf16 operands: forward form
+    (bias, ReLU, both bf16 copies), dX form (bf16 ReLU mask incl. -0 / 0 / negative entries, copies, per-band column sums),
+    fp32 result in store and += mode; ragged M / N / K incl. odd K behind NaN-poisoned row pads (the kernel masks the end of K
+    per element); pads of the copies zero, nothing behind them written; twice the same bits."""
+    import hipops as H
+    from nemo_cvpr2023_amd._lib import check, dptr
+    g = torch.Generator().manual_seed(11 * M + 3 * N + 7 * K)
+    r8 = lambda n: (n + 7) // 8 * 8
+    A32, B32 = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    Ab = torch.full((M, r8(K) + 8), 0x7fc0, dtype=torch.int16)            # everything behind column K is NaN
+    Bb = torch.full((N, r8(K) + 8), 0x7fc0, dtype=torch.int16)
+    Ab[:, :K] = A32.to(torch.bfloat16).view(torch.int16)
+    Bb[:, :K] = B32.to(torch.bfloat16).view(torch.int16)
+    Ab, Bb = Ab.to(DEV), Bb.to(DEV)
+    a, b = A32.to(torch.bfloat16).double().to(DEV), B32.to(torch.bfloat16).double().to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    mk = torch.randn(M, r8(N), generator=g)
+    mk[torch.rand(M, r8(N), generator=g) < 0.2] = 0.0
+    mk[torch.rand(M, r8(N), generator=g) < 0.1] = -0.0
+    mask = mk.to(torch.bfloat16).view(torch.int16).to(DEV)
+    ws = H.gemm_ws()
+    Keven = K                                                               # (odd K allowed by this kernel)
+    if K % 2:
+        Keven = K + 1                                                       # the ABI takes K in pairs: the pair's pad must be zero
+        Ab[:, K] = 0
+        Bb[:, K] = 0
+    ldcb, ldcbt = r8(N) + 8, r8(M) + 16
+    R = int(L.nemo_gemm_colsum_rows(M))
+
+    def run(C, out_mode, bias_, act, mask_, want_copies, want_cs):
+        Cb = torch.full((M, ldcb), 0x1111, dtype=torch.int16, device=DEV) if want_copies else None
+        CbT = torch.full((N, ldcbt), 0x1111, dtype=torch.int16, device=DEV) if want_copies else None
+        cs = torch.full((R, N + 3), float('nan'), device=DEV) if want_cs else None
+        check(L.nemo_gemm_bf16mem(M, N, Keven, dptr(Ab), Ab.stride(0), dptr(Bb), Bb.stride(0), dptr(C), C.stride(0) if C is not None else 0,
+                                  dptr(bias_), act, dptr(mask_), mask_.stride(0) if mask_ is not None else 0, 17 if mask_ is not None else 0,
+                                  0.5, out_mode, dptr(Cb), ldcb, dptr(CbT), ldcbt, dptr(cs), N + 3, dptr(ws), ws.numel() * 4, H.st()),
+              'gemm_bf16mem')
+        return Cb, CbT, cs
+
+    prod = 0.5 * (a @ b.T)
+    # forward form
+    C = torch.full((M, N + 5), float('nan'), device=DEV)
+    Cb, CbT, _ = run(C[:, :N], 0, bias, 1, None, True, False)
+    ref = torch.relu(prod + bias.double())
+    assert rel_err(C[:, :N], ref) < 2e-5 and bool(torch.isnan(C[:, N:]).all())
+    assert torch.equal(Cb[:, :N].view(torch.bfloat16), C[:, :N].to(torch.bfloat16))
+    assert torch.equal(CbT[:, :M].view(torch.bfloat16), C[:, :N].to(torch.bfloat16).T.contiguous())
+    assert int(Cb[:, N:r8(N)].abs().sum()) == 0 and bool((Cb[:, r8(N):] == 0x1111).all())
+    assert int(CbT[:, M:r8(M)].abs().sum()) == 0 and bool((CbT[:, r8(M):] == 0x1111).all())
+    Cb2, CbT2, _ = run(None, 0, bias, 1, None, True, False)                 # copies only; bit-identical
+    assert torch.equal(Cb2, Cb) and torch.equal(CbT2, CbT)
+    # dX form
+    C = torch.zeros(M, N, device=DEV)
+    Cb, CbT, cs = run(C, 0, None, 0, mask, True, True)
+    ref = prod * (mk[:, :N].to(torch.bfloat16).double().to(DEV) > 0)
+    assert rel_err(C, ref) < 2e-5
+    assert torch.equal(Cb[:, :N].view(torch.bfloat16), C.to(torch.bfloat16))
+    assert torch.equal(CbT[:, :M].view(torch.bfloat16), C.to(torch.bfloat16).T.contiguous())
+    band = torch.zeros(R * 32, N, dtype=torch.float64, device=DEV)
+    band[:M] = C.double()
+    assert bool(torch.isnan(cs[:, N:]).all()) and rel_err(cs[:, :N], band.reshape(R, 32, N).sum(1)) < 1e-5
+    # += mode
+    C0 = torch.randn(M, N, generator=g).to(DEV)
+    C2 = C0.clone()
+    run(C2, 1, None, 0, None, False, False)
+    assert rel_err(C2, C0.double() + prod) < 2e-5
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 1000, 30011), (520, 1000, 24577)])
+def test_large_tile_bf16_parameter_gradient_in_k_slices(L, M, N, K):
+    """The same kernel on the parameter-gradient shape (K = samples, from 24 576 on): K slices across workgroups, write-through
+    slabs, the last arriver sums them in slice order -- twice the same bits, tickets back at zero."""
+    import hipops as H
+    from nemo_cvpr2023_amd._lib import check, dptr
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    r8 = lambda n: (n + 7) // 8 * 8
+    A32, B32 = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    Ab = torch.full((M, r8(K) + 8), 0x7fc0, dtype=torch.int16)
+    Bb = torch.full((N, r8(K) + 8), 0x7fc0, dtype=torch.int16)
+    Ab[:, :K] = A32.to(torch.bfloat16).view(torch.int16)
+    Bb[:, :K] = B32.to(torch.bfloat16).view(torch.int16)
+    Ab[:, K] = 0
+    Bb[:, K] = 0
+    Ab, Bb = Ab.to(DEV), Bb.to(DEV)
+    ref = A32.to(torch.bfloat16).double().to(DEV) @ B32.to(torch.bfloat16).double().to(DEV).T
+    ws = H.gemm_ws()
+    outs = []
+    for _ in range(2):
+        C = torch.ones(M, N, device=DEV)
+        check(L.nemo_gemm_bf16mem(M, N, K + 1, dptr(Ab), Ab.stride(0), dptr(Bb), Bb.stride(0), dptr(C), N, None, 0, None, 0, 0, 1.0, 1,
+                                  None, 0, None, 0, None, 0, dptr(ws), ws.numel() * 4, H.st()), 'gemm_bf16mem')
+        outs.append(C)
+    assert rel_err(outs[0], ref + 1.0) < 2e-5
+    assert torch.equal(outs[0], outs[1])
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize('M,N,K', [(2400, 207, 20670), (8192, 207, 20670), (3808, 207, 20670), (300, 207, 20670), (257, 200, 4098),
                                    (1000, 130, 2050)])
 def test_blend_shape_adjoint_with_bf16_operands_on_the_mixed_shape_tile(L, M, N, K):

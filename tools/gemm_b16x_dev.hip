@@ -68,8 +68,9 @@ static int check() {
         CK(hipMalloc(&dbias, p.N * 4)); CK(hipMalloc(&dcs, csrows * p.N * 4));
         CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(dMask, hMask.data(), hMask.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dbias, hbias.data(), p.N * 4, hipMemcpyHostToDevice));
-        for (int cfg = 0; cfg < 3; ++cfg)
+        for (int cfg = 0; cfg < 6; ++cfg)
             for (const Feat& f : feats) {
+                if (cfg == 4) continue;
                 if (f.split > 1 && p.K < 64 * f.split) continue;
                 b16x::Args g{};
                 g.A = dA; g.B = dB; g.M = p.M; g.N = p.N; g.K = p.K; g.lda = lda; g.ldb = ldb;
@@ -114,8 +115,8 @@ static int check() {
                 const bool ok = errc <= 2e-5 * scale + 1e-6 && errb <= 4.5e-3 && errt <= 4.5e-3 && errs <= 1e-4 * scale * 32 + 1e-5 && pads && tk == 0;
                 if (!ok) ++bad;
                 if (nbadcb) printf("    %ld wrong Cb elements\n", nbadcb);
-                printf("cfg %d (%dx256) M=%4ld N=%4ld K=%4ld %-20s errC %.2g errCb %.2g errCbT %.2g errcs %.2g (scale %.3g) pads %s tickets %d %s\n", cfg,
-                       b16x::tile_bm(cfg), p.M, p.N, p.K, f.name, errc, errb, errt, errs, scale, pads ? "ok" : "BAD", tk, ok ? "ok" : "FAIL");
+                printf("cfg %d (%dx256%s) M=%4ld N=%4ld K=%4ld %-20s errC %.2g errCb %.2g errCbT %.2g errcs %.2g (scale %.3g) pads %s tickets %d %s\n", cfg,
+                       b16x::tile_bm(cfg), cfg >= 3 ? "+4L" : "", p.M, p.N, p.K, f.name, errc, errb, errt, errs, scale, pads ? "ok" : "BAD", tk, ok ? "ok" : "FAIL");
             }
         CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dMask)); CK(hipFree(dCb)); CK(hipFree(dCbT)); CK(hipFree(dC)); CK(hipFree(dbias)); CK(hipFree(dcs));
     }
@@ -149,6 +150,13 @@ static void timeit(long Mr) {
         {"head dX (mask, Cb, CbT, colsum)", Mr, 1000, 152, true, true, true, true, false, 0},
         {"plain C fp32", Mr, 1000, 1000, false, false, false, false, true, 0},
         {"hidden dW (C +=)", 1000, 1000, Mr, false, false, false, false, true, 1},
+        // the epilogues alone (one K tile)
+        {"K = 64: Cb", Mr, 1000, 64, true, false, false, false, false, 0},
+        {"K = 64: Cb, CbT", Mr, 1000, 64, true, true, false, false, false, 0},
+        {"K = 64: mask, Cb, CbT, colsum", Mr, 1000, 64, true, true, true, true, false, 0},
+        {"K = 64: mask, Cb", Mr, 1000, 64, true, false, true, false, false, 0},
+        {"K = 64: C fp32", Mr, 1000, 64, false, false, false, false, true, 0},
+        {"K = 64: colsum only", Mr, 1000, 64, false, false, false, true, false, 0},
     };
     float* ws; CK(hipMalloc(&ws, 256 << 20)); CK(hipMemset(ws, 0, 256 << 20));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -177,8 +185,9 @@ static void timeit(long Mr) {
         CK(hipMemcpy(dMask, hM.data(), hM.size() * 2, hipMemcpyHostToDevice)); CK(hipMemset(dC, 0, p.M * ldc * 4));
         const double gf = 2e-9 * p.M * p.N * p.K;
         printf("%-36s M=%6ld N=%5ld K=%6ld  %.2f GFLOP\n", p.name, p.M, p.N, p.K, gf);
-        for (int cfg = 0; cfg < 3; ++cfg) {
-            std::string line = std::string("   ") + std::to_string(b16x::tile_bm(cfg)) + "x256:";
+        for (int cfg = 0; cfg < 6; ++cfg) {
+            if (cfg == 4) continue;
+            std::string line = std::string("   ") + std::to_string(b16x::tile_bm(cfg)) + "x256" + (cfg >= 3 ? "+4L:" : ":");
             for (int split : {1, 2, 4, 6, 8, 10, 12, 16}) {
                 b16x::Args g{};
                 g.A = dA; g.B = dB; g.M = p.M; g.N = p.N; g.K = p.K; g.lda = lda; g.ldb = ldb; g.C = p.c ? dC : nullptr; g.ldc = ldc; g.out_mode = p.out_mode;
@@ -188,7 +197,7 @@ static void timeit(long Mr) {
                 if (!b16x::plan(g, cfg, split)) continue;
                 const long blocks = (long)g.tiles_m * g.tiles_n * g.split;
                 if (split > 1 && (p.K / split < 256 || blocks > 640 || p.colsum)) continue;
-                if (blocks * b16x::tile_bm(cfg) * 256 * 4 > (240L << 20)) continue;
+                if (g.split > 1 && blocks * b16x::tile_bm(cfg) * 256 * 4 > (240L << 20)) continue;
                 const float us = time_it([&] { CK(b16x::launch_cfg(cfg, g, 0)); });
                 char b[96]; snprintf(b, sizeof b, " s%d[%ldb]=%.1fus(%.0fTF)", g.split, blocks, us, gf / us * 1e3);
                 line += b;
