@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 11
+#define NEMO_ABI_VERSION 12
 int32_t nemo_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -90,6 +90,13 @@ int32_t nemo_gemm_f32_b16out(int32_t transA, int32_t transB, int64_t M, int64_t 
                              void* stream);
 int32_t nemo_cast_bf16(int64_t rows, int64_t cols, const float* src, int64_t lds, uint16_t* dst, int64_t ldd,
                        int32_t transpose, void* stream);
+/* fp32 -> THREE bf16 pieces per row for a split-precision product on the bf16 matrix cores (round 5: the first MotionNet layer,
+ * nn.Linear(105, h) of nemo/neural_motion_model.py:58-71, under gemm_dtype = 'bf16'): with hi = bf16(x), lo = bf16(x - hi) and
+ * seg = cols rounded up to 8, row r of dst (ldd >= 3 seg) is [hi | lo | hi] (order 0: the activation operand) or
+ * [hi | hi | lo] (order 1: the weight operand), pads zero -- one NT product with K = 3 seg then sums hi*hi + lo*hi + hi*lo,
+ * i.e. the fp32 product up to the 2^-17 terms, through nemo_gemm_bf16mem. */
+int32_t nemo_cast_bf16_split3(int64_t rows, int64_t cols, const float* src, int64_t lds, uint16_t* dst, int64_t ldd,
+                              int32_t order, void* stream);
 /* Up to NEMO_GEMM_GROUP_MAX independent products C_i (op)= alpha_i * opA(A_i) @ opB(B_i) (out_mode 0 store / 1 C +=; no
  * bias / activation / mask) in ONE launch when they share a layout and their operands are 16-byte aligned -- the
  * parameter gradients dW_l = dY_l^T X_l of the whole MotionNet backward (nemo/neural_motion_model.py:58-71,130-148 under

@@ -32,7 +32,7 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 11        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 12        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -47,6 +47,7 @@ SIGNATURES = {
     'nemo_gemm_f32_b16out': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, ptr, i64, ptr, i64,
                                    ptr]),
     'nemo_cast_bf16': (i32, [i64, i64, ptr, i64, ptr, i64, i32, ptr]),
+    'nemo_cast_bf16_split3': (i32, [i64, i64, ptr, i64, ptr, i64, i32, ptr]),
     'nemo_gemm_grouped_f32': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),
     'nemo_gemm_grouped_bf16': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),
     'nemo_colsum_f32': (i32, [ptr, i64, i64, i64, ptr, ptr]),

@@ -846,8 +846,11 @@ extern "C" int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint
     // The parameter gradients (K = samples) only from 24 576 samples on (65 537: 235 / 363; 12 001: 63 / 67, 8193: 55 / 46):
     // every workgroup streams its own K slice there and a CU pulls ~40 GB/s.
     static const bool no_b16x = getenv("NEMO_B16X") != nullptr && atoi(getenv("NEMO_B16X")) == 0;
-    const bool wide = M >= 3072 && N >= 512 && K >= 64;
-    const bool deep = K >= 24576 && M >= 512 && N >= 512 && M * N <= 2048L * 2048 && !Cb && !CbT && !colsum;
+    // (N >= 768: the 512-wide VPoser layers run beside the key-point branch of the step; a kernel that takes whole CUs -- 120+ KiB
+    //  of LDS, 768 threads -- got 100 us there for what the 64 x 64 kernel does in 65)
+    static const long deep_k = getenv("NEMO_B16X_DEEP_K") ? atol(getenv("NEMO_B16X_DEEP_K")) : 24576;
+    const bool wide = M >= 3072 && N >= 768 && K >= 64;
+    const bool deep = K >= deep_k && M >= 512 && N >= 512 && M * N <= 2048L * 2048 && !Cb && !CbT && !colsum;
     if (!no_b16x && (wide || deep) && (mask_mode == 0 || (mask_mode == 17 && mask)) && out_mode != 2 &&
         (!Cb || ((ldcb & 7) == 0 && ldcb >= (N + 7) / 8 * 8 && (((uintptr_t)Cb) & 15) == 0)) &&
         (!CbT || ((ldcbt & 7) == 0 && ldcbt >= (M + 7) / 8 * 8 && (((uintptr_t)CbT) & 15) == 0)) &&
@@ -937,6 +940,36 @@ extern "C" int32_t nemo_cast_bf16(int64_t rows, int64_t cols, const float* src, 
     dim3 grid(nemo_cdiv(transpose ? cols : pad_to, 32), nemo_cdiv(transpose ? pad_to : rows, 32));
     hipLaunchKernelGGL(cast_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (long)rows, (long)cols, src, (long)lds,
                        dst, (long)ldd, (int)transpose, pad_to);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+namespace {
+// dst row = [hi | lo | hi] (order 0) or [hi | hi | lo] (order 1), hi = bf16(x), lo = bf16(x - hi); segments of `seg` columns
+__global__ __launch_bounds__(256) void cast_bf16_split3_kernel(long rows, long cols, long seg, const float* __restrict__ src, long lds,
+                                                               unsigned short* __restrict__ dst, long ldd, int order) {
+    const long c = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const long r = (long)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= rows || c >= seg) return;
+    const float x = c < cols ? src[r * lds + c] : 0.f;
+    const __bf16 hi = (__bf16)x;
+    const __bf16 lo = (__bf16)(x - (float)hi);
+    const unsigned short h = __builtin_bit_cast(unsigned short, hi), l = __builtin_bit_cast(unsigned short, lo);
+    unsigned short* d = dst + r * ldd + c;
+    d[0] = h;
+    d[seg] = order ? h : l;
+    d[2 * seg] = order ? l : h;
+}
+}  // namespace
+
+extern "C" int32_t nemo_cast_bf16_split3(int64_t rows, int64_t cols, const float* src, int64_t lds, uint16_t* dst, int64_t ldd,
+                                         int32_t order, void* stream) {
+    const long seg = (cols + 7) / 8 * 8;
+    if (rows < 0 || cols < 0 || !src || !dst || lds < cols || ldd < 3 * seg || (order != 0 && order != 1)) return NEMO_EINVAL;
+    if (rows == 0 || cols == 0) return NEMO_OK;
+    dim3 grid(nemo_cdiv(seg, 64), nemo_cdiv(rows, 4));
+    hipLaunchKernelGGL(cast_bf16_split3_kernel, grid, dim3(256), 0, (hipStream_t)stream, (long)rows, (long)cols, seg, src, (long)lds,
+                       dst, (long)ldd, (int)order);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

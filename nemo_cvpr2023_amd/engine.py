@@ -353,6 +353,9 @@ class FitEngine:
 
     # ------------------------------------------------------------------ workspaces
     DW_ASIDE_ROWS = 65536           # fp32 chain: hidden-layer parameter-gradient products on the side stream up to this many rows
+    # bf16 chain: the first layer (K = 105) and its two backward products on the chain's bf16 kernels too (round 5; False: fp32
+    # products over nn.Linear(105, h)'s unaligned rows, rounds 3 - 4); NEMO_B16_FIRST_LAYER=0 restores that
+    B16_FIRST_LAYER = os.environ.get('NEMO_B16_FIRST_LAYER', '1') != '0'
     B16_DW_ASIDE_ROWS = 10000       # bf16 chain: parameter-gradient products on the side stream up to this many rows
     SMALL_BATCH_ROWS = 1024  # backward_mlp: below this many rows the dW GEMMs run beside the dX chain
     GROUPED_DW_ROWS = 400    # ... and up to this many as ONE grouped launch behind it (a one-instance shard)
@@ -419,6 +422,10 @@ class FitEngine:
                      dE_ab=Zb(N, 512))
             for k in ('H1', 'H2', 'H3', 'dH', 'dH_b', 'dH_c'):
                 w[k + 'b'], w[k + 'bT'] = Zb(N + 1, hp), Zb(h, rp)
+            # the network input (RBF features + code) as bf16, plain and transposed: first layer on the bf16 chain (round 5)
+            # (forward: three bf16 pieces per row -- [hi | lo | hi] against the weight's [hi | hi | lo]: the first layer's product in
+            #  fp32-equivalent split precision; backward: the plain transposed copy)
+            w['Xs'], w['XbT'] = Zb(N + 1, 3 * r8(self.din)), Zb(self.din, rp)
             # per-band column sums of the two hidden activation gradients (nemo_gemm_bf16mem(colsum)): their bias gradients
             R = int(self.lib.nemo_gemm_colsum_rows(N + 1))
             w['cs4'], w['cs2'], w['cs0'] = Z(R, h), Z(R, h), Z(R, h)
@@ -535,6 +542,13 @@ class FitEngine:
                         'head': torch.zeros(147, r8(h), **i16), '0T': torch.zeros(self.din, r8(h), **i16),
                         '2T': torch.zeros(h, r8(h), **i16), '4T': torch.zeros(h, r8(h), **i16), 'headT': torch.zeros(h, 152, **i16)}
         shapes = (('2', lm + 'net.net.2.weight', h, h), ('4', lm + 'net.net.4.weight', h, h), ('head', lm + 'rot_out.weight', 147, h))
+        if self.B16_FIRST_LAYER:
+            if '0s' not in self._wb:
+                self._wb['0s'] = torch.zeros(h, 3 * ((self.din + 7) // 8 * 8), dtype=torch.int16, device=self.device)
+            check(self.lib.nemo_cast_bf16_split3(h, self.din, self.p(lm + 'net.net.0.weight'), self.din, self._wb['0s'].data_ptr(),
+                                                 self._wb['0s'].stride(0), 1, _stream()), 'nemo_cast_bf16_split3')
+            if transposed:
+                self._cast(h, self.din, self.p(lm + 'net.net.0.weight'), self.din, self._wb['0T'], 1)
         for key, name, fo, fi in shapes:
             for tr in ((0, 1) if transposed == 'both' else (1,) if transposed else (0,)):
                 self._cast(fo, fi, self.p(name), fi, self._wb[key + ('T' if tr else '')], tr)
@@ -557,12 +571,26 @@ class FitEngine:
         # fp32 arithmetic (its operands never qualified for the bf16 path; 2 % of the MLP's FLOPs)
         # ... and leaves its output as bf16 straight from the epilogue (nemo_gemm_f32_b16out): H1 is only ever read as the
         # bf16 operand of the next layer, of the layer-2 parameter gradient and as a ReLU mask
-        ws = self.gemm_ws[1 if main == self.side_stream else (2 if main == self.side_stream2 else 0)]
-        check(self.lib.nemo_gemm_f32_b16out(0, 1, r, h, self.din, dptr(w['X']), self.ldx, self.p(lm + 'net.net.0.weight'),
-                                            self.din, None, 0, self.p(lm + 'net.net.0.bias'), 1, w['H1b'].data_ptr(),
-                                            w['H1b'].stride(0), dptr(T('H1bT')), w['H1bT'].stride(0), ws.data_ptr(),
-                                            ws.numel() * 4, _stream()), 'nemo_gemm_f32_b16out')
-        main.wait_event(casts_done)
+        if self.B16_FIRST_LAYER:
+            # Round 5: the first layer on the chain's kernels too -- at 12 001 rows the fp32 product over nn.Linear(105, h)'s
+            # unaligned rows took 67 us on the step's critical path.  In SPLIT precision (three bf16 pieces per operand row,
+            # K = 3 x 112: hi hi + lo hi + hi lo, the fp32 product up to 2^-17): with plainly rounded inputs the pre-activations
+            # of this layer move by 2^-9, ReLU masks of the large-gradient "phase 0" row flip and single entries of the layer-0 /
+            # layer-2 weight gradients are off by 30 - 70 % of the largest entry (tools/debug/bf16_first_layer_grads.py)
+            check(self.lib.nemo_cast_bf16_split3(r, self.din, dptr(w['X']), self.ldx, w['Xs'].data_ptr(), w['Xs'].stride(0), 0,
+                                                 _stream()), 'nemo_cast_bf16_split3')
+            if train:
+                self._cast(r, self.din, dptr(w['X']), self.ldx, w['XbT'], 1)
+            main.wait_event(casts_done)
+            self.gemm16(r, h, w['Xs'].shape[1], w['Xs'], wb['0s'], None, h, bias=self.p(lm + 'net.net.0.bias'), act=1,
+                        Cb=w['H1b'], CbT=T('H1bT'))
+        else:
+            ws = self.gemm_ws[1 if main == self.side_stream else (2 if main == self.side_stream2 else 0)]
+            check(self.lib.nemo_gemm_f32_b16out(0, 1, r, h, self.din, dptr(w['X']), self.ldx, self.p(lm + 'net.net.0.weight'),
+                                                self.din, None, 0, self.p(lm + 'net.net.0.bias'), 1, w['H1b'].data_ptr(),
+                                                w['H1b'].stride(0), dptr(T('H1bT')), w['H1bT'].stride(0), ws.data_ptr(),
+                                                ws.numel() * 4, _stream()), 'nemo_gemm_f32_b16out')
+            main.wait_event(casts_done)
         # (hidden activations exist as bf16 copies only: the ReLU masks of the backward read them -- sign and zero survive
         #  the rounding --, nothing else needs the fp32 values)
         self.gemm16(r, h, h, w['H1b'], wb['2'], None, h, bias=self.p(lm + 'net.net.2.bias'), act=1,
@@ -638,19 +666,29 @@ class FitEngine:
             ev = ready()
             dW(ev, lambda: self.gemm16(h, h, r, w['dH_bbT'], w['H1bT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1))
             cs.append((dptr(w['cs2']), R, h, h, self.g(lm + 'net.net.2.bias')))
-            self.gemm16(r, h, h, w['dH_bb'], wb['2T'], dptr(w['dH_c']), h, mask=dptr(w['H1b']), ldmask=w['H1b'].stride(0),
-                        mask_mode=17, Cb=None, CbT=None, colsum=w['cs0'])
+            if self.B16_FIRST_LAYER:
+                self.gemm16(r, h, h, w['dH_bb'], wb['2T'], None, h, mask=dptr(w['H1b']), ldmask=w['H1b'].stride(0),
+                            mask_mode=17, Cb=w['dH_cb'], CbT=w['dH_cbT'], colsum=w['cs0'])
+            else:
+                self.gemm16(r, h, h, w['dH_bb'], wb['2T'], dptr(w['dH_c']), h, mask=dptr(w['H1b']), ldmask=w['H1b'].stride(0),
+                            mask_mode=17, Cb=None, CbT=None, colsum=w['cs0'])
             flush_dW()
             end_of_stage()
         if 2 not in stages:
             return
-        # layer 0: as before (see _forward_nets_b16)
         ev = ready()
-        dW(ev, lambda: self._linear_bwd_params(r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h,
-                                               self.g(lm + 'net.net.0.weight'), None))
         cs.append((dptr(w['cs0']), R, h, h, self.g(lm + 'net.net.0.bias')))
-        self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din, dptr(w['dX']), self.ldx,
-                  dense=True)
+        if self.B16_FIRST_LAYER:
+            # layer 0 on the chain as well: dW_0 = dY_0^T X over the two transposed copies, dX_0 = dY_0 W_0 over the plain copy
+            # and the transposed weight copy (fp32 results: the weight gradient and the phase / RBF / code backward's input)
+            dW(ev, lambda: self.gemm16(h, self.din, r, w['dH_cbT'], w['XbT'], self.g(lm + 'net.net.0.weight'), self.din, out_mode=1))
+            self.gemm16(r, self.din, h, w['dH_cb'], wb['0T'], dptr(w['dX']), self.ldx)
+        else:
+            # layer 0 in fp32 (see _forward_nets_b16)
+            dW(ev, lambda: self._linear_bwd_params(r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h,
+                                                   self.g(lm + 'net.net.0.weight'), None))
+            self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din, dptr(w['dX']), self.ldx,
+                      dense=True)
         if bucketed:
             self.flush_colsums()
         self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=not bucketed)

@@ -250,7 +250,7 @@ def test_gemm_with_bf16_operands_in_memory(L, M, N, K):
     assert int(ws[:4096].view(torch.int32).abs().sum()) == 0
 
 
-@pytest.mark.parametrize('M,N,K', [(12001, 1000, 1000), (4801, 1000, 152), (3100, 520, 203), (8193, 1000, 1000), (3072, 512, 64)])
+@pytest.mark.parametrize('M,N,K', [(12001, 1000, 1000), (4801, 1000, 152), (3100, 778, 203), (8193, 1000, 1000), (3072, 768, 64)])
 def test_large_tile_bf16_product(L, M, N, K):
     """The large-tile kernel of round 5 (csrc/gemm_b16x.h: 8 MFMA waves on a 192 x 256 / 128 x 256 tile + 4 loader waves; what
     nemo_gemm_bf16mem runs from 3072 rows on) against the fp32-accumulated product of the same bf16 operands: forward form

@@ -3,7 +3,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp && cd "$R"
-O=gpurun_out/r03c3n
+O=${OUT:-gpurun_out/r05/c3n}
 rm -rf $O; mkdir -p $O
 B="--no-cpu-baseline --no-torch-gpu-baseline --repeat 1 --minibatch-steps 0"
 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python3 bench.py --instances 40 --dtype bf16 --steps 10 --warmup 2 $B > $O/trace.log 2>&1
