@@ -57,7 +57,7 @@ if ROOT not in sys.path:
 
 V0, T0 = 8, 300
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks (fp32: v_mfma_f32_32x32x2_f32; bf16: 32x32x16) and HBM3E
-MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}
+MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0, 'valu_f32': 157.3}      # (valu_f32: the fp32 vector peak = the fp32 MFMA peak)
 HBM_PEAK_GBS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'traffic.json')
 # what a supervisor tries, in order (environment of the worker processes)
@@ -71,13 +71,16 @@ ATTEMPTS = [('none', {}), ('NEMO_GRAPH_COMM=0', {'NEMO_GRAPH_COMM': '0'}),
 SKIN_NNZ = 4
 
 
-def step_flops(n, nv=6890, h=1000, din=105, skin_nnz=None):
+def step_flops(n, nv=6890, h=1000, din=105, skin_nnz=None, strict=False):
     """Algorithmic FLOPs of one published-configuration update step as THIS engine formulates it (DESIGN.md
     section 4): fused mesh term (2 pose blends, 2 skinnings, vertex->joint adjoint), blend-shape adjoint, MLP
     forward + activation-gradient + parameter-gradient GEMMs, VPoser encode/decode + KL backward, the
     pre-contracted joint GEMM and its adjoint, GMM prior.  Returns (total, per-part dict)."""
     nnz = SKIN_NNZ if skin_nnz is None else skin_nnz
-    mesh = 2.0 * n * nv * (2 * 3 * 207 + 2 * 12 * (nnz if nnz <= 4 else 24) + 288)
+    # (strict: the vertex->joint adjoint dA = W^T dT priced at the weight matrix's sparsity as well -- the kernel executes it as
+    #  a dense 24-joint product on two MFMA joint tiles whatever the weights are)
+    skin = 12 * (nnz if nnz <= 4 else 24)
+    mesh = 2.0 * n * nv * (2 * 3 * 207 + 2 * skin + (skin if strict else 288))
     adj = 2.0 * n * 207 * 3 * nv
     mlp = 3 * 2.0 * (n + 1) * (din * h + 2 * h * h + h * 147)
     vposer = 2.0 * n * (63 * 512 + 512 * 64 + 32 * 512 + 512 * 512 + 512 * 126) + 2.0 * n * (64 * 512 + 512 * 63)
@@ -502,17 +505,32 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
     traffic = {}
     if os.path.exists(TRAFFIC_FILE) and skin_nnz in (None, SKIN_NNZ):      # (counters were collected on the default body model)
         traffic = json.load(open(TRAFFIC_FILE)).get(f'{V}x{T}x{cx.world}x{dtype}', {})
-    ktr = traffic.get('kernels', {}).get(tag)
+    # counters are only quoted for the kernel instantiation they were taken on (the file records it, with the commit)
+    variant = engine.mesh_kernel_variant() if tag == 'mesh_v2v_fused' else None
+    stale = variant is not None and traffic.get('kernel_variants', {}).get(tag) not in (None, variant)
+    ktr = None if stale else traffic.get('kernels', {}).get(tag)
+    busy = None if stale else traffic.get('mfma_busy', {}).get(tag)
+    # the same kernel with the adjoint dA = W^T dT priced at the weights' real sparsity (`frac_strict`)
+    f_strict = flops
+    if tag == 'mesh_v2v_fused':
+        f_strict = flops * engine.mesh_macs(strict=True) / engine.mesh_macs()
     mesh_b16 = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh']).get('bf16', 0.0)
     on_bf16 = (mesh_b16 + parts['blend_adjoint'] + parts['mlp'] + parts['vposer']) if dtype == 'bf16' else 0.0
     step_peak = f_step / (on_bf16 / MFMA_PEAK_TFLOPS['bf16'] + (f_step - on_bf16) / MFMA_PEAK_TFLOPS['f32'])
     roof = {'kernel': tag, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(kpeak, 1),
             'unit': 'TFLOP/s', 'frac': round(achieved / kpeak, 4),
+            'frac_strict': round(achieved * (f_strict / flops) / kpeak, 4),
+            'frac_strict_note': 'the vertex->joint adjoint dA = W^T dT priced at the skinning weights\' real sparsity (4 of 24 joints) '
+                                'instead of the dense 24-joint product the kernel executes; = frac for a dense body model',
+            'mfma_busy': busy, 'mfma_busy_source': traffic.get('mfma_busy_source') if busy is not None else None,
             'pipes': {d: round(f / 1e9, 2) for d, f in pipes.items()},
             'peak_note': 'fp32 MFMA peak' if len(pipes) == 1 and 'f32' in pipes else
                          'harmonic mix of the bf16 (2500) and fp32 (157.3) MFMA peaks over this kernel\'s GFLOP per pipe '
                          '(`pipes`); the fp32 skinning part bounds it',
             'traffic': ktr, 'traffic_source': traffic.get('source') if ktr else None,
+            'traffic_commit': traffic.get('commit') if ktr else None, 'traffic_kernel': variant if ktr else None,
+            'traffic_dropped': 'counters in profiles/traffic.json were taken on ' + str(traffic.get('kernel_variants', {}).get(tag)) +
+                               ', this run launches ' + str(variant) if stale else None,
             'launches': n, 'mean_launch_ms': round(mean_ms, 4), 'flops_per_launch': flops,
             'timed_in': f'{n_inst} instrumented (un-captured) steps after the timed region',
             'per_kernel_ms_per_step': {t: round(sum(a.elapsed_time(b) for a, b, _ in e_) / n_inst, 4)
@@ -645,23 +663,31 @@ def scaling_model_single_gpu(cx, headline_ms, c4_ms):
     for name, V, T, base_ms, steps in (('headline_8x300', V0, T0, headline_ms, 30), ('c4_256x1024', 256, 1024, c4_ms, 3)):
         if base_ms is None:
             continue
-        per_rank, pred = {}, {}
+        per_rank, pred, regions = {}, {}, {}
         for W in (2, 4, 8):
             try:
                 model, engine, _ = build_model(cx, V // W, T, 'f32')
 
                 def step():
                     return model.step(None, None, update=True, full_batch=True)
-                for _ in range(3):
+                for _ in range(5):
                     step()
-                dt, _ = timed(cx, step, steps)
-                per_rank[W] = round(1e3 * dt / steps, 4)
+                # two timed regions, the minimum counts (BENCH_r04: one region after 3 set-up steps caught a 73 ms stall behind
+                # the previous model's release and reported 2.9 ms for a 0.47 ms step); every step of them must be a graph replay
+                model.launch_stats['replayed'] = model.launch_stats['other'] = 0
+                regs = [1e3 * timed(cx, step, steps)[0] / steps for _ in range(2)]
+                ls = model.launch_stats
+                frac = ls['replayed'] / max(1, ls['replayed'] + ls['other'])
+                per_rank[W] = round(min(regs), 4)
+                regions[W] = {'ms_per_step': [round(r_, 4) for r_ in regs], 'graph_replay_fraction': round(frac, 3),
+                              'suspect': bool(max(regs) > 1.3 * min(regs) or frac < 1.0)}
                 pred[W] = [round(base_ms / (per_rank[W] + a_), 2) for a_ in out['assumed_allreduce_ms']]
                 release(cx, model)
             except Exception as ex:
                 per_rank[W] = {'error': repr(ex)[:200]}
             cx.wd.beat(f'scaling model {name} W={W}')
-        out[name] = {'single_gpu_ms_per_step': round(base_ms, 4), 'per_rank_compute_ms': per_rank, 'predicted_speedup': pred}
+        out[name] = {'single_gpu_ms_per_step': round(base_ms, 4), 'per_rank_compute_ms': per_rank, 'predicted_speedup': pred,
+                     'regions': regions, 'suspect': any(r_.get('suspect') for r_ in regions.values())}
     return out
 
 
@@ -671,20 +697,32 @@ def published_fit(cx):
     import torch
     from nemo_cvpr2023_amd import fit
     try:
-        model, engine, args = build_model(cx, V0, T0, 'f32')
-        args.warmup_step, args.opt_cam_step, args.n_steps = 300, 1000, 2000
-        torch.manual_seed(0)
-        # set-up outside the clock (like the capture steps of the headline): workspaces + graphs of the three phases
-        model.warmup(3); model.opt_cam(3)
-        for _ in range(3):
-            model.step(*model.draw_batch())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        res = fit.run_fit(model, args, out_dir=None, evaluate=None)
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
+        walls, runs = [], []
+        for rep in range(2):                  # the schedule twice, each on a freshly built model from the same seeds; the faster
+            model, engine, args = build_model(cx, V0, T0, 'f32')       # run is reported, both are listed
+            args.warmup_step, args.opt_cam_step, args.n_steps = 300, 1000, 2000
+            torch.manual_seed(0)
+            # set-up outside the clock (like the capture steps of the headline): workspaces + graphs of the three phases
+            model.warmup(3); model.opt_cam(3)
+            for _ in range(3):
+                model.step(*model.draw_batch())
+            torch.manual_seed(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r_ = fit.run_fit(model, args, out_dir=None, evaluate=None)
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+            runs.append(r_)
+            release(cx, model)
+            cx.wd.beat(f'published_fit run {rep}')
+        res = runs[walls.index(min(walls))]
+        wall = min(walls)
         ph = res['phase_seconds']
-        out = {'wall_seconds': round(wall, 3), 'schedule': {'warmup': 300, 'opt_cam': 1000, 'steps': 2000, 'batch': 512},
+        out = {'wall_seconds': round(wall, 3), 'wall_seconds_runs': [round(w_, 3) for w_ in walls],
+               'suspect': bool(max(walls) > 1.3 * min(walls)),
+               'final_cam_loss_runs': [r_['cam_losses'][-1] for r_ in runs],
+               'final_total_loss_runs': [r_['losses']['total_loss'][-1] for r_ in runs],
+               'schedule': {'warmup': 300, 'opt_cam': 1000, 'steps': 2000, 'batch': 512},
                'phases': {k: {'seconds': round(v, 4), 'iters': n, 'iters_per_s': round(n / v, 1), 'ms_per_iter': round(1e3 * v / n, 4)}
                           for (k, v), n in zip(ph.items(), (300, 1000, 2000))},
                'final_total_loss': res['losses']['total_loss'][-1], 'final_warmup_loss': res['warmup_losses'][-1],
@@ -692,8 +730,6 @@ def published_fit(cx):
                'note': 'fit.run_fit on 8 x 300 synthetic sequences: host-drawn batches (CPU RNG, the script\'s order), evaluation '
                        'steps at step 0 and every 500th, no checkpoints / metrics written; warm-up and camera fit run as '
                        'captured iterations whose losses are read once per phase'}
-        release(cx, model)
-        cx.wd.beat('published_fit')
         return out
     except Exception as ex:
         import traceback
@@ -702,7 +738,27 @@ def published_fit(cx):
 
 
 # ----------------------------------------------------------------------------------------------- the measuring process
+def _capture_fault(sharded, comm_inside):
+    """Fault injection for the tests of the multi-GPU fallback (NEMO_TEST_FAIL_CAPTURE = raise | exit | hang): the first capture
+    of a sharded step on rank 1 of a supervisor's first attempt raises, kills the process or hangs.  Installed into the
+    product's capture seam (neural_motion_model._capture_hook) by worker_main, only when the variable is set."""
+    fault = os.environ.get('NEMO_TEST_FAIL_CAPTURE')
+    if not fault or not sharded:
+        return
+    if fault == 'raise' and comm_inside:
+        raise RuntimeError('NEMO_TEST_FAIL_CAPTURE=raise')
+    if os.environ.get('NEMO_BENCH_ATTEMPT') == 'main0' and os.environ.get('RANK') == '1':
+        if fault == 'exit':
+            os._exit(23)
+        if fault == 'hang':
+            time.sleep(3600)
+
+
 def worker_main(opts):
+    if os.environ.get('NEMO_TEST_FAIL_CAPTURE'):
+        from nemo_cvpr2023_amd import neural_motion_model as _nmm
+        _nmm._capture_hook = _capture_fault
+        print(f"bench.py: FAULT INJECTION ARMED (NEMO_TEST_FAIL_CAPTURE={os.environ['NEMO_TEST_FAIL_CAPTURE']})", file=sys.stderr, flush=True)
     V, T = opts.instances, opts.frames
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

@@ -73,6 +73,8 @@ class SmplContext:
         # the largest number of non-zero skinning weights of any vertex (4 for the published SMPL model): at <= 4 the
         # fused mesh kernel skins with the non-zero weights only
         self.skin_nnz = int(self.lib.nemo_ctx_skin_nnz(h))
+        # which mesh-kernel variant launches bake in (part of every graph key that contains the mesh term)
+        self.skin_sparse_flag = bool(self.lib.nemo_ctx_skin_sparse(h))
 
     @property
     def skin_sparse(self):
@@ -82,6 +84,7 @@ class SmplContext:
         """Dense 24-joint skinning product (False) or the non-zero weights only (True; needs skin_nnz <= 4)."""
         torch.cuda.synchronize()
         check(self.lib.nemo_ctx_set_skin_sparse(self.handle, int(bool(enable))), 'nemo_ctx_set_skin_sparse')
+        self.skin_sparse_flag = bool(self.lib.nemo_ctx_skin_sparse(self.handle))
 
     def set_betas(self, betas):
         b = np.ascontiguousarray(np.asarray(betas, dtype=np.float32).reshape(-1)[:10])
@@ -467,22 +470,38 @@ class FitEngine:
         tagged GEMMs run on the bf16 pipe; of the fused mesh kernel the two pose blends and the vertex->joint adjoint do
         (2 x 3 x 207 + 288 of its 2 x 3 x 207 + 2 x 288 + 288 multiply-adds per vertex and sample) -- skinning and L1 stay
         fp32."""
+        # (sparse skinning -- <= 4 non-zero weights per vertex -- is fp32 FMA work on the VALU, not on a matrix pipe: its own
+        #  entry, priced at the fp32 vector peak, which equals the fp32 MFMA peak on this part)
+        valu = 0.0
+        if tag == 'mesh_v2v_fused' and self.ctx.skin_sparse_flag:
+            valu = flops * (2 * 12 * 4) / self.mesh_macs()
         if not self.bf16:
-            return {'f32': flops}
+            return {'f32': flops - valu, 'valu_f32': valu} if valu else {'f32': flops}
         if tag == 'mesh_v2v_fused':
             # (csrc/smpl.hip MODE 3: the vertex->joint adjoint -- 288 of the multiply-adds -- runs on the bf16 pipe too, as
             #  four bf16 piece products per algorithmic product)
             on16 = 2 * 3 * 207 + 288
             b16 = flops * on16 / self.mesh_macs()
-            return {'bf16': b16, 'f32': flops - b16}
+            out = {'bf16': b16, 'f32': flops - b16 - valu}
+            if valu:
+                out['valu_f32'] = valu
+            return out
         return {'bf16': flops}
 
-    def mesh_macs(self):
+    def mesh_macs(self, strict=False):
         """Multiply-adds of the fused mesh kernel per (vertex, sample): two pose blends (3 x 207 each), two skinnings and
         the vertex->joint adjoint (24 x 12).  A skinning is 24 x 12 as the dense product of lbs.py:236-241, or
-        skin_nnz x 12 on the VALU when the model's weights are sparse (<= 4 non-zero per vertex: csrc/smpl.hip SPARSE)."""
-        skin = 12 * (4 if self.ctx.skin_sparse else 24)
-        return 2 * 3 * 207 + 2 * skin + 288
+        skin_nnz x 12 on the VALU when the model's weights are sparse (<= 4 non-zero per vertex: csrc/smpl.hip SPARSE).
+        ``strict``: the adjoint dA = W^T dT priced at the weight matrix's real sparsity too (skin_nnz x 12 instead of the
+        24 x 12 the kernel's two joint tiles execute) -- bench.py's `frac_strict`."""
+        sparse = self.ctx.skin_sparse_flag
+        skin = 12 * (4 if sparse else 24)
+        return 2 * 3 * 207 + 2 * skin + (skin if strict and sparse else 288)
+
+    def mesh_kernel_variant(self):
+        """The mesh kernel instantiation this engine launches (what counter files under profiles/ are keyed by)."""
+        mode = (3 if os.environ.get('NEMO_MESH_SPLIT', '1') != '0' else 1) if self.bf16 else 0
+        return f"mesh_v2v_fused_kernel<{mode}, {'true' if self.ctx.skin_sparse_flag else 'false'}>"
 
     # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
     # recorded on the stream the kernels are launched on (torch's current stream).

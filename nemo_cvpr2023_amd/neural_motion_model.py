@@ -94,20 +94,9 @@ class ShardInfo:
         self.pad = int(pad)
 
 
-def _inject_capture_fault(sharded, comm_inside):
-    """Fault injection for the tests of bench.py's multi-GPU fallback (NEMO_TEST_FAIL_CAPTURE = raise | exit | hang): the first
-    capture of a sharded step on rank 1 of a supervisor's first attempt raises, kills the process or hangs."""
-    fault = os.environ.get('NEMO_TEST_FAIL_CAPTURE')
-    if not fault or not sharded:
-        return
-    if fault == 'raise' and comm_inside:
-        raise RuntimeError('NEMO_TEST_FAIL_CAPTURE=raise')
-    if os.environ.get('NEMO_BENCH_ATTEMPT') == 'main0' and os.environ.get('RANK') == '1':
-        if fault == 'exit':
-            os._exit(23)
-        if fault == 'hang':
-            import time
-            time.sleep(3600)
+# Seam for harnesses that want to observe or disturb a graph capture (bench.py's multi-GPU fallback tests install their fault
+# injection here): called as _capture_hook(sharded, comm_inside) right before a capture opens.  None in the product.
+_capture_hook = None
 
 
 def clip_segments(segs, lo, hi):
@@ -717,10 +706,14 @@ class MultiViewModel(nn.Module):
             gc_on = gc.isenabled()
             gc.disable()
             try:
-                _inject_capture_fault(sharded, comm_inside)
-                # (sharded: the process group's watchdog thread polls events of earlier collectives -- legal next
-                #  to a capture in 'thread_local' mode, an invalidated capture in the default 'global' mode)
-                with torch.cuda.graph(g, capture_error_mode='thread_local' if sharded else 'global'):
+                if _capture_hook is not None:
+                    _capture_hook(sharded, comm_inside)
+                # (a process group's watchdog thread polls events of earlier collectives -- legal next to a capture in
+                #  'thread_local' mode, an invalidated capture in the default 'global' mode.  Any capture of a process
+                #  that HAS a device process group takes that mode, sharded launch or not: warm-up and camera-fit
+                #  iterations of a multi-GPU run are captured too)
+                pg = torch.distributed.is_available() and torch.distributed.is_initialized()
+                with torch.cuda.graph(g, capture_error_mode='thread_local' if (sharded or pg) else 'global'):
                     fn()
             except RuntimeError as ex:
                 # e.g. a capture invalidated by another thread of the process (a collective's
@@ -870,6 +863,7 @@ class MultiViewModel(nn.Module):
         e, sh = self.engine, b.sh
         return ('step', b.N, pl.update, b.is_full, sh.kr, sh.mr, sh.vr, sh.comm is not None, sh.live, part, pl.early,
                 b.padded, e.view_cnt is not None, e.detach_articulation, e.start_global_traj_anywhere, pl.has_inst, self._weights_key(),
+                e.ctx.skin_sparse_flag,
                 tuple((s_['offset'], s_['numel']) for s_ in pl.segs) if pl.in_graph_adam else None)
 
     def _inst_term(self, sh, update):                                                 # :3864-3867
@@ -950,8 +944,9 @@ class MultiViewModel(nn.Module):
     def _run_part(self, w, b, pl, part):
         """One launch of `part` of the step: a replayed HIP graph once the variant has been seen often enough."""
         e = self.engine
-        if not pl.graphable and not b.padded:
-            return self._body(w, b, pl, b.vi, b.fi, None, part)
+        # (un-captured launches -- instrumented passes, NEMO_GRAPHS=0, counter passes under a profiler -- stage their inputs like
+        #  captured ones: the per-view counts that travel with the staged indices select the fused key-point launch, so every
+        #  way of running a step launches the same kernels)
         if part in ('all', 'head', 'k0', 'allc', 'splitc', 'bucketc'):          # the first launch of a step stages its inputs
             self._stage_indices(w, b.vi, b.fi, b.N, b.Nv if b.padded else None, full=b.is_full)
         svi, sfi = w['vi_static'][:b.N], w['fi_static'][:b.N]
@@ -1278,7 +1273,8 @@ class MultiViewModel(nn.Module):
             for o in opts:
                 segs += o.segments(active)
             table = e.adam_table_sync(segs)
-            key = ('warmup', B, seq['gen'], tuple((s_['offset'], s_['numel']) for s_ in segs))
+            key = ('warmup', B, seq['gen'], e.ctx.skin_sparse_flag, e.start_global_traj_anywhere, e.detach_articulation,
+                   tuple((s_['offset'], s_['numel']) for s_ in segs))
             try:
                 self._captured(w, key, lambda: body(table))
             except BaseException:
@@ -1336,7 +1332,8 @@ class MultiViewModel(nn.Module):
             if graphable:
                 table = e.adam_table_sync(segs)
                 try:
-                    self._captured(w, ('opt_cam', N, seq['gen'], lt_weight, a.loss), lambda: body(table))
+                    self._captured(w, ('opt_cam', N, seq['gen'], lt_weight, a.loss, e.start_global_traj_anywhere),
+                                   lambda: body(table), sharded=sh.comm is not None)
                 except BaseException:
                     e.adam_table_invalidate()
                     raise
@@ -1421,7 +1418,7 @@ class NemoV4(NemoV3):
                 def body():
                     self._forward_backward(w, N, svi, sfi, True, use_vposer=False, detach_pose=True, sh=sh, adam_segs=table[0])
                     e.adam_from_table(*table)
-                key = ('cam4', N, e.detach_articulation, e.start_global_traj_anywhere, self._weights_key(),
+                key = ('cam4', N, e.detach_articulation, e.start_global_traj_anywhere, self._weights_key(), e.ctx.skin_sparse_flag,
                        e.view_cnt is not None, tuple((s_['offset'], s_['numel']) for s_ in segs))
                 try:
                     self._captured(w, key, body)
