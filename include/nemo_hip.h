@@ -29,6 +29,17 @@ extern "C" {
 #define NEMO_ABI_VERSION 12
 int32_t nemo_abi_version(void);
 
+/* Deterministic accumulation (round 5).  Every sum over the blocks of a launch that used float atomics until round 4 -- the
+ * per-view loss / camera-gradient sums of the key-point kernels (nemo/neural_motion_model.py:3551-3558, :3073-3124 under
+ * autograd), the phase-network gradients, bias column sums, the scalar losses -- is now added in a FIXED order by the launch's
+ * last-arriving block from per-block deposits in a scratch the library owns (allocated by nemo_ctx_create, 160 MB): the same
+ * inputs give the same bits, run to run.  Every launch takes its own region of the scratch (bump allocation);
+ * nemo_reduce_scratch_reset() rewinds the allocator -- call it at the top of every step, from the host thread that enqueues the
+ * step (the launches of a step then own distinct regions; a captured HIP graph keeps the regions it was captured with; two
+ * steps must not be IN FLIGHT at once on different streams).  A launch that finds the scratch exhausted falls back to the
+ * atomics of rounds 1 - 4 (correct, not bit-reproducible); NEMO_ORDERED_REDUCE=0 forces that. */
+int32_t nemo_reduce_scratch_reset(void);
+
 /* ------------------------------------------------------------------------------------------
  * Dense fp32 contraction on the matrix cores (v_mfma_f32_32x32x2_f32), fused epilogue:
  *   C (op)= maskfn( act( alpha * opA(A) @ opB(B) + bias[n] ) )

@@ -37,6 +37,7 @@ ABI_VERSION = 12        # NEMO_ABI_VERSION of include/nemo_hip.h this binding wa
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
     'nemo_abi_version': (i32, []),
+    'nemo_reduce_scratch_reset': (i32, []),
     'nemo_gemm_f32': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32,
                             f32, i32, i32, ptr, i64, ptr]),
     'nemo_gemm_bf16': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32,

@@ -34,3 +34,78 @@ __device__ __forceinline__ float block_sum(float v, float* red /* >= 16 floats L
         for (int i = 0; i < nw; ++i) t += red[i];
     return t;
 }
+
+// ---- ordered (deterministic) accumulation across the blocks of a launch (round 5) ------------------------------------------
+// Until round 4 per-view loss / camera / phase-network sums, bias column sums and the loss scalars were accumulated with
+// float atomicAdd: the order of the additions, and with it the last bits of every sum, changed from run to run (1000 camera
+// iterations at lr 0.1 amplified that to 4 % of the final camera loss).  Now every block deposits its partial value(s) in a
+// region of a library-owned scratch, takes a ticket, and the LAST-ARRIVING block sums the deposits in a fixed order and is the
+// only writer of the outputs -- the scheme the fused mesh kernel and the split-K GEMMs already used.
+//
+// Host side: nemo_red_take(floats, tickets) hands out a region per launch (bump allocation over a buffer allocated once in
+// nemo_ctx_create; nemo_reduce_scratch_reset() -- called by the engine at the top of every step -- rewinds it, so the launches
+// of a step own distinct regions and a captured graph keeps the ones it was captured with).  Tickets are zero between
+// launches (the last arriver resets its own).  When the scratch is exhausted or absent the region is {nullptr, nullptr} and
+// the kernels fall back to the atomics.
+struct NemoRed { float* part; int* ticket; };
+NemoRed nemo_red_take(size_t part_floats, int n_tickets);
+bool nemo_red_ensure();                 // allocates the scratch (never inside a stream capture: nemo_ctx_create calls it)
+
+#ifdef __HIPCC__
+// Every thread of the block calls this after the block's deposits (plain stores).  True in every thread of the LAST block to
+// arrive on ticket `tk` (of `nblk`): the others' deposits are then visible to its plain loads.  Placement-independent
+// hand-off (cdna_hip_programming.md G16): stores -> vmcnt(0) -> barrier -> one-lane agent release + vmcnt(0) -> ticket;
+// consumer: one-lane agent acquire -> barrier.
+__device__ __forceinline__ bool nemo_red_arrive(const NemoRed& r, int tk, int nblk, int* lds_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *lds_flag = __hip_atomic_fetch_add(r.ticket + tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (*lds_flag != nblk - 1) return false;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(r.ticket + tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+    }
+    __syncthreads();
+    return true;
+}
+
+// *out += scale-free sum over the blocks of a launch of the value `t` (valid in thread 0 of each block; block `blk` of `nblk`),
+// added in block order by the last arriver (thread i takes deposits i, i + blockDim, ...; then block_sum's fixed tree).
+// red: >= 16 floats of LDS, flag: one LDS int.  Every thread of the block must call it (barriers inside).
+__device__ __forceinline__ void nemo_red_scalar(float t, float* out, const NemoRed& r, int blk, int nblk, float* red, int* flag) {
+    if (!r.part) {
+        if (threadIdx.x == 0 && t != 0.f) atomicAdd(out, t);
+        return;
+    }
+    if (threadIdx.x == 0) r.part[blk] = t;
+    if (!nemo_red_arrive(r, 0, nblk, flag)) return;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) a += r.part[i];
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) *out += a;
+}
+
+// Column sums: block (strip, chunk) holds the sums of 64 columns over its row chunk in threads 0 .. 63 (`t`; column n, valid
+// while n < N); out[n] += the strip's chunks in chunk order.  Ticket `tk` is the strip's.
+__device__ __forceinline__ void nemo_colsum_finish(float t, long n, long N, float* out, const NemoRed& rr, int strip, int n_strips, int chunk,
+                                              int n_chunks, int tk, int* flag) {
+    if (!rr.part) {
+        if (threadIdx.x < 64 && n < N) atomicAdd(out + n, t);
+        return;
+    }
+    float* dep = rr.part + ((size_t)strip * n_chunks) * 64;
+    if (threadIdx.x < 64) dep[(size_t)chunk * 64 + threadIdx.x] = t;
+    if (!nemo_red_arrive(rr, tk, n_chunks, flag)) return;
+    if (threadIdx.x < 64 && n < N) {
+        float a = 0.f;
+        for (int c = 0; c < n_chunks; ++c) a += dep[(size_t)c * 64 + threadIdx.x];
+        out[n] += a;
+    }
+}
+
+#endif

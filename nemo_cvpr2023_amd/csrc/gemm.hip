@@ -1072,7 +1072,7 @@ extern "C" int32_t nemo_gemm_grouped_bf16(int32_t n, const nemo_gemm_problem* pr
 // Column sums of a row-major (M x N) matrix: out[n] (+)= sum_m X[m][n].  Bias gradients.
 namespace {
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long M, long N, long ldx,
-                                                     float* __restrict__ out, long rows_per_block) {
+                                                     float* __restrict__ out, long rows_per_block, NemoRed rr) {
     const long n = (long)blockIdx.x * 64 + (threadIdx.x & 63);
     const long mbeg = (long)blockIdx.y * rows_per_block;
     const long mend = min(M, mbeg + rows_per_block);
@@ -1080,33 +1080,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     if (n < N)
         for (long m = mbeg + (threadIdx.x >> 6); m < mend; m += 4) s += X[m * ldx + n];
     __shared__ float red[4][64];
+    __shared__ int rflag;
     red[threadIdx.x >> 6][threadIdx.x & 63] = s;
     __syncthreads();
-    if (threadIdx.x < 64 && n < N) {
-        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(out + n, t);
-    }
+    const float t = threadIdx.x < 64 ? red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x] : 0.f;
+    nemo_colsum_finish(t, n, N, out, rr, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y, (int)blockIdx.x, &rflag);
 }
 }  // namespace
 
 namespace {
 struct ColsumBatch { nemo_colsum_desc d[NEMO_COLSUM_MAX]; };
-__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumBatch b, long rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumBatch b, long rows_per_block, NemoRed rr) {
     const nemo_colsum_desc d = b.d[blockIdx.z];
     const long n = (long)blockIdx.x * 64 + (threadIdx.x & 63);
     const long mbeg = (long)blockIdx.y * rows_per_block;
-    if (mbeg >= d.M || (long)blockIdx.x * 64 >= d.N) return;       // block-uniform
+    if ((long)blockIdx.x * 64 >= d.N || d.M <= 0) return;           // block-uniform
+    // (a matrix shorter than the launch's tallest: its row chunks beyond M deposit zeros -- every strip sees gridDim.y arrivals)
     const long mend = min((long)d.M, mbeg + rows_per_block);
     float s = 0.f;
     if (n < d.N)
         for (long m = mbeg + (threadIdx.x >> 6); m < mend; m += 4) s += d.X[m * d.ldx + n];
     __shared__ float red[4][64];
+    __shared__ int rflag;
     red[threadIdx.x >> 6][threadIdx.x & 63] = s;
     __syncthreads();
-    if (threadIdx.x < 64 && n < d.N) {
-        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        atomicAdd(d.out + n, t);
-    }
+    const float t = threadIdx.x < 64 ? red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x] : 0.f;
+    const int strip = (int)(blockIdx.z * gridDim.x + blockIdx.x);
+    nemo_colsum_finish(t, n, d.N, d.out, rr, strip, (int)(gridDim.x * gridDim.z), (int)blockIdx.y, (int)gridDim.y, strip, &rflag);
 }
 }  // namespace
 
@@ -1124,7 +1124,8 @@ extern "C" int32_t nemo_colsum_multi(int32_t n, const nemo_colsum_desc* descs, v
     if (maxM == 0 || maxN == 0) return NEMO_OK;
     const long rows_per_block = 128;
     dim3 grid(nemo_cdiv(maxN, 64), nemo_cdiv(maxM, rows_per_block), n);
-    hipLaunchKernelGGL(colsum_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, b, rows_per_block);
+    hipLaunchKernelGGL(colsum_multi_kernel, grid, dim3(256), 0, (hipStream_t)stream, b, rows_per_block,
+                       nemo_red_take((size_t)grid.x * grid.y * grid.z * 64, (int)(grid.x * grid.z)));
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -1137,7 +1138,7 @@ extern "C" int32_t nemo_colsum_f32(const float* X, int64_t M, int64_t N, int64_t
     const long rows_per_block = 256;
     dim3 grid(nemo_cdiv(N, 64), nemo_cdiv(M, rows_per_block));
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (long)M, (long)N,
-                       (long)ldx, out, rows_per_block);
+                       (long)ldx, out, rows_per_block, nemo_red_take((size_t)grid.x * grid.y * 64, (int)grid.x));
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -451,7 +451,7 @@ __device__ __forceinline__ void phase_bwd_fused_body(
     const float* __restrict__ scales, long ldp, const float* __restrict__ log_sigmas, int kid,
     const float* __restrict__ phase, const float* __restrict__ den_ws, const float* __restrict__ dX, long ldx,
     float* __restrict__ d_shifts, float* __restrict__ d_scales, float* __restrict__ d_log_sigmas,
-    float* __restrict__ d_codes, int nAB, int spb) {
+    float* __restrict__ d_codes, int nAB, int spb, NemoRed rr, int rc) {
     __shared__ float red[16];
     __shared__ float cx[PH_SPB], cy[PH_SPB], cz[PH_SPB], co[PH_SPB];
     __shared__ long cv[PH_SPB];
@@ -532,20 +532,42 @@ __device__ __forceinline__ void phase_bwd_fused_body(
         }
     }
     __syncthreads();
-    // ---- stage B: lanes own the nodes; relu'(0) = 0 as in torch
+    // ---- stage B: lanes own the nodes; relu'(0) = 0 as in torch.  A group of Kp lanes walks samples grp, grp + ngrp, ... and
+    // sums each RUN of samples of one view.  Round 5 (deterministic, common.h): the first `rc` runs of a (block, group) are
+    // deposited as entries (view, d shifts[K], d scales[K]) in the launch's scratch instead of being added to the gradient
+    // with float atomics; the last-arriving block walks all entries in (block, group, run) order and is the only writer of
+    // d_shifts / d_scales.  Runs beyond `rc` (a random batch with more view changes than the scratch holds) and launches
+    // without scratch keep the atomics.
     int Kp = 16;
     while (Kp < K && Kp < 256) Kp <<= 1;
     const int ngrp = 256 / Kp, grp = threadIdx.x / Kp;
+    const bool ord = rr.part != nullptr && rc > 0;
+    const int nvb = nAB * ngrp, vb = bid * ngrp + grp;
+    int* const nruns = reinterpret_cast<int*>(rr.part);                       // [nvb]
+    int* const ev = nruns + nvb;                                             // [nvb][rc]
+    float* const eg = rr.part + (((size_t)nvb * (1 + rc) + 3) & ~(size_t)3);  // [nvb][rc][2][K]
+    int runs_total = 0;
     for (int k = threadIdx.x % Kp; k < K; k += Kp) {
         long cur = -1;
+        int run = 0;
         float shr = 0.f, scr = 0.f, shp = 0.f, scp = 0.f, d0 = 0.f, d1 = 0.f, gsh = 0.f, gsc = 0.f;
+        auto flush = [&]() {
+            const float vsh = shr > 0.f ? gsh : 0.f, vsc = scr > 0.f ? gsc : 0.f;
+            if (ord && run < rc) {
+                const size_t e = (size_t)vb * rc + run;
+                eg[(e * 2) * K + k] = vsh;
+                eg[(e * 2 + 1) * K + k] = vsc;
+                if (k == threadIdx.x % Kp && threadIdx.x % Kp == 0) ev[e] = (int)cur;
+            } else {
+                if (vsh != 0.f) atomicAdd(d_shifts + cur * ldp + k, vsh);
+                if (vsc != 0.f) atomicAdd(d_scales + cur * ldp + k, vsc);
+            }
+            ++run;
+        };
         for (int i = grp; i < ns; i += ngrp) {
             const long v = cv[i];
             if (v != cur) {
-                if (cur >= 0) {
-                    if (shr > 0.f && gsh != 0.f) atomicAdd(d_shifts + cur * ldp + k, gsh);
-                    if (scr > 0.f && gsc != 0.f) atomicAdd(d_scales + cur * ldp + k, gsc);
-                }
+                if (cur >= 0) flush();
                 cur = v; gsh = 0.f; gsc = 0.f;
                 shr = shifts[v * ldp + k]; scr = scales[v * ldp + k];
                 shp = fmaxf(shr, 0.f); scp = fmaxf(scr, 0.f);
@@ -558,10 +580,32 @@ __device__ __forceinline__ void phase_bwd_fused_body(
             gsc += wy * (x - shp) + wz * (0.f - shp) + wo * (1.f - shp);
             gsh -= (wy + wz + wo) * scp;
         }
-        if (cur >= 0) {
-            if (shr > 0.f && gsh != 0.f) atomicAdd(d_shifts + cur * ldp + k, gsh);
-            if (scr > 0.f && gsc != 0.f) atomicAdd(d_scales + cur * ldp + k, gsc);
+        if (cur >= 0) flush();
+        runs_total = run;
+    }
+    if (!ord) return;
+    if (threadIdx.x % Kp == 0) nruns[vb] = runs_total < rc ? runs_total : rc;
+    __shared__ int rflag;
+    if (!nemo_red_arrive(rr, 0, nAB, &rflag)) return;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        int cur = -1;
+        float ash = 0.f, asc = 0.f;
+        auto put = [&]() {
+            if (cur < 0) return;
+            if (ash != 0.f) d_shifts[(long)cur * ldp + k] += ash;
+            if (asc != 0.f) d_scales[(long)cur * ldp + k] += asc;
+        };
+        for (int b = 0; b < nvb; ++b) {
+            const int n = nruns[b];
+            for (int r = 0; r < n; ++r) {
+                const size_t e = (size_t)b * rc + r;
+                const int v = ev[e];
+                if (v != cur) { put(); cur = v; ash = 0.f; asc = 0.f; }
+                ash += eg[(e * 2) * K + k];
+                asc += eg[(e * 2 + 1) * K + k];
+            }
         }
+        put();
     }
 }
 struct PhaseBwdArgs {
@@ -569,17 +613,18 @@ struct PhaseBwdArgs {
     const float* shifts; const float* scales; long ldp; const float* log_sigmas; int kid; const float* phase;
     const float* den_ws; const float* dX; long ldx; float* d_shifts; float* d_scales; float* d_log_sigmas; float* d_codes;
     int nAB, spb;
+    NemoRed rr; int rc;             // ordered accumulation of d shifts / d scales: scratch region, run entries per (block, group)
 };
 #define PHASE_BWD_CALL(a, bid) phase_bwd_fused_body(bid, a.N, a.V, a.T, a.K, a.D, a.C, a.view_idx, a.frame_idx, a.raw_phase, \
     a.shifts, a.scales, a.ldp, a.log_sigmas, a.kid, a.phase, a.den_ws, a.dX, a.ldx, a.d_shifts, a.d_scales, a.d_log_sigmas, \
-    a.d_codes, a.nAB, a.spb)
+    a.d_codes, a.nAB, a.spb, a.rr, a.rc)
 __global__ __launch_bounds__(256) void phase_bwd_fused_kernel(PhaseBwdArgs a) { PHASE_BWD_CALL(a, (int)blockIdx.x); }
 
 // The phase backward with the step's batched bias column sums (nemo_colsum_multi: out[n] += sum_m X[m][n] for up to
 // NEMO_COLSUM_MAX matrices) in further blocks of the same grid: both only need the activation gradients the dX chain has
 // produced, and as a launch of its own the column-sum pass sat behind the last parameter-gradient GEMM on the side stream, at
 // the very end of the backward.
-struct ColsumBatchP { nemo_colsum_desc d[NEMO_COLSUM_MAX]; int n; int gx, gy; long rows_per_block; };
+struct ColsumBatchP { nemo_colsum_desc d[NEMO_COLSUM_MAX]; int n; int gx, gy; long rows_per_block; NemoRed rr; };
 __global__ __launch_bounds__(256) void phase_bwd_colsum_kernel(PhaseBwdArgs a, int n_phase, ColsumBatchP cb) {
     if ((int)blockIdx.x < n_phase) { PHASE_BWD_CALL(a, (int)blockIdx.x); return; }
     const int lin = (int)blockIdx.x - n_phase;
@@ -587,7 +632,7 @@ __global__ __launch_bounds__(256) void phase_bwd_colsum_kernel(PhaseBwdArgs a, i
     const nemo_colsum_desc d = cb.d[bz];
     const long n = (long)bx * 64 + (threadIdx.x & 63);
     const long mbeg = (long)by * cb.rows_per_block;
-    if (mbeg >= d.M || (long)bx * 64 >= d.N) return;                 // block-uniform
+    if ((long)bx * 64 >= d.N || d.M <= 0) return;                    // block-uniform (chunks beyond a shorter matrix deposit zeros)
     const long mend = min((long)d.M, mbeg + cb.rows_per_block);
     float sacc = 0.f;
     if (n < d.N) {
@@ -603,10 +648,12 @@ __global__ __launch_bounds__(256) void phase_bwd_colsum_kernel(PhaseBwdArgs a, i
         sacc += s1 + s2 + s3;
     }
     __shared__ float redc[4][64];
+    __shared__ int rflagc;
     redc[threadIdx.x >> 6][threadIdx.x & 63] = sacc;
     __syncthreads();
-    if (threadIdx.x < 64 && n < d.N)
-        atomicAdd(d.out + n, redc[0][threadIdx.x] + redc[1][threadIdx.x] + redc[2][threadIdx.x] + redc[3][threadIdx.x]);
+    const float t = threadIdx.x < 64 ? redc[0][threadIdx.x] + redc[1][threadIdx.x] + redc[2][threadIdx.x] + redc[3][threadIdx.x] : 0.f;
+    const int strip = bz * cb.gx + bx;
+    nemo_colsum_finish(t, n, d.N, d.out, cb.rr, strip, cb.gx * cb.n, by, cb.gy, strip, &rflagc);
 }
 }  // namespace
 
@@ -629,9 +676,22 @@ static int32_t phase_bwd_launch(int64_t N, int64_t V, int64_t T, int64_t K, int6
     const long nC = (d_log_sigmas || d_codes) ? D + (d_codes ? V * C : 0) : 0;
     PhaseBwdArgs a{(long)N, (long)V, (long)T, (int)K, (int)D, (int)C, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp,
                    log_sigmas, (int)kernel_id, phase, (const float*)ws, dX, (long)ldx, d_shifts, d_scales, d_log_sigmas, d_codes,
-                   (int)nAB, spb};
+                   (int)nAB, spb, NemoRed{nullptr, nullptr}, 0};
+    if (nAB > 0) {
+        // run entries of the ordered accumulation: as many per (block, group) as a group can have, within 48 MB of the scratch
+        int Kp = 16;
+        while (Kp < K && Kp < 256) Kp <<= 1;
+        const long ngrp = 256 / Kp, nvb = nAB * ngrp;
+        long rc = (spb + ngrp - 1) / ngrp;
+        const long per = 2 * (long)K * 4;                        // bytes per entry
+        while (rc > 0 && nvb * (1 + rc) * 4 + 16 + nvb * rc * per > (48L << 20)) --rc;
+        if (rc > 0) {
+            a.rr = nemo_red_take((size_t)(nvb * (1 + rc) + 4 + nvb * rc * 2 * K), 1);
+            a.rc = (int)rc;
+        }
+    }
     ColsumBatchP cb;
-    cb.n = 0; cb.gx = cb.gy = 0; cb.rows_per_block = 64;
+    cb.n = 0; cb.gx = cb.gy = 0; cb.rows_per_block = 64; cb.rr = NemoRed{nullptr, nullptr};
     long maxM = 0, maxN = 0;
     for (int i = 0; i < n_cs; ++i) {
         if (descs[i].M < 0 || descs[i].N < 0 || !descs[i].X || !descs[i].out) return NEMO_EINVAL;
@@ -643,6 +703,7 @@ static int32_t phase_bwd_launch(int64_t N, int64_t V, int64_t T, int64_t K, int6
     if (n_cs && maxM > 0 && maxN > 0) {
         cb.n = n_cs; cb.gx = (int)nemo_cdiv(maxN, 64); cb.gy = (int)nemo_cdiv(maxM, cb.rows_per_block);
         ncs = (long)cb.gx * cb.gy * n_cs;
+        cb.rr = nemo_red_take((size_t)ncs * 64, cb.gx * n_cs);
     }
     if (nAB + nC + ncs == 0) return NEMO_OK;
     if (ncs == 0)

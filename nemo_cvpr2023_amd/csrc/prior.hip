@@ -1,5 +1,6 @@
 // Pose priors and the fused optimiser: VPoser KL term, GMM max-mixture prior, robust 3-D pose loss,
 // multi-segment Adam.  Each loss kernel produces its (upstream-free) gradient in the same pass.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/nemo_hip.h"
 
@@ -9,8 +10,9 @@ namespace {
 // (torch.distributions.kl._kl_normal_normal; vposer_model.py:55; nemo/neural_motion_model.py:2795-2802)
 __global__ __launch_bounds__(256) void kl_kernel(long N, int L, const float* __restrict__ mulv, long ld,
                                                  float* __restrict__ out, float* __restrict__ d, long ldd,
-                                                 const int64_t* __restrict__ n_valid) {
+                                                 const int64_t* __restrict__ n_valid, NemoRed rr) {
     __shared__ float red[16];
+    __shared__ int rflag;
     float acc = 0.f;
     const long total = N * L;
     const float invN = 1.f / (float)N;
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void kl_kernel(long N, int L, const float* __r
         }
     }
     const float t = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, t * invN);
+    nemo_red_scalar(t * invN, out, rr, (int)blockIdx.x, (int)gridDim.x, red, &rflag);     // (deterministic: common.h)
 }
 
 // MaxMixturePrior.  Grid = (sample blocks of 128, mixture components): a block owns ONE component,
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(GMM_TS) void gmm_grad_kernel(long N, int M, const f
                                                           float* __restrict__ out,
                                                           float* __restrict__ per_sample, float coef,
                                                           float* __restrict__ dx, long lddx,
-                                                          const int64_t* __restrict__ n_valid) {
+                                                          const int64_t* __restrict__ n_valid, NemoRed rr) {
     __shared__ __attribute__((aligned(16))) float Ps[DIM][72];
     __shared__ float xs[DIM][GMM_TS];
     __shared__ float red[16];
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(GMM_TS) void gmm_grad_kernel(long N, int M, const f
     if (m == 0) {                                             // loss value: one block row does it
         if (per_sample && live) per_sample[s] = best;
         const float tot = block_sum(live ? best : 0.f, red);
-        if (tid == 0) atomicAdd(out, tot / (float)N);
+        __shared__ int rflag;
+        nemo_red_scalar(tot / (float)N, out, rr, (int)blockIdx.x, (int)gridDim.x, red, &rflag);
     }
     const bool mine = live && best_m == m;
     if (mine) any_sel = 1;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void gmm_mfma_kernel(long N, int M, const floa
                                                        const float* __restrict__ log_nllw,
                                                        float* __restrict__ out, float* __restrict__ per_sample,
                                                        float coef, float* __restrict__ dx, long lddx,
-                                                       const int64_t* __restrict__ n_valid) {
+                                                       const int64_t* __restrict__ n_valid, NemoRed rr) {
     constexpr int DIM = 69;
     __shared__ float llw[8][16];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -234,11 +237,15 @@ __global__ __launch_bounds__(256) void gmm_mfma_kernel(long N, int M, const floa
         const float v = llw[k][l15];
         if (v < best) { best = v; best_m = k; }
     }
-    if (wid == 0) {
-        if (per_sample && live && lane < 16) per_sample[s] = best;
-        float t = (live && lane < 16) ? best : 0.f;
-        t = wave_sum(t);
-        if (lane == 0) atomicAdd(out, t / (float)N);
+    {
+        float t = 0.f;
+        if (wid == 0) {
+            if (per_sample && live && lane < 16) per_sample[s] = best;
+            t = wave_sum((live && lane < 16) ? best : 0.f);
+        }
+        __shared__ float rred[16];
+        __shared__ int rflag;
+        nemo_red_scalar(t / (float)N, out, rr, (int)blockIdx.x, (int)gridDim.x, rred, &rflag);     // (thread 0 = wave 0, lane 0)
     }
     if (!dx || !live) return;
 #pragma unroll
@@ -263,8 +270,9 @@ __global__ __launch_bounds__(256) void pose3d_kernel(long N, int dim, const floa
                                                      const int64_t* __restrict__ frame_idx, long T,
                                                      float* __restrict__ out, float scale,
                                                      float* __restrict__ dx, long lddx,
-                                                     const int64_t* __restrict__ n_valid) {
+                                                     const int64_t* __restrict__ n_valid, NemoRed rr) {
     __shared__ float red[16];
+    __shared__ int rflag;
     const long total = N * dim;
     const float inv = 1.f / (float)total;
     const float rho2 = 10000.f;
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(256) void pose3d_kernel(long N, int dim, const floa
         }
     }
     const float t = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(out, t * inv);
+    nemo_red_scalar(t * inv, out, rr, (int)blockIdx.x, (int)gridDim.x, red, &rflag);
 }
 
 struct AdamSegs {
@@ -357,6 +365,46 @@ __global__ void publish_kernel(const float* __restrict__ src, int n, float* __re
 
 }  // namespace
 
+// ---- the library-owned scratch of the ordered reductions (common.h) ----------------------------------------------------------
+namespace {
+constexpr size_t RED_PART_BYTES = 160u << 20;     // deposits (C4: key-point partials 12.6 MB + phase runs <= 64 MB + column sums 33 MB)
+constexpr size_t RED_TICKETS = 1u << 16;
+char* g_red_base = nullptr;
+size_t g_red_off = 0, g_red_tk = 0;
+}  // namespace
+
+bool nemo_red_ensure() {
+    if (g_red_base) return true;
+    static bool failed = false;
+    if (failed) return false;
+    void* p = nullptr;
+    if (hipMalloc(&p, RED_PART_BYTES + RED_TICKETS * 4) != hipSuccess || hipMemset(p, 0, RED_PART_BYTES + RED_TICKETS * 4) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        failed = true;
+        return false;
+    }
+    g_red_base = (char*)p;
+    return true;
+}
+
+NemoRed nemo_red_take(size_t part_floats, int n_tickets) {
+    static const bool off = getenv("NEMO_ORDERED_REDUCE") != nullptr && atoi(getenv("NEMO_ORDERED_REDUCE")) == 0;
+    if (off || !g_red_base || n_tickets < 1) return NemoRed{nullptr, nullptr};
+    const size_t bytes = (part_floats * 4 + 255) / 256 * 256;
+    if (g_red_off + bytes > RED_PART_BYTES || g_red_tk + (size_t)n_tickets > RED_TICKETS) return NemoRed{nullptr, nullptr};
+    NemoRed r{reinterpret_cast<float*>(g_red_base + g_red_off), reinterpret_cast<int*>(g_red_base + RED_PART_BYTES) + g_red_tk};
+    g_red_off += bytes;
+    g_red_tk += (size_t)n_tickets;
+    return r;
+}
+
+extern "C" int32_t nemo_reduce_scratch_reset(void) {
+    g_red_off = 0;
+    g_red_tk = 0;
+    return NEMO_OK;
+}
+
 extern "C" int32_t nemo_step_begin(void* z0, int64_t bytes0, void* z1, int64_t bytes1, nemo_adam_seg* segs_dev,
                                    int32_t n_seg, double beta1, double beta2, void* stream) {
     if (bytes0 < 0 || bytes1 < 0 || (bytes0 && !z0) || (bytes1 && !z1) || ((bytes0 | bytes1) & 3) ||
@@ -390,7 +438,7 @@ extern "C" int32_t nemo_kl_fwd_bwd(int64_t N, int64_t L, const float* mulv, int6
     int blocks = nemo_cdiv(N * L, 256);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(kl_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)N, (int)L, mulv,
-                       (long)ld, scalar_out, d_mulv, (long)ldd, n_valid);
+                       (long)ld, scalar_out, d_mulv, (long)ldd, n_valid, nemo_red_take(blocks, 1));
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -406,7 +454,7 @@ extern "C" int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const flo
     if (M <= 8) {
         hipLaunchKernelGGL(gmm_mfma_kernel, dim3(nemo_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, (long)N,
                            (int)M, x, (long)ldx, means, precisions, log_nllw, scalar_out, per_sample,
-                           scale / (float)N, d_x, (long)lddx, n_valid);
+                           scale / (float)N, d_x, (long)lddx, n_valid, nemo_red_take(nemo_cdiv(N, 16), 1));
         NEMO_LAUNCH_CHECK();
         return NEMO_OK;
     }
@@ -416,7 +464,7 @@ extern "C" int32_t nemo_gmm_fwd_bwd(int64_t N, int64_t M, int64_t dim, const flo
     NEMO_LAUNCH_CHECK();
     hipLaunchKernelGGL(gmm_grad_kernel<69>, grid, dim3(GMM_TS), 0, (hipStream_t)stream, (long)N, (int)M, x,
                        (long)ldx, means, precisions, ws, scalar_out, per_sample, scale / (float)N, d_x,
-                       (long)lddx, n_valid);
+                       (long)lddx, n_valid, nemo_red_take(grid.x, 1));
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -430,7 +478,7 @@ extern "C" int32_t nemo_pose3d_fwd_bwd(int64_t N, int64_t dim, const float* x, i
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(pose3d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)N, (int)dim, x,
                        (long)ldx, target, mask, view_idx, frame_idx, (long)T, scalar_out, scale, d_x,
-                       (long)lddx, n_valid);
+                       (long)lddx, n_valid, nemo_red_take(blocks, 1));
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -110,6 +110,7 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
     if (parents[0] >= 0) return NEMO_EINVAL;
     for (int i = 1; i < 24; ++i)
         if (parents[i] < 0 || parents[i] >= i) return NEMO_EINVAL;   // topological order required
+    nemo_red_ensure();                       // scratch of the ordered reductions (common.h): allocated here, never inside a capture
     nemo_ctx* c = new nemo_ctx();
     c->NV = NV;
     c->NVp = ((NV + 15) / 16) * 16;          // vertices padded to whole 16-vertex MFMA tiles
@@ -633,10 +634,54 @@ __device__ __forceinline__ float group32_sum(float v) {
     return v;
 }
 
+// Deterministic per-view sums (round 5; common.h): every sample has deposited 12 floats -- [0] its loss x confidence, [1] 1 for a
+// real (non-padding) sample, [2 .. 10] its camera gradient -- and the launch's last-arriving block adds, for every view, the
+// deposits of the view's samples IN SAMPLE ORDER to view_acc[v][0 .. 1] / d_cams[v][0 .. 8] (components [k0, k1)): the only
+// writer of those accumulators, where float atomics used to add per-block partial sums in arrival order.  A batch sorted by
+// view (every full batch) is cut into the views' ranges by binary search; any other batch is scanned per view.
+constexpr int KP_DEP = 12;
+__device__ __forceinline__ void kp_view_finish(const float* __restrict__ part, const int64_t* __restrict__ view_idx, long N, long V,
+                                               float* __restrict__ view_acc, float* __restrict__ d_cams, int k0, int k1, int* sflag) {
+    if (threadIdx.x == 0) *sflag = 1;
+    __syncthreads();
+    int ok = 1;
+    for (long s = threadIdx.x; s + 1 < N; s += blockDim.x)
+        if (view_idx[s] > view_idx[s + 1]) ok = 0;
+    if (!ok) *sflag = 0;                                   // (every writer writes 0)
+    __syncthreads();
+    const bool sorted = *sflag != 0;
+    const int nk = k1 - k0;
+    auto lower = [&](long v) {                             // first s with view_idx[s] >= v
+        long lo = 0, hi = N;
+        while (lo < hi) { const long mid = (lo + hi) >> 1; if (view_idx[mid] < v) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    for (long p = threadIdx.x; p < V * nk; p += blockDim.x) {
+        const long v = p / nk;
+        const int k = k0 + (int)(p % nk);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four interleaved chains (loads in flight), combined in a fixed order
+        if (sorted) {
+            const long lo = lower(v), hi = lower(v + 1);
+            long s = lo;
+            for (; s + 3 < hi; s += 4) {
+                a0 += part[s * KP_DEP + k]; a1 += part[(s + 1) * KP_DEP + k];
+                a2 += part[(s + 2) * KP_DEP + k]; a3 += part[(s + 3) * KP_DEP + k];
+            }
+            for (; s < hi; ++s) a0 += part[s * KP_DEP + k];
+        } else {
+            for (long s = 0; s < N; ++s)
+                if (view_idx[s] == v) a0 += part[s * KP_DEP + k];
+        }
+        const float acc = (a0 + a1) + (a2 + a3);
+        if (k < 2) { if (view_acc) view_acc[v * 2 + k] += acc; }
+        else if (acc != 0.f) d_cams[v * 9 + (k - 2)] += acc;
+    }
+}
+
 template <int LANES>
 __global__ __launch_bounds__(256) void kp_fwd_kernel(KpArgs a, KpConst kc, float* __restrict__ j3d,
                                                      float* __restrict__ p2d, float* __restrict__ loss_all,
-                                                     float* __restrict__ view_acc) {
+                                                     float* __restrict__ view_acc, NemoRed rr) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long s = t / LANES;
     const int o = (int)(t % LANES);
@@ -679,7 +724,16 @@ __global__ __launch_bounds__(256) void kp_fwd_kernel(KpArgs a, KpConst kc, float
             wsum = (l[0] + (W == 2 ? l[1] : 0.f)) * (a.mean_mode == 0 ? g[2] : 1.f);
         }
     }
-    if (view_acc) {
+    if (view_acc && rr.part) {
+        // deterministic: per-sample deposits, summed per view in sample order by the last-arriving block
+        if (LANES == 32) wsum = group32_sum(wsum);
+        if (o == 0 && s < a.N) {
+            rr.part[s * KP_DEP] = pad ? 0.f : wsum;
+            rr.part[s * KP_DEP + 1] = pad ? 0.f : 1.f;
+        }
+        __shared__ int rflag;
+        if (nemo_red_arrive(rr, 0, (int)gridDim.x, &rflag)) kp_view_finish(rr.part, a.view_idx, a.N, a.V, view_acc, nullptr, 0, 2, &rflag);
+    } else if (view_acc) {
         // one atomic per (block, view) instead of one per sample: the V x 2 accumulators are hot
         // same-address targets (300 serialised L2 atomics each at N = 2400 otherwise)
         constexpr int SPB = 256 / LANES;
@@ -731,7 +785,8 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
                                                      const int64_t* __restrict__ view_cnt = nullptr,
                                                      float* __restrict__ j3d = nullptr, float* __restrict__ p2d = nullptr,
                                                      float* __restrict__ loss_all = nullptr,
-                                                     float* __restrict__ view_acc_out = nullptr) {
+                                                     float* __restrict__ view_acc_out = nullptr,
+                                                     NemoRed rr = NemoRed{nullptr, nullptr}) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long s = t / LANES;
     const int o = (int)(t % LANES);
@@ -818,7 +873,24 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
             dpos[0] += x[0]; dpos[1] += x[1]; dpos[2] += x[2];
         }
     }
-    if (FUSED && view_acc_out) {
+    const bool ordered = rr.part != nullptr && ((FUSED && view_acc_out) || d_cams);
+    if (ordered) {
+        // deterministic per-view sums (kp_view_finish): this sample's loss, count and camera gradient as one deposit
+        float dep[11];
+        dep[0] = LANES == 32 ? group32_sum(wsum) : wsum;
+        dep[1] = (live && !pad) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dep[2 + k] = LANES == 32 ? group32_sum(dcam[k]) : dcam[k];
+        if (o == 0 && live) {
+#pragma unroll
+            for (int k = 0; k < 11; ++k) rr.part[s * KP_DEP + k] = dep[k];
+        }
+        __shared__ int rflag;
+        if (nemo_red_arrive(rr, 0, (int)gridDim.x, &rflag))
+            kp_view_finish(rr.part, a.view_idx, a.N, a.V, (FUSED && view_acc_out) ? view_acc_out : nullptr, d_cams,
+                           (FUSED && view_acc_out) ? 0 : 2, d_cams ? 11 : 2, &rflag);
+    }
+    if (!ordered && FUSED && view_acc_out) {
         // the forward's per-view accumulators [sum(loss * conf), #samples]: one atomic per (block, view), as in kp_fwd_kernel
         constexpr int SPBf = 256 / LANES;
         __shared__ float fsum[SPBf];
@@ -842,7 +914,7 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
     }
     // camera gradient: reduce over the sample's joints (shuffles), then over the block's samples of the
     // same view (LDS), one atomic per (block, view, component)
-    if (d_cams) {
+    if (!ordered && d_cams) {
         constexpr int SPBc = 256 / LANES;
         __shared__ float bcam[SPBc][9];
         __shared__ long bviewc[SPBc];
@@ -880,11 +952,26 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
         }
     }
     if (!dA) return;
-    // kinematic joints: scatter into dJp (zero-initialised by the caller)
-    if (active && kind >= 0) {
-        atomicAdd(dJp + s * 72 + kind * 3, dpos[0]);
-        atomicAdd(dJp + s * 72 + kind * 3 + 1, dpos[1]);
-        atomicAdd(dJp + s * 72 + kind * 3 + 2, dpos[2]);
+    // kinematic joints: dJp[s][j] += the position gradients of the output joints that ARE kinematic joint j, added in output
+    // order by ONE thread per (sample, joint, component) (round 5: float atomics per output joint before -- several outputs can
+    // share a joint, and the order of their additions changed from run to run)
+    __shared__ float dkin[256 / LANES][NEMO_MAX_OUT][3];
+    __shared__ int kkin[NEMO_MAX_OUT];
+    if (threadIdx.x < NEMO_MAX_OUT) kkin[threadIdx.x] = threadIdx.x < kc.n_out ? kc.out_kind[threadIdx.x] : -1;
+    if (o < kc.n_out && o < NEMO_MAX_OUT) {
+        const int slk = threadIdx.x / LANES;
+        dkin[slk][o][0] = active ? dpos[0] : 0.f; dkin[slk][o][1] = active ? dpos[1] : 0.f; dkin[slk][o][2] = active ? dpos[2] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < (256 / LANES) * 72; idx += 256) {
+        const int ls = idx / 72, j = (idx % 72) / 3, c = idx % 3;
+        const long ss = (long)blockIdx.x * (256 / LANES) + ls;
+        if (ss >= a.N) continue;
+        float acc = 0.f;
+        bool any = false;
+        for (int q = 0; q < kc.n_out; ++q)
+            if (kkin[q] == j) { acc += dkin[ls][q][c]; any = true; }
+        if (any) dJp[ss * 72 + j * 3 + c] += acc;
     }
     // mesh functionals: pos = sum_j A_R[j] Mq[q][j] + A_t[j] w0[q][j].
     // d Mq[q][j] = A_R[j]^T dpos_q is private to the (sample, joint) lane; dA[j] sums over the mesh
@@ -1854,8 +1941,9 @@ __global__ __launch_bounds__(256) void mesh_combine_kernel(long N, int nr, int m
 // of its own joint (both neighbours), no atomics except the block sums of the scalar.
 __global__ __launch_bounds__(256) void smooth_kernel(long V, long T, int J, const float* __restrict__ j3d,
                                                      float weight, float* __restrict__ scalar_out,
-                                                     float* __restrict__ dj) {
+                                                     float* __restrict__ dj, NemoRed rr) {
     __shared__ float red[16];
+    __shared__ int rflag;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     float part = 0.f;
     if (i < V * T * J) {
@@ -1875,7 +1963,7 @@ __global__ __launch_bounds__(256) void smooth_kernel(long V, long T, int J, cons
         if (dj) { dj[i * 3] = weight * g[0]; dj[i * 3 + 1] = weight * g[1]; dj[i * 3 + 2] = weight * g[2]; }
     }
     const float tot = block_sum(part, red);
-    if (threadIdx.x == 0 && tot != 0.f) atomicAdd(scalar_out, tot);
+    nemo_red_scalar(tot, scalar_out, rr, (int)blockIdx.x, (int)gridDim.x, red, &rflag);      // (deterministic: common.h)
 }
 
 }  // namespace
@@ -1947,7 +2035,7 @@ extern "C" int32_t nemo_kp_fwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_
     if (N == 0) return NEMO_OK;
     if (ctx->n_out > 32) return NEMO_EINVAL;
     hipLaunchKernelGGL(kp_fwd_kernel<32>, dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       ctx->kc, j3d, p2d, loss_all, view_acc);
+                       ctx->kc, j3d, p2d, loss_all, view_acc, view_acc ? nemo_red_take((size_t)N * KP_DEP, 1) : NemoRed{nullptr, nullptr});
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -1979,7 +2067,9 @@ static int32_t kp_bwd_impl(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T,
     if (N == 0) return NEMO_OK;
     if (ctx->n_out > 32) return NEMO_EINVAL;
     hipLaunchKernelGGL(kp_bwd_kernel<32>, dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       ctx->kc, view_acc, norm, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams, (int)ctx->nq, dj3d_extra);
+                       ctx->kc, view_acc, norm, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams, (int)ctx->nq, dj3d_extra,
+                       (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       d_cams ? nemo_red_take((size_t)N * KP_DEP, 1) : NemoRed{nullptr, nullptr});
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -2028,7 +2118,8 @@ extern "C" int32_t nemo_kp_fwd_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, in
     if (ctx->n_out > 32) return NEMO_EINVAL;
     hipLaunchKernelGGL((kp_bwd_kernel<32, true>), dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
                        ctx->kc, (const float*)nullptr, (const float*)nullptr, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams,
-                       (int)ctx->nq, (const float*)nullptr, view_count, j3d, p2d, loss_all, view_acc);
+                       (int)ctx->nq, (const float*)nullptr, view_count, j3d, p2d, loss_all, view_acc,
+                       nemo_red_take((size_t)N * KP_DEP, 1));
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -2037,7 +2128,7 @@ extern "C" int32_t nemo_smooth_fwd_bwd(int64_t V, int64_t T, int64_t J, const fl
                                        float* scalar_out, float* dj3d, void* stream) {
     if (V <= 0 || T <= 0 || J <= 0 || !j3d || !scalar_out) return NEMO_EINVAL;
     hipLaunchKernelGGL(smooth_kernel, dim3(nemo_cdiv(V * T * J, 256)), dim3(256), 0, (hipStream_t)stream, (long)V,
-                       (long)T, (int)J, j3d, weight, scalar_out, dj3d);
+                       (long)T, (int)J, j3d, weight, scalar_out, dj3d, nemo_red_take((size_t)nemo_cdiv(V * T * J, 256), 1));
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -763,6 +763,9 @@ class FitEngine:
         """K1-K5: phase warp, RBF, MLP, rot6d->R->aa.  Fills X,H1..H3,ROT,TR,R,AA.
         ``begin`` = (arena, zero_grads, n_seg): what ``step_begin`` would be called with -- done by further blocks of the
         phase kernel's launch instead of a launch of its own (nemo_phase_embed_fwd_begin)."""
+        # every pass starts here: the launches that follow take their regions of the ordered-reduction scratch from its start
+        # (include/nemo_hip.h nemo_reduce_scratch_reset: deterministic sums instead of float atomics, round 5)
+        self.lib.nemo_reduce_scratch_reset()
         L, st = self.lib, _stream()
         sh0 = self.p('phase_networks.0.shifts')
         sc0 = self.p('phase_networks.0.scales')
@@ -1313,6 +1316,7 @@ class FitEngine:
         """First launch of an iteration whose first kernel is not the phase kernel (camera fit): zero the workspace's
         accumulator arena and `grads` (a slice of the flat gradient buffer, or None) and advance the device Adam table --
         one kernel instead of two memsets and a copy."""
+        self.lib.nemo_reduce_scratch_reset()
         check(self.lib.nemo_step_begin(arena.data_ptr(), arena.numel() * 4, dptr(grads),
                                        grads.numel() * 4 if grads is not None else 0,
                                        self._seg_dev.data_ptr() if n_seg else None, n_seg, 0.9, 0.999, _stream()),
