@@ -152,17 +152,19 @@ int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t
                              int32_t kernel_id, float* X, int64_t ldx, float* phase_out, float* den_out,
                              void* stream);
 /* dX (N+1, ldx) -> d_shifts,d_scales (V rows of stride ldp), d_log_sigmas (D), d_codes (V,C); all
- * accumulated.  One launch: blocks of 32 samples reduce their per-sample coefficients per (view, node) in
- * LDS and add one partial per run of samples of a view; further blocks reduce the log_sigma / code columns.
+ * accumulated.  One launch: block (view, slice of 64 nodes) sums the phase-network gradient of its nodes over ALL samples of
+ * its view in sample order (no cross-block sum, no atomics: deterministic, round 5); further blocks reduce the log_sigma /
+ * code columns.  sorted_by_view != 0: the caller vouches that view_idx is non-decreasing (every full batch) -- a view's
+ * samples are then found by a search instead of a scan of the batch; 0 is always correct.
  * ws (N floats, optional): the `den_out` the forward call wrote for the SAME inputs (the backward then skips two
- * K-long sigmoid sums per sample); NULL: they are re-evaluated here. */
+ * K-long sigmoid sums per view); NULL: they are re-evaluated here. */
 int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t D, int64_t C,
                              const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
                              const float* shifts, const float* scales, int64_t ldp,
                              const float* log_sigmas, int32_t kernel_id, const float* phase,
                              const float* dX, int64_t ldx, float* ws,
                              float* d_shifts, float* d_scales, float* d_log_sigmas, float* d_codes,
-                             void* stream);
+                             int32_t sorted_by_view, void* stream);
 /* nemo_phase_embed_bwd and nemo_colsum_multi(n_cs, descs) (same arguments, same results) in ONE launch: the batched bias
  * column sums of the MLP backward (nemo/neural_motion_model.py:58-71 under autograd) need only the activation gradients the
  * dX chain has produced by the time the phase backward starts, so they run in further blocks of its grid instead of as a
@@ -172,7 +174,7 @@ int32_t nemo_phase_embed_bwd_colsum(int64_t N, int64_t V, int64_t T, int64_t K, 
                                     const float* shifts, const float* scales, int64_t ldp, const float* log_sigmas,
                                     int32_t kernel_id, const float* phase, const float* dX, int64_t ldx, float* ws,
                                     float* d_shifts, float* d_scales, float* d_log_sigmas, float* d_codes, int32_t n_cs,
-                                    const nemo_colsum_desc* descs /* HOST array */, void* stream);
+                                    const nemo_colsum_desc* descs /* HOST array */, int32_t sorted_by_view, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * rot6d -> rotation matrix -> axis-angle, per (row, joint).

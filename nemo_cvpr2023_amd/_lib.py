@@ -56,9 +56,9 @@ SIGNATURES = {
     'nemo_phase_embed_fwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
                                    i32, ptr, i64, ptr, ptr, ptr]),
     'nemo_phase_embed_bwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i32, ptr,
-                                   ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr]),
+                                   ptr, i64, ptr, ptr, ptr, ptr, ptr, i32, ptr]),
     'nemo_phase_embed_bwd_colsum': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i32, ptr,
-                                          ptr, i64, ptr, ptr, ptr, ptr, ptr, i32, POINTER(ColsumDesc), ptr]),
+                                          ptr, i64, ptr, ptr, ptr, ptr, ptr, i32, POINTER(ColsumDesc), i32, ptr]),
     'nemo_rot6d_fwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr]),
     'nemo_rot6d_bwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr]),
     'nemo_pose_bwd_fused': (i32, [i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, i32, ptr]),

@@ -2,6 +2,8 @@
 // All of these are tiny (O(100) flops per sample-joint); they are written one thread per
 // (sample, joint) / per (sample), with coalesced reads along the (instance x frame) batch axis,
 // and exist to replace ~100 aten launches per step of the reference by 1 each.
+#include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "rot_math.h"
 #include "../../include/nemo_hip.h"
@@ -438,12 +440,68 @@ extern "C" int32_t nemo_phase_embed_fwd_begin(int64_t N, int64_t V, int64_t T, i
 }
 
 // The whole phase / RBF / code backward in ONE launch (it sits at the end of the dX chain of every update step, and three
-// dependent launches of 4 - 12 us each were 24 us of it).  Blocks [0, nAB): stage A + B for PH_SPB consecutive samples --
-// the per-sample coefficients of stage A stay in LDS and the block reduces them per (view, node) itself: thread groups
-// of Kp >= K lanes take every (256 / Kp)-th sample, a run of samples of one view is flushed with one atomic per
-// (view, node, group).  Blocks [nAB, ...): stage C (independent of A and B: column sums of dX).
+// dependent launches of 4 - 12 us each were 24 us of it).  Blocks [0, nAB): one per (view, slice of 64 phase-network nodes) --
+// d shifts / d scales of that view's nodes over ALL samples of the view, in sample order (round 5: deterministic; see below).
+// Blocks [nAB, ...): stage C (column sums of dX: d log_sigma, d code).
 namespace {
-constexpr int PH_SPB = 32;
+constexpr int PH_LMAX = 1024;               // samples of a view per pass
+constexpr int PH_DMAX = 128;                // RBF features whose constants are tabulated in LDS
+// The backward coefficients of ONE sample, computed by the four lanes l = 0 .. 3 of a quad (all four return the result): d phase
+// over the D RBF features -- a lane's <= 32 feature gradients are requested together: one memory latency --, then, with
+// ph = num / den saved by the forward pass, (x, dy / K, (-dy - dden) / K, dden / K).
+__device__ __forceinline__ float4 phase_sample_coef(int l, long s, long T, int K, int D, int kid, const int64_t* __restrict__ frame_idx,
+                                                    const float* __restrict__ raw_phase, const float* __restrict__ log_sigmas,
+                                                    const float* __restrict__ phase, const float* __restrict__ den_ws, float den_v,
+                                                    const float* __restrict__ dX, long ldx, const float* t_ies, const float* t_ctr) {
+    const float x = raw_phase ? raw_phase[s] : lin01(frame_idx[s], T);
+    const float ph = phase[s];
+    const float* g = dX + s * ldx;
+    float dph = 0.f;
+    if (D > 0 && D <= PH_DMAX) {
+        float gv[PH_DMAX / 4];
+#pragma unroll
+        for (int u = 0; u < PH_DMAX / 4; ++u) gv[u] = (l + 4 * u) < D ? g[l + 4 * u] : 0.f;
+        // (the kernel id is a launch constant: one switch per sample, not one per feature)
+        auto feats = [&](auto kidc) {
+#pragma unroll
+            for (int u = 0; u < PH_DMAX / 4; ++u) {
+                const int d = l + 4 * u;
+                if (d < D) {
+                    const float diff = ph - t_ctr[d], ies = t_ies[d];
+                    dph += gv[u] * rbf_dphi(decltype(kidc)::value, (diff * diff) * ies) * 2.f * diff * ies;
+                }
+            }
+        };
+        switch (kid) {
+            case 0: feats(std::integral_constant<int, 0>{}); break;
+            case 1: feats(std::integral_constant<int, 1>{}); break;
+            case 2: feats(std::integral_constant<int, 2>{}); break;
+            case 3: feats(std::integral_constant<int, 3>{}); break;
+            case 4: feats(std::integral_constant<int, 4>{}); break;
+            case 5: feats(std::integral_constant<int, 5>{}); break;
+            case 6: feats(std::integral_constant<int, 6>{}); break;
+            case 7: feats(std::integral_constant<int, 7>{}); break;
+            case 8: feats(std::integral_constant<int, 8>{}); break;
+            case 9: feats(std::integral_constant<int, 9>{}); break;
+            default: feats(std::integral_constant<int, 10>{}); break;
+        }
+    } else if (D > 0) {
+        for (int d = l; d < D; d += 4) {
+            const float diff = ph - lin01(d, D);
+            const float ies = 1.f / expf(log_sigmas[d]);
+            dph += g[d] * rbf_dphi(kid, (diff * diff) * ies) * 2.f * diff * ies;
+        }
+    } else if (l == 0) {
+        dph = g[0];
+    }
+    dph += __shfl_xor(dph, 1, 64);
+    dph += __shfl_xor(dph, 2, 64);
+    const float den = den_ws ? den_ws[s] : den_v;
+    const float dy = dph / den;                      // ph = num / den
+    const float dden = -dy * ph;                     // -dph * num / den^2
+    const float invK = 1.f / (float)K;
+    return make_float4(x, dy * invK, (-dy - dden) * invK, dden * invK);
+}
 __device__ __forceinline__ void phase_bwd_fused_body(
     const int bid,
     long N, long V, long T, int K, int D, int C, const int64_t* __restrict__ view_idx,
@@ -451,10 +509,8 @@ __device__ __forceinline__ void phase_bwd_fused_body(
     const float* __restrict__ scales, long ldp, const float* __restrict__ log_sigmas, int kid,
     const float* __restrict__ phase, const float* __restrict__ den_ws, const float* __restrict__ dX, long ldx,
     float* __restrict__ d_shifts, float* __restrict__ d_scales, float* __restrict__ d_log_sigmas,
-    float* __restrict__ d_codes, int nAB, int spb, NemoRed rr, int rc) {
+    float* __restrict__ d_codes, int nAB, int sorted, int mode, float4* __restrict__ coef) {
     __shared__ float red[16];
-    __shared__ float cx[PH_SPB], cy[PH_SPB], cz[PH_SPB], co[PH_SPB];
-    __shared__ long cv[PH_SPB];
     if (bid >= nAB) {
         // ---- stage C: one block per reduced column.  b < D: d log_sigma_d over all N + 1 rows; otherwise (c, v):
         // d code[v][c] over the samples of view v
@@ -483,141 +539,152 @@ __device__ __forceinline__ void phase_bwd_fused_body(
         }
         return;
     }
-    // ---- stage A: EIGHT LANES per sample, all spb <= PH_SPB samples of the block at once -- d phase, then the coefficients
-    // of the three sigmoid sums of the phase network.  With ph = num / den saved by the forward pass the backward needs
-    // den = o - z + 1e-6 only (a per-view constant: the forward kernel hands it over in den_ws; without it the two sums
-    // are re-evaluated here).  (Round 2 walked a wave's eight samples one after the other, each behind its own chain of
-    // dependent global loads and three K-long sigmoid sums: 35 us whatever N was.)
-    const long s0 = (long)bid * spb;
-    const int ns = (int)min((long)spb, N - s0);
-    {
-        const int i = threadIdx.x >> 3, l = threadIdx.x & 7;
-        const bool live = i < ns;
-        const long s = s0 + (live ? i : 0);
-        const long v = view_idx[s];
-        const float x = raw_phase ? raw_phase[s] : lin01(frame_idx[s], T);
-        const float ph = phase[s];
-        const float* g = dX + s * ldx;
-        float dph = 0.f;
-        if (D > 0) {
-            for (int d = l; d < D; d += 8) {
-                const float diff = ph - lin01(d, D);
-                const float ies = 1.f / expf(log_sigmas[d]);
-                dph += g[d] * rbf_dphi(kid, (diff * diff) * ies) * 2.f * diff * ies;
-            }
-        } else if (l == 0) {
-            dph = g[0];
-        }
+    // ---- the phase network's gradient.  Until round 4: blocks of 32 samples, per-sample coefficients in LDS, one float atomic
+    // per (run of samples of a view, node) -- the order of the additions, and the last bits of every gradient entry, changed
+    // from run to run.  Now a block (v, ks) owns a slice of the nodes of view v outright: it finds the view's samples (a 64-ary
+    // search when the caller vouches for a batch sorted by view, otherwise an ordered compaction of a scan over the batch),
+    // takes their coefficients -- d phase over the D RBF features; with ph = num / den saved by the forward pass only
+    // den = o - z + 1e-6 is needed, a per-view constant the forward kernel hands over in den_ws -- and lets thread (node kl,
+    // sample lane sl) add samples sl, sl + NSL, ... in order; the sample lanes are combined in a fixed order.  No cross-block
+    // sum is left.  mode 1 + mode 2 (two launches): the coefficients are computed once per sample by blocks of 64 samples and
+    // read back here; mode 0 (no scratch or no den_ws): every (view, slice) block recomputes its view's coefficients.
+    // (node-sum launch: 16 nodes x 16 sample lanes per block -- four times the blocks, a quarter of the serial loop)
+    const int NK = mode == 2 ? 16 : 64, NSL = 256 / NK;
+    const int KS = (K + NK - 1) / NK;
+    const long v = bid / KS;
+    const int ks = bid % KS, kl = threadIdx.x % NK, sl = threadIdx.x / NK, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int k = ks * NK + kl;
+    const bool kok = k < K;
+    __shared__ int list[PH_LMAX];
+    __shared__ float cx[PH_LMAX], cy[PH_LMAX], cz[PH_LMAX], co[PH_LMAX];
+    __shared__ float t_ies[PH_DMAX], t_ctr[PH_DMAX];
+    __shared__ int wcnt[4];
+    __shared__ long rng[2];
+    __shared__ float gred[2][256];
+    if (mode != 2)
+        for (int d = threadIdx.x; d < D && d < PH_DMAX; d += 256) { t_ies[d] = 1.f / expf(log_sigmas[d]); t_ctr[d] = lin01(d, D); }
+    if (mode == 1) {
+        // launch 1 of 2 (mode 2 follows on the same stream): this block's 64 samples -> their coefficients, once, in `coef`.
+        // (Computed inside the per-view blocks below -- mode 0 -- a 300-sample view is five sequential passes per block and the
+        //  8 x 300 step was 45 us longer.)
+        __syncthreads();
+        const long s = (long)bid * 64 + (threadIdx.x >> 2);
+        const int l = threadIdx.x & 3;
+        const bool live = s < N;
+        const float4 c4 = phase_sample_coef(l, live ? s : 0, T, K, D, kid, frame_idx, raw_phase, log_sigmas, phase, den_ws, 1.f, dX, ldx,
+                                            t_ies, t_ctr);
+        if (live && l == 0) coef[s] = c4;
+        return;
+    }
+    const float shr = kok ? shifts[v * ldp + k] : 0.f, scr = kok ? scales[v * ldp + k] : 0.f;
+    const float shp = fmaxf(shr, 0.f), scp = fmaxf(scr, 0.f);
+    const float s0v = sigmoidf_(scp * (0.f - shp)), s1v = sigmoidf_(scp * (1.f - shp));
+    const float d0 = s0v * (1.f - s0v), d1 = s1v * (1.f - s1v);
+    float den_v = 1.f;
+    if (mode == 0 && !den_ws) {                              // (no forward hand-over: the view's two sigmoid sums)
         float z = 0.f, o = 0.f;
-        if (!den_ws) {
-            const float* sh = shifts + v * ldp;
-            const float* sc = scales + v * ldp;
-            for (int k = l; k < K; k += 8) {
-                const float shp = fmaxf(sh[k], 0.f), scp = fmaxf(sc[k], 0.f);
-                z += sigmoidf_(scp * (0.f - shp));
-                o += sigmoidf_(scp * (1.f - shp));
-            }
+        for (int q = threadIdx.x; q < K; q += 256) {
+            const float a_ = fmaxf(shifts[v * ldp + q], 0.f), b_ = fmaxf(scales[v * ldp + q], 0.f);
+            z += sigmoidf_(b_ * (0.f - a_));
+            o += sigmoidf_(b_ * (1.f - a_));
         }
-#pragma unroll
-        for (int off = 4; off > 0; off >>= 1) {
-            dph += __shfl_xor(dph, off, 64);
-            z += __shfl_xor(z, off, 64);     o += __shfl_xor(o, off, 64);
-        }
-        const float den = den_ws ? den_ws[s] : o / (float)K - z / (float)K + 1e-6f;
-        const float dy = dph / den;                          // ph = num / den
-        const float dden = -dy * ph;                         // -dph * num / den^2
-        if (l == 0 && live) {
-            const float invK = 1.f / (float)K;
-            cx[i] = x; cy[i] = dy * invK; cz[i] = (-dy - dden) * invK; co[i] = dden * invK; cv[i] = v;
-        }
+        z = block_sum(z, red);
+        __syncthreads();
+        o = block_sum(o, red);
+        if (threadIdx.x == 0) red[15] = o / (float)K - z / (float)K + 1e-6f;
+        __syncthreads();
+        den_v = red[15];
     }
     __syncthreads();
-    // ---- stage B: lanes own the nodes; relu'(0) = 0 as in torch.  A group of Kp lanes walks samples grp, grp + ngrp, ... and
-    // sums each RUN of samples of one view.  Round 5 (deterministic, common.h): the first `rc` runs of a (block, group) are
-    // deposited as entries (view, d shifts[K], d scales[K]) in the launch's scratch instead of being added to the gradient
-    // with float atomics; the last-arriving block walks all entries in (block, group, run) order and is the only writer of
-    // d_shifts / d_scales.  Runs beyond `rc` (a random batch with more view changes than the scratch holds) and launches
-    // without scratch keep the atomics.
-    int Kp = 16;
-    while (Kp < K && Kp < 256) Kp <<= 1;
-    const int ngrp = 256 / Kp, grp = threadIdx.x / Kp;
-    const bool ord = rr.part != nullptr && rc > 0;
-    const int nvb = nAB * ngrp, vb = bid * ngrp + grp;
-    int* const nruns = reinterpret_cast<int*>(rr.part);                       // [nvb]
-    int* const ev = nruns + nvb;                                             // [nvb][rc]
-    float* const eg = rr.part + (((size_t)nvb * (1 + rc) + 3) & ~(size_t)3);  // [nvb][rc][2][K]
-    int runs_total = 0;
-    for (int k = threadIdx.x % Kp; k < K; k += Kp) {
-        long cur = -1;
-        int run = 0;
-        float shr = 0.f, scr = 0.f, shp = 0.f, scp = 0.f, d0 = 0.f, d1 = 0.f, gsh = 0.f, gsc = 0.f;
-        auto flush = [&]() {
-            const float vsh = shr > 0.f ? gsh : 0.f, vsc = scr > 0.f ? gsc : 0.f;
-            if (ord && run < rc) {
-                const size_t e = (size_t)vb * rc + run;
-                eg[(e * 2) * K + k] = vsh;
-                eg[(e * 2 + 1) * K + k] = vsc;
-                if (k == threadIdx.x % Kp && threadIdx.x % Kp == 0) ev[e] = (int)cur;
-            } else {
-                if (vsh != 0.f) atomicAdd(d_shifts + cur * ldp + k, vsh);
-                if (vsc != 0.f) atomicAdd(d_scales + cur * ldp + k, vsc);
+    float gsh = 0.f, gsc = 0.f;
+    // `cnt` samples: base + i (a batch sorted by view) or list[i] (gathered)
+    auto process = [&](int cnt, long base) {
+        if (mode == 2) {                                     // coefficients from launch 1
+            for (int i = threadIdx.x; i < cnt; i += 256) {
+                const float4 c4 = coef[base >= 0 ? base + i : (long)list[i]];
+                cx[i] = c4.x; cy[i] = c4.y; cz[i] = c4.z; co[i] = c4.w;
             }
-            ++run;
-        };
-        for (int i = grp; i < ns; i += ngrp) {
-            const long v = cv[i];
-            if (v != cur) {
-                if (cur >= 0) flush();
-                cur = v; gsh = 0.f; gsc = 0.f;
-                shr = shifts[v * ldp + k]; scr = scales[v * ldp + k];
-                shp = fmaxf(shr, 0.f); scp = fmaxf(scr, 0.f);
-                const float s0v = sigmoidf_(scp * (0.f - shp)), s1v = sigmoidf_(scp * (1.f - shp));
-                d0 = s0v * (1.f - s0v); d1 = s1v * (1.f - s1v);
+        } else {                                             // four lanes per sample, 64 samples per pass
+            for (int i0 = 0; i0 < cnt; i0 += 64) {
+                const int i = i0 + (threadIdx.x >> 2), l = threadIdx.x & 3;
+                const bool live = i < cnt;
+                const long s = base >= 0 ? base + (live ? i : 0) : (long)list[live ? i : 0];
+                const float4 c4 = phase_sample_coef(l, s, T, K, D, kid, frame_idx, raw_phase, log_sigmas, phase, den_ws, den_v, dX, ldx,
+                                                    t_ies, t_ctr);
+                if (l == 0 && live) { cx[i] = c4.x; cy[i] = c4.y; cz[i] = c4.z; co[i] = c4.w; }
             }
-            const float x = cx[i];
-            const float sx = sigmoidf_(scp * (x - shp));
-            const float wy = cy[i] * sx * (1.f - sx), wz = cz[i] * d0, wo = co[i] * d1;
-            gsc += wy * (x - shp) + wz * (0.f - shp) + wo * (1.f - shp);
-            gsh -= (wy + wz + wo) * scp;
         }
-        if (cur >= 0) flush();
-        runs_total = run;
+        __syncthreads();
+        if (kok)
+            for (int i = sl; i < cnt; i += NSL) {            // relu'(0) = 0 as in torch: applied when the sums are written
+                const float x = cx[i];
+                const float sx = sigmoidf_(scp * (x - shp));
+                const float wy = cy[i] * sx * (1.f - sx), wz = cz[i] * d0, wo = co[i] * d1;
+                gsc += wy * (x - shp) + wz * (0.f - shp) + wo * (1.f - shp);
+                gsh -= (wy + wz + wo) * scp;
+            }
+        __syncthreads();
+    };
+    if (sorted) {
+        // the caller vouches for a batch sorted by view (every full batch): the view's range by a 64-ary search per bound
+        if (threadIdx.x < 128) {
+            const long want = v + (threadIdx.x >> 6);        // wave 0: first index with view >= v; wave 1: >= v + 1
+            long lo = 0, hi = N;                             // answer in [lo, hi]
+            while (hi - lo > 0) {
+                const long step = (hi - lo + 63) / 64;
+                const long pos = lo + (long)lane * step;     // lanes probe 64 positions; the predicate is monotone
+                const bool ge = pos >= hi || view_idx[pos] >= want;
+                const unsigned long long m = __ballot(ge);
+                const int first = m ? __ffsll((long long)m) - 1 : 64;
+                const long nlo = first == 0 ? lo : lo + (long)(first - 1) * step + 1;
+                const long nhi = first == 64 ? hi : min(hi, lo + (long)first * step);
+                if (first == 0) { hi = lo; } else { lo = nlo; hi = nhi; }
+            }
+            if (lane == 0) rng[threadIdx.x >> 6] = lo;
+        }
+        __syncthreads();
+        const long lo = rng[0], hi = rng[1];
+        for (long b0 = lo; b0 < hi; b0 += PH_LMAX) process((int)min((long)PH_LMAX, hi - b0), b0);
+    } else {
+        int n = 0;
+        for (long base = 0; base < N; base += 256) {
+            const long s = base + threadIdx.x;
+            const bool hit = s < N && view_idx[s] == v;
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) wcnt[wv] = __popcll(m);
+            __syncthreads();
+            int off = n;
+            for (int w = 0; w < wv; ++w) off += wcnt[w];
+            if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (int)s;
+            n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+            if (n + 256 > PH_LMAX || base + 256 >= N) {
+                if (n > 0) process(n, -1);
+                n = 0;
+            }
+        }
     }
-    if (!ord) return;
-    if (threadIdx.x % Kp == 0) nruns[vb] = runs_total < rc ? runs_total : rc;
-    __shared__ int rflag;
-    if (!nemo_red_arrive(rr, 0, nAB, &rflag)) return;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        int cur = -1;
-        float ash = 0.f, asc = 0.f;
-        auto put = [&]() {
-            if (cur < 0) return;
-            if (ash != 0.f) d_shifts[(long)cur * ldp + k] += ash;
-            if (asc != 0.f) d_scales[(long)cur * ldp + k] += asc;
-        };
-        for (int b = 0; b < nvb; ++b) {
-            const int n = nruns[b];
-            for (int r = 0; r < n; ++r) {
-                const size_t e = (size_t)b * rc + r;
-                const int v = ev[e];
-                if (v != cur) { put(); cur = v; ash = 0.f; asc = 0.f; }
-                ash += eg[(e * 2) * K + k];
-                asc += eg[(e * 2 + 1) * K + k];
-            }
+    gred[0][threadIdx.x] = gsh; gred[1][threadIdx.x] = gsc;
+    __syncthreads();
+    if (sl == 0 && kok) {
+        float tsh = 0.f, tsc = 0.f;
+        for (int q = 0; q < NSL; q += 4) {                   // the sample lanes in a fixed order
+            tsh += (gred[0][q * NK + kl] + gred[0][(q + 1) * NK + kl]) + (gred[0][(q + 2) * NK + kl] + gred[0][(q + 3) * NK + kl]);
+            tsc += (gred[1][q * NK + kl] + gred[1][(q + 1) * NK + kl]) + (gred[1][(q + 2) * NK + kl] + gred[1][(q + 3) * NK + kl]);
         }
-        put();
+        if (shr > 0.f && tsh != 0.f) d_shifts[v * ldp + k] += tsh;
+        if (scr > 0.f && tsc != 0.f) d_scales[v * ldp + k] += tsc;
     }
 }
 struct PhaseBwdArgs {
     long N, V, T; int K, D, C; const int64_t* view_idx; const int64_t* frame_idx; const float* raw_phase;
     const float* shifts; const float* scales; long ldp; const float* log_sigmas; int kid; const float* phase;
     const float* den_ws; const float* dX; long ldx; float* d_shifts; float* d_scales; float* d_log_sigmas; float* d_codes;
-    int nAB, spb;
-    NemoRed rr; int rc;             // ordered accumulation of d shifts / d scales: scratch region, run entries per (block, group)
+    int nAB, sorted, mode; float4* coef;
 };
 #define PHASE_BWD_CALL(a, bid) phase_bwd_fused_body(bid, a.N, a.V, a.T, a.K, a.D, a.C, a.view_idx, a.frame_idx, a.raw_phase, \
     a.shifts, a.scales, a.ldp, a.log_sigmas, a.kid, a.phase, a.den_ws, a.dX, a.ldx, a.d_shifts, a.d_scales, a.d_log_sigmas, \
-    a.d_codes, a.nAB, a.spb, a.rr, a.rc)
+    a.d_codes, a.nAB, a.sorted, a.mode, a.coef)
 __global__ __launch_bounds__(256) void phase_bwd_fused_kernel(PhaseBwdArgs a) { PHASE_BWD_CALL(a, (int)blockIdx.x); }
 
 // The phase backward with the step's batched bias column sums (nemo_colsum_multi: out[n] += sum_m X[m][n] for up to
@@ -662,34 +729,25 @@ static int32_t phase_bwd_launch(int64_t N, int64_t V, int64_t T, int64_t K, int6
                                 const float* shifts, const float* scales, int64_t ldp, const float* log_sigmas,
                                 int32_t kernel_id, const float* phase, const float* dX, int64_t ldx, float* ws,
                                 float* d_shifts, float* d_scales, float* d_log_sigmas, float* d_codes, int32_t n_cs,
-                                const nemo_colsum_desc* descs, void* stream) {
+                                const nemo_colsum_desc* descs, int32_t sorted_by_view, void* stream) {
     if (N < 0 || V <= 0 || K <= 0 || D < 0 || C < 0 || !dX || !shifts || !scales || !phase) return NEMO_EINVAL;
     if ((d_shifts == nullptr) != (d_scales == nullptr)) return NEMO_EINVAL;
     if (n_cs < 0 || n_cs > NEMO_COLSUM_MAX || (n_cs && !descs)) return NEMO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    // samples per stage-A/B block: short node loops for small batches (a one-instance shard: 38 blocks of 8 samples
-    // instead of 10 blocks whose threads walk 32 samples each), fewer atomics for large ones
-    const int spb = N <= 1024 ? 8 : PH_SPB;
-    const long nAB = (d_shifts && N > 0) ? nemo_cdiv(N, spb) : 0;
+    // blocks [0, nAB): one per (view, 64-node slice) of the phase networks -- or, when the forward pass handed the views'
+    // denominators over in ws and the library scratch has room, one per 64 samples computing their coefficients, the
+    // (view, slice) blocks following as a second launch that only runs the node sums.
+    long nNodes = (d_shifts && N > 0) ? V * ((K + 63) / 64) : 0;
+    float4* coef = nullptr;
+    if (nNodes && ws) coef = reinterpret_cast<float4*>(nemo_red_take((size_t)N * 4, 1).part);
+    if (coef) nNodes = V * ((K + 15) / 16);                  // (the second launch's blocks take 16 nodes each)
+    const long nAB = coef ? nemo_cdiv(N, 64) : nNodes;
     // blocks [nAB, nAB + D) reduce log_sigma columns; if d_log_sigmas is NULL they are still launched (as no-ops) so
     // that the block -> column map stays fixed
     const long nC = (d_log_sigmas || d_codes) ? D + (d_codes ? V * C : 0) : 0;
     PhaseBwdArgs a{(long)N, (long)V, (long)T, (int)K, (int)D, (int)C, view_idx, frame_idx, raw_phase, shifts, scales, (long)ldp,
                    log_sigmas, (int)kernel_id, phase, (const float*)ws, dX, (long)ldx, d_shifts, d_scales, d_log_sigmas, d_codes,
-                   (int)nAB, spb, NemoRed{nullptr, nullptr}, 0};
-    if (nAB > 0) {
-        // run entries of the ordered accumulation: as many per (block, group) as a group can have, within 48 MB of the scratch
-        int Kp = 16;
-        while (Kp < K && Kp < 256) Kp <<= 1;
-        const long ngrp = 256 / Kp, nvb = nAB * ngrp;
-        long rc = (spb + ngrp - 1) / ngrp;
-        const long per = 2 * (long)K * 4;                        // bytes per entry
-        while (rc > 0 && nvb * (1 + rc) * 4 + 16 + nvb * rc * per > (48L << 20)) --rc;
-        if (rc > 0) {
-            a.rr = nemo_red_take((size_t)(nvb * (1 + rc) + 4 + nvb * rc * 2 * K), 1);
-            a.rc = (int)rc;
-        }
-    }
+                   (int)nAB, sorted_by_view ? 1 : 0, coef ? 1 : 0, coef};
     ColsumBatchP cb;
     cb.n = 0; cb.gx = cb.gy = 0; cb.rows_per_block = 64; cb.rr = NemoRed{nullptr, nullptr};
     long maxM = 0, maxN = 0;
@@ -701,6 +759,7 @@ static int32_t phase_bwd_launch(int64_t N, int64_t V, int64_t T, int64_t K, int6
     }
     long ncs = 0;
     if (n_cs && maxM > 0 && maxN > 0) {
+        if (maxM > 4096) cb.rows_per_block = 256;            // (tall matrices: fewer row chunks for a strip's last arriver to add up)
         cb.n = n_cs; cb.gx = (int)nemo_cdiv(maxN, 64); cb.gy = (int)nemo_cdiv(maxM, cb.rows_per_block);
         ncs = (long)cb.gx * cb.gy * n_cs;
         cb.rr = nemo_red_take((size_t)ncs * 64, cb.gx * n_cs);
@@ -711,6 +770,12 @@ static int32_t phase_bwd_launch(int64_t N, int64_t V, int64_t T, int64_t K, int6
     else
         hipLaunchKernelGGL(phase_bwd_colsum_kernel, dim3((unsigned)(nAB + nC + ncs)), dim3(256), 0, st, a, (int)(nAB + nC), cb);
     NEMO_LAUNCH_CHECK();
+    if (coef) {
+        a.nAB = (int)nNodes;
+        a.mode = 2;
+        hipLaunchKernelGGL(phase_bwd_fused_kernel, dim3((unsigned)nNodes), dim3(256), 0, st, a);
+        NEMO_LAUNCH_CHECK();
+    }
     return NEMO_OK;
 }
 
@@ -720,9 +785,9 @@ extern "C" int32_t nemo_phase_embed_bwd(int64_t N, int64_t V, int64_t T, int64_t
                                         int64_t ldp, const float* log_sigmas, int32_t kernel_id,
                                         const float* phase, const float* dX, int64_t ldx, float* ws,
                                         float* d_shifts, float* d_scales, float* d_log_sigmas,
-                                        float* d_codes, void* stream) {
+                                        float* d_codes, int32_t sorted_by_view, void* stream) {
     return phase_bwd_launch(N, V, T, K, D, C, view_idx, frame_idx, raw_phase, shifts, scales, ldp, log_sigmas, kernel_id, phase,
-                            dX, ldx, ws, d_shifts, d_scales, d_log_sigmas, d_codes, 0, nullptr, stream);
+                            dX, ldx, ws, d_shifts, d_scales, d_log_sigmas, d_codes, 0, nullptr, sorted_by_view, stream);
 }
 
 // nemo_phase_embed_bwd + nemo_colsum_multi(n_cs, descs) in ONE launch (further blocks of the same grid).
@@ -732,9 +797,9 @@ extern "C" int32_t nemo_phase_embed_bwd_colsum(int64_t N, int64_t V, int64_t T, 
                                                const float* log_sigmas, int32_t kernel_id, const float* phase,
                                                const float* dX, int64_t ldx, float* ws, float* d_shifts, float* d_scales,
                                                float* d_log_sigmas, float* d_codes, int32_t n_cs,
-                                               const nemo_colsum_desc* descs, void* stream) {
+                                               const nemo_colsum_desc* descs, int32_t sorted_by_view, void* stream) {
     return phase_bwd_launch(N, V, T, K, D, C, view_idx, frame_idx, raw_phase, shifts, scales, ldp, log_sigmas, kernel_id, phase,
-                            dX, ldx, ws, d_shifts, d_scales, d_log_sigmas, d_codes, n_cs, descs, stream);
+                            dX, ldx, ws, d_shifts, d_scales, d_log_sigmas, d_codes, n_cs, descs, sorted_by_view, stream);
 }
 
 extern "C" int32_t nemo_rot6d_fwd(int64_t rows, int64_t J, const float* rot6d, int64_t ld6, int32_t zero_nan,

@@ -641,40 +641,70 @@ __device__ __forceinline__ float group32_sum(float v) {
 // view (every full batch) is cut into the views' ranges by binary search; any other batch is scanned per view.
 constexpr int KP_DEP = 12;
 __device__ __forceinline__ void kp_view_finish(const float* __restrict__ part, const int64_t* __restrict__ view_idx, long N, long V,
-                                               float* __restrict__ view_acc, float* __restrict__ d_cams, int k0, int k1, int* sflag) {
-    if (threadIdx.x == 0) *sflag = 1;
-    __syncthreads();
-    int ok = 1;
-    for (long s = threadIdx.x; s + 1 < N; s += blockDim.x)
-        if (view_idx[s] > view_idx[s + 1]) ok = 0;
-    if (!ok) *sflag = 0;                                   // (every writer writes 0)
+                                               float* __restrict__ view_acc, float* __restrict__ d_cams, int k0, int k1, int* sflag,
+                                               int* unsorted_word) {
+    __shared__ long vlo[257];
+    // (sorted by view? every block has OR-ed what it saw -- its samples against their successors -- into the region's second
+    //  ticket word before it arrived: an integer OR, order-independent; reset here for the next launch)
+    if (threadIdx.x == 0) {
+        *sflag = __hip_atomic_load(unsorted_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ? 1 : 0;
+        __hip_atomic_store(unsorted_word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const bool sorted = *sflag != 0;
-    const int nk = k1 - k0;
-    auto lower = [&](long v) {                             // first s with view_idx[s] >= v
-        long lo = 0, hi = N;
-        while (lo < hi) { const long mid = (lo + hi) >> 1; if (view_idx[mid] < v) lo = mid + 1; else hi = mid; }
-        return lo;
-    };
-    for (long p = threadIdx.x; p < V * nk; p += blockDim.x) {
-        const long v = p / nk;
-        const int k = k0 + (int)(p % nk);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four interleaved chains (loads in flight), combined in a fixed order
-        if (sorted) {
-            const long lo = lower(v), hi = lower(v + 1);
-            long s = lo;
-            for (; s + 3 < hi; s += 4) {
-                a0 += part[s * KP_DEP + k]; a1 += part[(s + 1) * KP_DEP + k];
-                a2 += part[(s + 2) * KP_DEP + k]; a3 += part[(s + 3) * KP_DEP + k];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (long v0 = 0; v0 < V; v0 += 256) {
+        const long nvv = min(256L, V - v0);
+        if (sorted)                                        // the views' ranges: one binary search per thread, all at once
+            for (long i = threadIdx.x; i <= nvv; i += 256) {   // (nvv + 1 bounds: 257 of them when 256 views are in the pass)
+                const long v = v0 + i;
+                long lo = 0, hi = N;
+                while (lo < hi) { const long mid = (lo + hi) >> 1; if (view_idx[mid] < v) lo = mid + 1; else hi = mid; }
+                vlo[i] = lo;
             }
-            for (; s < hi; ++s) a0 += part[s * KP_DEP + k];
-        } else {
-            for (long s = 0; s < N; ++s)
-                if (view_idx[s] == v) a0 += part[s * KP_DEP + k];
+        __syncthreads();
+        // a wave per view (four views in flight): lane l takes the view's samples l, l + 64, ... in ascending order, then the
+        // xor-shuffle tree -- a fixed order whatever the launch's timing was
+        for (long vi = wv; vi < nvv; vi += 4) {
+            const long v = v0 + vi;
+            const long lo = sorted ? vlo[vi] : 0, hi = sorted ? vlo[vi + 1] : N;
+            float acc[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+            const float4* p4 = reinterpret_cast<const float4*>(part);
+            for (long s0 = lo + lane; s0 < hi; s0 += 256) {        // four samples per lane: their twelve 16-byte loads in flight
+                float4 q[4][3];
+                bool on[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long s = s0 + 64 * u;
+                    on[u] = s < hi && (sorted || view_idx[s] == v);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) q[u][c] = on[u] ? p4[s * 3 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!on[u]) continue;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        acc[4 * c] += q[u][c].x; acc[4 * c + 1] += q[u][c].y; acc[4 * c + 2] += q[u][c].z; acc[4 * c + 3] += q[u][c].w;
+                    }
+                }
+            }
+            float mine = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                float r = acc[k];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
+                if (lane == k) mine = r;
+            }
+            if (lane < 11 && lane >= k0 && lane < k1) {
+                if (lane < 2) { if (view_acc) view_acc[v * 2 + lane] += mine; }
+                else if (mine != 0.f) d_cams[v * 9 + (lane - 2)] += mine;
+            }
         }
-        const float acc = (a0 + a1) + (a2 + a3);
-        if (k < 2) { if (view_acc) view_acc[v * 2 + k] += acc; }
-        else if (acc != 0.f) d_cams[v * 9 + (k - 2)] += acc;
+        __syncthreads();
     }
 }
 
@@ -728,11 +758,12 @@ __global__ __launch_bounds__(256) void kp_fwd_kernel(KpArgs a, KpConst kc, float
         // deterministic: per-sample deposits, summed per view in sample order by the last-arriving block
         if (LANES == 32) wsum = group32_sum(wsum);
         if (o == 0 && s < a.N) {
-            rr.part[s * KP_DEP] = pad ? 0.f : wsum;
-            rr.part[s * KP_DEP + 1] = pad ? 0.f : 1.f;
+            nemo_red_put4(rr.part + s * KP_DEP, pad ? 0.f : wsum, pad ? 0.f : 1.f, 0.f, 0.f);
+            if (s + 1 < a.N && a.view_idx[s + 1] < v) __hip_atomic_fetch_or(rr.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __shared__ int rflag;
-        if (nemo_red_arrive(rr, 0, (int)gridDim.x, &rflag)) kp_view_finish(rr.part, a.view_idx, a.N, a.V, view_acc, nullptr, 0, 2, &rflag);
+        if (nemo_red_arrive(rr, 0, (int)gridDim.x, &rflag))
+            kp_view_finish(rr.part, a.view_idx, a.N, a.V, view_acc, nullptr, 0, 2, &rflag, rr.ticket + 1);
     } else if (view_acc) {
         // one atomic per (block, view) instead of one per sample: the V x 2 accumulators are hot
         // same-address targets (300 serialised L2 atomics each at N = 2400 otherwise)
@@ -881,14 +912,16 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
         dep[1] = (live && !pad) ? 1.f : 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) dep[2 + k] = LANES == 32 ? group32_sum(dcam[k]) : dcam[k];
-        if (o == 0 && live) {
-#pragma unroll
-            for (int k = 0; k < 11; ++k) rr.part[s * KP_DEP + k] = dep[k];
+        if (o < 3 && live) {                               // (every lane of the group holds all sums: lanes 0 .. 2 store 16 bytes each)
+            const float q0 = o == 0 ? dep[0] : (o == 1 ? dep[4] : dep[8]), q1 = o == 0 ? dep[1] : (o == 1 ? dep[5] : dep[9]);
+            const float q2 = o == 0 ? dep[2] : (o == 1 ? dep[6] : dep[10]), q3 = o == 0 ? dep[3] : (o == 1 ? dep[7] : 0.f);
+            nemo_red_put4(rr.part + s * KP_DEP + 4 * o, q0, q1, q2, q3);
+            if (o == 0 && s + 1 < a.N && a.view_idx[s + 1] < v) __hip_atomic_fetch_or(rr.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __shared__ int rflag;
         if (nemo_red_arrive(rr, 0, (int)gridDim.x, &rflag))
             kp_view_finish(rr.part, a.view_idx, a.N, a.V, (FUSED && view_acc_out) ? view_acc_out : nullptr, d_cams,
-                           (FUSED && view_acc_out) ? 0 : 2, d_cams ? 11 : 2, &rflag);
+                           (FUSED && view_acc_out) ? 0 : 2, d_cams ? 11 : 2, &rflag, rr.ticket + 1);
     }
     if (!ordered && FUSED && view_acc_out) {
         // the forward's per-view accumulators [sum(loss * conf), #samples]: one atomic per (block, view), as in kp_fwd_kernel
@@ -2035,7 +2068,7 @@ extern "C" int32_t nemo_kp_fwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_
     if (N == 0) return NEMO_OK;
     if (ctx->n_out > 32) return NEMO_EINVAL;
     hipLaunchKernelGGL(kp_fwd_kernel<32>, dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       ctx->kc, j3d, p2d, loss_all, view_acc, view_acc ? nemo_red_take((size_t)N * KP_DEP, 1) : NemoRed{nullptr, nullptr});
+                       ctx->kc, j3d, p2d, loss_all, view_acc, view_acc ? nemo_red_take((size_t)N * KP_DEP, 2) : NemoRed{nullptr, nullptr});
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -2069,7 +2102,7 @@ static int32_t kp_bwd_impl(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T,
     hipLaunchKernelGGL(kp_bwd_kernel<32>, dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
                        ctx->kc, view_acc, norm, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams, (int)ctx->nq, dj3d_extra,
                        (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                       d_cams ? nemo_red_take((size_t)N * KP_DEP, 1) : NemoRed{nullptr, nullptr});
+                       d_cams ? nemo_red_take((size_t)N * KP_DEP, 2) : NemoRed{nullptr, nullptr});
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -2119,7 +2152,7 @@ extern "C" int32_t nemo_kp_fwd_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, in
     hipLaunchKernelGGL((kp_bwd_kernel<32, true>), dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
                        ctx->kc, (const float*)nullptr, (const float*)nullptr, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams,
                        (int)ctx->nq, (const float*)nullptr, view_count, j3d, p2d, loss_all, view_acc,
-                       nemo_red_take((size_t)N * KP_DEP, 1));
+                       nemo_red_take((size_t)N * KP_DEP, 2));
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -359,6 +359,10 @@ class FitEngine:
     # bf16 chain: the first layer (K = 105) and its two backward products on the chain's bf16 kernels too (round 5; False: fp32
     # products over nn.Linear(105, h)'s unaligned rows, rounds 3 - 4); NEMO_B16_FIRST_LAYER=0 restores that
     B16_FIRST_LAYER = os.environ.get('NEMO_B16_FIRST_LAYER', '1') != '0'
+    # the batch of the pass in flight is sorted by view (the model sets it for full batches: view-major by construction); lets
+    # the phase backward find a view's samples by a search instead of a scan.  Part of a captured launch: full and random
+    # batches have different graph keys already.
+    batch_sorted = False
     B16_DW_ASIDE_ROWS = 10000       # bf16 chain: parameter-gradient products on the side stream up to this many rows
     SMALL_BATCH_ROWS = 1024  # backward_mlp: below this many rows the dW GEMMs run beside the dX chain
     GROUPED_DW_ROWS = 400    # ... and up to this many as ONE grouped launch behind it (a one-instance shard)
@@ -744,9 +748,9 @@ class FitEngine:
             for i, (x, m, nn, ld, out) in enumerate(self._colsums):
                 arr[i].X, arr[i].M, arr[i].N, arr[i].ldx, arr[i].out = x, m, nn, ld, out
             self._colsums = []
-            check(self.lib.nemo_phase_embed_bwd_colsum(*args, n, arr, _stream()), 'nemo_phase_embed_bwd_colsum')
+            check(self.lib.nemo_phase_embed_bwd_colsum(*args, n, arr, int(self.batch_sorted), _stream()), 'nemo_phase_embed_bwd_colsum')
         else:
-            check(self.lib.nemo_phase_embed_bwd(*args, _stream()), 'nemo_phase_embed_bwd')
+            check(self.lib.nemo_phase_embed_bwd(*args, int(self.batch_sorted), _stream()), 'nemo_phase_embed_bwd')
 
     def flush_colsums(self):
         if not self._colsums:
@@ -864,7 +868,7 @@ class FitEngine:
             N, self.V, self.T, self.K, 0, 0, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
             self.p('phase_networks.0.shifts'), self.p('phase_networks.0.scales'), self.ldp, None, 0,
             dptr(w['phase']), dptr(w['dX']), self.ldx, dptr(w['phase_ws']), self.g('phase_networks.0.shifts'),
-            self.g('phase_networks.0.scales'), None, None, _stream()), 'nemo_phase_embed_bwd')
+            self.g('phase_networks.0.scales'), None, None, int(self.batch_sorted), _stream()), 'nemo_phase_embed_bwd')
 
     def forward_joints(self, w, N, view_idx, frame_idx, with_loss, mean_mode=0, add_trans=True, ctx=None,
                        j3d=None, p2d=None, finalize=True):

@@ -877,6 +877,7 @@ class MultiViewModel(nn.Module):
     def _body(self, w, b, pl, vi_, fi_, adam_table, part='all', run_adam=True):
         """Everything of the step (or of one part of it) that runs on the device without host interaction."""
         e, sh, update = self.engine, b.sh, pl.update
+        e.batch_sorted = bool(b.is_full) and not b.padded           # (full batches are view-major: engine.batch_sorted)
         if part == 'bucketc':
             # 'buckets' mode as ONE launch: the three gradient buckets are all-reduced on the communication stream as
             # soon as the backward has completed them, each with its share of the fused Adam (device table, segments
@@ -1189,6 +1190,7 @@ class MultiViewModel(nn.Module):
         """One warm-up iteration up to (not including) the update: MLP forward, masked robust 3-D pose loss against the
         HMR / VIBE track, backward to every motion / phase parameter, NaN-gradient count (+= into ``nan_out``, default:
         slot 7 of the step's scalars)."""
+        self.engine.batch_sorted = False                        # (random batches: engine.batch_sorted)
         e = self.engine
         st = _stream()
         e.scal = w['scal']
@@ -1416,6 +1418,7 @@ class NemoV4(NemoV3):
                 table = e.adam_table_sync(segs)
 
                 def body():
+                    e.batch_sorted = False                      # (random batches)
                     self._forward_backward(w, N, svi, sfi, True, use_vposer=False, detach_pose=True, sh=sh, adam_segs=table[0])
                     e.adam_from_table(*table)
                 key = ('cam4', N, e.detach_articulation, e.start_global_traj_anywhere, self._weights_key(), e.ctx.skin_sparse_flag,
@@ -1431,6 +1434,7 @@ class NemoV4(NemoV3):
                 continue
             vi, fi = self._idx(b.vi), self._idx(b.fi)
             if N > 0:
+                e.batch_sorted = False
                 self._forward_backward(w, N, vi, fi, True, use_vposer=False, detach_pose=True, sh=sh)
             else:
                 e.scal.zero_()

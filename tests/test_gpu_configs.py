@@ -111,6 +111,15 @@ def test_c5_all_terms_and_smoothness_full_mesh_vs_oracle(version):
     m, args, seqs, assets, vps, gmm = _build(8, 300, version=version, **over)
     args.weight_smooth = 1e5
     o = OracleNemo(version, args, seqs, assets, vps, gmm, state={k: v.detach().cpu() for k, v in m.state_dict().items()})
+    from tiebound import model_v2v_tie_bound
+    from test_gpu_model import _float64_twin, _assert_gradients_up_to_l1_ties
+    o64 = _float64_twin(o)
+    bound, n_ties = model_v2v_tie_bound(o64, *o64.full_indices())
+    torch.set_default_dtype(torch.float64)
+    try:
+        o64.step(None, None, update=True, full_batch=True)
+    finally:
+        torch.set_default_dtype(torch.float32)
     ld_o, info_o = o.step(None, None, update=True, full_batch=True)
     ld_h, info_h = m.step(None, None, update=True, full_batch=True)
     assert ld_h.keys() == ld_o.keys() and float(ld_o['smooth_loss']) > 0
@@ -118,9 +127,8 @@ def test_c5_all_terms_and_smoothness_full_mesh_vs_oracle(version):
     for k in ld_o:
         assert rel_err(ld_h[k], ld_o[k]) < 1e-4, (k, ld_h[k], ld_o[k])
     assert rel_err(info_h['loss_all'], info_o['loss_all']) < 1e-4 and rel_err(info_h['j'], info_o['j']) < 1e-4
-    named = dict(m.named_parameters())
-    for k in SHARED + ('learned_cameras', 'phase_networks.5.scales', 'learned_instance_code'):
-        assert rel_err(named[k].grad, o.P[k].grad) < 2e-3, k
+    # (held to 1e-4 + the oracle's own float64 distance + the analytic bound of the L1 term's sign(0) ties: tiebound.py)
+    _assert_gradients_up_to_l1_ties(m, o, o64, bound, SHARED + ('learned_cameras', 'phase_networks.5.scales', 'learned_instance_code'))
     ld_o, _ = o.step(None, None, update=False, full_batch=True)
     ld_h, _ = m.step(None, None, update=False, full_batch=True)
     for k in ld_o:

@@ -207,6 +207,23 @@ def test_step0_gradients_vs_reference(tmp_path):
     assert checked >= 20
 
 
+def _assert_gradients_up_to_l1_ties(m, o, o64, bound, keys):
+    """|g_hip - g_oracle| <= 1e-4 of the tensor's largest entry + 3 x the oracle's own fp32-vs-float64 distance (as in
+    test_every_gradient_at_real_size_with_the_mesh_term_off) + what sign(0) ties of the L1 mesh term can change (tiebound.py:
+    elementwise, from the float64 twin) -- the flat 2e-3 of rounds 1 - 4 is gone."""
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for k in keys:
+        gh, go, g64 = named[k].grad.detach().cpu().double(), o.P[k].grad.double(), o64.P[k].grad.double()
+        scale = float(go.abs().max())
+        noise = float((go - g64).abs().max())
+        allow = 1e-4 * scale + 3.0 * noise + bound[k].double()
+        diff = (gh - go).abs()
+        worst = max(worst, float((diff - 3.0 * noise - bound[k].double()).max()) / scale)
+        assert bool((diff <= allow).all()), (k, float(diff.max()), scale, noise, float(bound[k].max()))
+    return worst
+
+
 def test_published_config_step_vs_oracle(tmp_path):
     """One real-size step (NemoV2, h=1000, RBF 100, 6890 vertices, minibatch 512 drawn from 8x300)
     against the CPU oracle on the same initial state: losses, 3-D joints, 2-D points."""
@@ -225,6 +242,14 @@ def test_published_config_step_vs_oracle(tmp_path):
     o = OracleNemo(2, args, seqs, assets, vps, gmm, state=state)
     torch.manual_seed(2)
     vi, fi = torch.randint(0, V, (B,)), torch.randint(0, T, (B,))
+    from tiebound import model_v2v_tie_bound
+    o64 = _float64_twin(o)
+    bound, n_ties = model_v2v_tie_bound(o64, vi, fi)
+    torch.set_default_dtype(torch.float64)
+    try:
+        o64.step(vi, fi, update=True)
+    finally:
+        torch.set_default_dtype(torch.float32)
     ld_o, info_o = o.step(vi, fi, update=True)
     ld_h, info_h = m.step(vi, fi, update=True)
     for k in ('kp_loss', 'gmm_loss', 'vp_recon_loss', 'vp_kl_loss', 'total_loss'):
@@ -234,9 +259,10 @@ def test_published_config_step_vs_oracle(tmp_path):
     assert rel_err(info_h['loss_all'], info_o['loss_all']) < 1e-4
     # gradients of the big shared tensors (before Adam they are in .grad on both sides)
     named = dict(m.named_parameters())
-    for k in ('learned_motion.net.net.2.weight', 'learned_motion.rot_out.weight', 'learned_cameras',
-              'phase_rbf.log_sigmas', 'learned_instance_code', 'phase_networks.3.shifts'):
-        assert rel_err(named[k].grad, o.P[k].grad) < 2e-3, k
+    worst = _assert_gradients_up_to_l1_ties(m, o, o64, bound, ('learned_motion.net.net.2.weight', 'learned_motion.rot_out.weight',
+                                                               'learned_cameras', 'phase_rbf.log_sigmas', 'learned_instance_code',
+                                                               'phase_networks.3.shifts'))
+    print('L1 coordinates within rounding of a tie:', n_ties, ' worst gradient error beyond the allowances / scale:', worst)
     # second step: the post-update state must produce matching losses too
     vi, fi = torch.randint(0, V, (B,)), torch.randint(0, T, (B,))
     ld_o, _ = o.step(vi, fi, update=False)
@@ -268,6 +294,14 @@ def test_benchmark_config_full_batch_step_vs_oracle(version, skin_nnz):
         m.learned_motion.rot_out.weight.mul_(2e3)
     o = OracleNemo(version, args, seqs, assets, vps, gmm,
                    state={k: v.detach().cpu() for k, v in m.state_dict().items()})
+    from tiebound import model_v2v_tie_bound
+    o64 = _float64_twin(o)
+    bound, n_ties = model_v2v_tie_bound(o64, *o64.full_indices())
+    torch.set_default_dtype(torch.float64)
+    try:
+        o64.step(None, None, update=True, full_batch=True)
+    finally:
+        torch.set_default_dtype(torch.float32)
     ld_o, info_o = o.step(None, None, update=True, full_batch=True)
     ld_h, info_h = m.step(None, None, update=True, full_batch=True)
     assert ld_h.keys() == ld_o.keys()
@@ -275,9 +309,10 @@ def test_benchmark_config_full_batch_step_vs_oracle(version, skin_nnz):
         assert rel_err(ld_h[k], ld_o[k]) < 1e-4, (k, ld_h[k], ld_o[k])
     assert rel_err(info_h['loss_all'], info_o['loss_all']) < 1e-4
     named = dict(m.named_parameters())
-    for k in ('learned_motion.net.net.0.weight', 'learned_motion.net.net.2.weight', 'learned_motion.rot_out.weight',
-              'learned_cameras', 'phase_rbf.log_sigmas', 'phase_networks.5.scales'):
-        assert rel_err(named[k].grad, o.P[k].grad) < 2e-3, k
+    worst = _assert_gradients_up_to_l1_ties(m, o, o64, bound, ('learned_motion.net.net.0.weight', 'learned_motion.net.net.2.weight',
+                                                               'learned_motion.rot_out.weight', 'learned_cameras',
+                                                               'phase_rbf.log_sigmas', 'phase_networks.5.scales'))
+    print('L1 coordinates within rounding of a tie:', n_ties, ' worst gradient error beyond the allowances / scale:', worst)
     ld_o, _ = o.step(None, None, update=False, full_batch=True)      # the updated state
     ld_h, _ = m.step(None, None, update=False, full_batch=True)
     for k in ld_o:

@@ -348,14 +348,15 @@ def test_phase_embed_vs_oracle(L, kern):
         assert back[i].step == st_ + 1
         assert abs(back[i].step_size - lr / (1 - 0.9 ** (st_ + 1))) <= 1e-6 * back[i].step_size
         assert abs(back[i].bias_corr2_sqrt - (1 - 0.999 ** (st_ + 1)) ** 0.5) <= 1e-6
-    for ws in (den, None):          # with the forward pass's denominators, and re-evaluating them
+    srt = int(bool((vi[1:] >= vi[:-1]).all()))          # the batch may be declared sorted by view only if it is
+    for ws, hint in ((den, 0), (None, 0), (den, srt)):   # with the forward pass's denominators, and re-evaluating them
         gpn = torch.zeros_like(pn)
         gls, gco = torch.zeros(D, device='cuda'), torch.zeros(V, C, device='cuda')
         assert L.nemo_phase_embed_bwd(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
                                       pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), kid, phd.data_ptr(),
                                       H.dev(ct).data_ptr(), D + C, ws.data_ptr() if ws is not None else None,
                                       gpn.data_ptr(), gpn.data_ptr() + 4 * K,
-                                      gls.data_ptr(), gco.data_ptr(), H.st()) == 0
+                                      gls.data_ptr(), gco.data_ptr(), hint, H.st()) == 0
         gpn = gpn.reshape(V, 2, K)
         assert rel_err(gls, lso.grad) < 1e-4
         assert rel_err(gco, co.grad) < 1e-5
@@ -374,7 +375,7 @@ def test_phase_embed_vs_oracle(L, kern):
     assert L.nemo_phase_embed_bwd_colsum(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
                                          pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), kid, phd.data_ptr(),
                                          H.dev(ct).data_ptr(), D + C, den.data_ptr(), gpn2.data_ptr(), gpn2.data_ptr() + 4 * K,
-                                         gls2.data_ptr(), gco2.data_ptr(), 2, arr, H.st()) == 0
+                                         gls2.data_ptr(), gco2.data_ptr(), 2, arr, 0, H.st()) == 0
     assert rel_err(gpn2.reshape(V, 2, K), gpn) < 1e-5 and rel_err(gls2, gls) < 1e-5 and rel_err(gco2, gco) < 1e-5
     assert rel_err(o1, 1.0 + Y1.double().sum(0)) < 1e-5 and rel_err(o2, Y2[:, :130].double().sum(0)) < 1e-5
 
@@ -538,6 +539,26 @@ def test_keypoint_loss_types_and_camera_mode(L, loss_type, lid):
     assert rel_err(dcg, co.grad) < 1e-4
 
 
+def _l1_grad_gate(assets, R2, N, dRg, Ro_grad):
+    """dRg (HIP) against the oracle's autograd gradient of sum |v_rec - v_orig| w.r.t. the N x 24 rotations: 1e-4 of the largest
+    entry + 3 x the fp32 oracle's own distance from a float64 evaluation + the elementwise bound of what sign(0) ties can change
+    (tests/tiebound.py) -- instead of the flat 2e-3 of rounds 1 - 4."""
+    from oracle import ops
+    from tiebound import l1_tie_bound
+    a64 = {k: (v.double() if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in assets.items()}
+    smpl64 = ops.SMPLOracle(a64)
+    Ro64 = R2[:N].double().clone().requires_grad_(True)
+    vr64 = smpl64.forward(torch.zeros(1, 10, dtype=torch.float64), R2[N:].double())[0].detach()
+    (bound,), n_ties = l1_tie_bound(lambda: smpl64.forward(torch.zeros(1, 10, dtype=torch.float64), Ro64)[0], [Ro64], vr64, 1.0)
+    vo64 = smpl64.forward(torch.zeros(1, 10, dtype=torch.float64), Ro64)[0]
+    (g64,) = torch.autograd.grad((vr64 - vo64).abs().sum(), [Ro64])
+    go = Ro_grad.double()
+    gh = dRg.detach().cpu().double().reshape(go.shape)
+    scale, noise = float(go.abs().max()), float((go - g64).abs().max())
+    diff = (gh - go).abs()
+    assert bool((diff <= 1e-4 * scale + 3.0 * noise + bound).all()), (float(diff.max()), scale, noise, float(bound.max()), n_ties)
+
+
 @pytest.mark.parametrize('num_verts', [128, 6890])
 def test_vertices_and_v2v(L, num_verts):
     """Full-mesh path: pose-blend GEMM + skinning; the fused L1 + gradient kernel against autograd."""
@@ -578,8 +599,8 @@ def test_vertices_and_v2v(L, num_verts):
                            0, None, 0, 0, 1.0, 2, 8, None, 0, H.st()) == 0
     assert L.nemo_fk_bwd(ctx.handle, N, dR2.data_ptr(), A.data_ptr(), dA.data_ptr(), None, dPF.data_ptr(), 207,
                          dRg.data_ptr(), H.st()) == 0
-    # |.| is non-smooth: a vertex coordinate within rounding of a tie flips a sign; compare in aggregate
-    assert rel_err(dRg.reshape(N, 24, 3, 3), Ro.grad) < 2e-3
+    # |.| is non-smooth: a vertex coordinate within rounding of a tie may flip a sign -- bounded analytically, not by a flat gate
+    _l1_grad_gate(assets, R2, N, dRg, Ro.grad)
 
 
 @pytest.mark.parametrize('num_verts,N,plan', [(128, 6, ''), (100, 37, ''), (6890, 20, ''),
@@ -640,8 +661,8 @@ def test_v2v_fused_mesh_kernel(L, num_verts, N, plan, skin_nnz, monkeypatch):
                            None, 0, None, 0, 0, 1.0, 2, 8, None, 0, H.st()) == 0
     assert L.nemo_fk_bwd(ctx.handle, N, dR2.data_ptr(), A.data_ptr(), dA.data_ptr(), None, dPF.data_ptr(), 208,
                          dRg.data_ptr(), H.st()) == 0
-    # |.| is non-smooth: a coordinate within rounding of a tie flips a sign; compare in aggregate
-    assert rel_err(dRg.reshape(N, 24, 3, 3), Ro.grad) < 2e-3
+    # |.| is non-smooth: a coordinate within rounding of a tie may flip a sign -- bounded analytically, not by a flat gate
+    _l1_grad_gate(assets, R2, N, dRg, Ro.grad)
 
 
 @pytest.mark.parametrize('bf16', [False, True])
