@@ -640,72 +640,86 @@ __device__ __forceinline__ float group32_sum(float v) {
 // writer of those accumulators, where float atomics used to add per-block partial sums in arrival order.  A batch sorted by
 // view (every full batch) is cut into the views' ranges by binary search; any other batch is scanned per view.
 constexpr int KP_DEP = 12;
-__device__ __forceinline__ void kp_view_finish(const float* __restrict__ part, const int64_t* __restrict__ view_idx, long N, long V,
-                                               float* __restrict__ view_acc, float* __restrict__ d_cams, int k0, int k1, int* sflag,
-                                               int* unsorted_word) {
-    __shared__ long vlo[257];
-    // (sorted by view? every block has OR-ed what it saw -- its samples against their successors -- into the region's second
-    //  ticket word before it arrived: an integer OR, order-independent; reset here for the next launch)
-    if (threadIdx.x == 0) {
-        *sflag = __hip_atomic_load(unsorted_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ? 1 : 0;
-        __hip_atomic_store(unsorted_word, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const bool sorted = *sflag != 0;
+// floats of scratch a launch over N samples of V views takes: the deposits, then the V + 1 view bounds (kp_mark_bounds)
+__host__ __device__ inline size_t kp_dep_floats(long N, long V) { return (size_t)N * KP_DEP + (size_t)V + 4; }
+// Deterministic per-view sums of the key-point kernels (loss, count, camera gradient).  The kernels DEPOSIT twelve floats per
+// sample [loss, count, d cam 0 .. 8, 0] (plain stores) and kp_view_finish_kernel, launched right behind them on the same
+// stream, adds a view's samples in a fixed order: one block per view.  (First version: the last-arriving block of the
+// depositing launch summed all views -- serial in V: 40 us at 40 views, on the step's main chain.)
+// kp_mark_bounds, called for every live sample s (view v) by one lane: ORs "the batch is not sorted by view" into the
+// region's second ticket word, and -- for a sorted batch -- leaves the first sample index of every view in bounds[0 .. V]
+// (bounds[V] = N): sample s writes the bounds of the views that begin right behind it, sample 0 those up to its own.
+__device__ __forceinline__ void kp_mark_bounds(const NemoRed& rr, const int64_t* __restrict__ view_idx, long N, long V, long s, long v) {
+    int* bounds = reinterpret_cast<int*>(rr.part + (size_t)N * KP_DEP);
+    const long vn = s + 1 < N ? (long)view_idx[s + 1] : V;
+    if (vn < v) { __hip_atomic_fetch_or(rr.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    for (long vv = v + 1; vv <= min(vn, V); ++vv) bounds[vv] = (int)(s + 1);
+    if (s == 0)
+        for (long vv = 0; vv <= min(v, V); ++vv) bounds[vv] = 0;
+}
+__device__ __forceinline__ void kp_deposit4(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+// Block v: view v's samples -- [bounds[v], bounds[v + 1]) of a sorted batch, otherwise every sample whose view is v -- thread t
+// takes samples t, t + 256, ... in ascending order, then the xor-shuffle tree and the four waves in order: a fixed order
+// whatever the launch's timing was.  Components [k0, k1) are written: 0, 1 -> view_acc[v][0 .. 1], 2 .. 10 -> d_cams[v][0 .. 8].
+// The last block to finish re-arms the region's two ticket words (arrival counter, unsorted flag).
+__global__ __launch_bounds__(256) void kp_view_finish_kernel(const float* __restrict__ part, const int64_t* __restrict__ view_idx, long N,
+                                                             long V, float* __restrict__ view_acc, float* __restrict__ d_cams, int k0,
+                                                             int k1, int* __restrict__ ticket) {
+    const long v = blockIdx.x;
+    const bool sorted = __hip_atomic_load(ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    const int* bounds = reinterpret_cast<const int*>(part + (size_t)N * KP_DEP);
+    const long lo = sorted ? bounds[v] : 0, hi = sorted ? bounds[v + 1] : N;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (long v0 = 0; v0 < V; v0 += 256) {
-        const long nvv = min(256L, V - v0);
-        if (sorted)                                        // the views' ranges: one binary search per thread, all at once
-            for (long i = threadIdx.x; i <= nvv; i += 256) {   // (nvv + 1 bounds: 257 of them when 256 views are in the pass)
-                const long v = v0 + i;
-                long lo = 0, hi = N;
-                while (lo < hi) { const long mid = (lo + hi) >> 1; if (view_idx[mid] < v) lo = mid + 1; else hi = mid; }
-                vlo[i] = lo;
-            }
-        __syncthreads();
-        // a wave per view (four views in flight): lane l takes the view's samples l, l + 64, ... in ascending order, then the
-        // xor-shuffle tree -- a fixed order whatever the launch's timing was
-        for (long vi = wv; vi < nvv; vi += 4) {
-            const long v = v0 + vi;
-            const long lo = sorted ? vlo[vi] : 0, hi = sorted ? vlo[vi + 1] : N;
-            float acc[12];
+    float acc[12];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) acc[k] = 0.f;
-            const float4* p4 = reinterpret_cast<const float4*>(part);
-            for (long s0 = lo + lane; s0 < hi; s0 += 256) {        // four samples per lane: their twelve 16-byte loads in flight
-                float4 q[4][3];
-                bool on[4];
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    for (long s0 = lo + threadIdx.x; s0 < hi; s0 += 1024) {           // four samples per thread: their twelve 16-byte loads in flight
+        float4 q[4][3];
+        bool on[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const long s = s0 + 64 * u;
-                    on[u] = s < hi && (sorted || view_idx[s] == v);
+        for (int u = 0; u < 4; ++u) {
+            const long s = s0 + 256 * u;
+            on[u] = s < hi && (sorted || view_idx[s] == v);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) q[u][c] = on[u] ? p4[s * 3 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+            for (int c = 0; c < 3; ++c) q[u][c] = on[u] ? p4[s * 3 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (!on[u]) continue;
+        for (int u = 0; u < 4; ++u) {
+            if (!on[u]) continue;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        acc[4 * c] += q[u][c].x; acc[4 * c + 1] += q[u][c].y; acc[4 * c + 2] += q[u][c].z; acc[4 * c + 3] += q[u][c].w;
-                    }
-                }
-            }
-            float mine = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                float r = acc[k];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
-                if (lane == k) mine = r;
-            }
-            if (lane < 11 && lane >= k0 && lane < k1) {
-                if (lane < 2) { if (view_acc) view_acc[v * 2 + lane] += mine; }
-                else if (mine != 0.f) d_cams[v * 9 + (lane - 2)] += mine;
+            for (int c = 0; c < 3; ++c) {
+                acc[4 * c] += q[u][c].x; acc[4 * c + 1] += q[u][c].y; acc[4 * c + 2] += q[u][c].z; acc[4 * c + 3] += q[u][c].w;
             }
         }
-        __syncthreads();
     }
+    __shared__ float wsum4[4][12];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        float r = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
+        if (lane == 0) wsum4[wv][k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 11 && (int)threadIdx.x >= k0 && (int)threadIdx.x < k1) {
+        const int k = threadIdx.x;
+        const float mine = (wsum4[0][k] + wsum4[1][k]) + (wsum4[2][k] + wsum4[3][k]);
+        if (k < 2) { if (view_acc) view_acc[v * 2 + k] += mine; }
+        else if (mine != 0.f) d_cams[v * 9 + (k - 2)] += mine;
+    }
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ticket + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+static void kp_launch_view_finish(const NemoRed& rr, const int64_t* view_idx, long N, long V, float* view_acc, float* d_cams, int k0, int k1,
+                                  hipStream_t st) {
+    if (!rr.part || V <= 0) return;
+    hipLaunchKernelGGL(kp_view_finish_kernel, dim3((unsigned)V), dim3(256), 0, st, rr.part, view_idx, N, V, view_acc, d_cams, k0, k1,
+                       rr.ticket);
 }
 
 template <int LANES>
@@ -755,15 +769,12 @@ __global__ __launch_bounds__(256) void kp_fwd_kernel(KpArgs a, KpConst kc, float
         }
     }
     if (view_acc && rr.part) {
-        // deterministic: per-sample deposits, summed per view in sample order by the last-arriving block
+        // deterministic: per-sample deposits, summed per view in sample order by kp_view_finish_kernel
         if (LANES == 32) wsum = group32_sum(wsum);
         if (o == 0 && s < a.N) {
-            nemo_red_put4(rr.part + s * KP_DEP, pad ? 0.f : wsum, pad ? 0.f : 1.f, 0.f, 0.f);
-            if (s + 1 < a.N && a.view_idx[s + 1] < v) __hip_atomic_fetch_or(rr.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            kp_deposit4(rr.part + s * KP_DEP, pad ? 0.f : wsum, pad ? 0.f : 1.f, 0.f, 0.f);
+            kp_mark_bounds(rr, a.view_idx, a.N, a.V, s, v);
         }
-        __shared__ int rflag;
-        if (nemo_red_arrive(rr, 0, (int)gridDim.x, &rflag))
-            kp_view_finish(rr.part, a.view_idx, a.N, a.V, view_acc, nullptr, 0, 2, &rflag, rr.ticket + 1);
     } else if (view_acc) {
         // one atomic per (block, view) instead of one per sample: the V x 2 accumulators are hot
         // same-address targets (300 serialised L2 atomics each at N = 2400 otherwise)
@@ -915,13 +926,9 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
         if (o < 3 && live) {                               // (every lane of the group holds all sums: lanes 0 .. 2 store 16 bytes each)
             const float q0 = o == 0 ? dep[0] : (o == 1 ? dep[4] : dep[8]), q1 = o == 0 ? dep[1] : (o == 1 ? dep[5] : dep[9]);
             const float q2 = o == 0 ? dep[2] : (o == 1 ? dep[6] : dep[10]), q3 = o == 0 ? dep[3] : (o == 1 ? dep[7] : 0.f);
-            nemo_red_put4(rr.part + s * KP_DEP + 4 * o, q0, q1, q2, q3);
-            if (o == 0 && s + 1 < a.N && a.view_idx[s + 1] < v) __hip_atomic_fetch_or(rr.ticket + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            kp_deposit4(rr.part + s * KP_DEP + 4 * o, q0, q1, q2, q3);
+            if (o == 0) kp_mark_bounds(rr, a.view_idx, a.N, a.V, s, v);
         }
-        __shared__ int rflag;
-        if (nemo_red_arrive(rr, 0, (int)gridDim.x, &rflag))
-            kp_view_finish(rr.part, a.view_idx, a.N, a.V, (FUSED && view_acc_out) ? view_acc_out : nullptr, d_cams,
-                           (FUSED && view_acc_out) ? 0 : 2, d_cams ? 11 : 2, &rflag, rr.ticket + 1);
     }
     if (!ordered && FUSED && view_acc_out) {
         // the forward's per-view accumulators [sum(loss * conf), #samples]: one atomic per (block, view), as in kp_fwd_kernel
@@ -984,13 +991,21 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
             if (live && o == 0) dTR[s * lddt + c] = r;
         }
     }
-    if (!dA) return;
+    if (dA) {
     // kinematic joints: dJp[s][j] += the position gradients of the output joints that ARE kinematic joint j, added in output
     // order by ONE thread per (sample, joint, component) (round 5: float atomics per output joint before -- several outputs can
     // share a joint, and the order of their additions changed from run to run)
+    // (the outputs of a joint as a list built once per block: a loop over all outputs with a look-up and a branch per
+    //  iteration was 75 dependent LDS round trips per thread, 8 us of the 8 x 300 step's kernel)
     __shared__ float dkin[256 / LANES][NEMO_MAX_OUT][3];
-    __shared__ int kkin[NEMO_MAX_OUT];
-    if (threadIdx.x < NEMO_MAX_OUT) kkin[threadIdx.x] = threadIdx.x < kc.n_out ? kc.out_kind[threadIdx.x] : -1;
+    __shared__ unsigned char klist[24][NEMO_MAX_OUT];
+    __shared__ int kcnt[24];
+    if (threadIdx.x < 24) {
+        int n = 0;
+        for (int q = 0; q < kc.n_out && q < NEMO_MAX_OUT; ++q)
+            if (kc.out_kind[q] == (int)threadIdx.x) klist[threadIdx.x][n++] = (unsigned char)q;
+        kcnt[threadIdx.x] = n;
+    }
     if (o < kc.n_out && o < NEMO_MAX_OUT) {
         const int slk = threadIdx.x / LANES;
         dkin[slk][o][0] = active ? dpos[0] : 0.f; dkin[slk][o][1] = active ? dpos[1] : 0.f; dkin[slk][o][2] = active ? dpos[2] : 0.f;
@@ -999,12 +1014,11 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
     for (int idx = threadIdx.x; idx < (256 / LANES) * 72; idx += 256) {
         const int ls = idx / 72, j = (idx % 72) / 3, c = idx % 3;
         const long ss = (long)blockIdx.x * (256 / LANES) + ls;
-        if (ss >= a.N) continue;
+        const int n = kcnt[j];
+        if (ss >= a.N || n == 0) continue;
         float acc = 0.f;
-        bool any = false;
-        for (int q = 0; q < kc.n_out; ++q)
-            if (kkin[q] == j) { acc += dkin[ls][q][c]; any = true; }
-        if (any) dJp[ss * 72 + j * 3 + c] += acc;
+        for (int i = 0; i < n; ++i) acc += dkin[ls][klist[j][i]][c];
+        dJp[ss * 72 + j * 3 + c] += acc;
     }
     // mesh functionals: pos = sum_j A_R[j] Mq[q][j] + A_t[j] w0[q][j].
     // d Mq[q][j] = A_R[j]^T dpos_q is private to the (sample, joint) lane; dA[j] sums over the mesh
@@ -1045,6 +1059,7 @@ __global__ __launch_bounds__(256) void kp_bwd_kernel(KpArgs a, KpConst kc, const
         }
         float* o3 = dA + ss * 288 + j * 12 + c;
         o3[0] = a0; o3[4] = a1; o3[8] = a2;
+    }
     }
 }
 
@@ -2067,8 +2082,11 @@ extern "C" int32_t nemo_kp_fwd(const nemo_ctx* ctx, int64_t N, int64_t V, int64_
     a.n_valid = n_valid;
     if (N == 0) return NEMO_OK;
     if (ctx->n_out > 32) return NEMO_EINVAL;
+    const NemoRed rr = view_acc ? nemo_red_take(kp_dep_floats(N, V), 2) : NemoRed{nullptr, nullptr};
     hipLaunchKernelGGL(kp_fwd_kernel<32>, dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
-                       ctx->kc, j3d, p2d, loss_all, view_acc, view_acc ? nemo_red_take((size_t)N * KP_DEP, 2) : NemoRed{nullptr, nullptr});
+                       ctx->kc, j3d, p2d, loss_all, view_acc, rr);
+    NEMO_LAUNCH_CHECK();
+    kp_launch_view_finish(rr, view_idx, N, V, view_acc, nullptr, 0, 2, (hipStream_t)stream);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -2099,10 +2117,12 @@ static int32_t kp_bwd_impl(const nemo_ctx* ctx, int64_t N, int64_t V, int64_t T,
     if (dA && (!dJp || (ctx->nq > 0 && !dMq))) return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
     if (ctx->n_out > 32) return NEMO_EINVAL;
+    const NemoRed rr = d_cams ? nemo_red_take(kp_dep_floats(N, V), 2) : NemoRed{nullptr, nullptr};
     hipLaunchKernelGGL(kp_bwd_kernel<32>, dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
                        ctx->kc, view_acc, norm, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams, (int)ctx->nq, dj3d_extra,
-                       (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                       d_cams ? nemo_red_take((size_t)N * KP_DEP, 2) : NemoRed{nullptr, nullptr});
+                       (const int64_t*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, rr);
+    NEMO_LAUNCH_CHECK();
+    kp_launch_view_finish(rr, view_idx, N, V, nullptr, d_cams, 2, 11, (hipStream_t)stream);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
@@ -2149,10 +2169,12 @@ extern "C" int32_t nemo_kp_fwd_bwd(const nemo_ctx* ctx, int64_t N, int64_t V, in
     if (dA && (!dJp || (ctx->nq > 0 && !dMq))) return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
     if (ctx->n_out > 32) return NEMO_EINVAL;
+    const NemoRed rr = nemo_red_take(kp_dep_floats(N, V), 2);
     hipLaunchKernelGGL((kp_bwd_kernel<32, true>), dim3(nemo_cdiv(N * 32, 256)), dim3(256), 0, (hipStream_t)stream, a,
                        ctx->kc, (const float*)nullptr, (const float*)nullptr, upstream, dA, dJp, dMq, dTR, (long)lddt, d_cams,
-                       (int)ctx->nq, (const float*)nullptr, view_count, j3d, p2d, loss_all, view_acc,
-                       nemo_red_take((size_t)N * KP_DEP, 2));
+                       (int)ctx->nq, (const float*)nullptr, view_count, j3d, p2d, loss_all, view_acc, rr);
+    NEMO_LAUNCH_CHECK();
+    kp_launch_view_finish(rr, view_idx, N, V, view_acc, d_cams, 0, d_cams ? 11 : 2, (hipStream_t)stream);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }
