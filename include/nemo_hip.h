@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 12
+#define NEMO_ABI_VERSION 13
 int32_t nemo_abi_version(void);
 
 /* Deterministic accumulation (round 5).  Every sum over the blocks of a launch that used float atomics until round 4 -- the
@@ -354,6 +354,15 @@ int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N);
 int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
                        float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* ws, int64_t ws_bytes,
                        void* stream);
+/* nemo_v2v_fused in fp32-EQUIVALENT arithmetic with the pose blend's products (lbs.py:229-233, K = 207: 76 % of the fp32
+ * kernel's matrix-pipe cycles) on the bf16 matrix cores: both operands are carried as THREE bf16 pieces (8 + 8 + 8 significant
+ * bits = the fp32 value; blend shapes split once at nemo_ctx_create, pose features when staged), the six piece products whose
+ * weight is >= 2^-24 are exact in fp32 and accumulated in fp32.  Skinning, L1, d vp and the vertex->joint adjoint as in
+ * nemo_v2v_fused.  Same arguments, outputs, scratch and determinism.  tests/test_gpu_ops.py::test_v2v_fused_split3_* hold its
+ * error against a float64 evaluation to the fp32-MFMA kernel's (round 5; the engine's `mesh_blend = 'f32_split'`). */
+int32_t nemo_v2v_fused_split3(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
+                              float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* ws, int64_t ws_bytes,
+                              void* stream);
 /* The same with the pose blend (lbs.py:229-233, K = 207) on the bf16 matrix cores: blend shapes rounded to bf16 once
  * at nemo_ctx_create, pose features rounded when staged, fp32 accumulate; skinning, L1 and d vp in fp32; the vertex->joint adjoint dA on the
  * bf16 cores in split precision (two bf16 pieces per fp32 operand, 16 significant bits; NEMO_MESH_SPLIT=0: fp32).

@@ -40,6 +40,7 @@ struct nemo_ctx {
     // blend shapes rounded to bf16 (RNE) in MFMA-operand order for nemo_v2v_fused_bf16: [k-step S = 0..6][lane group
     // g = 0..3][vertex][component][8 consecutive k = 32 S + 8 g ..], zero for k >= 207 and for pad vertices
     unsigned short* d_posedirs_bf16;
+    unsigned short* d_posedirs_sp3;    // three bf16 pieces per blend shape (mesh kernel MODE 4), [tile][S][component][piece][g][vertex][8 k]
     // skinning weights as TWO bf16 pieces (hi = bf16(w), lo = bf16(w - hi): 16 mantissa bits) for the split-precision
     // skinning of the bf16 mesh kernel, in MFMA-operand order:
     //   d_Wsk  [piece][vertex (NVp)][32]: forward A-operand rows (k = joint, zero for k >= 24)
@@ -194,17 +195,43 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
             if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);      // NaN
             return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);                    // round to nearest even
         };
+        // [vertex tile][k-step S of 32][component][g = 8-k group][vertex in tile][8 k]: the 64 lanes of ONE buffer_load_dwordx4 of
+        // the mesh kernel (lane = 16 g + vertex) read 1 KB of consecutive memory, a tile's 21 loads 21 KB.  (Until round 5:
+        // [S][g][vertex][component][8 k] -- a load took 16 bytes of every 48: 26 cache lines touched per instruction, the L1's
+        // tag / data-return path 66 - 79 % busy over the whole kernel, profiles/r05_pmc_mesh_b16.md.)
         std::vector<unsigned short> pb((size_t)28 * c->NVp * 24, 0);
         for (int k = 0; k < 207; ++k) {
             const int S = k / 32, g = (k % 32) / 8, i = k % 8;
             const float* Pk = posedirs + (size_t)k * NV * 3;
             for (long v = 0; v < NV; ++v)
                 for (int cc = 0; cc < 3; ++cc)
-                    pb[((((size_t)(S * 4 + g) * c->NVp + v) * 3 + cc) * 8) + i] = bf16(Pk[v * 3 + cc]);
+                    pb[(((((size_t)(v / 16) * 7 + S) * 3 + cc) * 4 + g) * 16 + v % 16) * 8 + i] = bf16(Pk[v * 3 + cc]);
         }
         c->d_posedirs_bf16 = nullptr;
         HIPCHK(hipMalloc((void**)&c->d_posedirs_bf16, pb.size() * 2));
         HIPCHK(hipMemcpy(c->d_posedirs_bf16, pb.data(), pb.size() * 2, hipMemcpyHostToDevice));
+        {
+            // fp32-equivalent split: x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (the
+            // subtractions are exact in fp32)
+            auto unb = [](unsigned short h) -> float { unsigned int u = (unsigned int)h << 16; float f; memcpy(&f, &u, 4); return f; };
+            std::vector<unsigned short> p3((size_t)28 * c->NVp * 72, 0);
+            for (int k = 0; k < 207; ++k) {
+                const int S = k / 32, g = (k % 32) / 8, i = k % 8;
+                const float* Pk = posedirs + (size_t)k * NV * 3;
+                for (long v = 0; v < NV; ++v)
+                    for (int cc = 0; cc < 3; ++cc) {
+                        float x = Pk[v * 3 + cc];
+                        for (int pc = 0; pc < 3; ++pc) {
+                            const unsigned short h = bf16(x);
+                            p3[((((((size_t)(v / 16) * 7 + S) * 3 + cc) * 3 + pc) * 4 + g) * 16 + v % 16) * 8 + i] = h;
+                            x -= unb(h);
+                        }
+                    }
+            }
+            c->d_posedirs_sp3 = nullptr;
+            HIPCHK(hipMalloc((void**)&c->d_posedirs_sp3, p3.size() * 2));
+            HIPCHK(hipMemcpy(c->d_posedirs_sp3, p3.data(), p3.size() * 2, hipMemcpyHostToDevice));
+        }
         auto unbf = [](unsigned short h) -> float { unsigned int u = (unsigned int)h << 16; float f; memcpy(&f, &u, 4); return f; };
         const long ntl = c->NVp / 16;
         std::vector<unsigned short> wsk((size_t)2 * c->NVp * 32, 0), wadj((size_t)ntl * 2 * 2 * 64 * 8, 0);
@@ -263,6 +290,7 @@ extern "C" int32_t nemo_ctx_destroy(nemo_ctx* c) {
     for (float* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->d_posedirs_bf16) (void)hipFree(c->d_posedirs_bf16);
+    if (c->d_posedirs_sp3) (void)hipFree(c->d_posedirs_sp3);
     if (c->d_Wsk) (void)hipFree(c->d_Wsk);
     if (c->d_Wadj) (void)hipFree(c->d_Wadj);
     if (c->d_Wsp_w) (void)hipFree(c->d_Wsp_w);
@@ -1332,7 +1360,13 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     int* __restrict__ grid_ticket, unsigned short* __restrict__ dVPb, long ldk,
     const unsigned short* __restrict__ Wsk, const unsigned short* __restrict__ Wadj,
     const float* __restrict__ Wsp_w, const unsigned int* __restrict__ Wsp_j) {
-    constexpr bool BF16 = MODE != 0, SPLIT = MODE == 2, ADJS = MODE >= 2;
+    constexpr bool BF16 = MODE >= 1 && MODE <= 3, SPLIT = MODE == 2, ADJS = MODE == 2 || MODE == 3;
+    // MODE 4 (round 5, "f32_split"): fp32 arithmetic everywhere EXCEPT that the pose blend's products run on the bf16 pipe with
+    // both operands carried as THREE bf16 pieces (8 + 8 + 8 significant bits = the fp32 value): x = x0 + x1 + x2, and
+    // P pf = P0 pf0 + P0 pf1 + P1 pf0 + P0 pf2 + P1 pf1 + P2 pf0 (+ terms below 2^-24 of |P| |pf|), every piece product exact in
+    // fp32, fp32 accumulation: 252 MFMAs of 16 cycles per tile instead of 312 of 32.  P then points at
+    // nemo_ctx::d_posedirs_sp3, pose features are split when they are staged.
+    constexpr bool SP3 = MODE == 4, B16 = BF16 || SP3;
     static_assert(!(SPARSE && SPLIT), "sparse skinning replaces the split-precision skinning");
     // All constants are zero-padded by nemo_ctx_create (P: 224 rows x 3*NVp columns, W / v_shaped: NVp
     // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
@@ -1344,9 +1378,10 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* pfL = lds;                                   // [2][16][MF_PFS] floats  (BF16: [2][16][MF_PFB] bf16)
     __bf16* pfB = reinterpret_cast<__bf16*>(lds);
-    float* AL = lds + (BF16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS);     // [2][16][MF_AS], entry (e*24 + j)
+    float* AL = lds + (SP3 ? 3 * 2 * 16 * MF_PFB / 2 : BF16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS);   // [2][16][MF_AS], entry (e*24 + j)
+                                                        // (SP3: pose features as [piece 3][body 2][16][MF_PFB] bf16)
     __bf16* ALb = reinterpret_cast<__bf16*>(AL);        // MODE 2: [body 2][piece 2][16][MF_AB] bf16, entry (e*32 + j)
-    float* red = AL + 2 * 16 * (SPARSE ? MF_ASP : MF_AS);                  // MF_TAIL: 16 floats + the two flags
+    float* red = AL + (SPLIT ? 2 * 2 * 16 * MF_AB / 2 : 2 * 16 * (SPARSE ? MF_ASP : MF_AS));   // MF_TAIL: 16 floats + the two flags
     int& ticket_old = *reinterpret_cast<int*>(red + 16);
     int& grid_last = *reinterpret_cast<int*>(red + 17);
     const long ntiles = (NV + 15) / 16;
@@ -1418,7 +1453,17 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             float4 v = vpf[it];
             if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q == 51) v.w = 0.f;                                 // column 207 is padding
-            if (BF16) {
+            if (SP3) {
+                typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    bf4 h;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { h[i] = (__bf16)x[i]; x[i] -= (float)h[i]; }
+                    *reinterpret_cast<bf4*>(pfB + ((pc * 2 + set) * 16 + n) * MF_PFB + 4 * q) = h;
+                }
+            } else if (BF16) {
                 typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
                 const bf4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
                 *reinterpret_cast<bf4*>(pfB + (set * 16 + n) * MF_PFB + 4 * q) = h;          // 8-byte store
@@ -1428,8 +1473,8 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
             }
         }
-        for (int idx = tid; idx < 2 * 16 * 16; idx += 256) {        // rows 208..223 of the k padding
-            if (BF16) pfB[(idx / 16) * MF_PFB + 208 + idx % 16] = (__bf16)0.f;
+        for (int idx = tid; idx < (SP3 ? 3 : 1) * 2 * 16 * 16; idx += 256) {        // rows 208..223 of the k padding
+            if (B16) pfB[(idx / 16) * MF_PFB + 208 + idx % 16] = (__bf16)0.f;
             else pfL[(idx / 16) * MF_PFS + 208 + idx % 16] = 0.f;
         }
 #pragma unroll
@@ -1463,7 +1508,15 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             const int set = idx / (16 * 224), n = (idx / 224) % 16, p = idx % 224;
             const long s = s0 + n;
             const float val = (s < N && p < 207) ? PF2[(set * N + s) * ldpf + p] : 0.f;
-            if (BF16) pfB[(set * 16 + n) * MF_PFB + p] = (__bf16)val;
+            if (SP3) {
+                float x = val;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    const __bf16 h = (__bf16)x;
+                    pfB[((pc * 2 + set) * 16 + n) * MF_PFB + p] = h;
+                    x -= (float)h;
+                }
+            } else if (BF16) pfB[(set * 16 + n) * MF_PFB + p] = (__bf16)val;
             else pfL[(set * 16 + n) * MF_PFS + p] = val;
         }
         for (int idx = tid; idx < 2 * 16 * 288; idx += 256) {
@@ -1512,23 +1565,32 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     // single load in flight (it otherwise moves each load to just before its use to save registers).
     // Buffer loads: one descriptor for the blend-shape matrix, a scalar byte offset for (tile, k-step) and
     // ONE 32-bit lane offset -- no 64-bit vector address arithmetic and no address registers in the ring.
-    // (BF16: P = bf16 blend shapes [S][g][vertex][component][8 k], ldP = NVp; one dwordx4 per lane, component and MFMA)
+    // (BF16: P = bf16 blend shapes [tile][S][component][g][vertex][8 k], ldP = NVp; one dwordx4 per lane, component and MFMA:
+    //  1 KB of consecutive memory per instruction)
     const __amdgpu_buffer_rsrc_t Prs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(P), 0, BF16 ? (int)(28 * ldP * 48) : (int)(224 * ldP * 4), 0x00020000);
-    const int loff = BF16 ? (g * (int)ldP + l15) * 48 : (g * (int)ldP + l15 * 3) * 4;   // lane part of the address (bytes)
-    const int kstride = BF16 ? 4 * (int)ldP * 48 : 4 * (int)ldP * 4;                    // bytes between consecutive k-steps
-    constexpr int TILE_B = BF16 ? 16 * 48 : 192;                 // bytes between consecutive vertex tiles
+        const_cast<float*>(P), 0, SP3 ? (int)(28 * ldP * 144) : BF16 ? (int)(28 * ldP * 48) : (int)(224 * ldP * 4), 0x00020000);
+    const int loff = B16 ? lane * 16 : (g * (int)ldP + l15 * 3) * 4;                    // lane part of the address (bytes)
+    const int kstride = SP3 ? 9 * 1024 : BF16 ? 3 * 1024 : 4 * (int)ldP * 4;            // bytes between consecutive k-steps
+    constexpr int TILE_B = SP3 ? 7 * 9 * 1024 : BF16 ? 7 * 3 * 1024 : 192;              // bytes between consecutive vertex tiles
+    // (SP3: P = [tile][S][component][piece][g][vertex][8 k] bf16, 1 KB per (S, component, piece))
     u32x3 pa[8];                                                 // fp32: eight k-steps (of 4) in flight
     constexpr int PQD = MODE == 3 ? MESH_PQD : 2;                      // bf16: PQD k-steps (of 32) x 3 components in flight
     u32x4m pq[PQD][3];
+    u32x4m ps[3][3];                                             // SP3: ONE k-step, [component][piece], refilled piece by piece
     {
         const int tf = (int)min(t_beg + wid, ntiles - 1);        // (a wave without tiles loads a valid one)
-        if (BF16) {
+        if (SP3) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    ps[c][pc] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, tf * TILE_B + (3 * c + pc) * 1024, 0);
+        } else if (BF16) {
 #pragma unroll
             for (int u = 0; u < PQD; ++u)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    pq[u][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff + 16 * c, tf * TILE_B + u * kstride, 0);
+                    pq[u][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, tf * TILE_B + u * kstride + 1024 * c, 0);
         } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) pa[u] = __builtin_amdgcn_raw_buffer_load_b96(Prs, loff, tf * 192 + u * kstride, 0);
@@ -1586,7 +1648,38 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             }
         const int pt = (int)t * TILE_B;                          // uniform byte offsets: this wave's vertex tile
         const int ptn = (int)min(t + 4, ntiles - 1) * TILE_B;    // and its next one (clamped: harmless re-read)
-        if constexpr (BF16) {
+        if constexpr (SP3) {
+            // 7 k-steps of 32 x 6 piece products x 3 components x 2 bodies = 252 MFMAs.  Product order per k-step: the three
+            // with P's piece 0, then its piece 1, then piece 2 -- a piece's registers are re-requested for the NEXT k-step as
+            // soon as its last product has been issued (384 - 576 MFMA cycles ahead of their next use: no second buffer).
+            // Six accumulators in rotation: no MFMA waits for its predecessor.
+#pragma unroll
+            for (int S = 0; S < 7; ++S) {
+                mbf16x8 b[2][3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                    for (int bd = 0; bd < 2; ++bd)
+                        b[bd][pc] = *reinterpret_cast<const mbf16x8*>(pfB + ((pc * 2 + bd) * 16 + l15) * MF_PFB + 8 * g + 32 * S);
+#pragma unroll
+                for (int pa = 0; pa < 3; ++pa) {
+#pragma unroll
+                    for (int pb = 2 - pa; pb >= 0; --pb)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const mbf16x8 a = __builtin_bit_cast(mbf16x8, ps[c][pa]);
+                            vp[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[0][pb], vp[0][c], 0, 0, 0);
+                            vp[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[1][pb], vp[1][c], 0, 0, 0);
+                        }
+                    if (S + 1 < 7) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            ps[c][pa] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, pt + (S + 1) * kstride + (3 * c + pa) * 1024, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else if constexpr (BF16) {
             // 7 k-steps of 32 (207 blend shapes + zero rows) x 3 components x 2 bodies = 42 MFMAs
             const __bf16* pb0 = pfB + (0 * 16 + l15) * MF_PFB + 8 * g;
             const __bf16* pb1 = pfB + (1 * 16 + l15) * MF_PFB + 8 * g;
@@ -1600,7 +1693,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 if (S + PQD < 7) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        pq[S % PQD][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff + 16 * c, pt + (S + PQD) * kstride, 0);
+                        pq[S % PQD][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, pt + (S + PQD) * kstride + 1024 * c, 0);
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -1736,12 +1829,18 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 // the wave's NEXT tile: first eight k-steps requested here, under the cover of the last 32
                 // adjoint MFMAs and the dvp store (their registers are dead during the skinning phases,
                 // where the pressure peaks -- a ring kept full across the whole tile spills)
-                if (BF16) {
+                if (SP3) {
+#pragma unroll
+                    for (int c2 = 0; c2 < 3; ++c2)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            ps[c2][pc] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, ptn + (3 * c2 + pc) * 1024, 0);
+                } else if (BF16) {
 #pragma unroll
                     for (int u = 0; u < PQD; ++u)
 #pragma unroll
                         for (int c2 = 0; c2 < 3; ++c2)
-                            pq[u][c2] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff + 16 * c2, ptn + u * kstride, 0);
+                            pq[u][c2] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, ptn + u * kstride + 1024 * c2, 0);
                 } else {
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
@@ -2297,9 +2396,11 @@ extern "C" int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N) {
     return MESH_HEADER_BYTES + groups * (long)(pl.RA + 1) * 96 * 64 * 4;
 }
 
-static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const float* PF2, int64_t ldpf,
+static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const float* PF2, int64_t ldpf,
                               const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
                               void* ws, int64_t ws_bytes, void* stream, unsigned short* dVPb = nullptr, int64_t ldk = 0) {
+    // kind: 0 = fp32, 1 = bf16 blend (+ split adjoint), 2 = fp32 with the blend's products on the bf16 pipe in three pieces
+    const bool bf16 = kind == 1;
     if (!ctx || N < 0 || !PF2 || !A2 || !loss_sum || ldpf < 207) return NEMO_EINVAL;
     if (dVPb ? (!bf16 || ldk < ctx->ldP || (ldk & 3) || (((uintptr_t)dVPb) & 7)) : (!dVPt || ldn < ((N + 15) / 16) * 16))
         return NEMO_EINVAL;                                    // (dA == NULL: deferred combine, nemo_v2v_combine)
@@ -2307,12 +2408,17 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const f
     // bf16: bf16 blend + split-precision vertex->joint adjoint on the bf16 pipe (kernel MODE 3).  MODE 1 (bf16 blend only:
     // 3.55 against 3.25 ms per C3 step) and MODE 2 (split-precision skinning as well: slower, 475 against ~300 us per
     // launch) were measured in round 3 (profiles/r03_experiments.md sections 10, 13) and are no longer instantiated.
-    const int mode = bf16 ? 3 : 0;
-    const bool sparse = ctx->skin_sparse != 0;
-    const int lds_bytes = ((bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * (sparse ? MF_ASP : MF_AS) + MF_TAIL) * (int)sizeof(float);
-    static bool attr_set[4][2] = {{false, false}, {false, false}, {false, false}, {false, false}};
+    static const int split_env = getenv("NEMO_MESH_SPLIT") ? atoi(getenv("NEMO_MESH_SPLIT")) : 0;
+    const int mode = bf16 ? (split_env == 2 ? 2 : 3) : kind == 2 ? 4 : 0;
+    const bool sparse = ctx->skin_sparse != 0 && mode != 2;
+    const int lds_bytes = mode == 2 ? (2 * 16 * MF_PFB / 2 + 2 * 2 * 16 * MF_AB / 2 + MF_TAIL) * (int)sizeof(float)
+        : ((mode == 4 ? 3 * 2 * 16 * MF_PFB / 2 : bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * (sparse ? MF_ASP : MF_AS) + MF_TAIL) *
+              (int)sizeof(float);
+    static bool attr_set[5][2] = {{false, false}, {false, false}, {false, false}, {false, false}, {false, false}};
     if (!attr_set[mode][sparse]) {
-        const void* fn = mode == 3 ? (sparse ? (const void*)mesh_v2v_fused_kernel<3, true> : (const void*)mesh_v2v_fused_kernel<3, false>)
+        const void* fn = mode == 4 ? (sparse ? (const void*)mesh_v2v_fused_kernel<4, true> : (const void*)mesh_v2v_fused_kernel<4, false>)
+                       : mode == 2 ? (const void*)mesh_v2v_fused_kernel<2, false>
+                       : mode == 3 ? (sparse ? (const void*)mesh_v2v_fused_kernel<3, true> : (const void*)mesh_v2v_fused_kernel<3, false>)
                                    : (sparse ? (const void*)mesh_v2v_fused_kernel<0, true> : (const void*)mesh_v2v_fused_kernel<0, false>);
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_set[mode][sparse] = true;
@@ -2335,7 +2441,10 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, bool bf16, int64_t N, const f
         (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, PP, LDP, ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA,  \
         pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets, loss_parts, grid_ticket, dVPb, (long)ldk,    \
         ctx->d_Wsk, ctx->d_Wadj, ctx->d_Wsp_w, ctx->d_Wsp_j)
-    if (mode == 3 && sparse) MESH_LAUNCH(3, true, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
+    if (mode == 4 && sparse) MESH_LAUNCH(4, true, reinterpret_cast<const float*>(ctx->d_posedirs_sp3), ctx->NVp);
+    else if (mode == 4) MESH_LAUNCH(4, false, reinterpret_cast<const float*>(ctx->d_posedirs_sp3), ctx->NVp);
+    else if (mode == 2) MESH_LAUNCH(2, false, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
+    else if (mode == 3 && sparse) MESH_LAUNCH(3, true, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
     else if (mode == 3) MESH_LAUNCH(3, false, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
     else if (sparse) MESH_LAUNCH(0, true, ctx->d_posedirs, ctx->ldP);
     else MESH_LAUNCH(0, false, ctx->d_posedirs, ctx->ldP);
@@ -2362,7 +2471,15 @@ extern "C" int32_t nemo_v2v_combine(const nemo_ctx* ctx, int64_t N, float* dA, c
 extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
                                   const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
                                   void* ws, int64_t ws_bytes, void* stream) {
-    return v2v_fused_impl(ctx, false, N, PF2, ldpf, A2, loss_sum, dVPt, ldn, dA, ws, ws_bytes, stream);
+    return v2v_fused_impl(ctx, 0, N, PF2, ldpf, A2, loss_sum, dVPt, ldn, dA, ws, ws_bytes, stream);
+}
+
+// fp32 in, fp32 out, fp32-equivalent arithmetic: the pose blend's products on the bf16 pipe with both operands in three bf16
+// pieces (kernel MODE 4); same arguments and outputs as nemo_v2v_fused
+extern "C" int32_t nemo_v2v_fused_split3(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
+                                         const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
+                                         void* ws, int64_t ws_bytes, void* stream) {
+    return v2v_fused_impl(ctx, 2, N, PF2, ldpf, A2, loss_sum, dVPt, ldn, dA, ws, ws_bytes, stream);
 }
 
 // bf16 variant whose d vp output is bf16 and NOT transposed: dVPb (16 * ceil(N / 16) rows x ldk >= 3 NVp, bf16) -- the
@@ -2370,11 +2487,11 @@ extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* P
 extern "C" int32_t nemo_v2v_fused_bf16mem(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
                                           float* loss_sum, uint16_t* dVPb, int64_t ldk, float* dA, void* ws, int64_t ws_bytes,
                                           void* stream) {
-    return v2v_fused_impl(ctx, true, N, PF2, ldpf, A2, loss_sum, nullptr, 0, dA, ws, ws_bytes, stream, dVPb, ldk);
+    return v2v_fused_impl(ctx, 1, N, PF2, ldpf, A2, loss_sum, nullptr, 0, dA, ws, ws_bytes, stream, dVPb, ldk);
 }
 
 extern "C" int32_t nemo_v2v_fused_bf16(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
                                        const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
                                        void* ws, int64_t ws_bytes, void* stream) {
-    return v2v_fused_impl(ctx, true, N, PF2, ldpf, A2, loss_sum, dVPt, ldn, dA, ws, ws_bytes, stream);
+    return v2v_fused_impl(ctx, 1, N, PF2, ldpf, A2, loss_sum, dVPt, ldn, dA, ws, ws_bytes, stream);
 }

@@ -267,6 +267,18 @@ class FitEngine:
         if dt not in ('f32', 'bf16'):
             raise ValueError(f"args.gemm_dtype must be 'f32' or 'bf16', got {dt!r}")
         self.bf16 = dt == 'bf16'
+        # mesh_blend (round 5), fp32 builds only -- gemm_dtype='bf16' blends in plain bf16 whatever it says:
+        #   'f32_split' (default): the fused mesh term's pose blend (76 % of that kernel's matrix-pipe cycles) on the bf16 matrix
+        #       cores in fp32-EQUIVALENT arithmetic -- three bf16 pieces per operand, six exact piece products per fp32 product,
+        #       fp32 accumulation (nemo_v2v_fused_split3).  Its error against a float64 evaluation equals the fp32-MFMA kernel's
+        #       (tests/test_gpu_ops.py::test_v2v_fused_split3_is_fp32_equivalent: dA 1.57e-7 against 1.58e-7 rms), every 1e-4
+        #       parity gate passes unchanged, and the launch is 24 % shorter (392 against 519 us at 8 x 300).
+        #   'f32': the products on the fp32 MFMA pipe (rounds 1 - 4; bench.py's `f32_mfma_blend` leg).
+        # args.mesh_blend, overridden by NEMO_MESH_BLEND.
+        mb = os.environ.get('NEMO_MESH_BLEND') or getattr(args, 'mesh_blend', None) or 'f32_split'
+        if mb not in ('f32', 'f32_split'):
+            raise ValueError(f"args.mesh_blend must be 'f32' or 'f32_split', got {mb!r}")
+        self.mesh_split3 = mb == 'f32_split' and not self.bf16
         # bf16 operands IN MEMORY (round 3): every dense product of the MotionNet / VPoser chain reads bf16 copies of its
         # operands (written by the producing GEMM's epilogue, plain and transposed, or by nemo_cast_bf16) through
         # nemo_gemm_bf16mem -- the same values enter the matrix cores as with the on-the-fly rounding of nemo_gemm_bf16
@@ -480,7 +492,15 @@ class FitEngine:
         if tag == 'mesh_v2v_fused' and self.ctx.skin_sparse_flag:
             valu = flops * (2 * 12 * 4) / self.mesh_macs()
         if not self.bf16:
-            return {'f32': flops - valu, 'valu_f32': valu} if valu else {'f32': flops}
+            out = {'f32': flops - valu}
+            if tag == 'mesh_v2v_fused' and self.mesh_split3:
+                # (csrc/smpl.hip MODE 4: the two pose blends run on the bf16 pipe as SIX bf16 piece products per algorithmic
+                #  product -- pipe 'bf16x6', whose peak is a sixth of the bf16 MFMA peak)
+                b16 = flops * (2 * 3 * 207) / self.mesh_macs()
+                out = {'bf16x6': b16, 'f32': flops - b16 - valu}
+            if valu:
+                out['valu_f32'] = valu
+            return out
         if tag == 'mesh_v2v_fused':
             # (csrc/smpl.hip MODE 3: the vertex->joint adjoint -- 288 of the multiply-adds -- runs on the bf16 pipe too, as
             #  four bf16 piece products per algorithmic product)
@@ -504,7 +524,7 @@ class FitEngine:
 
     def mesh_kernel_variant(self):
         """The mesh kernel instantiation this engine launches (what counter files under profiles/ are keyed by)."""
-        mode = (3 if os.environ.get('NEMO_MESH_SPLIT', '1') != '0' else 1) if self.bf16 else 0
+        mode = (3 if os.environ.get('NEMO_MESH_SPLIT', '1') != '0' else 1) if self.bf16 else (4 if self.mesh_split3 else 0)
         return f"mesh_v2v_fused_kernel<{mode}, {'true' if self.ctx.skin_sparse_flag else 'false'}>"
 
     # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
@@ -1000,7 +1020,7 @@ class FitEngine:
                                     dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
             ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * self.mesh_macs())
             ws = w['mesh_ws']
-            fused = L.nemo_v2v_fused_bf16 if self.bf16 else L.nemo_v2v_fused
+            fused = L.nemo_v2v_fused_bf16 if self.bf16 else (L.nemo_v2v_fused_split3 if self.mesh_split3 else L.nemo_v2v_fused)
             # single-chunk batches: the per-group sum of the blocks' partial dA images runs as a launch of its own on the
             # second side stream, beside the blend-shape adjoint GEMM (only the FK adjoint behind that GEMM needs dA)
             # (large batches only: at a one-instance shard the extra fork / join of the replayed graph costs more than the
