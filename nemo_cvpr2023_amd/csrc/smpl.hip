@@ -48,6 +48,7 @@ struct nemo_ctx {
     //          holds W[16 tile + 4 g + t][16 jt + l15] for t = 0..3 TWICE (k = 8 g + t and 8 g + 4 + t: the B-operand
     //          carries the hi pieces of dT in the first four k and the lo pieces in the last four)
     unsigned short *d_Wsk, *d_Wadj;
+    unsigned short* d_Wadj3;           // MODE 4: [tile][joint tile 2][variant 3: W0|W0, W1|W1, W0|W2][lane 64][8] (three bf16 pieces of W)
     // SPARSE skinning weights (the published SMPL model has at most four non-zero weights per vertex; the dense 24-column
     // product of lbs.py:236-241 then multiplies 20 zeros per vertex): per vertex (NVp of them, zero rows for the pad) the
     // <= 4 non-zero weights in ascending joint order, and their joints as four bytes holding 3 * joint (the offset of the
@@ -235,6 +236,7 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
         auto unbf = [](unsigned short h) -> float { unsigned int u = (unsigned int)h << 16; float f; memcpy(&f, &u, 4); return f; };
         const long ntl = c->NVp / 16;
         std::vector<unsigned short> wsk((size_t)2 * c->NVp * 32, 0), wadj((size_t)ntl * 2 * 2 * 64 * 8, 0);
+        std::vector<unsigned short> wadj3((size_t)ntl * 2 * 3 * 64 * 8, 0);
         for (long v = 0; v < NV; ++v)
             for (int j = 0; j < 24; ++j) {
                 const float w = lbs_weights[v * 24 + j];
@@ -245,12 +247,22 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
                 const size_t base = ((((size_t)t * 2 + jt) * 2) * 64 + (g * 16 + l15)) * 8;
                 wadj[base + r] = hi; wadj[base + 4 + r] = hi;
                 wadj[base + 64 * 8 + r] = lo; wadj[base + 64 * 8 + 4 + r] = lo;
+                // three pieces (fp32-equivalent adjoint of MODE 4): A images [W0 | W0], [W1 | W1], [W0 | W2] over the two
+                // 16-vertex piece slots of a K = 32 instruction
+                const unsigned short w0 = hi, w1 = lo, w2 = bf16(w - unbf(hi) - unbf(lo));
+                const size_t b3 = ((((size_t)t * 2 + jt) * 3) * 64 + (g * 16 + l15)) * 8;
+                wadj3[b3 + r] = w0; wadj3[b3 + 4 + r] = w0;
+                wadj3[b3 + 64 * 8 + r] = w1; wadj3[b3 + 64 * 8 + 4 + r] = w1;
+                wadj3[b3 + 2 * 64 * 8 + r] = w0; wadj3[b3 + 2 * 64 * 8 + 4 + r] = w2;
             }
         c->d_Wsk = c->d_Wadj = nullptr;
         HIPCHK(hipMalloc((void**)&c->d_Wsk, wsk.size() * 2));
         HIPCHK(hipMemcpy(c->d_Wsk, wsk.data(), wsk.size() * 2, hipMemcpyHostToDevice));
         HIPCHK(hipMalloc((void**)&c->d_Wadj, wadj.size() * 2));
         HIPCHK(hipMemcpy(c->d_Wadj, wadj.data(), wadj.size() * 2, hipMemcpyHostToDevice));
+        c->d_Wadj3 = nullptr;
+        HIPCHK(hipMalloc((void**)&c->d_Wadj3, wadj3.size() * 2));
+        HIPCHK(hipMemcpy(c->d_Wadj3, wadj3.data(), wadj3.size() * 2, hipMemcpyHostToDevice));
     }
     {
         int nnz_max = 0;
@@ -293,6 +305,7 @@ extern "C" int32_t nemo_ctx_destroy(nemo_ctx* c) {
     if (c->d_posedirs_sp3) (void)hipFree(c->d_posedirs_sp3);
     if (c->d_Wsk) (void)hipFree(c->d_Wsk);
     if (c->d_Wadj) (void)hipFree(c->d_Wadj);
+    if (c->d_Wadj3) (void)hipFree(c->d_Wadj3);
     if (c->d_Wsp_w) (void)hipFree(c->d_Wsp_w);
     if (c->d_Wsp_j) (void)hipFree(c->d_Wsp_j);
     delete c;
@@ -1367,6 +1380,23 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     // fp32, fp32 accumulation: 252 MFMAs of 16 cycles per tile instead of 312 of 32.  P then points at
     // nemo_ctx::d_posedirs_sp3, pose features are split when they are staged.
     constexpr bool SP3 = MODE == 4, B16 = BF16 || SP3;
+    // ... and the vertex->joint adjoint dA = W^T dT likewise (ADJ3): W in three pieces as A images [W0 | W0], [W1 | W1], [W0 | W2]
+    // over the two 16-vertex slots of a K = 32 instruction (Wadj then points at nemo_ctx::d_Wadj3), dT in three pieces as B
+    // operands [T0 ; T1] and [T2 ; T0]: three MFMAs of 16 cycles per (entry, joint tile) instead of eight fp32 ones of 32.
+    // dT_e = gs * vp_d with gs in {-1, 0, +1}: its pieces are the pieces of vp -- formed ONCE per tile -- with the sign bit
+    // flipped / zeroed per row.
+#ifndef MESH_ADJ3
+#define MESH_ADJ3 1
+#endif
+    constexpr bool ADJ3 = SP3 && MESH_ADJ3 != 0;
+#ifndef MESH_ADJ3_LATE
+#define MESH_ADJ3_LATE 1
+#endif
+    // Placement (measured, 8 x 300): the adjoint MFMAs of all three rows BEHIND the row loop and the dvp store, the three W images
+    // requested there too (MESH_ADJ3_LATE 1, MESH_ADJ3_WLOAD 3): no spilled register, 374 us per launch against 386 with the fp32
+    // adjoint (dense weights: 416 against 462).  Inside the row loop, or with the W images requested earlier, hipcc spills 33 - 231
+    // registers of the sparse instantiation (474 - 635 us).
+    constexpr bool ADJ3_LATE = MESH_ADJ3_LATE != 0;
     static_assert(!(SPARSE && SPLIT), "sparse skinning replaces the split-precision skinning");
     // All constants are zero-padded by nemo_ctx_create (P: 224 rows x 3*NVp columns, W / v_shaped: NVp
     // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
@@ -1603,6 +1633,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         // weights as A-operands: forward (rows = vertices, k = joints) and adjoint (rows = joints, k = vertices)
         float wf[6], wa[4][2];
         mbf16x8 wsk[2], wad[2][2];                               // split precision: [piece], [joint tile][piece]
+        mbf16x8 wad3[2][3];                                      // ADJ3: [joint tile][A image]
         float4 sw[4];                                            // sparse: this lane's 4 vertices x <= 4 (weight, joint)
         unsigned int sj[4];
         if constexpr (SPARSE) {
@@ -1617,7 +1648,13 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             for (int kk = 0; kk < 6; ++kk) wf[kk] = Wf[4 * kk];
         }
         auto load_adjoint_weights = [&]() {
-        if constexpr (ADJS) {
+        if constexpr (ADJ3) {
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    wad3[jt][q] = *reinterpret_cast<const mbf16x8*>(Wadj + (((t * 2 + jt) * 3 + q) * 64 + lane) * 8);
+        } else if constexpr (ADJS) {
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
@@ -1635,7 +1672,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         // (sparse bf16: requested after the reconstruction body -- first used a skinning row + the sign pass later -- so that
         //  their 16 registers are not live across the blend and the first skinning phase: 18 spilled registers otherwise.
         //  The fp32 form keeps them at the top of the tile: moved, hipcc spills 270.)
-        if constexpr (!(SPARSE && ADJS)) load_adjoint_weights();
+        if constexpr (!(SPARSE && (ADJS || ADJ3)) && !(ADJ3 && ADJ3_LATE)) load_adjoint_weights();
         // ---- pose blend of both bodies: 52 k-steps x 3 components, A-operand P[p][3v+c] from L2
         f32x4 vp[2][3];
         const float* vsl = vs + (v0 + 4 * g) * 3;
@@ -1653,14 +1690,19 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             // with P's piece 0, then its piece 1, then piece 2 -- a piece's registers are re-requested for the NEXT k-step as
             // soon as its last product has been issued (384 - 576 MFMA cycles ahead of their next use: no second buffer).
             // Six accumulators in rotation: no MFMA waits for its predecessor.
-#pragma unroll
-            for (int S = 0; S < 7; ++S) {
-                mbf16x8 b[2][3];
+            // (B operands -- the pose-feature pieces, LDS -- one k-step ahead: requested behind the first product group of the
+            //  previous k-step)
+            mbf16x8 b[2][2][3];                                  // [buffer][body][piece]
+            auto load_b = [&](const int buf, const int S) {
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
                     for (int bd = 0; bd < 2; ++bd)
-                        b[bd][pc] = *reinterpret_cast<const mbf16x8*>(pfB + ((pc * 2 + bd) * 16 + l15) * MF_PFB + 8 * g + 32 * S);
+                        b[buf][bd][pc] = *reinterpret_cast<const mbf16x8*>(pfB + ((pc * 2 + bd) * 16 + l15) * MF_PFB + 8 * g + 32 * S);
+            };
+            load_b(0, 0);
+#pragma unroll
+            for (int S = 0; S < 7; ++S) {
 #pragma unroll
                 for (int pa = 0; pa < 3; ++pa) {
 #pragma unroll
@@ -1668,13 +1710,14 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             const mbf16x8 a = __builtin_bit_cast(mbf16x8, ps[c][pa]);
-                            vp[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[0][pb], vp[0][c], 0, 0, 0);
-                            vp[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[1][pb], vp[1][c], 0, 0, 0);
+                            vp[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[S & 1][0][pb], vp[0][c], 0, 0, 0);
+                            vp[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[S & 1][1][pb], vp[1][c], 0, 0, 0);
                         }
                     if (S + 1 < 7) {
 #pragma unroll
                         for (int c = 0; c < 3; ++c)
                             ps[c][pa] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, pt + (S + 1) * kstride + (3 * c + pa) * 1024, 0);
+                        if (pa == 0) load_b((S + 1) & 1, S + 1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1775,7 +1818,62 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
         /*prof:c2*/
-        if constexpr (SPARSE && ADJS) load_adjoint_weights();
+        if constexpr (SPARSE && (ADJS || (ADJ3 && !ADJ3_LATE))) load_adjoint_weights();
+        unsigned int smz[3][2], zmz[3][2];                       // ADJ3: sign / zero masks of the three rows, [row][vertex pair]
+        unsigned int vpp[3][3][2];                               // ADJ3: [piece][coordinate d][vertex pair] of vp_orig, packed bf16
+        auto adj3_prefetch = [&]() {     // the wave's NEXT tile: its first k-step
+#pragma unroll
+            for (int c2 = 0; c2 < 3; ++c2)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    ps[c2][pc] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, ptn + (3 * c2 + pc) * 1024, 0);
+        };
+        auto adj3_pieces = [&]() {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float x[4] = {vp[0][d][0], vp[0][d][1], vp[0][d][2], vp[0][d][3]};
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const __bf16 h0 = (__bf16)x[2 * pr], h1 = (__bf16)x[2 * pr + 1];
+                        vpp[pc][d][pr] = (unsigned int)__builtin_bit_cast(unsigned short, h0) |
+                                         ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+                        x[2 * pr] -= (float)h0; x[2 * pr + 1] -= (float)h1;
+                    }
+            }
+        };
+        auto adj3_row = [&](const int c) {
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh) {                     // two entries (c, d) at a time: four accumulators in rotation
+                mbf16x8 b1[2], b2[2];                            // [T0 ; T1] and [T2 ; T0]
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd) {
+                    const int d = 2 * dh + dd;
+                    unsigned int tk[3][2];
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        // (d = 3: dT = gs itself, +-1.0 = 0x3f80 with the sign flipped, no lower pieces; vp pieces carry
+                        //  vp's sign: flipped when gs = -1)
+                        const unsigned int sm = smz[c][pr], zm = zmz[c][pr];
+                        tk[0][pr] = d < 3 ? ((vpp[0][d][pr] ^ sm) & zm) : ((0x3f803f80u ^ sm) & zm);
+                        tk[1][pr] = d < 3 ? ((vpp[1][d][pr] ^ sm) & zm) : 0u;
+                        tk[2][pr] = d < 3 ? ((vpp[2][d][pr] ^ sm) & zm) : 0u;
+                    }
+                    const u32x4m q1 = {tk[0][0], tk[0][1], tk[1][0], tk[1][1]}, q2 = {tk[2][0], tk[2][1], tk[0][0], tk[0][1]};
+                    b1[dd] = __builtin_bit_cast(mbf16x8, q1); b2[dd] = __builtin_bit_cast(mbf16x8, q2);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int dd = 0; dd < 2; ++dd) {
+                        const int e = 4 * c + 2 * dh + dd;
+                        accdA[e][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wad3[0][q], q < 2 ? b1[dd] : b2[dd], accdA[e][0], 0, 0, 0);
+                        accdA[e][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wad3[1][q], q < 2 ? b1[dd] : b2[dd], accdA[e][1], 0, 0, 0);
+                    }
+            }
+        };
+        if constexpr (ADJ3) { if (!ADJ3_LATE) adj3_pieces(); }
         // ---- original body: row c of the transform -> vertex coordinate c -> sign -> its share of dvp and
         // the four dT entries (c, 0..3), which go straight into the vertex->joint MFMA as B-operands
         float dvp[3][4];
@@ -1786,6 +1884,10 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             /*prof:q0*/
+#ifndef MESH_ADJ3_WLOAD
+#define MESH_ADJ3_WLOAD 3
+#endif
+            if constexpr (ADJ3 && ADJ3_LATE) { if (c == MESH_ADJ3_WLOAD) load_adjoint_weights(); }   // (the three W images: first used behind the rows)
             f32x4 T4[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d)
@@ -1825,7 +1927,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 for (int d2 = 0; d2 < 3; ++d2) dvp[d2][r] += T4[d2][r] * gs[r];
             }
             /*prof:q2*/
-            if (c == 2) {
+            if (c == 2 && !ADJ3) {
                 // the wave's NEXT tile: first eight k-steps requested here, under the cover of the last 32
                 // adjoint MFMAs and the dvp store (their registers are dead during the skinning phases,
                 // where the pressure peaks -- a ring kept full across the whole tile spills)
@@ -1848,7 +1950,21 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (ADJS) {
+            if constexpr (ADJ3) {
+                // sign (bit 15 / 31) and zero masks of the lane's two vertex pairs for this row; the adjoint MFMAs of all three
+                // rows follow the loop (with them here, the three W images + the pieces of vp + the skinning weights: 33 - 45
+                // spilled registers)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const unsigned int g0 = __float_as_uint(gs[2 * pr]), g1 = __float_as_uint(gs[2 * pr + 1]);
+                    smz[c][pr] = ((g0 >> 16) & 0x8000u) | (g1 & 0x80000000u);
+                    zmz[c][pr] = (g0 ? 0xffffu : 0u) | (g1 ? 0xffff0000u : 0u);
+                }
+                if (!ADJ3_LATE) {
+                    adj3_row(c);
+                    if (c == 2) adj3_prefetch();
+                }
+            } else if constexpr (ADJS) {
                 // B-operand of entry e = (c, d): k = 8 g + t <-> the lane's own vertex row 4 g + t, hi pieces in t = 0..3,
                 // lo pieces in t = 4..7 -- formed from the accumulator-layout values without leaving the lane
                 mbf16x8 bq[4];
@@ -1907,6 +2023,21 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int d = 0; d < 3; ++d) dst[(r * 3 + d) * ldn] = dvp[d][r];
+        }
+        if constexpr (ADJ3) {
+            if (ADJ3_LATE) {                                     // (behind the dvp store: its 12 registers are free)
+                __builtin_amdgcn_sched_barrier(0);
+                if (MESH_ADJ3_WLOAD > 2) load_adjoint_weights();
+                adj3_pieces();
+                __builtin_amdgcn_sched_barrier(0);
+                adj3_row(0);
+                __builtin_amdgcn_sched_barrier(0);
+                adj3_prefetch();
+                adj3_row(1);
+                __builtin_amdgcn_sched_barrier(0);
+                adj3_row(2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         /*prof:c3*/
     }
@@ -2437,10 +2568,11 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
     float* loss_parts = reinterpret_cast<float*>(wsb + 16);
     int* tickets = reinterpret_cast<int*>(wsb + 16 + MESH_MAX_BLOCKS * 4);
     float* parts = reinterpret_cast<float*>(wsb + MESH_HEADER_BYTES);
+    const unsigned short* WADJ = mode == 4 ? ctx->d_Wadj3 : ctx->d_Wadj;
 #define MESH_LAUNCH(M, SP, PP, LDP) hipLaunchKernelGGL((mesh_v2v_fused_kernel<M, SP>), dim3((unsigned)blocks), dim3(256), lds_bytes, \
         (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, PP, LDP, ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA,  \
         pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets, loss_parts, grid_ticket, dVPb, (long)ldk,    \
-        ctx->d_Wsk, ctx->d_Wadj, ctx->d_Wsp_w, ctx->d_Wsp_j)
+        ctx->d_Wsk, WADJ, ctx->d_Wsp_w, ctx->d_Wsp_j)
     if (mode == 4 && sparse) MESH_LAUNCH(4, true, reinterpret_cast<const float*>(ctx->d_posedirs_sp3), ctx->NVp);
     else if (mode == 4) MESH_LAUNCH(4, false, reinterpret_cast<const float*>(ctx->d_posedirs_sp3), ctx->NVp);
     else if (mode == 2) MESH_LAUNCH(2, false, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
