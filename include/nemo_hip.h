@@ -357,7 +357,8 @@ int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t
 /* nemo_v2v_fused in fp32-EQUIVALENT arithmetic with the pose blend's products (lbs.py:229-233, K = 207: 76 % of the fp32
  * kernel's matrix-pipe cycles) on the bf16 matrix cores: both operands are carried as THREE bf16 pieces (8 + 8 + 8 significant
  * bits = the fp32 value; blend shapes split once at nemo_ctx_create, pose features when staged), the six piece products whose
- * weight is >= 2^-24 are exact in fp32 and accumulated in fp32.  Skinning, L1, d vp and the vertex->joint adjoint as in
+ * weight is >= 2^-24 are exact in fp32 and accumulated in fp32.  The vertex->joint adjoint dA = W^T dT likewise (W split at
+ * nemo_ctx_create, dT = +-[vp; 1] from the pieces of vp with the sign bit flipped).  Skinning, L1 and d vp as in
  * nemo_v2v_fused.  Same arguments, outputs, scratch and determinism.  tests/test_gpu_ops.py::test_v2v_fused_split3_* hold its
  * error against a float64 evaluation to the fp32-MFMA kernel's (round 5; the engine's `mesh_blend = 'f32_split'`). */
 int32_t nemo_v2v_fused_split3(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,

@@ -494,9 +494,9 @@ class FitEngine:
         if not self.bf16:
             out = {'f32': flops - valu}
             if tag == 'mesh_v2v_fused' and self.mesh_split3:
-                # (csrc/smpl.hip MODE 4: the two pose blends run on the bf16 pipe as SIX bf16 piece products per algorithmic
-                #  product -- pipe 'bf16x6', whose peak is a sixth of the bf16 MFMA peak)
-                b16 = flops * (2 * 3 * 207) / self.mesh_macs()
+                # (csrc/smpl.hip MODE 4: the two pose blends and the vertex->joint adjoint run on the bf16 pipe as SIX bf16 piece
+                #  products per algorithmic product -- pipe 'bf16x6', whose peak is a sixth of the bf16 MFMA peak)
+                b16 = flops * (2 * 3 * 207 + 288) / self.mesh_macs()
                 out = {'bf16x6': b16, 'f32': flops - b16 - valu}
             if valu:
                 out['valu_f32'] = valu
