@@ -983,12 +983,12 @@ def worker_main(opts):
                 'what': 'the headline runs the fused mesh term with its pose blend (3 x 207 multiply-adds per vertex, body and sample) on '
                         'the bf16 matrix cores in fp32-equivalent arithmetic: both operands as three bf16 pieces (8 + 8 + 8 significant '
                         'bits), the six piece products >= 2^-24 exact in fp32, fp32 accumulation (nemo_v2v_fused_split3, csrc/smpl.hip '
-                        'MODE 4); everything else is the fp32 path.  `f32_mfma_blend` is the same step with the blend on the fp32 MFMA pipe',
+                        'MODE 4), and its vertex->joint adjoint likewise; everything else is the fp32 path.  `f32_mfma_blend` is the same step with the blend on the fp32 MFMA pipe',
                 'criteria': {'a_error_vs_float64': 'tests/test_gpu_ops.py::test_v2v_fused_split3_is_fp32_equivalent: error of loss, d vp and dA '
                                                    'against a float64 evaluation of the same fp32 inputs <= 1.5 x the fp32-MFMA kernel\'s '
-                                                   '(measured: dA rms 1.57e-7 against 1.58e-7, blend shapes x 100)',
+                                                   '(measured: dA rms 1.576e-7 against 1.578e-7, blend shapes x 100)',
                              'b_parity_gates': 'every 1e-4 parity gate of tests/ runs on this default, unchanged',
-                             'c_launch_time': 'profiles/r05_f32_split.md: 392 against 519 us per 8 x 300 launch (-24 %)'},
+                             'c_launch_time': 'profiles/r05_f32_split.md: 369 against 519 us per 8 x 300 launch (-29 %); this run: mesh_launch_ms against mesh_launch_ms_f32_mfma_blend below'},
                 'ms_per_step': round(ms_per_step, 3), 'ms_per_step_f32_mfma_blend': fm.get('ms_per_step'),
                 'mesh_launch_ms': (roof or {}).get('mean_launch_ms'),
                 'mesh_launch_ms_f32_mfma_blend': (fm.get('roofline') or {}).get('mean_launch_ms')}

@@ -102,6 +102,13 @@ def _rccl_world1(mode, q):
         else:
             ld, _ = m.step(torch.randint(0, V, (B,), generator=g), torch.randint(0, T, (B,), generator=g))
         out.append({k: float(v) for k, v in ld.items()})
+    # the captured camera fit under RCCL (its capture must open thread-local while the process group's watchdog
+    # thread is alive), twice with the global-trajectory switch toggled in between: the graph key must tell the two apart
+    cam = [[float(x) for x in m.opt_cam(6)]]
+    m.model.engine.start_global_traj_anywhere = not m.model.engine.start_global_traj_anywhere
+    cam.append([float(x) for x in m.opt_cam(6)])
+    m.model.engine.start_global_traj_anywhere = not m.model.engine.start_global_traj_anywhere
+    q['cam'] = cam
     graphs = [v for w in m.model.engine.ws.values() for v in w['graphs'].values()]
     q['res'] = (out, sum(isinstance(x, torch.cuda.CUDAGraph) for x in graphs))
     del graphs
@@ -143,6 +150,14 @@ def test_sharded_step_over_rccl_world_of_one(mode):
             ld, _ = m.step(torch.randint(0, V, (B,), generator=g), torch.randint(0, T, (B,), generator=g))
         for k, v in ld.items():
             assert abs(got[it][k] - float(v)) <= 1e-4 * max(abs(float(v)), 1e-6), (it, k, got[it][k], float(v))
+    ref = [[float(x) for x in m.opt_cam(6)]]
+    m.engine.start_global_traj_anywhere = not m.engine.start_global_traj_anywhere
+    ref.append([float(x) for x in m.opt_cam(6)])
+    for a, b in zip(q['cam'], ref):
+        assert len(a) == len(b) == 6
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 1e-4 * max(abs(y), 1e-6), (q['cam'], ref)
+    assert ref[0] != ref[1]                                  # (the switch changes the objective: a stale graph would repeat run 1)
 
 
 @pytest.mark.gpu
