@@ -366,7 +366,8 @@ int32_t nemo_v2v_fused_split3(const nemo_ctx* ctx, int64_t N, const float* PF2, 
                               void* stream);
 /* The same with the pose blend (lbs.py:229-233, K = 207) on the bf16 matrix cores: blend shapes rounded to bf16 once
  * at nemo_ctx_create, pose features rounded when staged, fp32 accumulate; skinning, L1 and d vp in fp32; the vertex->joint adjoint dA on the
- * bf16 cores in split precision (two bf16 pieces per fp32 operand, 16 significant bits; NEMO_MESH_SPLIT=0: fp32).
+ * bf16 cores in split precision (two bf16 pieces per fp32 operand, 16 significant bits), and since round 5 the two skinning
+ * products as well (NEMO_MESH_SPLIT=3: skinning in fp32, the round-3/4 kernel).
  * BASELINE configs[2] ("bf16"); not covered by the 1e-4 parity gate (tests state the bf16 tolerance). */
 /* nemo_v2v_fused_bf16 with d vp written as bf16 and NOT transposed (round 3): dVPb has 16 * ceil(N / 16) rows (one per
  * sample) of ldk >= 3 * NVp bf16 -- the k-contiguous A operand of the blend-shape adjoint through nemo_gemm_bf16mem. */

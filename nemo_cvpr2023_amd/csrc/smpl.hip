@@ -1389,14 +1389,10 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 #define MESH_ADJ3 1
 #endif
     constexpr bool ADJ3 = SP3 && MESH_ADJ3 != 0;
-#ifndef MESH_ADJ3_LATE
-#define MESH_ADJ3_LATE 1
-#endif
     // Placement (measured, 8 x 300): the adjoint MFMAs of all three rows BEHIND the row loop and the dvp store, the three W images
-    // requested there too (MESH_ADJ3_LATE 1, MESH_ADJ3_WLOAD 3): no spilled register, 374 us per launch against 386 with the fp32
-    // adjoint (dense weights: 416 against 462).  Inside the row loop, or with the W images requested earlier, hipcc spills 33 - 231
-    // registers of the sparse instantiation (474 - 635 us).
-    constexpr bool ADJ3_LATE = MESH_ADJ3_LATE != 0;
+    // requested there too: no spilled register, 374 us per launch against 386 with the fp32 adjoint (dense weights: 416 against 462).
+    // Inside the row loop, or with the W images requested earlier, hipcc spills 33 - 231 registers of the sparse instantiation
+    // (474 - 635 us per launch; profiles/r05_experiments.md section 5).
     static_assert(!(SPARSE && SPLIT), "sparse skinning replaces the split-precision skinning");
     // All constants are zero-padded by nemo_ctx_create (P: 224 rows x 3*NVp columns, W / v_shaped: NVp
     // vertices) and dVPt has 3*NVp rows x ldn >= 16*groups columns, so no load or store below needs a
@@ -1606,15 +1602,20 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     u32x3 pa[8];                                                 // fp32: eight k-steps (of 4) in flight
     constexpr int PQD = MODE == 3 ? MESH_PQD : 2;                      // bf16: PQD k-steps (of 32) x 3 components in flight
     u32x4m pq[PQD][3];
-    u32x4m ps[3][3];                                             // SP3: ONE k-step, [component][piece], refilled piece by piece
+    u32x4m ps[3][3];                                             // SP3: ONE k-step, [component][piece 1, 2], refilled piece by piece
+    u32x4m ps0[2][3];                                            // SP3: piece 0 (half of a k-step's products), double-buffered [k-step & 1][component]
+    auto sp3_request = [&](const int soff, const int buf0) {     // all nine pieces of one k-step (scalar byte offset soff)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ps0[buf0][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, soff + (3 * c) * 1024, 0);
+            ps[c][1] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, soff + (3 * c + 1) * 1024, 0);
+            ps[c][2] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, soff + (3 * c + 2) * 1024, 0);
+        }
+    };
     {
         const int tf = (int)min(t_beg + wid, ntiles - 1);        // (a wave without tiles loads a valid one)
         if (SP3) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    ps[c][pc] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, tf * TILE_B + (3 * c + pc) * 1024, 0);
+            sp3_request(tf * TILE_B, 0);
         } else if (BF16) {
 #pragma unroll
             for (int u = 0; u < PQD; ++u)
@@ -1672,7 +1673,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         // (sparse bf16: requested after the reconstruction body -- first used a skinning row + the sign pass later -- so that
         //  their 16 registers are not live across the blend and the first skinning phase: 18 spilled registers otherwise.
         //  The fp32 form keeps them at the top of the tile: moved, hipcc spills 270.)
-        if constexpr (!(SPARSE && (ADJS || ADJ3)) && !(ADJ3 && ADJ3_LATE)) load_adjoint_weights();
+        if constexpr (!(SPARSE && ADJS) && !ADJ3) load_adjoint_weights();
         // ---- pose blend of both bodies: 52 k-steps x 3 components, A-operand P[p][3v+c] from L2
         f32x4 vp[2][3];
         const float* vsl = vs + (v0 + 4 * g) * 3;
@@ -1687,8 +1688,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         const int ptn = (int)min(t + 4, ntiles - 1) * TILE_B;    // and its next one (clamped: harmless re-read)
         if constexpr (SP3) {
             // 7 k-steps of 32 x 6 piece products x 3 components x 2 bodies = 252 MFMAs.  Product order per k-step: the three
-            // with P's piece 0, then its piece 1, then piece 2 -- a piece's registers are re-requested for the NEXT k-step as
-            // soon as its last product has been issued (384 - 576 MFMA cycles ahead of their next use: no second buffer).
+            // with P's piece 0, the one with piece 2, the two with piece 1 (why: at the loop).
             // Six accumulators in rotation: no MFMA waits for its predecessor.
             // (B operands -- the pose-feature pieces, LDS -- one k-step ahead: requested behind the first product group of the
             //  previous k-step)
@@ -1703,21 +1703,33 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             load_b(0, 0);
 #pragma unroll
             for (int S = 0; S < 7; ++S) {
+                // piece 0 carries half of a k-step's products: re-requested behind them it would have 18 MFMAs (288 cycles) until
+                // its next use, less than an L2 round trip -- so it has two buffers and is requested a whole k-step ahead; pieces
+                // 2 and 1 (in this order) are re-requested behind their products, 30 and 24 MFMAs ahead
+                if (S + 1 < 7) {
 #pragma unroll
-                for (int pa = 0; pa < 3; ++pa) {
+                    for (int c = 0; c < 3; ++c)
+                        ps0[(S + 1) & 1][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, pt + (S + 1) * kstride + (3 * c) * 1024, 0);
+                }
+#pragma unroll
+                for (int gi = 0; gi < 3; ++gi) {
+                    const int pa = gi == 0 ? 0 : (gi == 1 ? 2 : 1);
 #pragma unroll
                     for (int pb = 2 - pa; pb >= 0; --pb)
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            const mbf16x8 a = __builtin_bit_cast(mbf16x8, ps[c][pa]);
+                            const mbf16x8 a = __builtin_bit_cast(mbf16x8, pa == 0 ? ps0[S & 1][c] : ps[c][pa]);
                             vp[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[S & 1][0][pb], vp[0][c], 0, 0, 0);
                             vp[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[S & 1][1][pb], vp[1][c], 0, 0, 0);
                         }
                     if (S + 1 < 7) {
+                        if (pa != 0) {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            ps[c][pa] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, pt + (S + 1) * kstride + (3 * c + pa) * 1024, 0);
-                        if (pa == 0) load_b((S + 1) & 1, S + 1);
+                            for (int c = 0; c < 3; ++c)
+                                ps[c][pa] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, pt + (S + 1) * kstride + (3 * c + pa) * 1024, 0);
+                        } else {
+                            load_b((S + 1) & 1, S + 1);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -1818,16 +1830,10 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
         /*prof:c2*/
-        if constexpr (SPARSE && (ADJS || (ADJ3 && !ADJ3_LATE))) load_adjoint_weights();
+        if constexpr (SPARSE && ADJS) load_adjoint_weights();
         unsigned int smz[3][2], zmz[3][2];                       // ADJ3: sign / zero masks of the three rows, [row][vertex pair]
         unsigned int vpp[3][3][2];                               // ADJ3: [piece][coordinate d][vertex pair] of vp_orig, packed bf16
-        auto adj3_prefetch = [&]() {     // the wave's NEXT tile: its first k-step
-#pragma unroll
-            for (int c2 = 0; c2 < 3; ++c2)
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    ps[c2][pc] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, ptn + (3 * c2 + pc) * 1024, 0);
-        };
+        auto adj3_prefetch = [&]() { sp3_request(ptn, 0); };     // the wave's NEXT tile: its first k-step
         auto adj3_pieces = [&]() {
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -1873,7 +1879,6 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                     }
             }
         };
-        if constexpr (ADJ3) { if (!ADJ3_LATE) adj3_pieces(); }
         // ---- original body: row c of the transform -> vertex coordinate c -> sign -> its share of dvp and
         // the four dT entries (c, 0..3), which go straight into the vertex->joint MFMA as B-operands
         float dvp[3][4];
@@ -1884,10 +1889,6 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             /*prof:q0*/
-#ifndef MESH_ADJ3_WLOAD
-#define MESH_ADJ3_WLOAD 3
-#endif
-            if constexpr (ADJ3 && ADJ3_LATE) { if (c == MESH_ADJ3_WLOAD) load_adjoint_weights(); }   // (the three W images: first used behind the rows)
             f32x4 T4[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d)
@@ -1932,11 +1933,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 // adjoint MFMAs and the dvp store (their registers are dead during the skinning phases,
                 // where the pressure peaks -- a ring kept full across the whole tile spills)
                 if (SP3) {
-#pragma unroll
-                    for (int c2 = 0; c2 < 3; ++c2)
-#pragma unroll
-                        for (int pc = 0; pc < 3; ++pc)
-                            ps[c2][pc] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, ptn + (3 * c2 + pc) * 1024, 0);
+                    sp3_request(ptn, 0);
                 } else if (BF16) {
 #pragma unroll
                     for (int u = 0; u < PQD; ++u)
@@ -1959,10 +1956,6 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                     const unsigned int g0 = __float_as_uint(gs[2 * pr]), g1 = __float_as_uint(gs[2 * pr + 1]);
                     smz[c][pr] = ((g0 >> 16) & 0x8000u) | (g1 & 0x80000000u);
                     zmz[c][pr] = (g0 ? 0xffffu : 0u) | (g1 ? 0xffff0000u : 0u);
-                }
-                if (!ADJ3_LATE) {
-                    adj3_row(c);
-                    if (c == 2) adj3_prefetch();
                 }
             } else if constexpr (ADJS) {
                 // B-operand of entry e = (c, d): k = 8 g + t <-> the lane's own vertex row 4 g + t, hi pieces in t = 0..3,
@@ -2024,20 +2017,18 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 #pragma unroll
             for (int d = 0; d < 3; ++d) dst[(r * 3 + d) * ldn] = dvp[d][r];
         }
-        if constexpr (ADJ3) {
-            if (ADJ3_LATE) {                                     // (behind the dvp store: its 12 registers are free)
-                __builtin_amdgcn_sched_barrier(0);
-                if (MESH_ADJ3_WLOAD > 2) load_adjoint_weights();
-                adj3_pieces();
-                __builtin_amdgcn_sched_barrier(0);
-                adj3_row(0);
-                __builtin_amdgcn_sched_barrier(0);
-                adj3_prefetch();
-                adj3_row(1);
-                __builtin_amdgcn_sched_barrier(0);
-                adj3_row(2);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        if constexpr (ADJ3) {                                    // (behind the dvp store: its 12 registers are free)
+            __builtin_amdgcn_sched_barrier(0);
+            load_adjoint_weights();
+            adj3_pieces();
+            __builtin_amdgcn_sched_barrier(0);
+            adj3_row(0);
+            __builtin_amdgcn_sched_barrier(0);
+            adj3_prefetch();
+            adj3_row(1);
+            __builtin_amdgcn_sched_barrier(0);
+            adj3_row(2);
+            __builtin_amdgcn_sched_barrier(0);
         }
         /*prof:c3*/
     }
@@ -2536,11 +2527,13 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
     if (dVPb ? (!bf16 || ldk < ctx->ldP || (ldk & 3) || (((uintptr_t)dVPb) & 7)) : (!dVPt || ldn < ((N + 15) / 16) * 16))
         return NEMO_EINVAL;                                    // (dA == NULL: deferred combine, nemo_v2v_combine)
     if (N == 0) return NEMO_OK;
-    // bf16: bf16 blend + split-precision vertex->joint adjoint on the bf16 pipe (kernel MODE 3).  MODE 1 (bf16 blend only:
-    // 3.55 against 3.25 ms per C3 step) and MODE 2 (split-precision skinning as well: slower, 475 against ~300 us per
-    // launch) were measured in round 3 (profiles/r03_experiments.md sections 10, 13) and are no longer instantiated.
-    static const int split_env = getenv("NEMO_MESH_SPLIT") ? atoi(getenv("NEMO_MESH_SPLIT")) : 0;
-    const int mode = bf16 ? (split_env == 2 ? 2 : 3) : kind == 2 ? 4 : 0;
+    // bf16: bf16 blend + split-precision vertex->joint adjoint AND split-precision skinning on the bf16 pipe (kernel MODE 2, the
+    // default since round 5: re-measured after the LDS alignment fix of round 4 it is 4 - 7 % shorter than MODE 3 with sparse VALU
+    // skinning -- 434 against 465 us per launch at 40 x 300, C3 step 2.34 -> 2.28 ms -- because the bf16 kernel is VALU-issue bound,
+    // profiles/r05_pmc_mesh_b16.md).  NEMO_MESH_SPLIT=3: MODE 3 (fp32 skinning: sparse on the VALU or dense on the fp32 pipe), an
+    // A/B aid.  MODE 1 (bf16 blend only) was measured in round 3 and is no longer instantiated.
+    static const int split_env = getenv("NEMO_MESH_SPLIT") ? atoi(getenv("NEMO_MESH_SPLIT")) : 2;
+    const int mode = bf16 ? (split_env == 3 ? 3 : 2) : kind == 2 ? 4 : 0;
     const bool sparse = ctx->skin_sparse != 0 && mode != 2;
     const int lds_bytes = mode == 2 ? (2 * 16 * MF_PFB / 2 + 2 * 2 * 16 * MF_AB / 2 + MF_TAIL) * (int)sizeof(float)
         : ((mode == 4 ? 3 * 2 * 16 * MF_PFB / 2 : bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * (sparse ? MF_ASP : MF_AS) + MF_TAIL) *

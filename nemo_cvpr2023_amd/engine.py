@@ -489,7 +489,8 @@ class FitEngine:
         # (sparse skinning -- <= 4 non-zero weights per vertex -- is fp32 FMA work on the VALU, not on a matrix pipe: its own
         #  entry, priced at the fp32 vector peak, which equals the fp32 MFMA peak on this part)
         valu = 0.0
-        if tag == 'mesh_v2v_fused' and self.ctx.skin_sparse_flag:
+        b16_skin = self.bf16 and os.environ.get('NEMO_MESH_SPLIT', '2') != '3'      # kernel MODE 2: skinning as split-precision MFMAs
+        if tag == 'mesh_v2v_fused' and self.ctx.skin_sparse_flag and not b16_skin:
             valu = flops * (2 * 12 * 4) / self.mesh_macs()
         if not self.bf16:
             out = {'f32': flops - valu}
@@ -505,6 +506,8 @@ class FitEngine:
             # (csrc/smpl.hip MODE 3: the vertex->joint adjoint -- 288 of the multiply-adds -- runs on the bf16 pipe too, as
             #  four bf16 piece products per algorithmic product)
             on16 = 2 * 3 * 207 + 288
+            if b16_skin:        # (MODE 2, the default: the two skinnings too -- their algorithmic work, the kernel executes the dense product)
+                on16 = self.mesh_macs()
             b16 = flops * on16 / self.mesh_macs()
             out = {'bf16': b16, 'f32': flops - b16 - valu}
             if valu:
@@ -524,8 +527,8 @@ class FitEngine:
 
     def mesh_kernel_variant(self):
         """The mesh kernel instantiation this engine launches (what counter files under profiles/ are keyed by)."""
-        mode = (3 if os.environ.get('NEMO_MESH_SPLIT', '1') != '0' else 1) if self.bf16 else (4 if self.mesh_split3 else 0)
-        return f"mesh_v2v_fused_kernel<{mode}, {'true' if self.ctx.skin_sparse_flag else 'false'}>"
+        mode = (3 if os.environ.get('NEMO_MESH_SPLIT', '2') == '3' else 2) if self.bf16 else (4 if self.mesh_split3 else 0)
+        return f"mesh_v2v_fused_kernel<{mode}, {'true' if self.ctx.skin_sparse_flag and mode != 2 else 'false'}>"
 
     # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
     # recorded on the stream the kernels are launched on (torch's current stream).

@@ -104,8 +104,8 @@ def test_v2v_fused_bf16_blend_vs_fp32_kernel(L, num_verts, N):
 @pytest.mark.parametrize('num_verts,N', [(700, 40), (6890, 50)])
 def test_v2v_fused_bf16_split_precision_skinning(L, num_verts, N):
     """With ZERO pose features the blend contributes nothing (vp == v_shaped in both kernels), so whatever separates the
-    bf16 kernel from the fp32 one is its vertex->joint adjoint -- which runs on
-    the bf16 pipe in split precision (two bf16 pieces per fp32 operand, csrc/smpl.hip MODE 3 / 2): 16 significant bits,
+    bf16 kernel from the fp32 one is its vertex->joint adjoint and (MODE 2, the default since round 5) its skinning -- which run on
+    the bf16 pipe in split precision (two bf16 pieces per fp32 operand, csrc/smpl.hip MODE 2 / 3): 16 significant bits,
     i.e. two orders below bf16."""
     import hipops as H
     from test_gpu_ops import _ctx, _rand_rot
@@ -129,7 +129,14 @@ def test_v2v_fused_bf16_split_precision_skinning(L, num_verts, N):
     (l32, v32, a32), (l16, v16, a16) = out
     assert float(l32) > 0 and rel_err(l16, l32) < 2e-5
     assert float(((v16 - v32).abs() > 1e-4 * float(v32.abs().max())).float().mean()) < 1e-3      # (sign flips at ties only)
-    assert rel_err(a16, a32) < 1e-3
+    # dA sums g [vp; 1] over the vertices: ONE sign that flips at an L1 tie moves an entry by 2 w |vp| (3.5e-2 of the tensor's
+    # scale seen at 700 vertices).  Samples with a coordinate within 8e-6 of a tie -- the split-precision skinning's error is
+    # 4e-6 of the transforms -- are compared by their loss and d vp above, not by dA.
+    from test_gpu_ops import _mesh_term_f64
+    d = _mesh_term_f64(assets, PF, A, N)[3]
+    clean = d.abs().reshape(N, -1).min(1).values > 8e-6
+    assert int(clean.sum()) >= 5                                        # (20 670 coordinates per sample: 15 of 50 samples at 6890 vertices)
+    assert rel_err(a16[clean], a32[clean]) < 1e-3
     assert bool((a16 != a32).any())                                     # (it really is another arithmetic)
 
 
