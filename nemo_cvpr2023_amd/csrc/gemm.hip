@@ -864,8 +864,11 @@ extern "C" int32_t nemo_gemm_bf16mem(int64_t M, int64_t N, int64_t K, const uint
         g.counters = reinterpret_cast<int*>(ws);
         g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
         const long t128 = ((M + 127) / 128) * ((N + 255) / 256), t192 = ((M + 191) / 192) * ((N + 255) / 256);
-        int cfg = 3, split = 1;                             // 192 x 256 + loader waves
-        if (wide && t128 <= 256) cfg = 5;                   // 128 x 256 + loader waves while its grid is one round of the chip
+        // (whole-line ring stages, BK = 64: 38.5 -> 35.6 us for the 12 001-row forward with both copies, 691 -> 762 TFLOP/s in the
+        //  evaluation form, 128 x 256: 53.2 -> 45.2 us; NEMO_B16X_BK=32: the 64-byte-row form)
+        static const bool bk32 = getenv("NEMO_B16X_BK") != nullptr && atoi(getenv("NEMO_B16X_BK")) == 32;
+        int cfg = bk32 ? 3 : 6, split = 1;                  // 192 x 256 + loader waves
+        if (wide && t128 <= 256) cfg = bk32 ? 5 : 8;        // 128 x 256 + loader waves while its grid is one round of the chip
         if (!wide) {                                        // K slices: ~one workgroup per CU, >= 2048 k each
             split = (int)(256 / t192);
             while (split > 1 && (K / split < 2048 || COUNTER_BYTES + t192 * split * 192L * 256 * 4 > ws_bytes)) --split;

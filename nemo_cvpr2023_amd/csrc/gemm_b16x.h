@@ -57,24 +57,30 @@ struct Args {
     unsigned a_bytes, b_bytes, mask_bytes;                  // buffer extents
 };
 
-constexpr int BK = 32;                                      // bf16 per ring stage: a stage row is 64 B = 4 chunks of 16 B
+// BK (template parameter BKT): bf16 per ring stage.  32: a stage row is 64 B = 4 chunks of 16 B, pieces of 16 rows (round 5, first
+// form).  64: a stage row is a whole 128-byte line = 8 chunks, pieces of 8 rows -- with every CU streaming, 64-byte row segments
+// reach HALF the L2 -> LDS rate of whole lines (profiles/r05_dma_rate.txt: 13 - 21 against 25 - 45 GB/s per CU), and the K loop
+// of the 192 x 256 tile needs 87 GB/s per CU at the full MFMA rate: the 32-wide form sits on that limit (~700 TFLOP/s).
 
 // LW: loader waves (0: the eight MFMA waves request their operand tiles themselves; 4: four more waves -- one per SIMD --
 // issue every LDS-DMA piece and the MFMA waves never stall on a DMA issue, ~100 - 180 cycles each beside MFMAs and LDS
 // reads: with eight pieces per wave and 64 k that was as long as the MFMAs themselves)
-template <int BM, int BN, int WGM, int WGN, int NST, int LW = 0>
+template <int BM, int BN, int WGM, int WGN, int NST, int LW = 0, int BKT = 32>
 struct Geo {
+    static_assert(BKT == 32 || BKT == 64, "ring stage of 32 or 64 k");
+    static constexpr int BK = BKT, ROWB = 2 * BKT, NCH = ROWB / 16, PR = 1024 / ROWB, KS = BKT / 16;   // row bytes, chunks, rows per piece, k-steps
     static constexpr int NW = WGM * WGN;
     static_assert(NW == 8, "8 MFMA waves");
     static_assert(LW == 0 || LW == 4, "loader waves: none or one per SIMD");
     static constexpr int THREADS = 64 * (NW + LW);
     static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile in 32 x 32 accumulators");
-    static constexpr int NPA = BM / 16, NPB = BN / 16;                            // 1-KiB DMA pieces (16 rows x 64 B) per stage
+    static constexpr int NPA = BM / PR, NPB = BN / PR;                            // 1-KiB DMA pieces (PR rows x ROWB bytes) per stage
+    static_assert(NPA % 2 == 0, "the swizzle of a piece depends on its parity only");
     static constexpr int NI = LW ? LW : NW;                                       // waves that issue DMAs
     static constexpr int GW = (NPA + NPB + NI - 1) / NI;                          // pieces per issuing wave and stage (waves whose
                                                                                   // last piece does not exist issue a dummy: same counts)
-    static constexpr int STAGE = (BM + BN) * 64;                                  // bytes
+    static constexpr int STAGE = (BM + BN) * ROWB;                                // bytes
     static constexpr int RING = NST * STAGE;
     // epilogue scratch per wave: the larger of the [m][n] image (row stride WN * 2 + 16 B) and the [n][m] image
     // (row stride WM * 2 + 16 B)
@@ -99,10 +105,11 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) { return (unsi
 
 constexpr int OOB = (int)0x80000000u;      // a buffer offset beyond every descriptor of this kernel (extents < 2^31)
 
-template <int BM, int BN, int WGM, int WGN, int NST, int LW>
+template <int BM, int BN, int WGM, int WGN, int NST, int LW, int BKT>
 __global__ __launch_bounds__(64 * (8 + LW)) void gemm_b16x_kernel(Args g) {
-    using Q = Geo<BM, BN, WGM, WGN, NST, LW>;
+    using Q = Geo<BM, BN, WGM, WGN, NST, LW, BKT>;
     constexpr int WM = Q::WM, WN = Q::WN, TM = Q::TM, TN = Q::TN, GW = Q::GW, NPA = Q::NPA, NPB = Q::NPB, NI = Q::NI;
+    constexpr int BK = Q::BK, ROWB = Q::ROWB, NCH = Q::NCH, PR = Q::PR, KS = Q::KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];          // the ONLY LDS object of the kernel
 
     // ---- block -> (K slice, row tile, column tile).  Block b runs on XCD b % 8 (observed; speed only): give every XCD a
@@ -145,11 +152,15 @@ __global__ __launch_bounds__(64 * (8 + LW)) void gemm_b16x_kernel(Args g) {
         return i32x4{(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xffffu), (int)bytes, 0x00020000};
     };
     const i32x4 rsA = rsrc(g.A, g.a_bytes), rsB = rsrc(g.B, g.b_bytes);
-    const int dr = lane >> 2;
-    const int dchunk = (lane & 3) ^ ((dr >> 2) & 3);
-    const int voffA = (int)((dr * g.lda + 8 * dchunk) * 2), voffB = (int)((dr * g.ldb + 8 * dchunk) * 2);
+    // (BK = 64: chunk c of row r at slot c ^ ((r >> 1) & 7), gemm_glds.h's "image K"; a piece holds 8 rows, so the swizzle of
+    //  its lane depends on the piece's parity: (dr >> 1) | 4 (piece & 1))
+    const int dr = lane / NCH, dslot = lane % NCH;
+    auto voff_of = [&](long ld, int par) {
+        const int swz = BK == 32 ? ((dr >> 2) & 3) : ((dr >> 1) | (par << 2));
+        return (int)((dr * ld + 8 * (dslot ^ swz)) * 2);
+    };
     const unsigned baseA = (unsigned)((m0 * g.lda + kbeg) * 2), baseB = (unsigned)((n0 * g.ldb + kbeg) * 2);
-    const unsigned rowsA = (unsigned)(16 * g.lda * 2), rowsB = (unsigned)(16 * g.ldb * 2);
+    const unsigned rowsA = (unsigned)(PR * g.lda * 2), rowsB = (unsigned)(PR * g.ldb * 2);
     // the p-th piece (0 .. GW - 1) of this wave: which operand, where in a stage, from where -- selected once, branch-free
     // (q = iw + NI p).  Pieces that do not exist (q >= NPA + NPB) and tiles beyond the slice are requested out of bounds
     // (nothing is fetched; zeros land in the 1 KiB behind the ring resp. in a stage nobody reads any more): every wave has the
@@ -164,28 +175,28 @@ __global__ __launch_bounds__(64 * (8 + LW)) void gemm_b16x_kernel(Args g) {
         const bool isA = q < NPA;
         pdummy[p] = q >= NPA + NPB;
         prs[p] = isA ? rsA : rsB;
-        plds[p] = pdummy[p] ? (unsigned)Q::RING : (isA ? (unsigned)(q * 1024) : (unsigned)(BM * 64 + (q - NPA) * 1024));
+        plds[p] = pdummy[p] ? (unsigned)Q::RING : (isA ? (unsigned)(q * 1024) : (unsigned)(BM * ROWB + (q - NPA) * 1024));
         psrc[p] = isA ? baseA + (unsigned)q * rowsA : baseB + (unsigned)(q - NPA) * rowsB;
-        pvoff[p] = pdummy[p] ? OOB : (isA ? voffA : voffB);
+        pvoff[p] = pdummy[p] ? OOB : voff_of(isA ? g.lda : g.ldb, q & 1);     // (NPA is even: q and q - NPA have one parity)
     }
     // piece p of K tile t into ring stage `stage`
     auto dma = [&](int p, int t, int stage) {
         const unsigned st = pdummy[p] ? 0u : (unsigned)(stage * Q::STAGE);
-        glds::dma_piece(prs[p], smem_byte + st + plds[p], t < nt ? pvoff[p] : OOB, psrc[p] + (unsigned)t * (BK * 2));
+        glds::dma_piece(prs[p], smem_byte + st + plds[p], t < nt ? pvoff[p] : OOB, psrc[p] + (unsigned)t * ROWB);
     };
 
     // ---- operand fetch.  k-step s (0 / 1) of a stage, lane half lh: chunk 2 s + lh of row l31 of each 32-row block;
     // (row >> 2) & 3 == (l31 >> 2) & 3 because every 32-row block starts at a multiple of 32.
     struct Frag { bf16x8 a[TM], b[TN]; };
-    const int sw = (l31 >> 2) & 3;
-    const unsigned fa0 = (unsigned)((wm * WM + l31) * 64), fb0 = (unsigned)(BM * 64 + (wn * WN + l31) * 64);
+    const int sw = BK == 32 ? ((l31 >> 2) & 3) : ((l31 >> 1) & 7);
+    const unsigned fa0 = (unsigned)((wm * WM + l31) * ROWB), fb0 = (unsigned)(BM * ROWB + (wn * WN + l31) * ROWB);
     auto fetch = [&](Frag& f, int stage, int s) {
         const unsigned char* st = smem + stage * Q::STAGE;
         const unsigned co = (unsigned)(((2 * s + lh) ^ sw) << 4);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(st + fa0 + i * 32 * 64 + co);
+        for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const bf16x8*>(st + fa0 + i * 32 * ROWB + co);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(st + fb0 + j * 32 * 64 + co);
+        for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(st + fb0 + j * 32 * ROWB + co);
     };
     auto mask_tail = [&](Frag& f, int t, int s) {           // elements at or beyond the end of K
         const int nv = klen - t * BK - (16 * s + 8 * lh);
@@ -261,23 +272,30 @@ __global__ __launch_bounds__(64 * (8 + LW)) void gemm_b16x_kernel(Args g) {
         asm volatile("" ::: "memory");
         fetch(F, 0, 0);
         int cur = 0;                                        // stage of tile t
+        // (KS k-steps per tile, fragments alternating F, G, ...; the LAST k-step of a tile sits behind the barrier)
         for (int t = 0; t < nt - 1; ++t) {
-            mma(F, [&] { fetch(G, cur, 1); }, -1, 0);
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s + 1 < KS; ++s) {
+                if (s & 1) mma(G, [&] { fetch(F, cur, s + 1); }, -1, 0);
+                else mma(F, [&] { fetch(G, cur, s + 1); }, -1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (LW == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * GW) : "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int nxt = cur + 1 == NST ? 0 : cur + 1;
-            mma(G, [&] { fetch(F, nxt, 0); }, t + NST, cur);
+            mma(G, [&] { fetch(F, nxt, 0); }, t + NST, cur);      // (KS is even: the last k-step's fragments are G's)
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
         }
-        fetch(G, cur, 1);
-        mask_tail(F, nt - 1, 0);
-        mask_tail(G, nt - 1, 1);
-        mma(F, [] {}, -1, 0);
-        mma(G, [] {}, -1, 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            Frag& f = (s & 1) ? G : F;
+            if (s > 0) fetch(f, cur, s);
+            mask_tail(f, nt - 1, s);
+            mma(f, [] {}, -1, 0);
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (dummy pieces of the tiles behind the slice)
     }
 
@@ -523,11 +541,11 @@ __global__ __launch_bounds__(64 * (8 + LW)) void gemm_b16x_kernel(Args g) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, int LW>
+template <int BM, int BN, int WGM, int WGN, int NST, int LW, int BKT = 32>
 hipError_t launch(const Args& g, hipStream_t s) {
-    using Q = Geo<BM, BN, WGM, WGN, NST, LW>;
+    using Q = Geo<BM, BN, WGM, WGN, NST, LW, BKT>;
     static bool attr_set = false;
-    auto kern = &gemm_b16x_kernel<BM, BN, WGM, WGN, NST, LW>;
+    auto kern = &gemm_b16x_kernel<BM, BN, WGM, WGN, NST, LW, BKT>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Q::LDS);
         if (e != hipSuccess) return e;
@@ -551,12 +569,15 @@ inline hipError_t launch_cfg(int cfg, const Args& g, hipStream_t s) {
     if (cfg == 2) return launch<128, 256, 2, 4, NST_DEFAULT, 0>(g, s);
     if (cfg == 3) return launch<192, 256, 2, 4, NST_DEFAULT, 4>(g, s);
     if (cfg == 5) return launch<128, 256, 2, 4, NST_DEFAULT, 4>(g, s);
+    // whole-line ring stages (BK = 64): 6 = 192 x 256 + 4L, two stages (112 KiB); 8 = 128 x 256 + 4L, three (144 KiB)
+    if (cfg == 6) return launch<192, 256, 2, 4, 2, 4, 64>(g, s);
+    if (cfg == 8) return launch<128, 256, 2, 4, 3, 4, 64>(g, s);
     return hipErrorInvalidValue;
 }
 
 // Fills tiles / slices / extents; false when the problem does not fit the kernel's addressing (32-bit buffer offsets).
 inline bool plan(Args& g, int cfg, int split) {
-    if (cfg == 4) return false;
+    if (cfg == 4 || cfg == 7 || cfg < 0 || cfg > 8) return false;
     const int BM = tile_bm(cfg), BN = 256;
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (int)((g.N + BN - 1) / BN);

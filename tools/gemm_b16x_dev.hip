@@ -68,9 +68,9 @@ static int check() {
         CK(hipMalloc(&dbias, p.N * 4)); CK(hipMalloc(&dcs, csrows * p.N * 4));
         CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(dMask, hMask.data(), hMask.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dbias, hbias.data(), p.N * 4, hipMemcpyHostToDevice));
-        for (int cfg = 0; cfg < 6; ++cfg)
+        for (int cfg = 0; cfg < 9; ++cfg)
             for (const Feat& f : feats) {
-                if (cfg == 4) continue;
+                if (cfg == 4 || cfg == 7) continue;
                 if (f.split > 1 && p.K < 64 * f.split) continue;
                 b16x::Args g{};
                 g.A = dA; g.B = dB; g.M = p.M; g.N = p.N; g.K = p.K; g.lda = lda; g.ldb = ldb;
@@ -116,7 +116,7 @@ static int check() {
                 if (!ok) ++bad;
                 if (nbadcb) printf("    %ld wrong Cb elements\n", nbadcb);
                 printf("cfg %d (%dx256%s) M=%4ld N=%4ld K=%4ld %-20s errC %.2g errCb %.2g errCbT %.2g errcs %.2g (scale %.3g) pads %s tickets %d %s\n", cfg,
-                       b16x::tile_bm(cfg), cfg >= 3 ? "+4L" : "", p.M, p.N, p.K, f.name, errc, errb, errt, errs, scale, pads ? "ok" : "BAD", tk, ok ? "ok" : "FAIL");
+                       b16x::tile_bm(cfg), cfg >= 6 ? "+4L k64" : cfg >= 3 ? "+4L" : "", p.M, p.N, p.K, f.name, errc, errb, errt, errs, scale, pads ? "ok" : "BAD", tk, ok ? "ok" : "FAIL");
             }
         CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dMask)); CK(hipFree(dCb)); CK(hipFree(dCbT)); CK(hipFree(dC)); CK(hipFree(dbias)); CK(hipFree(dcs));
     }
@@ -185,9 +185,9 @@ static void timeit(long Mr) {
         CK(hipMemcpy(dMask, hM.data(), hM.size() * 2, hipMemcpyHostToDevice)); CK(hipMemset(dC, 0, p.M * ldc * 4));
         const double gf = 2e-9 * p.M * p.N * p.K;
         printf("%-36s M=%6ld N=%5ld K=%6ld  %.2f GFLOP\n", p.name, p.M, p.N, p.K, gf);
-        for (int cfg = 0; cfg < 6; ++cfg) {
-            if (cfg == 4) continue;
-            std::string line = std::string("   ") + std::to_string(b16x::tile_bm(cfg)) + "x256" + (cfg >= 3 ? "+4L:" : ":");
+        for (int cfg = 0; cfg < 9; ++cfg) {
+            if (cfg == 4 || cfg == 7) continue;
+            std::string line = std::string("   ") + std::to_string(b16x::tile_bm(cfg)) + "x256" + (cfg >= 6 ? "+4L k64:" : cfg >= 3 ? "+4L:" : ":");
             for (int split : {1, 2, 4, 6, 8, 10, 12, 16}) {
                 b16x::Args g{};
                 g.A = dA; g.B = dB; g.M = p.M; g.N = p.N; g.K = p.K; g.lda = lda; g.ldb = ldb; g.C = p.c ? dC : nullptr; g.ldc = ldc; g.out_mode = p.out_mode;
