@@ -1307,10 +1307,12 @@ typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
 // rounded to bf16 once in nemo_ctx_create, pose features rounded when they are staged, fp32 accumulate.  BASELINE
 // configs[2].  P then points at nemo_ctx::d_posedirs_bf16 and ldP is NVp.
 //   MODE 1 (round 2): skinning, L1 and both adjoints on the fp32 pipe.
-//   MODE 3 (default): the vertex->joint adjoint on the bf16 pipe in SPLIT precision (its operands are lane-local),
-//   skinning on the fp32 pipe.  MODE 2: skinning in split precision too -- measured SLOWER than MODE 1 (475 against
-//   358 us at 8 x 300): its 48 ds_read_b128 per tile form serial LDS round trips the register budget (255 VGPRs) leaves no
-//   room to pipeline (tools/mesh_phase_prof.py: 11.9 k cycles per tile for the 36 MFMAs of one body); kept as an A/B aid.
+//   MODE 3: the vertex->joint adjoint on the bf16 pipe in SPLIT precision (its operands are lane-local), skinning on the fp32
+//   pipe (dense weights) or as sparse VALU FMAs (SPARSE).  MODE 2 (the bf16 default since round 5): skinning in split precision
+//   too.  Round 3 measured MODE 2 SLOWER (475 against 358 us at 8 x 300) -- but with every ds_read_b128 of the kernel 8-byte
+//   aligned (64 LDS cycles instead of 4, fixed in round 4); re-measured it is 4 - 7 % faster than MODE 3 with sparse skinning
+//   (434 against 465 us per 40 x 300 launch): the bf16 kernel is VALU-issue bound and the 384 skinning FMAs per tile leave the
+//   VALU for 72 MFMAs on a matrix pipe that is 23 % busy (profiles/r05_pmc_mesh_b16.md).
 //   Split precision: every fp32 operand is
 //   carried as two bf16 pieces (hi = bf16(x), lo = bf16(x - hi): 16 significant bits, ~4e-6 relative) and the product
 //   is the sum of the piece products with fp32 accumulation:

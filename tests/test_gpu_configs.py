@@ -270,3 +270,26 @@ def test_c4_rows_for_nemo_v3_v4(version):
     ld_h, _ = m.step(vs, fs, update=False)
     for k in ld_o:
         assert rel_err(ld_h[k], ld_o[k]) < 1e-4, (k, ld_h[k], ld_o[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('env,target', [
+    # the round-1..4 arithmetic of the fp32 build: mesh blend on the fp32 MFMA pipe, reductions by float atomics
+    ({'NEMO_MESH_BLEND': 'f32', 'NEMO_ORDERED_REDUCE': '0'}, ['tests/test_gpu_model.py', '-k', 'published_config_step_vs_oracle']),
+    # the bf16 build's earlier forms: fp32 / sparse skinning in the mesh kernel (MODE 3), 64-byte-row GEMM stages, fp32 first layer
+    ({'NEMO_MESH_SPLIT': '3', 'NEMO_B16X_BK': '32', 'NEMO_B16_FIRST_LAYER': '0'},
+     ['tests/test_gpu_bf16.py', '-k', 'c3_bf16_step or v2v_fused_bf16 or large_tile_bf16_product']),
+], ids=['fp32_mfma_blend_atomics', 'bf16_round4_forms'])
+def test_alternative_kernel_paths_stay_correct(env, target):
+    """The switches of INTEGRATION.md section F that select another KERNEL are read once per process: each alternative runs the
+    parity tests that cover it in a child process, so that the non-default forms (bench.py's `f32_mfma_blend` leg, the A/B aids)
+    cannot rot."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider'] + target, cwd=root, env=e,
+                       capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout or '')[-1500:]
+    assert r.returncode == 0, tail
+    assert ' passed' in tail and ' failed' not in tail, tail

@@ -609,11 +609,14 @@ def test_vertices_and_v2v(L, num_verts):
                                               (6890, 40, '3,9,3'), (6890, 40, '1,36,2'), (100, 37, '1,1,2'),
                                               (128, 50, '1,1,3'), (6890, 20, '5,0,0')])
 @pytest.mark.parametrize('skin_nnz', [24, 4, 3])
-def test_v2v_fused_mesh_kernel(L, num_verts, N, plan, skin_nnz, monkeypatch):
+@pytest.mark.parametrize('entry', ['nemo_v2v_fused', 'nemo_v2v_fused_split3'])
+def test_v2v_fused_mesh_kernel(L, num_verts, N, plan, skin_nnz, entry, monkeypatch):
     """Fused pose blend + skinning + L1 + gradient (MFMA accumulator layout end to end) against the
     oracle's unfused lbs + autograd; ragged vertex tiles (100, 6890 = 430*16+10) and sample groups.
     skin_nnz: 24 = dense weights (24-joint skinning product on the MFMA pipe), 4 / 3 = the published model's sparsity
-    (skinning with the non-zero weights only, csrc/smpl.hip SPARSE)."""
+    (skinning with the non-zero weights only, csrc/smpl.hip SPARSE).  entry: the fp32-MFMA kernel (MODE 0) and the
+    fp32-equivalent three-piece form the engine runs by default (MODE 4) -- same gates."""
+    fused = getattr(L, entry)
     if plan:
         monkeypatch.setenv('NEMO_MESH_PLAN', plan)
     from oracle import ops
@@ -641,20 +644,20 @@ def test_v2v_fused_mesh_kernel(L, num_verts, N, plan, skin_nnz, monkeypatch):
     dA.fill_(7.0)                                       # dA is overwritten, not accumulated
     for _ in range(2):                                  # second launch: tickets were returned to zero
         loss.zero_()
-        assert L.nemo_v2v_fused(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss.data_ptr(), dVPt.data_ptr(),
+        assert fused(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss.data_ptr(), dVPt.data_ptr(),
                                 ldn, dA.data_ptr(), ws.data_ptr(), ws.numel() * 4, H.st()) == 0
     assert rel_err(loss[0], l1.detach()) < 1e-5
     assert float(dVPt[NV3:].abs().sum()) == 0.0 and float(dVPt[:, N:].abs().sum()) == 0.0   # pads stay zero
     # deferred combine (dA = NULL + nemo_v2v_combine, what the step runs beside the adjoint GEMM): bit-identical dA, and
     # an in-launch combine afterwards still finds its tickets at zero
     loss2, dVPt2, dA2 = Z(1), Z(3 * ctx.NVp, ldn), Z(N, 24, 12).fill_(-3.0)
-    assert L.nemo_v2v_fused(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss2.data_ptr(), dVPt2.data_ptr(),
+    assert fused(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss2.data_ptr(), dVPt2.data_ptr(),
                             ldn, None, ws.data_ptr(), ws.numel() * 4, H.st()) == 0
     assert L.nemo_v2v_combine(ctx.handle, N, dA2.data_ptr(), ws.data_ptr(), ws.numel() * 4, H.st()) == 0
     assert torch.equal(dA2, dA) and torch.equal(dVPt2, dVPt) and torch.equal(loss2, loss)
     dA3 = Z(N, 24, 12)
     loss2.zero_()
-    assert L.nemo_v2v_fused(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss2.data_ptr(), dVPt2.data_ptr(),
+    assert fused(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss2.data_ptr(), dVPt2.data_ptr(),
                             ldn, dA3.data_ptr(), ws.data_ptr(), ws.numel() * 4, H.st()) == 0
     assert torch.equal(dA3, dA)
     assert L.nemo_gemm_f32(1, 1, N, 207, NV3, dVPt.data_ptr(), ldn, ctx.posedirs, ctx.ldP, dPF.data_ptr(), 208,
