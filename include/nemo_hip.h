@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 13
+#define NEMO_ABI_VERSION 14
 int32_t nemo_abi_version(void);
 
 /* Deterministic accumulation (round 5).  Every sum over the blocks of a launch that used float atomics until round 4 -- the
@@ -64,6 +64,16 @@ int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int64_t N, int6
                       const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
                       int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream);
 #define NEMO_GEMM_WS_MIN (16384 + 65536)
+/* nemo_gemm_f32 (out_mode 0, library-chosen plan) that ALSO leaves the column sums of its result -- after bias / activation /
+ * mask -- per 32-row band: colsum[band * ldcs + n], band = 0 .. nemo_gemm_colsum_rows(M) - 1, ldcs >= N (round 5).  The
+ * activation-gradient launches of the fp32 MotionNet backward (dX_l = mask(dY_{l+1} W_{l+1}), neural_motion_model.py:58-71 under
+ * autograd) hand the next layer's bias gradient over this way: a sum over 2 ceil(M / 64) short rows instead of a second pass
+ * over the M x N matrix (6.7 GB per step at 256 x 1024).  One writer per element: deterministic. */
+int32_t nemo_gemm_f32_colsum(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
+                             const float* A, int64_t lda, const float* B, int64_t ldb,
+                             float* C, int64_t ldc, const float* bias, int32_t act,
+                             const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
+                             float* colsum, int64_t ldcs, void* ws, int64_t ws_bytes, void* stream);
 /* Same contraction, arguments and epilogues with both operands rounded to bf16 (RNE) on their way from LDS into the
  * matrix cores (v_mfma_f32_32x32x16_bf16), fp32 accumulate, fp32 in memory on both sides -- BASELINE configs[2].
  * Operands that do not qualify for the LDS-DMA kernel (rows not 16-byte aligned) are multiplied in fp32 instead. */

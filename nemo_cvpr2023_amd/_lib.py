@@ -32,7 +32,7 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 13        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 14        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -40,6 +40,8 @@ SIGNATURES = {
     'nemo_reduce_scratch_reset': (i32, []),
     'nemo_gemm_f32': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32,
                             f32, i32, i32, ptr, i64, ptr]),
+    'nemo_gemm_f32_colsum': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32, f32,
+                                   ptr, i64, ptr, i64, ptr]),
     'nemo_gemm_bf16': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32,
                              f32, i32, i32, ptr, i64, ptr]),
     'nemo_gemm_bf16mem': (i32, [i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32, f32, i32, ptr, i64, ptr,

@@ -571,6 +571,16 @@ static int skinny_kind(bool akc, bool bkc, bool aligned, bool can_split, long M,
 // bf16: 0 = fp32 arithmetic; 1 = fp32 operands in memory, rounded to bf16 on their way into the matrix cores; 2 = operands
 // ALREADY bf16 in memory (NT only: A (M x K) and B (N x K) k-contiguous; A / B / lda / ldb / K arrive in units of bf16
 // PAIRS, i.e. as the fp32-typed view of the same bytes), optional bf16 copies of the result (Cb, CbT)
+// colsum[band][n] = sum of rows [32 band, 32 band + 32) of C (the scratch layout of the GEMM epilogues' per-band column sums)
+__global__ __launch_bounds__(64) void band_colsum_kernel(const float* __restrict__ C, long M, long N, long ldc, float* __restrict__ colsum,
+                                                         long ldcs) {
+    const long n = (long)blockIdx.x * 64 + threadIdx.x, m0 = (long)blockIdx.y * 32;
+    if (n >= N) return;
+    float s = 0.f;
+    for (long m = m0; m < min(M, m0 + 32); ++m) s += C[m * ldc + n];
+    colsum[(long)blockIdx.y * ldcs + n] = s;
+}
+
 static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
                          const float* A, int64_t lda, const float* B, int64_t ldb,
                          float* C, int64_t ldc, const float* bias, int32_t act,
@@ -583,7 +593,10 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     const bool b16out = bf16 == 0 && (Cb || CbT);
     if (M < 0 || N < 0 || K < 0 || (!C && !((bf16 == 2 || b16out) && (Cb || CbT) && out_mode == 0))) return NEMO_EINVAL;
     if (b16out && (out_mode != 0 || (Cb && ldcb < N) || (CbT && (ldcbt < M || (ldcbt & 3) || (((uintptr_t)CbT) & 7))))) return NEMO_EINVAL;
-    if (colsum && (bf16 != 2 || out_mode == 2 || ldcs < N)) return NEMO_EINVAL;
+    // (column sums of the result per 32-row band: the bf16-in-memory kernel's epilogue since round 3, the fp32 LDS-DMA kernel's
+    //  since round 5 -- nemo_gemm_f32_colsum; other plans compute them from C in a launch of their own, band_colsum_kernel)
+    if (colsum && (bf16 == 1 || out_mode == 2 || (bf16 == 0 && (out_mode != 0 || !C)) || ldcs < N)) return NEMO_EINVAL;
+    const bool cs32 = colsum != nullptr && bf16 == 0;
     if (M == 0 || N == 0) return NEMO_OK;
     if (K > 0 && (!A || !B)) return NEMO_EINVAL;
     if (act < 0 || act > 2 || mask_mode < 0 || mask_mode > 2 || out_mode < 0 || out_mode > 2)
@@ -625,7 +638,7 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     // resident -- a count that overshoots the 256 / 512 slots by a few workgroups costs a whole extra round -- and every slice
     // keeps >= 8 K tiles; beyond 16 slices they are summed in two levels (gemm_adj.h).
     if (glds_ok && !bf16 && transA && transB && N > 128 && N <= 208 && M >= 256 && K >= 2048 && split_k == 0 &&
-        out_mode != 2 && force_tile == 0 && can_split && !bias && !act && !mask_mode) {
+        out_mode != 2 && force_tile == 0 && can_split && !bias && !act && !mask_mode && !colsum) {
         const long tiles_m = (M + 63) / 64;
         int S = (int)((tiles_m <= 8 ? 256 : 512) / tiles_m);
         if (S < 1) S = 1;
@@ -689,7 +702,7 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     // mini-batches of a few hundred samples): the intra-block K split of gemm_skinny.h, 19 -> 13 us for 300 x 1000 x 1000
     // and ~2x on the small layers (profiles/r02_gemm_skinny.md).  Very long K (the blend-shape adjoint) stays with the
     // LDS-staged kernel: a wave's K slice would be thousands of steps.
-    const int sk_kind = !bf16 && !b16out && split_k == 0 && force_tile == 0 && K >= 1
+    const int sk_kind = !bf16 && !b16out && !colsum && split_k == 0 && force_tile == 0 && K >= 1
                             ? skinny_kind(!transA, transB != 0, (va || transA) && (vb || !transB),
                                           can_split && out_mode != 2 && ws_bytes >= COUNTER_BYTES + (8L << 20), M, N, K) : -1;
     if (sk_kind >= 0 && (glds_ok || glds::extents(transA, transB, M, N, K, lda, ldb, &a_bytes, &b_bytes))) {
@@ -725,6 +738,15 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
         return NEMO_OK;
     }
     const int tile = pl.tile;
+    if (cs32 && !(tile == 64 && glds_ok)) {                 // (unaligned operands, the 128 x 128 tile: sums from C afterwards)
+        const int32_t rc = gemm_impl(bf16, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, mask, ldmask, mask_mode, alpha,
+                                     out_mode, split_k, ws, ws_bytes, stream);
+        if (rc != NEMO_OK) return rc;
+        hipLaunchKernelGGL(band_colsum_kernel, dim3(nemo_cdiv(N, 64), (unsigned)(2 * ((M + 63) / 64))), dim3(64), 0, (hipStream_t)stream,
+                           C, (long)M, (long)N, (long)ldc, colsum, (long)ldcs);
+        NEMO_LAUNCH_CHECK();
+        return NEMO_OK;
+    }
     static const bool debug_plans = getenv("NEMO_GEMM_DEBUG") != nullptr;          // tuning aid: the plan of every call
     if (debug_plans)
         fprintf(stderr, "nemo_gemm_f32 ta=%d tb=%d M=%ld N=%ld K=%ld out=%d -> %s tile %d split %d t0 %ld (model %.1f us)\n",
@@ -806,6 +828,16 @@ extern "C" int32_t nemo_gemm_f32(int32_t transA, int32_t transB, int64_t M, int6
                                  int32_t out_mode, int32_t split_k, void* ws, int64_t ws_bytes, void* stream) {
     return gemm_impl(false, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, mask, ldmask, mask_mode, alpha,
                      out_mode, split_k, ws, ws_bytes, stream);
+}
+
+extern "C" int32_t nemo_gemm_f32_colsum(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,
+                                        const float* A, int64_t lda, const float* B, int64_t ldb,
+                                        float* C, int64_t ldc, const float* bias, int32_t act,
+                                        const float* mask, int64_t ldmask, int32_t mask_mode, float alpha,
+                                        float* colsum, int64_t ldcs, void* ws, int64_t ws_bytes, void* stream) {
+    if (!colsum) return NEMO_EINVAL;
+    return gemm_impl(false, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, act, mask, ldmask, mask_mode, alpha,
+                     0, 0, ws, ws_bytes, stream, nullptr, 0, nullptr, 0, nullptr, 0, colsum, ldcs);
 }
 
 extern "C" int32_t nemo_gemm_bf16(int32_t transA, int32_t transB, int64_t M, int64_t N, int64_t K,

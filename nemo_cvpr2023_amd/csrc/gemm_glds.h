@@ -73,7 +73,8 @@ struct Args {
     // C may be NULL when only the bf16 copies of the result are wanted (hidden activations of a bf16-in-memory chain)
     const unsigned short* mask16 = nullptr;
     long ldmask16 = 0;
-    // BF16 == 2 only: column sums of the RESULT (after bias / activation / mask) per 32-row wave band -- row
+    // (32 x 32 accumulators; fp32 operands since round 5 too) column sums of the RESULT (after bias / activation / mask, out_mode 0)
+    // per 32-row wave band -- row
     // (tile_m * (BM / 32) + band) of colsum[.][ldcs] gets the band's sum of every column: the bias gradient of a layer is
     // then a sum over 2 ceil(M / 64) short rows instead of a pass over the M x N result, which no longer has to exist in
     // fp32 at all.  One writer per element, no atomics: deterministic.
@@ -516,8 +517,8 @@ __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, flo
                     else if (g.out_mode == 1) { v += *c; *c = v; }
                     else atomicAdd(c, v);
                 }
+                csum += v;
                 if constexpr (BF16 == 2) {
-                    csum += v;
                     const unsigned short bits = __builtin_bit_cast(unsigned short, (__bf16)v);
                     if (g.Cb) g.Cb[m * g.ldcb + n] = bits;                 // 32 lanes x 2 B: 64-byte runs along n
                     if (g.CbT) {
@@ -535,7 +536,7 @@ __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, flo
                     }
                 }
             }
-            if constexpr (BF16 == 2 && T == 32) {
+            if constexpr (T == 32) {
                 if (g.colsum) {
                     csum += __shfl_xor(csum, 32, 64);              // lanes l and l + 32: the same column, the other rows
                     if (lh == 0) g.colsum[((long)tm * (BM / 32) + wm * TM + i) * g.ldcs + n] = csum;

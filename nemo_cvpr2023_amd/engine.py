@@ -378,6 +378,8 @@ class FitEngine:
     B16_DW_ASIDE_ROWS = 10000       # bf16 chain: parameter-gradient products on the side stream up to this many rows
     SMALL_BATCH_ROWS = 1024  # backward_mlp: below this many rows the dW GEMMs run beside the dX chain
     GROUPED_DW_ROWS = 400    # ... and up to this many as ONE grouped launch behind it (a one-instance shard)
+    ECS_ROWS = 1536          # fp32 backward_mlp: bias gradients from the dX launches' per-band column sums above this many rows
+                             # (same box: headline 1.257 / 1.259 ms without / with, C4 101.8 / 101.5 ms: the win is C4's 6.6 GB of reads)
     MAX_WORKSPACES = 24      # distinct batch sizes kept alive (a rank of a sharded minibatch run sees many)
 
     @staticmethod
@@ -445,9 +447,10 @@ class FitEngine:
             # (forward: three bf16 pieces per row -- [hi | lo | hi] against the weight's [hi | hi | lo]: the first layer's product in
             #  fp32-equivalent split precision; backward: the plain transposed copy)
             w['Xs'], w['XbT'] = Zb(N + 1, 3 * r8(self.din)), Zb(self.din, rp)
-            # per-band column sums of the two hidden activation gradients (nemo_gemm_bf16mem(colsum)): their bias gradients
-            R = int(self.lib.nemo_gemm_colsum_rows(N + 1))
-            w['cs4'], w['cs2'], w['cs0'] = Z(R, h), Z(R, h), Z(R, h)
+        # per-band column sums of the three activation gradients of the MotionNet backward (the epilogues of their launches:
+        # nemo_gemm_bf16mem(colsum) / nemo_gemm_f32_colsum): the bias gradients of layers 4, 2, 0 from 2 ceil(r / 64) short rows
+        R = int(self.lib.nemo_gemm_colsum_rows(N + 1))
+        w['cs4'], w['cs2'], w['cs0'] = Z(R, h), Z(R, h), Z(R, h)
         if self.version == 0:            # hidden activations of the orient and translation networks (poses: H1..H3)
             w.update(O1=Z(N + 1, h), O2=Z(N + 1, h), O3=Z(N + 1, h), T1=Z(N + 1, h), T2=Z(N + 1, h))
         # scratch of nemo_v2v_fused (arrival tickets, zero at allocation and returned to zero by the kernel, +
@@ -467,7 +470,7 @@ class FitEngine:
 
     # ------------------------------------------------------------------ kernel helpers
     def gemm(self, ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias=None, act=0, mask=None, ldmask=0,
-             mask_mode=0, alpha=1.0, out_mode=0, split_k=0, tag=None, dense=False):
+             mask_mode=0, alpha=1.0, out_mode=0, split_k=0, tag=None, dense=False, colsum=None):
         """split_k 0: the library picks the tile shape and the K split (combined inside the launch through
         this stream's scratch).  dense=True marks the contractions that ``args.gemm_dtype = 'bf16'`` moves to the
         bf16 matrix cores (nn.Linear forward / backward of MotionNet and VPoser, the blend-shape adjoint); the joint
@@ -475,6 +478,14 @@ class FitEngine:
         ev = self._event_begin(tag, 2.0 * M * N * K)
         cur = torch.cuda.current_stream()
         ws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]
+        if colsum is not None:
+            # fp32 only: the launch also leaves the per-band column sums of its result (nemo_gemm_f32_colsum, round 5)
+            assert not self.bf16 and out_mode == 0 and split_k == 0
+            check(self.lib.nemo_gemm_f32_colsum(ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias, act, mask, ldmask, mask_mode, alpha,
+                                                colsum.data_ptr(), colsum.stride(0), ws.data_ptr(), ws.numel() * 4, _stream()),
+                  'nemo_gemm_f32_colsum')
+            self._event_end(ev)
+            return
         fn = self.lib.nemo_gemm_bf16 if (dense and self.bf16) else self.lib.nemo_gemm_f32
         check(fn(ta, tb, M, N, K, A, lda, B, ldb, Cp, ldc, bias, act, mask, ldmask, mask_mode, alpha, out_mode,
                  split_k, ws.data_ptr(), ws.numel() * 4, _stream()), 'nemo_gemm')
@@ -1146,6 +1157,19 @@ class FitEngine:
         main, side = torch.cuda.current_stream(), self.side_stream
         cs_in = not bucketed      # bias column sums inside the phase backward's launch
         small = r <= self.SMALL_BATCH_ROWS
+        # Round 5 (fp32 arithmetic only): the three activation-gradient launches leave the per-band column sums of their result
+        # (nemo_gemm_f32_colsum): the bias gradients of layers 4, 2, 0 are sums over R = 2 ceil(r / 64) short rows, not passes
+        # over r x h matrices (at C4 a 6.7 GB read per step; at 8 x 300 the tail kernel of the step).
+        ecs = not self.bf16
+        R = int(L.nemo_gemm_colsum_rows(r))
+        cs4, cs2, cs0 = (w['cs4'], w['cs2'], w['cs0']) if ecs else (None, None, None)
+
+        def bias_from(cs_buf, name):
+            """the bias gradient of layer `name` as the column sum of the band sums; returns the gb to hand to the dW call"""
+            if not ecs:
+                return self.g(lm + name)
+            self._colsums.append((dptr(cs_buf), R, h, h, self.g(lm + name)))
+            return None
         # Round 4: the parameter-gradient products go beside the dX chain at (nearly) every size of an un-bucketed step -- same
         # box, ms per step, all of them beside / only the heads' beside / none (the round-2 schedule for > 1024 rows): 2400 rows
         # 1.386 / 1.380 / 1.405, 12 000: 5.581 / 5.607 / 5.718, 19 200: 8.766 / 8.864 / -, 38 400: 16.98 / 17.07 / -, 262 144 (C4):
@@ -1184,15 +1208,15 @@ class FitEngine:
             dWg(r, dptr(w['H3']), h, h, dptr(w['dHEAD']), HEAD_LD, nout, self.g(lm + 'rot_out.weight'),
                 self.g(lm + 'rot_out.bias'), nbias=nbias)
             self.gemm(0, 0, r, h, nout, dptr(w['dHEAD']), HEAD_LD, self.p(lm + 'rot_out.weight'), h,
-                      dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1, dense=True)
-            dWg(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
+                      dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1, dense=True, colsum=cs4)
+            dWg(r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), bias_from(cs4, 'net.net.4.bias'))
             self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
-                      mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx', dense=True)
-            dWg(r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+                      mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx', dense=True, colsum=cs2)
+            dWg(r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), bias_from(cs2, 'net.net.2.bias'))
             self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
-                      mask=dptr(w['H1']), ldmask=h, mask_mode=1, dense=True)
+                      mask=dptr(w['H1']), ldmask=h, mask_mode=1, dense=True, colsum=cs0)
             dWg(r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h, self.g(lm + 'net.net.0.weight'),
-                self.g(lm + 'net.net.0.bias'))
+                bias_from(cs0, 'net.net.0.bias'))
             ev = main.record_event()
             self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
                       dptr(w['dX']), self.ldx, dense=True)
@@ -1221,25 +1245,25 @@ class FitEngine:
             if ev is None:
                 dW(None, *a_, nbias=nbias)
             self.gemm(0, 0, r, h, nout, dptr(w['dHEAD']), HEAD_LD, self.p(lm + 'rot_out.weight'), h,
-                      dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1, dense=True)
+                      dptr(w['dH']), h, mask=dptr(w['H3']), ldmask=h, mask_mode=1, dense=True, colsum=cs4)
             if ev is not None:
                 dW(ev, *a_, nbias=nbias)
             ev = dY_ready()
-            a_ = (r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), self.g(lm + 'net.net.4.bias'))
+            a_ = (r, dptr(w['H2']), h, h, dptr(w['dH']), h, h, self.g(lm + 'net.net.4.weight'), bias_from(cs4, 'net.net.4.bias'))
             if ev is None:
                 dW(None, *a_)
             self.gemm(0, 0, r, h, h, dptr(w['dH']), h, self.p(lm + 'net.net.4.weight'), h, dptr(w['dH_b']), h,
-                      mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx', dense=True)
+                      mask=dptr(w['H2']), ldmask=h, mask_mode=1, tag='gemm_mlp_hidden_dx', dense=True, colsum=cs2)
             if ev is not None:
                 dW(ev, *a_)
             end_of_stage()
         if 1 in stages:
             ev = dY_ready()
-            a_ = (r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), self.g(lm + 'net.net.2.bias'))
+            a_ = (r, dptr(w['H1']), h, h, dptr(w['dH_b']), h, h, self.g(lm + 'net.net.2.weight'), bias_from(cs2, 'net.net.2.bias'))
             if ev is None:
                 dW(None, *a_)
             self.gemm(0, 0, r, h, h, dptr(w['dH_b']), h, self.p(lm + 'net.net.2.weight'), h, dptr(w['dH_c']), h,
-                      mask=dptr(w['H1']), ldmask=h, mask_mode=1, dense=True)
+                      mask=dptr(w['H1']), ldmask=h, mask_mode=1, dense=True, colsum=cs0)
             if ev is not None:
                 dW(ev, *a_)
             end_of_stage()
@@ -1253,13 +1277,13 @@ class FitEngine:
             self.gemm(0, 0, r, self.din, h, dptr(w['dH_c']), h, self.p(lm + 'net.net.0.weight'), self.din,
                       dptr(w['dX']), self.ldx, dense=True)
         w0 = (r, dptr(w['X']), self.ldx, self.din, dptr(w['dH_c']), h, h,
-              self.g(lm + 'net.net.0.weight'), self.g(lm + 'net.net.0.bias'))
+              self.g(lm + 'net.net.0.weight'), bias_from(cs0, 'net.net.0.bias'))
         # ONE more fork, one join: the side stream takes the layer-0 parameter gradient and the batched bias column
         # sums (every dY exists from here on), the main stream -- enqueued first, see above -- the layer-0 dX GEMM and
         # the three phase / RBF / code kernels that consume it
         ev = main.record_event()
         dX0()
-        if cs_in:             # (the layer-0 bias column sum rides in the phase launch with the others)
+        if cs_in and w0[8] is not None:   # (the layer-0 bias column sum rides in the phase launch with the others)
             self._colsums.append((w0[4], w0[0], w0[6], w0[5], w0[8]))
             w0 = w0[:8] + (None,)
         phase_bwd()

@@ -1085,3 +1085,33 @@ def test_v2v_fused_split3_is_fp32_equivalent(L, skin_nnz):
     assert s3['dvp_max'] <= 1.5 * f['dvp_max'] + 1e-9, err
     assert s3['loss'] <= 1.5 * f['loss'] + 2e-7, err              # (one fp32 scalar: both sit at its rounding)
     assert s3['dA_max'] < 1e-5 and s3['loss'] < 1e-5
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb', [(2401, 1000, 1000, 0, 0), (2401, 1000, 147, 0, 0), (700, 130, 96, 0, 1), (333, 77, 105, 0, 0),
+                                          (8200, 1000, 1000, 0, 0)])
+def test_gemm_f32_with_per_band_column_sums(L, M, N, K, ta, tb):
+    """nemo_gemm_f32_colsum: the product of nemo_gemm_f32 (bit-identical C) plus the column sums of the masked result per 32-row
+    band -- from the LDS-DMA kernel's epilogue when the plan is that kernel, from C otherwise (unaligned K = 105 rows)."""
+    H = _ops()
+    gen = torch.Generator().manual_seed(M + N)
+    A = H.dev(torch.randn(M, K, generator=gen))
+    B = H.dev(torch.randn(*((N, K) if tb else (K, N)), generator=gen))
+    mask = H.dev(torch.randn(M, N, generator=gen))
+    ws = torch.zeros((16384 + 65536 + (64 << 20)) // 4, device='cuda')
+    C1, C2 = torch.zeros(M, N, device='cuda'), torch.zeros(M, N, device='cuda')
+    R = int(L.nemo_gemm_colsum_rows(M))
+    cs = torch.full((R, N + 3), 7.0, device='cuda')
+    assert L.nemo_gemm_f32(ta, tb, M, N, K, A.data_ptr(), K, B.data_ptr(), B.stride(0), C1.data_ptr(), N, None, 0,
+                           mask.data_ptr(), N, 1, 1.0, 0, 0, ws.data_ptr(), ws.numel() * 4, H.st()) == 0
+    assert L.nemo_gemm_f32_colsum(ta, tb, M, N, K, A.data_ptr(), K, B.data_ptr(), B.stride(0), C2.data_ptr(), N, None, 0,
+                                  mask.data_ptr(), N, 1, 1.0, cs.data_ptr(), cs.stride(0), ws.data_ptr(), ws.numel() * 4, H.st()) == 0
+    torch.cuda.synchronize()
+    ref = (A.double() @ (B.double().t() if tb else B.double())) * (mask > 0)
+    assert rel_err(C2, ref) < 2e-5
+    if M > 1536 or N < 100:                      # (small M with aligned operands: nemo_gemm_f32 alone takes the skinny kernel)
+        assert torch.equal(C1, C2)
+    pad = torch.zeros(R * 32 - M, N, device='cuda', dtype=torch.float64)
+    bands = torch.cat([C2.double(), pad]).reshape(R, 32, N).sum(1)
+    assert rel_err(cs[:, :N], bands) < 1e-5
+    assert float((cs[:, N:] - 7.0).abs().max()) == 0.0                           # columns beyond N untouched
+    assert rel_err(cs[:, :N].double().sum(0), ref.sum(0)) < 1e-4
