@@ -1422,7 +1422,13 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     // an XCD's L2 once per range and hit by the other blocks (an earlier 1-D split at arbitrary chunk
     // offsets had every block on its own tile position: 10x the L2 fill traffic).  A group's partial dA
     // sums come from its RA range blocks + its left-over segment.
-    const int bid = blockIdx.x, GA = G * RA;
+    // From 128 sample groups on, workgroups b and b + 256 -- the two of a CU -- take ADJACENT positions of the (range, group) order,
+    // i.e. the same vertex range: their blend-shape loads meet in the CU's L1 (round 5; mesh launch at 8 / 16 / 40 x 300:
+    // 369 -> 360, 760 -> 737, 854 -> 821 us; with few groups and many ranges it costs instead -- 1 x 300: 90 -> 98 us -- and the
+    // plan's pairing of long with short ranges, below, is the better use of the two slots).
+    const int nbk = (int)gridDim.x, mpair = nbk > 256 ? nbk - 256 : 0, bx = (int)blockIdx.x;
+    const int bid = G < 128 ? bx : (bx < 256 ? (bx < mpair ? 2 * bx : 2 * mpair + (bx - mpair)) : 2 * (bx - 256) + 1);
+    const int GA = G * RA;
     int g_lo, nseg, k_beg, k_end, slot;
     if (bid < GA) {
         const int r = bid / G;
