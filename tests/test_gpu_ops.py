@@ -395,10 +395,13 @@ def _rand_rot(gen, n, small=False):
     return ops.batch_rodrigues(th)
 
 
+@pytest.mark.parametrize('order', ['random', 'sorted_by_view'])
 @pytest.mark.parametrize('num_verts,version', [(128, 2), (128, 4), (6890, 2)])
-def test_keypoint_path_forward_backward(L, num_verts, version):
+def test_keypoint_path_forward_backward(L, num_verts, version, order):
     """FK -> pre-contracted mesh joints -> projection -> robust loss, and the whole adjoint chain,
-    against the oracle's unfused lbs + autograd."""
+    against the oracle's unfused lbs + autograd.  order: the per-view sums (round 5: deposits + one block per view) take a
+    view's samples from a scan of the batch, or -- batch sorted by view, here with a view that has no sample -- from the view
+    bounds the depositing lanes leave behind."""
     from oracle import ops
     H = _ops()
     assets, ctx, idx = _ctx(num_verts, version)
@@ -410,6 +413,9 @@ def test_keypoint_path_forward_backward(L, num_verts, version):
     cams[:, 3] += 1; cams[:, 6] += 1; cams[:, 2] += 9.26
     vi = torch.randint(0, V, (N,), generator=gen); vi[vi == 1] = 2
     fi = torch.randint(0, T, (N,), generator=gen)
+    if order == 'sorted_by_view':
+        vi, perm = vi.sort()
+        fi = fi[perm]
     seqs = syn.SyntheticSequences(V, T, seed=5)
     tgt = torch.tensor(np.array([np.array(s['pose_2d_op']) for s in seqs.sequences]))
     # oracle
