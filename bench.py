@@ -58,7 +58,8 @@ if ROOT not in sys.path:
 V0, T0 = 8, 300
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks (fp32: v_mfma_f32_32x32x2_f32; bf16: 32x32x16) and HBM3E
 MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0, 'valu_f32': 157.3,      # (valu_f32: the fp32 vector peak = the fp32 MFMA peak)
-                    'bf16x6': 2500.0 / 6}     # fp32-equivalent products on the bf16 pipe: six bf16 piece products each (mesh_blend f32_split)
+                    'f16x3': 2500.0 / 3,      # fp32-equivalent products on the 16-bit pipe: three fp16 piece products each (mesh_blend f32_split)
+                    'bf16x6': 2500.0 / 6}     # ... as six bf16 piece products (NEMO_MESH_PIECES=3, the round's first form)
 HBM_PEAK_GBS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'traffic.json')
 # what a supervisor tries, in order (environment of the worker processes)
@@ -519,9 +520,10 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
         f_strict = flops * engine.mesh_macs(strict=True) / engine.mesh_macs()
     mesh_b16 = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh']).get('bf16', 0.0)
     on_bf16 = (mesh_b16 + parts['blend_adjoint'] + parts['mlp'] + parts['vposer']) if dtype == 'bf16' else 0.0
-    on_b16x6 = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh']).get('bf16x6', 0.0)
-    step_peak = f_step / (on_bf16 / MFMA_PEAK_TFLOPS['bf16'] + on_b16x6 / MFMA_PEAK_TFLOPS['bf16x6'] +
-                          (f_step - on_bf16 - on_b16x6) / MFMA_PEAK_TFLOPS['f32'])
+    _mp = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh'])
+    on_b16x6, on_f16x3 = _mp.get('bf16x6', 0.0), _mp.get('f16x3', 0.0)
+    step_peak = f_step / (on_bf16 / MFMA_PEAK_TFLOPS['bf16'] + on_b16x6 / MFMA_PEAK_TFLOPS['bf16x6'] + on_f16x3 / MFMA_PEAK_TFLOPS['f16x3'] +
+                          (f_step - on_bf16 - on_b16x6 - on_f16x3) / MFMA_PEAK_TFLOPS['f32'])
     roof = {'kernel': tag, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(kpeak, 1),
             'unit': 'TFLOP/s', 'frac': round(achieved / kpeak, 4),
             'frac_strict': round(achieved * (f_strict / flops) / kpeak, 4),
@@ -532,7 +534,7 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
             'frac_f32_pipe': round(achieved / MFMA_PEAK_TFLOPS['f32'], 4),
             'peak_note': 'fp32 MFMA peak' if set(pipes) <= {'f32', 'valu_f32'} else
                          'harmonic mix of the per-pipe peaks over this kernel\'s algorithmic GFLOP per pipe (`pipes`): bf16 MFMA 2500, '
-                         'fp32 MFMA / fp32 VALU 157.3, bf16x6 = fp32-equivalent products as six bf16 piece products = 2500 / 6 '
+                         'fp32 MFMA / fp32 VALU 157.3, f16x3 = fp32-equivalent products as three fp16 piece products = 2500 / 3 '
                          '(mesh_blend f32_split); `frac_f32_pipe` = the same achieved rate against the fp32 MFMA peak alone, '
                          'comparable with rounds 1 - 4',
             'traffic': ktr, 'traffic_source': traffic.get('source') if ktr else None,
@@ -901,7 +903,7 @@ def worker_main(opts):
     # ---- sharded runs: per-rank compute / collective (LAST on this model: the probe takes un-reduced update steps)
     shard_info = shard_probe(cx, model, step, opts.steps) if cx.sharded else None
     shard_mode = model.shard_mode if cx.sharded else None
-    mesh_split3, mesh_variant = bool(engine.mesh_split3), engine.mesh_kernel_variant()
+    mesh_split, mesh_variant = bool(engine.mesh_split), engine.mesh_kernel_variant()
     del engine
     release(cx, model)
     cx.wd.beat('headline done')
@@ -966,7 +968,7 @@ def worker_main(opts):
                                    + (f'{SKIN_NNZ} non-zero skinning weights per vertex (the published SMPL model\'s sparsity)'
                                       if SKIN_NNZ <= 4 else 'a dense skinning-weight matrix'),
                        'instances': V, 'frames': T, 'samples_per_step': V * T, 'h_dim': args.h_dim, 'skin_nnz': SKIN_NNZ,
-                       'mesh_blend': ('f32_split' if mesh_split3 else 'f32') if opts.dtype == 'f32' else 'bf16',
+                       'mesh_blend': ('f32_split' if mesh_split else 'f32') if opts.dtype == 'f32' else 'bf16',
                        'mesh_kernel': mesh_variant,
                        'parallelism': f'instance-shard x{world}' if world > 1 else
                        ('sharded code path in a process group of ONE rank (diagnostic)' if cx.sharded else 'single GPU')},
@@ -977,18 +979,21 @@ def worker_main(opts):
             'roofline': roof, 'cpu_baseline': cpu, 'torch_gpu_baseline': tgpu,
         }
         out.update(extra)
-        if opts.dtype == 'f32' and mesh_split3:
+        if opts.dtype == 'f32' and mesh_split:
             fm = extra.get('f32_mfma_blend') or {}
             out['f32_split'] = {
-                'what': 'the headline runs the fused mesh term with its pose blend (3 x 207 multiply-adds per vertex, body and sample) on '
-                        'the bf16 matrix cores in fp32-equivalent arithmetic: both operands as three bf16 pieces (8 + 8 + 8 significant '
-                        'bits), the six piece products >= 2^-24 exact in fp32, fp32 accumulation (nemo_v2v_fused_split3, csrc/smpl.hip '
-                        'MODE 4), and its vertex->joint adjoint likewise; everything else is the fp32 path.  `f32_mfma_blend` is the same step with the blend on the fp32 MFMA pipe',
-                'criteria': {'a_error_vs_float64': 'tests/test_gpu_ops.py::test_v2v_fused_split3_is_fp32_equivalent: error of loss, d vp and dA '
+                'what': 'the headline runs the fused mesh term with its pose blend (3 x 207 multiply-adds per vertex, body and sample) and its '
+                        'vertex->joint adjoint on the 16-bit matrix cores in fp32-equivalent arithmetic: both operands as two fp16 pieces of '
+                        's x (11 + 11 significant bits + the remainder\'s sign = the fp32 value to one ulp), the three leading piece products '
+                        'exact in fp32, fp32 accumulation (nemo_v2v_fused_split, csrc/smpl.hip MODE 5); everything else is the fp32 path.  '
+                        '`f32_mfma_blend` is the same step with these products on the fp32 MFMA pipe',
+                'criteria': {'a_error_vs_float64': 'tests/test_gpu_ops.py::test_v2v_fused_split_is_fp32_equivalent: error of loss, d vp and dA '
                                                    'against a float64 evaluation of the same fp32 inputs <= 1.5 x the fp32-MFMA kernel\'s '
-                                                   '(measured: dA rms 1.576e-7 against 1.578e-7, blend shapes x 100)',
+                                                   '(measured: dA rms 1.567e-7 against 1.578e-7, blend shapes x 100); the arithmetic itself: '
+                                                   'tests/test_split_precision.py',
                              'b_parity_gates': 'every 1e-4 parity gate of tests/ runs on this default, unchanged',
-                             'c_launch_time': 'profiles/r05_f32_split.md: 369 against 519 us per 8 x 300 launch (-29 %); this run: mesh_launch_ms against mesh_launch_ms_f32_mfma_blend below'},
+                             'c_launch_time': 'profiles/r05_f32_split.md: 316 against 519 us per 8 x 300 launch (-39 %); this run: '
+                                              'mesh_launch_ms against mesh_launch_ms_f32_mfma_blend below'},
                 'ms_per_step': round(ms_per_step, 3), 'ms_per_step_f32_mfma_blend': fm.get('ms_per_step'),
                 'mesh_launch_ms': (roof or {}).get('mean_launch_ms'),
                 'mesh_launch_ms_f32_mfma_blend': (fm.get('roofline') or {}).get('mean_launch_ms')}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 14
+#define NEMO_ABI_VERSION 15
 int32_t nemo_abi_version(void);
 
 /* Deterministic accumulation (round 5).  Every sum over the blocks of a launch that used float atomics until round 4 -- the
@@ -365,13 +365,18 @@ int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t
                        float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* ws, int64_t ws_bytes,
                        void* stream);
 /* nemo_v2v_fused in fp32-EQUIVALENT arithmetic with the pose blend's products (lbs.py:229-233, K = 207: 76 % of the fp32
- * kernel's matrix-pipe cycles) on the bf16 matrix cores: both operands are carried as THREE bf16 pieces (8 + 8 + 8 significant
- * bits = the fp32 value; blend shapes split once at nemo_ctx_create, pose features when staged), the six piece products whose
- * weight is >= 2^-24 are exact in fp32 and accumulated in fp32.  The vertex->joint adjoint dA = W^T dT likewise (W split at
- * nemo_ctx_create, dT = +-[vp; 1] from the pieces of vp with the sign bit flipped).  Skinning, L1 and d vp as in
- * nemo_v2v_fused.  Same arguments, outputs, scratch and determinism.  tests/test_gpu_ops.py::test_v2v_fused_split3_* hold its
- * error against a float64 evaluation to the fp32-MFMA kernel's (round 5; the engine's `mesh_blend = 'f32_split'`). */
-int32_t nemo_v2v_fused_split3(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
+ * kernel's matrix-pipe cycles) and the vertex->joint adjoint dA = W^T dT on the 16-bit matrix cores: every operand is carried as
+ * TWO fp16 pieces of s x (s a power of two that keeps them in fp16's normal range) -- x0 = fp16(s x), x1 = fp16(s x - x0):
+ * 11 + 11 significant bits and the remainder's sign = the fp32 value to one ulp (2^-23) in the worst case --, a product keeps
+ * x0 y0 + x0 y1 + x1 y0 (each exact in fp32; the dropped x1 y1 <= 2^-22 |x y|), fp32 accumulation, the scales divided out exactly
+ * afterwards.  Over the 207 terms of a blend / the 6890 of an adjoint sum the fp32 accumulation's own rounding dominates: measured
+ * error against float64 = the fp32 product's (5.0e-7 against 5.1e-7 of the result's scale, tests/test_split_precision.py).  Blend shapes and
+ * skinning weights are split once at nemo_ctx_create, pose features when staged, dT = +-[vp; 1] from the pieces of vp with the
+ * sign bit flipped.  Skinning, L1 and d vp as in nemo_v2v_fused.  Same arguments, outputs, scratch and determinism.
+ * tests/test_gpu_ops.py::test_v2v_fused_split_* hold its error against a float64 evaluation to the fp32-MFMA kernel's, and
+ * tests/test_split_precision.py the arithmetic itself (round 5; the engine's `mesh_blend = 'f32_split'`; NEMO_MESH_PIECES=3: the
+ * round's first form, three bf16 pieces per operand and six piece products). */
+int32_t nemo_v2v_fused_split(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
                               float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* ws, int64_t ws_bytes,
                               void* stream);
 /* The same with the pose blend (lbs.py:229-233, K = 207) on the bf16 matrix cores: blend shapes rounded to bf16 once

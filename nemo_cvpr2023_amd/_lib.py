@@ -32,7 +32,7 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 14        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 15        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -98,7 +98,7 @@ SIGNATURES = {
     'nemo_v2v_skin_l1': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr]),
     'nemo_v2v_fused_ws_bytes': (i64, [ptr, i64]),
     'nemo_v2v_fused': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
-    'nemo_v2v_fused_split3': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
+    'nemo_v2v_fused_split': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_fused_bf16': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_combine': (i32, [ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_fused_bf16mem': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),

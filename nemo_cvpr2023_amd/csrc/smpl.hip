@@ -48,6 +48,9 @@ struct nemo_ctx {
     //          holds W[16 tile + 4 g + t][16 jt + l15] for t = 0..3 TWICE (k = 8 g + t and 8 g + 4 + t: the B-operand
     //          carries the hi pieces of dT in the first four k and the lo pieces in the last four)
     unsigned short *d_Wsk, *d_Wadj;
+    unsigned short* d_posedirs_sph;    // two fp16 pieces per blend shape x sph_scale (mesh kernel MODE 5), [tile][S][component][piece][lane][8 k]
+    unsigned short* d_Wadjh;           // MODE 5: [tile][joint tile 2][variant 2: W0|W0, W1|0][lane 64][8] (two fp16 pieces of 2^14 W)
+    float sph_scale;                   // power of two: max |P| * sph_scale in [2^13, 2^14)
     unsigned short* d_Wadj3;           // MODE 4: [tile][joint tile 2][variant 3: W0|W0, W1|W1, W0|W2][lane 64][8] (three bf16 pieces of W)
     // SPARSE skinning weights (the published SMPL model has at most four non-zero weights per vertex; the dense 24-column
     // product of lbs.py:236-241 then multiplies 20 zeros per vertex): per vertex (NVp of them, zero rows for the pad) the
@@ -233,10 +236,41 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
             HIPCHK(hipMalloc((void**)&c->d_posedirs_sp3, p3.size() * 2));
             HIPCHK(hipMemcpy(c->d_posedirs_sp3, p3.data(), p3.size() * 2, hipMemcpyHostToDevice));
         }
+        {
+            // two fp16 pieces of s P: x0 = fp16(s x), x1 = fp16(s x - x0), s the power of two that puts max |P| into [2^13, 2^14):
+            // x0 + x1 = s x up to 2^-23 |s x| wherever x1 is a normal fp16 (|x| >= 2^-16 max |P|; below that the absolute error is
+            // <= 2^-24, i.e. 2^-38 of the largest blend shape)
+            float pmax = 0.f;
+            for (size_t i = 0; i < (size_t)207 * NV * 3; ++i) pmax = fmaxf(pmax, fabsf(posedirs[i]));
+            int ex = 0;
+            if (pmax > 0.f) (void)frexpf(pmax, &ex);            // pmax = m 2^ex, m in [0.5, 1)
+            c->sph_scale = ldexpf(1.f, 14 - ex);                // max |P| * scale in [2^13, 2^14)
+            auto f16b = [](float f) -> unsigned short { const _Float16 h = (_Float16)f; unsigned short b; memcpy(&b, &h, 2); return b; };
+            auto unf16 = [](unsigned short b) -> float { _Float16 h; memcpy(&h, &b, 2); return (float)h; };
+            std::vector<unsigned short> p2((size_t)28 * c->NVp * 48, 0);
+            for (int k = 0; k < 207; ++k) {
+                const int S = k / 32, g = (k % 32) / 8, i = k % 8;
+                const float* Pk = posedirs + (size_t)k * NV * 3;
+                for (long v = 0; v < NV; ++v)
+                    for (int cc = 0; cc < 3; ++cc) {
+                        float x = Pk[v * 3 + cc] * c->sph_scale;
+                        for (int pc = 0; pc < 2; ++pc) {
+                            const unsigned short h = f16b(x);
+                            p2[((((((size_t)(v / 16) * 7 + S) * 3 + cc) * 2 + pc) * 4 + g) * 16 + v % 16) * 8 + i] = h;
+                            x -= unf16(h);
+                        }
+                    }
+            }
+            c->d_posedirs_sph = nullptr;
+            HIPCHK(hipMalloc((void**)&c->d_posedirs_sph, p2.size() * 2));
+            HIPCHK(hipMemcpy(c->d_posedirs_sph, p2.data(), p2.size() * 2, hipMemcpyHostToDevice));
+        }
         auto unbf = [](unsigned short h) -> float { unsigned int u = (unsigned int)h << 16; float f; memcpy(&f, &u, 4); return f; };
         const long ntl = c->NVp / 16;
         std::vector<unsigned short> wsk((size_t)2 * c->NVp * 32, 0), wadj((size_t)ntl * 2 * 2 * 64 * 8, 0);
-        std::vector<unsigned short> wadj3((size_t)ntl * 2 * 3 * 64 * 8, 0);
+        std::vector<unsigned short> wadj3((size_t)ntl * 2 * 3 * 64 * 8, 0), wadjh((size_t)ntl * 2 * 2 * 64 * 8, 0);
+        auto f16w = [](float f) -> unsigned short { const _Float16 h = (_Float16)f; unsigned short b; memcpy(&b, &h, 2); return b; };
+        auto unf16w = [](unsigned short b) -> float { _Float16 h; memcpy(&h, &b, 2); return (float)h; };
         for (long v = 0; v < NV; ++v)
             for (int j = 0; j < 24; ++j) {
                 const float w = lbs_weights[v * 24 + j];
@@ -254,6 +288,11 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
                 wadj3[b3 + r] = w0; wadj3[b3 + 4 + r] = w0;
                 wadj3[b3 + 64 * 8 + r] = w1; wadj3[b3 + 64 * 8 + 4 + r] = w1;
                 wadj3[b3 + 2 * 64 * 8 + r] = w0; wadj3[b3 + 2 * 64 * 8 + 4 + r] = w2;
+                // two fp16 pieces of 2^14 W (MODE 5): A images [W0 | W0], [W1 | 0]
+                const unsigned short h0 = f16w(w * 16384.f), h1 = f16w(w * 16384.f - unf16w(f16w(w * 16384.f)));
+                const size_t bh = ((((size_t)t * 2 + jt) * 2) * 64 + (g * 16 + l15)) * 8;
+                wadjh[bh + r] = h0; wadjh[bh + 4 + r] = h0;
+                wadjh[bh + 64 * 8 + r] = h1;
             }
         c->d_Wsk = c->d_Wadj = nullptr;
         HIPCHK(hipMalloc((void**)&c->d_Wsk, wsk.size() * 2));
@@ -263,6 +302,9 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
         c->d_Wadj3 = nullptr;
         HIPCHK(hipMalloc((void**)&c->d_Wadj3, wadj3.size() * 2));
         HIPCHK(hipMemcpy(c->d_Wadj3, wadj3.data(), wadj3.size() * 2, hipMemcpyHostToDevice));
+        c->d_Wadjh = nullptr;
+        HIPCHK(hipMalloc((void**)&c->d_Wadjh, wadjh.size() * 2));
+        HIPCHK(hipMemcpy(c->d_Wadjh, wadjh.data(), wadjh.size() * 2, hipMemcpyHostToDevice));
     }
     {
         int nnz_max = 0;
@@ -306,6 +348,8 @@ extern "C" int32_t nemo_ctx_destroy(nemo_ctx* c) {
     if (c->d_Wsk) (void)hipFree(c->d_Wsk);
     if (c->d_Wadj) (void)hipFree(c->d_Wadj);
     if (c->d_Wadj3) (void)hipFree(c->d_Wadj3);
+    if (c->d_Wadjh) (void)hipFree(c->d_Wadjh);
+    if (c->d_posedirs_sph) (void)hipFree(c->d_posedirs_sph);
     if (c->d_Wsp_w) (void)hipFree(c->d_Wsp_w);
     if (c->d_Wsp_j) (void)hipFree(c->d_Wsp_j);
     delete c;
@@ -1302,6 +1346,7 @@ __global__ __launch_bounds__(256) void v2v_skin_l1_kernel(long N, long NV, const
                         // group touches land in 16 different 16-byte bank quads)
 typedef __bf16 mbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4m __attribute__((ext_vector_type(4)));
+typedef _Float16 mf16x8 __attribute__((ext_vector_type(8)));
 
 // MODE 1 / 2 (bf16): the pose blend (K = 207, 57 % of the kernel's MFMAs) runs on v_mfma_f32_16x16x32_bf16 -- blend shapes
 // rounded to bf16 once in nemo_ctx_create, pose features rounded when they are staged, fp32 accumulate.  BASELINE
@@ -1374,14 +1419,31 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     float* __restrict__ dA, float* __restrict__ parts, int* __restrict__ tickets, float* __restrict__ loss_parts,
     int* __restrict__ grid_ticket, unsigned short* __restrict__ dVPb, long ldk,
     const unsigned short* __restrict__ Wsk, const unsigned short* __restrict__ Wadj,
-    const float* __restrict__ Wsp_w, const unsigned int* __restrict__ Wsp_j) {
+    const float* __restrict__ Wsp_w, const unsigned int* __restrict__ Wsp_j, float pscale) {
     constexpr bool BF16 = MODE >= 1 && MODE <= 3, SPLIT = MODE == 2, ADJS = MODE == 2 || MODE == 3;
     // MODE 4 (round 5, "f32_split"): fp32 arithmetic everywhere EXCEPT that the pose blend's products run on the bf16 pipe with
     // both operands carried as THREE bf16 pieces (8 + 8 + 8 significant bits = the fp32 value): x = x0 + x1 + x2, and
     // P pf = P0 pf0 + P0 pf1 + P1 pf0 + P0 pf2 + P1 pf1 + P2 pf0 (+ terms below 2^-24 of |P| |pf|), every piece product exact in
     // fp32, fp32 accumulation: 252 MFMAs of 16 cycles per tile instead of 312 of 32.  P then points at
     // nemo_ctx::d_posedirs_sp3, pose features are split when they are staged.
-    constexpr bool SP3 = MODE == 4, B16 = BF16 || SP3;
+    // MODE 5 (round 5, last third; the form `mesh_blend = 'f32_split'` runs): the same with TWO fp16 pieces per operand --
+    // x0 = fp16(s x), x1 = fp16(s x - x0) with a power-of-two scale s that keeps the pieces in fp16's normal range: 11 + 11
+    // significant bits + the sign of the remainder = 23 of the fp32 value's 24 bits in the worst case (|s x - x0 - x1| <= 2^-23 |s x|,
+    // one fp32 ulp; tests/test_split_precision.py).  A product keeps x0 y0 + x0 y1 + x1 y0 (the dropped x1 y1 <= 2^-22 |x y|), each
+    // exact in fp32 (11 x 11 bits): 126 MFMAs of 16 cycles for the blend instead of 252, two thirds of the blend-shape bytes and of the
+    // LDS.  Per term that is up to 2^-21 against the 2^-24 of an fp32 FMA; over the 207 terms of a blend the fp32 accumulation's own
+    // rounding dominates either way -- error against float64: fp32 product 5.1e-7, this 5.0e-7, three bf16 pieces 3.2e-7 of the result's
+    // scale (same test), and the kernel's outputs equal the fp32-MFMA kernel's error (test_v2v_fused_split_is_fp32_equivalent).
+    constexpr bool SP3 = MODE == 4 || MODE == 5, SPH = MODE == 5, B16 = BF16 || SP3;
+    constexpr int NP = SPH ? 2 : 3;                          // pieces per operand
+    using e16 = std::conditional_t<SPH, _Float16, __bf16>;   // their element type
+    typedef e16 e16x8 __attribute__((ext_vector_type(8)));
+    auto mfma_p = [](const u32x4m& a, const u32x4m& b, const f32x4& c) {     // one piece product on the matrix pipe
+        if constexpr (SPH) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mf16x8, a), __builtin_bit_cast(mf16x8, b), c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mbf16x8, a), __builtin_bit_cast(mbf16x8, b), c, 0, 0, 0);
+    };
+    constexpr float PF_SCALE = SPH ? 4096.f : 1.f;           // pose features (|pf| <= 2) and vp (|vp| < 4 m) are staged x 2^12
+    const float blend_scale = SPH ? pscale * PF_SCALE : 1.f; // the blend accumulates scale(P) * scale(pf) * (P pf)
     // ... and the vertex->joint adjoint dA = W^T dT likewise (ADJ3): W in three pieces as A images [W0 | W0], [W1 | W1], [W0 | W2]
     // over the two 16-vertex slots of a K = 32 instruction (Wadj then points at nemo_ctx::d_Wadj3), dT in three pieces as B
     // operands [T0 ; T1] and [T2 ; T0]: three MFMAs of 16 cycles per (entry, joint tile) instead of eight fp32 ones of 32.
@@ -1406,8 +1468,8 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* pfL = lds;                                   // [2][16][MF_PFS] floats  (BF16: [2][16][MF_PFB] bf16)
     __bf16* pfB = reinterpret_cast<__bf16*>(lds);
-    float* AL = lds + (SP3 ? 3 * 2 * 16 * MF_PFB / 2 : BF16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS);   // [2][16][MF_AS], entry (e*24 + j)
-                                                        // (SP3: pose features as [piece 3][body 2][16][MF_PFB] bf16)
+    float* AL = lds + (SP3 ? NP * 2 * 16 * MF_PFB / 2 : BF16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS);   // [2][16][MF_AS], entry (e*24 + j)
+                                                        // (SP3: pose features as [piece NP][body 2][16][MF_PFB] bf16 / fp16)
     __bf16* ALb = reinterpret_cast<__bf16*>(AL);        // MODE 2: [body 2][piece 2][16][MF_AB] bf16, entry (e*32 + j)
     float* red = AL + (SPLIT ? 2 * 2 * 16 * MF_AB / 2 : 2 * 16 * (SPARSE ? MF_ASP : MF_AS));   // MF_TAIL: 16 floats + the two flags
     int& ticket_old = *reinterpret_cast<int*>(red + 16);
@@ -1488,14 +1550,14 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q == 51) v.w = 0.f;                                 // column 207 is padding
             if (SP3) {
-                typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
-                float x[4] = {v.x, v.y, v.z, v.w};
+                typedef e16 e4 __attribute__((ext_vector_type(4)));
+                float x[4] = {v.x * PF_SCALE, v.y * PF_SCALE, v.z * PF_SCALE, v.w * PF_SCALE};
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
-                    bf4 h;
+                for (int pc = 0; pc < NP; ++pc) {
+                    e4 h;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { h[i] = (__bf16)x[i]; x[i] -= (float)h[i]; }
-                    *reinterpret_cast<bf4*>(pfB + ((pc * 2 + set) * 16 + n) * MF_PFB + 4 * q) = h;
+                    for (int i = 0; i < 4; ++i) { h[i] = (e16)x[i]; x[i] -= (float)h[i]; }
+                    *reinterpret_cast<e4*>(pfB + ((pc * 2 + set) * 16 + n) * MF_PFB + 4 * q) = h;
                 }
             } else if (BF16) {
                 typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
@@ -1507,7 +1569,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
             }
         }
-        for (int idx = tid; idx < (SP3 ? 3 : 1) * 2 * 16 * 16; idx += 256) {        // rows 208..223 of the k padding
+        for (int idx = tid; idx < (SP3 ? NP : 1) * 2 * 16 * 16; idx += 256) {       // rows 208..223 of the k padding
             if (B16) pfB[(idx / 16) * MF_PFB + 208 + idx % 16] = (__bf16)0.f;
             else pfL[(idx / 16) * MF_PFS + 208 + idx % 16] = 0.f;
         }
@@ -1543,11 +1605,11 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             const long s = s0 + n;
             const float val = (s < N && p < 207) ? PF2[(set * N + s) * ldpf + p] : 0.f;
             if (SP3) {
-                float x = val;
+                float x = val * PF_SCALE;
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
-                    const __bf16 h = (__bf16)x;
-                    pfB[((pc * 2 + set) * 16 + n) * MF_PFB + p] = h;
+                for (int pc = 0; pc < NP; ++pc) {
+                    const e16 h = (e16)x;
+                    pfB[((pc * 2 + set) * 16 + n) * MF_PFB + p] = __builtin_bit_cast(__bf16, h);
                     x -= (float)h;
                 }
             } else if (BF16) pfB[(set * 16 + n) * MF_PFB + p] = (__bf16)val;
@@ -1602,22 +1664,22 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     // (BF16: P = bf16 blend shapes [tile][S][component][g][vertex][8 k], ldP = NVp; one dwordx4 per lane, component and MFMA:
     //  1 KB of consecutive memory per instruction)
     const __amdgpu_buffer_rsrc_t Prs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(P), 0, SP3 ? (int)(28 * ldP * 144) : BF16 ? (int)(28 * ldP * 48) : (int)(224 * ldP * 4), 0x00020000);
+        const_cast<float*>(P), 0, SP3 ? (int)(28 * ldP * 48 * NP) : BF16 ? (int)(28 * ldP * 48) : (int)(224 * ldP * 4), 0x00020000);
     const int loff = B16 ? lane * 16 : (g * (int)ldP + l15 * 3) * 4;                    // lane part of the address (bytes)
-    const int kstride = SP3 ? 9 * 1024 : BF16 ? 3 * 1024 : 4 * (int)ldP * 4;            // bytes between consecutive k-steps
-    constexpr int TILE_B = SP3 ? 7 * 9 * 1024 : BF16 ? 7 * 3 * 1024 : 192;              // bytes between consecutive vertex tiles
+    const int kstride = SP3 ? 3 * NP * 1024 : BF16 ? 3 * 1024 : 4 * (int)ldP * 4;            // bytes between consecutive k-steps
+    constexpr int TILE_B = SP3 ? 7 * 3 * NP * 1024 : BF16 ? 7 * 3 * 1024 : 192;              // bytes between consecutive vertex tiles
     // (SP3: P = [tile][S][component][piece][g][vertex][8 k] bf16, 1 KB per (S, component, piece))
     u32x3 pa[8];                                                 // fp32: eight k-steps (of 4) in flight
     constexpr int PQD = MODE == 3 ? MESH_PQD : 2;                      // bf16: PQD k-steps (of 32) x 3 components in flight
     u32x4m pq[PQD][3];
     u32x4m ps[3][3];                                             // SP3: ONE k-step, [component][piece 1, 2], refilled piece by piece
     u32x4m ps0[2][3];                                            // SP3: piece 0 (half of a k-step's products), double-buffered [k-step & 1][component]
-    auto sp3_request = [&](const int soff, const int buf0) {     // all nine pieces of one k-step (scalar byte offset soff)
+    auto sp3_request = [&](const int soff, const int buf0) {     // all 3 NP pieces of one k-step (scalar byte offset soff)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            ps0[buf0][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, soff + (3 * c) * 1024, 0);
-            ps[c][1] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, soff + (3 * c + 1) * 1024, 0);
-            ps[c][2] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, soff + (3 * c + 2) * 1024, 0);
+            ps0[buf0][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, soff + (NP * c) * 1024, 0);
+#pragma unroll
+            for (int pc = 1; pc < NP; ++pc) ps[c][pc] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, soff + (NP * c + pc) * 1024, 0);
         }
     };
     {
@@ -1642,7 +1704,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         // weights as A-operands: forward (rows = vertices, k = joints) and adjoint (rows = joints, k = vertices)
         float wf[6], wa[4][2];
         mbf16x8 wsk[2], wad[2][2];                               // split precision: [piece], [joint tile][piece]
-        mbf16x8 wad3[2][3];                                      // ADJ3: [joint tile][A image]
+        u32x4m wad3[2][NP];                                      // ADJ3: [joint tile][A image]
         float4 sw[4];                                            // sparse: this lane's 4 vertices x <= 4 (weight, joint)
         unsigned int sj[4];
         if constexpr (SPARSE) {
@@ -1661,8 +1723,8 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    wad3[jt][q] = *reinterpret_cast<const mbf16x8*>(Wadj + (((t * 2 + jt) * 3 + q) * 64 + lane) * 8);
+                for (int q = 0; q < NP; ++q)
+                    wad3[jt][q] = *reinterpret_cast<const u32x4m*>(Wadj + (((t * 2 + jt) * NP + q) * 64 + lane) * 8);
         } else if constexpr (ADJS) {
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt)
@@ -1695,52 +1757,61 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         const int pt = (int)t * TILE_B;                          // uniform byte offsets: this wave's vertex tile
         const int ptn = (int)min(t + 4, ntiles - 1) * TILE_B;    // and its next one (clamped: harmless re-read)
         if constexpr (SP3) {
-            // 7 k-steps of 32 x 6 piece products x 3 components x 2 bodies = 252 MFMAs.  Product order per k-step: the three
-            // with P's piece 0, the one with piece 2, the two with piece 1 (why: at the loop).
+            // 7 k-steps of 32 x NP (NP + 1) / 2 piece products x 3 components x 2 bodies = 252 (three bf16 pieces) / 126 (two fp16
+            // pieces) MFMAs.  Product order per k-step: those with P's piece 0, then its LAST piece, ..., piece 1 (why: at the loop).
             // Six accumulators in rotation: no MFMA waits for its predecessor.
             // (B operands -- the pose-feature pieces, LDS -- one k-step ahead: requested behind the first product group of the
             //  previous k-step)
-            mbf16x8 b[2][2][3];                                  // [buffer][body][piece]
+            if constexpr (SPH) {                                 // (the accumulators carry scale(P) scale(pf) x the sums)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { vp[0][c] *= blend_scale; vp[1][c] *= blend_scale; }
+            }
+            u32x4m b[2][2][NP];                                  // [buffer][body][piece]
             auto load_b = [&](const int buf, const int S) {
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
+                for (int pc = 0; pc < NP; ++pc)
 #pragma unroll
                     for (int bd = 0; bd < 2; ++bd)
-                        b[buf][bd][pc] = *reinterpret_cast<const mbf16x8*>(pfB + ((pc * 2 + bd) * 16 + l15) * MF_PFB + 8 * g + 32 * S);
+                        b[buf][bd][pc] = *reinterpret_cast<const u32x4m*>(pfB + ((pc * 2 + bd) * 16 + l15) * MF_PFB + 8 * g + 32 * S);
             };
             load_b(0, 0);
 #pragma unroll
             for (int S = 0; S < 7; ++S) {
-                // piece 0 carries half of a k-step's products: re-requested behind them it would have 18 MFMAs (288 cycles) until
-                // its next use, less than an L2 round trip -- so it has two buffers and is requested a whole k-step ahead; pieces
-                // 2 and 1 (in this order) are re-requested behind their products, 30 and 24 MFMAs ahead
+                // piece 0 carries half (two thirds) of a k-step's products: re-requested behind them it would have 18 (6) MFMAs until
+                // its next use, less than an L2 round trip -- so it has two buffers and is requested a whole k-step ahead; the other
+                // pieces are re-requested behind their products (three pieces: 2 then 1, 30 and 24 MFMAs ahead; two: 12 ahead)
                 if (S + 1 < 7) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        ps0[(S + 1) & 1][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, pt + (S + 1) * kstride + (3 * c) * 1024, 0);
+                        ps0[(S + 1) & 1][c] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, pt + (S + 1) * kstride + (NP * c) * 1024, 0);
                 }
 #pragma unroll
-                for (int gi = 0; gi < 3; ++gi) {
-                    const int pa = gi == 0 ? 0 : (gi == 1 ? 2 : 1);
+                for (int gi = 0; gi < NP; ++gi) {
+                    const int pa = gi == 0 ? 0 : NP - gi;
 #pragma unroll
-                    for (int pb = 2 - pa; pb >= 0; --pb)
+                    for (int pb = NP - 1 - pa; pb >= 0; --pb)
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            const mbf16x8 a = __builtin_bit_cast(mbf16x8, pa == 0 ? ps0[S & 1][c] : ps[c][pa]);
-                            vp[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[S & 1][0][pb], vp[0][c], 0, 0, 0);
-                            vp[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[S & 1][1][pb], vp[1][c], 0, 0, 0);
+                            const u32x4m a = pa == 0 ? ps0[S & 1][c] : ps[c][pa];
+                            vp[0][c] = mfma_p(a, b[S & 1][0][pb], vp[0][c]);
+                            vp[1][c] = mfma_p(a, b[S & 1][1][pb], vp[1][c]);
                         }
                     if (S + 1 < 7) {
                         if (pa != 0) {
 #pragma unroll
                             for (int c = 0; c < 3; ++c)
-                                ps[c][pa] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, pt + (S + 1) * kstride + (3 * c + pa) * 1024, 0);
+                                ps[c][pa] = __builtin_amdgcn_raw_buffer_load_b128(Prs, loff, pt + (S + 1) * kstride + (NP * c + pa) * 1024, 0);
                         } else {
                             load_b((S + 1) & 1, S + 1);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            if constexpr (SPH) {
+                const float inv = 1.f / blend_scale;             // (a power of two: exact)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { vp[0][c] *= inv; vp[1][c] *= inv; }
             }
         } else if constexpr (BF16) {
             // 7 k-steps of 32 (207 blend shapes + zero rows) x 3 components x 2 bodies = 42 MFMAs
@@ -1840,17 +1911,17 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         /*prof:c2*/
         if constexpr (SPARSE && ADJS) load_adjoint_weights();
         unsigned int smz[3][2], zmz[3][2];                       // ADJ3: sign / zero masks of the three rows, [row][vertex pair]
-        unsigned int vpp[3][3][2];                               // ADJ3: [piece][coordinate d][vertex pair] of vp_orig, packed bf16
+        unsigned int vpp[NP][3][2];                              // ADJ3: [piece][coordinate d][vertex pair] of vp_orig, packed 16-bit pieces
         auto adj3_prefetch = [&]() { sp3_request(ptn, 0); };     // the wave's NEXT tile: its first k-step
         auto adj3_pieces = [&]() {
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                float x[4] = {vp[0][d][0], vp[0][d][1], vp[0][d][2], vp[0][d][3]};
+                float x[4] = {vp[0][d][0] * PF_SCALE, vp[0][d][1] * PF_SCALE, vp[0][d][2] * PF_SCALE, vp[0][d][3] * PF_SCALE};
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
+                for (int pc = 0; pc < NP; ++pc)
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
-                        const __bf16 h0 = (__bf16)x[2 * pr], h1 = (__bf16)x[2 * pr + 1];
+                        const e16 h0 = (e16)x[2 * pr], h1 = (e16)x[2 * pr + 1];
                         vpp[pc][d][pr] = (unsigned int)__builtin_bit_cast(unsigned short, h0) |
                                          ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
                         x[2 * pr] -= (float)h0; x[2 * pr + 1] -= (float)h1;
@@ -1860,30 +1931,32 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         auto adj3_row = [&](const int c) {
 #pragma unroll
             for (int dh = 0; dh < 2; ++dh) {                     // two entries (c, d) at a time: four accumulators in rotation
-                mbf16x8 b1[2], b2[2];                            // [T0 ; T1] and [T2 ; T0]
+                u32x4m b1[2], b2[2];                             // [T0 ; T1] and (three pieces) [T2 ; T0]
 #pragma unroll
                 for (int dd = 0; dd < 2; ++dd) {
                     const int d = 2 * dh + dd;
-                    unsigned int tk[3][2];
+                    unsigned int tk[NP][2];
 #pragma unroll
                     for (int pr = 0; pr < 2; ++pr) {
-                        // (d = 3: dT = gs itself, +-1.0 = 0x3f80 with the sign flipped, no lower pieces; vp pieces carry
-                        //  vp's sign: flipped when gs = -1)
+                        // (d = 3: dT = gs itself, +-1.0 -- bf16 0x3f80 / fp16 PF_SCALE = 4096.0 = 0x6c00 -- with the sign flipped, no lower
+                        //  pieces; vp pieces carry vp's sign: flipped when gs = -1)
                         const unsigned int sm = smz[c][pr], zm = zmz[c][pr];
-                        tk[0][pr] = d < 3 ? ((vpp[0][d][pr] ^ sm) & zm) : ((0x3f803f80u ^ sm) & zm);
-                        tk[1][pr] = d < 3 ? ((vpp[1][d][pr] ^ sm) & zm) : 0u;
-                        tk[2][pr] = d < 3 ? ((vpp[2][d][pr] ^ sm) & zm) : 0u;
-                    }
-                    const u32x4m q1 = {tk[0][0], tk[0][1], tk[1][0], tk[1][1]}, q2 = {tk[2][0], tk[2][1], tk[0][0], tk[0][1]};
-                    b1[dd] = __builtin_bit_cast(mbf16x8, q1); b2[dd] = __builtin_bit_cast(mbf16x8, q2);
-                }
+                        tk[0][pr] = d < 3 ? ((vpp[0][d][pr] ^ sm) & zm) : (((SPH ? 0x6c006c00u : 0x3f803f80u) ^ sm) & zm);
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                        for (int pc = 1; pc < NP; ++pc) tk[pc][pr] = d < 3 ? ((vpp[pc][d][pr] ^ sm) & zm) : 0u;
+                    }
+                    b1[dd] = u32x4m{tk[0][0], tk[0][1], tk[1][0], tk[1][1]};
+                    b2[dd] = u32x4m{tk[NP - 1][0], tk[NP - 1][1], tk[0][0], tk[0][1]};
+                }
+                // A images (nemo_ctx_create): three pieces [W0 | W0], [W1 | W1], [W0 | W2] against [T0 ; T1], [T0 ; T1], [T2 ; T0];
+                // two pieces [W0 | W0], [W1 | 0] against [T0 ; T1] twice
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
 #pragma unroll
                     for (int dd = 0; dd < 2; ++dd) {
                         const int e = 4 * c + 2 * dh + dd;
-                        accdA[e][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wad3[0][q], q < 2 ? b1[dd] : b2[dd], accdA[e][0], 0, 0, 0);
-                        accdA[e][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wad3[1][q], q < 2 ? b1[dd] : b2[dd], accdA[e][1], 0, 0, 0);
+                        accdA[e][0] = mfma_p(wad3[0][q], q < 2 ? b1[dd] : b2[dd], accdA[e][0]);
+                        accdA[e][1] = mfma_p(wad3[1][q], q < 2 ? b1[dd] : b2[dd], accdA[e][1]);
                     }
             }
         };
@@ -2039,6 +2112,14 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
         /*prof:c3*/
+    }
+    if constexpr (SPH && ADJ3) {
+        // (the adjoint accumulated scale(W) scale(dT) x the sums: W images x 2^14, dT pieces x 2^12 -- back, exactly)
+        constexpr float inv = 1.f / (16384.f * 4096.f);
+#pragma unroll
+        for (int e = 0; e < 12; ++e)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) accdA[e][t] *= inv;
     }
 
     // ---- cross-wave reduction of dA through LDS (the staged sample data is dead now)
@@ -2541,14 +2622,19 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
     // profiles/r05_pmc_mesh_b16.md).  NEMO_MESH_SPLIT=3: MODE 3 (fp32 skinning: sparse on the VALU or dense on the fp32 pipe), an
     // A/B aid.  MODE 1 (bf16 blend only) was measured in round 3 and is no longer instantiated.
     static const int split_env = getenv("NEMO_MESH_SPLIT") ? atoi(getenv("NEMO_MESH_SPLIT")) : 2;
-    const int mode = bf16 ? (split_env == 3 ? 3 : 2) : kind == 2 ? 4 : 0;
+    // kind 2 (fp32-equivalent split precision): two fp16 pieces per operand (MODE 5); NEMO_MESH_PIECES=3: three bf16 pieces (MODE 4, the
+    // first form of the round: 360 against ... us per 8 x 300 launch), an A/B aid
+    static const int pieces_env = getenv("NEMO_MESH_PIECES") ? atoi(getenv("NEMO_MESH_PIECES")) : 2;
+    const int mode = bf16 ? (split_env == 3 ? 3 : 2) : kind == 2 ? (pieces_env == 3 ? 4 : 5) : 0;
     const bool sparse = ctx->skin_sparse != 0 && mode != 2;
     const int lds_bytes = mode == 2 ? (2 * 16 * MF_PFB / 2 + 2 * 2 * 16 * MF_AB / 2 + MF_TAIL) * (int)sizeof(float)
-        : ((mode == 4 ? 3 * 2 * 16 * MF_PFB / 2 : bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) + 2 * 16 * (sparse ? MF_ASP : MF_AS) + MF_TAIL) *
+        : ((mode == 4 ? 3 * 2 * 16 * MF_PFB / 2 : mode == 5 ? 2 * 2 * 16 * MF_PFB / 2 : bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) +
+           2 * 16 * (sparse ? MF_ASP : MF_AS) + MF_TAIL) *
               (int)sizeof(float);
-    static bool attr_set[5][2] = {{false, false}, {false, false}, {false, false}, {false, false}, {false, false}};
+    static bool attr_set[6][2] = {{false, false}, {false, false}, {false, false}, {false, false}, {false, false}, {false, false}};
     if (!attr_set[mode][sparse]) {
-        const void* fn = mode == 4 ? (sparse ? (const void*)mesh_v2v_fused_kernel<4, true> : (const void*)mesh_v2v_fused_kernel<4, false>)
+        const void* fn = mode == 5 ? (sparse ? (const void*)mesh_v2v_fused_kernel<5, true> : (const void*)mesh_v2v_fused_kernel<5, false>)
+                       : mode == 4 ? (sparse ? (const void*)mesh_v2v_fused_kernel<4, true> : (const void*)mesh_v2v_fused_kernel<4, false>)
                        : mode == 2 ? (const void*)mesh_v2v_fused_kernel<2, false>
                        : mode == 3 ? (sparse ? (const void*)mesh_v2v_fused_kernel<3, true> : (const void*)mesh_v2v_fused_kernel<3, false>)
                                    : (sparse ? (const void*)mesh_v2v_fused_kernel<0, true> : (const void*)mesh_v2v_fused_kernel<0, false>);
@@ -2569,12 +2655,14 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
     float* loss_parts = reinterpret_cast<float*>(wsb + 16);
     int* tickets = reinterpret_cast<int*>(wsb + 16 + MESH_MAX_BLOCKS * 4);
     float* parts = reinterpret_cast<float*>(wsb + MESH_HEADER_BYTES);
-    const unsigned short* WADJ = mode == 4 ? ctx->d_Wadj3 : ctx->d_Wadj;
+    const unsigned short* WADJ = mode == 5 ? ctx->d_Wadjh : mode == 4 ? ctx->d_Wadj3 : ctx->d_Wadj;
 #define MESH_LAUNCH(M, SP, PP, LDP) hipLaunchKernelGGL((mesh_v2v_fused_kernel<M, SP>), dim3((unsigned)blocks), dim3(256), lds_bytes, \
         (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, PP, LDP, ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA,  \
         pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets, loss_parts, grid_ticket, dVPb, (long)ldk,    \
-        ctx->d_Wsk, WADJ, ctx->d_Wsp_w, ctx->d_Wsp_j)
-    if (mode == 4 && sparse) MESH_LAUNCH(4, true, reinterpret_cast<const float*>(ctx->d_posedirs_sp3), ctx->NVp);
+        ctx->d_Wsk, WADJ, ctx->d_Wsp_w, ctx->d_Wsp_j, ctx->sph_scale)
+    if (mode == 5 && sparse) MESH_LAUNCH(5, true, reinterpret_cast<const float*>(ctx->d_posedirs_sph), ctx->NVp);
+    else if (mode == 5) MESH_LAUNCH(5, false, reinterpret_cast<const float*>(ctx->d_posedirs_sph), ctx->NVp);
+    else if (mode == 4 && sparse) MESH_LAUNCH(4, true, reinterpret_cast<const float*>(ctx->d_posedirs_sp3), ctx->NVp);
     else if (mode == 4) MESH_LAUNCH(4, false, reinterpret_cast<const float*>(ctx->d_posedirs_sp3), ctx->NVp);
     else if (mode == 2) MESH_LAUNCH(2, false, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
     else if (mode == 3 && sparse) MESH_LAUNCH(3, true, reinterpret_cast<const float*>(ctx->d_posedirs_bf16), ctx->NVp);
@@ -2609,7 +2697,7 @@ extern "C" int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* P
 
 // fp32 in, fp32 out, fp32-equivalent arithmetic: the pose blend's products on the bf16 pipe with both operands in three bf16
 // pieces (kernel MODE 4); same arguments and outputs as nemo_v2v_fused
-extern "C" int32_t nemo_v2v_fused_split3(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
+extern "C" int32_t nemo_v2v_fused_split(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf,
                                          const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
                                          void* ws, int64_t ws_bytes, void* stream) {
     return v2v_fused_impl(ctx, 2, N, PF2, ldpf, A2, loss_sum, dVPt, ldn, dA, ws, ws_bytes, stream);

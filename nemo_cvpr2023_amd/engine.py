@@ -268,17 +268,18 @@ class FitEngine:
             raise ValueError(f"args.gemm_dtype must be 'f32' or 'bf16', got {dt!r}")
         self.bf16 = dt == 'bf16'
         # mesh_blend (round 5), fp32 builds only -- gemm_dtype='bf16' blends in plain bf16 whatever it says:
-        #   'f32_split' (default): the fused mesh term's pose blend (76 % of that kernel's matrix-pipe cycles) on the bf16 matrix
-        #       cores in fp32-EQUIVALENT arithmetic -- three bf16 pieces per operand, six exact piece products per fp32 product,
-        #       fp32 accumulation (nemo_v2v_fused_split3).  Its error against a float64 evaluation equals the fp32-MFMA kernel's
-        #       (tests/test_gpu_ops.py::test_v2v_fused_split3_is_fp32_equivalent: dA 1.57e-7 against 1.58e-7 rms), every 1e-4
-        #       parity gate passes unchanged, and the launch is 24 % shorter (392 against 519 us at 8 x 300).
+        #   'f32_split' (default): the fused mesh term's pose blend (76 % of that kernel's matrix-pipe cycles) and vertex->joint adjoint
+        #       on the 16-bit matrix cores in fp32-EQUIVALENT arithmetic -- two fp16 pieces per operand (11 + 11 bits + the remainder's
+        #       sign: the fp32 value to one ulp), three exact piece products per fp32 product, fp32 accumulation (nemo_v2v_fused_split).
+        #       Its error against a float64 evaluation equals the fp32-MFMA kernel's
+        #       (tests/test_gpu_ops.py::test_v2v_fused_split_is_fp32_equivalent: dA 1.567e-7 against 1.578e-7 rms), every 1e-4
+        #       parity gate passes unchanged, and the launch is 39 % shorter (316 against 519 us at 8 x 300).
         #   'f32': the products on the fp32 MFMA pipe (rounds 1 - 4; bench.py's `f32_mfma_blend` leg).
         # args.mesh_blend, overridden by NEMO_MESH_BLEND.
         mb = os.environ.get('NEMO_MESH_BLEND') or getattr(args, 'mesh_blend', None) or 'f32_split'
         if mb not in ('f32', 'f32_split'):
             raise ValueError(f"args.mesh_blend must be 'f32' or 'f32_split', got {mb!r}")
-        self.mesh_split3 = mb == 'f32_split' and not self.bf16
+        self.mesh_split = mb == 'f32_split' and not self.bf16
         # bf16 operands IN MEMORY (round 3): every dense product of the MotionNet / VPoser chain reads bf16 copies of its
         # operands (written by the producing GEMM's epilogue, plain and transposed, or by nemo_cast_bf16) through
         # nemo_gemm_bf16mem -- the same values enter the matrix cores as with the on-the-fly rounding of nemo_gemm_bf16
@@ -505,11 +506,12 @@ class FitEngine:
             valu = flops * (2 * 12 * 4) / self.mesh_macs()
         if not self.bf16:
             out = {'f32': flops - valu}
-            if tag == 'mesh_v2v_fused' and self.mesh_split3:
-                # (csrc/smpl.hip MODE 4: the two pose blends and the vertex->joint adjoint run on the bf16 pipe as SIX bf16 piece
-                #  products per algorithmic product -- pipe 'bf16x6', whose peak is a sixth of the bf16 MFMA peak)
+            if tag == 'mesh_v2v_fused' and self.mesh_split:
+                # (csrc/smpl.hip MODE 5: the two pose blends and the vertex->joint adjoint run on the 16-bit matrix pipe as THREE fp16
+                #  piece products per algorithmic product -- pipe 'f16x3', whose peak is a third of the fp16 / bf16 MFMA peak;
+                #  NEMO_MESH_PIECES=3 (MODE 4): six bf16 piece products, 'bf16x6')
                 b16 = flops * (2 * 3 * 207 + 288) / self.mesh_macs()
-                out = {'bf16x6': b16, 'f32': flops - b16 - valu}
+                out = {('bf16x6' if os.environ.get('NEMO_MESH_PIECES') == '3' else 'f16x3'): b16, 'f32': flops - b16 - valu}
             if valu:
                 out['valu_f32'] = valu
             return out
@@ -538,7 +540,7 @@ class FitEngine:
 
     def mesh_kernel_variant(self):
         """The mesh kernel instantiation this engine launches (what counter files under profiles/ are keyed by)."""
-        mode = (3 if os.environ.get('NEMO_MESH_SPLIT', '2') == '3' else 2) if self.bf16 else (4 if self.mesh_split3 else 0)
+        mode = (3 if os.environ.get('NEMO_MESH_SPLIT', '2') == '3' else 2) if self.bf16 else ((4 if os.environ.get('NEMO_MESH_PIECES') == '3' else 5) if self.mesh_split else 0)
         return f"mesh_v2v_fused_kernel<{mode}, {'true' if self.ctx.skin_sparse_flag and mode != 2 else 'false'}>"
 
     # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
@@ -1034,7 +1036,7 @@ class FitEngine:
                                     dptr(w['PF2']), 208, st), 'nemo_fk_fwd')
             ev = self._event_begin('mesh_v2v_fused', 2.0 * n * self.NV * self.mesh_macs())
             ws = w['mesh_ws']
-            fused = L.nemo_v2v_fused_bf16 if self.bf16 else (L.nemo_v2v_fused_split3 if self.mesh_split3 else L.nemo_v2v_fused)
+            fused = L.nemo_v2v_fused_bf16 if self.bf16 else (L.nemo_v2v_fused_split if self.mesh_split else L.nemo_v2v_fused)
             # single-chunk batches: the per-group sum of the blocks' partial dA images runs as a launch of its own on the
             # second side stream, beside the blend-shape adjoint GEMM (only the FK adjoint behind that GEMM needs dA)
             # (large batches only: at a one-instance shard the extra fork / join of the replayed graph costs more than the

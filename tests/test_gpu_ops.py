@@ -615,7 +615,7 @@ def test_vertices_and_v2v(L, num_verts):
                                               (6890, 40, '3,9,3'), (6890, 40, '1,36,2'), (100, 37, '1,1,2'),
                                               (128, 50, '1,1,3'), (6890, 20, '5,0,0')])
 @pytest.mark.parametrize('skin_nnz', [24, 4, 3])
-@pytest.mark.parametrize('entry', ['nemo_v2v_fused', 'nemo_v2v_fused_split3'])
+@pytest.mark.parametrize('entry', ['nemo_v2v_fused', 'nemo_v2v_fused_split'])
 def test_v2v_fused_mesh_kernel(L, num_verts, N, plan, skin_nnz, entry, monkeypatch):
     """Fused pose blend + skinning + L1 + gradient (MFMA accumulator layout end to end) against the
     oracle's unfused lbs + autograd; ragged vertex tiles (100, 6890 = 430*16+10) and sample groups.
@@ -1047,8 +1047,8 @@ def _mesh_term_f64(assets, PF, A, N):
 
 
 @pytest.mark.parametrize('skin_nnz', [4, 24])
-def test_v2v_fused_split3_is_fp32_equivalent(L, skin_nnz):
-    """nemo_v2v_fused_split3 (pose blend on the bf16 pipe, three bf16 pieces per operand) against a float64 evaluation of
+def test_v2v_fused_split_is_fp32_equivalent(L, skin_nnz):
+    """nemo_v2v_fused_split (pose blend on the bf16 pipe, three bf16 pieces per operand) against a float64 evaluation of
     the same fp32 inputs: its error must not exceed 1.5 x the fp32-MFMA kernel's (criterion (a)) -- it
     is not narrower arithmetic than the reference's.  Blend shapes scaled x 100 so that the pose offsets are as large as
     the template (with the synthetic model's 1e-3 offsets a blend of ANY precision would hide behind the template's
@@ -1073,7 +1073,7 @@ def test_v2v_fused_split3_is_fp32_equivalent(L, skin_nnz):
     ldn = (N + 15) // 16 * 16
     ws = torch.zeros(int(L.nemo_v2v_fused_ws_bytes(ctx.handle, N)) // 4 + 1, device='cuda')
     err = {}
-    for name, fn in (('f32', L.nemo_v2v_fused), ('split3', L.nemo_v2v_fused_split3)):
+    for name, fn in (('f32', L.nemo_v2v_fused), ('split', L.nemo_v2v_fused_split)):
         loss, dVPt, dA = Z(1), Z(3 * ctx.NVp, ldn), Z(N, 24, 12)
         assert fn(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss.data_ptr(), dVPt.data_ptr(), ldn, dA.data_ptr(),
                   ws.data_ptr(), ws.numel() * 4, H.st()) == 0
@@ -1085,7 +1085,7 @@ def test_v2v_fused_split3_is_fp32_equivalent(L, skin_nnz):
                          dA_rms=float(e_dA.pow(2).mean().sqrt() / dA_ref.pow(2).mean().sqrt()),
                          dvp_max=float((dvp - dvp_ref)[clean].abs().max() / dvp_ref.abs().max()))
     print('mesh term error against float64:', err)
-    f, s3 = err['f32'], err['split3']
+    f, s3 = err['f32'], err['split']
     assert s3['dA_rms'] <= 1.5 * f['dA_rms'] + 1e-9, err
     assert s3['dA_max'] <= 1.5 * f['dA_max'] + 1e-9, err
     assert s3['dvp_max'] <= 1.5 * f['dvp_max'] + 1e-9, err
