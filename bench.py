@@ -522,6 +522,8 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
     on_bf16 = (mesh_b16 + parts['blend_adjoint'] + parts['mlp'] + parts['vposer']) if dtype == 'bf16' else 0.0
     _mp = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh'])
     on_b16x6, on_f16x3 = _mp.get('bf16x6', 0.0), _mp.get('f16x3', 0.0)
+    if dtype != 'bf16' and getattr(engine, 'split_adj', False):
+        on_f16x3 += parts['blend_adjoint']              # (the blend-shape adjoint in split precision too)
     step_peak = f_step / (on_bf16 / MFMA_PEAK_TFLOPS['bf16'] + on_b16x6 / MFMA_PEAK_TFLOPS['bf16x6'] + on_f16x3 / MFMA_PEAK_TFLOPS['f16x3'] +
                           (f_step - on_bf16 - on_b16x6 - on_f16x3) / MFMA_PEAK_TFLOPS['f32'])
     roof = {'kernel': tag, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(kpeak, 1),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 15
+#define NEMO_ABI_VERSION 16
 int32_t nemo_abi_version(void);
 
 /* Deterministic accumulation (round 5).  Every sum over the blocks of a launch that used float atomics until round 4 -- the
@@ -379,6 +379,17 @@ int32_t nemo_v2v_fused(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t
 int32_t nemo_v2v_fused_split(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
                               float* loss_sum, float* dVPt, int64_t ldn, float* dA, void* ws, int64_t ws_bytes,
                               void* stream);
+/* nemo_v2v_fused_split with d vp handed over as TWO fp16 piece planes of 2^12 d vp, NOT transposed (row = sample, 16 * ceil(N / 16)
+ * rows of ldk >= the blend-shape row stride elements, plane 1 `plane` elements behind plane 0) -- the A operand of
+ * nemo_gemm_f16x2mem_adj, which multiplies them with the two piece planes of s P in fp32-equivalent split precision
+ * (A0 B0^T + A0 B1^T + A1 B0^T on v_mfma_*_f16, the 64 x 208 tile of the blend-shape adjoint, lbs.py:229-233 backward):
+ * C (M x N) (op)= alpha * (...), 128 < N <= 208, K even, lda / ldb / plane strides multiples of 8 elements; alpha carries 1 / (the
+ * pieces' scales); ws as nemo_gemm_f32 (round 5, ABI 16; the engine uses the pair from 256 samples on). */
+int32_t nemo_v2v_fused_splitmem(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2, float* loss_sum,
+                                uint16_t* dVPh, int64_t ldk, int64_t plane, float* dA, void* ws, int64_t ws_bytes, void* stream);
+int32_t nemo_gemm_f16x2mem_adj(int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, int64_t a_plane, const uint16_t* B,
+                               int64_t ldb, int64_t b_plane, float* C, int64_t ldc, float alpha, int32_t out_mode, void* ws,
+                               int64_t ws_bytes, void* stream);
 /* The same with the pose blend (lbs.py:229-233, K = 207) on the bf16 matrix cores: blend shapes rounded to bf16 once
  * at nemo_ctx_create, pose features rounded when staged, fp32 accumulate; skinning, L1 and d vp in fp32; the vertex->joint adjoint dA on the
  * bf16 cores in split precision (two bf16 pieces per fp32 operand, 16 significant bits), and since round 5 the two skinning

@@ -32,7 +32,7 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 15        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 16        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -99,6 +99,8 @@ SIGNATURES = {
     'nemo_v2v_fused_ws_bytes': (i64, [ptr, i64]),
     'nemo_v2v_fused': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_fused_split': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
+    'nemo_v2v_fused_splitmem': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, ptr, i64, ptr]),
+    'nemo_gemm_f16x2mem_adj': (i32, [i64, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, f32, i32, ptr, i64, ptr]),
     'nemo_v2v_fused_bf16': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_combine': (i32, [ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_fused_bf16mem': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),

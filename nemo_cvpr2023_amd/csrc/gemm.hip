@@ -935,6 +935,57 @@ extern "C" int32_t nemo_gemm_f32_b16out(int32_t transA, int32_t transB, int64_t 
                      stream, Cb, ldcb, CbT, ldcbt);
 }
 
+// The blend-shape adjoint in fp32-EQUIVALENT split precision (round 5): C (M x N) (op)= alpha (A0 B0^T + A0 B1^T + A1 B0^T), A (M x K)
+// and B (N x K) each as TWO fp16 piece planes in memory (plane p of A at A + p a_plane elements; rows k-contiguous, lda / ldb / the
+// plane strides multiples of 8 elements, K even), 128 < N <= 208 -- the 64 x 208 mixed-shape tile of gemm_adj.h with its K slices dealt
+// over the three plane pairs.  alpha carries the pieces' scales (1 / (s_A s_B)).
+extern "C" int32_t nemo_gemm_f16x2mem_adj(int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, int64_t a_plane,
+                                          const uint16_t* B, int64_t ldb, int64_t b_plane, float* C, int64_t ldc, float alpha,
+                                          int32_t out_mode, void* ws, int64_t ws_bytes, void* stream) {
+    if (M < 0 || N <= 128 || N > 208 || K < 2 || (K & 1) || !A || !B || !C || (lda & 7) || (ldb & 7) || (a_plane & 7) || (b_plane & 7) ||
+        lda < K || ldb < K || ldc < N || out_mode < 0 || out_mode > 1 || (((uintptr_t)A | (uintptr_t)B) & 15))
+        return NEMO_EINVAL;
+    if (M == 0) return NEMO_OK;
+    const bool can_split = ws != nullptr && ws_bytes > COUNTER_BYTES && (((uintptr_t)ws) & 15) == 0;
+    if (!can_split) return NEMO_EINVAL;
+    const long K2 = K / 2, lda2 = lda / 2, ldb2 = ldb / 2;          // the fp32-typed view of the same bytes (pairs)
+    unsigned a_bytes = 0, b_bytes = 0;
+    if (!glds::extents(0, 1, M, N, K2, lda2, ldb2, &a_bytes, &b_bytes)) return NEMO_EINVAL;
+    const long tiles_m = (M + 63) / 64;
+    // slices per plane pair: ~one workgroup per CU (up to 8 row tiles) or two; every slice keeps >= 8 K tiles
+    int spp = (int)((tiles_m <= 8 ? 256 : 512) / (3 * tiles_m));
+    if (spp < 1) spp = 1;
+    auto fits = [&](int sp) {
+        return glds::adj_counter_ints(tiles_m, 3 * sp) <= COUNTER_BYTES / 4 &&
+               COUNTER_BYTES + glds::adj_slab_floats(tiles_m, 3 * sp) * 4 <= ws_bytes;
+    };
+    while (spp > 1 && ((K2 + 31) / 32 / spp < 8 || !fits(spp))) --spp;
+    if (!fits(spp)) return NEMO_EINVAL;
+    GemmArgs g;
+    g.A = reinterpret_cast<const float*>(A); g.B = reinterpret_cast<const float*>(B); g.C = C; g.bias = nullptr; g.mask = nullptr;
+    g.M = M; g.N = N; g.K = K2; g.lda = lda2; g.ldb = ldb2; g.ldc = ldc; g.ldmask = 0;
+    g.act = 0; g.mask_mode = 0; g.out_mode = out_mode; g.alpha = alpha;
+    g.counters = reinterpret_cast<int*>(ws);
+    g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
+    long kc = (K2 + spp - 1) / spp;
+    kc = ((kc + 31) / 32) * 32;
+    g.k_chunk = kc;
+    spp = (int)((K2 + kc - 1) / kc);
+    g.split = 3 * spp;
+    g.nseg = 3;
+    g.seg_a[0] = 0; g.seg_a[1] = 0; g.seg_a[2] = a_plane / 2;      // (A0, B0), (A0, B1), (A1, B0)
+    g.seg_b[0] = 0; g.seg_b[1] = b_plane / 2; g.seg_b[2] = 0;
+    g.tiles_m = (int)tiles_m; g.tiles_n = 1; g.n_tiles = (int)tiles_m; g.t0 = 0;
+    g.a_bytes = a_bytes; g.b_bytes = b_bytes; g.xcd_order = 0;
+    static const bool debug_h = getenv("NEMO_GEMM_DEBUG") != nullptr;
+    if (debug_h)
+        fprintf(stderr, "nemo_gemm_f16x2mem_adj M=%ld N=%ld K=%ld -> 64x208 mixed-shape tile, 3 plane pairs x %d K slices\n", (long)M, (long)N, (long)K, spp);
+    const hipError_t e = glds::launch_adj(g, (hipStream_t)stream, 2);
+    if (e != hipSuccess) return (int32_t)e;
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
 // rows of the `colsum` scratch nemo_gemm_bf16mem fills for an M-row result: one per 32-row band of its 64 x 64 tiles
 extern "C" int64_t nemo_gemm_colsum_rows(int64_t M) { return M < 0 ? -1 : 2 * ((M + 63) / 64); }
 

@@ -34,15 +34,21 @@ constexpr int ADJ_LDS_BYTES = (ADJ_NA * ADJ_A_FLOATS + ADJ_NB * ADJ_B_FLOATS) * 
 // 16-column remainder on v_mfma_f32_16x16x32_bf16 (2 per wave and K tile).  The 64 x 64 plan read the 339 MB of d vp four
 // times (once per column tile: 1.36 GB per 8192-sample launch at 5.4 TB/s -- bandwidth-bound) and spent 24 % of its MFMAs on
 // padding.
-template <bool B16>
+// B16 = 2 (round 5, last third): the operands are fp16 PIECES in memory (two planes each: x0 = fp16(s x), x1 = fp16(s x - x0)) and the
+// product is the fp32-equivalent sum A0 B0^T + A0 B1^T + A1 B0^T: the K slices of a row tile are dealt over the three
+// (plane of A, plane of B) pairs (Args::nseg / seg_a / seg_b) and summed by the same ordered slab combine; v_mfma_f32_32x32x16_f16 /
+// 16x16x32_f16 on the same images.  nemo_blend_adjoint_split.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int B16>
 __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
-    using OA = Operand<ADJ_BM, B16>;
+    using OA = Operand<ADJ_BM, B16 != 0>;
     using OB = Operand<ADJ_BN, true>;
     constexpr int GA = OA::PER_WAVE, GB = OB::NI / 4 + 1;        // 2 pieces of A per wave and K tile, 6 or 7 of B
     const int bid = (int)blockIdx.x;
     const int tile = bid % g.tiles_m, slice = bid / g.tiles_m, split = g.split;
     const long m0 = (long)tile * ADJ_BM;
-    const long kbeg = (long)slice * g.k_chunk;
+    const int spp = split / g.nseg, seg = slice / spp;           // slices per (plane, plane) pair; this slice's pair
+    const long kbeg = (long)(slice - seg * spp) * g.k_chunk;
     const long kend = min(g.K, kbeg + g.k_chunk);
     const long klen = kend > kbeg ? kend - kbeg : 0;
     const int nt = (int)((klen + BK - 1) / BK);
@@ -64,8 +70,10 @@ __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
 
     const unsigned smem_byte = (unsigned)reinterpret_cast<unsigned long long>(smem);
     OA oa; OB ob;
-    oa.init(g.A, g.a_bytes, g.lda, lane, wid);
-    ob.init(g.B, g.b_bytes, g.ldb, lane, wid);
+    const float* const Aq = g.A + g.seg_a[seg];
+    const float* const Bq = g.B + g.seg_b[seg];
+    oa.init(Aq, g.a_bytes, g.lda, lane, wid);
+    ob.init(Bq, g.b_bytes, g.ldb, lane, wid);
 
     float* const sa = smem;                                       // A ring, then B ring
     float* const sb = smem + ADJ_NA * ADJ_A_FLOATS;
@@ -77,7 +85,7 @@ __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
         const unsigned nbb = sb_byte + (unsigned)(((tb < 0 ? 0 : tb) % ADJ_NB) * ADJ_B_FLOATS * 4);
         const unsigned nab = sa_byte + (unsigned)(((ta < 0 ? 0 : ta) % ADJ_NA) * ADJ_A_FLOATS * 4);
         const long nkb = kbeg + (long)(tb < 0 ? 0 : tb) * BK, nka = kbeg + (long)(ta < 0 ? 0 : ta) * BK;
-        if constexpr (B16) {
+        if constexpr (B16 != 0) {
             int piece = 0;
             auto issue_one = [&]() {
                 if (piece < GB) {
@@ -100,14 +108,16 @@ __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
+                    if constexpr (B16 == 2) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), __builtin_bit_cast(f16x8, fb[j]), acc[j], 0, 0, 0);
+                    else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
                     issue_one();                       // one LDS-DMA piece behind every MFMA: B's 6 - 7 first, A's 2 last
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (ks & 1) {
                     const int s2 = ks >> 1;
                     const bf16x8 ga = chunk16(as, row16, 4 * s2 + lh16), gb = chunk16(bs, col16, 4 * s2 + lh16);
-                    acc16 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, gb, acc16, 0, 0, 0);
+                    if constexpr (B16 == 2) acc16 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ga), __builtin_bit_cast(f16x8, gb), acc16, 0, 0, 0);
+                    else acc16 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga, gb, acc16, 0, 0, 0);
                 }
             }
             return;
@@ -168,9 +178,9 @@ __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const long k0 = kbeg + (long)nfull * BK;
-        if constexpr (B16) oa.fill_tail(sa, g.A, m0, k0, g.M, kend);       // image K: masked through registers
+        if constexpr (B16 != 0) oa.fill_tail(sa, Aq, m0, k0, g.M, kend);   // image K: masked through registers
         else oa.dma(sa_byte, m0, k0, wid);                                 // image M: k rows beyond K read zeros
-        ob.fill_tail(sb, g.B, 0, k0, g.N, kend);                           // image K: masked through registers
+        ob.fill_tail(sb, Bq, 0, k0, g.N, kend);                            // image K: masked through registers
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -302,22 +312,29 @@ inline long adj_slab_floats(long tiles_m, int split) {
 
 __global__ __launch_bounds__(256, 2) void gemm_adj_kernel(Args g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_adj_body<false>(g, smem);
+    gemm_adj_body<0>(g, smem);
 }
 __global__ __launch_bounds__(256, 2) void gemm_adj_b16_kernel(Args g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_adj_body<true>(g, smem);
+    gemm_adj_body<1>(g, smem);
+}
+__global__ __launch_bounds__(256, 2) void gemm_adj_f16x2_kernel(Args g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_adj_body<2>(g, smem);
 }
 
-inline hipError_t launch_adj(const Args& g, hipStream_t s, bool b16 = false) {
-    static bool attr_set[2] = {false, false};
-    const void* fn = b16 ? reinterpret_cast<const void*>(&gemm_adj_b16_kernel) : reinterpret_cast<const void*>(&gemm_adj_kernel);
-    if (!attr_set[b16]) {
+// kind: 0 fp32 operands, 1 bf16 in memory, 2 fp16 piece planes (split % nseg == 0)
+inline hipError_t launch_adj(const Args& g, hipStream_t s, int kind = 0) {
+    static bool attr_set[3] = {false, false, false};
+    const void* fn = kind == 2 ? reinterpret_cast<const void*>(&gemm_adj_f16x2_kernel)
+                   : kind == 1 ? reinterpret_cast<const void*>(&gemm_adj_b16_kernel) : reinterpret_cast<const void*>(&gemm_adj_kernel);
+    if (!attr_set[kind]) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ADJ_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set[b16] = true;
+        attr_set[kind] = true;
     }
-    if (b16) hipLaunchKernelGGL(gemm_adj_b16_kernel, dim3(g.tiles_m * g.split), dim3(256), ADJ_LDS_BYTES, s, g);
+    if (kind == 2) hipLaunchKernelGGL(gemm_adj_f16x2_kernel, dim3(g.tiles_m * g.split), dim3(256), ADJ_LDS_BYTES, s, g);
+    else if (kind == 1) hipLaunchKernelGGL(gemm_adj_b16_kernel, dim3(g.tiles_m * g.split), dim3(256), ADJ_LDS_BYTES, s, g);
     else hipLaunchKernelGGL(gemm_adj_kernel, dim3(g.tiles_m * g.split), dim3(256), ADJ_LDS_BYTES, s, g);
     return hipSuccess;
 }

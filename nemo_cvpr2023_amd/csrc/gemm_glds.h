@@ -80,6 +80,10 @@ struct Args {
     // fp32 at all.  One writer per element, no atomics: deterministic.
     float* colsum = nullptr;
     long ldcs = 0;
+    // gemm_adj.h, split-precision form (round 5): the K slices are dealt over `nseg` (operand plane of A, operand plane of B)
+    // pairs -- slices [q split / nseg, (q + 1) split / nseg) read A + seg_a[q] and B + seg_b[q] (offsets in floats) over the whole K
+    long seg_a[3] = {0, 0, 0}, seg_b[3] = {0, 0, 0};
+    int nseg = 1;
 };
 
 constexpr int BK = 32;

@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     float* __restrict__ dA, float* __restrict__ parts, int* __restrict__ tickets, float* __restrict__ loss_parts,
     int* __restrict__ grid_ticket, unsigned short* __restrict__ dVPb, long ldk,
     const unsigned short* __restrict__ Wsk, const unsigned short* __restrict__ Wadj,
-    const float* __restrict__ Wsp_w, const unsigned int* __restrict__ Wsp_j, float pscale) {
+    const float* __restrict__ Wsp_w, const unsigned int* __restrict__ Wsp_j, float pscale, long hplane) {
     constexpr bool BF16 = MODE >= 1 && MODE <= 3, SPLIT = MODE == 2, ADJS = MODE == 2 || MODE == 3;
     // MODE 4 (round 5, "f32_split"): fp32 arithmetic everywhere EXCEPT that the pose blend's products run on the bf16 pipe with
     // both operands carried as THREE bf16 pieces (8 + 8 + 8 significant bits = the fp32 value): x = x0 + x1 + x2, and
@@ -2074,7 +2074,29 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             /*prof:q2e*/
         }
         /*prof:q3*/
-        if (BF16 && dVPb) {
+        if (SPH && dVPb) {
+            // split-precision adjoint (nemo_gemm_f16x2mem_adj): d vp as TWO fp16 pieces of 2^12 d vp, NOT transposed -- plane 0 at
+            // dVPb, plane 1 hplane elements behind it; row = sample, the lane's 4 vertices x 3 coordinates are 12 consecutive k
+            unsigned short* dst0 = dVPb + (s0 + l15) * ldk + (v0 + 4 * g) * 3;
+            unsigned short h0[12], h1[12];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const float x = dvp[d][r] * PF_SCALE;
+                    const _Float16 a = (_Float16)x, b = (_Float16)(x - (float)a);
+                    h0[r * 3 + d] = __builtin_bit_cast(unsigned short, a);
+                    h1[r * 3 + d] = __builtin_bit_cast(unsigned short, b);
+                }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                uint2 p0, p1;
+                p0.x = (unsigned)h0[4 * q] | ((unsigned)h0[4 * q + 1] << 16); p0.y = (unsigned)h0[4 * q + 2] | ((unsigned)h0[4 * q + 3] << 16);
+                p1.x = (unsigned)h1[4 * q] | ((unsigned)h1[4 * q + 1] << 16); p1.y = (unsigned)h1[4 * q + 2] | ((unsigned)h1[4 * q + 3] << 16);
+                reinterpret_cast<uint2*>(dst0)[q] = p0;
+                reinterpret_cast<uint2*>(dst0 + hplane)[q] = p1;
+            }
+        } else if (BF16 && dVPb) {
             // bf16-in-memory chain: d vp as bf16, NOT transposed -- row = sample, the lane's 4 vertices x 3 coordinates are
             // 12 consecutive k (24 bytes, 8-byte aligned): the k-contiguous A operand of the adjoint product dPF = dVP P^T
             unsigned short* dstb = dVPb + (s0 + l15) * ldk + (v0 + 4 * g) * 3;
@@ -2609,11 +2631,13 @@ extern "C" int64_t nemo_v2v_fused_ws_bytes(const nemo_ctx* ctx, int64_t N) {
 
 static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const float* PF2, int64_t ldpf,
                               const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
-                              void* ws, int64_t ws_bytes, void* stream, unsigned short* dVPb = nullptr, int64_t ldk = 0) {
+                              void* ws, int64_t ws_bytes, void* stream, unsigned short* dVPb = nullptr, int64_t ldk = 0, int64_t hplane = 0) {
     // kind: 0 = fp32, 1 = bf16 blend (+ split adjoint), 2 = fp32 with the blend's products on the bf16 pipe in three pieces
     const bool bf16 = kind == 1;
     if (!ctx || N < 0 || !PF2 || !A2 || !loss_sum || ldpf < 207) return NEMO_EINVAL;
-    if (dVPb ? (!bf16 || ldk < ctx->ldP || (ldk & 3) || (((uintptr_t)dVPb) & 7)) : (!dVPt || ldn < ((N + 15) / 16) * 16))
+    if (dVPb ? ((kind != 1 && kind != 2) || ldk < ctx->ldP || (ldk & 3) || (((uintptr_t)dVPb) & 7) ||
+                (kind == 2 && (hplane < ((N + 15) / 16) * 16 * ldk || (hplane & 3))))
+             : (!dVPt || ldn < ((N + 15) / 16) * 16))
         return NEMO_EINVAL;                                    // (dA == NULL: deferred combine, nemo_v2v_combine)
     if (N == 0) return NEMO_OK;
     // bf16: bf16 blend + split-precision vertex->joint adjoint AND split-precision skinning on the bf16 pipe (kernel MODE 2, the
@@ -2625,7 +2649,7 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
     // kind 2 (fp32-equivalent split precision): two fp16 pieces per operand (MODE 5); NEMO_MESH_PIECES=3: three bf16 pieces (MODE 4, the
     // first form of the round: 360 against ... us per 8 x 300 launch), an A/B aid
     static const int pieces_env = getenv("NEMO_MESH_PIECES") ? atoi(getenv("NEMO_MESH_PIECES")) : 2;
-    const int mode = bf16 ? (split_env == 3 ? 3 : 2) : kind == 2 ? (pieces_env == 3 ? 4 : 5) : 0;
+    const int mode = bf16 ? (split_env == 3 ? 3 : 2) : kind == 2 ? ((pieces_env == 3 && !dVPb) ? 4 : 5) : 0;   // (fp16 planes out: MODE 5 only)
     const bool sparse = ctx->skin_sparse != 0 && mode != 2;
     const int lds_bytes = mode == 2 ? (2 * 16 * MF_PFB / 2 + 2 * 2 * 16 * MF_AB / 2 + MF_TAIL) * (int)sizeof(float)
         : ((mode == 4 ? 3 * 2 * 16 * MF_PFB / 2 : mode == 5 ? 2 * 2 * 16 * MF_PFB / 2 : bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) +
@@ -2659,7 +2683,7 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
 #define MESH_LAUNCH(M, SP, PP, LDP) hipLaunchKernelGGL((mesh_v2v_fused_kernel<M, SP>), dim3((unsigned)blocks), dim3(256), lds_bytes, \
         (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, PP, LDP, ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA,  \
         pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets, loss_parts, grid_ticket, dVPb, (long)ldk,    \
-        ctx->d_Wsk, WADJ, ctx->d_Wsp_w, ctx->d_Wsp_j, ctx->sph_scale)
+        ctx->d_Wsk, WADJ, ctx->d_Wsp_w, ctx->d_Wsp_j, ctx->sph_scale, (long)hplane)
     if (mode == 5 && sparse) MESH_LAUNCH(5, true, reinterpret_cast<const float*>(ctx->d_posedirs_sph), ctx->NVp);
     else if (mode == 5) MESH_LAUNCH(5, false, reinterpret_cast<const float*>(ctx->d_posedirs_sph), ctx->NVp);
     else if (mode == 4 && sparse) MESH_LAUNCH(4, true, reinterpret_cast<const float*>(ctx->d_posedirs_sp3), ctx->NVp);
@@ -2701,6 +2725,15 @@ extern "C" int32_t nemo_v2v_fused_split(const nemo_ctx* ctx, int64_t N, const fl
                                          const float* A2, float* loss_sum, float* dVPt, int64_t ldn, float* dA,
                                          void* ws, int64_t ws_bytes, void* stream) {
     return v2v_fused_impl(ctx, 2, N, PF2, ldpf, A2, loss_sum, dVPt, ldn, dA, ws, ws_bytes, stream);
+}
+
+// nemo_v2v_fused_split whose d vp output is two fp16 piece planes of 2^12 d vp, NOT transposed: dVPh (16 * ceil(N / 16) rows x ldk >= the
+// blend-shape row stride, plane 1 `plane` elements behind plane 0) -- the A operand of nemo_gemm_f16x2mem_adj
+extern "C" int32_t nemo_v2v_fused_splitmem(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
+                                           float* loss_sum, uint16_t* dVPh, int64_t ldk, int64_t plane, float* dA, void* ws,
+                                           int64_t ws_bytes, void* stream) {
+    if (!dVPh) return NEMO_EINVAL;
+    return v2v_fused_impl(ctx, 2, N, PF2, ldpf, A2, loss_sum, nullptr, 0, dA, ws, ws_bytes, stream, dVPh, ldk, plane);
 }
 
 // bf16 variant whose d vp output is bf16 and NOT transposed: dVPb (16 * ceil(N / 16) rows x ldk >= 3 NVp, bf16) -- the

@@ -298,6 +298,20 @@ class FitEngine:
         self._jm = jm
         self.NV = self.ctx.NV
         self.vp = fold_vposer(vposer_sd, self.device)
+        # mesh_blend 'f32_split': the blend-shape ADJOINT dPF = dVP P^T in the same arithmetic from SPLIT_ADJ_ROWS samples on -- the
+        # mesh kernel hands d vp over as two fp16 piece planes (nemo_v2v_fused_splitmem), the blend shapes' two planes are made
+        # here, the product runs on the 64 x 208 tile with fp16 MFMAs (nemo_gemm_f16x2mem_adj); NEMO_SPLIT_ADJOINT=0: fp32 GEMM
+        self.split_adj = self.mesh_split and os.environ.get('NEMO_SPLIT_ADJOINT', '1') != '0'
+        if self.split_adj:
+            Pf = torch.as_tensor(np.asarray(assets['posedirs']), dtype=torch.float32).reshape(207, -1)
+            pmax = float(Pf.abs().max())
+            self.ph_scale = 2.0 ** (14 - math.frexp(pmax)[1]) if pmax > 0 else 1.0          # max |P| * scale in [2^13, 2^14)
+            x = Pf * self.ph_scale
+            h0 = x.half()
+            h1 = (x - h0.float()).half()
+            self.Ph = torch.zeros(2, 207, self.ctx.ldP, dtype=torch.int16, device=self.device)
+            self.Ph[0, :, :Pf.shape[1]] = h0.view(torch.int16).to(self.device)
+            self.Ph[1, :, :Pf.shape[1]] = h1.view(torch.int16).to(self.device)
         if self.b16mem:
             r8 = lambda n: (n + 7) // 8 * 8
             # blend shapes as a plain bf16 [207][3 NVp] matrix: the k-contiguous B operand of the adjoint product
@@ -379,6 +393,7 @@ class FitEngine:
     B16_DW_ASIDE_ROWS = 10000       # bf16 chain: parameter-gradient products on the side stream up to this many rows
     SMALL_BATCH_ROWS = 1024  # backward_mlp: below this many rows the dW GEMMs run beside the dX chain
     GROUPED_DW_ROWS = 400    # ... and up to this many as ONE grouped launch behind it (a one-instance shard)
+    SPLIT_ADJ_ROWS = 256     # mesh_blend 'f32_split': the blend-shape adjoint in split precision from this many samples on
     ECS_ROWS = 1536          # fp32 backward_mlp: bias gradients from the dX launches' per-band column sums above this many rows
                              # (same box: headline 1.257 / 1.259 ms without / with, C4 101.8 / 101.5 ms: the win is C4's 6.6 GB of reads)
     MAX_WORKSPACES = 24      # distinct batch sizes kept alive (a rank of a sharded minibatch run sees many)
@@ -422,6 +437,9 @@ class FitEngine:
             D3=Z(N, 126), AAdec=Z(N, 63),
             R2=Z(2 * Nc, 24, 9), A2=Z(2 * Nc, 24, 12), Jp2=Z(2 * Nc, 24, 3), PF2=Z(2 * Nc, 208),
             dVPt=Z(3 * self.ctx.NVp, (Nc + 15) // 16 * 16) if not self.b16mem else Z(16),
+            # (mesh_blend 'f32_split': d vp as two fp16 piece planes [2][samples][blend-shape row stride])
+            dVPh=(torch.zeros(2, (Nc + 15) // 16 * 16, self.ctx.ldP, dtype=torch.int16, device=self.device)
+                  if getattr(self, 'split_adj', False) else None),
             dR2=Z(N, 24, 9),
             dR=Z(N, 24, 9), dA=Z(N, 24, 12), dMq=Z(N, max(nq * 72, 1)),
             dPF=Z(N, 208), dHEAD=Z(N + 1, HEAD_LD), dH=Z(N + 1, h), dH_b=Z(N + 1, h), dH_c=Z(N + 1, h),
@@ -505,6 +523,8 @@ class FitEngine:
         if tag == 'mesh_v2v_fused' and self.ctx.skin_sparse_flag and not b16_skin:
             valu = flops * (2 * 12 * 4) / self.mesh_macs()
         if not self.bf16:
+            if tag == 'gemm_pose_blend_bwd' and self.split_adj:
+                return {'f16x3': flops}              # (nemo_gemm_f16x2mem_adj: three fp16 piece products per algorithmic product)
             out = {'f32': flops - valu}
             if tag == 'mesh_v2v_fused' and self.mesh_split:
                 # (csrc/smpl.hip MODE 5: the two pose blends and the vertex->joint adjoint run on the 16-bit matrix pipe as THREE fp16
@@ -1043,7 +1063,13 @@ class FitEngine:
             #  reduction's tail -- 0.509 against 0.503 ms, same box; 8 x 300: 1.557 against 1.564 ms; round 4: minibatch-512 steps
             #  0.572 against 0.579 ms deferred, two instances 0.602 against 0.618)
             defer = need_grad and self.SMALL_BATCH_ROWS < N <= Nc and self.timers is None
-            if self.b16mem:
+            hsplit = need_grad and self.split_adj and n >= self.SPLIT_ADJ_ROWS
+            if hsplit:
+                dh = w['dVPh']
+                check(L.nemo_v2v_fused_splitmem(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']), self.scal.data_ptr() + 4 * S_V2V,
+                                                dh.data_ptr(), dh.stride(1), dh.stride(0), None if defer else dptr(w['dA2']),
+                                                ws.data_ptr(), ws.numel() * 4, st), 'nemo_v2v_fused_splitmem')
+            elif self.b16mem:
                 check(L.nemo_v2v_fused_bf16mem(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']),
                                                self.scal.data_ptr() + 4 * S_V2V, dptr(w['dVPb']), w['dVPb'].stride(0),
                                                None if defer else dptr(w['dA2']), ws.data_ptr(), ws.numel() * 4, st),
@@ -1059,7 +1085,17 @@ class FitEngine:
             if need_grad:
                 if c0 > 0:
                     w['dPF2'].zero_()
-                if self.b16mem:
+                if hsplit:
+                    ev2 = self._event_begin('gemm_pose_blend_bwd', 2.0 * n * 207 * NV3)
+                    cur = torch.cuda.current_stream()
+                    gws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]
+                    dh = w['dVPh']
+                    check(L.nemo_gemm_f16x2mem_adj(n, 207, (NV3 + 1) // 2 * 2, dh.data_ptr(), dh.stride(1), dh.stride(0),
+                                                   self.Ph.data_ptr(), self.Ph.stride(1), self.Ph.stride(0), dptr(w['dPF2']), 208,
+                                                   1.0 / (4096.0 * self.ph_scale), 1, gws.data_ptr(), gws.numel() * 4, st),
+                          'nemo_gemm_f16x2mem_adj')
+                    self._event_end(ev2)
+                elif self.b16mem:
                     self.gemm16(n, 207, NV3, w['dVPb'], self.Pb, dptr(w['dPF2']), 208, out_mode=1, tag='gemm_pose_blend_bwd')
                 else:
                     self.gemm(1, 1, n, 207, NV3, dptr(w['dVPt']), ldn, ctx.posedirs, ldP, dptr(w['dPF2']), 208,

@@ -1121,3 +1121,48 @@ def test_gemm_f32_with_per_band_column_sums(L, M, N, K, ta, tb):
     assert rel_err(cs[:, :N], bands) < 1e-5
     assert float((cs[:, N:] - 7.0).abs().max()) == 0.0                           # columns beyond N untouched
     assert rel_err(cs[:, :N].double().sum(0), ref.sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize('M,K', [(2400, 20670), (300, 20670), (513, 4098), (8192, 20670), (257, 1030)])
+def test_blend_shape_adjoint_in_split_precision(L, M, K):
+    """nemo_gemm_f16x2mem_adj: C += alpha (A0 B0^T + A0 B1^T + A1 B0^T) over two fp16 piece planes per operand (the 64 x 208 tile, K
+    slices dealt over the three plane pairs) against float64 -- and no worse than 1.5 x the fp32 GEMM on the same operands."""
+    H = _ops()
+    N = 207
+    gen = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=gen) * torch.rand(M, 1, generator=gen)          # d vp-like: O(1), row scales differ
+    B = 1e-2 * torch.randn(N, K, generator=gen)
+    sa, sb = 4096.0, 2.0 ** (14 - math.frexp(float(B.abs().max()))[1])
+
+    def planes(x, s, ld):
+        y = x * s
+        h0 = y.half()
+        h1 = (y - h0.float()).half()
+        out = torch.zeros(2, x.shape[0], ld, dtype=torch.int16)
+        out[0, :, :x.shape[1]] = h0.view(torch.int16)
+        out[1, :, :x.shape[1]] = h1.view(torch.int16)
+        return out.cuda()
+    ld = (K + 15) // 8 * 8
+    Ah, Bh = planes(A, sa, ld), planes(B, sb, ld)
+    ws = torch.zeros((16384 + 65536 + (96 << 20)) // 4, device='cuda')
+    C0 = torch.randn(M, 208, generator=gen).cuda()
+    C = C0.clone()
+    K2 = (K + 1) // 2 * 2
+    assert L.nemo_gemm_f16x2mem_adj(M, N, K2, Ah.data_ptr(), ld, Ah.stride(0), Bh.data_ptr(), ld, Bh.stride(0), C.data_ptr(), 208,
+                                    1.0 / (sa * sb), 1, ws.data_ptr(), ws.numel() * 4, H.st()) == 0
+    torch.cuda.synchronize()
+    assert float(ws[:4096].abs().max()) == 0.0                                    # tickets back at zero
+    ref = A.double() @ B.double().t()
+    got = (C[:, :N] - C0[:, :N]).double().cpu()
+    e_split = float((got - ref).abs().max() / ref.abs().max())
+    # the fp32 product of the same operands through the library (transposed A, as the fp32 build runs it)
+    At = H.dev(A.t().contiguous())
+    Bd = H.dev(B)
+    C32 = torch.zeros(M, 208, device='cuda')
+    assert L.nemo_gemm_f32(1, 1, M, N, K, At.data_ptr(), M, Bd.data_ptr(), K, C32.data_ptr(), 208, None, 0, None, 0, 0, 1.0, 0, 0,
+                           ws.data_ptr(), ws.numel() * 4, H.st()) == 0
+    torch.cuda.synchronize()
+    e32 = float((C32[:, :N].double().cpu() - ref).abs().max() / ref.abs().max())
+    print('blend-shape adjoint, max error / max |result| against float64: split', e_split, 'fp32 kernel', e32)
+    assert e_split <= 1.5 * e32 + 1e-7 and e_split < 3e-6
+    assert torch.equal(C[:, N:], C0[:, N:])                                       # column 207 untouched
