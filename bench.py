@@ -987,7 +987,8 @@ def worker_main(opts):
                 'what': 'the headline runs the fused mesh term with its pose blend (3 x 207 multiply-adds per vertex, body and sample) and its '
                         'vertex->joint adjoint on the 16-bit matrix cores in fp32-equivalent arithmetic: both operands as two fp16 pieces of '
                         's x (11 + 11 significant bits + the remainder\'s sign = the fp32 value to one ulp), the three leading piece products '
-                        'exact in fp32, fp32 accumulation (nemo_v2v_fused_split, csrc/smpl.hip MODE 5); everything else is the fp32 path.  '
+                        'exact in fp32, fp32 accumulation (nemo_v2v_fused_split / _splitmem, csrc/smpl.hip MODE 5), and the blend-shape adjoint GEMM '
+                        'behind it the same way (nemo_gemm_f16x2mem_adj, from 256 samples on); everything else is the fp32 path.  '
                         '`f32_mfma_blend` is the same step with these products on the fp32 MFMA pipe',
                 'criteria': {'a_error_vs_float64': 'tests/test_gpu_ops.py::test_v2v_fused_split_is_fp32_equivalent: error of loss, d vp and dA '
                                                    'against a float64 evaluation of the same fp32 inputs <= 1.5 x the fp32-MFMA kernel\'s '
