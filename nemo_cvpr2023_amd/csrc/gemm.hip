@@ -951,14 +951,20 @@ extern "C" int32_t nemo_gemm_f16x2mem_adj(int64_t M, int64_t N, int64_t K, const
     const long K2 = K / 2, lda2 = lda / 2, ldb2 = ldb / 2;          // the fp32-typed view of the same bytes (pairs)
     unsigned a_bytes = 0, b_bytes = 0;
     if (!glds::extents(0, 1, M, N, K2, lda2, ldb2, &a_bytes, &b_bytes)) return NEMO_EINVAL;
-    const long tiles_m = (M + 63) / 64;
-    // slices per plane pair: ~one workgroup per CU (up to 8 row tiles) or two; every slice keeps >= 8 K tiles
-    // (2400 rows, us per launch against slices per pair: 2: 227, 3: 191, 4 -- 456 workgroups, this rule --: 167, 5: 217, 6: 219)
-    int spp = (int)((tiles_m <= 8 ? 256 : 512) / (3 * tiles_m));
+    // From 1024 rows on: the 128 x 208 tile on eight waves (one workgroup per CU) -- the blend-shape tiles are fetched once per 128
+    // rows; NEMO_ADJ128=0: the 64-row tile throughout (A/B aid)
+    static const bool no128 = getenv("NEMO_ADJ128") != nullptr && atoi(getenv("NEMO_ADJ128")) == 0;
+    const bool t128 = M >= 1024 && !no128;
+    const int bm = t128 ? 128 : 64;
+    const long tiles_m = (M + bm - 1) / bm;
+    // slices per plane pair: ~one workgroup per CU (64-row tile: two from 9 row tiles on); every slice keeps >= 8 K tiles
+    // (2400 rows, us per launch against slices per pair -- 64-row tile: 2: 227, 3: 191, 4 = 456 workgroups, this rule: 167, 5: 217,
+    //  6: 219; 128-row tile: 2: 225, 3: 173, 4 = 228 workgroups, this rule: 153, 5: 205, 6: 182, 8: 164)
+    int spp = (int)(((t128 || tiles_m <= 8) ? 256 : 512) / (3 * tiles_m));
     if (spp < 1) spp = 1;
     auto fits = [&](int sp) {
         return glds::adj_counter_ints(tiles_m, 3 * sp) <= COUNTER_BYTES / 4 &&
-               COUNTER_BYTES + glds::adj_slab_floats(tiles_m, 3 * sp) * 4 <= ws_bytes;
+               COUNTER_BYTES + glds::adj_slab_floats(tiles_m, 3 * sp, bm) * 4 <= ws_bytes;
     };
     while (spp > 1 && ((K2 + 31) / 32 / spp < 8 || !fits(spp))) --spp;
     if (!fits(spp)) return NEMO_EINVAL;
@@ -981,7 +987,7 @@ extern "C" int32_t nemo_gemm_f16x2mem_adj(int64_t M, int64_t N, int64_t K, const
     static const bool debug_h = getenv("NEMO_GEMM_DEBUG") != nullptr;
     if (debug_h)
         fprintf(stderr, "nemo_gemm_f16x2mem_adj M=%ld N=%ld K=%ld -> 64x208 mixed-shape tile, 3 plane pairs x %d K slices\n", (long)M, (long)N, (long)K, spp);
-    const hipError_t e = glds::launch_adj(g, (hipStream_t)stream, 2);
+    const hipError_t e = t128 ? glds::launch_adj128_f16x2(g, (hipStream_t)stream) : glds::launch_adj(g, (hipStream_t)stream, 2);
     if (e != hipSuccess) return (int32_t)e;
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;

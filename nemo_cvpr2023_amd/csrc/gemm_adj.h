@@ -24,8 +24,9 @@
 namespace glds {
 
 constexpr int ADJ_BM = 64, ADJ_BN = 208;
-constexpr int ADJ_A_FLOATS = ADJ_BM * BK, ADJ_B_FLOATS = ADJ_BN * BK, ADJ_NA = 3, ADJ_NB = 2;
-constexpr int ADJ_LDS_BYTES = (ADJ_NA * ADJ_A_FLOATS + ADJ_NB * ADJ_B_FLOATS) * 4;
+constexpr int ADJ_B_FLOATS = ADJ_BN * BK, ADJ_NA = 3, ADJ_NB = 2;
+constexpr int adj_lds_bytes(int nwv) { return (ADJ_NA * 16 * nwv * BK + ADJ_NB * ADJ_B_FLOATS) * 4; }
+constexpr int ADJ_LDS_BYTES = adj_lds_bytes(4);
 
 // B16 (round 4, last third): the same tile for the bf16-in-memory chain (BASELINE configs[2]) -- dPF (+)= dVP P^T with dVP
 // (samples x K) and P (207 x K) bf16 IN MEMORY, both k-contiguous (nemo_gemm_bf16mem's layout; A / B / lda / ldb / K arrive as
@@ -39,11 +40,14 @@ constexpr int ADJ_LDS_BYTES = (ADJ_NA * ADJ_A_FLOATS + ADJ_NB * ADJ_B_FLOATS) * 
 // (plane of A, plane of B) pairs (Args::nseg / seg_a / seg_b) and summed by the same ordered slab combine; v_mfma_f32_32x32x16_f16 /
 // 16x16x32_f16 on the same images.  nemo_blend_adjoint_split.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int B16>
+// NWV = 8 (round 5, the split-precision form): a 128 x 208 tile on eight waves -- the blend-shape tiles (26 of the 34 KB a K tile of
+// the 64-row form moves) are fetched once per 128 rows: the kernel is bound by the L2 -> LDS stream, not by the matrix pipe.
+template <int B16, int NWV = 4>
 __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
-    using OA = Operand<ADJ_BM, B16 != 0>;
-    using OB = Operand<ADJ_BN, true>;
-    constexpr int GA = OA::PER_WAVE, GB = OB::NI / 4 + 1;        // 2 pieces of A per wave and K tile, 6 or 7 of B
+    constexpr int ADJ_BM = 16 * NWV, ADJ_A_FLOATS = ADJ_BM * BK, NTH = 64 * NWV;
+    using OA = Operand<ADJ_BM, B16 != 0, NWV>;
+    using OB = Operand<ADJ_BN, true, NWV>;
+    constexpr int GA = OA::PER_WAVE, GB = OB::NI / NWV + 1;      // 2 pieces of A per wave and K tile, 6 or 7 (3 or 4) of B
     const int bid = (int)blockIdx.x;
     const int tile = bid % g.tiles_m, slice = bid / g.tiles_m, split = g.split;
     const long m0 = (long)tile * ADJ_BM;
@@ -58,7 +62,7 @@ __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane & 31, lh = lane >> 5, lr16 = lane & 15, lh16 = lane >> 4;
-    const int row32 = 32 * (wid & 1) + lr, col32 = 96 * (wid >> 1) + lr;        // (+ 32 j)
+    const int row32 = 32 * (wid % (NWV / 2)) + lr, col32 = 96 * (wid / (NWV / 2)) + lr;        // (+ 32 j)
     const int row16 = 16 * wid + lr16, col16 = 192 + lr16;
 
     f32x16 acc[3];
@@ -78,7 +82,7 @@ __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
     float* const sa = smem;                                       // A ring, then B ring
     float* const sb = smem + ADJ_NA * ADJ_A_FLOATS;
     const unsigned sa_byte = smem_byte, sb_byte = smem_byte + ADJ_NA * ADJ_A_FLOATS * 4;
-    const bool b_extra = wid < OB::NI % 4;                        // this wave issues a 7th piece of B
+    const bool b_extra = wid < OB::NI % NWV;                      // this wave issues one more piece of B
 
     // MFMAs of K tile t (A slot t % 3, B slot t % 2); meanwhile request B of tile tb and then A of tile ta (< 0: none)
     auto compute = [&](const float* as, const float* bs, int tb, int ta) {
@@ -202,7 +206,7 @@ __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
         int* const cnt1 = g.counters + g.tiles_m + tile * ngroups + grp;               // slices of this group that have arrived
         int* flag = reinterpret_cast<int*>(smem);
         auto put = [&](float4* slab, int idx, f32x4 vv) {
-            float4* dst = slab + idx * 256 + threadIdx.x;
+            float4* dst = slab + idx * NTH + threadIdx.x;
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
         };
         auto put_all = [&](float4* slab) {
@@ -224,7 +228,7 @@ __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
                 const float4* p1 = p0 + TILE4;
                 float4 v0[13], v1[13];
 #pragma unroll
-                for (int i = 0; i < 13; ++i) { v0[i] = p0[i * 256]; v1[i] = p1[i * 256]; }
+                for (int i = 0; i < 13; ++i) { v0[i] = p0[i * NTH]; v1[i] = p1[i * NTH]; }
 #pragma unroll
                 for (int i = 0; i < 13; ++i) {
                     sum[i].x += v0[i].x; sum[i].y += v0[i].y; sum[i].z += v0[i].z; sum[i].w += v0[i].w;
@@ -235,7 +239,7 @@ __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
                 const float4* p0 = base + (size_t)sl * TILE4 + threadIdx.x;
 #pragma unroll
                 for (int i = 0; i < 13; ++i) {
-                    const float4 v = p0[i * 256];
+                    const float4 v = p0[i * NTH];
                     sum[i].x += v.x; sum[i].y += v.y; sum[i].z += v.z; sum[i].w += v.w;
                 }
             }
@@ -282,7 +286,7 @@ __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
         if (n >= g.N) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long m = m0 + 32 * (wid & 1) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const long m = m0 + 32 * (wid % (NWV / 2)) + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m >= g.M) continue;
             float* c = g.C + m * g.ldc + n;
             const float v = g.alpha * acc[j][r];
@@ -306,8 +310,8 @@ __device__ __forceinline__ void gemm_adj_body(const Args& g, float* smem) {
 // adj_slab_floats(tiles_m, split) floats
 inline long adj_groups(int split) { return split <= 16 ? 1 : (split + 7) / 8; }
 inline long adj_counter_ints(long tiles_m, int split) { return tiles_m * (1 + adj_groups(split)); }
-inline long adj_slab_floats(long tiles_m, int split) {
-    return tiles_m * (split + (adj_groups(split) > 1 ? adj_groups(split) : 0)) * (long)(ADJ_BM * ADJ_BN);
+inline long adj_slab_floats(long tiles_m, int split, int bm = ADJ_BM) {
+    return tiles_m * (split + (adj_groups(split) > 1 ? adj_groups(split) : 0)) * (long)(bm * ADJ_BN);
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_adj_kernel(Args g) {
@@ -321,6 +325,23 @@ __global__ __launch_bounds__(256, 2) void gemm_adj_b16_kernel(Args g) {
 __global__ __launch_bounds__(256, 2) void gemm_adj_f16x2_kernel(Args g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_adj_body<2>(g, smem);
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_adj128_f16x2_kernel(Args g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_adj_body<2, 8>(g, smem);
+}
+// the 128-row form of kind 2: tiles_m = ceil(M / 128), one workgroup of 512 threads per CU
+inline hipError_t launch_adj128_f16x2(const Args& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_adj128_f16x2_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, adj_lds_bytes(8));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_adj128_f16x2_kernel, dim3(g.tiles_m * g.split), dim3(512), adj_lds_bytes(8), s, g);
+    return hipSuccess;
 }
 
 // kind: 0 fp32 operands, 1 bf16 in memory, 2 fp16 piece planes (split % nseg == 0)

@@ -94,7 +94,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 // ------------------------------------------------------------------------------------------ staging
 // One operand: ROWS x 32 tile, image K (KC) or image M.
-template <int ROWS, bool KC>
+template <int ROWS, bool KC, int NW = 4>      // NW: waves of the workgroup that issue the pieces (4; 8 in the 128-row adjoint tile)
 struct Operand {
     static constexpr int FLOATS = ROWS * BK;
     static constexpr int NI = ROWS / 8;                 // 1-KiB DMA pieces per tile
@@ -122,18 +122,18 @@ struct Operand {
     // pieces of the tile whose first row is row0 and first k is k0, into the LDS bytes starting at `tile_byte`
     __device__ __forceinline__ void dma(unsigned tile_byte, long row0, long k0, int wid) const {
 #pragma unroll
-        for (int u0 = 0; u0 < NI; u0 += 4) {
+        for (int u0 = 0; u0 < NI; u0 += NW) {
             const int u = u0 + wid;
-            if (NI % 4 != 0 && u >= NI) break;             // (wave-uniform)
+            if (NI % NW != 0 && u >= NI) break;            // (wave-uniform)
             const long so = KC ? ((row0 + 8 * u) * ld + k0) * 4 : ((k0 + (64 / CPR) * u) * ld + row0) * 4;
             dma_piece(rs, tile_byte + u * 1024, voff, (unsigned)so);
         }
     }
     // pieces a wave issues per tile (waves with wid < NI % 4 issue one more when NI % 4 != 0)
-    static constexpr int PER_WAVE = NI / 4;
+    static constexpr int PER_WAVE = NI / NW;
     // the i-th of this wave's pieces alone (interleaved issue: one piece between two MFMAs)
     __device__ __forceinline__ void dma_one(unsigned tile_byte, long row0, long k0, int wid, int i) const {
-        const int u = 4 * i + wid;
+        const int u = NW * i + wid;
         const long so = KC ? ((row0 + 8 * u) * ld + k0) * 4 : ((k0 + (64 / CPR) * u) * ld + row0) * 4;
         dma_piece(rs, tile_byte + u * 1024, voff, (unsigned)so);
     }
@@ -142,7 +142,7 @@ struct Operand {
     __device__ __forceinline__ void fill_tail(float* tile, const float* base, long row0, long k0, long rows,
                                               long K) const {
         static_assert(KC, "tail fill is for image K");
-        for (int idx = threadIdx.x; idx < ROWS * 8; idx += 256) {
+        for (int idx = threadIdx.x; idx < ROWS * 8; idx += 64 * NW) {
             const int r = idx >> 3, c = idx & 7;
             const long gr = row0 + r, gk = k0 + 4 * c;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
