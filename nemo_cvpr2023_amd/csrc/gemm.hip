@@ -670,13 +670,17 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
     // K counts bf16 pairs here.
     if (glds_ok && bf16 == 2 && !transA && transB && N > 128 && N <= 208 && M >= 256 && K >= 1024 && split_k == 0 && C &&
         out_mode != 2 && force_tile == 0 && can_split && !bias && !act && !mask_mode && !mask16 && !Cb && !CbT && !colsum) {
-        const long tiles_m = (M + 63) / 64;
-        int S = (int)((tiles_m <= 8 ? 256 : 512) / tiles_m);
+        // (from 1024 rows on: the 128 x 208 tile on eight waves, one workgroup per CU -- as nemo_gemm_f16x2mem_adj; NEMO_ADJ128=0: never)
+        static const bool no128b = getenv("NEMO_ADJ128") != nullptr && atoi(getenv("NEMO_ADJ128")) == 0;
+        const bool t128 = M >= 1024 && !no128b;
+        const int bm = t128 ? 128 : 64;
+        const long tiles_m = (M + bm - 1) / bm;
+        int S = (int)(((t128 || tiles_m <= 8) ? 256 : 512) / tiles_m);
         if (S < 1) S = 1;
-        while (S > 1 && ((K + 31) / 32 / S < 8 || COUNTER_BYTES + glds::adj_slab_floats(tiles_m, S) * 4 > ws_bytes ||
+        while (S > 1 && ((K + 31) / 32 / S < 8 || COUNTER_BYTES + glds::adj_slab_floats(tiles_m, S, bm) * 4 > ws_bytes ||
                          glds::adj_counter_ints(tiles_m, S) > COUNTER_BYTES / 4)) --S;
         if (glds::adj_counter_ints(tiles_m, S) <= COUNTER_BYTES / 4 &&
-            COUNTER_BYTES + glds::adj_slab_floats(tiles_m, S) * 4 <= ws_bytes) {
+            COUNTER_BYTES + glds::adj_slab_floats(tiles_m, S, bm) * 4 <= ws_bytes) {
             GemmArgs g;
             g.A = A; g.B = B; g.C = C; g.bias = nullptr; g.mask = nullptr;
             g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldmask = 0;
@@ -692,7 +696,7 @@ static int32_t gemm_impl(int bf16, int32_t transA, int32_t transB, int64_t M, in
             static const bool debug_b16 = getenv("NEMO_GEMM_DEBUG") != nullptr;
             if (debug_b16)
                 fprintf(stderr, "nemo_gemm_bf16mem M=%ld N=%ld K=%ld (bf16 pairs) -> 64x208 mixed-shape tile, %d K slices\n", (long)M, (long)N, (long)K, g.split);
-            hipError_t e = glds::launch_adj(g, (hipStream_t)stream, true);
+            hipError_t e = t128 ? glds::launch_adj128_b16(g, (hipStream_t)stream) : glds::launch_adj(g, (hipStream_t)stream, true);
             if (e != hipSuccess) return (int32_t)e;
             NEMO_LAUNCH_CHECK();
             return NEMO_OK;

@@ -331,6 +331,21 @@ __global__ __launch_bounds__(512, 1) void gemm_adj128_f16x2_kernel(Args g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_adj_body<2, 8>(g, smem);
 }
+__global__ __launch_bounds__(512, 1) void gemm_adj128_b16_kernel(Args g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_adj_body<1, 8>(g, smem);
+}
+inline hipError_t launch_adj128_b16(const Args& g, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_adj128_b16_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, adj_lds_bytes(8));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_adj128_b16_kernel, dim3(g.tiles_m * g.split), dim3(512), adj_lds_bytes(8), s, g);
+    return hipSuccess;
+}
 // the 128-row form of kind 2: tiles_m = ceil(M / 128), one workgroup of 512 threads per CU
 inline hipError_t launch_adj128_f16x2(const Args& g, hipStream_t s) {
     static bool attr_set = false;
