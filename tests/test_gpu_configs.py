@@ -279,7 +279,11 @@ def test_c4_rows_for_nemo_v3_v4(version):
     # the bf16 build's earlier forms: fp32 / sparse skinning in the mesh kernel (MODE 3), 64-byte-row GEMM stages, fp32 first layer
     ({'NEMO_MESH_SPLIT': '3', 'NEMO_B16X_BK': '32', 'NEMO_B16_FIRST_LAYER': '0'},
      ['tests/test_gpu_bf16.py', '-k', 'c3_bf16_step or v2v_fused_bf16 or large_tile_bf16_product']),
-], ids=['fp32_mfma_blend_atomics', 'bf16_round4_forms'])
+    # f32_split's first form (three bf16 pieces), the fp32 blend-shape adjoint beside it, the 64-row adjoint tile at every size
+    ({'NEMO_MESH_PIECES': '3', 'NEMO_SPLIT_ADJOINT': '0', 'NEMO_ADJ128': '0'},
+     ['tests/test_gpu_ops.py', 'tests/test_gpu_bf16.py', 'tests/test_gpu_model.py', '-k',
+      'split_is_fp32 or adjoint or (v2v_fused_mesh and 6890) or published_config_step_vs_oracle']),
+], ids=['fp32_mfma_blend_atomics', 'bf16_round4_forms', 'f32_split_first_forms'])
 def test_alternative_kernel_paths_stay_correct(env, target):
     """The switches of INTEGRATION.md section F that select another KERNEL are read once per process: each alternative runs the
     parity tests that cover it in a child process, so that the non-default forms (bench.py's `f32_mfma_blend` leg, the A/B aids)
