@@ -11,8 +11,10 @@
  *  - every function returns int32: 0 ok, <0 invalid argument, >0 a hipError_t;
  *  - all pointers are DEVICE pointers to contiguous row-major fp32 unless stated
  *    (index arrays are int64); the caller (PyTorch allocator) owns all memory; no
- *    allocation, no hidden global state, re-entrant; "ld*" arguments are row strides
- *    in elements;
+ *    allocation (nemo_ctx_create's immutable per-device constants excepted), no process-global
+ *    state, re-entrant; the ONE piece of state outside the arguments is the calling host
+ *    thread's binding of a caller-owned reduction arena (nemo_reduce_ws_bind below);
+ *    "ld*" arguments are row strides in elements;
  *  - the last argument is the hipStream_t to launch on (as void*);
  *  - immutable model constants live in an opaque nemo_ctx created per device.
  *  - "_bwd" entry points *accumulate* (+=) into parameter-gradient outputs (the caller
@@ -26,19 +28,29 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 16
+#define NEMO_ABI_VERSION 17
 int32_t nemo_abi_version(void);
 
-/* Deterministic accumulation (round 5).  Every sum over the blocks of a launch that used float atomics until round 4 -- the
- * per-view loss / camera-gradient sums of the key-point kernels (nemo/neural_motion_model.py:3551-3558, :3073-3124 under
- * autograd), the phase-network gradients, bias column sums, the scalar losses -- is now added in a FIXED order by the launch's
- * last-arriving block from per-block deposits in a scratch the library owns (allocated by nemo_ctx_create, 160 MB): the same
- * inputs give the same bits, run to run.  Every launch takes its own region of the scratch (bump allocation);
- * nemo_reduce_scratch_reset() rewinds the allocator -- call it at the top of every step, from the host thread that enqueues the
- * step (the launches of a step then own distinct regions; a captured HIP graph keeps the regions it was captured with; two
- * steps must not be IN FLIGHT at once on different streams).  A launch that finds the scratch exhausted falls back to the
- * atomics of rounds 1 - 4 (correct, not bit-reproducible); NEMO_ORDERED_REDUCE=0 forces that. */
+/* Deterministic accumulation (round 5; caller-owned since ABI 17).  Every sum over the blocks of a launch that used float atomics
+ * until round 4 -- the per-view loss / camera-gradient sums of the key-point kernels (nemo/neural_motion_model.py:3551-3558,
+ * :3073-3124 under autograd), the phase-network gradients, bias column sums, the scalar losses -- is added in a FIXED order by the
+ * launch's last-arriving block from per-block deposits in a scratch arena: the same inputs give the same bits, run to run.
+ *   - The arena is CALLER-OWNED device memory: ws 256-byte aligned, bytes >= nemo_reduce_ws_bytes(N, V) for passes of up to N samples
+ *     over V views, ZERO-FILLED ONCE when allocated (its head holds arrival tickets the kernels return to zero), on the device the
+ *     launches run on.
+ *   - nemo_reduce_ws_bind(ws, bytes) binds it to the CALLING HOST THREAD (thread-local; NULL unbinds) and rewinds its bump cursor;
+ *     every launch of this library that reduces across blocks then takes its own region of the bound arena.
+ *     nemo_reduce_scratch_reset() rewinds the cursor of the calling thread's arena.  Bind (or reset) at the top of every pass: the
+ *     launches of a pass then own distinct regions, and a captured HIP graph keeps the regions it was captured with.
+ *   - Threading / streams: launches that share an arena must be ordered on ONE stream (or by events); concurrent passes -- other
+ *     streams, other devices, other host threads -- bind DIFFERENT arenas.  The library keeps no other state, no process globals.
+ *   - A launch that finds no arena bound, or the arena exhausted, falls back to the float atomics of rounds 1 - 4 (correct, not
+ *     bit-reproducible) and nemo_reduce_fallbacks() -- a process-wide count of such launches -- goes up: a determinism test asserts
+ *     it stays 0.  NEMO_ORDERED_REDUCE=0 forces the atomics (not counted). */
+int64_t nemo_reduce_ws_bytes(int64_t n_samples, int64_t n_views);
+int32_t nemo_reduce_ws_bind(void* ws, int64_t bytes);
 int32_t nemo_reduce_scratch_reset(void);
+int64_t nemo_reduce_fallbacks(void);
 
 /* ------------------------------------------------------------------------------------------
  * Dense fp32 contraction on the matrix cores (v_mfma_f32_32x32x2_f32), fused epilogue:
@@ -118,6 +130,34 @@ int32_t nemo_cast_bf16(int64_t rows, int64_t cols, const float* src, int64_t lds
  * i.e. the fp32 product up to the 2^-17 terms, through nemo_gemm_bf16mem. */
 int32_t nemo_cast_bf16_split3(int64_t rows, int64_t cols, const float* src, int64_t lds, uint16_t* dst, int64_t ldd,
                               int32_t order, void* stream);
+/* ---- fp32-EQUIVALENT split precision on the 16-bit matrix cores for the MotionNet chain (round 6; csrc/gemm_xp.h) ----
+ * Replaces, in fp32 builds (args.mlp_gemm = 'f32_split'), the nn.Linear products of MotionNet and their autograd
+ * (nemo/neural_motion_model.py:58-71, :130-148): Y = X W^T, dX = dY W, dW = dY^T X, each as C = A B^T over k-contiguous
+ * "xp matrices".  An xp matrix (rows x K, format fmt) holds every fp32 value x as NP = fmt 16-bit pieces whose sum is x:
+ *   fmt 3: three bf16 pieces x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (= x exactly; no scale, fp32's range);
+ *   fmt 2: two fp16 pieces of s x, x0 = fp16(s x), x1 = fp16(s x - x0), s a power of two chosen by the caller with |s x| < 65504;
+ * piece p of element (r, k) is the 16-bit word r * ld + (k / 32) * 32 NP + p * 32 + k % 32, ld >= nemo_xp_ld(fmt, K) =
+ * 32 NP ceil(K / 32), ld % 8 == 0, base 16-byte aligned, and elements k in [K, 32 ceil(K / 32)) of every row are ZERO.
+ * nemo_gemm_xp: C (M x N, fp32, may be NULL) (op)= v, v = maskfn(act(alpha * A B^T + bias)), keeping the piece products of weight
+ * >= 2^-24 (fmt 3: six, fmt 2: three; each exact in fp32, fp32 accumulation): error against float64 <= that of nemo_gemm_f32.
+ * mask_mode 1: v = x0(maskx[m][n]) > 0 ? v : 0 with maskx an xp matrix (M x N) -- the copy of the ReLU output.  Cx / CxT (may be
+ * NULL): v * out_scale and its transpose written as xp matrices (M x N, ld ldcx / N x M, ld ldcxt) -- the operands of the next
+ * products of the chain; colsum as nemo_gemm_bf16mem.  ws as nemo_gemm_f32.
+ * nemo_cast_xp: up to NEMO_CAST_XP_MAX fp32 matrices (rows x cols, row stride lds) -> their xp copies dst (rows x cols) and / or
+ * dstT (cols x rows) of `scale` * src in ONE launch (fmt 3 ignores scale). */
+#define NEMO_CAST_XP_MAX 8
+typedef struct {
+    const float* src; int64_t rows, cols, lds;
+    uint16_t* dst; int64_t ldd;
+    uint16_t* dstT; int64_t lddT;
+    float scale;
+} nemo_cast_xp_desc;
+int64_t nemo_xp_ld(int32_t fmt, int64_t k);
+int32_t nemo_gemm_xp(int32_t fmt, int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                     float* C, int64_t ldc, const float* bias, int32_t act, const uint16_t* maskx, int64_t ldmask,
+                     int32_t mask_mode, float alpha, int32_t out_mode, uint16_t* Cx, int64_t ldcx, uint16_t* CxT, int64_t ldcxt,
+                     float out_scale, float* colsum, int64_t ldcs, void* ws, int64_t ws_bytes, void* stream);
+int32_t nemo_cast_xp(int32_t fmt, int32_t n, const nemo_cast_xp_desc* descs, void* stream);
 /* Up to NEMO_GEMM_GROUP_MAX independent products C_i (op)= alpha_i * opA(A_i) @ opB(B_i) (out_mode 0 store / 1 C +=; no
  * bias / activation / mask) in ONE launch when they share a layout and their operands are 16-byte aligned -- the
  * parameter gradients dW_l = dY_l^T X_l of the whole MotionNet backward (nemo/neural_motion_model.py:58-71,130-148 under

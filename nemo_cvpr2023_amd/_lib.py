@@ -25,6 +25,11 @@ class GemmProblem(Structure):
                 ('alpha', c_float), ('out_mode', c_int32)]
 
 
+class CastXpDesc(Structure):
+    _fields_ = [('src', c_void_p), ('rows', c_int64), ('cols', c_int64), ('lds', c_int64), ('dst', c_void_p), ('ldd', c_int64),
+                ('dstT', c_void_p), ('lddT', c_int64), ('scale', c_float)]
+
+
 class AdamSeg(Structure):
     _fields_ = [('offset', c_int64), ('numel', c_int64), ('lr', c_float), ('weight_decay', c_float),
                 ('step_size', c_float), ('bias_corr2_sqrt', c_float), ('adamw', c_int32), ('step', c_int32)]
@@ -32,12 +37,15 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 16        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 17        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
     'nemo_abi_version': (i32, []),
+    'nemo_reduce_ws_bytes': (i64, [i64, i64]),
+    'nemo_reduce_ws_bind': (i32, [ptr, i64]),
     'nemo_reduce_scratch_reset': (i32, []),
+    'nemo_reduce_fallbacks': (i64, []),
     'nemo_gemm_f32': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32,
                             f32, i32, i32, ptr, i64, ptr]),
     'nemo_gemm_f32_colsum': (i32, [i32, i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32, f32,
@@ -51,6 +59,10 @@ SIGNATURES = {
                                    ptr]),
     'nemo_cast_bf16': (i32, [i64, i64, ptr, i64, ptr, i64, i32, ptr]),
     'nemo_cast_bf16_split3': (i32, [i64, i64, ptr, i64, ptr, i64, i32, ptr]),
+    'nemo_xp_ld': (i64, [i32, i64]),
+    'nemo_gemm_xp': (i32, [i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32, f32, i32, ptr, i64, ptr, i64,
+                           f32, ptr, i64, ptr, i64, ptr]),
+    'nemo_cast_xp': (i32, [i32, i32, POINTER(CastXpDesc), ptr]),
     'nemo_gemm_grouped_f32': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),
     'nemo_gemm_grouped_bf16': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),
     'nemo_colsum_f32': (i32, [ptr, i64, i64, i64, ptr, ptr]),

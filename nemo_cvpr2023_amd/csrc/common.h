@@ -39,17 +39,16 @@ __device__ __forceinline__ float block_sum(float v, float* red /* >= 16 floats L
 // Until round 4 per-view loss / camera / phase-network sums, bias column sums and the loss scalars were accumulated with
 // float atomicAdd: the order of the additions, and with it the last bits of every sum, changed from run to run (1000 camera
 // iterations at lr 0.1 amplified that to 4 % of the final camera loss).  Now every block deposits its partial value(s) in a
-// region of a library-owned scratch, takes a ticket, and the LAST-ARRIVING block sums the deposits in a fixed order and is the
+// region of a caller-owned scratch, takes a ticket, and the LAST-ARRIVING block sums the deposits in a fixed order and is the
 // only writer of the outputs -- the scheme the fused mesh kernel and the split-K GEMMs already used.
 //
-// Host side: nemo_red_take(floats, tickets) hands out a region per launch (bump allocation over a buffer allocated once in
-// nemo_ctx_create; nemo_reduce_scratch_reset() -- called by the engine at the top of every step -- rewinds it, so the launches
-// of a step own distinct regions and a captured graph keeps the ones it was captured with).  Tickets are zero between
-// launches (the last arriver resets its own).  When the scratch is exhausted or absent the region is {nullptr, nullptr} and
-// the kernels fall back to the atomics.
+// Host side: nemo_red_take(floats, tickets) hands out a region per launch -- bump allocation over the CALLER-OWNED arena the
+// calling thread bound with nemo_reduce_ws_bind (include/nemo_hip.h, ABI 17; the bind / nemo_reduce_scratch_reset() at the top
+// of every step rewinds it, so the launches of a step own distinct regions and a captured graph keeps the ones it was captured
+// with).  Tickets are zero between launches (the last arriver resets its own).  When no arena is bound or it is exhausted the
+// region is {nullptr, nullptr}, the kernels fall back to the atomics and nemo_reduce_fallbacks() counts it.
 struct NemoRed { float* part; int* ticket; };
 NemoRed nemo_red_take(size_t part_floats, int n_tickets);
-bool nemo_red_ensure();                 // allocates the scratch (never inside a stream capture: nemo_ctx_create calls it)
 
 #ifdef __HIPCC__
 // A deposit: WRITE-THROUGH (sc1) store -- device-visible once the storing wave's vmcnt has drained, no L2 write-back fence (a

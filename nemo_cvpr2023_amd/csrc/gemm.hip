@@ -29,6 +29,7 @@
 #include "gemm_adj.h"
 #include "gemm_skinny.h"
 #include "gemm_b16x.h"
+#include "gemm_xp.h"
 #include "../../include/nemo_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -993,6 +994,78 @@ extern "C" int32_t nemo_gemm_f16x2mem_adj(int64_t M, int64_t N, int64_t K, const
         fprintf(stderr, "nemo_gemm_f16x2mem_adj M=%ld N=%ld K=%ld -> 64x208 mixed-shape tile, 3 plane pairs x %d K slices\n", (long)M, (long)N, (long)K, spp);
     const hipError_t e = t128 ? glds::launch_adj128_f16x2(g, (hipStream_t)stream) : glds::launch_adj(g, (hipStream_t)stream, 2);
     if (e != hipSuccess) return (int32_t)e;
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+// ---- fp32-EQUIVALENT split precision for the MotionNet chain (round 6; gemm_xp.h) -------------------------------------------
+// fmt 3: three bf16 pieces per operand, six piece products (no scale, no range condition); fmt 2: two fp16 pieces, three
+// products, power-of-two scales carried by the caller (alpha = 1 / (s_A s_B), out_scale = the scale of the result's copies).
+// Operands / copies are "xp matrices" (include/nemo_hip.h).
+extern "C" int64_t nemo_xp_ld(int32_t fmt, int64_t k) { return (fmt != 2 && fmt != 3) || k < 0 ? -1 : xp::ld_for(fmt, k); }
+
+extern "C" int32_t nemo_gemm_xp(int32_t fmt, int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, const uint16_t* B,
+                                int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t act, const uint16_t* maskx,
+                                int64_t ldmask, int32_t mask_mode, float alpha, int32_t out_mode, uint16_t* Cx, int64_t ldcx,
+                                uint16_t* CxT, int64_t ldcxt, float out_scale, float* colsum, int64_t ldcs, void* ws,
+                                int64_t ws_bytes, void* stream) {
+    if ((fmt != 2 && fmt != 3) || M < 0 || N < 0 || K < 0 || !A || !B) return NEMO_EINVAL;
+    if (!C && !Cx && !CxT) return NEMO_EINVAL;
+    if ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)Cx) | ((uintptr_t)CxT) | ((uintptr_t)maskx)) & 15) return NEMO_EINVAL;
+    if (out_mode < 0 || out_mode > 1 || (mask_mode != 0 && mask_mode != 1) || (mask_mode && !maskx)) return NEMO_EINVAL;
+    if ((Cx && (ldcx & 7)) || (CxT && (ldcxt & 7)) || (mask_mode && (ldmask & 7)) || (C && ldc < N) || (colsum && ldcs < N)) return NEMO_EINVAL;
+    if (M == 0 || N == 0) return NEMO_OK;
+    if (K == 0) return NEMO_EINVAL;
+    xp::Args g{};
+    g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.C = C; g.ldc = ldc; g.out_mode = out_mode;
+    g.bias = bias; g.act = act; g.alpha = alpha; g.maskx = mask_mode ? maskx : nullptr; g.ldmask = ldmask; g.mask_mode = mask_mode;
+    g.Cx = Cx; g.ldcx = ldcx; g.CxT = CxT; g.ldcxt = ldcxt; g.out_scale = out_scale; g.colsum = colsum; g.ldcs = ldcs;
+    g.counters = reinterpret_cast<int*>(ws);
+    g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
+    // tile: 128 x 128 while its grid is at most ~2 rounds of the chip, 128 x 256 beyond (fewer bytes through L2 -> LDS per product)
+    static const int force_bn = getenv("NEMO_XP_BN") ? atoi(getenv("NEMO_XP_BN")) : 0;
+    const long t128 = ((M + 127) / 128) * ((N + 127) / 128);
+    int bn = (t128 > 512 && N > 128) ? 256 : 128;
+    if (force_bn == 128 || force_bn == 256) bn = force_bn;
+    const long tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
+    // K slices: about one workgroup per CU, every slice >= 4 K tiles of 32
+    static const int force_split = getenv("NEMO_XP_SPLIT") ? atoi(getenv("NEMO_XP_SPLIT")) : 0;
+    int split = (int)(256 / tiles);
+    if (split < 1) split = 1;
+    while (split > 1 && (K / split < 128 || COUNTER_BYTES + tiles * split * 128L * bn * 4 > ws_bytes)) --split;
+    if (force_split > 0) split = force_split;
+    if (!ws || (((uintptr_t)ws) & 15) || tiles > COUNTER_BYTES / 4 || COUNTER_BYTES + tiles * split * 128L * bn * 4 > ws_bytes) split = 1;
+    if (!xp::plan(g, fmt, bn, split)) return NEMO_EINVAL;
+    static const bool debug_x = getenv("NEMO_GEMM_DEBUG") != nullptr;
+    if (debug_x)
+        fprintf(stderr, "nemo_gemm_xp fmt=%d M=%ld N=%ld K=%ld -> 128x%d, %d K slices\n", fmt, (long)M, (long)N, (long)K, bn, g.split);
+    hipError_t e;
+    if (fmt == 3) e = bn == 128 ? xp::launch<3, 128>(g, (hipStream_t)stream) : xp::launch<3, 256>(g, (hipStream_t)stream);
+    else e = bn == 128 ? xp::launch<2, 128>(g, (hipStream_t)stream) : xp::launch<2, 256>(g, (hipStream_t)stream);
+    if (e != hipSuccess) return (int32_t)e;
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_cast_xp(int32_t fmt, int32_t n, const nemo_cast_xp_desc* descs, void* stream) {
+    if ((fmt != 2 && fmt != 3) || n < 0 || n > xp::MAX_CAST || (n && !descs)) return NEMO_EINVAL;
+    xp::CastArgs a{};
+    int tiles = 0, m = 0;
+    for (int i = 0; i < n; ++i) {
+        const nemo_cast_xp_desc& q = descs[i];
+        if (q.rows < 0 || q.cols < 0 || !q.src || (!q.dst && !q.dstT) || q.lds < q.cols) return NEMO_EINVAL;
+        if ((q.dst && (q.ldd < xp::ld_for(fmt, q.cols) || (q.ldd & 7))) || (q.dstT && (q.lddT < xp::ld_for(fmt, q.rows) || (q.lddT & 7)))) return NEMO_EINVAL;
+        if (q.rows == 0 || q.cols == 0) continue;
+        xp::CastDesc& d = a.d[m++];
+        d.src = q.src; d.rows = q.rows; d.cols = q.cols; d.lds = q.lds; d.dst = q.dst; d.ldd = q.ldd; d.dstT = q.dstT; d.lddT = q.lddT;
+        d.scale = fmt == 2 ? q.scale : 1.f;
+        d.tile0 = tiles; d.tiles_c = nemo_cdiv(q.cols, 32);
+        tiles += d.tiles_c * nemo_cdiv(q.rows, 32);
+    }
+    a.n = m;
+    if (m == 0) return NEMO_OK;
+    if (fmt == 3) hipLaunchKernelGGL(xp::cast_xp_kernel<3>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(xp::cast_xp_kernel<2>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

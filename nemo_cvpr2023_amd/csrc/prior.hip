@@ -1,6 +1,7 @@
 // Pose priors and the fused optimiser: VPoser KL term, GMM max-mixture prior, robust 3-D pose loss,
 // multi-segment Adam.  Each loss kernel produces its (upstream-free) gradient in the same pass.
 #include <cstdlib>
+#include <atomic>
 #include "common.h"
 #include "../../include/nemo_hip.h"
 
@@ -365,45 +366,60 @@ __global__ void publish_kernel(const float* __restrict__ src, int n, float* __re
 
 }  // namespace
 
-// ---- the library-owned scratch of the ordered reductions (common.h) ----------------------------------------------------------
+// ---- the CALLER-OWNED scratch of the ordered reductions (common.h; ABI 17) --------------------------------------------------
+// Until ABI 16 this was one library-owned, process-global buffer behind unsynchronised globals (allocated on whichever device
+// was current at the first nemo_ctx_create).  Now the caller owns the memory (nemo_reduce_ws_bytes / nemo_reduce_ws_bind) and
+// the only state the library keeps is the CALLING THREAD's binding of such an arena and its bump cursor: engines on different
+// devices / streams bind different arenas, host threads do not share a cursor.
 namespace {
-constexpr size_t RED_PART_BYTES = 160u << 20;     // deposits (C4: key-point partials 12.6 MB + phase runs <= 64 MB + column sums 33 MB)
-constexpr size_t RED_TICKETS = 1u << 16;
-char* g_red_base = nullptr;
-size_t g_red_off = 0, g_red_tk = 0;
+constexpr size_t RED_TICKETS = 1u << 16;          // ints at the head of the arena
+struct RedArena { char* base = nullptr; size_t part_bytes = 0, off = 0, tk = 0; };
+thread_local RedArena t_red;
+std::atomic<long> g_red_fallbacks{0};
 }  // namespace
-
-bool nemo_red_ensure() {
-    if (g_red_base) return true;
-    static bool failed = false;
-    if (failed) return false;
-    void* p = nullptr;
-    if (hipMalloc(&p, RED_PART_BYTES + RED_TICKETS * 4) != hipSuccess || hipMemset(p, 0, RED_PART_BYTES + RED_TICKETS * 4) != hipSuccess ||
-        hipDeviceSynchronize() != hipSuccess) {
-        (void)hipGetLastError();
-        failed = true;
-        return false;
-    }
-    g_red_base = (char*)p;
-    return true;
-}
 
 NemoRed nemo_red_take(size_t part_floats, int n_tickets) {
     static const bool off = getenv("NEMO_ORDERED_REDUCE") != nullptr && atoi(getenv("NEMO_ORDERED_REDUCE")) == 0;
-    if (off || !g_red_base || n_tickets < 1) return NemoRed{nullptr, nullptr};
+    if (off || n_tickets < 1) return NemoRed{nullptr, nullptr};
+    RedArena& a = t_red;
     const size_t bytes = (part_floats * 4 + 255) / 256 * 256;
-    if (g_red_off + bytes > RED_PART_BYTES || g_red_tk + (size_t)n_tickets > RED_TICKETS) return NemoRed{nullptr, nullptr};
-    NemoRed r{reinterpret_cast<float*>(g_red_base + g_red_off), reinterpret_cast<int*>(g_red_base + RED_PART_BYTES) + g_red_tk};
-    g_red_off += bytes;
-    g_red_tk += (size_t)n_tickets;
+    if (!a.base || a.off + bytes > a.part_bytes || a.tk + (size_t)n_tickets > RED_TICKETS) {
+        g_red_fallbacks.fetch_add(1, std::memory_order_relaxed);          // (no arena bound / exhausted: float atomics, counted)
+        return NemoRed{nullptr, nullptr};
+    }
+    NemoRed r{reinterpret_cast<float*>(a.base + RED_TICKETS * 4 + a.off), reinterpret_cast<int*>(a.base) + a.tk};
+    a.off += bytes;
+    a.tk += (size_t)n_tickets;
     return r;
 }
 
-extern "C" int32_t nemo_reduce_scratch_reset(void) {
-    g_red_off = 0;
-    g_red_tk = 0;
+extern "C" int64_t nemo_reduce_ws_bytes(int64_t n_samples, int64_t n_views) {
+    if (n_samples < 0 || n_views < 0) return -1;
+    // tickets + deposits of one pass: key-point partials (3 launches), phase runs, column sums, scalars; generous and bounded
+    const long per_sample = 48 * 4 * 3 + 16 + 4 * 64;                  // bytes
+    long b = (long)RED_TICKETS * 4 + (8L << 20) + n_samples * per_sample + n_views * 4096;
+    if (b > (long)RED_TICKETS * 4 + (160L << 20)) b = (long)RED_TICKETS * 4 + (160L << 20);
+    return (b + 255) / 256 * 256;
+}
+
+extern "C" int32_t nemo_reduce_ws_bind(void* ws, int64_t bytes) {
+    if (ws == nullptr) { t_red = RedArena{}; return NEMO_OK; }
+    if ((((uintptr_t)ws) & 255) || bytes < (int64_t)(RED_TICKETS * 4 + 4096)) return NEMO_EINVAL;
+    RedArena& a = t_red;
+    a.base = (char*)ws;
+    a.part_bytes = (size_t)bytes - RED_TICKETS * 4;
+    a.off = 0;
+    a.tk = 0;
     return NEMO_OK;
 }
+
+extern "C" int32_t nemo_reduce_scratch_reset(void) {
+    t_red.off = 0;
+    t_red.tk = 0;
+    return NEMO_OK;
+}
+
+extern "C" int64_t nemo_reduce_fallbacks(void) { return g_red_fallbacks.load(std::memory_order_relaxed); }
 
 extern "C" int32_t nemo_step_begin(void* z0, int64_t bytes0, void* z1, int64_t bytes1, nemo_adam_seg* segs_dev,
                                    int32_t n_seg, double beta1, double beta2, void* stream) {

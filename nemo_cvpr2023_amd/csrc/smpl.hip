@@ -115,7 +115,6 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
     if (parents[0] >= 0) return NEMO_EINVAL;
     for (int i = 1; i < 24; ++i)
         if (parents[i] < 0 || parents[i] >= i) return NEMO_EINVAL;   // topological order required
-    nemo_red_ensure();                       // scratch of the ordered reductions (common.h): allocated here, never inside a capture
     nemo_ctx* c = new nemo_ctx();
     c->NV = NV;
     c->NVp = ((NV + 15) / 16) * 16;          // vertices padded to whole 16-vertex MFMA tiles

@@ -280,6 +280,17 @@ class FitEngine:
         if mb not in ('f32', 'f32_split'):
             raise ValueError(f"args.mesh_blend must be 'f32' or 'f32_split', got {mb!r}")
         self.mesh_split = mb == 'f32_split' and not self.bf16
+        # mlp_gemm (round 6), fp32 builds only: 'f32_split' (default) -- the nn.Linear products of MotionNet (forward, activation and
+        # parameter gradients; nemo/neural_motion_model.py:58-71, :130-148) on the bf16 matrix cores in fp32-EQUIVALENT arithmetic:
+        # every operand as three bf16 pieces (8 + 8 + 8 bits = the fp32 value exactly, fp32's exponent range: no scales, no range
+        # condition), the six piece products of weight >= 2^-24, fp32 accumulation (csrc/gemm_xp.h, nemo_gemm_xp fmt 3); error against
+        # float64 <= the fp32-MFMA GEMM's (tests/test_gpu_xp.py), from XP_MIN_ROWS rows on.  'f32': v_mfma_f32_32x32x2_f32 throughout
+        # (rounds 1 - 5; bench.py's `f32_mfma_blend` leg).  args.mlp_gemm, overridden by NEMO_MLP_GEMM.
+        mg = os.environ.get('NEMO_MLP_GEMM') or getattr(args, 'mlp_gemm', None) or 'f32_split'
+        if mg not in ('f32', 'f32_split'):
+            raise ValueError(f"args.mlp_gemm must be 'f32' or 'f32_split', got {mg!r}")
+        self.mlp_split = mg == 'f32_split' and not self.bf16 and version >= 1
+        self.xp_fmt = 3
         # bf16 operands IN MEMORY (round 3): every dense product of the MotionNet / VPoser chain reads bf16 copies of its
         # operands (written by the producing GEMM's epilogue, plain and transposed, or by nemo_cast_bf16) through
         # nemo_gemm_bf16mem -- the same values enter the matrix cores as with the on-the-fly rounding of nemo_gemm_bf16
@@ -355,6 +366,9 @@ class FitEngine:
         self.side_stream = torch.cuda.Stream(device=self.device)   # prior branches of the step (see _forward_backward)
         self.side_stream2 = torch.cuda.Stream(device=self.device)
         self.comm_stream = torch.cuda.Stream(device=self.device)    # bucketed gradient all-reduces + their Adam (dist.py)
+        # arena of the ordered (deterministic) reductions: owned by THIS engine, on its device, bound to the calling thread at the top
+        # of every pass (include/nemo_hip.h nemo_reduce_ws_bind, ABI 17): engines on other devices / streams have their own
+        self.red_ws = torch.zeros(int(self.lib.nemo_reduce_ws_bytes(max(V * T, 8192), V)) // 4, **f32)
         # split-K scratch of nemo_gemm_f32 (arrival tickets + partial tiles), one per stream that launches GEMMs
         self.gemm_ws = [torch.zeros(16 << 20, device=self.device) for _ in range(3)]
         self._colsums = []
@@ -368,6 +382,10 @@ class FitEngine:
         # device int64[V]: samples per view of the batch being launched (known from the indices: MultiViewModel._stage_indices),
         # or None -- then the key-point objective runs as two launches (nemo_kp_fwd, nemo_kp_bwd_ex)
         self.view_cnt = None
+
+    def bind_reduce_ws(self):
+        """Bind this engine's reduction arena to the calling host thread and rewind it (top of every pass)."""
+        check(self.lib.nemo_reduce_ws_bind(self.red_ws.data_ptr(), self.red_ws.numel() * 4), 'nemo_reduce_ws_bind')
 
     # ------------------------------------------------------------------ parameter views
     def view(self, name, buf=None):
@@ -394,6 +412,8 @@ class FitEngine:
     SMALL_BATCH_ROWS = 1024  # backward_mlp: below this many rows the dW GEMMs run beside the dX chain
     GROUPED_DW_ROWS = 400    # ... and up to this many as ONE grouped launch behind it (a one-instance shard)
     SPLIT_ADJ_ROWS = 256     # mesh_blend 'f32_split': the blend-shape adjoint in split precision from this many samples on
+    XP_MIN_ROWS = int(os.environ.get('NEMO_XP_MIN_ROWS', '1024'))    # mlp_gemm 'f32_split': the chain on nemo_gemm_xp from this many rows on
+    XP_DW_ASIDE_ROWS = 65536  # ... its parameter-gradient products on the side stream up to this many rows
     ECS_ROWS = 1536          # fp32 backward_mlp: bias gradients from the dX launches' per-band column sums above this many rows
                              # (same box: headline 1.257 / 1.259 ms without / with, C4 101.8 / 101.5 ms: the win is C4's 6.6 GB of reads)
     MAX_WORKSPACES = 24      # distinct batch sizes kept alive (a rank of a sharded minibatch run sees many)
@@ -466,6 +486,15 @@ class FitEngine:
             # (forward: three bf16 pieces per row -- [hi | lo | hi] against the weight's [hi | hi | lo]: the first layer's product in
             #  fp32-equivalent split precision; backward: the plain transposed copy)
             w['Xs'], w['XbT'] = Zb(N + 1, 3 * r8(self.din)), Zb(self.din, rp)
+        if self.mlp_split and N + 1 >= self.XP_MIN_ROWS:
+            # xp copies (csrc/gemm_xp.h: three bf16 pieces per value, k-blocks of 32) of every operand of the MotionNet chain: plain
+            # [row][feature] for the forward / dX products, T [feature][row] for the parameter gradients; zero-initialised
+            i16 = dict(dtype=torch.int16, device=self.device)
+            xl = lambda k: int(self.lib.nemo_xp_ld(self.xp_fmt, k))
+            Zx = lambda rows, k: torch.zeros(rows, xl(k), **i16)
+            w.update(Xx=Zx(N + 1, self.din), XxT=Zx(self.din, N + 1), dHEADx=Zx(N + 1, 147), dHEADxT=Zx(147, N + 1))
+            for k in ('H1', 'H2', 'H3', 'dH', 'dH_b', 'dH_c'):
+                w[k + 'x'], w[k + 'xT'] = Zx(N + 1, h), Zx(h, N + 1)
         # per-band column sums of the three activation gradients of the MotionNet backward (the epilogues of their launches:
         # nemo_gemm_bf16mem(colsum) / nemo_gemm_f32_colsum): the bias gradients of layers 4, 2, 0 from 2 ceil(r / 64) short rows
         R = int(self.lib.nemo_gemm_colsum_rows(N + 1))
@@ -523,6 +552,8 @@ class FitEngine:
         if tag == 'mesh_v2v_fused' and self.ctx.skin_sparse_flag and not b16_skin:
             valu = flops * (2 * 12 * 4) / self.mesh_macs()
         if not self.bf16:
+            if tag in ('gemm_mlp_hidden_fwd', 'gemm_mlp_hidden_dx') and self.mlp_split and any('Xx' in w_ for w_ in self.ws.values()):
+                return {'bf16x6': flops}             # (nemo_gemm_xp fmt 3: six bf16 piece products per algorithmic product)
             if tag == 'gemm_pose_blend_bwd' and self.split_adj:
                 return {'f16x3': flops}              # (nemo_gemm_f16x2mem_adj: three fp16 piece products per algorithmic product)
             out = {'f32': flops - valu}
@@ -775,6 +806,147 @@ class FitEngine:
         if aside:
             main.wait_stream(side)
 
+    # ---- fp32-equivalent split-precision chain (self.mlp_split; csrc/gemm_xp.h) -------------------------------------------------
+    def _use_xp(self, w):
+        return self.mlp_split and 'Xx' in w
+
+    def gemm_xp(self, M, N, K, Ax, Bx, Cp=None, ldc=0, bias=None, act=0, maskx=None, alpha=1.0, out_mode=0, Cx=None, CxT=None,
+                colsum=None, tag=None):
+        """C (M x N, fp32, may be None) (op)= epilogue(alpha * A B^T), A (M x K) / B (N x K) xp matrices; Cx / CxT: the result's xp
+        copies for the next products of the chain (include/nemo_hip.h nemo_gemm_xp)."""
+        ev = self._event_begin(tag, 2.0 * M * N * K)
+        cur = torch.cuda.current_stream()
+        ws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]
+        check(self.lib.nemo_gemm_xp(self.xp_fmt, M, N, K, Ax.data_ptr(), Ax.stride(0), Bx.data_ptr(), Bx.stride(0), Cp, ldc, bias, act,
+                                    dptr(maskx), maskx.stride(0) if maskx is not None else 0, 1 if maskx is not None else 0, alpha,
+                                    out_mode, dptr(Cx), Cx.stride(0) if Cx is not None else 0, dptr(CxT),
+                                    CxT.stride(0) if CxT is not None else 0, 1.0, dptr(colsum),
+                                    colsum.stride(0) if colsum is not None else 0, ws.data_ptr(), ws.numel() * 4, _stream()),
+              'nemo_gemm_xp')
+        self._event_end(ev)
+
+    def cast_xp(self, items):
+        """items: (src_ptr, rows, cols, lds, dst or None, dstT or None) -- their xp copies in ONE launch."""
+        arr = (_lib.CastXpDesc * len(items))()
+        for i, (src, rows, cols, lds, dst, dstT) in enumerate(items):
+            q = arr[i]
+            q.src, q.rows, q.cols, q.lds, q.scale = src, rows, cols, lds, 1.0
+            q.dst, q.ldd = dptr(dst), dst.stride(0) if dst is not None else 0
+            q.dstT, q.lddT = dptr(dstT), dstT.stride(0) if dstT is not None else 0
+        check(self.lib.nemo_cast_xp(self.xp_fmt, len(items), arr, _stream()), 'nemo_cast_xp')
+
+    def _weights_xp(self, transposed):
+        """xp copies of the four MotionNet weight matrices for this step (they change in Adam at the step's end): plain [out][in] for
+        the forward and -- `transposed` -- [in][out] for the activation gradients, all in one launch."""
+        lm, h = 'learned_motion.', self.h
+        if not hasattr(self, '_wx'):
+            i16 = dict(dtype=torch.int16, device=self.device)
+            xl = lambda k: int(self.lib.nemo_xp_ld(self.xp_fmt, k))
+            self._wx = {'0': torch.zeros(h, xl(self.din), **i16), '2': torch.zeros(h, xl(h), **i16), '4': torch.zeros(h, xl(h), **i16),
+                        'head': torch.zeros(147, xl(h), **i16), '0T': torch.zeros(self.din, xl(h), **i16),
+                        '2T': torch.zeros(h, xl(h), **i16), '4T': torch.zeros(h, xl(h), **i16), 'headT': torch.zeros(h, xl(147), **i16)}
+        wx = self._wx
+        T = lambda k: wx[k + 'T'] if transposed else None
+        self.cast_xp([(self.p(lm + 'net.net.0.weight'), h, self.din, self.din, wx['0'], T('0')),
+                      (self.p(lm + 'net.net.2.weight'), h, h, h, wx['2'], T('2')),
+                      (self.p(lm + 'net.net.4.weight'), h, h, h, wx['4'], T('4')),
+                      (self.p(lm + 'rot_out.weight'), 147, h, h, wx['head'], T('head'))])
+        return wx
+
+    def _forward_nets_xp(self, w, N, train):
+        """forward_pose's MLP on the split-precision chain: every layer reads the previous layer's xp copy and leaves its own (plain
+        for the next layer, transposed for its parameter gradient when `train`); the hidden activations exist as xp copies only
+        (three bf16 pieces = the fp32 value), the heads' output in fp32."""
+        lm, h, r = 'learned_motion.', self.h, N + 1
+        main, side = torch.cuda.current_stream(), self.side_stream
+        side.wait_event(main.record_event())
+        with torch.cuda.stream(side):
+            wx = self._weights_xp(bool(train))
+            casts_done = side.record_event()
+        self._wxT_fresh = bool(train)
+        T = lambda k: w[k] if train else None
+        self.cast_xp([(dptr(w['X']), r, self.din, self.ldx, w['Xx'], T('XxT'))])
+        main.wait_event(casts_done)
+        self.gemm_xp(r, h, self.din, w['Xx'], wx['0'], bias=self.p(lm + 'net.net.0.bias'), act=1, Cx=w['H1x'], CxT=T('H1xT'))
+        self.gemm_xp(r, h, h, w['H1x'], wx['2'], bias=self.p(lm + 'net.net.2.bias'), act=1, Cx=w['H2x'], CxT=T('H2xT'),
+                     tag='gemm_mlp_hidden_fwd')
+        self.gemm_xp(r, h, h, w['H2x'], wx['4'], bias=self.p(lm + 'net.net.4.bias'), act=1, Cx=w['H3x'], CxT=T('H3xT'))
+        self.gemm_xp(r, 147, h, w['H3x'], wx['head'], dptr(w['HEAD']), HEAD_LD, bias=self.p(lm + 'rot_out.bias'))
+
+    def _backward_mlp_xp(self, w, N, view_idx, frame_idx, raw_phase, nout, nbias, stages=(0, 1, 2), bucketed=False):
+        """backward_mlp on the split-precision chain.  Every product is C = A B^T over xp copies: dX_l = dY_l (W_l^T)^T reads dY_l's
+        plain copy and the transposed weight copy; dW_l = dY_l^T X_l reads the two TRANSPOSED activation copies (K = rows).
+        ``stages`` / ``bucketed`` as in backward_mlp."""
+        L, lm, h, r = self.lib, 'learned_motion.', self.h, N + 1
+        if 0 in stages and not getattr(self, '_wxT_fresh', False):
+            self._weights_xp(True)            # (no training forward ran in front of this backward: warm-up after an eval pass)
+        self._wxT_fresh = False
+        wx = self._wx
+        cs = self._colsums
+        R = int(L.nemo_gemm_colsum_rows(r))
+
+        def end_of_stage():
+            if bucketed:
+                self.flush_colsums()
+
+        # the parameter-gradient products go beside the dX chain on the side stream (un-bucketed), each as soon as its dY exists,
+        # ENQUEUED BEHIND the chain's next product (a replayed graph keeps a node's first successor on its queue)
+        main, side = torch.cuda.current_stream(), self.side_stream
+        aside = (not bucketed) and r <= self.XP_DW_ASIDE_ROWS
+        pend = []
+
+        def ready():
+            return main.record_event() if aside else None
+
+        def dW(ev, fn):
+            if not aside:
+                return fn()
+            pend.append((ev, fn))
+
+        def flush_dW():
+            for ev, fn in pend:
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    fn()
+            del pend[:]
+
+        if 0 in stages:
+            self.cast_xp([(dptr(w['dHEAD']), r, nout, HEAD_LD, w['dHEADx'], w['dHEADxT'])])
+            # heads
+            ev = ready()
+            dW(ev, lambda: self.gemm_xp(nout, h, r, w['dHEADxT'], w['H3xT'], self.g(lm + 'rot_out.weight'), h, out_mode=1))
+            cs.append((dptr(w['dHEAD']), r, nbias, HEAD_LD, self.g(lm + 'rot_out.bias')))
+            self.gemm_xp(r, h, nout, w['dHEADx'], wx['headT'], maskx=w['H3x'], Cx=w['dHx'], CxT=w['dHxT'], colsum=w['cs4'])
+            flush_dW()
+            # layer 4
+            ev = ready()
+            dW(ev, lambda: self.gemm_xp(h, h, r, w['dHxT'], w['H2xT'], self.g(lm + 'net.net.4.weight'), h, out_mode=1))
+            cs.append((dptr(w['cs4']), R, h, h, self.g(lm + 'net.net.4.bias')))
+            self.gemm_xp(r, h, h, w['dHx'], wx['4T'], maskx=w['H2x'], Cx=w['dH_bx'], CxT=w['dH_bxT'], colsum=w['cs2'],
+                         tag='gemm_mlp_hidden_dx')
+            flush_dW()
+            end_of_stage()
+        if 1 in stages:
+            # layer 2
+            ev = ready()
+            dW(ev, lambda: self.gemm_xp(h, h, r, w['dH_bxT'], w['H1xT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1))
+            cs.append((dptr(w['cs2']), R, h, h, self.g(lm + 'net.net.2.bias')))
+            self.gemm_xp(r, h, h, w['dH_bx'], wx['2T'], maskx=w['H1x'], Cx=w['dH_cx'], CxT=w['dH_cxT'], colsum=w['cs0'])
+            flush_dW()
+            end_of_stage()
+        if 2 not in stages:
+            return
+        ev = ready()
+        cs.append((dptr(w['cs0']), R, h, h, self.g(lm + 'net.net.0.bias')))
+        dW(ev, lambda: self.gemm_xp(h, self.din, r, w['dH_cxT'], w['XxT'], self.g(lm + 'net.net.0.weight'), self.din, out_mode=1))
+        self.gemm_xp(r, self.din, h, w['dH_cx'], wx['0T'], dptr(w['dX']), self.ldx)
+        if bucketed:
+            self.flush_colsums()
+        self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=not bucketed)
+        flush_dW()
+        if aside:
+            main.wait_stream(side)
+
     def gemm_grouped(self, problems, dense=True):
         """problems: list of (ta, tb, M, N, K, A, lda, B, ldb, C, ldc, out_mode) -- independent products of one layout in
         ONE launch (nemo_gemm_grouped_f32: the parameter gradients of the whole MLP backward)."""
@@ -823,9 +995,9 @@ class FitEngine:
         """K1-K5: phase warp, RBF, MLP, rot6d->R->aa.  Fills X,H1..H3,ROT,TR,R,AA.
         ``begin`` = (arena, zero_grads, n_seg): what ``step_begin`` would be called with -- done by further blocks of the
         phase kernel's launch instead of a launch of its own (nemo_phase_embed_fwd_begin)."""
-        # every pass starts here: the launches that follow take their regions of the ordered-reduction scratch from its start
-        # (include/nemo_hip.h nemo_reduce_scratch_reset: deterministic sums instead of float atomics, round 5)
-        self.lib.nemo_reduce_scratch_reset()
+        # every pass starts here: the launches that follow take their regions of this engine's ordered-reduction arena from its start
+        # (include/nemo_hip.h nemo_reduce_ws_bind: deterministic sums instead of float atomics)
+        self.bind_reduce_ws()
         L, st = self.lib, _stream()
         sh0 = self.p('phase_networks.0.shifts')
         sc0 = self.p('phase_networks.0.scales')
@@ -848,6 +1020,10 @@ class FitEngine:
         lm = 'learned_motion.'
         if self.b16mem:
             self._forward_nets_b16(w, N, train)
+            check(L.nemo_rot6d_fwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, dptr(w['R']), dptr(w['AA']), st), 'nemo_rot6d_fwd')
+            return
+        if self._use_xp(w):
+            self._forward_nets_xp(w, N, train)
             check(L.nemo_rot6d_fwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, dptr(w['R']), dptr(w['AA']), st), 'nemo_rot6d_fwd')
             return
         self._linear(r, dptr(w['X']), self.ldx, self.din, self.p(lm + 'net.net.0.weight'),
@@ -1186,6 +1362,8 @@ class FitEngine:
         nbias = 147 if (has_trans_grad and self.start_global_traj_anywhere) else 144
         if self.b16mem:
             return self._backward_mlp_b16(w, N, view_idx, frame_idx, raw_phase, nout, nbias, tuple(stages), bucketed)
+        if self._use_xp(w):
+            return self._backward_mlp_xp(w, N, view_idx, frame_idx, raw_phase, nout, nbias, tuple(stages), bucketed)
         # Schedule.  The parameter-gradient GEMMs (dW) are off the dependency chain: up to DW_ASIDE_ROWS rows they ALL go to
         # the side stream, each as soon as its dY exists, and the chain dX_head -> dX4 -> dX2 -> dX0 -> phase backward runs
         # uninterrupted on the main stream.  Beyond that (C4: every hidden-layer GEMM is thousands of tiles) only the heads'
@@ -1405,7 +1583,7 @@ class FitEngine:
         """First launch of an iteration whose first kernel is not the phase kernel (camera fit): zero the workspace's
         accumulator arena and `grads` (a slice of the flat gradient buffer, or None) and advance the device Adam table --
         one kernel instead of two memsets and a copy."""
-        self.lib.nemo_reduce_scratch_reset()
+        self.bind_reduce_ws()
         check(self.lib.nemo_step_begin(arena.data_ptr(), arena.numel() * 4, dptr(grads),
                                        grads.numel() * 4 if grads is not None else 0,
                                        self._seg_dev.data_ptr() if n_seg else None, n_seg, 0.9, 0.999, _stream()),

@@ -1,0 +1,155 @@
+"""Split-precision GEMM of the fp32 MotionNet chain (csrc/gemm_xp.h, nemo_gemm_xp / nemo_cast_xp) against float64:
+its error must not exceed the fp32-MFMA GEMM's (nemo_gemm_f32) by more than 1.5x in any role it plays for
+nemo/neural_motion_model.py:58-71, :130-148 (forward, activation gradient, parameter gradient), over operand magnitudes
+1e-10 ... 1e4."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests import hipops as H  # noqa: E402
+
+
+def _rand(rows, cols, mag, seed, heavy=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, cols, generator=g, dtype=torch.float64)
+    if heavy:       # rows spread over 6 decades (per-sample gradient magnitudes)
+        x = x * torch.pow(10.0, -6.0 * torch.rand(rows, 1, generator=g, dtype=torch.float64))
+    return (x * mag).float().to(H.DEV)
+
+
+def _err(c, ref):
+    return float((c.double() - ref).abs().max() / ref.abs().max())
+
+
+@pytest.mark.parametrize('fmt', [3])
+@pytest.mark.parametrize('rows,cols', [(33, 32), (2401, 105), (130, 1000), (64, 147)])
+def test_cast_roundtrip(fmt, rows, cols):
+    x = _rand(rows, cols, 3.0, 1)
+    d, dT = H.cast_xp(fmt, x, True, True)
+    # three bf16 pieces hold an fp32 value exactly
+    assert torch.equal(H.xp_decode(fmt, d, cols), x.double())
+    assert torch.equal(H.xp_decode(fmt, dT, rows), x.double().t())
+    # k-pads are zero
+    kb = (cols + 31) // 32
+    pads = d[:, :kb * 32 * fmt].reshape(rows, kb, fmt, 32)[:, -1, :, cols - (kb - 1) * 32:]
+    assert int(pads.abs().max()) == 0 if pads.numel() else True
+
+
+ROLES = [
+    # name, M, N, K
+    ('fwd_hidden', 2401, 1000, 1000),
+    ('fwd_first', 2401, 1000, 105),
+    ('fwd_head', 2401, 147, 1000),
+    ('dx_head', 2401, 1000, 147),
+    ('dw_hidden', 1000, 1000, 2401),
+    ('dw_head', 147, 1000, 2401),
+    ('dw_first', 1000, 105, 2401),
+    ('dx_first', 2401, 105, 1000),
+    ('small', 301, 1000, 1000),
+    ('odd', 77, 45, 33),
+]
+
+
+@pytest.mark.parametrize('fmt', [3])
+@pytest.mark.parametrize('name,M,N,K', ROLES)
+@pytest.mark.parametrize('mag_a,mag_b', [(1.0, 1.0), (1e-10, 1e4), (1e4, 1e-10), (1e-5, 1e-5)])
+def test_gemm_xp_error_vs_fp32_gemm(fmt, name, M, N, K, mag_a, mag_b):
+    A = _rand(M, K, mag_a, 11, heavy=name.startswith('d'))
+    B = _rand(N, K, mag_b, 12)
+    ref = A.double() @ B.double().t()
+    Ax, _ = H.cast_xp(fmt, A)
+    Bx, _ = H.cast_xp(fmt, B)
+    C, _, _, _ = H.gemm_xp(fmt, Ax, Bx, M, N, K)
+    C32 = H.gemm(A, B, 0, 1)
+    e_xp, e_32 = _err(C, ref), _err(C32, ref)
+    assert e_xp <= 1.5 * e_32 + 1e-9, (name, e_xp, e_32)
+
+
+def test_gemm_xp_epilogue_copies_mask_bias_colsum():
+    fmt, M, N, K = 3, 2401, 1000, 1000
+    A, B = _rand(M, K, 1.0, 21), _rand(N, K, 0.03, 22)
+    bias = _rand(1, N, 0.1, 23)[0].contiguous()
+    act_src = _rand(M, N, 1.0, 24).clamp_min(0)            # a ReLU output: zeros and positives
+    maskx, _ = H.cast_xp(fmt, act_src)
+    Ax, _ = H.cast_xp(fmt, A)
+    Bx, _ = H.cast_xp(fmt, B)
+    ref = (A.double() @ B.double().t() + bias.double())
+    # forward role: bias + ReLU, copies only
+    _, Cx, CxT, _ = H.gemm_xp(fmt, Ax, Bx, M, N, K, bias=bias, act=1, want_cx=True, want_cxt=True)
+    want = ref.clamp_min(0)
+    got, gotT = H.xp_decode(fmt, Cx, N), H.xp_decode(fmt, CxT, M)
+    assert _err(got, want) < 2e-6
+    assert torch.equal(got, gotT.t())
+    # dX role: mask from the activation copy, fp32 output + copies + column sums
+    C, Cx, CxT, cs = H.gemm_xp(fmt, Ax, Bx, M, N, K, maskx=maskx, want_cx=True, want_cxt=True, colsum=True, C=torch.zeros(M, N, device=H.DEV))
+    want = (A.double() @ B.double().t()) * (act_src > 0)
+    assert _err(C, want) < 2e-6
+    assert torch.equal(H.xp_decode(fmt, Cx, N), C.double())
+    assert torch.equal(H.xp_decode(fmt, CxT, M), C.double().t())
+    assert float((cs.double().sum(0) - want.sum(0)).abs().max() / want.sum(0).abs().max()) < 1e-5
+    # += and split-K (parameter-gradient role)
+    A2, B2 = _rand(1000, 2401, 1e-3, 25), _rand(1000, 2401, 1.0, 26)
+    A2x, _ = H.cast_xp(fmt, A2)
+    B2x, _ = H.cast_xp(fmt, B2)
+    C0 = _rand(1000, 1000, 1.0, 27)
+    Cacc = C0.clone()
+    H.gemm_xp(fmt, A2x, B2x, 1000, 1000, 2401, C=Cacc, out_mode=1)
+    want = C0.double() + A2.double() @ B2.double().t()
+    assert _err(Cacc, want) < 2e-6
+    # the same launch twice gives the same bits (ordered slab combine)
+    Cacc2 = C0.clone()
+    H.gemm_xp(fmt, A2x, B2x, 1000, 1000, 2401, C=Cacc2, out_mode=1)
+    assert torch.equal(Cacc, Cacc2)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The chain inside the step: args.mlp_gemm = 'f32_split' against 'f32' (v_mfma_f32_32x32x2_f32 throughout) on the same state.
+def _pair(V, T, h, num_verts, version=2, **over):
+    from nemo_cvpr2023_amd import synthetic as syn
+    from nemo_cvpr2023_amd.neural_motion_model import NEMO_VERSIONS
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(num_verts, seed=1, skin_nnz=4), syn.make_vposer_state(), syn.make_gmm()
+    ms = []
+    for mg in ('f32', 'f32_split'):
+        args = syn.published_args(batch_size=64, out_dir='', h_dim=h, mlp_gemm=mg, **over)
+        torch.manual_seed(0)
+        ms.append(NEMO_VERSIONS[version](args, seqs, H.DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm))
+    ms[1].load_state_dict({k: v.detach().clone() for k, v in ms[0].state_dict().items()}, strict=False)
+    return ms
+
+
+@pytest.mark.parametrize('V,T,h,nv,version,full', [(3, 10, 48, 100, 2, True), (3, 10, 48, 100, 3, False), (4, 50, 1000, 256, 2, True),
+                                                   (8, 300, 1000, 6890, 2, True), (8, 300, 1000, 512, 4, False)])
+def test_split_chain_matches_fp32_chain_in_the_step(V, T, h, nv, version, full, monkeypatch):
+    from nemo_cvpr2023_amd.engine import FitEngine
+    monkeypatch.setattr(FitEngine, 'XP_MIN_ROWS', 0)
+    over = dict(monotonic_network_n_nodes=20, phase_rbf_dim=16) if h < 100 else {}
+    m32, mxp = _pair(V, T, h, nv, version, **over)
+    assert mxp.engine.mlp_split and not m32.engine.mlp_split
+    with torch.no_grad():
+        for m in (m32, mxp):
+            m.learned_motion.rot_out.weight.mul_(2e3 if h >= 1000 else 1.0)
+    for m in (m32, mxp):
+        for o in m.optimizers:
+            o.param_groups[0]['lr'] = 0.0
+    torch.manual_seed(5)
+    B = V * T if full else 37
+    vi, fi = torch.randint(0, V, (B,)), torch.randint(0, T, (B,))
+    call = (lambda mdl: mdl.step(None, None, update=True, full_batch=True)) if full else (lambda mdl: mdl.step(vi, fi, update=True))
+    l32, i32 = call(m32)
+    lxp, ixp = call(mxp)
+    assert any('Xx' in w for w in mxp.engine.ws.values())           # the chain really ran on nemo_gemm_xp
+    for k in l32:
+        assert abs(float(lxp[k]) - float(l32[k])) <= 2e-6 * abs(float(l32[k])) + 1e-12, (k, lxp[k], l32[k])
+    assert float((ixp['j'] - i32['j']).abs().max()) <= 2e-6 * float(i32['j'].abs().max())
+    g32, gxp = dict(m32.named_parameters()), dict(mxp.named_parameters())
+    for k, p in g32.items():
+        if p.grad is None:
+            continue
+        a, b = p.grad.double(), gxp[k].grad.double()
+        scale = float(a.abs().max())
+        # two fp32-accurate evaluations: a few 1e-6 of the tensor's scale (the L1 mesh term's sign ties excepted: the 6890-vertex
+        # case runs with the term on, where single vertices may flip)
+        tol = 2e-5 if nv < 6890 else 2e-4
+        assert float((a - b).abs().max()) <= tol * scale + 1e-30, (k, float((a - b).abs().max()), scale)
