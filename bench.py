@@ -405,6 +405,7 @@ def build_model(cx, V, T, dtype, batch_size=512, skin_nnz=None, weight_smooth=0.
     args.gemm_dtype = dtype
     if mesh_blend:
         args.mesh_blend = mesh_blend            # 'f32': the mesh term's blend on the fp32 MFMA pipe (engine default: 'f32_split')
+        args.mlp_gemm = mesh_blend              # ... and the MotionNet chain too: the `f32_mfma_blend` leg is the step on the fp32 pipe only
     if weight_smooth:
         args.weight_smooth = weight_smooth      # BASELINE configs[4]: the temporal-smoothness term in the loop
     seqs = syn.SyntheticSequences(V, T, seed=1234)
@@ -524,6 +525,12 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
     on_b16x6, on_f16x3 = _mp.get('bf16x6', 0.0), _mp.get('f16x3', 0.0)
     if dtype != 'bf16' and getattr(engine, 'split_adj', False):
         on_f16x3 += parts['blend_adjoint']              # (the blend-shape adjoint in split precision too)
+    if dtype != 'bf16' and getattr(engine, 'mlp_split', False) and any('Xx' in w_ for w_ in engine.ws.values()):
+        # (the MotionNet chain on nemo_gemm_xp: three fp16 / six bf16 piece products per algorithmic product)
+        if engine.xp_fmt == 2:
+            on_f16x3 += parts['mlp']
+        else:
+            on_b16x6 += parts['mlp']
     step_peak = f_step / (on_bf16 / MFMA_PEAK_TFLOPS['bf16'] + on_b16x6 / MFMA_PEAK_TFLOPS['bf16x6'] + on_f16x3 / MFMA_PEAK_TFLOPS['f16x3'] +
                           (f_step - on_bf16 - on_b16x6 - on_f16x3) / MFMA_PEAK_TFLOPS['f32'])
     roof = {'kernel': tag, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(kpeak, 1),
@@ -988,12 +995,17 @@ def worker_main(opts):
                         'vertex->joint adjoint on the 16-bit matrix cores in fp32-equivalent arithmetic: both operands as two fp16 pieces of '
                         's x (11 + 11 significant bits + the remainder\'s sign = the fp32 value to one ulp), the three leading piece products '
                         'exact in fp32, fp32 accumulation (nemo_v2v_fused_split / _splitmem, csrc/smpl.hip MODE 5), and the blend-shape adjoint GEMM '
-                        'behind it the same way (nemo_gemm_f16x2mem_adj, from 256 samples on); everything else is the fp32 path.  '
-                        '`f32_mfma_blend` is the same step with these products on the fp32 MFMA pipe',
+                        'behind it the same way (nemo_gemm_f16x2mem_adj, from 256 samples on); round 6: the nn.Linear products of MotionNet '
+                        '(forward, dX, dW) likewise (nemo_gemm_xp fmt 2, from 1600 rows on; the range guard of the fp16 pieces is device-side: '
+                        'scale records, see include/nemo_hip.h); everything else is the fp32 path.  '
+                        '`f32_mfma_blend` is the same step with ALL these products on the fp32 MFMA pipe (mesh_blend = mlp_gemm = f32)',
                 'criteria': {'a_error_vs_float64': 'tests/test_gpu_ops.py::test_v2v_fused_split_is_fp32_equivalent: error of loss, d vp and dA '
                                                    'against a float64 evaluation of the same fp32 inputs <= 1.5 x the fp32-MFMA kernel\'s '
                                                    '(measured: dA rms 1.567e-7 against 1.578e-7, blend shapes x 100); the arithmetic itself: '
                                                    'tests/test_split_precision.py',
+                             'a2_mlp_error_vs_float64': 'tests/test_gpu_xp.py: nemo_gemm_xp error against float64 <= 1.5 x nemo_gemm_f32\'s in every '
+                                                        'role of the chain, operand magnitudes 1e-30 ... 1e30; the chain inside the step against the '
+                                                        'fp32 chain: losses to 2e-6, gradients to 2e-5 of their scale',
                              'b_parity_gates': 'every 1e-4 parity gate of tests/ runs on this default, unchanged',
                              'c_launch_time': 'profiles/r05_f32_split.md: 316 against 519 us per 8 x 300 launch (-39 %); this run: '
                                               'mesh_launch_ms against mesh_launch_ms_f32_mfma_blend below'},

@@ -144,20 +144,36 @@ int32_t nemo_cast_bf16_split3(int64_t rows, int64_t cols, const float* src, int6
  * NULL): v * out_scale and its transpose written as xp matrices (M x N, ld ldcx / N x M, ld ldcxt) -- the operands of the next
  * products of the chain; colsum as nemo_gemm_bf16mem.  ws as nemo_gemm_f32.
  * nemo_cast_xp: up to NEMO_CAST_XP_MAX fp32 matrices (rows x cols, row stride lds) -> their xp copies dst (rows x cols) and / or
- * dstT (cols x rows) of `scale` * src in ONE launch (fmt 3 ignores scale). */
+ * dstT (cols x rows) of `scale` * src in ONE launch (fmt 3 ignores scale).
+ * fmt 2 scale records (device memory, float[NEMO_XP_META_FLOATS], 16-byte aligned: [0] the power-of-two scale s of the pieces, [2, 34)
+ * absmax slots -- the absmax of the true values is their maximum; ZERO the record before its producer runs): the range guard of the
+ * fp16 pieces lives on the device, inside captured graphs.  nemo_absmax_multi accumulates max |src| into the slots (desc.overwrite:
+ * 32 blocks each STORE their partial maximum into their own slot -- the record needs no zeroing, the previous contents are gone);
+ * nemo_cast_xp with desc.meta reads the absmax, scales by s = 2^floor(log2(2^15 / absmax)) (|s x| < 2^15 < 65504: cannot overflow) and
+ * writes meta[0] = s; nemo_gemm_xp divides alpha by the operands' s (metaA[0], metaB[0]; NULL: 1) and, with metaOut, scales the
+ * result's copies by s_out = 2^floor(log2(2^15 / (|alpha| K absmax_A absmax_B + absmax_bias))) -- a bound on |v|, so the copies cannot
+ * overflow either --, writes metaOut[0] = s_out and accumulates the result's true absmax into metaOut's slots; metaZero (may be NULL): a
+ * record whose absmax slots the launch returns to zero (the caller orders it behind their last reader) -- how a record that a
+ * producer OUTSIDE the step's zero-filled arena accumulates into (X, by nemo_phase_embed_fwd_begin) is ready for the next pass.
+ * What a loose bound costs is relative precision of entries below 2^-18 of it (fp16 subnormals), never range. */
+#define NEMO_XP_META_FLOATS 64
 #define NEMO_CAST_XP_MAX 8
 typedef struct {
     const float* src; int64_t rows, cols, lds;
     uint16_t* dst; int64_t ldd;
     uint16_t* dstT; int64_t lddT;
     float scale;
+    float* meta;        /* fmt 2, may be NULL: scale record (absmax in, scale out); overrides `scale` */
 } nemo_cast_xp_desc;
+typedef struct { const float* src; int64_t rows, cols, lds; float* meta; int32_t overwrite; } nemo_absmax_desc;
 int64_t nemo_xp_ld(int32_t fmt, int64_t k);
 int32_t nemo_gemm_xp(int32_t fmt, int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
                      float* C, int64_t ldc, const float* bias, int32_t act, const uint16_t* maskx, int64_t ldmask,
                      int32_t mask_mode, float alpha, int32_t out_mode, uint16_t* Cx, int64_t ldcx, uint16_t* CxT, int64_t ldcxt,
-                     float out_scale, float* colsum, int64_t ldcs, void* ws, int64_t ws_bytes, void* stream);
+                     float out_scale, float* colsum, int64_t ldcs, const float* metaA, const float* metaB, const float* metaBias,
+                     float* metaOut, float* metaZero, void* ws, int64_t ws_bytes, void* stream);
 int32_t nemo_cast_xp(int32_t fmt, int32_t n, const nemo_cast_xp_desc* descs, void* stream);
+int32_t nemo_absmax_multi(int32_t n, const nemo_absmax_desc* descs, void* stream);
 /* Up to NEMO_GEMM_GROUP_MAX independent products C_i (op)= alpha_i * opA(A_i) @ opB(B_i) (out_mode 0 store / 1 C +=; no
  * bias / activation / mask) in ONE launch when they share a layout and their operands are 16-byte aligned -- the
  * parameter gradients dW_l = dY_l^T X_l of the whole MotionNet backward (nemo/neural_motion_model.py:58-71,130-148 under
@@ -200,7 +216,9 @@ int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t K, int64_t
                              const float* shifts, const float* scales, int64_t ldp,
                              const float* log_sigmas, const float* codes, const float* code_noise,
                              int32_t kernel_id, float* X, int64_t ldx, float* phase_out, float* den_out,
-                             void* stream);
+                             float* x_meta, void* stream);
+/* x_meta (may be NULL; ABI 17): the scale record of X (nemo_gemm_xp fmt 2) -- the launch accumulates max |X| into its absmax slots,
+ * so the split-precision MotionNet chain needs no pass over X of its own. */
 /* dX (N+1, ldx) -> d_shifts,d_scales (V rows of stride ldp), d_log_sigmas (D), d_codes (V,C); all
  * accumulated.  One launch: block (view, slice of 64 nodes) sums the phase-network gradient of its nodes over ALL samples of
  * its view in sample order (no cross-block sum, no atomics: deterministic, round 5); further blocks reduce the log_sigma /
@@ -246,7 +264,9 @@ int32_t nemo_rot6d_bwd(int64_t rows, int64_t J, const float* rot6d, int64_t ld6,
  * batch sizes otherwise keeps an earlier, larger batch's row there). */
 int32_t nemo_pose_bwd_fused(int64_t N, const float* rot6d, int64_t ld6, int32_t zero_nan, const float* dR,
                             const float* daa, float* d_rot6d, int64_t ldd, const float* aa, const float* dR2,
-                            float v2v_scale, float* dTR, int64_t ldt, int32_t zero_row, void* stream);
+                            float v2v_scale, float* dTR, int64_t ldt, int32_t zero_row, float* head_meta, void* stream);
+/* head_meta (may be NULL; ABI 17): the scale record of the head gradient (nemo_gemm_xp fmt 2) -- the launch accumulates the absmax of the
+ * 144 rotation columns it writes and, with dTR, of the three translation columns (row N included) into its slots. */
 /* Stand-alone conversions (API parity with hmr/geometry.py). */
 int32_t nemo_rotmat_to_aa(int64_t M, const float* R, int32_t zero_nan, float* aa, void* stream);
 /* hmr/geometry.py:9-45: quaternion-form Rodrigues, angle = ||theta + 1e-8||; form=1 selects the
@@ -553,8 +573,9 @@ int32_t nemo_phase_embed_fwd_begin(int64_t N, int64_t V, int64_t T, int64_t K, i
                                    const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase,
                                    const float* shifts, const float* scales, int64_t ldp, const float* log_sigmas,
                                    const float* codes, const float* code_noise, int32_t kernel_id, float* X, int64_t ldx,
-                                   float* phase_out, float* den_out, void* z0, int64_t bytes0, void* z1, int64_t bytes1,
-                                   nemo_adam_seg* segs_dev, int32_t n_seg, double beta1, double beta2, void* stream);
+                                   float* phase_out, float* den_out, float* x_meta, void* z0, int64_t bytes0, void* z1,
+                                   int64_t bytes1, nemo_adam_seg* segs_dev, int32_t n_seg, double beta1, double beta2, void* stream);
+/* (x_meta must lie OUTSIDE the two zero-filled ranges: their blocks run beside the phase blocks) */
 
 /* Instance-code regulariser of NemoV3 / V4 (nemo/neural_motion_model.py:3864-3867):
  * scalar_out += mean(x[0..n)^2);  grad (may be NULL) += gscale * x. */

@@ -27,7 +27,11 @@ class GemmProblem(Structure):
 
 class CastXpDesc(Structure):
     _fields_ = [('src', c_void_p), ('rows', c_int64), ('cols', c_int64), ('lds', c_int64), ('dst', c_void_p), ('ldd', c_int64),
-                ('dstT', c_void_p), ('lddT', c_int64), ('scale', c_float)]
+                ('dstT', c_void_p), ('lddT', c_int64), ('scale', c_float), ('meta', c_void_p)]
+
+
+class AbsmaxDesc(Structure):
+    _fields_ = [('src', c_void_p), ('rows', c_int64), ('cols', c_int64), ('lds', c_int64), ('meta', c_void_p), ('overwrite', c_int32)]
 
 
 class AdamSeg(Structure):
@@ -61,21 +65,22 @@ SIGNATURES = {
     'nemo_cast_bf16_split3': (i32, [i64, i64, ptr, i64, ptr, i64, i32, ptr]),
     'nemo_xp_ld': (i64, [i32, i64]),
     'nemo_gemm_xp': (i32, [i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32, f32, i32, ptr, i64, ptr, i64,
-                           f32, ptr, i64, ptr, i64, ptr]),
+                           f32, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i64, ptr]),
     'nemo_cast_xp': (i32, [i32, i32, POINTER(CastXpDesc), ptr]),
+    'nemo_absmax_multi': (i32, [i32, POINTER(AbsmaxDesc), ptr]),
     'nemo_gemm_grouped_f32': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),
     'nemo_gemm_grouped_bf16': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),
     'nemo_colsum_f32': (i32, [ptr, i64, i64, i64, ptr, ptr]),
     'nemo_colsum_multi': (i32, [i32, POINTER(ColsumDesc), ptr]),
     'nemo_phase_embed_fwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
-                                   i32, ptr, i64, ptr, ptr, ptr]),
+                                   i32, ptr, i64, ptr, ptr, ptr, ptr]),
     'nemo_phase_embed_bwd': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i32, ptr,
                                    ptr, i64, ptr, ptr, ptr, ptr, ptr, i32, ptr]),
     'nemo_phase_embed_bwd_colsum': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i32, ptr,
                                           ptr, i64, ptr, ptr, ptr, ptr, ptr, i32, POINTER(ColsumDesc), i32, ptr]),
     'nemo_rot6d_fwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr]),
     'nemo_rot6d_bwd': (i32, [i64, i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr]),
-    'nemo_pose_bwd_fused': (i32, [i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, i32, ptr]),
+    'nemo_pose_bwd_fused': (i32, [i64, ptr, i64, i32, ptr, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, i32, ptr, ptr]),
     'nemo_rotmat_to_aa': (i32, [i64, ptr, i32, ptr, ptr]),
     'nemo_rodrigues_fwd': (i32, [i64, ptr, i32, ptr, ptr]),
     'nemo_rodrigues_bwd': (i32, [i64, ptr, ptr, ptr, ptr]),
@@ -132,7 +137,7 @@ SIGNATURES = {
     'nemo_sqmean_fwd_bwd': (i32, [i64, ptr, ptr, ptr, f32, ptr]),
     'nemo_step_begin': (i32, [ptr, i64, ptr, i64, ptr, i32, c_double, c_double, ptr]),
     'nemo_phase_embed_fwd_begin': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
-                                         i32, ptr, i64, ptr, ptr, ptr, i64, ptr, i64, ptr, i32, c_double, c_double, ptr]),
+                                         i32, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i32, c_double, c_double, ptr]),
     'nemo_scale_neg_rowsum': (i32, [i64, i64, ptr, i64, ptr, ptr]),
 }
 

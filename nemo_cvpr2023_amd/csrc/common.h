@@ -138,4 +138,22 @@ __device__ __forceinline__ void nemo_colsum_finish(float t, long n, long N, floa
     if (threadIdx.x < 64 && n < N) out[n] += (cfin[0][threadIdx.x] + cfin[1][threadIdx.x]) + (cfin[2][threadIdx.x] + cfin[3][threadIdx.x]);
 }
 
+// ---- scale records of the fp16 split-precision copies (include/nemo_hip.h nemo_gemm_xp fmt 2; csrc/gemm_xp.h) ------------------
+namespace nemo_meta {
+constexpr int META_FLOATS = 64, META_SLOTS = 32;            // a scale record: [0] scale, [2, 2 + META_SLOTS) absmax slots
+// the absmax a record holds (every lane of the calling wave gets it)
+__device__ __forceinline__ float meta_absmax(const float* m) {
+    float v = m[2 + (threadIdx.x & (META_SLOTS - 1))];
+#pragma unroll
+    for (int off = META_SLOTS / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ void meta_absmax_put(float* m, int slot, float mx) {
+    float* p = m + 2 + (slot & (META_SLOTS - 1));
+    // (the slot only grows: a value that is not above what is already there needs no atomic)
+    if (mx > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, mx));
+}
+
+}  // namespace nemo_meta
+
 #endif

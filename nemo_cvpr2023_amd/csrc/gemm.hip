@@ -1003,12 +1003,14 @@ extern "C" int32_t nemo_gemm_f16x2mem_adj(int64_t M, int64_t N, int64_t K, const
 // products, power-of-two scales carried by the caller (alpha = 1 / (s_A s_B), out_scale = the scale of the result's copies).
 // Operands / copies are "xp matrices" (include/nemo_hip.h).
 extern "C" int64_t nemo_xp_ld(int32_t fmt, int64_t k) { return (fmt != 2 && fmt != 3) || k < 0 ? -1 : xp::ld_for(fmt, k); }
+static_assert(NEMO_XP_META_FLOATS == xp::META_FLOATS, "scale record size");
 
 extern "C" int32_t nemo_gemm_xp(int32_t fmt, int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, const uint16_t* B,
                                 int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t act, const uint16_t* maskx,
                                 int64_t ldmask, int32_t mask_mode, float alpha, int32_t out_mode, uint16_t* Cx, int64_t ldcx,
-                                uint16_t* CxT, int64_t ldcxt, float out_scale, float* colsum, int64_t ldcs, void* ws,
-                                int64_t ws_bytes, void* stream) {
+                                uint16_t* CxT, int64_t ldcxt, float out_scale, float* colsum, int64_t ldcs, const float* metaA,
+                                const float* metaB, const float* metaBias, float* metaOut, float* metaZero, void* ws, int64_t ws_bytes,
+                                void* stream) {
     if ((fmt != 2 && fmt != 3) || M < 0 || N < 0 || K < 0 || !A || !B) return NEMO_EINVAL;
     if (!C && !Cx && !CxT) return NEMO_EINVAL;
     if ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)Cx) | ((uintptr_t)CxT) | ((uintptr_t)maskx)) & 15) return NEMO_EINVAL;
@@ -1020,6 +1022,9 @@ extern "C" int32_t nemo_gemm_xp(int32_t fmt, int64_t M, int64_t N, int64_t K, co
     g.A = A; g.B = B; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.C = C; g.ldc = ldc; g.out_mode = out_mode;
     g.bias = bias; g.act = act; g.alpha = alpha; g.maskx = mask_mode ? maskx : nullptr; g.ldmask = ldmask; g.mask_mode = mask_mode;
     g.Cx = Cx; g.ldcx = ldcx; g.CxT = CxT; g.ldcxt = ldcxt; g.out_scale = out_scale; g.colsum = colsum; g.ldcs = ldcs;
+    g.metaA = fmt == 2 ? metaA : nullptr; g.metaB = fmt == 2 ? metaB : nullptr; g.metaBias = fmt == 2 ? metaBias : nullptr;
+    g.metaOut = (fmt == 2 && (Cx || CxT)) ? metaOut : nullptr;
+    g.metaZero = fmt == 2 ? metaZero : nullptr;
     g.counters = reinterpret_cast<int*>(ws);
     g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES);
     // tile: 128 x 128 while its grid is at most ~2 rounds of the chip, 128 x 256 beyond (fewer bytes through L2 -> LDS per product)
@@ -1059,6 +1064,7 @@ extern "C" int32_t nemo_cast_xp(int32_t fmt, int32_t n, const nemo_cast_xp_desc*
         xp::CastDesc& d = a.d[m++];
         d.src = q.src; d.rows = q.rows; d.cols = q.cols; d.lds = q.lds; d.dst = q.dst; d.ldd = q.ldd; d.dstT = q.dstT; d.lddT = q.lddT;
         d.scale = fmt == 2 ? q.scale : 1.f;
+        d.meta = fmt == 2 ? q.meta : nullptr;
         d.tile0 = tiles; d.tiles_c = nemo_cdiv(q.cols, 32);
         tiles += d.tiles_c * nemo_cdiv(q.rows, 32);
     }
@@ -1066,6 +1072,27 @@ extern "C" int32_t nemo_cast_xp(int32_t fmt, int32_t n, const nemo_cast_xp_desc*
     if (m == 0) return NEMO_OK;
     if (fmt == 3) hipLaunchKernelGGL(xp::cast_xp_kernel<3>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(xp::cast_xp_kernel<2>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
+extern "C" int32_t nemo_absmax_multi(int32_t n, const nemo_absmax_desc* descs, void* stream) {
+    if (n < 0 || n > xp::MAX_CAST || (n && !descs)) return NEMO_EINVAL;
+    xp::AbsmaxArgs a{};
+    int blocks = 0, m = 0;
+    for (int i = 0; i < n; ++i) {
+        const nemo_absmax_desc& q = descs[i];
+        if (q.rows < 0 || q.cols < 0 || !q.meta || q.lds < q.cols || ((q.rows && q.cols) && !q.src)) return NEMO_EINVAL;
+        if ((q.rows == 0 || q.cols == 0) && !q.overwrite) continue;
+        xp::AbsmaxDesc& d = a.d[m++];
+        d.src = q.src; d.rows = q.rows; d.cols = q.cols; d.lds = q.lds; d.meta = q.meta; d.block0 = blocks;
+        d.overwrite = q.overwrite ? 1 : 0;
+        long nb = (q.rows * q.cols + 4095) / 4096;          // ~16 elements per thread
+        blocks += q.overwrite ? xp::META_SLOTS : (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
+    }
+    a.n = m;
+    if (m == 0) return NEMO_OK;
+    hipLaunchKernelGGL(xp::absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -40,6 +40,11 @@
 
 namespace xp {
 
+using nemo_meta::META_FLOATS;
+using nemo_meta::META_SLOTS;
+using nemo_meta::meta_absmax;
+using nemo_meta::meta_absmax_put;
+
 using glds::f32x16;
 using glds::i32x4;
 typedef __bf16 xbf16x8 __attribute__((ext_vector_type(8)));
@@ -54,7 +59,16 @@ struct Args {
     const unsigned short* maskx; long ldmask; int mask_mode;      // 0 none, 1: v = piece0(mask[m][n]) > 0 ? v : 0
     unsigned short* Cx; long ldcx;                          // >= 32 NP ceil(N / 32)
     unsigned short* CxT; long ldcxt;                        // >= 32 NP ceil(M / 32)
-    float out_scale;                                        // pieces of v * out_scale (1 for bf16 pieces)
+    float out_scale;                                        // pieces of v * out_scale (1 for bf16 pieces; fmt 2 without metaOut)
+    // fmt 2 (fp16 pieces): device-resident scale records, float[META_FLOATS] = {power-of-two scale s of the pieces, -, 32 absmax slots of
+    // the TRUE values (the absmax is their maximum: same-address atomics of ~1200 waves serialise, 15 us per launch)}.
+    // metaA / metaB (may be NULL: scale 1): the operands' records; alpha is divided by s_A s_B in the kernel.  metaOut (may be NULL):
+    // the record of the result's copies -- the kernel derives s_out = 2^floor(log2(2^15 / bound)) from the BOUND
+    // |alpha| K absmax_A absmax_B + absmax_bias >= |v| (no overflow by construction), writes it to metaOut[0] and accumulates the
+    // result's true absmax into metaOut's slots (atomic max over non-negative floats; zero before the launch).
+    const float* metaA; const float* metaB; const float* metaBias; float* metaOut;
+    float* metaZero;                                        // may be NULL: a record whose absmax slots this launch returns to zero (it is
+                                                            // stream-ordered behind their last reader; its scale [0] stays)
     float* colsum; long ldcs;                               // rows: one per 32-row band, 2 ceil(M / 64) of them
     float* slabs; int* counters;
     long k_chunk; int split;                                // K range per slice (multiple of 32)
@@ -90,6 +104,17 @@ struct Geo {
     static constexpr int LDS = (RING + (DUMMY ? 1024 : 0) > 8 * EPI ? RING + (DUMMY ? 1024 : 0) : 8 * EPI);
     static_assert(LDS <= 163840, "160 KiB of LDS per workgroup");
 };
+
+// the power of two s with s * bound in [2^(top - 1), 2^top), exponent clamped to [-120, 120] (only ever towards SMALLER |s x|: a
+// clamped scale costs precision, never range); bound <= 0 or not finite: 1
+__device__ __forceinline__ float pow2_scale(float bound, int top) {
+    if (!(bound > 0.f) || !(bound < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(bound, &e);                    // bound = m 2^e, m in [0.5, 1)
+    int k = top - e;
+    k = k > 120 ? 120 : (k < -120 ? -120 : k);
+    return ldexpf(1.f, k);
+}
 
 constexpr int OOB = (int)0x80000000u;      // a buffer offset beyond every descriptor of this kernel (extents < 2^31)
 
@@ -156,6 +181,21 @@ __global__ __launch_bounds__(768) void gemm_xp_kernel(Args g) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+
+    // fmt 2: the operands' scales leave through alpha; the scale of the result's copies from the bound on |v| (read here, at the top:
+    // five dependent global loads in front of the epilogue cost ~5 us per launch)
+    float alpha = g.alpha, out_scale = g.out_scale;
+    if constexpr (NP == 2) {
+        if (!loader) {
+            const float sA = g.metaA ? g.metaA[0] : 1.f, sB = g.metaB ? g.metaB[0] : 1.f;
+            alpha = (g.alpha / sA) / sB;
+            if (g.metaOut) {
+                const float mA = g.metaA ? meta_absmax(g.metaA) : 1.f, mB = g.metaB ? meta_absmax(g.metaB) : 1.f;
+                const float bound = fabsf(g.alpha) * (float)g.K * mA * mB + (g.metaBias ? meta_absmax(g.metaBias) : 0.f);
+                out_scale = pow2_scale(bound, 15);
+            }
+        }
+    }
 
     const unsigned smem_byte = (unsigned)reinterpret_cast<unsigned long long>(smem);
 
@@ -341,6 +381,10 @@ __global__ __launch_bounds__(768) void gemm_xp_kernel(Args g) {
     const int mlim_ = edge ? mrem : (1 << 20);
     auto row_limit = [&]() { int v = mlim_; asm volatile("" : "+v"(v)); return v; };
 
+    if constexpr (NP == 2) {
+        if (g.metaOut && tile == 0 && threadIdx.x == 0) g.metaOut[0] = out_scale;
+        if (g.metaZero && tile == 0 && threadIdx.x < META_SLOTS) g.metaZero[2 + threadIdx.x] = 0.f;
+    }
     // final values in place of the accumulators
     const float slope = g.act == 1 ? 0.f : (g.act == 2 ? 0.01f : 1.f);
 #pragma unroll
@@ -351,7 +395,7 @@ __global__ __launch_bounds__(768) void gemm_xp_kernel(Args g) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = g.alpha * av[i][j][r] + bv;
+                const float v = alpha * av[i][j][r] + bv;
                 av[i][j][r] = v > 0.f ? v : v * slope;
             }
     }
@@ -392,6 +436,21 @@ __global__ __launch_bounds__(768) void gemm_xp_kernel(Args g) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) av[i][j][r] = rowc(i, r) >= lim ? 0.f : av[i][j][r];
+        }
+    }
+
+    if constexpr (NP == 2) {
+        if (g.metaOut) {                                    // the result's true absmax (rows / columns beyond the matrix: zero unless
+            float mx = 0.f;                                 // an interior tile, where every element is valid)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(av[i][j][r]));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            if (lane == 0) meta_absmax_put(g.metaOut, tile * 8 + wid, mx);
         }
     }
 
@@ -463,7 +522,7 @@ __global__ __launch_bounds__(768) void gemm_xp_kernel(Args g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     unsigned short pc[NP];
-                    split_pieces<NP>(av[i][j][r] * g.out_scale, pc);
+                    split_pieces<NP>(av[i][j][r] * out_scale, pc);
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
                         *reinterpret_cast<unsigned short*>(ws + (rowc(i, r) + 4 * lh) * SROW + p * 64 + l31 * 2) = pc[p];
@@ -493,7 +552,7 @@ __global__ __launch_bounds__(768) void gemm_xp_kernel(Args g) {
                 for (int q = 0; q < 4; ++q) {
                     unsigned short pc[4][NP];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) split_pieces<NP>(av[i][j][4 * q + c] * g.out_scale, pc[c]);
+                    for (int c = 0; c < 4; ++c) split_pieces<NP>(av[i][j][4 * q + c] * out_scale, pc[c]);
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
                         uint2 pk;
@@ -571,6 +630,7 @@ struct CastDesc {
     unsigned short* dst; long ldd;                          // [rows][xp over cols] or NULL
     unsigned short* dstT; long lddT;                        // [cols][xp over rows] or NULL
     float scale;
+    float* meta;                                            // fmt 2, may be NULL: scale record, absmax in, scale = 2^floor(log2(2^15 / absmax)) out
     int tile0, tiles_c;                                     // first block of this matrix in the launch, 32-column tiles per row of tiles
 };
 constexpr int MAX_CAST = 8;
@@ -587,9 +647,14 @@ __global__ __launch_bounds__(256) void cast_xp_kernel(CastArgs a) {
     const int bt = (int)blockIdx.x - d.tile0;
     const long r0 = (long)(bt / d.tiles_c) * 32, c0 = (long)(bt % d.tiles_c) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    float scale = d.scale;
+    if (NP == 2 && d.meta) {
+        scale = pow2_scale(meta_absmax(d.meta), 15);
+        if (bt == 0 && threadIdx.x == 0) d.meta[0] = scale;
+    }
     for (int i = ty; i < 32; i += 8) {
         const long r = r0 + i, c = c0 + tx;
-        t[i][tx] = (r < d.rows && c < d.cols) ? d.src[r * d.lds + c] * d.scale : 0.f;
+        t[i][tx] = (r < d.rows && c < d.cols) ? d.src[r * d.lds + c] * scale : 0.f;
     }
     __syncthreads();
     if (d.dst) {
@@ -613,6 +678,70 @@ __global__ __launch_bounds__(256) void cast_xp_kernel(CastArgs a) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) o[p * 32] = pc[p];
         }
+    }
+}
+
+// absmax slots of `meta` = max(themselves, max |src|) for a list of matrices (grid-stride over each; slots zero or previous maxima)
+struct AbsmaxDesc { const float* src; long rows, cols, lds; float* meta; int block0; int overwrite; };
+struct AbsmaxArgs { AbsmaxDesc d[MAX_CAST]; int n; };
+
+__global__ __launch_bounds__(256) void absmax_kernel(AbsmaxArgs a) {
+    int di = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_CAST; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.d[i].block0) di = i;
+    const AbsmaxDesc& d = a.d[di];
+    const int nb = (di + 1 < a.n ? a.d[di + 1].block0 : (int)gridDim.x) - d.block0;
+    // block b of the matrix's nb takes rows [b R / nb, (b + 1) R / nb): coalesced row segments, no index division per element
+    // (the first form -- a flat grid-stride loop with e / cols, e % cols per element -- took 53 us for the chain's weights)
+    const long b = (long)blockIdx.x - d.block0;
+    const long r0 = b * d.rows / nb, r1 = (b + 1) * d.rows / nb;
+    float mx = 0.f;
+    // eight rows' loads in flight per thread (one load per round trip took 48 us for the chain's weights: 124 dependent trips)
+    const float* src = d.src;
+    const long lds = d.lds, cols = d.cols;
+    if ((lds & 3) == 0 && (cols & 3) == 0 && (reinterpret_cast<unsigned long long>(src) & 15) == 0) {
+        const long c4n = cols >> 2;
+        for (long c4 = threadIdx.x; c4 < c4n; c4 += 256)
+            for (long r = r0; r < r1; r += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = r + u < r1 ? *reinterpret_cast<const float4*>(src + (r + u) * lds + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+            }
+    } else {
+        // unaligned / narrow rows (nn.Linear(105, h), the head gradient): the block's rows as one flat range of (row, 64-column group)
+        const long cg = (cols + 63) >> 6;
+        for (long r = r0; r < r1; r += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long rr = r + 4 * u + (threadIdx.x >> 6);
+                float acc = 0.f;
+                if (rr < r1)
+                    for (long g2 = 0; g2 < cg; ++g2) {
+                        const long c = (g2 << 6) + (threadIdx.x & 63);
+                        if (c < cols) acc = fmaxf(acc, fabsf(src[rr * lds + c]));
+                    }
+                v[u] = acc;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mx = fmaxf(mx, v[u]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    // (NaN: fmaxf drops it -- a NaN operand reaches the result through the pieces themselves)
+    __shared__ float wmx[4];
+    if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float bm = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+        // overwrite: this matrix has exactly META_SLOTS blocks and block b OWNS slot b -- plain stores, nothing to zero beforehand
+        if (d.overwrite) d.meta[2 + ((int)blockIdx.x - d.block0)] = bm;
+        else meta_absmax_put(d.meta, (int)blockIdx.x, bm);
     }
 }
 

@@ -65,6 +65,7 @@ struct PhaseFwdArgs {
     const float* shifts; const float* scales; long ldp;
     const float* log_sigmas; const float* codes; const float* code_noise;
     int kid; float* X; long ldx; float* phase_out; float* den_out;
+    float* x_meta;      // may be NULL: scale record of X (include/nemo_hip.h nemo_gemm_xp fmt 2) -- the rows' absmax is accumulated into it
 };
 __device__ __forceinline__ void phase_embed_fwd_body(const PhaseFwdArgs& a, long bid) {
     const long N = a.N, T = a.T, ldp = a.ldp, ldx = a.ldx;
@@ -103,13 +104,17 @@ __device__ __forceinline__ void phase_embed_fwd_body(const PhaseFwdArgs& a, long
         if (den_out && lane == 0) den_out[s] = o - z + 1e-6f;
     }
     float* xr = X + s * ldx;
+    float mx = 0.f;
     if (D > 0) {
         for (int d = lane; d < D; d += 64) {
             const float diff = ph - lin01(d, D);        // centres = linspace(0,1,D)  rbf.py:38-39
-            xr[d] = rbf_phi(kid, (diff * diff) / expf(log_sigmas[d]));
+            const float u = rbf_phi(kid, (diff * diff) / expf(log_sigmas[d]));
+            xr[d] = u;
+            mx = fmaxf(mx, fabsf(u));
         }
     } else if (lane == 0) {
         xr[0] = ph;
+        mx = fabsf(ph);
     }
     const int off = D > 0 ? D : 1;
     for (int c = lane; c < C; c += 64) {
@@ -119,6 +124,12 @@ __device__ __forceinline__ void phase_embed_fwd_body(const PhaseFwdArgs& a, long
             if (code_noise) cv += code_noise[s * C + c];
         }
         xr[off + c] = cv;
+        mx = fmaxf(mx, fabsf(cv));
+    }
+    if (a.x_meta) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) nemo_meta::meta_absmax_put(a.x_meta, (int)s, mx);
     }
 }
 __global__ __launch_bounds__(256) void phase_embed_fwd_kernel(PhaseFwdArgs a) { phase_embed_fwd_body(a, (long)blockIdx.x); }
@@ -315,23 +326,38 @@ __global__ __launch_bounds__(256) void pose_bwd_fused_kernel(long N, const float
                                                              float* __restrict__ d_rot6d, long ldd,
                                                              const float* __restrict__ aa,
                                                              const float* __restrict__ dR2, float scale,
-                                                             float* __restrict__ dTR, long ldt, int zero_row) {
+                                                             float* __restrict__ dTR, long ldt, int zero_row,
+                                                             float* __restrict__ head_meta) {
     if (blockIdx.x == gridDim.x - 1) {                 // the reduction block
         // row N of the head gradient belongs to the "phase 0 / zero code" row of the MLP: its rotation columns carry no
         // gradient.  Workspaces are shared by batch sizes, so whatever an earlier, larger batch left there is cleared
         if (zero_row && threadIdx.x < 144) d_rot6d[N * ldd + threadIdx.x] = 0.f;
         if (!dTR) return;
         __shared__ float red[16];
+        float mx = 0.f;
         for (int c = 0; c < 3; ++c) {
             float s = 0.f;
-            for (long r = threadIdx.x; r < N; r += blockDim.x) s += dTR[r * ldt + c];
+            for (long r = threadIdx.x; r < N; r += blockDim.x) {
+                const float v = dTR[r * ldt + c];
+                s += v;
+                mx = fmaxf(mx, fabsf(v));
+            }
             const float t = block_sum(s, red);
-            if (threadIdx.x == 0) dTR[N * ldt + c] = -t;
+            if (threadIdx.x == 0) {
+                dTR[N * ldt + c] = -t;
+                mx = fmaxf(mx, fabsf(t));
+            }
+        }
+        if (head_meta) {                               // the three translation columns of the head gradient, row N included
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            if ((threadIdx.x & 63) == 0) nemo_meta::meta_absmax_put(head_meta, (int)(threadIdx.x >> 6), mx);
         }
         return;
     }
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * 24) return;
+    float hmx = 0.f;
+    if (i < N * 24) {
     const long row = i / 24;
     const int j = (int)(i % 24);
     float x[6], Rm[9], g[9];
@@ -364,7 +390,13 @@ __global__ __launch_bounds__(256) void pose_bwd_fused_kernel(long N, const float
     rot6d_bwd(x, g, dx);
     float* dst = d_rot6d + row * ldd + j * 6;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dst[k] = dx[k];
+    for (int k = 0; k < 6; ++k) { dst[k] = dx[k]; hmx = fmaxf(hmx, fabsf(dx[k])); }
+    }
+    if (head_meta) {                                   // absmax of the 144 rotation columns written here (whole waves get here)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hmx = fmaxf(hmx, __shfl_xor(hmx, o, 64));
+        if ((threadIdx.x & 63) == 0) nemo_meta::meta_absmax_put(head_meta, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), hmx);
+    }
 }
 
 __global__ __launch_bounds__(1024) void neg_rowsum_kernel(long N, int cols, const float* __restrict__ X,
@@ -386,13 +418,13 @@ static int32_t phase_fwd_args(PhaseFwdArgs* a, int64_t N, int64_t V, int64_t T, 
                               const int64_t* view_idx, const int64_t* frame_idx, const float* raw_phase, const float* shifts,
                               const float* scales, int64_t ldp, const float* log_sigmas, const float* codes,
                               const float* code_noise, int32_t kernel_id, float* X, int64_t ldx, float* phase_out,
-                              float* den_out) {
+                              float* den_out, float* x_meta) {
     if (N < 0 || V <= 0 || K <= 0 || D < 0 || C < 0 || !X || !shifts || !scales) return NEMO_EINVAL;
     if (N > 0 && (!view_idx || (!frame_idx && !raw_phase))) return NEMO_EINVAL;
     if ((D > 0 && !log_sigmas) || (C > 0 && !codes) || kernel_id < 0 || kernel_id > 10) return NEMO_EINVAL;
     if (ldx < (D > 0 ? D : 1) + C || ldp < K) return NEMO_EINVAL;
     *a = PhaseFwdArgs{(long)N, (long)V, (long)T, (int)K, (int)D, (int)C, view_idx, frame_idx, raw_phase, shifts, scales,
-                      (long)ldp, log_sigmas, codes, code_noise, (int)kernel_id, X, (long)ldx, phase_out, den_out};
+                      (long)ldp, log_sigmas, codes, code_noise, (int)kernel_id, X, (long)ldx, phase_out, den_out, x_meta};
     return NEMO_OK;
 }
 
@@ -401,10 +433,10 @@ extern "C" int32_t nemo_phase_embed_fwd(int64_t N, int64_t V, int64_t T, int64_t
                                         const float* raw_phase, const float* shifts, const float* scales,
                                         int64_t ldp, const float* log_sigmas, const float* codes,
                                         const float* code_noise, int32_t kernel_id, float* X, int64_t ldx,
-                                        float* phase_out, float* den_out, void* stream) {
+                                        float* phase_out, float* den_out, float* x_meta, void* stream) {
     PhaseFwdArgs a;
     const int32_t rc = phase_fwd_args(&a, N, V, T, K, D, C, view_idx, frame_idx, raw_phase, shifts, scales, ldp, log_sigmas,
-                                      codes, code_noise, kernel_id, X, ldx, phase_out, den_out);
+                                      codes, code_noise, kernel_id, X, ldx, phase_out, den_out, x_meta);
     if (rc) return rc;
     hipLaunchKernelGGL(phase_embed_fwd_kernel, dim3(nemo_cdiv(N + 1, 4)), dim3(256), 0, (hipStream_t)stream, a);
     NEMO_LAUNCH_CHECK();
@@ -417,12 +449,15 @@ extern "C" int32_t nemo_phase_embed_fwd_begin(int64_t N, int64_t V, int64_t T, i
                                               const float* shifts, const float* scales, int64_t ldp,
                                               const float* log_sigmas, const float* codes, const float* code_noise,
                                               int32_t kernel_id, float* X, int64_t ldx, float* phase_out, float* den_out,
-                                              void* z0, int64_t bytes0, void* z1, int64_t bytes1, nemo_adam_seg* segs_dev,
+                                              float* x_meta, void* z0, int64_t bytes0, void* z1, int64_t bytes1, nemo_adam_seg* segs_dev,
                                               int32_t n_seg, double beta1, double beta2, void* stream) {
     PhaseFwdArgs a;
     const int32_t rc = phase_fwd_args(&a, N, V, T, K, D, C, view_idx, frame_idx, raw_phase, shifts, scales, ldp, log_sigmas,
-                                      codes, code_noise, kernel_id, X, ldx, phase_out, den_out);
+                                      codes, code_noise, kernel_id, X, ldx, phase_out, den_out, x_meta);
     if (rc) return rc;
+    // (x_meta must not lie in [z0, z0 + bytes0) / [z1, z1 + bytes1): the zero-fill blocks of this launch run beside the phase blocks)
+    if (x_meta && (((char*)x_meta >= (char*)z0 && (char*)x_meta < (char*)z0 + bytes0) || ((char*)x_meta >= (char*)z1 && (char*)x_meta < (char*)z1 + bytes1)))
+        return NEMO_EINVAL;
     if (bytes0 < 0 || bytes1 < 0 || (bytes0 && !z0) || (bytes1 && !z1) || ((bytes0 | bytes1) & 3) ||
         (((uintptr_t)z0 | (uintptr_t)z1) & 15) || n_seg < 0 || n_seg > NEMO_ADAM_MAX_SEG)
         return NEMO_EINVAL;
@@ -827,14 +862,14 @@ extern "C" int32_t nemo_rot6d_bwd(int64_t rows, int64_t J, const float* rot6d, i
 extern "C" int32_t nemo_pose_bwd_fused(int64_t N, const float* rot6d, int64_t ld6, int32_t zero_nan,
                                        const float* dR, const float* daa, float* d_rot6d, int64_t ldd,
                                        const float* aa, const float* dR2, float v2v_scale,
-                                       float* dTR, int64_t ldt, int32_t zero_row, void* stream) {
+                                       float* dTR, int64_t ldt, int32_t zero_row, float* head_meta, void* stream) {
     if (N < 0 || !rot6d || !d_rot6d || ld6 < 144 || ldd < 144 || (dR2 && !aa) || (dTR && ldt < 3))
         return NEMO_EINVAL;
     if (N == 0) return NEMO_OK;
     const unsigned blocks = (unsigned)nemo_cdiv(N * 24, 256) + 1;          // + the reduction block
     hipLaunchKernelGGL(pose_bwd_fused_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (long)N, rot6d,
                        (long)ld6, (int)zero_nan, dR, daa, d_rot6d, (long)ldd, aa, dR2, v2v_scale, dTR, (long)ldt,
-                       (int)zero_row);
+                       (int)zero_row, head_meta);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -280,17 +280,23 @@ class FitEngine:
         if mb not in ('f32', 'f32_split'):
             raise ValueError(f"args.mesh_blend must be 'f32' or 'f32_split', got {mb!r}")
         self.mesh_split = mb == 'f32_split' and not self.bf16
-        # mlp_gemm (round 6), fp32 builds only: 'f32_split' (default) -- the nn.Linear products of MotionNet (forward, activation and
-        # parameter gradients; nemo/neural_motion_model.py:58-71, :130-148) on the bf16 matrix cores in fp32-EQUIVALENT arithmetic:
-        # every operand as three bf16 pieces (8 + 8 + 8 bits = the fp32 value exactly, fp32's exponent range: no scales, no range
-        # condition), the six piece products of weight >= 2^-24, fp32 accumulation (csrc/gemm_xp.h, nemo_gemm_xp fmt 3); error against
-        # float64 <= the fp32-MFMA GEMM's (tests/test_gpu_xp.py), from XP_MIN_ROWS rows on.  'f32': v_mfma_f32_32x32x2_f32 throughout
-        # (rounds 1 - 5; bench.py's `f32_mfma_blend` leg).  args.mlp_gemm, overridden by NEMO_MLP_GEMM.
+        # mlp_gemm (round 6), fp32 builds only -- the nn.Linear products of MotionNet (forward, activation and parameter gradients;
+        # nemo/neural_motion_model.py:58-71, :130-148) on the 16-bit matrix cores in fp32-EQUIVALENT arithmetic (csrc/gemm_xp.h,
+        # nemo_gemm_xp), from XP_MIN_ROWS rows on (below, the fp32 kernels' smaller tiles win):
+        #   'f32_split' (default) = 'f32_split2': two fp16 pieces per operand (11 + 11 bits + the remainder's sign), three piece products,
+        #       fp32 accumulation; a k-block of a row is exactly one 128-byte line.  fp16's narrow exponent is handled ON THE DEVICE: every
+        #       copy carries a scale record {power-of-two scale, absmax}; cast-made copies are scaled from their absmax, GEMM-made copies
+        #       from the bound |alpha| K absmax_A absmax_B + absmax_bias on their entries -- no copy can overflow, whatever the magnitudes
+        #       (include/nemo_hip.h; tests/test_gpu_xp.py::test_fp16_pieces_cannot_overflow_and_degrade_gracefully).
+        #   'f32_split3': three bf16 pieces (8 + 8 + 8 bits = the fp32 value exactly, fp32's exponent range: no scales at all), six piece
+        #       products -- 1.5 x the bytes, 2 x the matrix work (8 x 300: 1.096 against 1.089 ms, C4: 81.9 against 71.8 ms).
+        #   'f32': v_mfma_f32_32x32x2_f32 throughout (rounds 1 - 5; bench.py's `f32_mfma` leg; C4 92.4 ms).
+        # Error against float64 <= the fp32-MFMA GEMM's in every role (tests/test_gpu_xp.py).  args.mlp_gemm, overridden by NEMO_MLP_GEMM.
         mg = os.environ.get('NEMO_MLP_GEMM') or getattr(args, 'mlp_gemm', None) or 'f32_split'
-        if mg not in ('f32', 'f32_split'):
-            raise ValueError(f"args.mlp_gemm must be 'f32' or 'f32_split', got {mg!r}")
-        self.mlp_split = mg == 'f32_split' and not self.bf16 and version >= 1
-        self.xp_fmt = 3
+        if mg not in ('f32', 'f32_split', 'f32_split2', 'f32_split3'):
+            raise ValueError(f"args.mlp_gemm must be 'f32', 'f32_split' (= 'f32_split2') or 'f32_split3', got {mg!r}")
+        self.mlp_split = mg != 'f32' and not self.bf16 and version >= 1
+        self.xp_fmt = 3 if mg == 'f32_split3' else 2
         # bf16 operands IN MEMORY (round 3): every dense product of the MotionNet / VPoser chain reads bf16 copies of its
         # operands (written by the producing GEMM's epilogue, plain and transposed, or by nemo_cast_bf16) through
         # nemo_gemm_bf16mem -- the same values enter the matrix cores as with the on-the-fly rounding of nemo_gemm_bf16
@@ -412,8 +418,9 @@ class FitEngine:
     SMALL_BATCH_ROWS = 1024  # backward_mlp: below this many rows the dW GEMMs run beside the dX chain
     GROUPED_DW_ROWS = 400    # ... and up to this many as ONE grouped launch behind it (a one-instance shard)
     SPLIT_ADJ_ROWS = 256     # mesh_blend 'f32_split': the blend-shape adjoint in split precision from this many samples on
-    XP_MIN_ROWS = int(os.environ.get('NEMO_XP_MIN_ROWS', '1024'))    # mlp_gemm 'f32_split': the chain on nemo_gemm_xp from this many rows on
+    XP_MIN_ROWS = int(os.environ.get('NEMO_XP_MIN_ROWS', '1600'))    # mlp_gemm 'f32_split': the chain on nemo_gemm_xp from this many rows on
     XP_DW_ASIDE_ROWS = 65536  # ... its parameter-gradient products on the side stream up to this many rows
+    XMETA = ('X', 'H1', 'H2', 'H3', 'dHEAD', 'dH', 'dH_b', 'dH_c', 'W0', 'W2', 'W4', 'Whead', 'b0', 'b2', 'b4')
     ECS_ROWS = 1536          # fp32 backward_mlp: bias gradients from the dX launches' per-band column sums above this many rows
                              # (same box: headline 1.257 / 1.259 ms without / with, C4 101.8 / 101.5 ms: the win is C4's 6.6 GB of reads)
     MAX_WORKSPACES = 24      # distinct batch sizes kept alive (a rank of a sharded minibatch run sees many)
@@ -440,7 +447,9 @@ class FitEngine:
         Nc = min(N, 8192)
         # everything that must be zero at the start of a step lives in ONE arena (a single memset)
         # (incl. this workspace's loss-scalar slots: FitEngine.scal points at the active workspace's)
-        sizes = OrderedDict(scal=(8,), view_acc=(self.V, 2), dAA=(N, 72), dJp=(N, 24, 3), dA2=(Nc, 24, 12),
+        # (xmeta: the scale records of the split-precision MLP chain's copies, include/nemo_hip.h nemo_gemm_xp fmt 2: absmax
+        #  accumulators must be zero at the start of a step)
+        sizes = OrderedDict(scal=(8,), xmeta=(len(self.XMETA), 64), view_acc=(self.V, 2), dAA=(N, 72), dJp=(N, 24, 3), dA2=(Nc, 24, 12),
                             dPF2=(Nc, 208))
         arena = Z(sum(int(np.prod(v)) for v in sizes.values()))
         views, off = {}, 0
@@ -493,6 +502,9 @@ class FitEngine:
             xl = lambda k: int(self.lib.nemo_xp_ld(self.xp_fmt, k))
             Zx = lambda rows, k: torch.zeros(rows, xl(k), **i16)
             w.update(Xx=Zx(N + 1, self.din), XxT=Zx(self.din, N + 1), dHEADx=Zx(N + 1, 147), dHEADxT=Zx(147, N + 1))
+            # X's scale record: OUTSIDE the zero-filled arena (the phase kernel accumulates into it in the same launch that zero-fills
+            # the arena); its absmax slots are returned to zero by the forward's last product (nemo_gemm_xp metaZero)
+            w['xmeta_x'] = torch.zeros(64, dtype=torch.float32, device=self.device)
             for k in ('H1', 'H2', 'H3', 'dH', 'dH_b', 'dH_c'):
                 w[k + 'x'], w[k + 'xT'] = Zx(N + 1, h), Zx(h, N + 1)
         # per-band column sums of the three activation gradients of the MotionNet backward (the epilogues of their launches:
@@ -553,7 +565,7 @@ class FitEngine:
             valu = flops * (2 * 12 * 4) / self.mesh_macs()
         if not self.bf16:
             if tag in ('gemm_mlp_hidden_fwd', 'gemm_mlp_hidden_dx') and self.mlp_split and any('Xx' in w_ for w_ in self.ws.values()):
-                return {'bf16x6': flops}             # (nemo_gemm_xp fmt 3: six bf16 piece products per algorithmic product)
+                return {('f16x3' if self.xp_fmt == 2 else 'bf16x6'): flops}      # (nemo_gemm_xp: three fp16 / six bf16 piece products per product)
             if tag == 'gemm_pose_blend_bwd' and self.split_adj:
                 return {'f16x3': flops}              # (nemo_gemm_f16x2mem_adj: three fp16 piece products per algorithmic product)
             out = {'f32': flops - valu}
@@ -811,9 +823,10 @@ class FitEngine:
         return self.mlp_split and 'Xx' in w
 
     def gemm_xp(self, M, N, K, Ax, Bx, Cp=None, ldc=0, bias=None, act=0, maskx=None, alpha=1.0, out_mode=0, Cx=None, CxT=None,
-                colsum=None, tag=None):
+                colsum=None, tag=None, mA=None, mB=None, mBias=None, mOut=None, mZero=None):
         """C (M x N, fp32, may be None) (op)= epilogue(alpha * A B^T), A (M x K) / B (N x K) xp matrices; Cx / CxT: the result's xp
-        copies for the next products of the chain (include/nemo_hip.h nemo_gemm_xp)."""
+        copies for the next products of the chain (include/nemo_hip.h nemo_gemm_xp).  mA / mB / mBias / mOut: the scale records of
+        the operands, the bias and the result's copies (device pointers; fmt 2 only)."""
         ev = self._event_begin(tag, 2.0 * M * N * K)
         cur = torch.cuda.current_stream()
         ws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]
@@ -821,23 +834,57 @@ class FitEngine:
                                     dptr(maskx), maskx.stride(0) if maskx is not None else 0, 1 if maskx is not None else 0, alpha,
                                     out_mode, dptr(Cx), Cx.stride(0) if Cx is not None else 0, dptr(CxT),
                                     CxT.stride(0) if CxT is not None else 0, 1.0, dptr(colsum),
-                                    colsum.stride(0) if colsum is not None else 0, ws.data_ptr(), ws.numel() * 4, _stream()),
+                                    colsum.stride(0) if colsum is not None else 0, mA, mB, mBias, mOut, mZero, ws.data_ptr(),
+                                    ws.numel() * 4, _stream()),
               'nemo_gemm_xp')
         self._event_end(ev)
 
+    def absmax_xp(self, items, overwrite=False):
+        """items: (src_ptr, rows, cols, lds, meta pointer) -- max |src| into their scale records, one launch (fmt 2); ``overwrite``:
+        the records' slots are stored, not accumulated into (they need no zeroing)."""
+        am = (_lib.AbsmaxDesc * len(items))()
+        for i, (src, rows, cols, lds, meta) in enumerate(items):
+            am[i].src, am[i].rows, am[i].cols, am[i].lds, am[i].meta, am[i].overwrite = src, rows, cols, lds, meta, int(overwrite)
+        check(self.lib.nemo_absmax_multi(len(items), am, _stream()), 'nemo_absmax_multi')
+
     def cast_xp(self, items):
-        """items: (src_ptr, rows, cols, lds, dst or None, dstT or None) -- their xp copies in ONE launch."""
-        arr = (_lib.CastXpDesc * len(items))()
-        for i, (src, rows, cols, lds, dst, dstT) in enumerate(items):
+        """items: (src_ptr, rows, cols, lds, dst or None, dstT or None, meta pointer or None) -- their xp copies in ONE launch
+        (fmt 2: scaled from the absmax their records hold)."""
+        n = len(items)
+        arr = (_lib.CastXpDesc * n)()
+        for i, (src, rows, cols, lds, dst, dstT, meta) in enumerate(items):
             q = arr[i]
             q.src, q.rows, q.cols, q.lds, q.scale = src, rows, cols, lds, 1.0
             q.dst, q.ldd = dptr(dst), dst.stride(0) if dst is not None else 0
             q.dstT, q.lddT = dptr(dstT), dstT.stride(0) if dstT is not None else 0
-        check(self.lib.nemo_cast_xp(self.xp_fmt, len(items), arr, _stream()), 'nemo_cast_xp')
+            q.meta = meta if self.xp_fmt == 2 else None
+        check(self.lib.nemo_cast_xp(self.xp_fmt, n, arr, _stream()), 'nemo_cast_xp')
 
-    def _weights_xp(self, transposed):
-        """xp copies of the four MotionNet weight matrices for this step (they change in Adam at the step's end): plain [out][in] for
-        the forward and -- `transposed` -- [in][out] for the activation gradients, all in one launch."""
+    def _xm(self, w, name):
+        """device pointer of the scale record of copy `name` (fmt 2; None for the bf16 form, which has no scales)"""
+        if self.xp_fmt != 2:
+            return None
+        if name == 'X':
+            return w['xmeta_x'].data_ptr()
+        if name[0] in 'Wb':             # weights and biases: engine-level records, overwritten by every pass's absmax launch
+            if not hasattr(self, '_wmeta'):
+                self._wmeta = torch.zeros(len(self.XMETA), 64, dtype=torch.float32, device=self.device)
+            return self._wmeta[self.XMETA.index(name)].data_ptr()
+        return w['xmeta'][self.XMETA.index(name)].data_ptr()
+
+    def head_meta(self, w, covers_all):
+        """The scale record nemo_pose_bwd_fused should accumulate the head gradient's absmax into, or None.  ``covers_all``: the
+        launch sees every column the backward will read (no translation columns, or it is handed them); otherwise the chain
+        runs a pass of its own over dHEAD."""
+        self._dhead_absmax_done = None
+        if not (self.version >= 1 and self._use_xp(w) and self.xp_fmt == 2 and covers_all):
+            return None
+        self._dhead_absmax_done = w
+        return self._xm(w, 'dHEAD')
+
+    def _weight_items(self, w, transposed):
+        """the cast descriptors of the four MotionNet weight matrices (plain [out][in] for the forward and -- `transposed` -- [in][out]
+        for the activation gradients); they change in Adam at the step's end, so the copies are made every step"""
         lm, h = 'learned_motion.', self.h
         if not hasattr(self, '_wx'):
             i16 = dict(dtype=torch.int16, device=self.device)
@@ -847,43 +894,60 @@ class FitEngine:
                         '2T': torch.zeros(h, xl(h), **i16), '4T': torch.zeros(h, xl(h), **i16), 'headT': torch.zeros(h, xl(147), **i16)}
         wx = self._wx
         T = lambda k: wx[k + 'T'] if transposed else None
-        self.cast_xp([(self.p(lm + 'net.net.0.weight'), h, self.din, self.din, wx['0'], T('0')),
-                      (self.p(lm + 'net.net.2.weight'), h, h, h, wx['2'], T('2')),
-                      (self.p(lm + 'net.net.4.weight'), h, h, h, wx['4'], T('4')),
-                      (self.p(lm + 'rot_out.weight'), 147, h, h, wx['head'], T('head'))])
-        return wx
+        return [(self.p(lm + 'net.net.0.weight'), h, self.din, self.din, wx['0'], T('0'), self._xm(w, 'W0')),
+                (self.p(lm + 'net.net.2.weight'), h, h, h, wx['2'], T('2'), self._xm(w, 'W2')),
+                (self.p(lm + 'net.net.4.weight'), h, h, h, wx['4'], T('4'), self._xm(w, 'W4')),
+                (self.p(lm + 'rot_out.weight'), 147, h, h, wx['head'], T('head'), self._xm(w, 'Whead'))]
 
-    def _forward_nets_xp(self, w, N, train):
+    def _weights_absmax(self, w, items):
+        """fmt 2: the absmax records of the weights and of the three hidden-layer biases (which enter the bounds the hidden copies
+        are scaled by) in one launch"""
+        lm, h = 'learned_motion.', self.h
+        am = [(src, rows, cols, lds, meta) for src, rows, cols, lds, _, _, meta in items]
+        am += [(self.p(lm + nm), 1, h, h, self._xm(w, key)) for nm, key in (('net.net.0.bias', 'b0'), ('net.net.2.bias', 'b2'),
+                                                                                   ('net.net.4.bias', 'b4'))]
+        self.absmax_xp(am, overwrite=True)
+
+    def _forward_nets_xp(self, w, N, train, am_done=None):
         """forward_pose's MLP on the split-precision chain: every layer reads the previous layer's xp copy and leaves its own (plain
-        for the next layer, transposed for its parameter gradient when `train`); the hidden activations exist as xp copies only
-        (three bf16 pieces = the fp32 value), the heads' output in fp32."""
+        for the next layer, transposed for its parameter gradient when `train`); the hidden activations exist as xp copies only,
+        the heads' output in fp32.  Launches in front of the first product: [phase kernel (+ max |X|) on the main stream beside the
+        weights' absmax pass on the side stream (fmt 2)] -> ONE cast launch (weights + X)."""
         lm, h, r = 'learned_motion.', self.h, N + 1
         main, side = torch.cuda.current_stream(), self.side_stream
-        side.wait_event(main.record_event())
-        with torch.cuda.stream(side):
-            wx = self._weights_xp(bool(train))
-            casts_done = side.record_event()
-        self._wxT_fresh = bool(train)
+        items = self._weight_items(w, bool(train))
+        wx = self._wx
         T = lambda k: w[k] if train else None
-        self.cast_xp([(dptr(w['X']), r, self.din, self.ldx, w['Xx'], T('XxT'))])
-        main.wait_event(casts_done)
-        self.gemm_xp(r, h, self.din, w['Xx'], wx['0'], bias=self.p(lm + 'net.net.0.bias'), act=1, Cx=w['H1x'], CxT=T('H1xT'))
+        m = lambda k: self._xm(w, k)
+        if self.xp_fmt == 2:
+            main.wait_event(am_done)        # (the weights' absmax pass forward_pose started on the side stream beside the phase kernel)
+        self.cast_xp(items + [(dptr(w['X']), r, self.din, self.ldx, w['Xx'], T('XxT'), m('X'))])
+        self._wxT_fresh = w if train else None
+        self.gemm_xp(r, h, self.din, w['Xx'], wx['0'], bias=self.p(lm + 'net.net.0.bias'), act=1, Cx=w['H1x'], CxT=T('H1xT'),
+                     mA=m('X'), mB=m('W0'), mBias=m('b0'), mOut=m('H1'))
         self.gemm_xp(r, h, h, w['H1x'], wx['2'], bias=self.p(lm + 'net.net.2.bias'), act=1, Cx=w['H2x'], CxT=T('H2xT'),
-                     tag='gemm_mlp_hidden_fwd')
-        self.gemm_xp(r, h, h, w['H2x'], wx['4'], bias=self.p(lm + 'net.net.4.bias'), act=1, Cx=w['H3x'], CxT=T('H3xT'))
-        self.gemm_xp(r, 147, h, w['H3x'], wx['head'], dptr(w['HEAD']), HEAD_LD, bias=self.p(lm + 'rot_out.bias'))
+                     tag='gemm_mlp_hidden_fwd', mA=m('H1'), mB=m('W2'), mBias=m('b2'), mOut=m('H2'))
+        self.gemm_xp(r, h, h, w['H2x'], wx['4'], bias=self.p(lm + 'net.net.4.bias'), act=1, Cx=w['H3x'], CxT=T('H3xT'),
+                     mA=m('H2'), mB=m('W4'), mBias=m('b4'), mOut=m('H3'))
+        # (the last product of the forward returns X's absmax slots to zero for the next pass's phase kernel)
+        self.gemm_xp(r, 147, h, w['H3x'], wx['head'], dptr(w['HEAD']), HEAD_LD, bias=self.p(lm + 'rot_out.bias'), mA=m('H3'), mB=m('Whead'),
+                     mZero=m('X'))
 
     def _backward_mlp_xp(self, w, N, view_idx, frame_idx, raw_phase, nout, nbias, stages=(0, 1, 2), bucketed=False):
         """backward_mlp on the split-precision chain.  Every product is C = A B^T over xp copies: dX_l = dY_l (W_l^T)^T reads dY_l's
         plain copy and the transposed weight copy; dW_l = dY_l^T X_l reads the two TRANSPOSED activation copies (K = rows).
         ``stages`` / ``bucketed`` as in backward_mlp."""
         L, lm, h, r = self.lib, 'learned_motion.', self.h, N + 1
-        if 0 in stages and not getattr(self, '_wxT_fresh', False):
-            self._weights_xp(True)            # (no training forward ran in front of this backward: warm-up after an eval pass)
-        self._wxT_fresh = False
+        if 0 in stages and getattr(self, '_wxT_fresh', None) is not w:
+            items = self._weight_items(w, True)     # (no training forward of this workspace ran in front: warm-up after an eval pass)
+            if self.xp_fmt == 2:
+                self._weights_absmax(w, items)
+            self.cast_xp(items)
+        self._wxT_fresh = None
         wx = self._wx
         cs = self._colsums
         R = int(L.nemo_gemm_colsum_rows(r))
+        m = lambda k: self._xm(w, k)
 
         def end_of_stage():
             if bucketed:
@@ -911,35 +975,44 @@ class FitEngine:
             del pend[:]
 
         if 0 in stages:
-            self.cast_xp([(dptr(w['dHEAD']), r, nout, HEAD_LD, w['dHEADx'], w['dHEADxT'])])
+            if self.xp_fmt == 2 and getattr(self, '_dhead_absmax_done', None) is not w:
+                self.absmax_xp([(dptr(w['dHEAD']), r, nout, HEAD_LD, m('dHEAD'))])       # (else: left by nemo_pose_bwd_fused)
+            self._dhead_absmax_done = None
+            self.cast_xp([(dptr(w['dHEAD']), r, nout, HEAD_LD, w['dHEADx'], w['dHEADxT'], m('dHEAD'))])
             # heads
             ev = ready()
-            dW(ev, lambda: self.gemm_xp(nout, h, r, w['dHEADxT'], w['H3xT'], self.g(lm + 'rot_out.weight'), h, out_mode=1))
+            dW(ev, lambda: self.gemm_xp(nout, h, r, w['dHEADxT'], w['H3xT'], self.g(lm + 'rot_out.weight'), h, out_mode=1,
+                                        mA=m('dHEAD'), mB=m('H3')))
             cs.append((dptr(w['dHEAD']), r, nbias, HEAD_LD, self.g(lm + 'rot_out.bias')))
-            self.gemm_xp(r, h, nout, w['dHEADx'], wx['headT'], maskx=w['H3x'], Cx=w['dHx'], CxT=w['dHxT'], colsum=w['cs4'])
+            self.gemm_xp(r, h, nout, w['dHEADx'], wx['headT'], maskx=w['H3x'], Cx=w['dHx'], CxT=w['dHxT'], colsum=w['cs4'],
+                         mA=m('dHEAD'), mB=m('Whead'), mOut=m('dH'))
             flush_dW()
             # layer 4
             ev = ready()
-            dW(ev, lambda: self.gemm_xp(h, h, r, w['dHxT'], w['H2xT'], self.g(lm + 'net.net.4.weight'), h, out_mode=1))
+            dW(ev, lambda: self.gemm_xp(h, h, r, w['dHxT'], w['H2xT'], self.g(lm + 'net.net.4.weight'), h, out_mode=1,
+                                        mA=m('dH'), mB=m('H2')))
             cs.append((dptr(w['cs4']), R, h, h, self.g(lm + 'net.net.4.bias')))
             self.gemm_xp(r, h, h, w['dHx'], wx['4T'], maskx=w['H2x'], Cx=w['dH_bx'], CxT=w['dH_bxT'], colsum=w['cs2'],
-                         tag='gemm_mlp_hidden_dx')
+                         tag='gemm_mlp_hidden_dx', mA=m('dH'), mB=m('W4'), mOut=m('dH_b'))
             flush_dW()
             end_of_stage()
         if 1 in stages:
             # layer 2
             ev = ready()
-            dW(ev, lambda: self.gemm_xp(h, h, r, w['dH_bxT'], w['H1xT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1))
+            dW(ev, lambda: self.gemm_xp(h, h, r, w['dH_bxT'], w['H1xT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1,
+                                        mA=m('dH_b'), mB=m('H1')))
             cs.append((dptr(w['cs2']), R, h, h, self.g(lm + 'net.net.2.bias')))
-            self.gemm_xp(r, h, h, w['dH_bx'], wx['2T'], maskx=w['H1x'], Cx=w['dH_cx'], CxT=w['dH_cxT'], colsum=w['cs0'])
+            self.gemm_xp(r, h, h, w['dH_bx'], wx['2T'], maskx=w['H1x'], Cx=w['dH_cx'], CxT=w['dH_cxT'], colsum=w['cs0'],
+                         mA=m('dH_b'), mB=m('W2'), mOut=m('dH_c'))
             flush_dW()
             end_of_stage()
         if 2 not in stages:
             return
         ev = ready()
         cs.append((dptr(w['cs0']), R, h, h, self.g(lm + 'net.net.0.bias')))
-        dW(ev, lambda: self.gemm_xp(h, self.din, r, w['dH_cxT'], w['XxT'], self.g(lm + 'net.net.0.weight'), self.din, out_mode=1))
-        self.gemm_xp(r, self.din, h, w['dH_cx'], wx['0T'], dptr(w['dX']), self.ldx)
+        dW(ev, lambda: self.gemm_xp(h, self.din, r, w['dH_cxT'], w['XxT'], self.g(lm + 'net.net.0.weight'), self.din, out_mode=1,
+                                    mA=m('dH_c'), mB=m('X')))
+        self.gemm_xp(r, self.din, h, w['dH_cx'], wx['0T'], dptr(w['dX']), self.ldx, mA=m('dH_c'), mB=m('W0'))
         if bucketed:
             self.flush_colsums()
         self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=not bucketed)
@@ -1004,7 +1077,18 @@ class FitEngine:
         pargs = (N, self.V, self.T, self.K, self.D, self.C, dptr(view_idx), dptr(frame_idx), dptr(raw_phase),
                  sh0, sc0, self.ldp, self.p('phase_rbf.log_sigmas') if self.D > 0 else None,
                  self.p('learned_instance_code') if self.C > 0 else None, dptr(code_noise), self.kernel_id,
-                 dptr(w['X']), self.ldx, dptr(w['phase']), dptr(w['phase_ws']))
+                 dptr(w['X']), self.ldx, dptr(w['phase']), dptr(w['phase_ws']),
+                 # (fmt 2 of the split-precision chain: the phase kernel leaves max |X| in X's scale record)
+                 w['xmeta_x'].data_ptr() if (self.version >= 1 and self._use_xp(w) and self.xp_fmt == 2) else None)
+        am_done = None
+        if self.version >= 1 and self._use_xp(w) and self.xp_fmt == 2:
+            # the weights' / biases' absmax records (engine-level, overwritten: nothing to wait for) on the side stream, beside the
+            # phase kernel
+            main, side = torch.cuda.current_stream(), self.side_stream
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                self._weights_absmax(w, self._weight_items(w, bool(train)))
+                am_done = side.record_event()
         if begin is not None:
             arena, zero_grads, n_seg = begin
             check(L.nemo_phase_embed_fwd_begin(*pargs, arena.data_ptr(), arena.numel() * 4,
@@ -1023,7 +1107,7 @@ class FitEngine:
             check(L.nemo_rot6d_fwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, dptr(w['R']), dptr(w['AA']), st), 'nemo_rot6d_fwd')
             return
         if self._use_xp(w):
-            self._forward_nets_xp(w, N, train)
+            self._forward_nets_xp(w, N, train, am_done)
             check(L.nemo_rot6d_fwd(N, 24, dptr(w['ROT']), HEAD_LD, 1, dptr(w['R']), dptr(w['AA']), st), 'nemo_rot6d_fwd')
             return
         self._linear(r, dptr(w['X']), self.ldx, self.din, self.p(lm + 'net.net.0.weight'),

@@ -140,7 +140,7 @@ class MonotonicNetwork(nn.Module):
         vi = torch.zeros(n, dtype=torch.long, device=e.device)
         check(e.lib.nemo_phase_embed_fwd(n, 1, e.T, e.K, 0, 0, dptr(vi), None, dptr(x),
                                          self.shifts.data_ptr(), self.scales.data_ptr(), 2 * e.K, None, None,
-                                         None, 0, dptr(out), 1, dptr(ph), None, _stream()), 'nemo_phase_embed_fwd')
+                                         None, 0, dptr(out), 1, dptr(ph), None, None, _stream()), 'nemo_phase_embed_fwd')
         return ph.unsqueeze(1)
 
 
@@ -678,7 +678,7 @@ class MultiViewModel(nn.Module):
             N, dptr(w['ROT']), HEAD_LD, 1, dptr(w['dR']), dptr(w['dAA']), dptr(w['dROT']), HEAD_LD,
             dptr(w['AA']) if v2v else None, dptr(w['dR2']) if v2v else None,
             float(a.weight_vp_loss) * sh.mr / float(N * e.NV * 3) if v2v else 0.0,
-            dptr(w['dTR']) if anchored else None, HEAD_LD, 1, st), 'nemo_pose_bwd_fused')
+            dptr(w['dTR']) if anchored else None, HEAD_LD, 1, e.head_meta(w, anchored), st), 'nemo_pose_bwd_fused')
         if not anchored:
             e.finish_trans_grad(w, N)
         e.backward_mlp(w, N, vi, fi, None, stages=stages, bucketed=bucketed)
@@ -1201,7 +1201,7 @@ class MultiViewModel(nn.Module):
         # rot6d backward of the axis-angle gradient; row N (the phase-0 row: a workspace shared with larger batches keeps
         # their row there) cleared in the same launch
         check(e.lib.nemo_pose_bwd_fused(N, dptr(w['ROT']), HEAD_LD, 1, None, dptr(w['dAA']), dptr(w['dROT']), HEAD_LD,
-                                        None, None, 0.0, None, HEAD_LD, 1, st), 'nemo_pose_bwd_fused')
+                                        None, None, 0.0, None, HEAD_LD, 1, e.head_meta(w, True), st), 'nemo_pose_bwd_fused')
         e.backward_mlp(w, N, vi, fi, None, has_trans_grad=False)
         check(e.lib.nemo_nan_count(e.grads.data_ptr(), e.grads.numel(),
                                    e.scal.data_ptr() + 4 * S_NAN if nan_out is None else dptr(nan_out), _stream()), 'nemo_nan_count')

@@ -54,8 +54,29 @@ def xp_ld(fmt, k):
     return int(_lib.load().nemo_xp_ld(fmt, k))
 
 
-def cast_xp(fmt, src, plain=True, transposed=False, scale=1.0):
-    """fp32 (rows x cols) -> its xp copies (int16 tensors): (plain or None, transposed or None)."""
+def absmax_meta(*srcs):
+    """One scale record (include/nemo_hip.h: [0] scale, [2, 34) absmax slots) per fp32 matrix: a (n, 64) float tensor holding the
+    absmax (nemo_absmax_multi)."""
+    L = _lib.load()
+    meta = torch.zeros(len(srcs), 64, device=DEV)
+    d = (_lib.AbsmaxDesc * len(srcs))()
+    for i, x in enumerate(srcs):
+        d[i].src, d[i].rows, d[i].cols, d[i].lds, d[i].meta = dptr(x), x.shape[0], x.shape[1], x.stride(0), meta[i].data_ptr()
+    check(L.nemo_absmax_multi(len(srcs), d, st()), 'absmax_multi')
+    return meta
+
+
+def meta_scale(meta):
+    return float(meta[0])
+
+
+def meta_amax(meta):
+    return float(meta[2:34].max())
+
+
+def cast_xp(fmt, src, plain=True, transposed=False, scale=1.0, meta=None):
+    """fp32 (rows x cols) -> its xp copies (int16 tensors): (plain or None, transposed or None).  fmt 2 with `meta` (a float[2]
+    device record whose [0] holds the absmax): the scale is chosen on the device and left in meta[1]."""
     L = _lib.load()
     rows, cols = src.shape
     d = (_lib.CastXpDesc * 1)()
@@ -65,6 +86,7 @@ def cast_xp(fmt, src, plain=True, transposed=False, scale=1.0):
     d[0].dst, d[0].ldd = dptr(dst), dst.stride(0) if plain else 0
     d[0].dstT, d[0].lddT = dptr(dstT), dstT.stride(0) if transposed else 0
     d[0].scale = scale
+    d[0].meta = dptr(meta)
     check(L.nemo_cast_xp(fmt, 1, d, st()), 'cast_xp')
     return dst, dstT
 
@@ -79,7 +101,7 @@ def xp_decode(fmt, x, k, scale=1.0):
 
 
 def gemm_xp(fmt, Ax, Bx, M, N, K, C=None, bias=None, act=0, maskx=None, alpha=1.0, out_mode=0, want_cx=False, want_cxt=False,
-            out_scale=1.0, colsum=False, ws=True):
+            out_scale=1.0, colsum=False, ws=True, metaA=None, metaB=None, metaBias=None, metaOut=None):
     L = _lib.load()
     if C is None and not (want_cx or want_cxt):
         C = torch.zeros(M, N, device=DEV)
@@ -89,6 +111,6 @@ def gemm_xp(fmt, Ax, Bx, M, N, K, C=None, bias=None, act=0, maskx=None, alpha=1.
     check(L.nemo_gemm_xp(fmt, M, N, K, dptr(Ax), Ax.stride(0), dptr(Bx), Bx.stride(0), dptr(C), C.stride(0) if C is not None else 0,
                          dptr(bias), act, dptr(maskx), maskx.stride(0) if maskx is not None else 0, 1 if maskx is not None else 0,
                          alpha, out_mode, dptr(Cx), Cx.stride(0) if want_cx else 0, dptr(CxT), CxT.stride(0) if want_cxt else 0,
-                         out_scale, dptr(cs), cs.stride(0) if colsum else 0, dptr(gemm_ws()) if ws else None,
-                         gemm_ws().numel() * 4 if ws else 0, st()), 'gemm_xp')
+                         out_scale, dptr(cs), cs.stride(0) if colsum else 0, dptr(metaA), dptr(metaB), dptr(metaBias), dptr(metaOut), None,
+                         dptr(gemm_ws()) if ws else None, gemm_ws().numel() * 4 if ws else 0, st()), 'gemm_xp')
     return C, Cx, CxT, cs

@@ -323,11 +323,13 @@ def test_phase_embed_vs_oracle(L, kern):
     phd, den = torch.zeros(N, device='cuda'), torch.zeros(N, device='cuda')
     dvi, dfi, dls, dco = H.dev(vi, torch.long), H.dev(fi, torch.long), H.dev(ls), H.dev(codes)
     kid = RBF_KERNELS[kern]
+    xmeta = torch.zeros(64, device='cuda')
     assert L.nemo_phase_embed_fwd(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
                                   pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), dco.data_ptr(), None, kid,
-                                  Xd.data_ptr(), D + C, phd.data_ptr(), den.data_ptr(), H.st()) == 0
+                                  Xd.data_ptr(), D + C, phd.data_ptr(), den.data_ptr(), xmeta.data_ptr(), H.st()) == 0
     assert rel_err(phd, ph.detach().squeeze(1)) < 1e-5
     assert rel_err(Xd, Xo.detach()) < 1e-5
+    assert H.meta_amax(xmeta) == float(Xd.abs().max())          # x_meta: the launch leaves max |X| in the scale record
     # the same launch with the step's zero-fills and Adam-table bookkeeping in further blocks (nemo_phase_embed_fwd_begin)
     from nemo_cvpr2023_amd._lib import AdamSeg
     import ctypes
@@ -339,7 +341,7 @@ def test_phase_embed_vs_oracle(L, kern):
     seg_dev = torch.frombuffer(bytearray(bytes(seg_host)), dtype=torch.uint8).cuda()
     assert L.nemo_phase_embed_fwd_begin(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
                                         pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), dco.data_ptr(), None, kid,
-                                        Xd2.data_ptr(), D + C, phd2.data_ptr(), den2.data_ptr(), z0.data_ptr(), 1003 * 4,
+                                        Xd2.data_ptr(), D + C, phd2.data_ptr(), den2.data_ptr(), None, z0.data_ptr(), 1003 * 4,
                                         z1.data_ptr(), 77 * 4, seg_dev.data_ptr(), 2, 0.9, 0.999, H.st()) == 0
     assert torch.equal(Xd2, Xd) and torch.equal(phd2, phd) and torch.equal(den2, den)
     assert float(z0.abs().sum()) == 0.0 and float(z1.abs().sum()) == 0.0
@@ -842,9 +844,13 @@ def test_pose_bwd_fused_equals_the_three_launches(L):
             assert L.nemo_scale_neg_rowsum(N, 3, a_dh.data_ptr() + 4 * 144, LD,
                                            a_dh.data_ptr() + 4 * (N * LD + 144), H.st()) == 0
         b_dh = dhead0.clone()
+        hmeta = torch.zeros(64, device='cuda')
         assert L.nemo_pose_bwd_fused(N, head.data_ptr(), LD, 1, dR.data_ptr(), dAA.data_ptr(), b_dh.data_ptr(), LD,
                                      AA.data_ptr() if v2v else None, dR2.data_ptr() if v2v else None, scale,
-                                     b_dh.data_ptr() + 4 * 144 if anchored else None, LD, 1 if v2v else 0, H.st()) == 0
+                                     b_dh.data_ptr() + 4 * 144 if anchored else None, LD, 1 if v2v else 0, hmeta.data_ptr(), H.st()) == 0
+        # head_meta: the absmax of what the launch wrote (rotation columns; with dTR the translation columns incl. row N)
+        cols = 147 if anchored else 144
+        assert H.meta_amax(hmeta) == float(torch.cat([b_dh[:N, :144].reshape(-1), b_dh[:N + 1, 144:cols].reshape(-1)]).abs().max())
         # zero_row: the rotation columns of row N are cleared (else untouched)
         assert torch.equal(b_dh[N, :144], torch.zeros_like(b_dh[N, :144]) if v2v else dhead0[N, :144])
         assert rel_err(b_dh[:N, :144], a_dh[:N, :144]) < 1e-6, (v2v, anchored)

@@ -22,14 +22,27 @@ def _err(c, ref):
     return float((c.double() - ref).abs().max() / ref.abs().max())
 
 
-@pytest.mark.parametrize('fmt', [3])
+def _xp_operand(fmt, x, transposed=False):
+    """xp copy of x + its scale record (fmt 2: absmax and scale chosen on the device; fmt 3: None)."""
+    meta = H.absmax_meta(x)[0] if fmt == 2 else None
+    d, dT = H.cast_xp(fmt, x, True, transposed, meta=meta)
+    return d, dT, meta
+
+
+@pytest.mark.parametrize('fmt', [3, 2])
 @pytest.mark.parametrize('rows,cols', [(33, 32), (2401, 105), (130, 1000), (64, 147)])
 def test_cast_roundtrip(fmt, rows, cols):
     x = _rand(rows, cols, 3.0, 1)
-    d, dT = H.cast_xp(fmt, x, True, True)
-    # three bf16 pieces hold an fp32 value exactly
-    assert torch.equal(H.xp_decode(fmt, d, cols), x.double())
-    assert torch.equal(H.xp_decode(fmt, dT, rows), x.double().t())
+    d, dT, meta = _xp_operand(fmt, x, True)
+    if fmt == 3:        # three bf16 pieces hold an fp32 value exactly
+        assert torch.equal(H.xp_decode(fmt, d, cols), x.double())
+        assert torch.equal(H.xp_decode(fmt, dT, rows), x.double().t())
+    else:               # two fp16 pieces of s x: 22 bits of the largest entries, never less than 2^-25 / s absolutely; s from the absmax
+        amax, s = H.meta_amax(meta), H.meta_scale(meta)
+        assert amax == float(x.abs().max()) and 2 ** 14 <= s * amax < 2 ** 15
+        err = (H.xp_decode(fmt, d, cols, s) - x.double()).abs()
+        assert float((err - (x.double().abs() * 2.0 ** -22).clamp_min(2.0 ** -25 / s)).max()) <= 0
+        assert torch.equal(H.xp_decode(fmt, dT, rows, s), H.xp_decode(fmt, d, cols, s).t())
     # k-pads are zero
     kb = (cols + 31) // 32
     pads = d[:, :kb * 32 * fmt].reshape(rows, kb, fmt, 32)[:, -1, :, cols - (kb - 1) * 32:]
@@ -51,67 +64,108 @@ ROLES = [
 ]
 
 
-@pytest.mark.parametrize('fmt', [3])
+@pytest.mark.parametrize('fmt', [3, 2])
 @pytest.mark.parametrize('name,M,N,K', ROLES)
 @pytest.mark.parametrize('mag_a,mag_b', [(1.0, 1.0), (1e-10, 1e4), (1e4, 1e-10), (1e-5, 1e-5)])
 def test_gemm_xp_error_vs_fp32_gemm(fmt, name, M, N, K, mag_a, mag_b):
     A = _rand(M, K, mag_a, 11, heavy=name.startswith('d'))
     B = _rand(N, K, mag_b, 12)
     ref = A.double() @ B.double().t()
-    Ax, _ = H.cast_xp(fmt, A)
-    Bx, _ = H.cast_xp(fmt, B)
-    C, _, _, _ = H.gemm_xp(fmt, Ax, Bx, M, N, K)
+    Ax, _, mA = _xp_operand(fmt, A)
+    Bx, _, mB = _xp_operand(fmt, B)
+    C, _, _, _ = H.gemm_xp(fmt, Ax, Bx, M, N, K, metaA=mA, metaB=mB)
     C32 = H.gemm(A, B, 0, 1)
     e_xp, e_32 = _err(C, ref), _err(C32, ref)
     assert e_xp <= 1.5 * e_32 + 1e-9, (name, e_xp, e_32)
 
 
-def test_gemm_xp_epilogue_copies_mask_bias_colsum():
-    fmt, M, N, K = 3, 2401, 1000, 1000
-    A, B = _rand(M, K, 1.0, 21), _rand(N, K, 0.03, 22)
-    bias = _rand(1, N, 0.1, 23)[0].contiguous()
+@pytest.mark.parametrize('fmt', [3, 2])
+@pytest.mark.parametrize('mag', [1.0, 1e-6, 300.0])
+def test_gemm_xp_epilogue_copies_mask_bias_colsum(fmt, mag):
+    M, N, K = 2401, 1000, 1000
+    A, B = _rand(M, K, mag, 21), _rand(N, K, 0.03, 22)
+    bias = (_rand(1, N, 0.1 * mag, 23)[0]).contiguous()
     act_src = _rand(M, N, 1.0, 24).clamp_min(0)            # a ReLU output: zeros and positives
-    maskx, _ = H.cast_xp(fmt, act_src)
-    Ax, _ = H.cast_xp(fmt, A)
-    Bx, _ = H.cast_xp(fmt, B)
+    maskx, _, _ = _xp_operand(fmt, act_src)
+    Ax, _, mA = _xp_operand(fmt, A)
+    Bx, _, mB = _xp_operand(fmt, B)
+    mBias = H.absmax_meta(bias[None])[0] if fmt == 2 else None
     ref = (A.double() @ B.double().t() + bias.double())
     # forward role: bias + ReLU, copies only
-    _, Cx, CxT, _ = H.gemm_xp(fmt, Ax, Bx, M, N, K, bias=bias, act=1, want_cx=True, want_cxt=True)
+    mo = torch.zeros(64, device=H.DEV) if fmt == 2 else None
+    _, Cx, CxT, _ = H.gemm_xp(fmt, Ax, Bx, M, N, K, bias=bias, act=1, want_cx=True, want_cxt=True, metaA=mA, metaB=mB, metaBias=mBias,
+                              metaOut=mo)
     want = ref.clamp_min(0)
-    got, gotT = H.xp_decode(fmt, Cx, N), H.xp_decode(fmt, CxT, M)
+    so = H.meta_scale(mo) if fmt == 2 else 1.0
+    got, gotT = H.xp_decode(fmt, Cx, N, so), H.xp_decode(fmt, CxT, M, so)
     assert _err(got, want) < 2e-6
     assert torch.equal(got, gotT.t())
+    if fmt == 2:        # the record: the result's true absmax, and a scale under which nothing can overflow
+        assert abs(H.meta_amax(mo) - float(want.abs().max())) <= 2e-6 * float(want.abs().max())
+        assert so * H.meta_amax(mo) < 2 ** 15 and so == 2.0 ** round(torch.log2(torch.tensor(so)).item())
     # dX role: mask from the activation copy, fp32 output + copies + column sums
-    C, Cx, CxT, cs = H.gemm_xp(fmt, Ax, Bx, M, N, K, maskx=maskx, want_cx=True, want_cxt=True, colsum=True, C=torch.zeros(M, N, device=H.DEV))
+    mo = torch.zeros(64, device=H.DEV) if fmt == 2 else None
+    C, Cx, CxT, cs = H.gemm_xp(fmt, Ax, Bx, M, N, K, maskx=maskx, want_cx=True, want_cxt=True, colsum=True, C=torch.zeros(M, N, device=H.DEV),
+                               metaA=mA, metaB=mB, metaOut=mo)
     want = (A.double() @ B.double().t()) * (act_src > 0)
+    so = H.meta_scale(mo) if fmt == 2 else 1.0
     assert _err(C, want) < 2e-6
-    assert torch.equal(H.xp_decode(fmt, Cx, N), C.double())
-    assert torch.equal(H.xp_decode(fmt, CxT, M), C.double().t())
+    if fmt == 3:
+        assert torch.equal(H.xp_decode(fmt, Cx, N), C.double())
+        assert torch.equal(H.xp_decode(fmt, CxT, M), C.double().t())
+    else:
+        assert _err(H.xp_decode(fmt, Cx, N, so), C.double()) < 1e-6
+        assert torch.equal(H.xp_decode(fmt, CxT, M, so), H.xp_decode(fmt, Cx, N, so).t())
     assert float((cs.double().sum(0) - want.sum(0)).abs().max() / want.sum(0).abs().max()) < 1e-5
     # += and split-K (parameter-gradient role)
-    A2, B2 = _rand(1000, 2401, 1e-3, 25), _rand(1000, 2401, 1.0, 26)
-    A2x, _ = H.cast_xp(fmt, A2)
-    B2x, _ = H.cast_xp(fmt, B2)
-    C0 = _rand(1000, 1000, 1.0, 27)
+    A2, B2 = _rand(1000, 2401, 1e-3 * mag, 25), _rand(1000, 2401, 1.0, 26)
+    A2x, _, m2A = _xp_operand(fmt, A2)
+    B2x, _, m2B = _xp_operand(fmt, B2)
+    C0 = _rand(1000, 1000, mag, 27)
     Cacc = C0.clone()
-    H.gemm_xp(fmt, A2x, B2x, 1000, 1000, 2401, C=Cacc, out_mode=1)
+    H.gemm_xp(fmt, A2x, B2x, 1000, 1000, 2401, C=Cacc, out_mode=1, metaA=m2A, metaB=m2B)
     want = C0.double() + A2.double() @ B2.double().t()
     assert _err(Cacc, want) < 2e-6
     # the same launch twice gives the same bits (ordered slab combine)
     Cacc2 = C0.clone()
-    H.gemm_xp(fmt, A2x, B2x, 1000, 1000, 2401, C=Cacc2, out_mode=1)
+    H.gemm_xp(fmt, A2x, B2x, 1000, 1000, 2401, C=Cacc2, out_mode=1, metaA=m2A, metaB=m2B)
     assert torch.equal(Cacc, Cacc2)
+
+
+def test_fp16_pieces_cannot_overflow_and_degrade_gracefully():
+    """fmt 2's range guard: scales come from absmax records / bounds on the device, so magnitudes from 1e-30 to 1e30 neither overflow
+    nor flush the product; operands whose entries spread over 12 decades keep the error of the fp32 GEMM relative to the result's
+    largest entry."""
+    M, N, K = 512, 384, 1000
+    for ma, mb in [(1e30, 1e-30), (1e-25, 1e-10), (3e4, 3e4), (65504.0, 1.0)]:
+        A, B = _rand(M, K, ma, 31), _rand(N, K, mb, 32)
+        Ax, _, mA = _xp_operand(2, A)
+        Bx, _, mB = _xp_operand(2, B)
+        mo = torch.zeros(64, device=H.DEV)
+        C, Cx, _, _ = H.gemm_xp(2, Ax, Bx, M, N, K, C=torch.zeros(M, N, device=H.DEV), want_cx=True, metaA=mA, metaB=mB, metaOut=mo)
+        ref = A.double() @ B.double().t()
+        assert torch.isfinite(C).all() and _err(C, ref) < 2e-6, (ma, mb)
+        assert int((Cx.view(torch.float16).float().abs() > 65000).sum()) == 0
+        assert _err(H.xp_decode(2, Cx, N, H.meta_scale(mo)), ref) < 2e-6
+    g = torch.Generator().manual_seed(33)
+    A = (torch.randn(M, K, generator=g, dtype=torch.float64) * torch.pow(10.0, -12.0 * torch.rand(M, K, generator=g, dtype=torch.float64))).float().to(H.DEV)
+    B = _rand(N, K, 1.0, 34)
+    Ax, _, mA = _xp_operand(2, A)
+    Bx, _, mB = _xp_operand(2, B)
+    C, _, _, _ = H.gemm_xp(2, Ax, Bx, M, N, K, metaA=mA, metaB=mB)
+    ref = A.double() @ B.double().t()
+    assert _err(C, ref) <= 1.5 * _err(H.gemm(A, B, 0, 1), ref) + 1e-9
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # The chain inside the step: args.mlp_gemm = 'f32_split' against 'f32' (v_mfma_f32_32x32x2_f32 throughout) on the same state.
-def _pair(V, T, h, num_verts, version=2, **over):
+def _pair(V, T, h, num_verts, version=2, variant='f32_split', **over):
     from nemo_cvpr2023_amd import synthetic as syn
     from nemo_cvpr2023_amd.neural_motion_model import NEMO_VERSIONS
     seqs = syn.SyntheticSequences(V, T, seed=1234)
     assets, vps, gmm = syn.make_smpl_assets(num_verts, seed=1, skin_nnz=4), syn.make_vposer_state(), syn.make_gmm()
     ms = []
-    for mg in ('f32', 'f32_split'):
+    for mg in ('f32', variant):
         args = syn.published_args(batch_size=64, out_dir='', h_dim=h, mlp_gemm=mg, **over)
         torch.manual_seed(0)
         ms.append(NEMO_VERSIONS[version](args, seqs, H.DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm))
@@ -121,11 +175,12 @@ def _pair(V, T, h, num_verts, version=2, **over):
 
 @pytest.mark.parametrize('V,T,h,nv,version,full', [(3, 10, 48, 100, 2, True), (3, 10, 48, 100, 3, False), (4, 50, 1000, 256, 2, True),
                                                    (8, 300, 1000, 6890, 2, True), (8, 300, 1000, 512, 4, False)])
-def test_split_chain_matches_fp32_chain_in_the_step(V, T, h, nv, version, full, monkeypatch):
+@pytest.mark.parametrize('variant', ['f32_split3', 'f32_split2'])
+def test_split_chain_matches_fp32_chain_in_the_step(V, T, h, nv, version, full, variant, monkeypatch):
     from nemo_cvpr2023_amd.engine import FitEngine
     monkeypatch.setattr(FitEngine, 'XP_MIN_ROWS', 0)
     over = dict(monotonic_network_n_nodes=20, phase_rbf_dim=16) if h < 100 else {}
-    m32, mxp = _pair(V, T, h, nv, version, **over)
+    m32, mxp = _pair(V, T, h, nv, version, variant, **over)
     assert mxp.engine.mlp_split and not m32.engine.mlp_split
     with torch.no_grad():
         for m in (m32, mxp):

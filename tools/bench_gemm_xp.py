@@ -33,8 +33,11 @@ for name, M, N, K, kw in [('fwd hidden (copies)', rows, 1000, 1000, dict(want_cx
                           ('dX first', rows, 105, 1000, {})]:
     A = torch.randn(M, K, device=H.DEV)
     B = torch.randn(N, K, device=H.DEV)
-    Ax, _ = H.cast_xp(fmt, A)
-    Bx, _ = H.cast_xp(fmt, B)
+    mA = H.absmax_meta(A)[0] if fmt == 2 else None
+    mB = H.absmax_meta(B)[0] if fmt == 2 else None
+    mo = torch.zeros(64, device=H.DEV)
+    Ax, _ = H.cast_xp(fmt, A, meta=mA)
+    Bx, _ = H.cast_xp(fmt, B, meta=mB)
     kw = dict(kw)
     maskx = None
     if kw.pop('mask', False):
@@ -50,7 +53,8 @@ for name, M, N, K, kw in [('fwd hidden (copies)', rows, 1000, 1000, dict(want_cx
         H.check(L.nemo_gemm_xp(fmt, M, N, K, H.dptr(Ax), Ax.stride(0), H.dptr(Bx), Bx.stride(0), H.dptr(C), N, None, kw.get('act', 0),
                                H.dptr(maskx), maskx.stride(0) if maskx is not None else 0, 1 if maskx is not None else 0, 1.0,
                                kw.get('out_mode', 0), H.dptr(Cx), Cx.stride(0) if Cx is not None else 0, H.dptr(CxT),
-                               CxT.stride(0) if CxT is not None else 0, 1.0, H.dptr(cs), N if cs is not None else 0, H.dptr(ws),
+                               CxT.stride(0) if CxT is not None else 0, 1.0, H.dptr(cs), N if cs is not None else 0, H.dptr(mA), H.dptr(mB), None,
+                               H.dptr(mo) if Cx is not None else None, None, H.dptr(ws),
                                ws.numel() * 4, H.st()), 'xp')
     t_xp = timeit(run)
     Cf = torch.zeros(M, N, device=H.DEV)
