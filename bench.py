@@ -523,7 +523,7 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
     on_bf16 = (mesh_b16 + parts['blend_adjoint'] + parts['mlp'] + parts['vposer']) if dtype == 'bf16' else 0.0
     _mp = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh'])
     on_b16x6, on_f16x3 = _mp.get('bf16x6', 0.0), _mp.get('f16x3', 0.0)
-    if dtype != 'bf16' and getattr(engine, 'split_adj', False):
+    if dtype != 'bf16' and getattr(engine, 'split_adj', False) and engine.ctx.split_ok:
         on_f16x3 += parts['blend_adjoint']              # (the blend-shape adjoint in split precision too)
     if dtype != 'bf16' and getattr(engine, 'mlp_split', False) and any('Xx' in w_ for w_ in engine.ws.values()):
         # (the MotionNet chain on nemo_gemm_xp: three fp16 / six bf16 piece products per algorithmic product)
@@ -913,6 +913,8 @@ def worker_main(opts):
     shard_info = shard_probe(cx, model, step, opts.steps) if cx.sharded else None
     shard_mode = model.shard_mode if cx.sharded else None
     mesh_split, mesh_variant = bool(engine.mesh_split), engine.mesh_kernel_variant()
+    engine_blend = engine.mesh_blend_in_effect()
+    engine_mlp = 'bf16' if engine.bf16 else (('f32_split' if engine.xp_fmt == 2 else 'f32_split3') if engine.mlp_split else 'f32')
     del engine
     release(cx, model)
     cx.wd.beat('headline done')
@@ -977,7 +979,7 @@ def worker_main(opts):
                                    + (f'{SKIN_NNZ} non-zero skinning weights per vertex (the published SMPL model\'s sparsity)'
                                       if SKIN_NNZ <= 4 else 'a dense skinning-weight matrix'),
                        'instances': V, 'frames': T, 'samples_per_step': V * T, 'h_dim': args.h_dim, 'skin_nnz': SKIN_NNZ,
-                       'mesh_blend': ('f32_split' if mesh_split else 'f32') if opts.dtype == 'f32' else 'bf16',
+                       'mesh_blend': engine_blend, 'mlp_gemm': engine_mlp,
                        'mesh_kernel': mesh_variant,
                        'parallelism': f'instance-shard x{world}' if world > 1 else
                        ('sharded code path in a process group of ONE rank (diagnostic)' if cx.sharded else 'single GPU')},

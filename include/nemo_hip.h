@@ -302,6 +302,14 @@ int64_t nemo_ctx_num_verts(const nemo_ctx* ctx);
  * zero terms); nemo_ctx_set_skin_sparse(ctx, 0) selects the dense product again (EINVAL for enable != 0 when
  * skin_nnz > 4), nemo_ctx_skin_sparse reports the current choice.  Change it only while no launch is in flight. */
 int32_t nemo_ctx_skin_nnz(const nemo_ctx* ctx);
+/* Range guard of the fp16 split-precision mesh kernel (ABI 17).  nemo_v2v_fused_split(mem) stage the blended vertices
+ * vp = v_shaped + P pf (human_body_prior/body_model/lbs.py:229-233) as two fp16 pieces of 2^12 vp.  nemo_ctx_vp_bound: the bound
+ * max_v (|v_shaped[v]| + 2 sum_k |posedirs[k][v]|) >= |vp| for every pose (|pf| <= 2), recomputed by nemo_ctx_set_betas;
+ * nemo_ctx_split_ok: 1 while 2^12 * bound < 2^15.9 (a body model in metres: bound ~ 1.5), else 0 -- then nemo_v2v_fused_split runs its
+ * three-bf16-piece form (fp32's exponent range; same fp32-equivalent arithmetic, 14 % slower) and nemo_v2v_fused_splitmem returns
+ * NEMO_EINVAL: the caller keeps d vp in fp32 (nemo_v2v_fused_split + the fp32 adjoint GEMM). */
+int32_t nemo_ctx_split_ok(const nemo_ctx* ctx);
+float nemo_ctx_vp_bound(const nemo_ctx* ctx);
 int32_t nemo_ctx_skin_sparse(const nemo_ctx* ctx);
 int32_t nemo_ctx_set_skin_sparse(nemo_ctx* ctx, int32_t enable);
 int64_t nemo_ctx_nq(const nemo_ctx* ctx);            /* # non-kinematic output joints            */

@@ -51,6 +51,12 @@ struct nemo_ctx {
     unsigned short* d_posedirs_sph;    // two fp16 pieces per blend shape x sph_scale (mesh kernel MODE 5), [tile][S][component][piece][lane][8 k]
     unsigned short* d_Wadjh;           // MODE 5: [tile][joint tile 2][variant 2: W0|W0, W1|0][lane 64][8] (two fp16 pieces of 2^14 W)
     float sph_scale;                   // power of two: max |P| * sph_scale in [2^13, 2^14)
+    // range guard of MODE 5 (two fp16 pieces): the kernel stages the blended vertices vp = v_shaped + P pf and their pieces x 2^12,
+    // |pf| <= 2 (entries of R - I) -- vp_bound = max_v (|v_shaped| + 2 sum_k |P[k][v]|) bounds every |vp|; MODE 5 is used only while
+    // vp_bound * 2^12 < 2^15.9 (else MODE 4: three bf16 pieces, fp32's exponent range).  h_pabs2 = 2 sum_k |P[k][.]| per coordinate.
+    std::vector<float> h_pabs2;
+    float vp_bound = 0.f;
+    int split_ok = 1;
     unsigned short* d_Wadj3;           // MODE 4: [tile][joint tile 2][variant 3: W0|W0, W1|W1, W0|W2][lane 64][8] (three bf16 pieces of W)
     // SPARSE skinning weights (the published SMPL model has at most four non-zero weights per vertex; the dense 24-column
     // product of lbs.py:236-241 then multiplies 20 zeros per vertex): per vertex (NVp of them, zero rows for the pad) the
@@ -80,6 +86,12 @@ extern "C" int32_t nemo_ctx_set_betas(nemo_ctx* ctx, const float* betas) {
             for (int l = 0; l < 10; ++l) acc += (double)b[l] * ctx->h_shapedirs[(v * 3 + c) * 10 + l];
             vs[v * 3 + c] = ctx->h_v_template[v * 3 + c] + (float)acc;
         }
+    {
+        float bnd = 0.f;
+        for (long i = 0; i < NV * 3; ++i) bnd = fmaxf(bnd, fabsf(vs[i]) + (ctx->h_pabs2.empty() ? 0.f : ctx->h_pabs2[i]));
+        ctx->vp_bound = bnd;
+        ctx->split_ok = (bnd * 4096.f < 61000.f) ? 1 : 0;      // 2^15.9 = 61 147; not finite: 0
+    }
     std::vector<float> J(72);
     for (int j = 0; j < 24; ++j)
         for (int c = 0; c < 3; ++c) {
@@ -123,6 +135,9 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
     for (int i = 0; i < 24; ++i) c->kc.parents[i] = (int)parents[i];
     c->h_v_template.assign(v_template, v_template + NV * 3);
     c->h_shapedirs.assign(shapedirs, shapedirs + NV * 30);
+    c->h_pabs2.assign((size_t)NV * 3, 0.f);
+    for (int k = 0; k < 207; ++k)
+        for (long i = 0; i < NV * 3; ++i) c->h_pabs2[i] += 2.f * fabsf(posedirs[(size_t)k * NV * 3 + i]);
     c->h_Jreg.assign(J_regressor, J_regressor + 24 * NV);
     c->h_W.assign(lbs_weights, lbs_weights + NV * 24);
     // classify the output joints
@@ -356,6 +371,8 @@ extern "C" int32_t nemo_ctx_destroy(nemo_ctx* c) {
 }
 extern "C" int64_t nemo_ctx_num_verts(const nemo_ctx* c) { return c ? c->NV : -1; }
 extern "C" int32_t nemo_ctx_skin_nnz(const nemo_ctx* c) { return c ? c->skin_nnz : -1; }
+extern "C" int32_t nemo_ctx_split_ok(const nemo_ctx* c) { return c ? c->split_ok : -1; }
+extern "C" float nemo_ctx_vp_bound(const nemo_ctx* c) { return c ? c->vp_bound : -1.f; }
 extern "C" int32_t nemo_ctx_skin_sparse(const nemo_ctx* c) { return c ? c->skin_sparse : -1; }
 extern "C" int32_t nemo_ctx_set_skin_sparse(nemo_ctx* c, int32_t enable) {
     if (!c || (enable && c->skin_nnz > 4)) return NEMO_EINVAL;
@@ -2648,7 +2665,11 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
     // kind 2 (fp32-equivalent split precision): two fp16 pieces per operand (MODE 5); NEMO_MESH_PIECES=3: three bf16 pieces (MODE 4, the
     // first form of the round: 360 against ... us per 8 x 300 launch), an A/B aid
     static const int pieces_env = getenv("NEMO_MESH_PIECES") ? atoi(getenv("NEMO_MESH_PIECES")) : 2;
-    const int mode = bf16 ? (split_env == 3 ? 3 : 2) : kind == 2 ? ((pieces_env == 3 && !dVPb) ? 4 : 5) : 0;   // (fp16 planes out: MODE 5 only)
+    // Range guard: the fp16 pieces of the blended vertices hold |vp| 2^12 < 2^15.9 only while the body model's bound allows it
+    // (nemo_ctx_split_ok, set by nemo_ctx_create / nemo_ctx_set_betas); beyond it the three-bf16-piece form runs -- and the caller
+    // that asked for fp16 piece planes of d vp is refused (the engine asks nemo_ctx_split_ok first)
+    if (kind == 2 && dVPb && !ctx->split_ok) return NEMO_EINVAL;
+    const int mode = bf16 ? (split_env == 3 ? 3 : 2) : kind == 2 ? (((pieces_env == 3 || !ctx->split_ok) && !dVPb) ? 4 : 5) : 0;   // (fp16 planes out: MODE 5 only)
     const bool sparse = ctx->skin_sparse != 0 && mode != 2;
     const int lds_bytes = mode == 2 ? (2 * 16 * MF_PFB / 2 + 2 * 2 * 16 * MF_AB / 2 + MF_TAIL) * (int)sizeof(float)
         : ((mode == 4 ? 3 * 2 * 16 * MF_PFB / 2 : mode == 5 ? 2 * 2 * 16 * MF_PFB / 2 : bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) +

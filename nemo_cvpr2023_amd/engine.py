@@ -75,6 +75,13 @@ class SmplContext:
         self.skin_nnz = int(self.lib.nemo_ctx_skin_nnz(h))
         # which mesh-kernel variant launches bake in (part of every graph key that contains the mesh term)
         self.skin_sparse_flag = bool(self.lib.nemo_ctx_skin_sparse(h))
+        # range guard of the fp16 split-precision mesh kernel (include/nemo_hip.h nemo_ctx_split_ok): False for a body model whose
+        # blended vertices could reach 2^15.9 / 2^12 (other units than metres, extreme betas) -- then the three-bf16-piece form runs
+        self.split_ok = bool(self.lib.nemo_ctx_split_ok(h))
+
+    @property
+    def vp_bound(self):
+        return float(self.lib.nemo_ctx_vp_bound(self.handle))
 
     @property
     def skin_sparse(self):
@@ -93,6 +100,7 @@ class SmplContext:
             check(self.lib.nemo_ctx_set_betas(self.handle, b.ctypes.data_as(ctypes.c_void_p)),
                   'nemo_ctx_set_betas')
             self._betas = b.copy()
+            self.split_ok = bool(self.lib.nemo_ctx_split_ok(self.handle))
 
     def __del__(self):
         try:
@@ -566,7 +574,7 @@ class FitEngine:
         if not self.bf16:
             if tag in ('gemm_mlp_hidden_fwd', 'gemm_mlp_hidden_dx') and self.mlp_split and any('Xx' in w_ for w_ in self.ws.values()):
                 return {('f16x3' if self.xp_fmt == 2 else 'bf16x6'): flops}      # (nemo_gemm_xp: three fp16 / six bf16 piece products per product)
-            if tag == 'gemm_pose_blend_bwd' and self.split_adj:
+            if tag == 'gemm_pose_blend_bwd' and self.split_adj and self.ctx.split_ok:
                 return {'f16x3': flops}              # (nemo_gemm_f16x2mem_adj: three fp16 piece products per algorithmic product)
             out = {'f32': flops - valu}
             if tag == 'mesh_v2v_fused' and self.mesh_split:
@@ -574,7 +582,7 @@ class FitEngine:
                 #  piece products per algorithmic product -- pipe 'f16x3', whose peak is a third of the fp16 / bf16 MFMA peak;
                 #  NEMO_MESH_PIECES=3 (MODE 4): six bf16 piece products, 'bf16x6')
                 b16 = flops * (2 * 3 * 207 + 288) / self.mesh_macs()
-                out = {('bf16x6' if os.environ.get('NEMO_MESH_PIECES') == '3' else 'f16x3'): b16, 'f32': flops - b16 - valu}
+                out = {('bf16x6' if self._mesh_three_pieces() else 'f16x3'): b16, 'f32': flops - b16 - valu}
             if valu:
                 out['valu_f32'] = valu
             return out
@@ -601,9 +609,22 @@ class FitEngine:
         skin = 12 * (4 if sparse else 24)
         return 2 * 3 * 207 + 2 * skin + (skin if strict and sparse else 288)
 
+    def _mesh_three_pieces(self):
+        """mesh_blend 'f32_split' runs its three-bf16-piece form (kernel MODE 4): asked for (NEMO_MESH_PIECES=3, without fp16 planes of
+        d vp) or forced by the range guard (nemo_ctx_split_ok == 0)."""
+        return (os.environ.get('NEMO_MESH_PIECES') == '3' and not self.split_adj) or not self.ctx.split_ok
+
+    def mesh_blend_in_effect(self):
+        """What bench.py reports as config.mesh_blend."""
+        if self.bf16:
+            return 'bf16'
+        if not self.mesh_split:
+            return 'f32'
+        return 'f32_split3 (range guard: vp bound %.3g)' % self.ctx.vp_bound if not self.ctx.split_ok else ('f32_split3' if self._mesh_three_pieces() else 'f32_split')
+
     def mesh_kernel_variant(self):
         """The mesh kernel instantiation this engine launches (what counter files under profiles/ are keyed by)."""
-        mode = (3 if os.environ.get('NEMO_MESH_SPLIT', '2') == '3' else 2) if self.bf16 else ((4 if os.environ.get('NEMO_MESH_PIECES') == '3' else 5) if self.mesh_split else 0)
+        mode = (3 if os.environ.get('NEMO_MESH_SPLIT', '2') == '3' else 2) if self.bf16 else ((4 if self._mesh_three_pieces() else 5) if self.mesh_split else 0)
         return f"mesh_v2v_fused_kernel<{mode}, {'true' if self.ctx.skin_sparse_flag and mode != 2 else 'false'}>"
 
     # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
@@ -1241,8 +1262,12 @@ class FitEngine:
         calls it BEFORE replaying a captured graph -- a replay skips the Python body that used to do it."""
         ctx = ctx or self.ctx
         if self.betas._version != getattr(ctx, '_betas_version', None):   # no D2H sync in the steady state
+            was = ctx.split_ok
             ctx.set_betas(self.betas.detach().cpu().numpy())
             ctx._betas_version = self.betas._version
+            if ctx.split_ok != was:        # the mesh kernel variant changes: captured graphs bake the old one in
+                for w_ in self.ws.values():
+                    w_['graphs'].clear()
 
     def vposer_mulv(self, w, N):
         """The encoder's (mu | logvar) product: only the KL term reads it, so it runs on the KL stream (the decoder starts
@@ -1323,7 +1348,8 @@ class FitEngine:
             #  reduction's tail -- 0.509 against 0.503 ms, same box; 8 x 300: 1.557 against 1.564 ms; round 4: minibatch-512 steps
             #  0.572 against 0.579 ms deferred, two instances 0.602 against 0.618)
             defer = need_grad and self.SMALL_BATCH_ROWS < N <= Nc and self.timers is None
-            hsplit = need_grad and self.split_adj and n >= self.SPLIT_ADJ_ROWS
+            # (fp16 piece planes of d vp only while the body model is inside the fp16 form's range: nemo_ctx_split_ok)
+            hsplit = need_grad and self.split_adj and ctx.split_ok and w['dVPh'] is not None and n >= self.SPLIT_ADJ_ROWS
             if hsplit:
                 dh = w['dVPh']
                 check(L.nemo_v2v_fused_splitmem(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']), self.scal.data_ptr() + 4 * S_V2V,

@@ -1056,16 +1056,18 @@ def _mesh_term_f64(assets, PF, A, N):
 def test_v2v_fused_split_is_fp32_equivalent(L, skin_nnz):
     """nemo_v2v_fused_split (pose blend on the bf16 pipe, three bf16 pieces per operand) against a float64 evaluation of
     the same fp32 inputs: its error must not exceed 1.5 x the fp32-MFMA kernel's (criterion (a)) -- it
-    is not narrower arithmetic than the reference's.  Blend shapes scaled x 100 so that the pose offsets are as large as
+    is not narrower arithmetic than the reference's.  Blend shapes scaled x 30 so that the pose offsets are a third of
     the template (with the synthetic model's 1e-3 offsets a blend of ANY precision would hide behind the template's
-    rounding)."""
+    rounding; x 100, the scaling of round 5, puts the model's worst-case vertex bound outside the fp16 form's range guard --
+    nemo_ctx_split_ok -- and the three-piece form would run: that case is test_v2v_fused_split_regimes_and_range_guard's)."""
     H = _ops()
     num_verts, N = 6890, 40
     assets = syn.make_smpl_assets(num_verts, seed=1, skin_nnz=skin_nnz)
-    assets['posedirs'] = assets['posedirs'] * 100.0
+    assets['posedirs'] = assets['posedirs'] * 30.0
     from nemo_cvpr2023_amd.engine import SmplContext
     jm = [int(x) for x in assets['joint_map']]
     ctx = SmplContext(assets, [jm[i] for i in [38] + list(range(1, 25))], 'cuda:0')
+    assert ctx.split_ok, ctx.vp_bound
     gen = torch.Generator().manual_seed(3)
     R2 = H.dev(_rand_rot(gen, 2 * N * 24, small=True).reshape(2 * N, 24, 9))
     Z = lambda *s: torch.zeros(*s, device='cuda')
@@ -1172,3 +1174,82 @@ def test_blend_shape_adjoint_in_split_precision(L, M, K):
     print('blend-shape adjoint, max error / max |result| against float64: split', e_split, 'fp32 kernel', e32)
     assert e_split <= 1.5 * e32 + 1e-7 and e_split < 3e-6
     assert torch.equal(C[:, N:], C0[:, N:])                                       # column 207 untouched
+
+
+@pytest.mark.parametrize('regime', ['model_x2.5', 'model_x10', 'model_x100', 'pose_1e-5', 'pose_1e-7', 'posedirs_6_decades', 'vp_at_the_edge'])
+def test_v2v_fused_split_regimes_and_range_guard(L, regime):
+    """nemo_v2v_fused_split over the magnitude regimes its fp16 pieces could be sensitive to, each against a
+    float64 evaluation of the same fp32 inputs and against the fp32-MFMA kernel's error (<= 1.5 x, as in the test above):
+      model_x2.5 / x10 / x100  the body model in other units: v_template and posedirs x 2.5 (inside the fp16 form's range: 2^12 x the bound
+                        on |vp| < 2^15.9), x 10 and x 100 (outside: nemo_ctx_split_ok must say so and the three-bf16-piece form must run
+                        -- no inf / NaN, same error bar);
+      pose_1e-5 / 1e-7  pose features of the "orig" body at the published initialisation's size (rotations within 1e-5 / 1e-7 rad of
+                        identity: the low fp16 piece of a pose feature is a subnormal or zero) against a reconstruction body at 0.3 rad
+                        -- what the step sees at its first iterations (the VPoser reconstruction is NOT near identity);
+      posedirs_6_decades  blend shapes whose entries spread log-uniformly over six decades (real SMPL spans > 4);
+      vp_at_the_edge    a model scaled so that the bound sits just inside the guard (2^12 bound = 0.97 x 61 000)."""
+    H = _ops()
+    num_verts, N = 6890, 40
+    assets = syn.make_smpl_assets(num_verts, seed=1, skin_nnz=4)
+    assets['posedirs'] = assets['posedirs'] * 10.0
+    small = 0.3
+    gen = torch.Generator().manual_seed(7)
+    if regime.startswith('model_x'):
+        k = float(regime.split('x')[1])
+        assets['v_template'] = assets['v_template'] * k
+        assets['posedirs'] = assets['posedirs'] * k
+    elif regime.startswith('pose_'):
+        small = float(regime.split('_')[1])
+    elif regime == 'posedirs_6_decades':
+        P = assets['posedirs']
+        assets['posedirs'] = P * torch.pow(10.0, -6.0 * torch.rand(P.shape, generator=gen))
+    from nemo_cvpr2023_amd.engine import SmplContext
+    jm = [int(x) for x in assets['joint_map']]
+    oj = [jm[i] for i in [38] + list(range(1, 25))]
+    ctx = SmplContext(assets, oj, 'cuda:0')
+    if regime == 'vp_at_the_edge':
+        k = 0.97 * 61000.0 / 4096.0 / ctx.vp_bound
+        assets['v_template'] = assets['v_template'] * k
+        assets['posedirs'] = assets['posedirs'] * k
+        ctx = SmplContext(assets, oj, 'cuda:0')
+        assert ctx.split_ok and ctx.vp_bound * 4096 > 0.9 * 61000
+    assert ctx.split_ok == (regime not in ('model_x10', 'model_x100')), (regime, ctx.vp_bound)
+    from oracle import ops
+    th = torch.randn(2 * N * 24, 3, generator=gen, dtype=torch.float64) * small
+    if regime.startswith('pose_'):
+        th[N * 24:] *= 0.3 / small
+    R2 = H.dev(ops.batch_rodrigues(th).float().reshape(2 * N, 24, 9))
+    Z = lambda *s: torch.zeros(*s, device='cuda')
+    A, Jp, PF = Z(2 * N, 24, 12), Z(2 * N, 24, 3), Z(2 * N, 208)
+    assert L.nemo_fk_fwd(ctx.handle, 2 * N, R2.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), 208, H.st()) == 0
+    torch.cuda.synchronize()
+    l_ref, dvp_ref, dA_ref, d = _mesh_term_f64(assets, PF, A, N)
+    vmax = float(assets['v_template'].abs().max())
+    clean = (d.abs().reshape(N, -1).min(1).values > 3e-6 * max(vmax, 1.0))
+    ldn = (N + 15) // 16 * 16
+    ws = torch.zeros(int(L.nemo_v2v_fused_ws_bytes(ctx.handle, N)) // 4 + 1, device='cuda')
+    err = {}
+    for name, fn in (('f32', L.nemo_v2v_fused), ('split', L.nemo_v2v_fused_split)):
+        loss, dVPt, dA = Z(1), Z(3 * ctx.NVp, ldn), Z(N, 24, 12)
+        assert fn(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss.data_ptr(), dVPt.data_ptr(), ldn, dA.data_ptr(),
+                  ws.data_ptr(), ws.numel() * 4, H.st()) == 0
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss).all() and torch.isfinite(dA).all() and torch.isfinite(dVPt).all(), (regime, name)
+        dvp = dVPt[:3 * num_verts, :N].t().reshape(N, num_verts, 3).double()
+        e_dA = (dA.double() - dA_ref)[clean]
+        err[name] = dict(loss=abs(float(loss) - float(l_ref)) / max(float(l_ref), 1e-30),
+                         dA_max=float(e_dA.abs().max() / dA_ref.abs().max()),
+                         dA_rms=float(e_dA.pow(2).mean().sqrt() / dA_ref.pow(2).mean().sqrt()),
+                         dvp_max=float((dvp - dvp_ref)[clean].abs().max() / dvp_ref.abs().max()))
+    print(regime, 'mesh term error against float64:', err)
+    f, s = err['f32'], err['split']
+    assert int(clean.sum()) >= N // 2
+    assert s['dA_rms'] <= 1.5 * f['dA_rms'] + 1e-9, err
+    assert s['dA_max'] <= 1.5 * f['dA_max'] + 1e-9, err
+    assert s['dvp_max'] <= 1.5 * f['dvp_max'] + 1e-9, err
+    assert s['loss'] <= 1.5 * f['loss'] + 2e-7, err
+    # fp16 piece planes of d vp are refused outside the range (the engine keeps d vp in fp32 then)
+    if not ctx.split_ok:
+        dh = torch.zeros(2, ldn, ctx.ldP, dtype=torch.int16, device='cuda')
+        assert L.nemo_v2v_fused_splitmem(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), Z(1).data_ptr(), dh.data_ptr(), dh.stride(1),
+                                         dh.stride(0), Z(N, 24, 12).data_ptr(), ws.data_ptr(), ws.numel() * 4, H.st()) < 0
