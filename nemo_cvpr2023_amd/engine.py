@@ -429,8 +429,8 @@ class FitEngine:
     XP_MIN_ROWS = int(os.environ.get('NEMO_XP_MIN_ROWS', '1600'))    # mlp_gemm 'f32_split': the chain on nemo_gemm_xp from this many rows on
     XP_DW_ASIDE_ROWS = 65536  # ... its parameter-gradient products on the side stream up to this many rows
     XMETA = ('X', 'H1', 'H2', 'H3', 'dHEAD', 'dH', 'dH_b', 'dH_c', 'W0', 'W2', 'W4', 'Whead', 'b0', 'b2', 'b4')
-    ECS_ROWS = 1536          # fp32 backward_mlp: bias gradients from the dX launches' per-band column sums above this many rows
-                             # (same box: headline 1.257 / 1.259 ms without / with, C4 101.8 / 101.5 ms: the win is C4's 6.6 GB of reads)
+    # (fp32 backward_mlp: the bias gradients come from the dX launches' per-band column sums at EVERY size -- headline 1.257 / 1.259 ms
+    #  without / with, C4 101.8 / 101.5 ms: the win is C4's 6.6 GB of reads; a row threshold was never applied and is gone)
     MAX_WORKSPACES = 24      # distinct batch sizes kept alive (a rank of a sharded minibatch run sees many)
 
     @staticmethod
@@ -473,6 +473,8 @@ class FitEngine:
             E1=Z(N, 512), MULV=Z(N, 64), D1=Z(N, 512), D2=Z(N, 512),
             D3=Z(N, 126), AAdec=Z(N, 63),
             R2=Z(2 * Nc, 24, 9), A2=Z(2 * Nc, 24, 12), Jp2=Z(2 * Nc, 24, 3), PF2=Z(2 * Nc, 208),
+            # (kept at full size beside dVPh: evaluation passes, chunk tails below SPLIT_ADJ_ROWS and a model the range guard sends back
+            #  to fp32 planes -- nemo_ctx_split_ok after a set_betas -- all write it; 680 MB per 8192-sample workspace of 288 GB)
             dVPt=Z(3 * self.ctx.NVp, (Nc + 15) // 16 * 16) if not self.b16mem else Z(16),
             # (mesh_blend 'f32_split': d vp as two fp16 piece planes [2][samples][blend-shape row stride])
             dVPh=(torch.zeros(2, (Nc + 15) // 16 * 16, self.ctx.ldP, dtype=torch.int16, device=self.device)

@@ -876,8 +876,18 @@ class MultiViewModel(nn.Module):
 
     def _body(self, w, b, pl, vi_, fi_, adam_table, part='all', run_adam=True):
         """Everything of the step (or of one part of it) that runs on the device without host interaction."""
+        e = self.engine
+        # full batches are view-major by construction: the phase backward may find a view's samples by a search (engine.batch_sorted).
+        # The flag is valid for THIS body only -- it is taken back on every way out, so that no later caller of engine.phase_bwd /
+        # backward_mlp inherits it (ADVICE r05: a stale True gives wrong d_shifts / d_scales for an unsorted batch, silently)
+        e.batch_sorted = bool(b.is_full) and not b.padded
+        try:
+            return self._body_impl(w, b, pl, vi_, fi_, adam_table, part, run_adam)
+        finally:
+            e.batch_sorted = False
+
+    def _body_impl(self, w, b, pl, vi_, fi_, adam_table, part, run_adam):
         e, sh, update = self.engine, b.sh, pl.update
-        e.batch_sorted = bool(b.is_full) and not b.padded           # (full batches are view-major: engine.batch_sorted)
         if part == 'bucketc':
             # 'buckets' mode as ONE launch: the three gradient buckets are all-reduced on the communication stream as
             # soon as the backward has completed them, each with its share of the fused Adam (device table, segments
