@@ -397,7 +397,7 @@ class Ctx:
     pass
 
 
-def build_model(cx, V, T, dtype, batch_size=512, skin_nnz=None, weight_smooth=0.0, mesh_blend=None):
+def build_model(cx, V, T, dtype, batch_size=512, skin_nnz=None, weight_smooth=0.0, mesh_blend=None, locality=False):
     """(model, engine) for a V x T synthetic fit on this worker's device -- ShardedNemo over the ranks when sharded."""
     import torch
     from nemo_cvpr2023_amd import synthetic as syn
@@ -409,7 +409,7 @@ def build_model(cx, V, T, dtype, batch_size=512, skin_nnz=None, weight_smooth=0.
     if weight_smooth:
         args.weight_smooth = weight_smooth      # BASELINE configs[4]: the temporal-smoothness term in the loop
     seqs = syn.SyntheticSequences(V, T, seed=1234)
-    assets = dict(smpl_assets=syn.make_smpl_assets(6890, seed=1, skin_nnz=SKIN_NNZ if skin_nnz is None else skin_nnz),
+    assets = dict(smpl_assets=syn.make_smpl_assets(6890, seed=1, skin_nnz=SKIN_NNZ if skin_nnz is None else skin_nnz, locality=locality),
                   vposer_state=syn.make_vposer_state(), gmm=syn.make_gmm())
     torch.manual_seed(0)
     if cx.sharded:
@@ -540,12 +540,10 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
                                 'instead of the dense 24-joint product the kernel executes; = frac for a dense body model',
             'mfma_busy': busy, 'mfma_busy_source': traffic.get('mfma_busy_source') if busy is not None else None,
             'pipes': {d: round(f / 1e9, 2) for d, f in pipes.items()},
-            'frac_f32_pipe': round(achieved / MFMA_PEAK_TFLOPS['f32'], 4),
             'peak_note': 'fp32 MFMA peak' if set(pipes) <= {'f32', 'valu_f32'} else
                          'harmonic mix of the per-pipe peaks over this kernel\'s algorithmic GFLOP per pipe (`pipes`): bf16 MFMA 2500, '
                          'fp32 MFMA / fp32 VALU 157.3, f16x3 = fp32-equivalent products as three fp16 piece products = 2500 / 3 '
-                         '(mesh_blend f32_split); `frac_f32_pipe` = the same achieved rate against the fp32 MFMA peak alone, '
-                         'comparable with rounds 1 - 4',
+                         '(mesh_blend f32_split, mlp_gemm f32_split), bf16x6 = six bf16 piece products = 2500 / 6',
             'traffic': ktr, 'traffic_source': traffic.get('source') if ktr else None,
             'traffic_commit': traffic.get('commit') if ktr else None, 'traffic_kernel': variant if ktr else None,
             'traffic_dropped': 'counters in profiles/traffic.json were taken on ' + str(traffic.get('kernel_variants', {}).get(tag)) +
@@ -563,7 +561,14 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
                      'gflop_on_bf16_pipe': round(on_bf16 / 1e9, 2),
                      'flops_parts': {k: round(v / 1e9, 2) for k, v in parts.items()}},
             'hbm': None}
-    if traffic.get('step_bytes'):
+    # the step's counter bytes are only quoted for the build they were counted on: mesh kernel variant + MotionNet-chain arithmetic
+    # (profiles/traffic.json records both as `step_variant`)
+    step_variant = engine.mesh_kernel_variant() + '|mlp=' + (('f32_split' if engine.xp_fmt == 2 else 'f32_split3') if (
+        getattr(engine, 'mlp_split', False) and any('Xx' in w_ for w_ in engine.ws.values())) else ('bf16' if engine.bf16 else 'f32'))
+    roof['step_variant'] = step_variant
+    if traffic.get('step_bytes') and traffic.get('step_variant') not in (None, step_variant):
+        roof['hbm_dropped'] = f"step bytes in profiles/traffic.json were counted on {traffic.get('step_variant')}, this run is {step_variant}"
+    elif traffic.get('step_bytes'):
         gbs = traffic['step_bytes'] / (ms_per_step * 1e-3) / 1e9
         roof['hbm'] = {'bytes_per_step': traffic['step_bytes'], 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS,
                        'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4), 'source': traffic.get('source')}
@@ -582,12 +587,12 @@ def instrumented(cx, engine, step, n_inst):
     return timers
 
 
-def leg(cx, name, V, T, dtype, steps, warm, shard_mode='single', skin_nnz=None, weight_smooth=0.0, mesh_blend=None):
+def leg(cx, name, V, T, dtype, steps, warm, shard_mode='single', skin_nnz=None, weight_smooth=0.0, mesh_blend=None, locality=False):
     """A further BASELINE configuration as an extra key of the line: full-batch update steps of a V x T fit, timed like
     the headline (barrier + synchronize, max over ranks), with its own roofline block."""
     import torch
     try:
-        model, engine, _ = build_model(cx, V, T, dtype, skin_nnz=skin_nnz, weight_smooth=weight_smooth, mesh_blend=mesh_blend)
+        model, engine, _ = build_model(cx, V, T, dtype, skin_nnz=skin_nnz, weight_smooth=weight_smooth, mesh_blend=mesh_blend, locality=locality)
         if cx.sharded:
             model.set_shard_mode(shard_mode)
 
@@ -611,6 +616,7 @@ def leg(cx, name, V, T, dtype, steps, warm, shard_mode='single', skin_nnz=None, 
                'final_total_loss': float(out[0]['total_loss']),
                **({'final_smooth_loss': float(out[0]['smooth_loss'])} if weight_smooth else {}),
                'skinning': 'sparse' if engine.ctx.skin_sparse else 'dense', 'skin_nnz': engine.ctx.skin_nnz,
+               'body_model': 'synthetic, spatially structured (synthetic.make_smpl_assets(locality=True))' if locality else 'synthetic, random permutation (default)',
                'mesh_kernel': engine.mesh_kernel_variant(),
                'roofline': roofline_block(cx, engine, timers, 2, ms, V, T, dtype, skin_nnz=skin_nnz)}
         if cx.sharded:
@@ -939,6 +945,10 @@ def worker_main(opts):
             # the headline workload with the mesh term's pose blend on the fp32 MFMA pipe (the arithmetic of rounds 1 - 4); the
             # headline itself runs the engine default, the fp32-equivalent three-piece bf16 blend (`f32_split` below)
             extra['f32_mfma_blend'] = leg(cx, 'f32_mfma_blend', V0, T0, 'f32', 20, 3, mesh_blend='f32')
+            # the headline workload on a body model with SMPL's spatial structure (vertices ordered by body part, 1 - 2 dominant
+            # skinning weights, sparse local joint regressors): every other number of this line is on the default synthetic model,
+            # whose vertices are a random permutation -- pessimal for the sparse skinning's LDS reads and the mesh kernel's L1
+            extra['locality_body_model'] = leg(cx, 'locality_body_model', V0, T0, 'f32', 20, 3, locality=True)
 
     cpu = None
     if rank == 0 and world == 1 and not opts.no_cpu_baseline:

@@ -41,8 +41,92 @@ def _row_normalised(gen, rows, cols, power):
     return (w / w.sum(1, keepdim=True)).float()
 
 
-def make_smpl_assets(num_verts: int = 6890, seed: int = 1, skin_nnz: int = 24) -> dict:
+def _locality_assets(nv: int, g, skin_nnz: int) -> dict:
+    """A body model with the published SMPL model's SPATIAL structure (the model file itself is not redistributable,
+    hmr/hmr_config.py:70-76): a skeleton of 24 rest joints laid out along the kinematic tree; vertices stored body part by
+    body part (consecutive indices share their dominant joint, as SMPL's do within a part), each around its part's bone;
+    1 - 2 dominant skinning weights -- the part's joint and its parent or a child, a rest among their neighbours in the tree --;
+    J_regressor rows that are sparse and local (a joint is regressed from ~1 % of the vertices, those of its own and its
+    parent's part); pose blend shapes that are large for the joints next to the vertex and 50 x smaller elsewhere.
+    Everything the kernels' access patterns depend on (which joints a 16-vertex tile touches, how many regressor entries a
+    joint has) then looks like the real model's instead of a random permutation's."""
+    par = SMPL_PARENTS
+    # rest skeleton: every joint 8 - 25 cm from its parent, in a direction that depends on the limb
+    J = torch.zeros(24, 3)
+    for j in range(1, 24):
+        d = torch.randn(3, generator=g)
+        J[j] = J[par[j]] + d / d.norm() * (0.08 + 0.17 * float(torch.rand((), generator=g)))
+    # vertices per part ~ bone length (at least 64), parts in joint order -> contiguous index ranges
+    w_part = torch.tensor([0.12] + [float((J[j] - J[par[j]]).norm()) for j in range(1, 24)])
+    cnt = torch.clamp((w_part / w_part.sum() * nv).long(), min=min(64, nv // 24))
+    cnt[0] += nv - int(cnt.sum())
+    if int(cnt[0]) < 1:
+        cnt = torch.full((24,), nv // 24, dtype=torch.long)
+        cnt[0] += nv - int(cnt.sum())
+    part = torch.repeat_interleave(torch.arange(24), cnt)
+    children = [[c for c in range(24) if par[c] == j] for j in range(24)]
+    vt = torch.zeros(nv, 3)
+    W = torch.zeros(nv, 24, dtype=torch.float64)
+    t_along = torch.rand(nv, generator=g)                       # position along the part's bone (towards the parent)
+    off = 0.04 * torch.randn(nv, 3, generator=g)
+    r1, r2 = torch.rand(nv, generator=g), torch.rand(nv, generator=g)
+    for v in range(nv):
+        j = int(part[v])
+        p = par[j] if j > 0 else 0
+        vt[v] = J[j] + float(t_along[v]) * 0.6 * (J[p] - J[j]) + off[v]
+        # second joint: the parent for vertices on the parent's side of the bone, else a child (if any)
+        second = p if (float(t_along[v]) > 0.5 or not children[j]) else children[j][int(r1[v] * len(children[j])) % len(children[j])]
+        main = 0.55 + 0.45 * abs(2.0 * float(t_along[v]) - 1.0) ** 0.5          # 1 - 2 dominant weights
+        W[v, j] += main
+        if second != j:
+            W[v, second] += (1.0 - main) * 0.85
+        rest = 1.0 - float(W[v].sum())
+        if skin_nnz >= 3 and rest > 0:
+            nb = [x for x in ([par[p]] if p > 0 else []) + children[second if second != j else j] if x not in (j, second) and x >= 0]
+            nb = nb[:max(skin_nnz - 2, 0)] if skin_nnz < 24 else nb
+            if nb:
+                for x in nb:
+                    W[v, x] += rest / len(nb)
+        W[v] /= W[v].sum()
+    if skin_nnz < 24:
+        keep = torch.zeros_like(W).scatter_(1, W.topk(int(skin_nnz), dim=1).indices, 1.0)
+        W = W * keep
+        W = W / W.sum(1, keepdim=True)
+    # J_regressor: joint j from ~nv / 100 vertices of its own and its parent's part (positive, rows sum to one)
+    starts = torch.cumsum(torch.cat([torch.zeros(1, dtype=torch.long), cnt]), 0)
+    Jr = torch.zeros(24, nv, dtype=torch.float64)
+    k_reg = max(8, nv // 100)
+    for j in range(24):
+        cand = torch.cat([torch.arange(int(starts[q]), int(starts[q + 1])) for q in {j, par[j] if j > 0 else 0}])
+        pick = cand[torch.randperm(cand.numel(), generator=g)[:min(k_reg, cand.numel())]]
+        wts = torch.rand(pick.numel(), generator=g, dtype=torch.float64) ** 2 + 1e-3
+        Jr[j, pick] = wts / wts.sum()
+    Jx = torch.zeros(NUM_EXTRA_ROWS, nv, dtype=torch.float64)
+    for q in range(NUM_EXTRA_ROWS):
+        j = int(torch.randint(0, 24, (1,), generator=g))
+        cand = torch.arange(int(starts[j]), int(starts[j + 1]))
+        pick = cand[torch.randperm(cand.numel(), generator=g)[:min(max(4, k_reg // 4), cand.numel())]]
+        wts = torch.rand(pick.numel(), generator=g, dtype=torch.float64) + 1e-3
+        Jx[q, pick] = wts / wts.sum()
+    # pose blend shapes: feature k belongs to joint 1 + k // 9; large where that joint is the vertex's part, its parent or a child
+    P = 1e-3 * torch.randn(207, nv, 3, generator=g)
+    near = torch.zeros(24, 24, dtype=torch.bool)
+    for j in range(24):
+        near[j, j] = True
+        if j > 0:
+            near[j, par[j]] = near[par[j], j] = True
+    scale = torch.where(near[1 + torch.arange(207) // 9][:, part], torch.tensor(1.0), torch.tensor(0.02))     # (207, nv)
+    P = (P * scale.unsqueeze(-1)).reshape(207, nv * 3)
+    return dict(v_template=vt, lbs_weights=W.float(), J_regressor=Jr.float(), J_regressor_extra=Jx.float(), posedirs=P,
+                shapedirs=0.01 * torch.randn(nv, 3, 10, generator=g))
+
+
+def make_smpl_assets(num_verts: int = 6890, seed: int = 1, skin_nnz: int = 24, locality: bool = False) -> dict:
     """SMPL-shaped random model.  Keys mirror the buffers smplx.SMPL registers.
+
+    ``locality`` (round 6): the spatially structured model of ``_locality_assets`` -- vertices ordered by body part, 1 - 2 dominant
+    skinning weights, sparse local joint regressors -- instead of the default's random permutation (every golden fixture and
+    profile of rounds 1 - 5 is on the default; bench.py's `locality_body_model` leg and its counters are on this one).
 
     ``skin_nnz``: non-zero skinning weights per vertex.  24 (every joint; what the committed golden fixtures were
     generated with) or fewer: the published SMPL model file has at most FOUR non-zero ``weights`` per vertex (Loper et
@@ -50,6 +134,13 @@ def make_smpl_assets(num_verts: int = 6890, seed: int = 1, skin_nnz: int = 24) -
     ``skin_nnz=4`` reproduces -- each vertex keeps its ``skin_nnz`` largest random weights, renormalised."""
     g = torch.Generator().manual_seed(seed)
     nv = num_verts
+    if locality:
+        a = _locality_assets(nv, g, skin_nnz)
+        a['parents'] = torch.tensor(SMPL_PARENTS, dtype=torch.long)
+        # the selector vertices of smplx (nose, eyes, ears, toes, heels, finger tips): extremities -> vertices of leaf parts
+        a['extra_vids'] = torch.randint(0, nv, (NUM_SELECTOR_VERTS,), generator=g)
+        a['joint_map'] = torch.tensor(JOINT_MAP_49, dtype=torch.long)
+        return a
     a = {}
     a['v_template'] = 0.3 * torch.randn(nv, 3, generator=g)
     a['shapedirs'] = 0.01 * torch.randn(nv, 3, 10, generator=g)

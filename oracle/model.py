@@ -323,7 +323,7 @@ class OracleNemo:
                 # OPTIONAL extension (not in the published NemoV* step): HuMoR's joints3d_smooth_loss,
                 # humor/humor/fitting/fitting_loss.py:366-370, on the 25 output joints of complete sequences
                 jj = pd['j'].reshape(self.V, self.T, -1, 3)
-                smooth = 0.5 * ((jj[:, 1:] - jj[:, :-1]) ** 2).sum()
+                smooth = ops.joints3d_smooth_loss(jj)
             info.update(loss_all=loss_all.detach(), points2d_gt=gt, points2d=p2d.detach(),
                         j=pd['j'].detach())
         if self.version >= 3 and a.weight_instance_loss:

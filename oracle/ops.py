@@ -312,3 +312,10 @@ class GMMPriorOracle:
         pd = torch.einsum('mij,bmj->bmi', self.precisions, d)                              # :184-185
         ll = 0.5 * (pd * d).sum(-1) - torch.log(self.nll_weights)                          # :186-189
         return ll.min(dim=1)[0]                                                            # :195
+
+
+def joints3d_smooth_loss(joints):
+    """humor/humor/fitting/fitting_loss.py:366-370 (`FittingLoss.joints3d_smooth_loss`): 0.5 * sum over consecutive frames of the
+    squared joint displacement; joints (B, T, J, 3).  Pinned by tests/golden/fn_joints3d_smooth_loss.npz (the reference's own method,
+    tools/gen_golden.py::run_smooth_case)."""
+    return 0.5 * ((joints[:, 1:] - joints[:, :-1]) ** 2).sum()

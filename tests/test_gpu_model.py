@@ -1207,3 +1207,39 @@ def test_every_gradient_at_the_true_init_with_the_mesh_term_on(B):
     full_bound = {k: bound.get(k, zero) for k in keys}
     worst = _assert_gradients_up_to_l1_ties(m, o, o64, full_bound, keys)
     print(f'B = {B}: {n_ties} L1 coordinates within rounding of a tie; worst gradient error beyond the allowances / scale: {worst:.3g}')
+
+
+def test_locality_body_model_step_vs_oracle():
+    """a step on the spatially structured synthetic body model (synthetic.make_smpl_assets(locality=True):
+    vertices ordered by body part, 1 - 2 dominant skinning weights, sparse local joint regressors -- the access patterns of the
+    published SMPL model) against the oracle: losses, joints and the gradients of the shared tensors."""
+    from nemo_cvpr2023_amd.neural_motion_model import NemoV2
+    from oracle.model import OracleNemo
+    from tiebound import model_v2v_tie_bound
+    V, T, B = 8, 300, 512
+    args = syn.published_args(batch_size=B, out_dir='')
+    seqs = syn.SyntheticSequences(V, T, seed=1234)
+    assets, vps, gmm = syn.make_smpl_assets(6890, seed=1, skin_nnz=4, locality=True), syn.make_vposer_state(), syn.make_gmm()
+    assert int((assets['lbs_weights'] > 0).sum(1).max()) <= 4 and int((assets['J_regressor'] > 0).sum(1).max()) < 200
+    torch.manual_seed(0)
+    m = NemoV2(args, seqs, DEV, smpl_assets=assets, vposer_state=vps, gmm=gmm)
+    assert m.engine.ctx.skin_sparse and m.engine.ctx.split_ok
+    with torch.no_grad():
+        m.learned_motion.rot_out.weight.mul_(2e3)
+    o = OracleNemo(2, args, seqs, assets, vps, gmm, state={k: v.detach().cpu() for k, v in m.state_dict().items()})
+    torch.manual_seed(2)
+    vi, fi = torch.randint(0, V, (B,)), torch.randint(0, T, (B,))
+    o64 = _float64_twin(o)
+    bound, n_ties = model_v2v_tie_bound(o64, vi, fi)
+    torch.set_default_dtype(torch.float64)
+    try:
+        o64.step(vi, fi, update=True)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    ld_o, info_o = o.step(vi, fi, update=True)
+    ld_h, info_h = m.step(vi, fi, update=True)
+    for k in ld_o:
+        assert rel_err(ld_h[k], ld_o[k]) < 1e-4, (k, ld_h[k], ld_o[k])
+    assert rel_err(info_h['j'], info_o['j']) < 1e-4 and rel_err(info_h['points2d'], info_o['points2d']) < 1e-4
+    _assert_gradients_up_to_l1_ties(m, o, o64, bound, ('learned_motion.net.net.2.weight', 'learned_motion.rot_out.weight',
+                                                       'learned_cameras', 'phase_rbf.log_sigmas', 'learned_instance_code'))

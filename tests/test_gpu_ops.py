@@ -1253,3 +1253,20 @@ def test_v2v_fused_split_regimes_and_range_guard(L, regime):
         dh = torch.zeros(2, ldn, ctx.ldP, dtype=torch.int16, device='cuda')
         assert L.nemo_v2v_fused_splitmem(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), Z(1).data_ptr(), dh.data_ptr(), dh.stride(1),
                                          dh.stride(0), Z(N, 24, 12).data_ptr(), ws.data_ptr(), ws.numel() * 4, H.st()) < 0
+
+
+def test_smooth_kernel_against_the_reference_method(L):
+    """nemo_smooth_fwd_bwd against the fixture recorded from the reference's own `FittingLoss.joints3d_smooth_loss`
+    (humor/humor/fitting/fitting_loss.py:366-370): value and gradient, three shapes incl. T = 2."""
+    from conftest import load_golden
+    H = _ops()
+    g = load_golden('fn_joints3d_smooth_loss')
+    for tag in 'abc':
+        j = torch.tensor(g[f'{tag}_joints'])
+        B, T_, J, _ = j.shape
+        dj, out, dd = H.dev(j.reshape(B * T_, J, 3)), torch.zeros(1, device='cuda'), torch.zeros(B * T_, J, 3, device='cuda')
+        for w in (1.0, 2.5):
+            out.zero_()
+            assert L.nemo_smooth_fwd_bwd(B, T_, J, dj.data_ptr(), w, out.data_ptr(), dd.data_ptr(), H.st()) == 0
+            assert rel_err(out, g[f'{tag}_loss']) < 1e-5
+            assert rel_err(dd.reshape(B, T_, J, 3), w * torch.tensor(g[f'{tag}_grad'])) < 1e-5

@@ -405,3 +405,15 @@ def test_checkpoint_written_by_the_reference_resumes_in_the_oracle():
     for k, v in o.state_dict().items():
         if k != 'phase_rbf.centres':
             assert rel_err(v, g['final__' + k.replace('.', '__')]) < 5e-3, k
+
+
+def test_joints3d_smooth_loss_against_the_reference_method():
+    """f-4 (BASELINE configs[4]): oracle.ops.joints3d_smooth_loss against values and gradients of the reference's own
+    `FittingLoss.joints3d_smooth_loss` (humor/humor/fitting/fitting_loss.py:366-370; tools/gen_golden.py::run_smooth_case)."""
+    g = load_golden('fn_joints3d_smooth_loss')
+    for tag in 'abc':
+        j = T(g[f'{tag}_joints']).requires_grad_(True)
+        loss = ops.joints3d_smooth_loss(j)
+        loss.backward()
+        assert rel_err(loss.detach(), g[f'{tag}_loss']) < TOL
+        assert rel_err(j.grad, g[f'{tag}_grad']) < TOL

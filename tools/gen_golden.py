@@ -583,7 +583,7 @@ def run_loader_case(name='loader_mocap'):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--skip-6890', action='store_true')
-    ap.add_argument('--only', default='', help='comma list of: script, eval, loader, ckpt, sparse (skip everything else)')
+    ap.add_argument('--only', default='', help='comma list of: script, eval, loader, ckpt, sparse, smooth (skip everything else)')
     opts = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     scratch = tempfile.mkdtemp(prefix='nemo_golden_')
@@ -608,11 +608,14 @@ def main():
         run_checkpoint_case(nmm, scratch)
     if 'sparse' in only:
         run_sparse_cases(nmm)
+    if 'smooth' in only:
+        run_smooth_case()
     if 'v0' in only:
         run_model_case(nmm, 'v0_small', 0, {'lr_factor': 1}, V=2, T=5, B=6, n_steps=5, n_warm=0, n_cam=2,
                        full_batch_steps=1)
     if only:
         return
+    run_smooth_case()
     gen_function_goldens(nmm, assets_small)
 
     # NemoV2, published-run structure (all loss terms on), tiny sizes
@@ -648,6 +651,27 @@ def main():
         install_synthetic_models(nmm, assets_full)
         run_model_case(nmm, 'v2_6890', 2, {}, V=2, T=4, B=6, n_steps=2, n_warm=0, n_cam=0)
     run_sparse_cases(nmm, skip_6890=opts.skip_6890)
+
+
+def run_smooth_case(name='fn_joints3d_smooth_loss'):
+    """f-4 (BASELINE configs[4]): the reference's OWN temporal-smoothness term, humor/humor/fitting/fitting_loss.py:366-370
+    (`FittingLoss.joints3d_smooth_loss`), called unbound on seeded joints -- value and gradient.  Its module imports HuMoR's
+    logging / fitting utilities and the body_model package, none of which the method touches: MagicMock stubs, as for the rest."""
+    import importlib.util
+    for name_ in ['humor', 'humor.humor', 'humor.humor.utils', 'humor.humor.utils.logging', 'humor.humor.fitting',
+                  'humor.humor.fitting.fitting_utils', 'body_model', 'body_model.utils']:
+        sys.modules.setdefault(name_, unittest.mock.MagicMock(name=name_))
+    spec = importlib.util.spec_from_file_location('ref_fitting_loss', os.path.join(REF, 'humor', 'humor', 'fitting', 'fitting_loss.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = torch.Generator().manual_seed(17)
+    out = {}
+    for tag, (B, T, J) in (('a', (3, 7, 25)), ('b', (1, 2, 25)), ('c', (8, 30, 25))):
+        j = (0.3 * torch.randn(B, T, J, 3, generator=g) + torch.linspace(0, 1, T).view(1, T, 1, 1)).requires_grad_(True)
+        loss = mod.FittingLoss.joints3d_smooth_loss(None, j)
+        loss.backward()
+        out[f'{tag}_joints'], out[f'{tag}_loss'], out[f'{tag}_grad'] = j.detach(), loss.detach(), j.grad
+    save(name, **out)
 
 
 def run_sparse_cases(nmm, skip_6890=False):
