@@ -1033,11 +1033,14 @@ extern "C" int32_t nemo_gemm_xp(int32_t fmt, int64_t M, int64_t N, int64_t K, co
     int bn = (t128 > 512 && N > 128) ? 256 : 128;
     if (force_bn == 128 || force_bn == 256) bn = force_bn;
     const long tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
-    // K slices: about one workgroup per CU, every slice >= 4 K tiles of 32
+    // K slices: about one workgroup per CU, every slice >= 8 K tiles of 32, at most 8 slices -- the last arriver sums a tile's slabs
+    // eight at a time, one batch of round trips (2401-row chain, us per launch at 1 / 3 / 4 / 8 / 16 slices: head dW 37 / 24 / 23 /
+    // 22 / 27, first-layer dX 18.6 / 16.6 / 16.8 / 19.3 / -, hidden dW 40 / 30 / 31 / 55 / -)
     static const int force_split = getenv("NEMO_XP_SPLIT") ? atoi(getenv("NEMO_XP_SPLIT")) : 0;
     int split = (int)(256 / tiles);
+    if (split > 8) split = 8;
     if (split < 1) split = 1;
-    while (split > 1 && (K / split < 128 || COUNTER_BYTES + tiles * split * 128L * bn * 4 > ws_bytes)) --split;
+    while (split > 1 && (K / split < 256 || COUNTER_BYTES + tiles * split * 128L * bn * 4 > ws_bytes)) --split;
     if (force_split > 0) split = force_split;
     if (!ws || (((uintptr_t)ws) & 15) || tiles > COUNTER_BYTES / 4 || COUNTER_BYTES + tiles * split * 128L * bn * 4 > ws_bytes) split = 1;
     if (!xp::plan(g, fmt, bn, split)) return NEMO_EINVAL;
