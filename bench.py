@@ -403,6 +403,9 @@ def build_model(cx, V, T, dtype, batch_size=512, skin_nnz=None, weight_smooth=0.
     from nemo_cvpr2023_amd import synthetic as syn
     args = syn.published_args(batch_size=batch_size, out_dir='')
     args.gemm_dtype = dtype
+    # (profiling aid: every model of the run on the spatially structured synthetic body model -- tools/profile_r06.sh takes the mesh
+    #  kernel's LDS / L1 counters on both body models this way; the line's `config.body_model` says which one ran)
+    locality = locality or os.environ.get('NEMO_BENCH_LOCALITY') == '1'
     if mesh_blend:
         args.mesh_blend = mesh_blend            # 'f32': the mesh term's blend on the fp32 MFMA pipe (engine default: 'f32_split')
         args.mlp_gemm = mesh_blend              # ... and the MotionNet chain too: the `f32_mfma_blend` leg is the step on the fp32 pipe only
@@ -990,6 +993,8 @@ def worker_main(opts):
                                       if SKIN_NNZ <= 4 else 'a dense skinning-weight matrix'),
                        'instances': V, 'frames': T, 'samples_per_step': V * T, 'h_dim': args.h_dim, 'skin_nnz': SKIN_NNZ,
                        'mesh_blend': engine_blend, 'mlp_gemm': engine_mlp,
+                       'body_model': ('synthetic, spatially structured (NEMO_BENCH_LOCALITY=1)' if os.environ.get('NEMO_BENCH_LOCALITY') == '1'
+                                      else 'synthetic, random vertex permutation (default; the `locality_body_model` key is the same step on the structured one)'),
                        'mesh_kernel': mesh_variant,
                        'parallelism': f'instance-shard x{world}' if world > 1 else
                        ('sharded code path in a process group of ONE rank (diagnostic)' if cx.sharded else 'single GPU')},

@@ -334,17 +334,15 @@ __global__ __launch_bounds__(64 * (8 + LW)) void gemm_b16x_kernel(Args g) {
         for (int c = 0; c < NV4; ++c) {
             float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4* src = base + c * 512 + threadIdx.x;
-            int sl = 0;
-            for (; sl + 8 <= g.split; sl += 8) {            // eight slabs in flight, added in slice order
+            // eight slabs in flight, added in slice order; a last group of fewer padded with zeros (x + 0 = x; round 6: the tail used to
+            // take one round trip per slab)
+            for (int sl = 0; sl < g.split; sl += 8) {
                 float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(sl + u) * (BM * BN / 4)];
+                for (int u = 0; u < 8; ++u)
+                    v[u] = sl + u < g.split ? src[(size_t)(sl + u) * (BM * BN / 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
-            }
-            for (; sl < g.split; ++sl) {
-                const float4 v = src[(size_t)sl * (BM * BN / 4)];
-                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             }
             const int i = c / (TN * 4), j = (c / 4) % TN, r4 = c % 4;
             acc[i][j][4 * r4] = sum.x; acc[i][j][4 * r4 + 1] = sum.y; acc[i][j][4 * r4 + 2] = sum.z; acc[i][j][4 * r4 + 3] = sum.w;

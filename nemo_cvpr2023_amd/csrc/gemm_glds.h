@@ -458,6 +458,8 @@ __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, flo
         }
         __syncthreads();
         const float4* base = reinterpret_cast<const float4*>(g.slabs) + (size_t)(tile - g.t0) * split * (size_t)(BM * BN / 4);
+        // fixed order: deterministic.  Four slabs' loads in flight per accumulator quad (round 6; one load per round trip before: a tile
+        // in S slices paid S dependent trips per quad), a last group of fewer padded with zeros -- x + 0 = x, the bits do not change
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -465,9 +467,14 @@ __device__ __forceinline__ void gemm_glds_body(const Args& g, const int bid, flo
 #pragma unroll
                 for (int r4 = 0; r4 < AR / 4; ++r4) {
                     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int sl = 0; sl < split; ++sl) {          // fixed order: deterministic
-                        const float4 v = base[(size_t)sl * (BM * BN / 4) + ((i * TN + j) * (AR / 4) + r4) * 256 + threadIdx.x];
-                        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                    const float4* src = base + ((i * TN + j) * (AR / 4) + r4) * 256 + threadIdx.x;
+                    for (int sl = 0; sl < split; sl += 4) {
+                        float4 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            v[u] = sl + u < split ? src[(size_t)(sl + u) * (BM * BN / 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
                     }
                     acc[i][j][4 * r4] = sum.x; acc[i][j][4 * r4 + 1] = sum.y;
                     acc[i][j][4 * r4 + 2] = sum.z; acc[i][j][4 * r4 + 3] = sum.w;
