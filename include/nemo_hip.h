@@ -455,6 +455,13 @@ int32_t nemo_v2v_fused_split(const nemo_ctx* ctx, int64_t N, const float* PF2, i
  * pieces' scales); ws as nemo_gemm_f32 (round 5, ABI 16; the engine uses the pair from 256 samples on). */
 int32_t nemo_v2v_fused_splitmem(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2, float* loss_sum,
                                 uint16_t* dVPh, int64_t ldk, int64_t plane, float* dA, void* ws, int64_t ws_bytes, void* stream);
+/* nemo_v2v_fused_splitmem with d vp handed over as ONE xp matrix (nemo_gemm_xp fmt 2: the two fp16 pieces of 2^12 d vp interleaved per
+ * k-block of 32; 16 * ceil(N / 16) rows of ldk >= nemo_xp_ld(2, 3 * 16 ceil(NV / 16)) elements, ldk % 8 == 0) -- the A operand of the
+ * blend-shape adjoint dPF = d vp P^T (lbs.py:229-233 backward) through nemo_gemm_xp against the xp copy of the blend shapes, metaA[0] =
+ * 4096: one pass over d vp and the blend shapes per tile with all three piece products (round 6, ABI 17; 8 x 300: 150 -> ~90 us).
+ * NEMO_EINVAL outside the range guard (nemo_ctx_split_ok == 0), as nemo_v2v_fused_splitmem. */
+int32_t nemo_v2v_fused_splitxp(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2, float* loss_sum,
+                               uint16_t* dVPx, int64_t ldk, float* dA, void* ws, int64_t ws_bytes, void* stream);
 int32_t nemo_gemm_f16x2mem_adj(int64_t M, int64_t N, int64_t K, const uint16_t* A, int64_t lda, int64_t a_plane, const uint16_t* B,
                                int64_t ldb, int64_t b_plane, float* C, int64_t ldc, float alpha, int32_t out_mode, void* ws,
                                int64_t ws_bytes, void* stream);

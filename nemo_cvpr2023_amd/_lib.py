@@ -119,6 +119,7 @@ SIGNATURES = {
     'nemo_v2v_fused': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_fused_split': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_fused_splitmem': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, i64, ptr, ptr, i64, ptr]),
+    'nemo_v2v_fused_splitxp': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_gemm_f16x2mem_adj': (i32, [i64, i64, i64, ptr, i64, i64, ptr, i64, i64, ptr, i64, f32, i32, ptr, i64, ptr]),
     'nemo_v2v_fused_bf16': (i32, [ptr, i64, ptr, i64, ptr, ptr, ptr, i64, ptr, ptr, i64, ptr]),
     'nemo_v2v_combine': (i32, [ptr, i64, ptr, ptr, i64, ptr]),

@@ -2094,6 +2094,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             // split-precision adjoint (nemo_gemm_f16x2mem_adj): d vp as TWO fp16 pieces of 2^12 d vp, NOT transposed -- plane 0 at
             // dVPb, plane 1 hplane elements behind it; row = sample, the lane's 4 vertices x 3 coordinates are 12 consecutive k
             unsigned short* dst0 = dVPb + (s0 + l15) * ldk + (v0 + 4 * g) * 3;
+            const long k0 = (long)(v0 + 4 * g) * 3;          // (hplane < 0: the xp layout, see the stores below)
             unsigned short h0[12], h1[12];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -2109,8 +2110,17 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 uint2 p0, p1;
                 p0.x = (unsigned)h0[4 * q] | ((unsigned)h0[4 * q + 1] << 16); p0.y = (unsigned)h0[4 * q + 2] | ((unsigned)h0[4 * q + 3] << 16);
                 p1.x = (unsigned)h1[4 * q] | ((unsigned)h1[4 * q + 1] << 16); p1.y = (unsigned)h1[4 * q + 2] | ((unsigned)h1[4 * q + 3] << 16);
-                reinterpret_cast<uint2*>(dst0)[q] = p0;
-                reinterpret_cast<uint2*>(dst0 + hplane)[q] = p1;
+                if (hplane < 0) {
+                    // xp matrix (csrc/gemm_xp.h fmt 2): the two pieces of 32 consecutive k are 128 consecutive bytes -- a group of four k
+                    // (k0 + 4 q: a multiple of four) never straddles a k-block
+                    const long kq = k0 + 4 * q;
+                    unsigned short* dx = dVPb + (s0 + l15) * ldk + (kq >> 5) * 64 + (kq & 31);
+                    *reinterpret_cast<uint2*>(dx) = p0;
+                    *reinterpret_cast<uint2*>(dx + 32) = p1;
+                } else {
+                    reinterpret_cast<uint2*>(dst0)[q] = p0;
+                    reinterpret_cast<uint2*>(dst0 + hplane)[q] = p1;
+                }
             }
         } else if (BF16 && dVPb) {
             // bf16-in-memory chain: d vp as bf16, NOT transposed -- row = sample, the lane's 4 vertices x 3 coordinates are
@@ -2652,7 +2662,8 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
     const bool bf16 = kind == 1;
     if (!ctx || N < 0 || !PF2 || !A2 || !loss_sum || ldpf < 207) return NEMO_EINVAL;
     if (dVPb ? ((kind != 1 && kind != 2) || ldk < ctx->ldP || (ldk & 3) || (((uintptr_t)dVPb) & 7) ||
-                (kind == 2 && (hplane < ((N + 15) / 16) * 16 * ldk || (hplane & 3))))
+                (kind == 2 && hplane >= 0 && (hplane < ((N + 15) / 16) * 16 * ldk || (hplane & 3))) ||
+                (kind == 2 && hplane < 0 && (ldk < 64 * ((3 * ctx->NVp + 31) / 32) || (ldk & 7))))
              : (!dVPt || ldn < ((N + 15) / 16) * 16))
         return NEMO_EINVAL;                                    // (dA == NULL: deferred combine, nemo_v2v_combine)
     if (N == 0) return NEMO_OK;
@@ -2754,6 +2765,16 @@ extern "C" int32_t nemo_v2v_fused_splitmem(const nemo_ctx* ctx, int64_t N, const
                                            int64_t ws_bytes, void* stream) {
     if (!dVPh) return NEMO_EINVAL;
     return v2v_fused_impl(ctx, 2, N, PF2, ldpf, A2, loss_sum, nullptr, 0, dA, ws, ws_bytes, stream, dVPh, ldk, plane);
+}
+
+// nemo_v2v_fused_splitmem whose d vp output is ONE xp matrix (include/nemo_hip.h nemo_gemm_xp fmt 2: the two fp16 pieces of 2^12 d vp
+// interleaved per k-block of 32): dVPx (16 * ceil(N / 16) rows x ldk >= nemo_xp_ld(2, 3 NVp)) -- the A operand of the blend-shape
+// adjoint through nemo_gemm_xp (round 6)
+extern "C" int32_t nemo_v2v_fused_splitxp(const nemo_ctx* ctx, int64_t N, const float* PF2, int64_t ldpf, const float* A2,
+                                          float* loss_sum, uint16_t* dVPx, int64_t ldk, float* dA, void* ws, int64_t ws_bytes,
+                                          void* stream) {
+    if (!dVPx) return NEMO_EINVAL;
+    return v2v_fused_impl(ctx, 2, N, PF2, ldpf, A2, loss_sum, nullptr, 0, dA, ws, ws_bytes, stream, dVPx, ldk, -1);
 }
 
 // bf16 variant whose d vp output is bf16 and NOT transposed: dVPb (16 * ceil(N / 16) rows x ldk >= 3 NVp, bf16) -- the

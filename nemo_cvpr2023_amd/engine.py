@@ -337,6 +337,22 @@ class FitEngine:
             self.Ph = torch.zeros(2, 207, self.ctx.ldP, dtype=torch.int16, device=self.device)
             self.Ph[0, :, :Pf.shape[1]] = h0.view(torch.int16).to(self.device)
             self.Ph[1, :, :Pf.shape[1]] = h1.view(torch.int16).to(self.device)
+        # Round 6: the split-precision adjoint through nemo_gemm_xp (fmt 2) -- d vp as ONE xp matrix (nemo_v2v_fused_splitxp), the blend
+        # shapes' xp copy made here (scaled from their absmax on the device): one pass over both operands per tile with all three piece
+        # products (the plane-pair form above streams A0 / B0 twice): 150 -> ~90 us per 8 x 300 launch.  NEMO_ADJ_XP=0: the round-5 pair.
+        self.adj_xp = self.split_adj and os.environ.get('NEMO_ADJ_XP', '1') != '0'
+        if self.adj_xp:
+            self.Px = torch.zeros(207, int(self.lib.nemo_xp_ld(2, 3 * self.NV)), dtype=torch.int16, device=self.device)
+            self.adj_meta = torch.zeros(2, 64, dtype=torch.float32, device=self.device)     # records of [d vp (scale 2^12), blend shapes]
+            self.adj_meta[0, 0] = 4096.0
+            am = (_lib.AbsmaxDesc * 1)()
+            am[0].src, am[0].rows, am[0].cols, am[0].lds, am[0].meta, am[0].overwrite = (self.ctx.posedirs, 207, 3 * self.NV, self.ctx.ldP,
+                                                                                          self.adj_meta[1].data_ptr(), 1)
+            check(self.lib.nemo_absmax_multi(1, am, _stream()), 'nemo_absmax_multi')
+            cd = (_lib.CastXpDesc * 1)()
+            cd[0].src, cd[0].rows, cd[0].cols, cd[0].lds = self.ctx.posedirs, 207, 3 * self.NV, self.ctx.ldP
+            cd[0].dst, cd[0].ldd, cd[0].dstT, cd[0].lddT, cd[0].scale, cd[0].meta = self.Px.data_ptr(), self.Px.stride(0), None, 0, 1.0, self.adj_meta[1].data_ptr()
+            check(self.lib.nemo_cast_xp(2, 1, cd, _stream()), 'nemo_cast_xp')
         if self.b16mem:
             r8 = lambda n: (n + 7) // 8 * 8
             # blend shapes as a plain bf16 [207][3 NVp] matrix: the k-contiguous B operand of the adjoint product
@@ -478,7 +494,10 @@ class FitEngine:
             dVPt=Z(3 * self.ctx.NVp, (Nc + 15) // 16 * 16) if not self.b16mem else Z(16),
             # (mesh_blend 'f32_split': d vp as two fp16 piece planes [2][samples][blend-shape row stride])
             dVPh=(torch.zeros(2, (Nc + 15) // 16 * 16, self.ctx.ldP, dtype=torch.int16, device=self.device)
-                  if getattr(self, 'split_adj', False) else None),
+                  if (getattr(self, 'split_adj', False) and not getattr(self, 'adj_xp', False)) else None),
+            # (round 6: ... or as ONE xp matrix, the pieces interleaved per k-block of 32: the adjoint through nemo_gemm_xp)
+            dVPx=(torch.zeros((Nc + 15) // 16 * 16, int(self.lib.nemo_xp_ld(2, 3 * self.ctx.NVp)), dtype=torch.int16, device=self.device)
+                  if getattr(self, 'adj_xp', False) else None),
             dR2=Z(N, 24, 9),
             dR=Z(N, 24, 9), dA=Z(N, 24, 12), dMq=Z(N, max(nq * 72, 1)),
             dPF=Z(N, 208), dHEAD=Z(N + 1, HEAD_LD), dH=Z(N + 1, h), dH_b=Z(N + 1, h), dH_c=Z(N + 1, h),
@@ -1351,8 +1370,14 @@ class FitEngine:
             #  0.572 against 0.579 ms deferred, two instances 0.602 against 0.618)
             defer = need_grad and self.SMALL_BATCH_ROWS < N <= Nc and self.timers is None
             # (fp16 piece planes of d vp only while the body model is inside the fp16 form's range: nemo_ctx_split_ok)
-            hsplit = need_grad and self.split_adj and ctx.split_ok and w['dVPh'] is not None and n >= self.SPLIT_ADJ_ROWS
-            if hsplit:
+            hsplit = need_grad and self.split_adj and ctx.split_ok and (w['dVPh'] is not None or w['dVPx'] is not None) and n >= self.SPLIT_ADJ_ROWS
+            hxp = hsplit and w['dVPx'] is not None
+            if hxp:
+                dx = w['dVPx']
+                check(L.nemo_v2v_fused_splitxp(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']), self.scal.data_ptr() + 4 * S_V2V,
+                                               dx.data_ptr(), dx.stride(0), None if defer else dptr(w['dA2']),
+                                               ws.data_ptr(), ws.numel() * 4, st), 'nemo_v2v_fused_splitxp')
+            elif hsplit:
                 dh = w['dVPh']
                 check(L.nemo_v2v_fused_splitmem(ctx.handle, n, dptr(w['PF2']), 208, dptr(w['A2']), self.scal.data_ptr() + 4 * S_V2V,
                                                 dh.data_ptr(), dh.stride(1), dh.stride(0), None if defer else dptr(w['dA2']),
@@ -1373,7 +1398,16 @@ class FitEngine:
             if need_grad:
                 if c0 > 0:
                     w['dPF2'].zero_()
-                if hsplit:
+                if hxp:
+                    ev2 = self._event_begin('gemm_pose_blend_bwd', 2.0 * n * 207 * NV3)
+                    cur = torch.cuda.current_stream()
+                    gws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]
+                    dx = w['dVPx']
+                    check(L.nemo_gemm_xp(2, n, 207, NV3, dx.data_ptr(), dx.stride(0), self.Px.data_ptr(), self.Px.stride(0), dptr(w['dPF2']), 208,
+                                         None, 0, None, 0, 0, 1.0, 1, None, 0, None, 0, 1.0, None, 0, self.adj_meta[0].data_ptr(),
+                                         self.adj_meta[1].data_ptr(), None, None, None, gws.data_ptr(), gws.numel() * 4, st), 'nemo_gemm_xp')
+                    self._event_end(ev2)
+                elif hsplit:
                     ev2 = self._event_begin('gemm_pose_blend_bwd', 2.0 * n * 207 * NV3)
                     cur = torch.cuda.current_stream()
                     gws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]

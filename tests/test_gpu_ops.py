@@ -1270,3 +1270,72 @@ def test_smooth_kernel_against_the_reference_method(L):
             assert L.nemo_smooth_fwd_bwd(B, T_, J, dj.data_ptr(), w, out.data_ptr(), dd.data_ptr(), H.st()) == 0
             assert rel_err(out.reshape(()), g[f'{tag}_loss']) < 1e-5
             assert rel_err(dd.reshape(B, T_, J, 3), w * torch.tensor(g[f'{tag}_grad'])) < 1e-5
+
+
+def test_blend_shape_adjoint_split_precision_pairs(L):
+    """The blend-shape adjoint dPF = d vp P^T (lbs.py:229-233 backward) of fp32 builds, three ways on the same inputs:
+      (a) nemo_v2v_fused_split -> fp32 d vp^T -> nemo_gemm_f32;
+      (b) round 5: nemo_v2v_fused_splitmem (two fp16 piece planes) -> nemo_gemm_f16x2mem_adj;
+      (c) round 6, the engine's default: nemo_v2v_fused_splitxp (one xp matrix) -> nemo_gemm_xp against the blend shapes' xp copy.
+    (b) and (c) must hold the SAME pieces of d vp, and their dPF must be as close to a float64 product as (a)'s."""
+    H = _ops()
+    num_verts, N = 6890, 320
+    assets = syn.make_smpl_assets(num_verts, seed=1, skin_nnz=4)
+    assets['posedirs'] = assets['posedirs'] * 30.0
+    from nemo_cvpr2023_amd.engine import SmplContext
+    jm = [int(x) for x in assets['joint_map']]
+    ctx = SmplContext(assets, [jm[i] for i in [38] + list(range(1, 25))], 'cuda:0')
+    gen = torch.Generator().manual_seed(5)
+    R2 = H.dev(_rand_rot(gen, 2 * N * 24, small=True).reshape(2 * N, 24, 9))
+    Z = lambda *s: torch.zeros(*s, device='cuda')
+    A, Jp, PF = Z(2 * N, 24, 12), Z(2 * N, 24, 3), Z(2 * N, 208)
+    assert L.nemo_fk_fwd(ctx.handle, 2 * N, R2.data_ptr(), A.data_ptr(), Jp.data_ptr(), PF.data_ptr(), 208, H.st()) == 0
+    _, dvp_ref, _, _ = _mesh_term_f64(assets, PF, A, N)
+    P64 = assets['posedirs'].to('cuda').double()                                  # (207, 3 NV)
+    dPF_ref = dvp_ref.reshape(N, -1) @ P64.t()
+    ldn, NV3 = (N + 15) // 16 * 16, 3 * num_verts
+    ws = torch.zeros(int(L.nemo_v2v_fused_ws_bytes(ctx.handle, N)) // 4 + 1, device='cuda')
+    gws = H.gemm_ws()
+    # (a)
+    loss, dVPt, dA = Z(1), Z(3 * ctx.NVp, ldn), Z(N, 24, 12)
+    assert L.nemo_v2v_fused_split(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), loss.data_ptr(), dVPt.data_ptr(), ldn, dA.data_ptr(),
+                                  ws.data_ptr(), ws.numel() * 4, H.st()) == 0
+    Pd = torch.zeros(207, ctx.ldP, device='cuda')
+    Pd[:, :NV3] = assets['posedirs'].to('cuda')
+    dPF_a = H.gemm(dVPt[:NV3], Pd[:, :NV3], 1, 1)
+    # (b)
+    dh = torch.zeros(2, ldn, ctx.ldP, dtype=torch.int16, device='cuda')
+    assert L.nemo_v2v_fused_splitmem(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), Z(1).data_ptr(), dh.data_ptr(), dh.stride(1), dh.stride(0),
+                                     Z(N, 24, 12).data_ptr(), ws.data_ptr(), ws.numel() * 4, H.st()) == 0
+    x = Pd * 1.0
+    pmax = float(x.abs().max())
+    import math
+    ps = 2.0 ** (14 - math.frexp(pmax)[1])
+    h0 = (x * ps).half()
+    h1 = (x * ps - h0.float()).half()
+    Ph = torch.stack([h0.view(torch.int16), h1.view(torch.int16)])
+    dPF_b = Z(N, 208)
+    assert L.nemo_gemm_f16x2mem_adj(N, 207, (NV3 + 1) // 2 * 2, dh.data_ptr(), dh.stride(1), dh.stride(0), Ph.data_ptr(), Ph.stride(1), Ph.stride(0),
+                                    dPF_b.data_ptr(), 208, 1.0 / (4096.0 * ps), 0, gws.data_ptr(), gws.numel() * 4, H.st()) == 0
+    # (c)
+    dx = torch.zeros(ldn, H.xp_ld(2, 3 * ctx.NVp), dtype=torch.int16, device='cuda')
+    assert L.nemo_v2v_fused_splitxp(ctx.handle, N, PF.data_ptr(), 208, A.data_ptr(), Z(1).data_ptr(), dx.data_ptr(), dx.stride(0),
+                                    Z(N, 24, 12).data_ptr(), ws.data_ptr(), ws.numel() * 4, H.st()) == 0
+    mP = H.absmax_meta(Pd[:, :NV3])[0]
+    Px, _ = H.cast_xp(2, Pd[:, :NV3], meta=mP)
+    mA = torch.zeros(64, device='cuda')
+    mA[0] = 4096.0
+    dPF_c = Z(N, 208)
+    H.gemm_xp(2, dx, Px, N, 207, NV3, C=dPF_c, metaA=mA, metaB=mP)
+    torch.cuda.synchronize()
+    # the two hand-overs hold the same pieces
+    planes = dh[:, :N, :NV3].view(torch.float16).double().sum(0)
+    assert torch.equal(H.xp_decode(2, dx[:N], NV3), planes)
+    err = lambda c: float((c[:, :207].double() - dPF_ref).abs().max() / dPF_ref.abs().max())
+    ea, eb, ec = err(dPF_a), err(dPF_b), err(dPF_c)
+    print('blend-shape adjoint error against float64: fp32', ea, ' f16 planes', eb, ' xp', ec)
+    assert eb <= 1.5 * ea + 1e-9 and ec <= 1.5 * ea + 1e-9
+    # the xp route twice: same bits (ordered slab combine)
+    dPF_c2 = Z(N, 208)
+    H.gemm_xp(2, dx, Px, N, 207, NV3, C=dPF_c2, metaA=mA, metaB=mP)
+    assert torch.equal(dPF_c, dPF_c2)

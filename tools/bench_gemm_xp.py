@@ -30,7 +30,8 @@ for name, M, N, K, kw in [('fwd hidden (copies)', rows, 1000, 1000, dict(want_cx
                           ('dW hidden', 1000, 1000, rows, dict(out_mode=1)),
                           ('dW head', 147, 1000, rows, dict(out_mode=1)),
                           ('dW first', 1000, 105, rows, dict(out_mode=1)),
-                          ('dX first', rows, 105, 1000, {})]:
+                          ('dX first', rows, 105, 1000, {}),
+                          ('blend-shape adjoint', rows - 1, 207, 20670, dict(out_mode=1))]:
     A = torch.randn(M, K, device=H.DEV)
     B = torch.randn(N, K, device=H.DEV)
     mA = H.absmax_meta(A)[0] if fmt == 2 else None
