@@ -1369,6 +1369,8 @@ class FitEngine:
             #  reduction's tail -- 0.509 against 0.503 ms, same box; 8 x 300: 1.557 against 1.564 ms; round 4: minibatch-512 steps
             #  0.572 against 0.579 ms deferred, two instances 0.602 against 0.618)
             defer = need_grad and self.SMALL_BATCH_ROWS < N <= Nc and self.timers is None
+            # (round 6, the adjoint through nemo_gemm_xp takes whole CUs and the combine beside it 83 us instead of 25 -- the FK adjoint
+            #  behind both starts ~16 us after the GEMM ends; still ahead of the in-kernel combine: 0.992 against 1.020 ms per step)
             # (fp16 piece planes of d vp only while the body model is inside the fp16 form's range: nemo_ctx_split_ok)
             hsplit = need_grad and self.split_adj and ctx.split_ok and (w['dVPh'] is not None or w['dVPx'] is not None) and n >= self.SPLIT_ADJ_ROWS
             hxp = hsplit and w['dVPx'] is not None
