@@ -67,7 +67,8 @@ struct PhaseFwdArgs {
     int kid; float* X; long ldx; float* phase_out; float* den_out;
     float* x_meta;      // may be NULL: scale record of X (include/nemo_hip.h nemo_gemm_xp fmt 2) -- the rows' absmax is accumulated into it
 };
-__device__ __forceinline__ void phase_embed_fwd_body(const PhaseFwdArgs& a, long bid) {
+// returns max |value| this lane wrote into X (0 for a wave without a sample)
+__device__ __forceinline__ float phase_embed_fwd_body(const PhaseFwdArgs& a, long bid) {
     const long N = a.N, T = a.T, ldp = a.ldp, ldx = a.ldx;
     const int K = a.K, D = a.D, C = a.C, kid = a.kid;
     const int64_t* __restrict__ view_idx = a.view_idx;
@@ -83,7 +84,7 @@ __device__ __forceinline__ void phase_embed_fwd_body(const PhaseFwdArgs& a, long
     float* __restrict__ den_out = a.den_out;
     const long s = bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (s > N) return;                      // wave-uniform
+    if (s > N) return 0.f;                  // wave-uniform
     float ph = 0.f;
     long v = 0;
     if (s < N) {
@@ -126,13 +127,21 @@ __device__ __forceinline__ void phase_embed_fwd_body(const PhaseFwdArgs& a, long
         xr[off + c] = cv;
         mx = fmaxf(mx, fabsf(cv));
     }
-    if (a.x_meta) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        if (lane == 0) nemo_meta::meta_absmax_put(a.x_meta, (int)s, mx);
-    }
+    return mx;
 }
-__global__ __launch_bounds__(256) void phase_embed_fwd_kernel(PhaseFwdArgs a) { phase_embed_fwd_body(a, (long)blockIdx.x); }
+// the block's max |X| into X's scale record: ONE atomic per block (one per wave -- 2401 on 32 slots -- took the launch from 10 to 24 us)
+__device__ __forceinline__ void phase_embed_put_absmax(float* x_meta, float mx) {
+    __shared__ float wmx[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) nemo_meta::meta_absmax_put(x_meta, (int)blockIdx.x, fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3])));
+}
+__global__ __launch_bounds__(256) void phase_embed_fwd_kernel(PhaseFwdArgs a) {
+    const float mx = phase_embed_fwd_body(a, (long)blockIdx.x);
+    if (a.x_meta) phase_embed_put_absmax(a.x_meta, mx);
+}
 
 // The FIRST launch of a step: phase / RBF / code forward in blocks [0, nb_phase), and in the blocks behind them what
 // nemo_step_begin does (zero-fill of the gradient buffer and of the workspace's accumulator arena -- nothing the phase blocks
@@ -142,7 +151,11 @@ struct StepBeginArgs {
     nemo_adam_seg* segs; int n_seg; double b1, b2;
 };
 __global__ __launch_bounds__(256) void phase_embed_begin_kernel(PhaseFwdArgs a, StepBeginArgs b, int nb_phase) {
-    if ((int)blockIdx.x < nb_phase) { phase_embed_fwd_body(a, (long)blockIdx.x); return; }
+    if ((int)blockIdx.x < nb_phase) {              // (block-uniform)
+        const float mx = phase_embed_fwd_body(a, (long)blockIdx.x);
+        if (a.x_meta) phase_embed_put_absmax(a.x_meta, mx);
+        return;
+    }
     const long nbz = (long)gridDim.x - nb_phase, bz = (long)blockIdx.x - nb_phase;
     const long stride = nbz * blockDim.x, i0 = bz * blockDim.x + threadIdx.x;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -392,10 +405,13 @@ __global__ __launch_bounds__(256) void pose_bwd_fused_kernel(long N, const float
 #pragma unroll
     for (int k = 0; k < 6; ++k) { dst[k] = dx[k]; hmx = fmaxf(hmx, fabsf(dx[k])); }
     }
-    if (head_meta) {                                   // absmax of the 144 rotation columns written here (whole waves get here)
+    if (head_meta) {                                   // absmax of the 144 rotation columns written here: one atomic per block
+        __shared__ float hw[4];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) hmx = fmaxf(hmx, __shfl_xor(hmx, o, 64));
-        if ((threadIdx.x & 63) == 0) nemo_meta::meta_absmax_put(head_meta, (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), hmx);
+        if ((threadIdx.x & 63) == 0) hw[threadIdx.x >> 6] = hmx;
+        __syncthreads();
+        if (threadIdx.x == 0) nemo_meta::meta_absmax_put(head_meta, (int)blockIdx.x, fmaxf(fmaxf(hw[0], hw[1]), fmaxf(hw[2], hw[3])));
     }
 }
 

@@ -941,6 +941,21 @@ class FitEngine:
                 (self.p(lm + 'net.net.4.weight'), h, h, h, wx['4'], T('4'), self._xm(w, 'W4')),
                 (self.p(lm + 'rot_out.weight'), 147, h, h, wx['head'], T('head'), self._xm(w, 'Whead'))]
 
+    # ---- are the weights' absmax records (fmt 2) those of the CURRENT weights?  Host-side bookkeeping: every Adam launch through this
+    # engine clears the flag, every pass over the weights sets it; writes from outside (load_state_dict, user code) are seen through the
+    # flat buffer's version counter.  MultiViewModel._captured keeps the flag right across graph replays (a replay runs no Python).
+    _wrec_ok, _wrec_version = False, -1
+
+    def wrec_ok(self):
+        return self._wrec_ok and self._wrec_version == self.params._version
+
+    def refresh_weight_records(self, w):
+        """The pass over the weights in front of a replayed graph that was captured while the records were fresh (an evaluation pass
+        behind another one) and finds them stale."""
+        if self.version >= 1 and self._use_xp(w) and self.xp_fmt == 2:
+            self._weights_absmax(w, self._weight_items(w, False))
+            self._wrec_ok, self._wrec_version = True, self.params._version
+
     def _weights_absmax(self, w, items):
         """fmt 2: the absmax records of the weights and of the three hidden-layer biases (which enter the bounds the hidden copies
         are scaled by) in one launch"""
@@ -961,7 +976,7 @@ class FitEngine:
         wx = self._wx
         T = lambda k: w[k] if train else None
         m = lambda k: self._xm(w, k)
-        if self.xp_fmt == 2:
+        if am_done is not None:
             main.wait_event(am_done)        # (the weights' absmax pass forward_pose started on the side stream beside the phase kernel)
         self.cast_xp(items + [(dptr(w['X']), r, self.din, self.ldx, w['Xx'], T('XxT'), m('X'))])
         self._wxT_fresh = w if train else None
@@ -1123,14 +1138,16 @@ class FitEngine:
                  # (fmt 2 of the split-precision chain: the phase kernel leaves max |X| in X's scale record)
                  w['xmeta_x'].data_ptr() if (self.version >= 1 and self._use_xp(w) and self.xp_fmt == 2) else None)
         am_done = None
-        if self.version >= 1 and self._use_xp(w) and self.xp_fmt == 2:
-            # the weights' / biases' absmax records (engine-level, overwritten: nothing to wait for) on the side stream, beside the
-            # phase kernel
+        if self.version >= 1 and self._use_xp(w) and self.xp_fmt == 2 and not self.wrec_ok():
+            # the weights' / biases' absmax records do not describe the current weights (first pass, an update whose launch did not
+            # refresh them, a checkpoint load): the pass over the weights on the side stream, beside the phase kernel (14 us there,
+            # and the phase kernel 25 instead of 10).  The step's own update leaves them fresh (refresh_weight_records, behind Adam).
             main, side = torch.cuda.current_stream(), self.side_stream
             side.wait_event(main.record_event())
             with torch.cuda.stream(side):
                 self._weights_absmax(w, self._weight_items(w, bool(train)))
                 am_done = side.record_event()
+            self._wrec_ok, self._wrec_version = True, self.params._version
         if begin is not None:
             arena, zero_grads, n_seg = begin
             check(L.nemo_phase_embed_fwd_begin(*pargs, arena.data_ptr(), arena.numel() * 4,
@@ -1680,6 +1697,7 @@ class FitEngine:
         """segments: list of dicts(offset, numel, lr, wd, adamw, step) -- step is the NEW step count."""
         if not segments:
             return
+        self._wrec_ok = False
         arr = (AdamSeg * len(segments))()
         self._fill_segs(arr, segments)
         m = self.exp_avg if exp_avg is None else exp_avg
@@ -1742,6 +1760,7 @@ class FitEngine:
         update when it is non-zero (warm-up: NaN gradients were counted)."""
         m = self.exp_avg if exp_avg is None else exp_avg
         v = self.exp_avg_sq if exp_avg_sq is None else exp_avg_sq
+        self._wrec_ok = False
         check(self.lib.nemo_adam_step_dev_if(n, self._seg_dev.data_ptr() + start * ctypes.sizeof(AdamSeg), max_numel,
                                              self.params.data_ptr(), self.grads.data_ptr(), m.data_ptr(), v.data_ptr(),
                                              0.9, 0.999, 1e-8, dptr(guard), _stream()), 'nemo_adam_step_dev_if')
