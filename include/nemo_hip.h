@@ -173,6 +173,18 @@ int32_t nemo_gemm_xp(int32_t fmt, int64_t M, int64_t N, int64_t K, const uint16_
                      float out_scale, float* colsum, int64_t ldcs, const float* metaA, const float* metaB, const float* metaBias,
                      float* metaOut, float* metaZero, void* ws, int64_t ws_bytes, void* stream);
 int32_t nemo_cast_xp(int32_t fmt, int32_t n, const nemo_cast_xp_desc* descs, void* stream);
+/* Up to NEMO_GEMM_GROUP_MAX products C_i (M_i x N_i, fp32) (op)= alpha_i A_i B_i^T over xp matrices in ONE launch (out_mode 0 store /
+ * 1 +=; no bias / activation / mask / copies; metaA / metaB as nemo_gemm_xp): the four parameter gradients dW_l = dY_l^T X_l of the
+ * MotionNet backward (nemo/neural_motion_model.py:58-71, :130-148 under autograd) behind its dX chain -- a nemo_gemm_xp launch takes whole
+ * CUs, so dX and dW launches side by side only time-share; one grouped launch covers the chip ~2.7 times.  ws as nemo_gemm_f32, shared by
+ * the problems (zero-filled once; >= 64 MB covers the chain at any batch size). */
+typedef struct {
+    int64_t M, N, K;
+    const uint16_t* A; int64_t lda; const uint16_t* B; int64_t ldb; float* C; int64_t ldc;
+    float alpha; int32_t out_mode;
+    const float* metaA; const float* metaB;
+} nemo_gemm_xp_problem;
+int32_t nemo_gemm_xp_grouped(int32_t fmt, int32_t n, const nemo_gemm_xp_problem* problems, void* ws, int64_t ws_bytes, void* stream);
 int32_t nemo_absmax_multi(int32_t n, const nemo_absmax_desc* descs, void* stream);
 /* Up to NEMO_GEMM_GROUP_MAX independent products C_i (op)= alpha_i * opA(A_i) @ opB(B_i) (out_mode 0 store / 1 C +=; no
  * bias / activation / mask) in ONE launch when they share a layout and their operands are 16-byte aligned -- the

@@ -30,6 +30,11 @@ class CastXpDesc(Structure):
                 ('dstT', c_void_p), ('lddT', c_int64), ('scale', c_float), ('meta', c_void_p)]
 
 
+class GemmXpProblem(Structure):
+    _fields_ = [('M', c_int64), ('N', c_int64), ('K', c_int64), ('A', c_void_p), ('lda', c_int64), ('B', c_void_p), ('ldb', c_int64),
+                ('C', c_void_p), ('ldc', c_int64), ('alpha', c_float), ('out_mode', c_int32), ('metaA', c_void_p), ('metaB', c_void_p)]
+
+
 class AbsmaxDesc(Structure):
     _fields_ = [('src', c_void_p), ('rows', c_int64), ('cols', c_int64), ('lds', c_int64), ('meta', c_void_p), ('overwrite', c_int32)]
 
@@ -67,6 +72,7 @@ SIGNATURES = {
     'nemo_gemm_xp': (i32, [i32, i64, i64, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i32, ptr, i64, i32, f32, i32, ptr, i64, ptr, i64,
                            f32, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i64, ptr]),
     'nemo_cast_xp': (i32, [i32, i32, POINTER(CastXpDesc), ptr]),
+    'nemo_gemm_xp_grouped': (i32, [i32, i32, POINTER(GemmXpProblem), ptr, i64, ptr]),
     'nemo_absmax_multi': (i32, [i32, POINTER(AbsmaxDesc), ptr]),
     'nemo_gemm_grouped_f32': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),
     'nemo_gemm_grouped_bf16': (i32, [i32, POINTER(GemmProblem), ptr, i64, ptr]),

@@ -1055,6 +1055,48 @@ extern "C" int32_t nemo_gemm_xp(int32_t fmt, int64_t M, int64_t N, int64_t K, co
     return NEMO_OK;
 }
 
+// Up to NEMO_GEMM_GROUP_MAX products C_i (op)= alpha_i A_i B_i^T over xp matrices in ONE launch of the 128 x 128 kernel (fp32 results,
+// out_mode 0 / 1; no bias / activation / mask / copies): the four parameter gradients of the MotionNet backward.
+extern "C" int32_t nemo_gemm_xp_grouped(int32_t fmt, int32_t n, const nemo_gemm_xp_problem* pr, void* ws, int64_t ws_bytes, void* stream) {
+    if ((fmt != 2 && fmt != 3) || n < 0 || n > xp::MAX_GROUP || (n && !pr) || !ws || (((uintptr_t)ws) & 15)) return NEMO_EINVAL;
+    xp::GroupArgs ga{};
+    long tiles_tot = 0, slab_off = 0;
+    int blocks = 0, m = 0;
+    for (int i = 0; i < n; ++i) {
+        const nemo_gemm_xp_problem& q = pr[i];
+        if (q.M < 0 || q.N < 0 || q.K < 0 || !q.C || q.ldc < q.N || q.out_mode < 0 || q.out_mode > 1) return NEMO_EINVAL;
+        if (q.M == 0 || q.N == 0) continue;
+        if (q.K == 0 || !q.A || !q.B || ((((uintptr_t)q.A) | ((uintptr_t)q.B)) & 15)) return NEMO_EINVAL;
+        xp::Args& g = ga.p[m];
+        g = xp::Args{};
+        g.A = q.A; g.B = q.B; g.M = q.M; g.N = q.N; g.K = q.K; g.lda = q.lda; g.ldb = q.ldb; g.C = q.C; g.ldc = q.ldc; g.out_mode = q.out_mode;
+        g.alpha = q.alpha; g.out_scale = 1.f;
+        g.metaA = fmt == 2 ? q.metaA : nullptr; g.metaB = fmt == 2 ? q.metaB : nullptr;
+        const long tiles = ((q.M + 127) / 128) * ((q.N + 127) / 128);
+        // K slices: the launch as a whole should cover the chip about twice (704 workgroups for the chain's four gradients at 2401 rows)
+        int split = (int)(192 / tiles);
+        if (split > 8) split = 8;
+        if (split < 1) split = 1;
+        while (split > 1 && q.K / split < 256) --split;
+        if (!xp::plan(g, fmt, 128, split)) return NEMO_EINVAL;
+        if (tiles_tot + tiles > COUNTER_BYTES / 4 || COUNTER_BYTES + (slab_off + tiles * g.split * 128L * 128) * 4 > ws_bytes) return NEMO_EINVAL;
+        g.counters = reinterpret_cast<int*>(ws) + tiles_tot;
+        g.slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + COUNTER_BYTES) + slab_off;
+        tiles_tot += tiles;
+        slab_off += tiles * g.split * 128L * 128;
+        ga.first[m] = blocks;
+        ga.nwg[m] = (int)(tiles * (g.split > 1 ? g.split : 1));
+        blocks = (blocks + ga.nwg[m] + 7) / 8 * 8;
+        ++m;
+    }
+    ga.n = m;
+    if (m == 0) return NEMO_OK;
+    const hipError_t e = fmt == 3 ? xp::launch_grouped<3, 128>(ga, blocks, (hipStream_t)stream) : xp::launch_grouped<2, 128>(ga, blocks, (hipStream_t)stream);
+    if (e != hipSuccess) return (int32_t)e;
+    NEMO_LAUNCH_CHECK();
+    return NEMO_OK;
+}
+
 extern "C" int32_t nemo_cast_xp(int32_t fmt, int32_t n, const nemo_cast_xp_desc* descs, void* stream) {
     if ((fmt != 2 && fmt != 3) || n < 0 || n > xp::MAX_CAST || (n && !descs)) return NEMO_EINVAL;
     xp::CastArgs a{};

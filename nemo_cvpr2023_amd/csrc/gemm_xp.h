@@ -143,8 +143,9 @@ __device__ __forceinline__ f32x16 mfma16(i32x4 a, i32x4 b, f32x16 c) {
     else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(xf16x8, a), __builtin_bit_cast(xf16x8, b), c, 0, 0, 0);
 }
 
+// The kernel body: workgroup `bid` of the `nwg` of problem g (a launch of its own, or one of a grouped launch's problems)
 template <int NP, int BN>
-__global__ __launch_bounds__(768) void gemm_xp_kernel(Args g) {
+__device__ __forceinline__ void gemm_xp_body(const Args& g, const int bid, const int nwg) {
     using Q = Geo<NP, BN>;
     constexpr int BM = Q::BM, WM = Q::WM, WN = Q::WN, TM = Q::TM, TN = Q::TN, GW = Q::GW, NPA = Q::NPA, NPC = Q::NPC, NST = Q::NST;
     constexpr int CH = Q::CH, CPR = Q::CPR, RS = Q::RS, KBB = Q::KBB, LW = Q::LW, WGN = Q::WGN;
@@ -152,7 +153,6 @@ __global__ __launch_bounds__(768) void gemm_xp_kernel(Args g) {
 
     // ---- block -> (K slice, row tile, column tile); every XCD (block b runs on XCD b % 8) gets a contiguous run of the
     // (slice, tm, tn) order with tn fastest: its blocks share A row panels in its L2 (gemm_b16x.h)
-    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     const int lin = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int tn = lin % g.tiles_n, tm = (lin / g.tiles_n) % g.tiles_m, slice = lin / (g.tiles_n * g.tiles_m);
@@ -574,6 +574,41 @@ __global__ __launch_bounds__(768) void gemm_xp_kernel(Args g) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
+}
+
+template <int NP, int BN>
+__global__ __launch_bounds__(768) void gemm_xp_kernel(Args g) { gemm_xp_body<NP, BN>(g, (int)blockIdx.x, (int)gridDim.x); }
+
+// Several independent products in ONE launch (round 6: the four parameter gradients dW_l = dY_l^T X_l of the MotionNet backward, behind
+// the dX chain instead of beside it -- every launch of this kernel takes whole CUs, so dX and dW launches side by side only time-share).
+// Problem i owns blocks [first[i], first[i] + nwg[i]); first[i] is a multiple of 8 so that a problem's block b still runs on XCD b % 8;
+// the blocks in between exit at once.
+constexpr int MAX_GROUP = 4;
+struct GroupArgs { Args p[MAX_GROUP]; int first[MAX_GROUP]; int nwg[MAX_GROUP]; int n; };
+
+template <int NP, int BN>
+__global__ __launch_bounds__(768) void gemm_xp_grouped_kernel(GroupArgs a) {
+    int i = 0;
+#pragma unroll
+    for (int q = 1; q < MAX_GROUP; ++q)
+        if (q < a.n && (int)blockIdx.x >= a.first[q]) i = q;
+    const int bid = (int)blockIdx.x - a.first[i];
+    if (bid >= a.nwg[i]) return;                            // (block-uniform: padding between problems)
+    gemm_xp_body<NP, BN>(a.p[i], bid, a.nwg[i]);
+}
+
+template <int NP, int BN>
+hipError_t launch_grouped(const GroupArgs& a, int blocks, hipStream_t s) {
+    using Q = Geo<NP, BN>;
+    static bool attr_set = false;
+    auto kern = &gemm_xp_grouped_kernel<NP, BN>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Q::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q::THREADS), Q::LDS, s, a);
+    return hipSuccess;
 }
 
 template <int NP, int BN>

@@ -444,6 +444,7 @@ class FitEngine:
     SPLIT_ADJ_ROWS = 256     # mesh_blend 'f32_split': the blend-shape adjoint in split precision from this many samples on
     XP_MIN_ROWS = int(os.environ.get('NEMO_XP_MIN_ROWS', '1600'))    # mlp_gemm 'f32_split': the chain on nemo_gemm_xp from this many rows on
     XP_DW_ASIDE_ROWS = 65536  # ... its parameter-gradient products on the side stream up to this many rows
+    XP_GROUPED_DW_ROWS = int(os.environ.get('NEMO_XP_GROUPED_DW_ROWS', '8192'))   # ... as ONE grouped launch up to this many rows
     XMETA = ('X', 'H1', 'H2', 'H3', 'dHEAD', 'dH', 'dH_b', 'dH_c', 'W0', 'W2', 'W4', 'Whead', 'b0', 'b2', 'b4')
     # (fp32 backward_mlp: the bias gradients come from the dX launches' per-band column sums at EVERY size -- headline 1.257 / 1.259 ms
     #  without / with, C4 101.8 / 101.5 ms: the win is C4's 6.6 GB of reads; a row threshold was never applied and is gone)
@@ -990,6 +991,12 @@ class FitEngine:
         self.gemm_xp(r, 147, h, w['H3x'], wx['head'], dptr(w['HEAD']), HEAD_LD, bias=self.p(lm + 'rot_out.bias'), mA=m('H3'), mB=m('Whead'),
                      mZero=m('X'))
 
+    def _dw_problem(self, grouped, M, N, K, Ax, Bx, Cp, ldc, mA, mB):
+        """A parameter-gradient product of the chain: a problem record for the grouped launch, or the closure that launches it alone."""
+        if grouped:
+            return (M, N, K, Ax.data_ptr(), Ax.stride(0), Bx.data_ptr(), Bx.stride(0), Cp, ldc, 1.0, 1, mA, mB)
+        return lambda: self.gemm_xp(M, N, K, Ax, Bx, Cp, ldc, out_mode=1, mA=mA, mB=mB)
+
     def _backward_mlp_xp(self, w, N, view_idx, frame_idx, raw_phase, nout, nbias, stages=(0, 1, 2), bucketed=False):
         """backward_mlp on the split-precision chain.  Every product is C = A B^T over xp copies: dX_l = dY_l (W_l^T)^T reads dY_l's
         plain copy and the transposed weight copy; dW_l = dY_l^T X_l reads the two TRANSPOSED activation copies (K = rows).
@@ -1015,11 +1022,19 @@ class FitEngine:
         main, side = torch.cuda.current_stream(), self.side_stream
         aside = (not bucketed) and r <= self.XP_DW_ASIDE_ROWS
         pend = []
+        # NEMO_XP_GROUPED_DW=1 (A/B aid, measured and NOT the default): the four parameter gradients as ONE grouped launch
+        # (nemo_gemm_xp_grouped) on the side stream behind the dX chain's last hidden product instead of one launch each beside the dX
+        # launches.  Same box, 8 x 300: 1.035 - 1.036 against 1.024 ms per step -- the dX launches alone are not faster in the graph (38 - 40
+        # us, their operands come cold from the previous launch) and the grouped launch takes 78 us (profiles/r06_experiments.md).
+        grouped = aside and tuple(stages) == (0, 1, 2) and r <= self.XP_GROUPED_DW_ROWS and os.environ.get('NEMO_XP_GROUPED_DW', '0') == '1'
+        probs = []
 
         def ready():
-            return main.record_event() if aside else None
+            return main.record_event() if (aside and not grouped) else None
 
         def dW(ev, fn):
+            if grouped:
+                return probs.append(fn)
             if not aside:
                 return fn()
             pend.append((ev, fn))
@@ -1038,16 +1053,14 @@ class FitEngine:
             self.cast_xp([(dptr(w['dHEAD']), r, nout, HEAD_LD, w['dHEADx'], w['dHEADxT'], m('dHEAD'))])
             # heads
             ev = ready()
-            dW(ev, lambda: self.gemm_xp(nout, h, r, w['dHEADxT'], w['H3xT'], self.g(lm + 'rot_out.weight'), h, out_mode=1,
-                                        mA=m('dHEAD'), mB=m('H3')))
+            dW(ev, self._dw_problem(grouped, nout, h, r, w['dHEADxT'], w['H3xT'], self.g(lm + 'rot_out.weight'), h, m('dHEAD'), m('H3')))
             cs.append((dptr(w['dHEAD']), r, nbias, HEAD_LD, self.g(lm + 'rot_out.bias')))
             self.gemm_xp(r, h, nout, w['dHEADx'], wx['headT'], maskx=w['H3x'], Cx=w['dHx'], CxT=w['dHxT'], colsum=w['cs4'],
                          mA=m('dHEAD'), mB=m('Whead'), mOut=m('dH'))
             flush_dW()
             # layer 4
             ev = ready()
-            dW(ev, lambda: self.gemm_xp(h, h, r, w['dHxT'], w['H2xT'], self.g(lm + 'net.net.4.weight'), h, out_mode=1,
-                                        mA=m('dH'), mB=m('H2')))
+            dW(ev, self._dw_problem(grouped, h, h, r, w['dHxT'], w['H2xT'], self.g(lm + 'net.net.4.weight'), h, m('dH'), m('H2')))
             cs.append((dptr(w['cs4']), R, h, h, self.g(lm + 'net.net.4.bias')))
             self.gemm_xp(r, h, h, w['dHx'], wx['4T'], maskx=w['H2x'], Cx=w['dH_bx'], CxT=w['dH_bxT'], colsum=w['cs2'],
                          tag='gemm_mlp_hidden_dx', mA=m('dH'), mB=m('W4'), mOut=m('dH_b'))
@@ -1056,8 +1069,7 @@ class FitEngine:
         if 1 in stages:
             # layer 2
             ev = ready()
-            dW(ev, lambda: self.gemm_xp(h, h, r, w['dH_bxT'], w['H1xT'], self.g(lm + 'net.net.2.weight'), h, out_mode=1,
-                                        mA=m('dH_b'), mB=m('H1')))
+            dW(ev, self._dw_problem(grouped, h, h, r, w['dH_bxT'], w['H1xT'], self.g(lm + 'net.net.2.weight'), h, m('dH_b'), m('H1')))
             cs.append((dptr(w['cs2']), R, h, h, self.g(lm + 'net.net.2.bias')))
             self.gemm_xp(r, h, h, w['dH_bx'], wx['2T'], maskx=w['H1x'], Cx=w['dH_cx'], CxT=w['dH_cxT'], colsum=w['cs0'],
                          mA=m('dH_b'), mB=m('W2'), mOut=m('dH_c'))
@@ -1067,9 +1079,21 @@ class FitEngine:
             return
         ev = ready()
         cs.append((dptr(w['cs0']), R, h, h, self.g(lm + 'net.net.0.bias')))
-        dW(ev, lambda: self.gemm_xp(h, self.din, r, w['dH_cxT'], w['XxT'], self.g(lm + 'net.net.0.weight'), self.din, out_mode=1,
-                                    mA=m('dH_c'), mB=m('X')))
+        dW(ev, self._dw_problem(grouped, h, self.din, r, w['dH_cxT'], w['XxT'], self.g(lm + 'net.net.0.weight'), self.din, m('dH_c'), m('X')))
+        if grouped:
+            # every dY exists: the four gradients in one launch on the side stream, enqueued BEHIND the chain's next product
+            ev_g = main.record_event()
         self.gemm_xp(r, self.din, h, w['dH_cx'], wx['0T'], dptr(w['dX']), self.ldx, mA=m('dH_c'), mB=m('W0'))
+        if grouped:
+            side.wait_event(ev_g)
+            with torch.cuda.stream(side):
+                arr = (_lib.GemmXpProblem * len(probs))()
+                for i, q in enumerate(probs):
+                    (arr[i].M, arr[i].N, arr[i].K, arr[i].A, arr[i].lda, arr[i].B, arr[i].ldb, arr[i].C, arr[i].ldc, arr[i].alpha,
+                     arr[i].out_mode, arr[i].metaA, arr[i].metaB) = q
+                gws = self.gemm_ws[1]
+                check(self.lib.nemo_gemm_xp_grouped(self.xp_fmt, len(probs), arr, gws.data_ptr(), gws.numel() * 4, _stream()),
+                      'nemo_gemm_xp_grouped')
         if bucketed:
             self.flush_colsums()
         self.phase_bwd(w, N, view_idx, frame_idx, raw_phase, with_colsums=not bucketed)

@@ -208,3 +208,38 @@ def test_split_chain_matches_fp32_chain_in_the_step(V, T, h, nv, version, full, 
         # case runs with the term on, where single vertices may flip)
         tol = 2e-5 if nv < 6890 else 2e-4
         assert float((a - b).abs().max()) <= tol * scale + 1e-30, (k, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize('fmt', [2, 3])
+def test_gemm_xp_grouped_parameter_gradients(fmt):
+    """nemo_gemm_xp_grouped: the four parameter gradients of the chain (dW_l = dY_l^T X_l, K = rows) in ONE launch, accumulating into
+    non-zero gradient buffers -- each against float64 with the fp32 GEMM's error as the bar, and bit-identical run to run."""
+    from nemo_cvpr2023_amd._lib import GemmXpProblem
+    L = H._lib.load()
+    r = 2401
+    shapes = [(147, 1000), (1000, 1000), (1000, 1000), (1000, 105)]
+    ops = []
+    for i, (M, N) in enumerate(shapes):
+        A = _rand(r, M, 1e-3, 40 + i, heavy=True)           # dY (rows x out): per-sample magnitudes over six decades
+        B = _rand(r, N, 1.0, 50 + i)                         # X  (rows x in)
+        _, AxT, mA = _xp_operand(fmt, A, True)
+        _, BxT, mB = _xp_operand(fmt, B, True)
+        ops.append((A, B, AxT, BxT, mA, mB, _rand(M, N, 1e-2, 60 + i)))
+    ws = H.gemm_ws()
+
+    def run():
+        Cs = [c0.clone() for *_, c0 in ops]
+        arr = (GemmXpProblem * len(ops))()
+        for i, ((M, N), (A, B, AxT, BxT, mA, mB, _), C) in enumerate(zip(shapes, ops, Cs)):
+            q = arr[i]
+            q.M, q.N, q.K, q.A, q.lda, q.B, q.ldb, q.C, q.ldc = M, N, r, AxT.data_ptr(), AxT.stride(0), BxT.data_ptr(), BxT.stride(0), C.data_ptr(), N
+            q.alpha, q.out_mode, q.metaA, q.metaB = 1.0, 1, H.dptr(mA), H.dptr(mB)
+        H.check(L.nemo_gemm_xp_grouped(fmt, len(ops), arr, ws.data_ptr(), ws.numel() * 4, H.st()), 'grouped')
+        return Cs
+    Cs = run()
+    for (M, N), (A, B, *_, c0), C in zip(shapes, ops, Cs):
+        ref = c0.double() + A.double().t() @ B.double()
+        e32 = _err(c0 + H.gemm(A, B, 1, 0), ref)
+        assert _err(C, ref) <= 1.5 * e32 + 1e-9, (M, N, _err(C, ref), e32)
+    assert all(torch.equal(a, b) for a, b in zip(Cs, run()))
+    assert int(ws[:4096].view(torch.int32).abs().sum()) == 0           # tickets back at zero
