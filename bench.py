@@ -491,7 +491,7 @@ def choose_shard_mode(cx, model, step, V, T, want):
     return best, ms, {m_: {'total_loss_after_14_steps': last[m_], 'agrees_with_' + modes[0]: agree[m_]} for m_ in modes}
 
 
-def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nnz=None):
+def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nnz=None, counters_apply=True):
     """The dominant tagged kernel of `timers` against the peak of its own mix of matrix pipes, + the whole step."""
     best = None
     for tag, evs in timers.items():
@@ -511,7 +511,8 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
     kpeak = flops / sum(f / MFMA_PEAK_TFLOPS[d] for d, f in pipes.items())
     achieved = flops / (mean_ms * 1e-3) / 1e12
     traffic = {}
-    if os.path.exists(TRAFFIC_FILE) and skin_nnz in (None, SKIN_NNZ):      # (counters were collected on the default body model)
+    # (counters were collected on the default body model and loss terms: legs on another body model / with further terms quote none)
+    if os.path.exists(TRAFFIC_FILE) and skin_nnz in (None, SKIN_NNZ) and counters_apply and os.environ.get('NEMO_BENCH_LOCALITY') != '1':
         traffic = json.load(open(TRAFFIC_FILE)).get(f'{V}x{T}x{cx.world}x{dtype}', {})
     # counters are only quoted for the kernel instantiation they were taken on (the file records it, with the commit)
     variant = engine.mesh_kernel_variant() if tag == 'mesh_v2v_fused' else None
@@ -621,7 +622,8 @@ def leg(cx, name, V, T, dtype, steps, warm, shard_mode='single', skin_nnz=None, 
                'skinning': 'sparse' if engine.ctx.skin_sparse else 'dense', 'skin_nnz': engine.ctx.skin_nnz,
                'body_model': 'synthetic, spatially structured (synthetic.make_smpl_assets(locality=True))' if locality else 'synthetic, random permutation (default)',
                'mesh_kernel': engine.mesh_kernel_variant(),
-               'roofline': roofline_block(cx, engine, timers, 2, ms, V, T, dtype, skin_nnz=skin_nnz)}
+               'roofline': roofline_block(cx, engine, timers, 2, ms, V, T, dtype, skin_nnz=skin_nnz,
+                                          counters_apply=not (locality or weight_smooth))}
         if cx.sharded:
             res['shard_mode'] = model.shard_mode
             res.update(shard_probe(cx, model, step, steps))
