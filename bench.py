@@ -59,7 +59,8 @@ V0, T0 = 8, 300
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks (fp32: v_mfma_f32_32x32x2_f32; bf16: 32x32x16) and HBM3E
 MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0, 'valu_f32': 157.3,      # (valu_f32: the fp32 vector peak = the fp32 MFMA peak)
                     'f16x3': 2500.0 / 3,      # fp32-equivalent products on the 16-bit pipe: three fp16 piece products each (mesh_blend f32_split)
-                    'bf16x6': 2500.0 / 6}     # ... as six bf16 piece products (NEMO_MESH_PIECES=3, the round's first form)
+                    'bf16x6': 2500.0 / 6,     # ... as six bf16 piece products (NEMO_MESH_PIECES=3, the round's first form)
+                    'f16x4': 2500.0 / 4}      # ... as four fp16 piece products (the mesh kernel's skinnings, MODE 6)
 HBM_PEAK_GBS = 8000.0
 TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'traffic.json')
 # what a supervisor tries, in order (environment of the worker processes)
@@ -526,7 +527,7 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
     mesh_b16 = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh']).get('bf16', 0.0)
     on_bf16 = (mesh_b16 + parts['blend_adjoint'] + parts['mlp'] + parts['vposer']) if dtype == 'bf16' else 0.0
     _mp = engine.kernel_flops_by_pipe('mesh_v2v_fused', parts['mesh'])
-    on_b16x6, on_f16x3 = _mp.get('bf16x6', 0.0), _mp.get('f16x3', 0.0)
+    on_b16x6, on_f16x3, on_f16x4 = _mp.get('bf16x6', 0.0), _mp.get('f16x3', 0.0), _mp.get('f16x4', 0.0)
     if dtype != 'bf16' and getattr(engine, 'split_adj', False) and engine.ctx.split_ok:
         on_f16x3 += parts['blend_adjoint']              # (the blend-shape adjoint in split precision too)
     if dtype != 'bf16' and getattr(engine, 'mlp_split', False) and any('Xx' in w_ for w_ in engine.ws.values()):
@@ -536,7 +537,7 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
         else:
             on_b16x6 += parts['mlp']
     step_peak = f_step / (on_bf16 / MFMA_PEAK_TFLOPS['bf16'] + on_b16x6 / MFMA_PEAK_TFLOPS['bf16x6'] + on_f16x3 / MFMA_PEAK_TFLOPS['f16x3'] +
-                          (f_step - on_bf16 - on_b16x6 - on_f16x3) / MFMA_PEAK_TFLOPS['f32'])
+                          on_f16x4 / MFMA_PEAK_TFLOPS['f16x4'] + (f_step - on_bf16 - on_b16x6 - on_f16x3 - on_f16x4) / MFMA_PEAK_TFLOPS['f32'])
     roof = {'kernel': tag, 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': round(kpeak, 1),
             'unit': 'TFLOP/s', 'frac': round(achieved / kpeak, 4),
             'frac_strict': round(achieved * (f_strict / flops) / kpeak, 4),
@@ -547,7 +548,8 @@ def roofline_block(cx, engine, timers, n_inst, ms_per_step, V, T, dtype, skin_nn
             'peak_note': 'fp32 MFMA peak' if set(pipes) <= {'f32', 'valu_f32'} else
                          'harmonic mix of the per-pipe peaks over this kernel\'s algorithmic GFLOP per pipe (`pipes`): bf16 MFMA 2500, '
                          'fp32 MFMA / fp32 VALU 157.3, f16x3 = fp32-equivalent products as three fp16 piece products = 2500 / 3 '
-                         '(mesh_blend f32_split, mlp_gemm f32_split), bf16x6 = six bf16 piece products = 2500 / 6',
+                         '(mesh_blend f32_split, mlp_gemm f32_split), f16x4 = four fp16 piece products = 2500 / 4 (the mesh kernel\'s skinnings), '
+                         'bf16x6 = six bf16 piece products = 2500 / 6',
             'traffic': ktr, 'traffic_source': traffic.get('source') if ktr else None,
             'traffic_commit': traffic.get('commit') if ktr else None, 'traffic_kernel': variant if ktr else None,
             'traffic_dropped': 'counters in profiles/traffic.json were taken on ' + str(traffic.get('kernel_variants', {}).get(tag)) +

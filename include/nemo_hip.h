@@ -322,6 +322,12 @@ int32_t nemo_ctx_skin_nnz(const nemo_ctx* ctx);
  * NEMO_EINVAL: the caller keeps d vp in fp32 (nemo_v2v_fused_split + the fp32 adjoint GEMM). */
 int32_t nemo_ctx_split_ok(const nemo_ctx* ctx);
 float nemo_ctx_vp_bound(const nemo_ctx* ctx);
+/* nemo_ctx_skin_mfma_ok: 1 while, in addition, the relative joint transforms' entries (bounded from the rest joints: |J_0| + the longest
+ * chain of bone lengths + max |J|) keep 2^12 |A| < 2^15.9 -- then nemo_v2v_fused_split(mem / xp) also run their two skinnings
+ * (lbs.py:236-252) as fp16 split-precision MFMAs (kernel MODE 6: weights as three fp16 pieces = exactly, transforms as two, four piece
+ * products: fp32-equivalent, error against float64 <= the fp32 kernel's), the dense 24-joint product on the 16-bit pipe instead of the
+ * <= 4 non-zero weights on the VALU; NEMO_MESH_SKIN=sparse keeps the VALU form (MODE 5). */
+int32_t nemo_ctx_skin_mfma_ok(const nemo_ctx* ctx);
 int32_t nemo_ctx_skin_sparse(const nemo_ctx* ctx);
 int32_t nemo_ctx_set_skin_sparse(nemo_ctx* ctx, int32_t enable);
 int64_t nemo_ctx_nq(const nemo_ctx* ctx);            /* # non-kinematic output joints            */

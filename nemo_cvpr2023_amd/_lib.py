@@ -97,6 +97,7 @@ SIGNATURES = {
     'nemo_ctx_num_verts': (i64, [ptr]),
     'nemo_ctx_skin_nnz': (i32, [ptr]),
     'nemo_ctx_split_ok': (i32, [ptr]),
+    'nemo_ctx_skin_mfma_ok': (i32, [ptr]),
     'nemo_ctx_vp_bound': (f32, [ptr]),
     'nemo_ctx_skin_sparse': (i32, [ptr]),
     'nemo_ctx_set_skin_sparse': (i32, [ptr, i32]),

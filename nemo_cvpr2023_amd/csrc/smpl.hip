@@ -57,6 +57,11 @@ struct nemo_ctx {
     std::vector<float> h_pabs2;
     float vp_bound = 0.f;
     int split_ok = 1;
+    // MODE 6: the relative transforms' entries are staged as fp16 pieces of 2^12 A: |A| <= 1 for the rotation part, <= |J_0| + the longest
+    // chain of bone lengths + max |J| for the translation part (a_bound, from the rest joints: recomputed by nemo_ctx_set_betas)
+    float a_bound = 0.f;
+    int skin_mfma_ok = 1;
+    unsigned short* d_Wskh = nullptr;   // three fp16 pieces of 2^14 W, [piece][NVp][32 joints (24 + zero tail)]
     unsigned short* d_Wadj3;           // MODE 4: [tile][joint tile 2][variant 3: W0|W0, W1|W1, W0|W2][lane 64][8] (three bf16 pieces of W)
     // SPARSE skinning weights (the published SMPL model has at most four non-zero weights per vertex; the dense 24-column
     // product of lbs.py:236-241 then multiplies 20 zeros per vertex): per vertex (NVp of them, zero rows for the pad) the
@@ -99,6 +104,20 @@ extern "C" int32_t nemo_ctx_set_betas(nemo_ctx* ctx, const float* betas) {
             for (long v = 0; v < NV; ++v) acc += (double)ctx->h_Jreg[j * NV + v] * vs[v * 3 + c];
             J[j * 3 + c] = (float)acc;
         }
+    {
+        float path[24], mj = 0.f, worst = 0.f;
+        auto nrm = [&](int a) { return sqrtf(J[a * 3] * J[a * 3] + J[a * 3 + 1] * J[a * 3 + 1] + J[a * 3 + 2] * J[a * 3 + 2]); };
+        for (int j = 0; j < 24; ++j) {
+            mj = fmaxf(mj, nrm(j));
+            if (j == 0) { path[0] = nrm(0); continue; }
+            const int p = ctx->kc.parents[j];
+            const float dx = J[j * 3] - J[p * 3], dy = J[j * 3 + 1] - J[p * 3 + 1], dz = J[j * 3 + 2] - J[p * 3 + 2];
+            path[j] = path[p] + sqrtf(dx * dx + dy * dy + dz * dz);
+            worst = fmaxf(worst, path[j]);
+        }
+        ctx->a_bound = fmaxf(1.f, worst + mj);
+        ctx->skin_mfma_ok = (ctx->split_ok && ctx->a_bound * 4096.f < 61000.f) ? 1 : 0;
+    }
     std::vector<float> c0((size_t)ctx->nq * 72 + 1, 0.f);
     for (int q = 0; q < ctx->nq; ++q)
         for (int j = 0; j < 24; ++j) {
@@ -308,6 +327,21 @@ extern "C" int32_t nemo_ctx_create(nemo_ctx** out, int64_t NV, const float* v_te
                 wadjh[bh + r] = h0; wadjh[bh + 4 + r] = h0;
                 wadjh[bh + 64 * 8 + r] = h1;
             }
+        {
+            // THREE fp16 pieces of 2^14 W (33 bits: the weights exactly) -- they live in registers; the transforms keep two (LDS)
+            std::vector<unsigned short> wskh((size_t)3 * c->NVp * 32, 0);
+            for (long v = 0; v < NV; ++v)
+                for (int j = 0; j < 24; ++j) {
+                    float x = lbs_weights[v * 24 + j] * 16384.f;
+                    for (int pc = 0; pc < 3; ++pc) {
+                        const unsigned short h = f16w(x);
+                        wskh[((size_t)pc * c->NVp + v) * 32 + j] = h;
+                        x -= unf16w(h);
+                    }
+                }
+            HIPCHK(hipMalloc((void**)&c->d_Wskh, wskh.size() * 2));
+            HIPCHK(hipMemcpy(c->d_Wskh, wskh.data(), wskh.size() * 2, hipMemcpyHostToDevice));
+        }
         c->d_Wsk = c->d_Wadj = nullptr;
         HIPCHK(hipMalloc((void**)&c->d_Wsk, wsk.size() * 2));
         HIPCHK(hipMemcpy(c->d_Wsk, wsk.data(), wsk.size() * 2, hipMemcpyHostToDevice));
@@ -363,6 +397,7 @@ extern "C" int32_t nemo_ctx_destroy(nemo_ctx* c) {
     if (c->d_Wadj) (void)hipFree(c->d_Wadj);
     if (c->d_Wadj3) (void)hipFree(c->d_Wadj3);
     if (c->d_Wadjh) (void)hipFree(c->d_Wadjh);
+    if (c->d_Wskh) (void)hipFree(c->d_Wskh);
     if (c->d_posedirs_sph) (void)hipFree(c->d_posedirs_sph);
     if (c->d_Wsp_w) (void)hipFree(c->d_Wsp_w);
     if (c->d_Wsp_j) (void)hipFree(c->d_Wsp_j);
@@ -372,6 +407,7 @@ extern "C" int32_t nemo_ctx_destroy(nemo_ctx* c) {
 extern "C" int64_t nemo_ctx_num_verts(const nemo_ctx* c) { return c ? c->NV : -1; }
 extern "C" int32_t nemo_ctx_skin_nnz(const nemo_ctx* c) { return c ? c->skin_nnz : -1; }
 extern "C" int32_t nemo_ctx_split_ok(const nemo_ctx* c) { return c ? c->split_ok : -1; }
+extern "C" int32_t nemo_ctx_skin_mfma_ok(const nemo_ctx* c) { return c ? c->skin_mfma_ok : -1; }
 extern "C" float nemo_ctx_vp_bound(const nemo_ctx* c) { return c ? c->vp_bound : -1.f; }
 extern "C" int32_t nemo_ctx_skin_sparse(const nemo_ctx* c) { return c ? c->skin_sparse : -1; }
 extern "C" int32_t nemo_ctx_set_skin_sparse(nemo_ctx* c, int32_t enable) {
@@ -1436,7 +1472,11 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     int* __restrict__ grid_ticket, unsigned short* __restrict__ dVPb, long ldk,
     const unsigned short* __restrict__ Wsk, const unsigned short* __restrict__ Wadj,
     const float* __restrict__ Wsp_w, const unsigned int* __restrict__ Wsp_j, float pscale, long hplane) {
-    constexpr bool BF16 = MODE >= 1 && MODE <= 3, SPLIT = MODE == 2, ADJS = MODE == 2 || MODE == 3;
+    // MODE 6 (round 6): MODE 5 whose two skinnings run as split-precision MFMAs too -- T = W A with W as two fp16 pieces of 2^14 W and the
+    // transforms as two fp16 pieces of 2^12 A (three piece products: fp32-equivalent), the dense 24-joint product of lbs.py:236-241 on the
+    // 16-bit pipe instead of the <= 4 non-zero weights on the VALU (768 FMAs per tile and lane); SKH marks it inside the SPLIT paths
+    constexpr bool BF16 = MODE >= 1 && MODE <= 3, SKH = MODE == 6, SPLIT = MODE == 2 || SKH, ADJS = MODE == 2 || MODE == 3;
+    constexpr float A_SCALE = SKH ? 4096.f : 1.f, T_UNSCALE = SKH ? 1.f / (16384.f * 4096.f) : 1.f;
     // MODE 4 (round 5, "f32_split"): fp32 arithmetic everywhere EXCEPT that the pose blend's products run on the bf16 pipe with
     // both operands carried as THREE bf16 pieces (8 + 8 + 8 significant bits = the fp32 value): x = x0 + x1 + x2, and
     // P pf = P0 pf0 + P0 pf1 + P1 pf0 + P0 pf2 + P1 pf1 + P2 pf0 (+ terms below 2^-24 of |P| |pf|), every piece product exact in
@@ -1450,7 +1490,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     // LDS.  Per term that is up to 2^-21 against the 2^-24 of an fp32 FMA; over the 207 terms of a blend the fp32 accumulation's own
     // rounding dominates either way -- error against float64: fp32 product 5.1e-7, this 5.0e-7, three bf16 pieces 3.2e-7 of the result's
     // scale (same test), and the kernel's outputs equal the fp32-MFMA kernel's error (test_v2v_fused_split_is_fp32_equivalent).
-    constexpr bool SP3 = MODE == 4 || MODE == 5, SPH = MODE == 5, B16 = BF16 || SP3;
+    constexpr bool SP3 = MODE == 4 || MODE == 5 || MODE == 6, SPH = MODE == 5 || MODE == 6, B16 = BF16 || SP3;
     constexpr int NP = SPH ? 2 : 3;                          // pieces per operand
     using e16 = std::conditional_t<SPH, _Float16, __bf16>;   // their element type
     typedef e16 e16x8 __attribute__((ext_vector_type(8)));
@@ -1605,9 +1645,14 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 __bf16* dl = ALb + ((set * 2 + 1) * 16 + n) * MF_AB + e * 32 + j;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float xv = live ? x[i] : 0.f;
-                    const __bf16 h = (__bf16)xv;
-                    dh[32 * i] = h; dl[32 * i] = (__bf16)(xv - (float)h);
+                    const float xv = (live ? x[i] : 0.f) * A_SCALE;
+                    if constexpr (SKH) {
+                        const _Float16 h = (_Float16)xv;
+                        dh[32 * i] = __builtin_bit_cast(__bf16, h); dl[32 * i] = __builtin_bit_cast(__bf16, (_Float16)(xv - (float)h));
+                    } else {
+                        const __bf16 h = (__bf16)xv;
+                        dh[32 * i] = h; dl[32 * i] = (__bf16)(xv - (float)h);
+                    }
                 }
             } else {
             float* d = AL + (set * 16 + n) * MF_AS + e * 24 + j;
@@ -1638,6 +1683,11 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             const float xv = (s < N) ? A2[(set * N + s) * 288 + je] : 0.f;
             if constexpr (SPARSE) {
                 AL[((set * 72 + je / 4) * 16 + n) * 4 + je % 4] = xv;
+            } else if constexpr (SKH) {
+                const float xs = xv * A_SCALE;
+                const _Float16 h = (_Float16)xs;
+                ALb[((set * 2 + 0) * 16 + n) * MF_AB + e * 32 + j] = __builtin_bit_cast(__bf16, h);
+                ALb[((set * 2 + 1) * 16 + n) * MF_AB + e * 32 + j] = __builtin_bit_cast(__bf16, (_Float16)(xs - (float)h));
             } else if constexpr (SPLIT) {
                 const __bf16 h = (__bf16)xv;
                 ALb[((set * 2 + 0) * 16 + n) * MF_AB + e * 32 + j] = h;
@@ -1719,7 +1769,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         const long v0 = t * 16;
         // weights as A-operands: forward (rows = vertices, k = joints) and adjoint (rows = joints, k = vertices)
         float wf[6], wa[4][2];
-        mbf16x8 wsk[2], wad[2][2];                               // split precision: [piece], [joint tile][piece]
+        mbf16x8 wsk[SKH ? 3 : 2], wad[2][2];                     // split precision: [piece], [joint tile][piece]
         u32x4m wad3[2][NP];                                      // ADJ3: [joint tile][A image]
         float4 sw[4];                                            // sparse: this lane's 4 vertices x <= 4 (weight, joint)
         unsigned int sj[4];
@@ -1727,7 +1777,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
         } else if constexpr (SPLIT) {
             const long NVp16 = ((NV + 15) / 16) * 16;
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc)
+            for (int pc = 0; pc < (SKH ? 3 : 2); ++pc)
                 wsk[pc] = *reinterpret_cast<const mbf16x8*>(Wsk + ((long)pc * NVp16 + v0 + l15) * 32 + 8 * g);
         } else {
             const float* Wf = W + (v0 + l15) * 24 + g;
@@ -1906,12 +1956,26 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                     bh[d] = *reinterpret_cast<const mbf16x8*>(Ab1 + (4 * c + d) * 32);
                     bl[d] = *reinterpret_cast<const mbf16x8*>(Ab1 + 16 * MF_AB + (4 * c + d) * 32);
                 }
+                auto mf = [](const mbf16x8& a, const mbf16x8& b, const f32x4& acc) {
+                    if constexpr (SKH) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mf16x8, a), __builtin_bit_cast(mf16x8, b), acc, 0, 0, 0);
+                    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+                };
+                if constexpr (SKH) {         // W exact (three pieces), A to 2^-23; W1 A1 (<= 2^-24 of the product) is dropped
 #pragma unroll
-                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[0], bh[d], T4[d], 0, 0, 0);
+                    for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[2], bh[d], T4[d]);
+                }
 #pragma unroll
-                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[0], bl[d], T4[d], 0, 0, 0);
+                for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[0], bl[d], T4[d]);          // (minor products first)
 #pragma unroll
-                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[1], bh[d], T4[d], 0, 0, 0);
+                for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[1], bh[d], T4[d]);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[0], bh[d], T4[d]);
+                if constexpr (SKH) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) T4[d][r] *= T_UNSCALE;
+                }
             } else {
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk)
@@ -2000,12 +2064,26 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                     bh[d] = *reinterpret_cast<const mbf16x8*>(Ab0 + (4 * c + d) * 32);
                     bl[d] = *reinterpret_cast<const mbf16x8*>(Ab0 + 16 * MF_AB + (4 * c + d) * 32);
                 }
+                auto mf = [](const mbf16x8& a, const mbf16x8& b, const f32x4& acc) {
+                    if constexpr (SKH) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mf16x8, a), __builtin_bit_cast(mf16x8, b), acc, 0, 0, 0);
+                    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+                };
+                if constexpr (SKH) {         // W exact (three pieces), A to 2^-23; W1 A1 (<= 2^-24 of the product) is dropped
 #pragma unroll
-                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[0], bh[d], T4[d], 0, 0, 0);
+                    for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[2], bh[d], T4[d]);
+                }
 #pragma unroll
-                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[0], bl[d], T4[d], 0, 0, 0);
+                for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[0], bl[d], T4[d]);          // (minor products first)
 #pragma unroll
-                for (int d = 0; d < 4; ++d) T4[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wsk[1], bh[d], T4[d], 0, 0, 0);
+                for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[1], bh[d], T4[d]);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[0], bh[d], T4[d]);
+                if constexpr (SKH) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) T4[d][r] *= T_UNSCALE;
+                }
             } else {
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk)
@@ -2680,15 +2758,23 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
     // (nemo_ctx_split_ok, set by nemo_ctx_create / nemo_ctx_set_betas); beyond it the three-bf16-piece form runs -- and the caller
     // that asked for fp16 piece planes of d vp is refused (the engine asks nemo_ctx_split_ok first)
     if (kind == 2 && dVPb && !ctx->split_ok) return NEMO_EINVAL;
-    const int mode = bf16 ? (split_env == 3 ? 3 : 2) : kind == 2 ? (((pieces_env == 3 || !ctx->split_ok) && !dVPb) ? 4 : 5) : 0;   // (fp16 planes out: MODE 5 only)
-    const bool sparse = ctx->skin_sparse != 0 && mode != 2;
-    const int lds_bytes = mode == 2 ? (2 * 16 * MF_PFB / 2 + 2 * 2 * 16 * MF_AB / 2 + MF_TAIL) * (int)sizeof(float)
+    int mode = bf16 ? (split_env == 3 ? 3 : 2) : kind == 2 ? (((pieces_env == 3 || !ctx->split_ok) && !dVPb) ? 4 : 5) : 0;   // (fp16 planes out: MODE 5 only)
+    // MODE 6 (round 6, the default of kind 2; NEMO_MESH_SKIN=sparse: MODE 5): MODE 5 with both skinnings as fp16 split-precision MFMAs --
+    // the dense 24-joint product of lbs.py:236-241 with the weights as three fp16 pieces (exact) and the transforms as two, four piece
+    // products -- instead of the <= 4 non-zero weights on the VALU: 357 -> 344 us per 8 x 300 launch; inside the range guard of the
+    // transforms' pieces only (nemo_ctx_skin_mfma_ok: 2^12 |A| < 2^15.9)
+    static const bool skin_mfma = !(getenv("NEMO_MESH_SKIN") != nullptr && !strcmp(getenv("NEMO_MESH_SKIN"), "sparse"));
+    if (mode == 5 && skin_mfma && ctx->skin_mfma_ok) mode = 6;
+    const bool sparse = ctx->skin_sparse != 0 && mode != 2 && mode != 6;
+    const int lds_bytes = mode == 6 ? (2 * 2 * 16 * MF_PFB / 2 + 2 * 2 * 16 * MF_AB / 2 + MF_TAIL) * (int)sizeof(float)
+        : mode == 2 ? (2 * 16 * MF_PFB / 2 + 2 * 2 * 16 * MF_AB / 2 + MF_TAIL) * (int)sizeof(float)
         : ((mode == 4 ? 3 * 2 * 16 * MF_PFB / 2 : mode == 5 ? 2 * 2 * 16 * MF_PFB / 2 : bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) +
            2 * 16 * (sparse ? MF_ASP : MF_AS) + MF_TAIL) *
               (int)sizeof(float);
-    static bool attr_set[6][2] = {{false, false}, {false, false}, {false, false}, {false, false}, {false, false}, {false, false}};
+    static bool attr_set[7][2] = {{false, false}, {false, false}, {false, false}, {false, false}, {false, false}, {false, false}, {false, false}};
     if (!attr_set[mode][sparse]) {
-        const void* fn = mode == 5 ? (sparse ? (const void*)mesh_v2v_fused_kernel<5, true> : (const void*)mesh_v2v_fused_kernel<5, false>)
+        const void* fn = mode == 6 ? (const void*)mesh_v2v_fused_kernel<6, false>
+                       : mode == 5 ? (sparse ? (const void*)mesh_v2v_fused_kernel<5, true> : (const void*)mesh_v2v_fused_kernel<5, false>)
                        : mode == 4 ? (sparse ? (const void*)mesh_v2v_fused_kernel<4, true> : (const void*)mesh_v2v_fused_kernel<4, false>)
                        : mode == 2 ? (const void*)mesh_v2v_fused_kernel<2, false>
                        : mode == 3 ? (sparse ? (const void*)mesh_v2v_fused_kernel<3, true> : (const void*)mesh_v2v_fused_kernel<3, false>)
@@ -2710,12 +2796,14 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
     float* loss_parts = reinterpret_cast<float*>(wsb + 16);
     int* tickets = reinterpret_cast<int*>(wsb + 16 + MESH_MAX_BLOCKS * 4);
     float* parts = reinterpret_cast<float*>(wsb + MESH_HEADER_BYTES);
-    const unsigned short* WADJ = mode == 5 ? ctx->d_Wadjh : mode == 4 ? ctx->d_Wadj3 : ctx->d_Wadj;
+    const unsigned short* WADJ = (mode == 5 || mode == 6) ? ctx->d_Wadjh : mode == 4 ? ctx->d_Wadj3 : ctx->d_Wadj;
+    const unsigned short* WSK = mode == 6 ? ctx->d_Wskh : ctx->d_Wsk;
 #define MESH_LAUNCH(M, SP, PP, LDP) hipLaunchKernelGGL((mesh_v2v_fused_kernel<M, SP>), dim3((unsigned)blocks), dim3(256), lds_bytes, \
         (hipStream_t)stream, (long)N, ctx->NV, PF2, (long)ldpf, A2, PP, LDP, ctx->d_v_shaped, ctx->d_W, pl.G, pl.cpg, pl.RA,  \
         pl.CA, pl.nB, vec_stage, loss_sum, dVPt, (long)ldn, dA, parts, tickets, loss_parts, grid_ticket, dVPb, (long)ldk,    \
-        ctx->d_Wsk, WADJ, ctx->d_Wsp_w, ctx->d_Wsp_j, ctx->sph_scale, (long)hplane)
-    if (mode == 5 && sparse) MESH_LAUNCH(5, true, reinterpret_cast<const float*>(ctx->d_posedirs_sph), ctx->NVp);
+        WSK, WADJ, ctx->d_Wsp_w, ctx->d_Wsp_j, ctx->sph_scale, (long)hplane)
+    if (mode == 6) MESH_LAUNCH(6, false, reinterpret_cast<const float*>(ctx->d_posedirs_sph), ctx->NVp);
+    else if (mode == 5 && sparse) MESH_LAUNCH(5, true, reinterpret_cast<const float*>(ctx->d_posedirs_sph), ctx->NVp);
     else if (mode == 5) MESH_LAUNCH(5, false, reinterpret_cast<const float*>(ctx->d_posedirs_sph), ctx->NVp);
     else if (mode == 4 && sparse) MESH_LAUNCH(4, true, reinterpret_cast<const float*>(ctx->d_posedirs_sp3), ctx->NVp);
     else if (mode == 4) MESH_LAUNCH(4, false, reinterpret_cast<const float*>(ctx->d_posedirs_sp3), ctx->NVp);

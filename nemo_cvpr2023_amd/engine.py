@@ -80,6 +80,12 @@ class SmplContext:
         self.split_ok = bool(self.lib.nemo_ctx_split_ok(h))
 
     @property
+    def skin_mfma(self):
+        """mesh_blend 'f32_split' skins with split-precision MFMAs (kernel MODE 6) -- the library's default inside the transforms' range
+        guard; NEMO_MESH_SKIN=sparse keeps the sparse VALU form."""
+        return bool(self.lib.nemo_ctx_skin_mfma_ok(self.handle)) and os.environ.get('NEMO_MESH_SKIN') != 'sparse'
+
+    @property
     def vp_bound(self):
         return float(self.lib.nemo_ctx_vp_bound(self.handle))
 
@@ -591,7 +597,12 @@ class FitEngine:
         #  entry, priced at the fp32 vector peak, which equals the fp32 MFMA peak on this part)
         valu = 0.0
         b16_skin = self.bf16 and os.environ.get('NEMO_MESH_SPLIT', '2') != '3'      # kernel MODE 2: skinning as split-precision MFMAs
-        if tag == 'mesh_v2v_fused' and self.ctx.skin_sparse_flag and not b16_skin:
+        skin16 = 0.0
+        if tag == 'mesh_v2v_fused' and self._mesh_mode6():
+            # (kernel MODE 6: the two skinnings on the 16-bit pipe as FOUR fp16 piece products per algorithmic product -- pipe 'f16x4';
+            #  the algorithmic work stays what mesh_macs counts: the model's non-zero weights)
+            skin16 = flops * (2 * 12 * (4 if self.ctx.skin_sparse_flag else 24)) / self.mesh_macs()
+        elif tag == 'mesh_v2v_fused' and self.ctx.skin_sparse_flag and not b16_skin:
             valu = flops * (2 * 12 * 4) / self.mesh_macs()
         if not self.bf16:
             if tag in ('gemm_mlp_hidden_fwd', 'gemm_mlp_hidden_dx') and self.mlp_split and any('Xx' in w_ for w_ in self.ws.values()):
@@ -604,7 +615,9 @@ class FitEngine:
                 #  piece products per algorithmic product -- pipe 'f16x3', whose peak is a third of the fp16 / bf16 MFMA peak;
                 #  NEMO_MESH_PIECES=3 (MODE 4): six bf16 piece products, 'bf16x6')
                 b16 = flops * (2 * 3 * 207 + 288) / self.mesh_macs()
-                out = {('bf16x6' if self._mesh_three_pieces() else 'f16x3'): b16, 'f32': flops - b16 - valu}
+                out = {('bf16x6' if self._mesh_three_pieces() else 'f16x3'): b16, 'f32': flops - b16 - valu - skin16}
+                if skin16:
+                    out['f16x4'] = skin16
             if valu:
                 out['valu_f32'] = valu
             return out
@@ -646,8 +659,11 @@ class FitEngine:
 
     def mesh_kernel_variant(self):
         """The mesh kernel instantiation this engine launches (what counter files under profiles/ are keyed by)."""
-        mode = (3 if os.environ.get('NEMO_MESH_SPLIT', '2') == '3' else 2) if self.bf16 else ((4 if self._mesh_three_pieces() else 5) if self.mesh_split else 0)
-        return f"mesh_v2v_fused_kernel<{mode}, {'true' if self.ctx.skin_sparse_flag and mode != 2 else 'false'}>"
+        mode = (3 if os.environ.get('NEMO_MESH_SPLIT', '2') == '3' else 2) if self.bf16 else ((4 if self._mesh_three_pieces() else (6 if self.ctx.skin_mfma else 5)) if self.mesh_split else 0)
+        return f"mesh_v2v_fused_kernel<{mode}, {'true' if self.ctx.skin_sparse_flag and mode not in (2, 6) else 'false'}>"
+
+    def _mesh_mode6(self):
+        return (not self.bf16) and self.mesh_split and not self._mesh_three_pieces() and self.ctx.skin_mfma
 
     # Optional per-launch HIP-event timing of tagged kernels (bench.py's roofline leg).  Events are
     # recorded on the stream the kernels are launched on (torch's current stream).

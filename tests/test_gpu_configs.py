@@ -283,7 +283,11 @@ def test_c4_rows_for_nemo_v3_v4(version):
     ({'NEMO_MESH_PIECES': '3', 'NEMO_SPLIT_ADJOINT': '0', 'NEMO_ADJ128': '0'},
      ['tests/test_gpu_ops.py', 'tests/test_gpu_bf16.py', 'tests/test_gpu_model.py', '-k',
       'split_is_fp32 or adjoint or (v2v_fused_mesh and 6890) or published_config_step_vs_oracle']),
-], ids=['fp32_mfma_blend_atomics', 'bf16_round4_forms', 'f32_split_first_forms'])
+    # f32_split with the sparse VALU skinning of round 5 (kernel MODE 5) and the round-5 adjoint pair
+    ({'NEMO_MESH_SKIN': 'sparse', 'NEMO_ADJ_XP': '0'},
+     ['tests/test_gpu_ops.py', 'tests/test_gpu_model.py', '-k',
+      'split_is_fp32 or regimes_and_range or (v2v_fused_mesh and 6890) or published_config_step_vs_oracle or true_init']),
+], ids=['fp32_mfma_blend_atomics', 'bf16_round4_forms', 'f32_split_first_forms', 'f32_split_sparse_skinning'])
 def test_alternative_kernel_paths_stay_correct(env, target):
     """The switches of INTEGRATION.md section F that select another KERNEL are read once per process: each alternative runs the
     parity tests that cover it in a child process, so that the non-default forms (bench.py's `f32_mfma_blend` leg, the A/B aids)
