@@ -1970,12 +1970,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[1], bh[d], T4[d]);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[0], bh[d], T4[d]);
-                if constexpr (SKH) {
-#pragma unroll
-                    for (int d = 0; d < 4; ++d)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) T4[d][r] *= T_UNSCALE;
-                }
+                // (SKH: T4 stays 2^26 T here -- the power of two leaves with the row's result / the sign, 12 multiplies per row instead of 32)
             } else {
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk)
@@ -1985,7 +1980,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                vrec[c][r] = T4[0][r] * vp[1][0][r] + T4[1][r] * vp[1][1][r] + T4[2][r] * vp[1][2][r] + T4[3][r];
+                vrec[c][r] = (T4[0][r] * vp[1][0][r] + T4[1][r] * vp[1][1][r] + T4[2][r] * vp[1][2][r] + T4[3][r]) * T_UNSCALE;
             __builtin_amdgcn_sched_barrier(0);
         }
         /*prof:c2*/
@@ -2078,12 +2073,7 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
                 for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[1], bh[d], T4[d]);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) T4[d] = mf(wsk[0], bh[d], T4[d]);
-                if constexpr (SKH) {
-#pragma unroll
-                    for (int d = 0; d < 4; ++d)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) T4[d][r] *= T_UNSCALE;
-                }
+                // (SKH: T4 stays 2^26 T here -- the power of two leaves with the row's result / the sign, 12 multiplies per row instead of 32)
             } else {
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk)
@@ -2095,12 +2085,13 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
             float gs[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float vo = T4[0][r] * vp[0][0][r] + T4[1][r] * vp[0][1][r] + T4[2][r] * vp[0][2][r] + T4[3][r];
+                const float vo = (T4[0][r] * vp[0][0][r] + T4[1][r] * vp[0][1][r] + T4[2][r] * vp[0][2][r] + T4[3][r]) * T_UNSCALE;
                 const float d = vrec[c][r] - vo;
                 lsum += fabsf(d);
                 gs[r] = d == 0.f ? 0.f : (d > 0.f ? -1.f : 1.f);          // d|v_rec - v_orig| / d v_orig
+                const float gst = gs[r] * T_UNSCALE;
 #pragma unroll
-                for (int d2 = 0; d2 < 3; ++d2) dvp[d2][r] += T4[d2][r] * gs[r];
+                for (int d2 = 0; d2 < 3; ++d2) dvp[d2][r] += T4[d2][r] * gst;
             }
             /*prof:q2*/
             if (c == 2 && !ADJ3) {
