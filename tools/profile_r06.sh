@@ -43,6 +43,6 @@ python3 bench.py --instances 40 --steps 20 --warmup 3 $B > $O/bench_c3_f32.json 
 python3 bench.py $C3 --steps 20 --warmup 3 $B > $O/bench_c3_bf16.json 2>/dev/null
 for v in 1 2 4; do python3 bench.py --instances $v --steps 100 --warmup 5 $B > $O/bench_shard_v$v.json 2>/dev/null; done
 for v in 1 8; do NEMO_BENCH_SHARD_OF_ONE=1 python3 bench.py --instances $v --steps 100 --warmup 5 $B 2>/dev/null | grep '^{' > $O/bench_group1_v$v.json; done
-find $O -name "*.db" -size +30M -delete
+find $O -name "*.db" -delete
 find $O -name "*.csv" -size +20M -delete
 du -sh $O

@@ -11,5 +11,5 @@ export NEMO_GRAPHS=0
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_c4 -o f -- python3 bench.py --instances 256 --frames 1024 --steps 2 --warmup 1 $B > $O/pmc_f_c4.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_c4 -o w -- python3 bench.py --instances 256 --frames 1024 --steps 2 --warmup 1 $B > $O/pmc_w_c4.log 2>&1
 python3 tools/pmc_summary.py $O/pmc_fetch_c4/f_results.db $O/pmc_write_c4/w_results.db > $O/pmc_traffic_c4.md 2>&1
-find $O -name "*.db" -size +30M -delete
+find $O -name "*.db" -delete
 tail -n 3 $O/pmc_traffic_c4.md
