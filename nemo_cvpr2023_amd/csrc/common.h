@@ -12,6 +12,20 @@
         if (e_ != hipSuccess) return (int32_t)e_;   \
     } while (0)
 
+// The > 64 KB dynamic-LDS opt-in (hipFuncSetAttribute) is per DEVICE: one flag per (call site, device), so that a process that drives
+// several GPUs sets it on each (until round 6 a per-process flag set it on the first device only).
+struct NemoAttrOnce {
+    bool done[32] = {};
+    bool need() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        d &= 31;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
 static inline int nemo_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // 64-lane wavefront sum (all lanes receive the total).

@@ -393,12 +393,11 @@ hipError_t launch_one(const GemmArgs& g, int blocks, hipStream_t s) {
     using SA = Stager<BM, BK, !TA, VA, NS>;
     using SB = Stager<BN, BK, TB, VB, NS>;
     constexpr size_t lds = 2 * (SA::SIZE + SB::SIZE) * sizeof(float);
-    static bool attr_set = false;        // > 64 KB of LDS needs the opt-in once per instantiation
-    if (!attr_set) {
+    static NemoAttrOnce attr_once;        // > 64 KB of LDS needs the opt-in once per instantiation
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, BK, TA, TB, VA, VB, NS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, TA, TB, VA, VB, NS>), dim3(blocks), dim3(256), lds, s, g);
     return hipSuccess;

@@ -336,24 +336,22 @@ __global__ __launch_bounds__(512, 1) void gemm_adj128_b16_kernel(Args g) {
     gemm_adj_body<1, 8>(g, smem);
 }
 inline hipError_t launch_adj128_b16(const Args& g, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NemoAttrOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_adj128_b16_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, adj_lds_bytes(8));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(gemm_adj128_b16_kernel, dim3(g.tiles_m * g.split), dim3(512), adj_lds_bytes(8), s, g);
     return hipSuccess;
 }
 // the 128-row form of kind 2: tiles_m = ceil(M / 128), one workgroup of 512 threads per CU
 inline hipError_t launch_adj128_f16x2(const Args& g, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NemoAttrOnce attr_once;
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_adj128_f16x2_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, adj_lds_bytes(8));
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(gemm_adj128_f16x2_kernel, dim3(g.tiles_m * g.split), dim3(512), adj_lds_bytes(8), s, g);
     return hipSuccess;
@@ -361,13 +359,12 @@ inline hipError_t launch_adj128_f16x2(const Args& g, hipStream_t s) {
 
 // kind: 0 fp32 operands, 1 bf16 in memory, 2 fp16 piece planes (split % nseg == 0)
 inline hipError_t launch_adj(const Args& g, hipStream_t s, int kind = 0) {
-    static bool attr_set[3] = {false, false, false};
+    static NemoAttrOnce attr_once[3];
     const void* fn = kind == 2 ? reinterpret_cast<const void*>(&gemm_adj_f16x2_kernel)
                    : kind == 1 ? reinterpret_cast<const void*>(&gemm_adj_b16_kernel) : reinterpret_cast<const void*>(&gemm_adj_kernel);
-    if (!attr_set[kind]) {
+    if (attr_once[kind].need()) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ADJ_LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set[kind] = true;
     }
     if (kind == 2) hipLaunchKernelGGL(gemm_adj_f16x2_kernel, dim3(g.tiles_m * g.split), dim3(256), ADJ_LDS_BYTES, s, g);
     else if (kind == 1) hipLaunchKernelGGL(gemm_adj_b16_kernel, dim3(g.tiles_m * g.split), dim3(256), ADJ_LDS_BYTES, s, g);

@@ -542,12 +542,11 @@ __global__ __launch_bounds__(64 * (8 + LW)) void gemm_b16x_kernel(Args g) {
 template <int BM, int BN, int WGM, int WGN, int NST, int LW, int BKT = 32>
 hipError_t launch(const Args& g, hipStream_t s) {
     using Q = Geo<BM, BN, WGM, WGN, NST, LW, BKT>;
-    static bool attr_set = false;
+    static NemoAttrOnce attr_once;
     auto kern = &gemm_b16x_kernel<BM, BN, WGM, WGN, NST, LW, BKT>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Q::LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const long blocks = (long)g.tiles_m * g.tiles_n * (g.split > 1 ? g.split : 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q::THREADS), Q::LDS, s, g);

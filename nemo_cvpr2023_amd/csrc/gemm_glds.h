@@ -585,13 +585,12 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_grouped_kernel(GroupArgs ga)
 template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, int BF16 = 0>
 hipError_t launch_grouped(const GroupArgs& ga, hipStream_t s) {
     constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(float);
-    static bool attr_set = false;
+    static NemoAttrOnce attr_once;
     auto kern = &gemm_glds_grouped_kernel<BM, BN, WM, WN, T, AKC, BKC, NST, SPREAD, BF16>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(ga.blk0[MAX_GROUP]), dim3(256), lds, s, ga);
     return hipSuccess;
@@ -600,13 +599,12 @@ hipError_t launch_grouped(const GroupArgs& ga, hipStream_t s) {
 template <int BM, int BN, int WM, int WN, int T, bool AKC, bool BKC, int NST, bool SPREAD = false, int BF16 = 0>
 hipError_t launch(const Args& g, int blocks, hipStream_t s) {
     constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(float);
-    static bool attr_set = false;
+    static NemoAttrOnce attr_once;
     auto kern = &gemm_glds_kernel<BM, BN, WM, WN, T, AKC, BKC, NST, SPREAD, BF16>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, g);
     return hipSuccess;

@@ -223,11 +223,10 @@ hipError_t launch(Args g, hipStream_t s) {
     constexpr int lds = W * NI * NJ * 16 * 64 * (int)sizeof(float);
     auto kern = &gemm_skinny_kernel<AKC, BKC, AV, BV, NI, NJ, W, D>;
     if (lds > 64 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static NemoAttrOnce attr_once;
+        if (attr_once.need()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return e;
-            attr_set = true;
         }
     }
     g.tiles_m = (int)((g.M + 32 * NI - 1) / (32 * NI));

@@ -600,12 +600,11 @@ __global__ __launch_bounds__(768) void gemm_xp_grouped_kernel(GroupArgs a) {
 template <int NP, int BN>
 hipError_t launch_grouped(const GroupArgs& a, int blocks, hipStream_t s) {
     using Q = Geo<NP, BN>;
-    static bool attr_set = false;
+    static NemoAttrOnce attr_once;
     auto kern = &gemm_xp_grouped_kernel<NP, BN>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Q::LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q::THREADS), Q::LDS, s, a);
     return hipSuccess;
@@ -614,12 +613,11 @@ hipError_t launch_grouped(const GroupArgs& a, int blocks, hipStream_t s) {
 template <int NP, int BN>
 hipError_t launch(const Args& g, hipStream_t s) {
     using Q = Geo<NP, BN>;
-    static bool attr_set = false;
+    static NemoAttrOnce attr_once;
     auto kern = &gemm_xp_kernel<NP, BN>;
-    if (!attr_set) {
+    if (attr_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Q::LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const long blocks = (long)g.tiles_m * g.tiles_n * (g.split > 1 ? g.split : 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(Q::THREADS), Q::LDS, s, g);

@@ -2448,11 +2448,10 @@ extern "C" int32_t nemo_fk_fwd(const nemo_ctx* ctx, int64_t rows, const float* R
                                float* PF, int64_t ldpf, void* stream) {
     if (!ctx || rows < 0 || !R || !A || !Jp || (PF && ldpf < 207)) return NEMO_EINVAL;
     if (rows == 0) return NEMO_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NemoAttrOnce attr_once;
+    if (attr_once.need()) {
         HIPCHK(hipFuncSetAttribute((const void*)fk_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    FK_LDS_BYTES));
-        attr_set = true;
     }
     hipLaunchKernelGGL(fk_fwd_kernel, dim3(nemo_cdiv(rows, FK_TB)), dim3(256), FK_LDS_BYTES,
                        (hipStream_t)stream, (long)rows, R, ctx->d_Jrest, ctx->kc, A, Jp, PF, (long)ldpf);
@@ -2465,11 +2464,10 @@ extern "C" int32_t nemo_fk_bwd(const nemo_ctx* ctx, int64_t rows, const float* R
                                void* stream) {
     if (!ctx || rows < 0 || !R || !A || !dA || !dR || (dPF && lddpf < 207)) return NEMO_EINVAL;
     if (rows == 0) return NEMO_OK;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static NemoAttrOnce attr_once;
+    if (attr_once.need()) {
         HIPCHK(hipFuncSetAttribute((const void*)fk_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    FK_LDS_BYTES));
-        attr_set = true;
     }
     hipLaunchKernelGGL(fk_bwd_kernel, dim3(nemo_cdiv(rows, FK_TB)), dim3(256), FK_LDS_BYTES,
                        (hipStream_t)stream, (long)rows, R, A, ctx->d_Jrest, ctx->kc, dA, dJp, dPF, (long)lddpf, dR);
@@ -2762,8 +2760,8 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
         : ((mode == 4 ? 3 * 2 * 16 * MF_PFB / 2 : mode == 5 ? 2 * 2 * 16 * MF_PFB / 2 : bf16 ? 2 * 16 * MF_PFB / 2 : 2 * 16 * MF_PFS) +
            2 * 16 * (sparse ? MF_ASP : MF_AS) + MF_TAIL) *
               (int)sizeof(float);
-    static bool attr_set[7][2] = {{false, false}, {false, false}, {false, false}, {false, false}, {false, false}, {false, false}, {false, false}};
-    if (!attr_set[mode][sparse]) {
+    static NemoAttrOnce attr_once[7][2];
+    if (attr_once[mode][sparse].need()) {
         const void* fn = mode == 6 ? (const void*)mesh_v2v_fused_kernel<6, false>
                        : mode == 5 ? (sparse ? (const void*)mesh_v2v_fused_kernel<5, true> : (const void*)mesh_v2v_fused_kernel<5, false>)
                        : mode == 4 ? (sparse ? (const void*)mesh_v2v_fused_kernel<4, true> : (const void*)mesh_v2v_fused_kernel<4, false>)
@@ -2771,7 +2769,6 @@ static int32_t v2v_fused_impl(const nemo_ctx* ctx, int kind, int64_t N, const fl
                        : mode == 3 ? (sparse ? (const void*)mesh_v2v_fused_kernel<3, true> : (const void*)mesh_v2v_fused_kernel<3, false>)
                                    : (sparse ? (const void*)mesh_v2v_fused_kernel<0, true> : (const void*)mesh_v2v_fused_kernel<0, false>);
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_set[mode][sparse] = true;
     }
     const int vec_stage = (ldpf % 4 == 0) && (((uintptr_t)PF2 | (uintptr_t)A2) & 15) == 0 && ldpf >= 208;
     const long groups = (N + 15) / 16, ntiles = (ctx->NV + 15) / 16;
