@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NEMO_ABI_VERSION 17
+#define NEMO_ABI_VERSION 18
 int32_t nemo_abi_version(void);
 
 /* Deterministic accumulation (round 5; caller-owned since ABI 17).  Every sum over the blocks of a launch that used float atomics
@@ -607,8 +607,13 @@ int32_t nemo_phase_embed_fwd_begin(int64_t N, int64_t V, int64_t T, int64_t K, i
                                    const float* shifts, const float* scales, int64_t ldp, const float* log_sigmas,
                                    const float* codes, const float* code_noise, int32_t kernel_id, float* X, int64_t ldx,
                                    float* phase_out, float* den_out, float* x_meta, void* z0, int64_t bytes0, void* z1,
-                                   int64_t bytes1, nemo_adam_seg* segs_dev, int32_t n_seg, double beta1, double beta2, void* stream);
-/* (x_meta must lie OUTSIDE the two zero-filled ranges: their blocks run beside the phase blocks) */
+                                   int64_t bytes1, nemo_adam_seg* segs_dev, int32_t n_seg, double beta1, double beta2,
+                                   int32_t n_absmax, const nemo_absmax_desc* absmax, void* stream);
+/* (x_meta must lie OUTSIDE the two zero-filled ranges: their blocks run beside the phase blocks)
+ * ABI 18: n_absmax (0 ... NEMO_CAST_XP_MAX) / absmax = a nemo_absmax_multi list that runs in the LEADING blocks of the same launch --
+ * the pass over the split-precision chain's weights, which every update step needs in front of its cast launch (the weights changed):
+ * beside the phase kernel on a second stream it cost a fork and a cross-queue join per step.  The records must lie outside the
+ * zero-filled ranges too; nothing the other blocks write may be among the sources. */
 
 /* Instance-code regulariser of NemoV3 / V4 (nemo/neural_motion_model.py:3864-3867):
  * scalar_out += mean(x[0..n)^2);  grad (may be NULL) += gscale * x. */

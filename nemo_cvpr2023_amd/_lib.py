@@ -46,7 +46,7 @@ class AdamSeg(Structure):
 
 i32, i64, f32, ptr = c_int32, c_int64, c_float, c_void_p
 
-ABI_VERSION = 17        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
+ABI_VERSION = 18        # NEMO_ABI_VERSION of include/nemo_hip.h this binding was written against
 
 # name -> (restype, argtypes).  Mirrors include/nemo_hip.h one to one (tests check the symbol list).
 SIGNATURES = {
@@ -147,7 +147,7 @@ SIGNATURES = {
     'nemo_sqmean_fwd_bwd': (i32, [i64, ptr, ptr, ptr, f32, ptr]),
     'nemo_step_begin': (i32, [ptr, i64, ptr, i64, ptr, i32, c_double, c_double, ptr]),
     'nemo_phase_embed_fwd_begin': (i32, [i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr,
-                                         i32, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i32, c_double, c_double, ptr]),
+                                         i32, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, i32, c_double, c_double, i32, ptr, ptr]),
     'nemo_scale_neg_rowsum': (i32, [i64, i64, ptr, i64, ptr, ptr]),
 }
 

@@ -1121,21 +1121,11 @@ extern "C" int32_t nemo_cast_xp(int32_t fmt, int32_t n, const nemo_cast_xp_desc*
 }
 
 extern "C" int32_t nemo_absmax_multi(int32_t n, const nemo_absmax_desc* descs, void* stream) {
-    if (n < 0 || n > xp::MAX_CAST || (n && !descs)) return NEMO_EINVAL;
-    xp::AbsmaxArgs a{};
-    int blocks = 0, m = 0;
-    for (int i = 0; i < n; ++i) {
-        const nemo_absmax_desc& q = descs[i];
-        if (q.rows < 0 || q.cols < 0 || !q.meta || q.lds < q.cols || ((q.rows && q.cols) && !q.src)) return NEMO_EINVAL;
-        if ((q.rows == 0 || q.cols == 0) && !q.overwrite) continue;
-        xp::AbsmaxDesc& d = a.d[m++];
-        d.src = q.src; d.rows = q.rows; d.cols = q.cols; d.lds = q.lds; d.meta = q.meta; d.block0 = blocks;
-        d.overwrite = q.overwrite ? 1 : 0;
-        long nb = (q.rows * q.cols + 4095) / 4096;          // ~16 elements per thread
-        blocks += q.overwrite ? xp::META_SLOTS : (int)(nb < 1 ? 1 : (nb > 256 ? 256 : nb));
-    }
-    a.n = m;
-    if (m == 0) return NEMO_OK;
+    xp::AbsmaxArgs a;
+    int blocks = 0;
+    const int rc = xp::absmax_fill(a, n, descs, blocks);
+    if (rc) return rc;
+    if (a.n == 0) return NEMO_OK;
     hipLaunchKernelGGL(xp::absmax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;

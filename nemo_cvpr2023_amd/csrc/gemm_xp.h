@@ -37,6 +37,7 @@
 #include <type_traits>
 #include "common.h"
 #include "gemm_glds.h"
+#include "absmax.h"
 
 namespace xp {
 
@@ -665,7 +666,6 @@ struct CastDesc {
     float* meta;                                            // fmt 2, may be NULL: scale record, absmax in, scale = 2^floor(log2(2^15 / absmax)) out
     int tile0, tiles_c;                                     // first block of this matrix in the launch, 32-column tiles per row of tiles
 };
-constexpr int MAX_CAST = 8;
 struct CastArgs { CastDesc d[MAX_CAST]; int n; };
 
 template <int NP>
@@ -713,68 +713,6 @@ __global__ __launch_bounds__(256) void cast_xp_kernel(CastArgs a) {
     }
 }
 
-// absmax slots of `meta` = max(themselves, max |src|) for a list of matrices (grid-stride over each; slots zero or previous maxima)
-struct AbsmaxDesc { const float* src; long rows, cols, lds; float* meta; int block0; int overwrite; };
-struct AbsmaxArgs { AbsmaxDesc d[MAX_CAST]; int n; };
-
-__global__ __launch_bounds__(256) void absmax_kernel(AbsmaxArgs a) {
-    int di = 0;
-#pragma unroll
-    for (int i = 1; i < MAX_CAST; ++i)
-        if (i < a.n && (int)blockIdx.x >= a.d[i].block0) di = i;
-    const AbsmaxDesc& d = a.d[di];
-    const int nb = (di + 1 < a.n ? a.d[di + 1].block0 : (int)gridDim.x) - d.block0;
-    // block b of the matrix's nb takes rows [b R / nb, (b + 1) R / nb): coalesced row segments, no index division per element
-    // (the first form -- a flat grid-stride loop with e / cols, e % cols per element -- took 53 us for the chain's weights)
-    const long b = (long)blockIdx.x - d.block0;
-    const long r0 = b * d.rows / nb, r1 = (b + 1) * d.rows / nb;
-    float mx = 0.f;
-    // eight rows' loads in flight per thread (one load per round trip took 48 us for the chain's weights: 124 dependent trips)
-    const float* src = d.src;
-    const long lds = d.lds, cols = d.cols;
-    if ((lds & 3) == 0 && (cols & 3) == 0 && (reinterpret_cast<unsigned long long>(src) & 15) == 0) {
-        const long c4n = cols >> 2;
-        for (long c4 = threadIdx.x; c4 < c4n; c4 += 256)
-            for (long r = r0; r < r1; r += 8) {
-                float4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    v[u] = r + u < r1 ? *reinterpret_cast<const float4*>(src + (r + u) * lds + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
-            }
-    } else {
-        // unaligned / narrow rows (nn.Linear(105, h), the head gradient): the block's rows as one flat range of (row, 64-column group)
-        const long cg = (cols + 63) >> 6;
-        for (long r = r0; r < r1; r += 32) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long rr = r + 4 * u + (threadIdx.x >> 6);
-                float acc = 0.f;
-                if (rr < r1)
-                    for (long g2 = 0; g2 < cg; ++g2) {
-                        const long c = (g2 << 6) + (threadIdx.x & 63);
-                        if (c < cols) acc = fmaxf(acc, fabsf(src[rr * lds + c]));
-                    }
-                v[u] = acc;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) mx = fmaxf(mx, v[u]);
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    // (NaN: fmaxf drops it -- a NaN operand reaches the result through the pieces themselves)
-    __shared__ float wmx[4];
-    if ((threadIdx.x & 63) == 0) wmx[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float bm = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
-        // overwrite: this matrix has exactly META_SLOTS blocks and block b OWNS slot b -- plain stores, nothing to zero beforehand
-        if (d.overwrite) d.meta[2 + ((int)blockIdx.x - d.block0)] = bm;
-        else meta_absmax_put(d.meta, (int)blockIdx.x, bm);
-    }
-}
+__global__ __launch_bounds__(256) void absmax_kernel(AbsmaxArgs a) { absmax_block(a, (int)blockIdx.x, (int)gridDim.x); }
 
 }  // namespace xp

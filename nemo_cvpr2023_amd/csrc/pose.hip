@@ -6,6 +6,7 @@
 #include <type_traits>
 #include "common.h"
 #include "rot_math.h"
+#include "absmax.h"
 #include "../../include/nemo_hip.h"
 
 extern "C" int32_t nemo_abi_version(void) { return NEMO_ABI_VERSION; }
@@ -150,13 +151,21 @@ struct StepBeginArgs {
     float4* z0; long n0; float4* z1; long n1; float* t0; int r0; float* t1; int r1;
     nemo_adam_seg* segs; int n_seg; double b1, b2;
 };
-__global__ __launch_bounds__(256) void phase_embed_begin_kernel(PhaseFwdArgs a, StepBeginArgs b, int nb_phase) {
-    if ((int)blockIdx.x < nb_phase) {              // (block-uniform)
-        const float mx = phase_embed_fwd_body(a, (long)blockIdx.x);
+// (round 6, last part) ... and the absmax pass over the split-precision chain's weights (nemo_absmax_multi's blocks): the LEADING nb_abs
+// blocks of the grid -- the longest ones, dispatched first.  Beside the phase kernel on a second stream that pass cost a fork and a
+// cross-queue join at the top of every update step (~38 us from the end of Adam to the chain's cast launch; ~20 in one launch).
+__global__ __launch_bounds__(256) void phase_embed_begin_kernel(PhaseFwdArgs a, StepBeginArgs b, int nb_phase, int nb_abs, xp::AbsmaxArgs am) {
+    if ((int)blockIdx.x < nb_abs) {                // (block-uniform)
+        xp::absmax_block(am, (int)blockIdx.x, nb_abs);
+        return;
+    }
+    const int bid = (int)blockIdx.x - nb_abs;
+    if (bid < nb_phase) {
+        const float mx = phase_embed_fwd_body(a, (long)bid);
         if (a.x_meta) phase_embed_put_absmax(a.x_meta, mx);
         return;
     }
-    const long nbz = (long)gridDim.x - nb_phase, bz = (long)blockIdx.x - nb_phase;
+    const long nbz = (long)gridDim.x - nb_abs - nb_phase, bz = (long)bid - nb_phase;
     const long stride = nbz * blockDim.x, i0 = bz * blockDim.x + threadIdx.x;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long i = i0; i < b.n0; i += stride) b.z0[i] = z;
@@ -466,8 +475,16 @@ extern "C" int32_t nemo_phase_embed_fwd_begin(int64_t N, int64_t V, int64_t T, i
                                               const float* log_sigmas, const float* codes, const float* code_noise,
                                               int32_t kernel_id, float* X, int64_t ldx, float* phase_out, float* den_out,
                                               float* x_meta, void* z0, int64_t bytes0, void* z1, int64_t bytes1, nemo_adam_seg* segs_dev,
-                                              int32_t n_seg, double beta1, double beta2, void* stream) {
+                                              int32_t n_seg, double beta1, double beta2, int32_t n_absmax,
+                                              const nemo_absmax_desc* absmax, void* stream) {
     PhaseFwdArgs a;
+    xp::AbsmaxArgs am;
+    int nb_abs = 0;
+    if (xp::absmax_fill(am, n_absmax, absmax, nb_abs)) return NEMO_EINVAL;
+    for (int i = 0; i < am.n; ++i) {               // (the records must lie outside the zero-filled ranges, as x_meta)
+        const char* m = (const char*)am.d[i].meta;
+        if ((m >= (char*)z0 && m < (char*)z0 + bytes0) || (m >= (char*)z1 && m < (char*)z1 + bytes1)) return NEMO_EINVAL;
+    }
     const int32_t rc = phase_fwd_args(&a, N, V, T, K, D, C, view_idx, frame_idx, raw_phase, shifts, scales, ldp, log_sigmas,
                                       codes, code_noise, kernel_id, X, ldx, phase_out, den_out, x_meta);
     if (rc) return rc;
@@ -485,7 +502,7 @@ extern "C" int32_t nemo_phase_embed_fwd_begin(int64_t N, int64_t V, int64_t T, i
     const int nbp = (int)nemo_cdiv(N + 1, 4);
     StepBeginArgs b{(float4*)z0, n0, (float4*)z1, n1, (float*)z0 + 4 * n0, (int)((bytes0 & 15) / 4), (float*)z1 + 4 * n1,
                     (int)((bytes1 & 15) / 4), n_seg ? segs_dev : nullptr, (int)n_seg, beta1, beta2};
-    hipLaunchKernelGGL(phase_embed_begin_kernel, dim3(nbp + bz), dim3(256), 0, (hipStream_t)stream, a, b, nbp);
+    hipLaunchKernelGGL(phase_embed_begin_kernel, dim3(nb_abs + nbp + bz), dim3(256), 0, (hipStream_t)stream, a, b, nbp, nb_abs, am);
     NEMO_LAUNCH_CHECK();
     return NEMO_OK;
 }

@@ -901,10 +901,15 @@ class FitEngine:
     def absmax_xp(self, items, overwrite=False):
         """items: (src_ptr, rows, cols, lds, meta pointer) -- max |src| into their scale records, one launch (fmt 2); ``overwrite``:
         the records' slots are stored, not accumulated into (they need no zeroing)."""
+        am = self._absmax_descs(items, overwrite)
+        check(self.lib.nemo_absmax_multi(len(items), am, _stream()), 'nemo_absmax_multi')
+
+    @staticmethod
+    def _absmax_descs(items, overwrite):
         am = (_lib.AbsmaxDesc * len(items))()
         for i, (src, rows, cols, lds, meta) in enumerate(items):
             am[i].src, am[i].rows, am[i].cols, am[i].lds, am[i].meta, am[i].overwrite = src, rows, cols, lds, meta, int(overwrite)
-        check(self.lib.nemo_absmax_multi(len(items), am, _stream()), 'nemo_absmax_multi')
+        return am
 
     def cast_xp(self, items):
         """items: (src_ptr, rows, cols, lds, dst or None, dstT or None, meta pointer or None) -- their xp copies in ONE launch
@@ -977,10 +982,14 @@ class FitEngine:
         """fmt 2: the absmax records of the weights and of the three hidden-layer biases (which enter the bounds the hidden copies
         are scaled by) in one launch"""
         lm, h = 'learned_motion.', self.h
+        self.absmax_xp(self._weights_absmax_items(w, items), overwrite=True)
+
+    def _weights_absmax_items(self, w, items):
+        lm, h = 'learned_motion.', self.h
         am = [(src, rows, cols, lds, meta) for src, rows, cols, lds, _, _, meta in items]
         am += [(self.p(lm + nm), 1, h, h, self._xm(w, key)) for nm, key in (('net.net.0.bias', 'b0'), ('net.net.2.bias', 'b2'),
                                                                                    ('net.net.4.bias', 'b4'))]
-        self.absmax_xp(am, overwrite=True)
+        return am
 
     def _forward_nets_xp(self, w, N, train, am_done=None):
         """forward_pose's MLP on the split-precision chain: every layer reads the previous layer's xp copy and leaves its own (plain
@@ -1177,23 +1186,29 @@ class FitEngine:
                  dptr(w['X']), self.ldx, dptr(w['phase']), dptr(w['phase_ws']),
                  # (fmt 2 of the split-precision chain: the phase kernel leaves max |X| in X's scale record)
                  w['xmeta_x'].data_ptr() if (self.version >= 1 and self._use_xp(w) and self.xp_fmt == 2) else None)
-        am_done = None
+        am_done, am_n, am_descs = None, 0, None
         if self.version >= 1 and self._use_xp(w) and self.xp_fmt == 2 and not self.wrec_ok():
             # the weights' / biases' absmax records do not describe the current weights (first pass, an update whose launch did not
-            # refresh them, a checkpoint load): the pass over the weights on the side stream, beside the phase kernel (14 us there,
-            # and the phase kernel 25 instead of 10).  The step's own update leaves them fresh (refresh_weight_records, behind Adam).
-            main, side = torch.cuda.current_stream(), self.side_stream
-            side.wait_event(main.record_event())
-            with torch.cuda.stream(side):
-                self._weights_absmax(w, self._weight_items(w, bool(train)))
-                am_done = side.record_event()
+            # refresh them, a checkpoint load): the pass over the weights runs in the leading blocks of the step's first launch
+            # (nemo_phase_embed_fwd_begin, ABI 18) -- or, for a pass without that launch (evaluation) or with NEMO_ABSMAX_ASIDE=1 (the
+            # form before: A/B aid), on the side stream beside the phase kernel (14 us there, the phase kernel 25 instead of 10, and
+            # a fork + cross-queue join in front of the chain's cast launch).
+            am_items = self._weights_absmax_items(w, self._weight_items(w, bool(train)))
+            if begin is not None and os.environ.get('NEMO_ABSMAX_ASIDE') != '1':
+                am_n, am_descs = len(am_items), self._absmax_descs(am_items, True)
+            else:
+                main, side = torch.cuda.current_stream(), self.side_stream
+                side.wait_event(main.record_event())
+                with torch.cuda.stream(side):
+                    self.absmax_xp(am_items, overwrite=True)
+                    am_done = side.record_event()
             self._wrec_ok, self._wrec_version = True, self.params._version
         if begin is not None:
             arena, zero_grads, n_seg = begin
             check(L.nemo_phase_embed_fwd_begin(*pargs, arena.data_ptr(), arena.numel() * 4,
                                                self.grads.data_ptr() if zero_grads else None,
                                                self.grads.numel() * 4 if zero_grads else 0,
-                                               self._seg_dev.data_ptr() if n_seg else None, n_seg, 0.9, 0.999, st),
+                                               self._seg_dev.data_ptr() if n_seg else None, n_seg, 0.9, 0.999, am_n, am_descs, st),
                   'nemo_phase_embed_fwd_begin')
         else:
             check(L.nemo_phase_embed_fwd(*pargs, st), 'nemo_phase_embed_fwd')
@@ -1509,6 +1524,8 @@ class FitEngine:
                 FOCAL_LENGTH, self.cx, self.cy, lt, mean_mode, fused_counts, upstream, dptr(w['j3d']), dptr(w['p2d']),
                 dptr(w['loss_all']), dptr(w['view_acc']), dptr(w['dA']), dptr(w['dJp']), dptr(w['dMq']), dptr(w['dTR']),
                 HEAD_LD, self.g('learned_cameras'), self.nvalid, st), 'nemo_kp_fwd_bwd')
+            # the per-view accumulators are complete here: finalize_kp (on another stream) need not wait for the rest of this chain
+            self.kp_acc_done = torch.cuda.current_stream().record_event()
         else:
             check(L.nemo_kp_bwd_ex(
                 ctx.handle, N, self.V, self.T, dptr(w['A']), dptr(w['Jp']), dptr(Mq), nq72, dptr(w['TR']),

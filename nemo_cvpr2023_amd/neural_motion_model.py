@@ -579,7 +579,10 @@ class MultiViewModel(nn.Module):
             Mq = e.joint_functionals(w, N)
             e.backward_kp(w, N, vi, fi, Mq, mean_mode=0, upstream=float(sh.kr), detach_pose=detach_pose,
                           fused_counts=e.view_cnt)
-            kp_done = main.record_event()
+            # the loss scalar's kernel (side2, below) only needs the view accumulators -- complete behind the fused launch -- not the
+            # joint-functional adjoint and the FK backward behind it: waiting for those put a 3 us kernel and two cross-queue hops
+            # between the end of the longest branch and the mesh kernel
+            kp_done = e.kp_acc_done if os.environ.get('NEMO_KP_FIN_LATE') != '1' else main.record_event()
         else:
             Mq = e.forward_joints(w, N, vi, fi, with_loss=True, mean_mode=0, finalize=False)
             kp_done = main.record_event()        # (view accumulators complete: the loss scalar is finalised on side2, below)

@@ -342,8 +342,33 @@ def test_phase_embed_vs_oracle(L, kern):
     assert L.nemo_phase_embed_fwd_begin(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
                                         pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), dco.data_ptr(), None, kid,
                                         Xd2.data_ptr(), D + C, phd2.data_ptr(), den2.data_ptr(), None, z0.data_ptr(), 1003 * 4,
-                                        z1.data_ptr(), 77 * 4, seg_dev.data_ptr(), 2, 0.9, 0.999, H.st()) == 0
+                                        z1.data_ptr(), 77 * 4, seg_dev.data_ptr(), 2, 0.9, 0.999, 0, None, H.st()) == 0
     assert torch.equal(Xd2, Xd) and torch.equal(phd2, phd) and torch.equal(den2, den)
+    # ... and (ABI 18) with an absmax list in the launch's leading blocks: the records equal nemo_absmax_multi's, everything else as above
+    from nemo_cvpr2023_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    mats = [H.dev(torch.randn(1000, 1000, generator=g) * 3.0), H.dev(torch.randn(147, 1000, generator=g)),
+            H.dev(torch.randn(1000, 105, generator=g) * 1e-3), H.dev(torch.randn(1, 1000, generator=g))]
+    want = H.absmax_meta(*mats)
+    for overwrite in (1, 0):
+        got = torch.full((len(mats), 64), 5.0 if overwrite else 0.0, device='cuda')      # (overwrite: stale slots are replaced)
+        d = (_lib.AbsmaxDesc * len(mats))()
+        for i, x in enumerate(mats):
+            d[i].src, d[i].rows, d[i].cols, d[i].lds, d[i].meta, d[i].overwrite = x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), got[i].data_ptr(), overwrite
+        Xd3, z0 = torch.full_like(Xd, 7.0), torch.ones(1003, device='cuda')
+        assert L.nemo_phase_embed_fwd_begin(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
+                                            pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), dco.data_ptr(), None, kid,
+                                            Xd3.data_ptr(), D + C, phd2.data_ptr(), den2.data_ptr(), None, z0.data_ptr(), 1003 * 4,
+                                            None, 0, None, 0, 0.9, 0.999, len(mats), d, H.st()) == 0
+        assert torch.equal(Xd3, Xd) and float(z0.abs().sum()) == 0.0
+        for i, x in enumerate(mats):
+            assert H.meta_amax(got[i]) == float(x.abs().max()) == H.meta_amax(want[i])
+    # a record inside a zero-filled range is refused (its blocks run beside the zero-fill's)
+    d[0].meta = z0.data_ptr() + 64
+    assert L.nemo_phase_embed_fwd_begin(N, V, T, K, D, C, dvi.data_ptr(), dfi.data_ptr(), None, pn.data_ptr(),
+                                        pn.data_ptr() + 4 * K, 2 * K, dls.data_ptr(), dco.data_ptr(), None, kid,
+                                        Xd3.data_ptr(), D + C, phd2.data_ptr(), den2.data_ptr(), None, z0.data_ptr(), 1003 * 4,
+                                        None, 0, None, 0, 0.9, 0.999, len(mats), d, H.st()) != 0
     assert float(z0.abs().sum()) == 0.0 and float(z1.abs().sum()) == 0.0
     back = (AdamSeg * 2).from_buffer_copy(bytes(seg_dev.cpu().numpy().tobytes()))
     for i, (lr, st_) in enumerate(((1e-3, 4), (5e-2, 0))):

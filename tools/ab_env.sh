@@ -1,14 +1,10 @@
 #!/bin/bash
-# A/B of environment switches on one box:  bash tools/ab_env.sh "<bench args>" "VAR=a" "VAR=b" ...   (each variant 3 runs)
-set -u
-ARGS=$1; shift
-for rep in 1 2 3; do
-  for v in "$@"; do
-    if [ "$v" = "-" ]; then
-      r=$(python3 bench.py $ARGS --no-cpu-baseline --no-torch-gpu-baseline 2>/dev/null | tail -1)
-    else
-      r=$(env $v python3 bench.py $ARGS --no-cpu-baseline --no-torch-gpu-baseline 2>/dev/null | tail -1)
-    fi
-    echo "$v rep$rep ms_per_step=$(echo "$r" | python3 -c 'import sys,json; print(json.loads(sys.stdin.read())["ms_per_step"])')"
-  done
+# same-box A/B of one environment switch at 8 x 300, alternating:  gpurun -- 'bash tools/ab_env.sh NEMO_KP_FIN_LATE 1 [rounds] [bench args]'
+# prints ms per step with the variable unset / set, `rounds` times each (default 3)
+VAR=$1; VAL=$2; R=${3:-3}; shift 3 || shift $#
+B="--no-cpu-baseline --no-torch-gpu-baseline --no-extra-legs --minibatch-steps 0 --repeat 3 --steps 200 --warmup 20"
+run() { python3 bench.py $B "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%8.4f ms' % d['ms_per_step'])"; }
+for i in $(seq $R); do
+  echo -n "unset      "; run "$@"
+  echo -n "$VAR=$VAL  "; env $VAR=$VAL python3 bench.py $B "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%8.4f ms' % d['ms_per_step'])"
 done
