@@ -140,7 +140,8 @@ int32_t nemo_cast_bf16_split3(int64_t rows, int64_t cols, const float* src, int6
  * 32 NP ceil(K / 32), ld % 8 == 0, base 16-byte aligned, and elements k in [K, 32 ceil(K / 32)) of every row are ZERO.
  * nemo_gemm_xp: C (M x N, fp32, may be NULL) (op)= v, v = maskfn(act(alpha * A B^T + bias)), keeping the piece products of weight
  * >= 2^-24 (fmt 3: six, fmt 2: three; each exact in fp32, fp32 accumulation): error against float64 <= that of nemo_gemm_f32.
- * mask_mode 1: v = x0(maskx[m][n]) > 0 ? v : 0 with maskx an xp matrix (M x N) -- the copy of the ReLU output.  Cx / CxT (may be
+ * mask_mode 1: v = x0(maskx[m][n]) > 0 ? v : 0 with maskx an xp matrix (M x N) -- the copy of the ReLU output; 2 (ABI 18): ... : 0.01 v,
+ * LeakyReLU' of the copy of a LeakyReLU output (VPoser's encoder, vposer_model.py:69-76, under the KL term's autograd).  Cx / CxT (may be
  * NULL): v * out_scale and its transpose written as xp matrices (M x N, ld ldcx / N x M, ld ldcxt) -- the operands of the next
  * products of the chain; colsum as nemo_gemm_bf16mem.  ws as nemo_gemm_f32.
  * nemo_cast_xp: up to NEMO_CAST_XP_MAX fp32 matrices (rows x cols, row stride lds) -> their xp copies dst (rows x cols) and / or

@@ -1013,7 +1013,7 @@ extern "C" int32_t nemo_gemm_xp(int32_t fmt, int64_t M, int64_t N, int64_t K, co
     if ((fmt != 2 && fmt != 3) || M < 0 || N < 0 || K < 0 || !A || !B) return NEMO_EINVAL;
     if (!C && !Cx && !CxT) return NEMO_EINVAL;
     if ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)Cx) | ((uintptr_t)CxT) | ((uintptr_t)maskx)) & 15) return NEMO_EINVAL;
-    if (out_mode < 0 || out_mode > 1 || (mask_mode != 0 && mask_mode != 1) || (mask_mode && !maskx)) return NEMO_EINVAL;
+    if (out_mode < 0 || out_mode > 1 || mask_mode < 0 || mask_mode > 2 || (mask_mode && !maskx)) return NEMO_EINVAL;
     if ((Cx && (ldcx & 7)) || (CxT && (ldcxt & 7)) || (mask_mode && (ldmask & 7)) || (C && ldc < N) || (colsum && ldcs < N)) return NEMO_EINVAL;
     if (M == 0 || N == 0) return NEMO_OK;
     if (K == 0) return NEMO_EINVAL;

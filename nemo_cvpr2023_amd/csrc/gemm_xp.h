@@ -57,7 +57,7 @@ struct Args {
     long lda, ldb;                                          // 16-bit elements; multiples of 8, >= 32 NP ceil(K / 32)
     float* C; long ldc; int out_mode;                       // C may be NULL; 0 store, 1 +=
     const float* bias; int act; float alpha;                // act 0 / 1 ReLU / 2 LeakyReLU(0.01)
-    const unsigned short* maskx; long ldmask; int mask_mode;      // 0 none, 1: v = piece0(mask[m][n]) > 0 ? v : 0
+    const unsigned short* maskx; long ldmask; int mask_mode;      // 0 none, 1: v = piece0(mask[m][n]) > 0 ? v : 0, 2: ... : 0.01 v
     unsigned short* Cx; long ldcx;                          // >= 32 NP ceil(N / 32)
     unsigned short* CxT; long ldcxt;                        // >= 32 NP ceil(M / 32)
     float out_scale;                                        // pieces of v * out_scale (1 for bf16 pieces; fmt 2 without metaOut)
@@ -403,6 +403,7 @@ __device__ __forceinline__ void gemm_xp_body(const Args& g, const int bid, const
         // piece 0 of the wave's WM x 32 mask block j: 64 B per row -> LDS image [m][64 B + 16]; OOB rows read as zero = masked out
         const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g.maskx), 0, (int)g.mask_bytes, 0x00020000);
         constexpr int MROW = 80;
+        const float mslope = g.mask_mode == 2 ? 0.01f : 0.f;   // 2: LeakyReLU'(0.01) of the masked activation (VPoser's encoder)
         const int row0 = lane >> 2, ch = lane & 3;          // 16 rows per load
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -422,7 +423,7 @@ __device__ __forceinline__ void gemm_xp_body(const Args& g, const int bid, const
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const short mb = *reinterpret_cast<const short*>(ws + (rowc(i, r) + 4 * lh) * MROW + l31 * 2);
-                    av[i][j][r] = mb > 0 ? av[i][j][r] : 0.f;             // bf16 / fp16 > 0  <=>  its bits, as int16, > 0
+                    av[i][j][r] = mb > 0 ? av[i][j][r] : av[i][j][r] * mslope;   // bf16 / fp16 > 0  <=>  its bits, as int16, > 0
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }

@@ -451,7 +451,14 @@ class FitEngine:
     XP_MIN_ROWS = int(os.environ.get('NEMO_XP_MIN_ROWS', '1600'))    # mlp_gemm 'f32_split': the chain on nemo_gemm_xp from this many rows on
     XP_DW_ASIDE_ROWS = 65536  # ... its parameter-gradient products on the side stream up to this many rows
     XP_GROUPED_DW_ROWS = int(os.environ.get('NEMO_XP_GROUPED_DW_ROWS', '8192'))   # ... as ONE grouped launch up to this many rows
-    XMETA = ('X', 'H1', 'H2', 'H3', 'dHEAD', 'dH', 'dH_b', 'dH_c', 'W0', 'W2', 'W4', 'Whead', 'b0', 'b2', 'b4')
+    # ... and the frozen VPoser's products (encode, decode, the KL term's adjoint) from this many rows on.  OFF by default (measured, same
+    # box, xp from 8192 rows / fp32: 40 x 300 3.39 - 3.45 / 3.38 - 3.40 ms, C4 68.4 - 69.7 / 68.6 - 68.7 ms): the fp32 launches are 15 of
+    # C4's 87 ms of kernel time but run BESIDE the key-point and prior branches, and a nemo_gemm_xp launch takes whole CUs (160 KB of
+    # LDS) -- what its 3x shorter launches save, the branches beside them lose.  NEMO_VP_XP_MIN_ROWS=<rows> switches it on.
+    VP_XP_MIN_ROWS = int(os.environ.get('NEMO_VP_XP_MIN_ROWS', str(1 << 62)))
+    XMETA = ('X', 'H1', 'H2', 'H3', 'dHEAD', 'dH', 'dH_b', 'dH_c', 'W0', 'W2', 'W4', 'Whead', 'b0', 'b2', 'b4',
+             'vAA', 'vE1', 'vD1', 'vD2', 'vdM', 'vdE')
+    VPMETA = ('e2w', 'd0mw', 'd3w', 'd5w', 'emw', 'e2b', 'd0mb', 'd3b')
     # (fp32 backward_mlp: the bias gradients come from the dX launches' per-band column sums at EVERY size -- headline 1.257 / 1.259 ms
     #  without / with, C4 101.8 / 101.5 ms: the win is C4's 6.6 GB of reads; a row threshold was never applied and is gone)
     MAX_WORKSPACES = 24      # distinct batch sizes kept alive (a rank of a sharded minibatch run sees many)
@@ -543,6 +550,11 @@ class FitEngine:
             w['xmeta_x'] = torch.zeros(64, dtype=torch.float32, device=self.device)
             for k in ('H1', 'H2', 'H3', 'dH', 'dH_b', 'dH_c'):
                 w[k + 'x'], w[k + 'xT'] = Zx(N + 1, h), Zx(h, N + 1)
+            if N >= self.VP_XP_MIN_ROWS and self.version >= 1:
+                # ... and of the VPoser chain's operands (forward_vposer / vposer_mulv / backward_vposer_kl); the frozen weights' copies
+                # and records are made here, once, outside any capture
+                w.update(AAx=Zx(N, 63), E1x=Zx(N, 512), D1x=Zx(N, 512), D2x=Zx(N, 512), dMULVx=Zx(N, 64), dE_ax=Zx(N, 512))
+                self._vposer_xp_weights()
         # per-band column sums of the three activation gradients of the MotionNet backward (the epilogues of their launches:
         # nemo_gemm_bf16mem(colsum) / nemo_gemm_f32_colsum): the bias gradients of layers 4, 2, 0 from 2 ceil(r / 64) short rows
         R = int(self.lib.nemo_gemm_colsum_rows(N + 1))
@@ -881,8 +893,41 @@ class FitEngine:
     def _use_xp(self, w):
         return self.mlp_split and 'Xx' in w
 
+    def _use_xp_vp(self, w):
+        return self.mlp_split and 'AAx' in w
+
+    def _vposer_xp_weights(self):
+        """xp copies of the frozen (BatchNorm-folded, fold_vposer) VPoser weights: plain [out][in] for the forward products, transposed
+        [in][out] for the two products of the KL term's adjoint; fmt 2: their scale records (and the biases') -- all static."""
+        if hasattr(self, '_vpx'):
+            return
+        vp = self.vp
+        i16 = dict(dtype=torch.int16, device=self.device)
+        xl = lambda k: int(self.lib.nemo_xp_ld(self.xp_fmt, k))
+        self._vpmeta = torch.zeros(len(self.VPMETA), 64, dtype=torch.float32, device=self.device)
+        vx, items = {}, []
+        for name, T in (('e2w', True), ('d0mw', False), ('d3w', False), ('d5w', False), ('emw', True)):
+            W = vp[name]
+            rows, cols = W.shape
+            vx[name] = torch.zeros(rows, xl(cols), **i16)
+            if T:
+                vx[name + 'T'] = torch.zeros(cols, xl(rows), **i16)
+            items.append((dptr(W), rows, cols, W.stride(0), vx[name], vx.get(name + 'T'), self._vm(name)))
+        if self.xp_fmt == 2:
+            am = [(src, rows, cols, lds, meta) for src, rows, cols, lds, _, _, meta in items]
+            am += [(dptr(vp[b]), 1, vp[b].numel(), vp[b].numel(), self._vm(b)) for b in ('e2b', 'd0mb', 'd3b')]
+            self.absmax_xp(am, overwrite=True)
+        self.cast_xp(items)
+        self._vpx = vx
+
+    def _vm(self, name):
+        """device pointer of the (static) scale record of a VPoser weight / bias (fmt 2)"""
+        if self.xp_fmt != 2:
+            return None
+        return self._vpmeta[self.VPMETA.index(name)].data_ptr()
+
     def gemm_xp(self, M, N, K, Ax, Bx, Cp=None, ldc=0, bias=None, act=0, maskx=None, alpha=1.0, out_mode=0, Cx=None, CxT=None,
-                colsum=None, tag=None, mA=None, mB=None, mBias=None, mOut=None, mZero=None):
+                colsum=None, tag=None, mA=None, mB=None, mBias=None, mOut=None, mZero=None, mask_mode=1):
         """C (M x N, fp32, may be None) (op)= epilogue(alpha * A B^T), A (M x K) / B (N x K) xp matrices; Cx / CxT: the result's xp
         copies for the next products of the chain (include/nemo_hip.h nemo_gemm_xp).  mA / mB / mBias / mOut: the scale records of
         the operands, the bias and the result's copies (device pointers; fmt 2 only)."""
@@ -890,7 +935,7 @@ class FitEngine:
         cur = torch.cuda.current_stream()
         ws = self.gemm_ws[1 if cur == self.side_stream else (2 if cur == self.side_stream2 else 0)]
         check(self.lib.nemo_gemm_xp(self.xp_fmt, M, N, K, Ax.data_ptr(), Ax.stride(0), Bx.data_ptr(), Bx.stride(0), Cp, ldc, bias, act,
-                                    dptr(maskx), maskx.stride(0) if maskx is not None else 0, 1 if maskx is not None else 0, alpha,
+                                    dptr(maskx), maskx.stride(0) if maskx is not None else 0, mask_mode if maskx is not None else 0, alpha,
                                     out_mode, dptr(Cx), Cx.stride(0) if Cx is not None else 0, dptr(CxT),
                                     CxT.stride(0) if CxT is not None else 0, 1.0, dptr(colsum),
                                     colsum.stride(0) if colsum is not None else 0, mA, mB, mBias, mOut, mZero, ws.data_ptr(),
@@ -1366,7 +1411,10 @@ class FitEngine:
         """The encoder's (mu | logvar) product: only the KL term reads it, so it runs on the KL stream (the decoder starts
         from the encoder's hidden activation, forward_vposer)."""
         vp = self.vp
-        if self.b16mem:
+        if self._use_xp_vp(w):
+            self.gemm_xp(N, 64, 512, w['E1x'], self._vpx['emw'], dptr(w['MULV']), 64, bias=dptr(vp['emb']), mA=self._xm(w, 'vE1'),
+                         mB=self._vm('emw'))
+        elif self.b16mem:
             self.gemm16(N, 64, 512, w['E1b'], self.vpb['emw'], dptr(w['MULV']), 64, bias=dptr(vp['emb']), Cb=w['MULVb'])
         else:
             self._linear(N, dptr(w['E1']), 512, 512, dptr(vp['emw']), dptr(vp['emb']), 64, dptr(w['MULV']), 64)
@@ -1380,7 +1428,22 @@ class FitEngine:
         st, vp = _stream(), self.vp
         aa63 = w['AA'].data_ptr() + 4 * 3
         cur = torch.cuda.current_stream()
-        if self.b16mem:
+        if self._use_xp_vp(w):
+            # split precision (nemo_gemm_xp; >= VP_XP_MIN_ROWS rows): every layer reads the previous layer's xp copy and leaves its own;
+            # the hidden activations exist as xp copies only (E1x is also the LeakyReLU' mask of the KL term's adjoint)
+            vx, m, vm = self._vpx, (lambda k: self._xm(w, k)), self._vm
+            if self.xp_fmt == 2:
+                self.absmax_xp([(aa63, N, 63, 72, m('vAA'))], overwrite=True)
+            self.cast_xp([(aa63, N, 63, 72, w['AAx'], None, m('vAA'))])
+            self.gemm_xp(N, 512, 63, w['AAx'], vx['e2w'], bias=dptr(vp['e2b']), act=2, Cx=w['E1x'], mA=m('vAA'), mB=vm('e2w'),
+                         mBias=vm('e2b'), mOut=m('vE1'))
+            enc_done = cur.record_event()
+            self.gemm_xp(N, 512, 512, w['E1x'], vx['d0mw'], bias=dptr(vp['d0mb']), act=2, Cx=w['D1x'], mA=m('vE1'), mB=vm('d0mw'),
+                         mBias=vm('d0mb'), mOut=m('vD1'))
+            self.gemm_xp(N, 512, 512, w['D1x'], vx['d3w'], bias=dptr(vp['d3b']), act=2, Cx=w['D2x'], mA=m('vD1'), mB=vm('d3w'),
+                         mBias=vm('d3b'), mOut=m('vD2'))
+            self.gemm_xp(N, 126, 512, w['D2x'], vx['d5w'], dptr(w['D3']), 126, bias=dptr(vp['d5b']), mA=m('vD2'), mB=vm('d5w'))
+        elif self.b16mem:
             vb = self.vpb
             self._cast(N, 63, aa63, 72, w['AAb'], 0)
             self.gemm16(N, 512, 63, w['AAb'], vb['e2w'], dptr(w['E1']), 512, bias=dptr(vp['e2b']), act=2, Cb=w['E1b'])
@@ -1553,6 +1616,15 @@ class FitEngine:
     def backward_vposer_kl(self, w, N, weight):
         """d(weight*KL)/d poses[:, :63] through the frozen encoder, accumulated into dAA[:, 3:66]."""
         vp = self.vp
+        if self._use_xp_vp(w):
+            vx, m, vm = self._vpx, (lambda k: self._xm(w, k)), self._vm
+            if self.xp_fmt == 2:
+                self.absmax_xp([(dptr(w['dMULV']), N, 64, 64, m('vdM'))], overwrite=True)
+            self.cast_xp([(dptr(w['dMULV']), N, 64, 64, w['dMULVx'], None, m('vdM'))])
+            self.gemm_xp(N, 512, 64, w['dMULVx'], vx['emwT'], alpha=weight, maskx=w['E1x'], mask_mode=2, Cx=w['dE_ax'],
+                         mA=m('vdM'), mB=vm('emw'), mOut=m('vdE'))
+            self.gemm_xp(N, 63, 512, w['dE_ax'], vx['e2wT'], w['dAA'].data_ptr() + 4 * 3, 72, out_mode=1, mA=m('vdE'), mB=vm('e2w'))
+            return
         if self.b16mem:
             vb = self.vpb
             self._cast(N, 64, dptr(w['dMULV']), 64, w['dMULVb'], 0)

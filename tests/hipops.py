@@ -101,7 +101,7 @@ def xp_decode(fmt, x, k, scale=1.0):
 
 
 def gemm_xp(fmt, Ax, Bx, M, N, K, C=None, bias=None, act=0, maskx=None, alpha=1.0, out_mode=0, want_cx=False, want_cxt=False,
-            out_scale=1.0, colsum=False, ws=True, metaA=None, metaB=None, metaBias=None, metaOut=None):
+            out_scale=1.0, colsum=False, ws=True, metaA=None, metaB=None, metaBias=None, metaOut=None, mask_mode=1):
     L = _lib.load()
     if C is None and not (want_cx or want_cxt):
         C = torch.zeros(M, N, device=DEV)
@@ -109,7 +109,7 @@ def gemm_xp(fmt, Ax, Bx, M, N, K, C=None, bias=None, act=0, maskx=None, alpha=1.
     CxT = torch.zeros(N, xp_ld(fmt, M), dtype=torch.int16, device=DEV) if want_cxt else None
     cs = torch.zeros(int(L.nemo_gemm_colsum_rows(M)), N, device=DEV) if colsum else None
     check(L.nemo_gemm_xp(fmt, M, N, K, dptr(Ax), Ax.stride(0), dptr(Bx), Bx.stride(0), dptr(C), C.stride(0) if C is not None else 0,
-                         dptr(bias), act, dptr(maskx), maskx.stride(0) if maskx is not None else 0, 1 if maskx is not None else 0,
+                         dptr(bias), act, dptr(maskx), maskx.stride(0) if maskx is not None else 0, mask_mode if maskx is not None else 0,
                          alpha, out_mode, dptr(Cx), Cx.stride(0) if want_cx else 0, dptr(CxT), CxT.stride(0) if want_cxt else 0,
                          out_scale, dptr(cs), cs.stride(0) if colsum else 0, dptr(metaA), dptr(metaB), dptr(metaBias), dptr(metaOut), None,
                          dptr(gemm_ws()) if ws else None, gemm_ws().numel() * 4 if ws else 0, st()), 'gemm_xp')

@@ -294,8 +294,12 @@ def test_c4_rows_for_nemo_v3_v4(version):
       'lockstep_with_oracle or reference_trajectory or ragged_and_degenerate or sharded_gradients_and_parameters or sharded_hip_equals or padded_launch']),
     ({'NEMO_XP_MIN_ROWS': '0', 'NEMO_MLP_GEMM': 'f32_split3'},
      ['tests/test_gpu_model.py', '-k', 'lockstep_with_oracle or ragged_and_degenerate']),
+    # ... and the frozen VPoser's products on nemo_gemm_xp too (NEMO_VP_XP_MIN_ROWS; off by default), against the oracle and across ranks
+    ({'NEMO_XP_MIN_ROWS': '0', 'NEMO_VP_XP_MIN_ROWS': '0'},
+     ['tests/test_gpu_model.py', 'tests/test_dist.py', '-k',
+      'lockstep_with_oracle or reference_trajectory or ragged_and_degenerate or sharded_hip_equals or padded_launch or published_config_step_vs_oracle']),
 ], ids=['fp32_mfma_blend_atomics', 'bf16_round4_forms', 'f32_split_first_forms', 'f32_split_sparse_skinning', 'xp_chain_every_size',
-        'xp_chain_bf16_pieces_every_size'])
+        'xp_chain_bf16_pieces_every_size', 'xp_vposer_every_size'])
 def test_alternative_kernel_paths_stay_correct(env, target):
     """The switches of INTEGRATION.md section F that select another KERNEL are read once per process: each alternative runs the
     parity tests that cover it in a child process, so that the non-default forms (bench.py's `f32_mfma_blend` leg, the A/B aids)

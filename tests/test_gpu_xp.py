@@ -132,6 +132,54 @@ def test_gemm_xp_epilogue_copies_mask_bias_colsum(fmt, mag):
     assert torch.equal(Cacc, Cacc2)
 
 
+@pytest.mark.parametrize('fmt', [3, 2])
+def test_gemm_xp_vposer_roles(fmt):
+    """The products of the frozen VPoser chain (engine.forward_vposer / backward_vposer_kl on nemo_gemm_xp): K = 63 from a strided
+    source, LeakyReLU + its copy, the LeakyReLU' mask read from that copy (mask_mode 2), a 63-column += into a 72-wide matrix."""
+    M = 4099
+    AA = _rand(M, 72, 1.5, 31)
+    W2, b2 = _rand(512, 63, 0.2, 32), _rand(1, 512, 0.1, 33)[0].contiguous()
+    src = AA[:, 3:66]                                           # (rows 72 floats apart, base 12 bytes into the matrix)
+    meta = H.absmax_meta(src) if fmt == 2 else None
+    Ax, _ = H.cast_xp(fmt, src, meta=meta[0] if fmt == 2 else None)
+    mA = meta[0] if fmt == 2 else None
+    Bx, _, mB = _xp_operand(fmt, W2)
+    mBias = H.absmax_meta(b2[None])[0] if fmt == 2 else None
+    mo = torch.zeros(64, device=H.DEV) if fmt == 2 else None
+    _, E1x, _, _ = H.gemm_xp(fmt, Ax, Bx, M, 512, 63, bias=b2, act=2, want_cx=True, metaA=mA, metaB=mB, metaBias=mBias, metaOut=mo)
+    pre = src.double() @ W2.double().t() + b2.double()
+    E1 = torch.where(pre > 0, pre, 0.01 * pre)
+    s1 = H.meta_scale(mo) if fmt == 2 else 1.0
+    assert _err(H.xp_decode(fmt, E1x, 512, s1), E1) < 2e-6
+    # KL adjoint, first product: dE = 0.37 (dMULV emw) * LeakyReLU'(E1)
+    dM, emw = _rand(M, 64, 1e-3, 34), _rand(64, 512, 0.3, 35)
+    dMx, _, mdM = _xp_operand(fmt, dM)
+    emwT = emw.t().contiguous()                                 # B = emw^T (512 x K = 64)
+    Ex, _, mE = _xp_operand(fmt, emwT)
+    mo2 = torch.zeros(64, device=H.DEV) if fmt == 2 else None
+    C, dEx, _, _ = H.gemm_xp(fmt, dMx, Ex, M, 512, 64, alpha=0.37, maskx=E1x, mask_mode=2, want_cx=True, C=torch.zeros(M, 512, device=H.DEV),
+                             metaA=mdM, metaB=mE, metaOut=mo2)
+    want = 0.37 * (dM.double() @ emw.double()) * torch.where(E1 > 0, 1.0, 0.01)
+    # (entries of E1 within rounding of zero may take the other slope: compare where |pre| is not tiny)
+    sure = pre.abs() > 1e-5
+    assert _err(C.double() * sure, want * sure) < 2e-6
+    s2 = H.meta_scale(mo2) if fmt == 2 else 1.0
+    assert _err(H.xp_decode(fmt, dEx, 512, s2), C.double()) < 1e-6
+    # second product: dAA[:, 3:66] += dE e2w, into the 72-wide matrix
+    W2T = W2.t().contiguous()                                   # B = e2w^T (63 x K = 512)
+    Wx, _, mW = _xp_operand(fmt, W2T)
+    dAA0 = _rand(M, 72, 1e-4, 36)
+    dAA = dAA0.clone()
+    L = H._lib.load()
+    H.check(L.nemo_gemm_xp(fmt, M, 63, 512, dEx.data_ptr(), dEx.stride(0), Wx.data_ptr(), Wx.stride(0), dAA.data_ptr() + 12, 72, None, 0,
+                           None, 0, 0, 1.0, 1, None, 0, None, 0, 1.0, None, 0, H.dptr(mo2), H.dptr(mW), None, None, None,
+                           H.dptr(H.gemm_ws()), H.gemm_ws().numel() * 4, H.st()), 'gemm_xp')
+    want2 = dAA0.double()
+    want2[:, 3:66] += C.double() @ W2.double()
+    assert _err(dAA, want2) < 2e-6
+    assert torch.equal(dAA[:, :3], dAA0[:, :3]) and torch.equal(dAA[:, 66:], dAA0[:, 66:])
+
+
 def test_fp16_pieces_cannot_overflow_and_degrade_gracefully():
     """fmt 2's range guard: scales come from absmax records / bounds on the device, so magnitudes from 1e-30 to 1e30 neither overflow
     nor flush the product; operands whose entries spread over 12 decades keep the error of the fp32 GEMM relative to the result's
@@ -177,8 +225,21 @@ def _pair(V, T, h, num_verts, version=2, variant='f32_split', **over):
                                                    (8, 300, 1000, 6890, 2, True), (8, 300, 1000, 512, 4, False)])
 @pytest.mark.parametrize('variant', ['f32_split3', 'f32_split2'])
 def test_split_chain_matches_fp32_chain_in_the_step(V, T, h, nv, version, full, variant, monkeypatch):
+    _chain_in_the_step(V, T, h, nv, version, full, variant, monkeypatch, vposer_xp=False)
+
+
+@pytest.mark.parametrize('V,T,h,nv,version,full', [(3, 10, 48, 100, 2, True), (3, 10, 48, 100, 3, False), (8, 300, 1000, 512, 4, True)])
+@pytest.mark.parametrize('variant', ['f32_split3', 'f32_split2'])
+def test_split_vposer_chain_matches_fp32_chain_in_the_step(V, T, h, nv, version, full, variant, monkeypatch):
+    """... with the frozen VPoser's products (encode, decode, the KL term's adjoint) on nemo_gemm_xp too (FitEngine.VP_XP_MIN_ROWS /
+    NEMO_VP_XP_MIN_ROWS: off by default -- measured without gain, profiles/r06_experiments.md)."""
+    _chain_in_the_step(V, T, h, nv, version, full, variant, monkeypatch, vposer_xp=True)
+
+
+def _chain_in_the_step(V, T, h, nv, version, full, variant, monkeypatch, vposer_xp):
     from nemo_cvpr2023_amd.engine import FitEngine
     monkeypatch.setattr(FitEngine, 'XP_MIN_ROWS', 0)
+    monkeypatch.setattr(FitEngine, 'VP_XP_MIN_ROWS', 0 if vposer_xp else 1 << 40)
     over = dict(monotonic_network_n_nodes=20, phase_rbf_dim=16) if h < 100 else {}
     m32, mxp = _pair(V, T, h, nv, version, variant, **over)
     assert mxp.engine.mlp_split and not m32.engine.mlp_split
@@ -195,6 +256,7 @@ def test_split_chain_matches_fp32_chain_in_the_step(V, T, h, nv, version, full, 
     l32, i32 = call(m32)
     lxp, ixp = call(mxp)
     assert any('Xx' in w for w in mxp.engine.ws.values())           # the chain really ran on nemo_gemm_xp
+    assert any('AAx' in w for w in mxp.engine.ws.values()) == vposer_xp
     for k in l32:
         assert abs(float(lxp[k]) - float(l32[k])) <= 2e-6 * abs(float(l32[k])) + 1e-12, (k, lxp[k], l32[k])
     assert float((ixp['j'] - i32['j']).abs().max()) <= 2e-6 * float(i32['j'].abs().max())
