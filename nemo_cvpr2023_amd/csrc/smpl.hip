@@ -722,8 +722,10 @@ template <int LANES>
 __device__ __forceinline__ void kp_stage_A(const KpArgs& a, float (*Al)[288]) {
     constexpr int SPB = 256 / LANES;
     const long sbase = (long)blockIdx.x * SPB;
+    static_assert(SPB * 288 % 256 == 0, "whole passes of the block");
 #pragma unroll
-    for (int idx = threadIdx.x; idx < SPB * 288; idx += 256) {
+    for (int it = 0; it < SPB * 288 / 256; ++it) {          // (a compile-time trip count: the passes' loads are in flight together)
+        const int idx = it * 256 + (int)threadIdx.x;
         const long ss = sbase + idx / 288;
         Al[idx / 288][idx % 288] = ss < a.N ? a.A[ss * 288 + idx % 288] : 0.f;
     }
@@ -1493,7 +1495,6 @@ __global__ __launch_bounds__(256, 2) void mesh_v2v_fused_kernel(
     constexpr bool SP3 = MODE == 4 || MODE == 5 || MODE == 6, SPH = MODE == 5 || MODE == 6, B16 = BF16 || SP3;
     constexpr int NP = SPH ? 2 : 3;                          // pieces per operand
     using e16 = std::conditional_t<SPH, _Float16, __bf16>;   // their element type
-    typedef e16 e16x8 __attribute__((ext_vector_type(8)));
     auto mfma_p = [](const u32x4m& a, const u32x4m& b, const f32x4& c) {     // one piece product on the matrix pipe
         if constexpr (SPH) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mf16x8, a), __builtin_bit_cast(mf16x8, b), c, 0, 0, 0);
         else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mbf16x8, a), __builtin_bit_cast(mbf16x8, b), c, 0, 0, 0);
