@@ -8,6 +8,9 @@
 namespace xp {
 
 constexpr int MAX_CAST = NEMO_CAST_XP_MAX;
+#ifndef ABSMAX_ROWS
+#define ABSMAX_ROWS 16       // rows' loads in flight per thread: a 1000 x 1000 weight matrix is 31 rows per block in overwrite mode -- two round trips
+#endif
 
 // absmax slots of `meta` = max(themselves, max |src|) for a list of matrices (grid-stride over each; slots zero or previous maxima)
 struct AbsmaxDesc { const float* src; long rows, cols, lds; float* meta; int block0; int overwrite; };
@@ -27,38 +30,40 @@ __device__ __forceinline__ void absmax_block(const AbsmaxArgs& a, const int bid,
     const long b = (long)bid - d.block0;
     const long r0 = b * d.rows / nb, r1 = (b + 1) * d.rows / nb;
     float mx = 0.f;
-    // eight rows' loads in flight per thread (one load per round trip took 48 us for the chain's weights: 124 dependent trips)
+    // ABSMAX_ROWS rows' loads in flight per thread (one load per round trip took 48 us for the chain's weights: 124 dependent trips; eight: 13.5)
     const float* src = d.src;
     const long lds = d.lds, cols = d.cols;
-    if ((lds & 3) == 0 && (cols & 3) == 0 && (reinterpret_cast<unsigned long long>(src) & 15) == 0) {
-        const long c4n = cols >> 2;
-        for (long c4 = threadIdx.x; c4 < c4n; c4 += 256)
-            for (long r = r0; r < r1; r += 8) {
-                float4 v[8];
+    // Every load is UNCONDITIONAL -- rows / columns beyond the range are clamped onto its last row / column (a maximum does not mind seeing
+    // an element twice).  With a predicate per load (`r + u < r1 ? load : 0`) hipcc branches around each load and waits for it: one
+    // round trip per row, 31 dependent trips for a 1000 x 1000 matrix in 32 blocks.
+    if (r1 > r0 && cols > 0) {
+        if ((lds & 3) == 0 && (cols & 3) == 0 && (reinterpret_cast<unsigned long long>(src) & 15) == 0) {
+            const long c4n = cols >> 2;
+            for (long c4 = threadIdx.x; c4 < c4n; c4 += 256)
+                for (long r = r0; r < r1; r += ABSMAX_ROWS) {
+                    float4 v[ABSMAX_ROWS];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    v[u] = r + u < r1 ? *reinterpret_cast<const float4*>(src + (r + u) * lds + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int u = 0; u < ABSMAX_ROWS; ++u)
+                        v[u] = *reinterpret_cast<const float4*>(src + min(r + u, r1 - 1) * lds + 4 * c4);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+                    for (int u = 0; u < ABSMAX_ROWS; ++u)
+                        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v[u].x), fabsf(v[u].y))), fmaxf(fabsf(v[u].z), fabsf(v[u].w)));
+                }
+        } else {
+            // unaligned / narrow rows (nn.Linear(105, h), the head gradient, a strided view): thread = (row of four, column of 64); per pass
+            // ABSMAX_ROWS / 2 row quads x one 64-column group, all loads in flight
+            const long cg = (cols + 63) >> 6;
+            const long tr = threadIdx.x >> 6, tc = threadIdx.x & 63;
+            for (long g2 = 0; g2 < cg; ++g2) {
+                const long c = min((g2 << 6) + tc, cols - 1);
+                for (long r = r0; r < r1; r += 4 * (ABSMAX_ROWS / 2)) {
+                    float v[ABSMAX_ROWS / 2];
+#pragma unroll
+                    for (int u = 0; u < ABSMAX_ROWS / 2; ++u) v[u] = src[min(r + 4 * u + tr, r1 - 1) * lds + c];
+#pragma unroll
+                    for (int u = 0; u < ABSMAX_ROWS / 2; ++u) mx = fmaxf(mx, fabsf(v[u]));
+                }
             }
-    } else {
-        // unaligned / narrow rows (nn.Linear(105, h), the head gradient): the block's rows as one flat range of (row, 64-column group)
-        const long cg = (cols + 63) >> 6;
-        for (long r = r0; r < r1; r += 32) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long rr = r + 4 * u + (threadIdx.x >> 6);
-                float acc = 0.f;
-                if (rr < r1)
-                    for (long g2 = 0; g2 < cg; ++g2) {
-                        const long c = (g2 << 6) + (threadIdx.x & 63);
-                        if (c < cols) acc = fmaxf(acc, fabsf(src[rr * lds + c]));
-                    }
-                v[u] = acc;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) mx = fmaxf(mx, v[u]);
         }
     }
 #pragma unroll

@@ -820,10 +820,12 @@ __global__ __launch_bounds__(256) void kp_view_finish_kernel(const float* __rest
         bool on[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long s = s0 + 256 * u;
-            on[u] = s < hi && (sorted || view_idx[s] == v);
+            // (unconditional loads from a clamped index: behind a predicate per load hipcc branches around each and waits for it -- one
+            //  round trip per load instead of one per pass)
+            const long s = min(s0 + 256 * u, hi - 1);
+            on[u] = s0 + 256 * u < hi && (sorted || view_idx[s] == v);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) q[u][c] = on[u] ? p4[s * 3 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int c = 0; c < 3; ++c) q[u][c] = p4[s * 3 + c];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
