@@ -685,9 +685,19 @@ __global__ __launch_bounds__(256) void cast_xp_kernel(CastArgs a) {
         scale = pow2_scale(meta_absmax(d.meta), 15);
         if (bt == 0 && threadIdx.x == 0) d.meta[0] = scale;
     }
-    for (int i = ty; i < 32; i += 8) {
-        const long r = r0 + i, c = c0 + tx;
-        t[i][tx] = (r < d.rows && c < d.cols) ? d.src[r * d.lds + c] * scale : 0.f;
+    if (d.rows <= 0 || d.cols <= 0) return;                   // (block-uniform)
+    {
+        // the thread's four loads are UNCONDITIONAL, from indices clamped into the matrix, and in flight together: behind the bounds
+        // predicate hipcc compiled the loop to one load + wait per iteration (four dependent round trips per block)
+        float v[4];
+        const long cc = min(c0 + tx, d.cols - 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = d.src[min(r0 + ty + 8 * q, d.rows - 1) * d.lds + cc];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = ty + 8 * q;
+            t[i][tx] = (r0 + i < d.rows && c0 + tx < d.cols) ? v[q] * scale : 0.f;
+        }
     }
     __syncthreads();
     if (d.dst) {
