@@ -708,12 +708,20 @@ def scaling_model_single_gpu(cx, headline_ms, c4_ms):
                 # two timed regions, the minimum counts (BENCH_r04: one region after 3 set-up steps caught a 73 ms stall behind
                 # the previous model's release and reported 2.9 ms for a 0.47 ms step); every step of them must be a graph replay
                 model.launch_stats['replayed'] = model.launch_stats['other'] = 0
-                regs = [1e3 * timed(cx, step, steps)[0] / steps for _ in range(2)]
+                # (round 6: a region that disagrees with the other -- the stall lands in either, two of ten default runs had it in the
+                #  second -- is repeated, up to four regions, until the two fastest agree within 10 %)
+                regs = []
+                while len(regs) < 4:
+                    regs.append(1e3 * timed(cx, step, steps)[0] / steps)
+                    two = sorted(regs)[:2]
+                    if len(regs) >= 2 and two[1] <= 1.1 * two[0]:
+                        break
+                two = sorted(regs)[:2]
                 ls = model.launch_stats
                 frac = ls['replayed'] / max(1, ls['replayed'] + ls['other'])
                 per_rank[W] = round(min(regs), 4)
                 regions[W] = {'ms_per_step': [round(r_, 4) for r_ in regs], 'graph_replay_fraction': round(frac, 3),
-                              'suspect': bool(max(regs) > 1.3 * min(regs) or frac < 1.0)}
+                              'suspect': bool(two[1] > 1.1 * two[0] or frac < 1.0)}
                 pred[W] = [round(base_ms / (per_rank[W] + a_), 2) for a_ in out['assumed_allreduce_ms']]
                 release(cx, model)
             except Exception as ex:
