@@ -514,6 +514,7 @@ extern "C" int32_t nemo_phase_embed_fwd_begin(int64_t N, int64_t V, int64_t T, i
 namespace {
 constexpr int PH_LMAX = 1024;               // samples of a view per pass
 constexpr int PH_DMAX = 128;                // RBF features whose constants are tabulated in LDS
+constexpr int PH_CU = 10;                   // stage C: rows per pass of a column block (a 2401-row column at 256 threads: one pass)
 // The backward coefficients of ONE sample, computed by the four lanes l = 0 .. 3 of a quad (all four return the result): d phase
 // over the D RBF features -- a lane's <= 32 feature gradients are requested together: one memory latency --, then, with
 // ph = num / den saved by the forward pass, (x, dy / K, (-dy - dden) / K, dden / K).
@@ -588,10 +589,25 @@ __device__ __forceinline__ void phase_bwd_fused_body(
             if (!d_log_sigmas) return;
             const int d = b;
             const float es = expf(log_sigmas[d]), c = lin01(d, D);
-            for (long s = threadIdx.x; s <= N; s += blockDim.x) {
-                const float diff = (s < N ? phase[s] : 0.f) - c;
-                const float a = (diff * diff) / es;
-                acc -= dX[s * ldx + d] * rbf_dphi(kid, a) * a;      // d a / d log_sigma = -a
+            // PH_CU rows per pass, their loads UNCONDITIONAL (indices clamped into the matrix) and in flight together, the terms added in
+            // row order as before: behind a predicate per row hipcc emits load -> wait -> branch, one round trip per row, and a 2401-row
+            // column was ten dependent trips per thread -- the long pole of this launch at the tail of every step
+            for (long s0 = threadIdx.x; s0 <= N; s0 += (long)blockDim.x * PH_CU) {
+                float ph[PH_CU], g[PH_CU];
+#pragma unroll
+                for (int u = 0; u < PH_CU; ++u) {
+                    const long sc = min(s0 + (long)blockDim.x * u, N);
+                    ph[u] = phase[min(sc, N > 0 ? N - 1 : 0)];
+                    g[u] = dX[sc * ldx + d];
+                }
+#pragma unroll
+                for (int u = 0; u < PH_CU; ++u) {
+                    const long su = s0 + (long)blockDim.x * u;
+                    if (su > N) continue;
+                    const float diff = (su < N ? ph[u] : 0.f) - c;
+                    const float a = (diff * diff) / es;
+                    acc -= g[u] * rbf_dphi(kid, a) * a;             // d a / d log_sigma = -a
+                }
             }
             const float t = block_sum(acc, red);
             if (threadIdx.x == 0) d_log_sigmas[d] += t;
@@ -600,8 +616,19 @@ __device__ __forceinline__ void phase_bwd_fused_body(
             const int c = idx % C;
             const long v = idx / C;
             const int off = D > 0 ? D : 1;
-            for (long s = threadIdx.x; s < N; s += blockDim.x)
-                if (view_idx[s] == v) acc += dX[s * ldx + off + c];
+            for (long s0 = threadIdx.x; s0 < N; s0 += (long)blockDim.x * PH_CU) {
+                long vi[PH_CU];
+                float g[PH_CU];
+#pragma unroll
+                for (int u = 0; u < PH_CU; ++u) {
+                    const long sc = min(s0 + (long)blockDim.x * u, N - 1);
+                    vi[u] = view_idx[sc];
+                    g[u] = dX[sc * ldx + off + c];
+                }
+#pragma unroll
+                for (int u = 0; u < PH_CU; ++u)
+                    if (s0 + (long)blockDim.x * u < N && vi[u] == v) acc += g[u];
+            }
             const float t = block_sum(acc, red);
             if (threadIdx.x == 0) d_codes[v * C + c] += t;
         }
